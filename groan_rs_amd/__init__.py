@@ -1,0 +1,20 @@
+"""groan_rs_amd -- MI355X-native per-frame geometry engine behind the groan_rs System API.
+
+The product is groan_rs_amd/libgroan_hip.so (hand-written HIP kernels for gfx950 + the C ABI of
+include/groan_hip.h).  This package is the thin host-side mirror of the reference interface used by
+the tests and the benchmark; importing it does not load the library (so CPU-only tooling can import
+it), but every operation does and fails loudly when the library is missing.
+"""
+from . import _lib
+from .system import (AtomContainer, AtomError, DeviceError, Dimension, GroanError, GroupError, RMSDError,
+                     RMSDPlan, SimBoxError, System)
+from .traj import (FrameAnalyze, FrameConvert, FrameConvertAnalyze, RMSDConverterAnalyzer, TrajAnalyzer,
+                   TrajAnalysisError, TrajConverter, TrajConverterAnalyzer, TrajReader)
+from .parallel import ParallelTrajData, gather_per_frame, interleave, shard_frames, traj_iter_map_reduce
+
+__all__ = [
+    "AtomContainer", "AtomError", "DeviceError", "Dimension", "GroanError", "GroupError", "RMSDError", "RMSDPlan",
+    "SimBoxError", "System", "FrameAnalyze", "FrameConvert", "FrameConvertAnalyze", "RMSDConverterAnalyzer",
+    "TrajAnalyzer", "TrajAnalysisError", "TrajConverter", "TrajConverterAnalyzer", "TrajReader",
+    "ParallelTrajData", "gather_per_frame", "interleave", "shard_frames", "traj_iter_map_reduce",
+]

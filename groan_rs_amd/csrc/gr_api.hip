@@ -1,0 +1,804 @@
+// gr_api.hip -- C ABI of libgroan_hip.so (include/groan_hip.h): host control flow of the MI355X
+// geometry engine.  Mirrors the reference's System-level entry points (src/system/{analysis,rmsd,
+// modifying,utility}.rs) including the order of their checks; all per-atom work runs in the HIP
+// kernels of gr_kernels.h on the context's own stream.  There is no CPU fallback anywhere in this
+// file: without a usable device gr_ctx_create fails with GR_E_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/groan_hip.h"
+#include "gr_container.h"
+#include "gr_kernels.h"
+
+#define GR_MAX_BATCH 64      // frames per batched launch (workspace is sized for this)
+#define GR_MAX_CHUNKS 256    // workgroups per frame in the reduction kernels
+
+namespace {
+
+struct Group {
+    std::vector<grc::Block> blocks;
+    uint64_t n = 0;
+    bool contiguous = true;
+    uint32_t start = 0;
+    uint32_t *idx_dev = nullptr;
+};
+
+}  // namespace
+
+struct gr_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    uint64_t n = 0, n_pad = 0;
+    uint32_t n_slots = 0;
+    size_t frame_stride = 0;          // floats per slot
+    float *frames = nullptr;          // [n_slots][n_pad][3]
+    float *masses = nullptr;          // [n_pad]
+    std::vector<float> masses_host;   // copy kept for plan bookkeeping (weights == masses test)
+    GrBox *boxes_dev = nullptr;       // [n_slots]
+    GrBox *boxes_host = nullptr;      // pinned [n_slots]
+    std::vector<int> box_status;      // per slot: GR_OK / GR_E_NO_BOX / GR_E_ZERO_BOX / GR_E_UNSUPPORTED_BOX
+    std::vector<uint8_t> box9_set;
+    std::vector<float> box9_host;     // [n_slots][9]
+    std::map<std::string, Group> groups;
+    // workspace
+    GrCenPartial *cen_partials = nullptr;
+    GrAccPartial *acc_partials = nullptr;
+    GrFrameState *state_dev = nullptr;
+    GrFrameState *state_host = nullptr;   // pinned
+    uint32_t *bad_dev = nullptr;          // [4]
+    uint32_t *bad_host = nullptr;         // pinned [4]
+    float *pd_out = nullptr; size_t pd_cap = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int strict = 0;
+    std::string err;
+    uint64_t err_index = 0;
+    uint64_t counts[2] = { 0, 0 };
+};
+
+struct gr_rmsd_plan {
+    gr_ctx *target = nullptr;
+    std::string group;
+    uint64_t n_ref = 0;
+    float *p_dev = nullptr, *w_dev = nullptr;
+    std::vector<float> w_host;   // reference masses of the group, selection order
+    GrPlanDev dev = {};
+    int exact = 0;
+    uint32_t last_fallbacks = 0;
+    bool resolved = false;
+};
+
+namespace {
+
+thread_local std::string g_create_err;
+
+#define HIPCHK(ctx, call)                                                                      \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                    \
+            return GR_E_HIP;                                                                   \
+        }                                                                                      \
+    } while (0)
+
+int fail(gr_ctx *c, int status, const std::string &msg, uint64_t index = 0) {
+    c->err = msg; c->err_index = index; return status;
+}
+
+GrSel make_sel(const Group &g) {
+    GrSel s;
+    s.n = (uint32_t)g.n; s.contiguous = g.contiguous ? 1u : 0u; s.start = g.start; s.g0 = g.start >> 2; s.idx = g.idx_dev;
+    return s;
+}
+
+uint32_t chunks_for(const GrSel &s) {
+    const uint64_t units = s.contiguous ? ((uint64_t)s.n + 3) / 4 : (uint64_t)s.n;
+    uint64_t c = units / ((uint64_t)GR_WG * 4);
+    if (c < 1) c = 1;
+    if (c > GR_MAX_CHUNKS) c = GR_MAX_CHUNKS;
+    return (uint32_t)c;
+}
+
+int install_group(gr_ctx *c, const char *name, std::vector<grc::Block> blocks) {
+    if (!name) return fail(c, GR_E_INVALID_ARG, "group name is NULL");
+    const bool existed = c->groups.count(name) != 0;
+    if (existed && c->groups[name].idx_dev) { (void)hipFree(c->groups[name].idx_dev); }
+    Group g;
+    g.blocks = std::move(blocks);
+    g.n = grc::n_atoms(g.blocks);
+    g.contiguous = g.blocks.size() <= 1;
+    g.start = g.blocks.empty() ? 0u : (uint32_t)g.blocks[0].first;
+    if (!g.contiguous) {
+        std::vector<uint64_t> e = grc::expand(g.blocks);
+        std::vector<uint32_t> e32(e.begin(), e.end());
+        HIPCHK(c, hipMalloc(&g.idx_dev, e32.size() * sizeof(uint32_t)));
+        HIPCHK(c, hipMemcpy(g.idx_dev, e32.data(), e32.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
+    c->groups[name] = g;
+    return existed ? GR_E_GROUP_EXISTS : GR_OK;
+}
+
+const Group *find_group(const gr_ctx *c, const char *name) {
+    if (!name) return nullptr;
+    auto it = c->groups.find(name);
+    return it == c->groups.end() ? nullptr : &it->second;
+}
+
+// simbox_check (simbox.rs:230-236) for one slot
+int box_check(gr_ctx *c, uint32_t slot) {
+    const int st = c->box_status[slot];
+    if (st == GR_E_NO_BOX) return fail(c, GR_E_NO_BOX, "simulation box does not exist");
+    if (c->strict && !c->boxes_host[slot].ortho) return fail(c, GR_E_NOT_ORTHOGONAL, "simulation box is not orthogonal");
+    if (st != GR_OK) return fail(c, st, st == GR_E_ZERO_BOX ? "box length is not positive" : "box too skewed");
+    return GR_OK;
+}
+
+int slot_check(gr_ctx *c, uint32_t slot, uint32_t n = 1) {
+    if (!c) return GR_E_INVALID_ARG;
+    if ((uint64_t)slot + n > c->n_slots || n == 0) return fail(c, GR_E_INVALID_ARG, "slot out of range");
+    return GR_OK;
+}
+
+int set_box(gr_ctx *c, uint32_t slot, const float *box9) {
+    GrBox &b = c->boxes_host[slot];
+    if (!box9) {
+        gr_box_setup(nullptr, &b);
+        c->box_status[slot] = GR_E_NO_BOX; c->box9_set[slot] = 0;
+    } else {
+        // count feasible candidates first: more than the table holds = unsupported skew
+        const int ok = gr_box_setup(box9, &b);
+        memcpy(&c->box9_host[9 * (size_t)slot], box9, 9 * sizeof(float));
+        c->box9_set[slot] = 1;
+        if (!ok) c->box_status[slot] = GR_E_ZERO_BOX;
+        else if (b.ncand >= GR_MAX_CAND) c->box_status[slot] = GR_E_UNSUPPORTED_BOX;
+        else c->box_status[slot] = GR_OK;
+    }
+    HIPCHK(c, hipMemcpyAsync(c->boxes_dev + slot, &b, sizeof(GrBox), hipMemcpyHostToDevice, c->stream));
+    return GR_OK;
+}
+
+int state_reset(gr_ctx *c, uint32_t n) {
+    k_state_reset<<<dim3((n + 63) / 64), dim3(64), 0, c->stream>>>(c->state_dev, n);
+    HIPCHK(c, hipGetLastError());
+    return GR_OK;
+}
+
+int fetch_states(gr_ctx *c, uint32_t n) {
+    HIPCHK(c, hipMemcpyAsync(c->state_host, c->state_dev, n * sizeof(GrFrameState), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return GR_OK;
+}
+
+int frame_status(gr_ctx *c, const GrFrameState &st) {
+    if (st.status == GR_OK) return GR_OK;
+    if (st.status == GR_E_NO_POSITION) return fail(c, GR_E_NO_POSITION, "atom has no position", st.err_index);
+    if (st.status == GR_E_NO_MASS) return fail(c, GR_E_NO_MASS, "atom has no mass", st.err_index);
+    return fail(c, st.status, "frame analysis failed");
+}
+
+// launch one centre stage (sums + finalize) for `nf` frames starting at first_slot
+int center_stage(gr_ctx *c, uint32_t first_slot, uint32_t nf, const GrSel &sel, int kind, int weighted,
+                 int mass_first, int target) {
+    const uint32_t nch = chunks_for(sel);
+    k_center_sums<<<dim3(nch, nf), dim3(GR_WG), 0, c->stream>>>(c->frames, c->frame_stride, first_slot, c->masses, sel, c->boxes_dev, c->state_dev, kind, weighted, c->cen_partials);
+    k_center_finalize<<<dim3(nf), dim3(GR_WG), 0, c->stream>>>(c->cen_partials, nch, c->boxes_dev, first_slot, kind, weighted, mass_first, target, sel.n, c->state_dev);
+    HIPCHK(c, hipGetLastError());
+    return GR_OK;
+}
+
+// get_center / get_com: unweighted Bai-Breen estimate, then the (weighted) unwrapped mean
+int pbc_center_stages(gr_ctx *c, uint32_t first_slot, uint32_t nf, const GrSel &sel, int weighted) {
+    int st = center_stage(c, first_slot, nf, sel, 1, 0, 0, 0);
+    if (st != GR_OK) return st;
+    return center_stage(c, first_slot, nf, sel, 2, weighted, 0, 1);
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *gr_version(void) { return "groan_hip 0.1.0 (gfx950)"; }
+
+const char *gr_status_string(int s) {
+    switch (s) {
+    case GR_OK: return "ok";
+    case GR_E_NO_BOX: return "simulation box does not exist";
+    case GR_E_NOT_ORTHOGONAL: return "simulation box is not orthogonal";
+    case GR_E_ZERO_BOX: return "box length is zero or negative";
+    case GR_E_EMPTY_GROUP: return "group is empty";
+    case GR_E_INCONSISTENT_GROUP: return "group has a different number of atoms in reference and target";
+    case GR_E_NO_POSITION: return "atom has undefined position";
+    case GR_E_NO_MASS: return "atom has undefined mass";
+    case GR_E_GROUP_NOT_FOUND: return "group does not exist";
+    case GR_E_OUT_OF_RANGE: return "atom index out of range";
+    case GR_E_INVALID_ARG: return "invalid argument";
+    case GR_E_GROUP_EXISTS: return "group already existed and was overwritten";
+    case GR_E_HIP: return "HIP runtime error";
+    case GR_E_NO_DEVICE: return "no usable HIP device";
+    case GR_E_UNSUPPORTED_BOX: return "box too skewed for the minimum-image table";
+    default: return "unknown status";
+    }
+}
+
+int gr_device_count(int *count) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { if (count) *count = 0; return GR_E_NO_DEVICE; }
+    if (count) *count = n;
+    return n > 0 ? GR_OK : GR_E_NO_DEVICE;
+}
+
+gr_ctx *gr_ctx_create(int device, uint64_t n_atoms, uint32_t n_slots, int *status) {
+    int dummy; if (!status) status = &dummy;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) { *status = GR_E_NO_DEVICE; return nullptr; }
+    if (n_atoms == 0 || n_atoms > 0xFFFFFFF0ull || n_slots == 0) { *status = GR_E_INVALID_ARG; return nullptr; }
+    if (hipSetDevice(device) != hipSuccess) { *status = GR_E_NO_DEVICE; return nullptr; }
+    gr_ctx *c = new gr_ctx();
+    c->device = device; c->n = n_atoms; c->n_pad = (n_atoms + 3) & ~3ull; c->n_slots = n_slots;
+    c->frame_stride = (size_t)c->n_pad * 3;
+    bool ok = true;
+    ok = ok && hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipMalloc(&c->frames, (size_t)n_slots * c->frame_stride * sizeof(float)) == hipSuccess;
+    ok = ok && hipMalloc(&c->masses, c->n_pad * sizeof(float)) == hipSuccess;
+    ok = ok && hipMalloc(&c->boxes_dev, n_slots * sizeof(GrBox)) == hipSuccess;
+    ok = ok && hipHostMalloc(&c->boxes_host, n_slots * sizeof(GrBox), hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipMalloc(&c->cen_partials, (size_t)GR_MAX_BATCH * GR_MAX_CHUNKS * sizeof(GrCenPartial)) == hipSuccess;
+    ok = ok && hipMalloc(&c->acc_partials, (size_t)GR_MAX_BATCH * GR_MAX_CHUNKS * sizeof(GrAccPartial)) == hipSuccess;
+    ok = ok && hipMalloc(&c->state_dev, GR_MAX_BATCH * sizeof(GrFrameState)) == hipSuccess;
+    ok = ok && hipHostMalloc(&c->state_host, GR_MAX_BATCH * sizeof(GrFrameState), hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipMalloc(&c->bad_dev, 4 * sizeof(uint32_t)) == hipSuccess;
+    ok = ok && hipHostMalloc(&c->bad_host, 4 * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess;
+    if (!ok) { *status = GR_E_HIP; gr_ctx_destroy(c); return nullptr; }
+    // masses undefined (None) until gr_set_masses; padding and frames zero
+    std::vector<float> nanv(c->n_pad, NAN);
+    c->masses_host.assign(c->n, NAN);
+    (void)hipMemcpy(c->masses, nanv.data(), c->n_pad * sizeof(float), hipMemcpyHostToDevice);
+    (void)hipMemset(c->frames, 0, (size_t)n_slots * c->frame_stride * sizeof(float));
+    c->box_status.assign(n_slots, GR_E_NO_BOX);
+    c->box9_set.assign(n_slots, 0);
+    c->box9_host.assign((size_t)n_slots * 9, 0.0f);
+    for (uint32_t s = 0; s < n_slots; ++s) gr_box_setup(nullptr, &c->boxes_host[s]);
+    (void)hipMemcpy(c->boxes_dev, c->boxes_host, n_slots * sizeof(GrBox), hipMemcpyHostToDevice);
+    // System::new creates the group "all" (src/system/mod.rs)
+    std::vector<grc::Block> all(1, grc::Block(0, n_atoms - 1));
+    install_group(c, "all", all);
+    *status = GR_OK;
+    return c;
+}
+
+void gr_ctx_destroy(gr_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto &kv : c->groups) if (kv.second.idx_dev) (void)hipFree(kv.second.idx_dev);
+    if (c->frames) (void)hipFree(c->frames);
+    if (c->masses) (void)hipFree(c->masses);
+    if (c->boxes_dev) (void)hipFree(c->boxes_dev);
+    if (c->boxes_host) (void)hipHostFree(c->boxes_host);
+    if (c->cen_partials) (void)hipFree(c->cen_partials);
+    if (c->acc_partials) (void)hipFree(c->acc_partials);
+    if (c->state_dev) (void)hipFree(c->state_dev);
+    if (c->state_host) (void)hipHostFree(c->state_host);
+    if (c->bad_dev) (void)hipFree(c->bad_dev);
+    if (c->bad_host) (void)hipHostFree(c->bad_host);
+    if (c->pd_out) (void)hipFree(c->pd_out);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char *gr_last_error(const gr_ctx *c) { return c ? c->err.c_str() : "null context"; }
+uint64_t gr_last_error_index(const gr_ctx *c) { return c ? c->err_index : 0; }
+void gr_last_error_counts(const gr_ctx *c, uint64_t counts[2]) { if (c && counts) { counts[0] = c->counts[0]; counts[1] = c->counts[1]; } }
+int gr_ctx_set_strict_orthogonal(gr_ctx *c, int on) { if (!c) return GR_E_INVALID_ARG; c->strict = on ? 1 : 0; return GR_OK; }
+uint64_t gr_n_atoms(const gr_ctx *c) { return c ? c->n : 0; }
+uint32_t gr_n_slots(const gr_ctx *c) { return c ? c->n_slots : 0; }
+
+int gr_sync(gr_ctx *c) {
+    if (!c) return GR_E_INVALID_ARG;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return GR_OK;
+}
+
+int gr_set_masses(gr_ctx *c, const float *masses, uint64_t n) {
+    if (!c || !masses || n != c->n) return c ? fail(c, GR_E_INVALID_ARG, "masses: size mismatch") : GR_E_INVALID_ARG;
+    c->masses_host.assign(masses, masses + n);
+    HIPCHK(c, hipMemcpyAsync(c->masses, masses, n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return GR_OK;
+}
+
+/* ------------------------------------------------------------ containers */
+size_t gr_container_from_indices(const uint64_t *indices, size_t n, uint64_t n_atoms, uint64_t *os, uint64_t *oe) {
+    return grc::store(grc::from_indices(std::vector<uint64_t>(indices, indices + n), n_atoms), os, oe);
+}
+size_t gr_container_from_ranges(const uint64_t *s, const uint64_t *e, size_t n, uint64_t n_atoms, uint64_t *os, uint64_t *oe) {
+    return grc::store(grc::from_ranges(s, e, n, n_atoms), os, oe);
+}
+size_t gr_container_union(const uint64_t *s1, const uint64_t *e1, size_t n1, const uint64_t *s2, const uint64_t *e2, size_t n2,
+                          uint64_t *os, uint64_t *oe) {
+    return grc::store(grc::set_union(grc::make(s1, e1, n1), grc::make(s2, e2, n2)), os, oe);
+}
+size_t gr_container_intersection(const uint64_t *s1, const uint64_t *e1, size_t n1, const uint64_t *s2, const uint64_t *e2, size_t n2,
+                                 uint64_t *os, uint64_t *oe) {
+    return grc::store(grc::set_intersection(grc::make(s1, e1, n1), grc::make(s2, e2, n2)), os, oe);
+}
+uint64_t gr_container_n_atoms(const uint64_t *s, const uint64_t *e, size_t n) { return grc::n_atoms(grc::make(s, e, n)); }
+size_t gr_container_expand(const uint64_t *s, const uint64_t *e, size_t n, uint64_t *out) {
+    std::vector<uint64_t> v = grc::expand(grc::make(s, e, n));
+    for (size_t k = 0; k < v.size(); ++k) out[k] = v[k];
+    return v.size();
+}
+int gr_container_isin(const uint64_t *s, const uint64_t *e, size_t n, uint64_t index) { return grc::isin(grc::make(s, e, n), index) ? 1 : 0; }
+
+/* ------------------------------------------------------------ groups */
+int gr_group_create_from_ranges(gr_ctx *c, const char *name, const uint64_t *s, const uint64_t *e, size_t n) {
+    if (!c) return GR_E_INVALID_ARG;
+    (void)hipSetDevice(c->device);
+    return install_group(c, name, grc::from_ranges(s, e, n, c->n));
+}
+int gr_group_create_from_indices(gr_ctx *c, const char *name, const uint64_t *indices, size_t n) {
+    if (!c) return GR_E_INVALID_ARG;
+    (void)hipSetDevice(c->device);
+    return install_group(c, name, grc::from_indices(std::vector<uint64_t>(indices, indices + n), c->n));
+}
+int gr_group_remove(gr_ctx *c, const char *name) {
+    if (!c || !name) return GR_E_INVALID_ARG;
+    auto it = c->groups.find(name);
+    if (it == c->groups.end()) return fail(c, GR_E_GROUP_NOT_FOUND, name);
+    if (it->second.idx_dev) (void)hipFree(it->second.idx_dev);
+    c->groups.erase(it);
+    return GR_OK;
+}
+int gr_group_exists(const gr_ctx *c, const char *name) { return (c && find_group(c, name)) ? 1 : 0; }
+int gr_group_n_atoms(const gr_ctx *c, const char *name, uint64_t *n) {
+    const Group *g = c ? find_group(c, name) : nullptr;
+    if (!g) return GR_E_GROUP_NOT_FOUND;
+    if (n) *n = g->n;
+    return GR_OK;
+}
+int gr_group_n_blocks(const gr_ctx *c, const char *name, size_t *nb) {
+    const Group *g = c ? find_group(c, name) : nullptr;
+    if (!g) return GR_E_GROUP_NOT_FOUND;
+    if (nb) *nb = g->blocks.size();
+    return GR_OK;
+}
+int gr_group_blocks(const gr_ctx *c, const char *name, uint64_t *os, uint64_t *oe) {
+    const Group *g = c ? find_group(c, name) : nullptr;
+    if (!g) return GR_E_GROUP_NOT_FOUND;
+    grc::store(g->blocks, os, oe);
+    return GR_OK;
+}
+
+/* ------------------------------------------------------------ frames */
+int gr_frame_upload(gr_ctx *c, uint32_t slot, const float *xyz, const float *box9) {
+    int st = slot_check(c, slot); if (st) return st;
+    if (!xyz) return fail(c, GR_E_INVALID_ARG, "xyz is NULL");
+    (void)hipSetDevice(c->device);
+    HIPCHK(c, hipMemcpyAsync(c->frames + (size_t)slot * c->frame_stride, xyz, c->n * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    return set_box(c, slot, box9);
+}
+int gr_frame_download(gr_ctx *c, uint32_t slot, float *xyz) {
+    int st = slot_check(c, slot); if (st) return st;
+    if (!xyz) return fail(c, GR_E_INVALID_ARG, "xyz is NULL");
+    (void)hipSetDevice(c->device);
+    HIPCHK(c, hipMemcpyAsync(xyz, c->frames + (size_t)slot * c->frame_stride, c->n * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return GR_OK;
+}
+int gr_frame_set_box(gr_ctx *c, uint32_t slot, const float *box9) {
+    int st = slot_check(c, slot); if (st) return st;
+    (void)hipSetDevice(c->device);
+    HIPCHK(c, hipStreamSynchronize(c->stream));   // boxes_host[slot] may still feed an earlier async copy
+    return set_box(c, slot, box9);
+}
+int gr_frame_get_box(const gr_ctx *c, uint32_t slot, float box9[9]) {
+    if (!c || slot >= c->n_slots) return GR_E_INVALID_ARG;
+    if (!c->box9_set[slot]) return GR_E_NO_BOX;
+    memcpy(box9, &c->box9_host[9 * (size_t)slot], 9 * sizeof(float));
+    return GR_OK;
+}
+int gr_frame_copy(gr_ctx *c, uint32_t dst, uint32_t src) {
+    int st = slot_check(c, dst); if (st) return st;
+    st = slot_check(c, src); if (st) return st;
+    (void)hipSetDevice(c->device);
+    HIPCHK(c, hipMemcpyAsync(c->frames + (size_t)dst * c->frame_stride, c->frames + (size_t)src * c->frame_stride,
+                             c->frame_stride * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return set_box(c, dst, c->box9_set[src] ? &c->box9_host[9 * (size_t)src] : nullptr);
+}
+void *gr_host_alloc(size_t bytes) { void *p = nullptr; return hipHostMalloc(&p, bytes, hipHostMallocDefault) == hipSuccess ? p : nullptr; }
+void gr_host_free(void *p) { if (p) (void)hipHostFree(p); }
+
+/* ------------------------------------------------------------ centres */
+int gr_group_center(gr_ctx *c, uint32_t slot, const char *group, int kind, int weighted, float out[3]) {
+    int st = slot_check(c, slot); if (st) return st;
+    (void)hipSetDevice(c->device);
+    const Group *g = find_group(c, group);
+    if (!g) return fail(c, GR_E_GROUP_NOT_FOUND, group ? group : "(null)");
+    if (g->n == 0) return fail(c, GR_E_EMPTY_GROUP, group);               // analysis.rs:52-55
+    if (kind != GR_CENTER_NAIVE) { st = box_check(c, slot); if (st) return st; }
+    const GrSel sel = make_sel(*g);
+    st = state_reset(c, 1); if (st) return st;
+    if (kind == GR_CENTER_NAIVE) st = center_stage(c, slot, 1, sel, 0, weighted, 0, 1);          // position first (:946-958)
+    else if (kind == GR_CENTER_ESTIMATE) st = center_stage(c, slot, 1, sel, 1, weighted, 1, 1);  // mass first (:1324-1339)
+    else if (kind == GR_CENTER_PBC) st = pbc_center_stages(c, slot, 1, sel, weighted);
+    else return fail(c, GR_E_INVALID_ARG, "unknown centre kind");
+    if (st) return st;
+    st = fetch_states(c, 1); if (st) return st;
+    st = frame_status(c, c->state_host[0]); if (st) return st;
+    if (out) { out[0] = c->state_host[0].com[0]; out[1] = c->state_host[0].com[1]; out[2] = c->state_host[0].com[2]; }
+    return GR_OK;
+}
+
+/* ------------------------------------------------------------ distances */
+int gr_group_distance(gr_ctx *c, uint32_t slot, const char *g1, const char *g2, int dim, float *out) {
+    float c1[3], c2[3];
+    int st = gr_group_center(c, slot, g1, GR_CENTER_PBC, 0, c1); if (st) return st;   // analysis.rs:354-355
+    st = gr_group_center(c, slot, g2, GR_CENTER_PBC, 0, c2); if (st) return st;
+    st = box_check(c, slot); if (st) return st;
+    if (dim < 0 || dim > 7) return fail(c, GR_E_INVALID_ARG, "bad dimension");
+    if (out) *out = gr_distance(c1[0], c1[1], c1[2], c2[0], c2[1], c2[2], dim, c->boxes_host[slot]);
+    return GR_OK;
+}
+
+static int pairdist_run(gr_ctx *c, uint32_t slot, const GrSel &s1, const GrSel &s2, int dim, float *out_dev) {
+    HIPCHK(c, hipMemsetAsync(c->bad_dev, 0xFF, 4 * sizeof(uint32_t), c->stream));
+    if (s1.n && s2.n) {
+        dim3 grid((s2.n + GR_WG * 4 - 1) / (GR_WG * 4), (s1.n + GR_PD_TI - 1) / GR_PD_TI);
+        k_pairdist<<<grid, dim3(GR_WG), 0, c->stream>>>(c->frames + (size_t)slot * c->frame_stride, s1, s2, c->boxes_dev + slot, dim, out_dev, c->bad_dev);
+        HIPCHK(c, hipGetLastError());
+    }
+    HIPCHK(c, hipMemcpyAsync(c->bad_host, c->bad_dev, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    // loop order of analysis.rs:414-424 with atom.rs:780-790: row atom first, then the column atoms of that row
+    if (c->bad_host[0] != GR_NOIDX || c->bad_host[1] != GR_NOIDX) {
+        const uint32_t b1 = c->bad_host[0], b2 = c->bad_host[1];
+        uint32_t first1 = s1.start;
+        uint32_t idx;
+        if (b1 == first1) idx = b1; else if (b2 != GR_NOIDX) idx = b2; else idx = b1;
+        return fail(c, GR_E_NO_POSITION, "atom has no position", idx);
+    }
+    return GR_OK;
+}
+
+int gr_group_all_distances_device(gr_ctx *c, uint32_t slot, const char *g1, const char *g2, int dim,
+                                  float **out_dev, uint64_t *n1, uint64_t *n2) {
+    int st = slot_check(c, slot); if (st) return st;
+    (void)hipSetDevice(c->device);
+    const Group *a = find_group(c, g1); if (!a) return fail(c, GR_E_GROUP_NOT_FOUND, g1 ? g1 : "(null)");
+    const Group *b = find_group(c, g2); if (!b) return fail(c, GR_E_GROUP_NOT_FOUND, g2 ? g2 : "(null)");
+    st = box_check(c, slot); if (st) return st;
+    if (dim < 0 || dim > 7) return fail(c, GR_E_INVALID_ARG, "bad dimension");
+    const size_t need = (size_t)a->n * b->n;
+    if (need > c->pd_cap) {
+        if (c->pd_out) (void)hipFree(c->pd_out);
+        c->pd_out = nullptr; c->pd_cap = 0;
+        HIPCHK(c, hipMalloc(&c->pd_out, (need ? need : 1) * sizeof(float)));
+        c->pd_cap = need;
+    }
+    st = pairdist_run(c, slot, make_sel(*a), make_sel(*b), dim, c->pd_out); if (st) return st;
+    if (out_dev) *out_dev = c->pd_out;
+    if (n1) *n1 = a->n;
+    if (n2) *n2 = b->n;
+    return GR_OK;
+}
+
+int gr_group_all_distances(gr_ctx *c, uint32_t slot, const char *g1, const char *g2, int dim, float *out_host, size_t cap) {
+    float *dev = nullptr; uint64_t n1 = 0, n2 = 0;
+    int st = gr_group_all_distances_device(c, slot, g1, g2, dim, &dev, &n1, &n2); if (st) return st;
+    if ((size_t)(n1 * n2) > cap || !out_host) return fail(c, GR_E_INVALID_ARG, "output buffer too small");
+    if (n1 * n2) {
+        HIPCHK(c, hipMemcpyAsync(out_host, dev, (size_t)(n1 * n2) * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    return GR_OK;
+}
+
+int gr_atoms_distance(gr_ctx *c, uint32_t slot, uint64_t i1, uint64_t i2, int dim, float *out) {
+    int st = slot_check(c, slot); if (st) return st;
+    (void)hipSetDevice(c->device);
+    if (i1 >= c->n) return fail(c, GR_E_OUT_OF_RANGE, "atom index out of range", i1);   // analysis.rs:465-466
+    if (i2 >= c->n) return fail(c, GR_E_OUT_OF_RANGE, "atom index out of range", i2);
+    st = box_check(c, slot); if (st) return st;
+    if (dim < 0 || dim > 7) return fail(c, GR_E_INVALID_ARG, "bad dimension");
+    GrSel s1 = { 1u, 1u, (uint32_t)i1, (uint32_t)i1 >> 2, nullptr }, s2 = { 1u, 1u, (uint32_t)i2, (uint32_t)i2 >> 2, nullptr };
+    if (!c->pd_out) { HIPCHK(c, hipMalloc(&c->pd_out, 16 * sizeof(float))); c->pd_cap = 16; }
+    st = pairdist_run(c, slot, s1, s2, dim, c->pd_out); if (st) return st;
+    float v = 0.f;
+    HIPCHK(c, hipMemcpy(&v, c->pd_out, sizeof(float), hipMemcpyDeviceToHost));
+    if (out) *out = v;
+    return GR_OK;
+}
+
+/* ------------------------------------------------------------ translate / wrap / centre */
+static int translate_impl(gr_ctx *c, uint32_t slot, const char *group, const float *v, int use_state, int dim_mask) {
+    const Group *g = find_group(c, group ? group : "all");
+    if (!g) return fail(c, GR_E_GROUP_NOT_FOUND, group);
+    int st = box_check(c, slot); if (st) return st;
+    if (g->n == 0) return GR_OK;
+    const GrSel sel = make_sel(*g);
+    HIPCHK(c, hipMemsetAsync(c->bad_dev, 0xFF, 4 * sizeof(uint32_t), c->stream));
+    const uint64_t units = sel.contiguous ? ((uint64_t)sel.n + 3) / 4 + 1 : sel.n;
+    uint32_t nwg = (uint32_t)std::min<uint64_t>((units + GR_WG - 1) / GR_WG, 4096);
+    k_translate_wrap<<<dim3(nwg), dim3(GR_WG), 0, c->stream>>>(c->frames + (size_t)slot * c->frame_stride, sel, c->boxes_dev + slot, c->state_dev, use_state, dim_mask, v ? v[0] : 0.f, v ? v[1] : 0.f, v ? v[2] : 0.f, c->bad_dev);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(c->bad_host, c->bad_dev, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->bad_host[0] != GR_NOIDX) return fail(c, GR_E_NO_POSITION, "atom has no position", c->bad_host[0]);
+    return GR_OK;
+}
+
+int gr_group_translate(gr_ctx *c, uint32_t slot, const char *group, const float v[3]) {
+    int st = slot_check(c, slot); if (st) return st;
+    if (!v) return fail(c, GR_E_INVALID_ARG, "vector is NULL");
+    (void)hipSetDevice(c->device);
+    return translate_impl(c, slot, group, v, 0, 7);
+}
+int gr_group_wrap(gr_ctx *c, uint32_t slot, const char *group) {
+    int st = slot_check(c, slot); if (st) return st;
+    (void)hipSetDevice(c->device);
+    const float z[3] = { 0.f, 0.f, 0.f };
+    return translate_impl(c, slot, group, z, 0, 7);
+}
+int gr_atoms_center(gr_ctx *c, uint32_t slot, const char *ref_group, int dim, int weighted) {
+    int st = slot_check(c, slot); if (st) return st;
+    (void)hipSetDevice(c->device);
+    const Group *g = find_group(c, ref_group);
+    if (!g) return fail(c, GR_E_GROUP_NOT_FOUND, ref_group ? ref_group : "(null)");
+    if (g->n == 0) return fail(c, GR_E_EMPTY_GROUP, ref_group);
+    st = box_check(c, slot); if (st) return st;
+    if (dim < 0 || dim > 7) return fail(c, GR_E_INVALID_ARG, "bad dimension");
+    static const int mask[8] = { 0, 1, 2, 4, 3, 5, 6, 7 };
+    st = state_reset(c, 1); if (st) return st;
+    st = center_stage(c, slot, 1, make_sel(*g), 1, weighted, 1, 0); if (st) return st;   // group_estimate_center / _com
+    st = fetch_states(c, 1); if (st) return st;
+    st = frame_status(c, c->state_host[0]); if (st) return st;
+    return translate_impl(c, slot, "all", nullptr, 1, mask[dim]);
+}
+
+/* ------------------------------------------------------------ RMSD */
+void gr_rmsd_plan_destroy(gr_rmsd_plan *p) {
+    if (!p) return;
+    if (p->target) (void)hipSetDevice(p->target->device);
+    if (p->p_dev) (void)hipFree(p->p_dev);
+    if (p->w_dev) (void)hipFree(p->w_dev);
+    delete p;
+}
+
+gr_rmsd_plan *gr_rmsd_plan_create(gr_ctx *ref, uint32_t ref_slot, gr_ctx *target, const char *group, int *status) {
+    int dummy; if (!status) status = &dummy;
+    if (!ref || !target || !group || ref_slot >= ref->n_slots) { *status = GR_E_INVALID_ARG; return nullptr; }
+    if (ref->device != target->device) { *status = fail(ref, GR_E_INVALID_ARG, "reference and target live on different devices"); return nullptr; }
+    (void)hipSetDevice(ref->device);
+    // extract_data_from_system(reference): box first (rmsd.rs:430), then group_get_com (:433)
+    int st = box_check(ref, ref_slot);
+    if (st) { *status = st; return nullptr; }
+    const Group *g = find_group(ref, group);
+    if (!g) { *status = fail(ref, GR_E_GROUP_NOT_FOUND, group); return nullptr; }
+    if (g->n == 0) { *status = fail(ref, GR_E_EMPTY_GROUP, group); return nullptr; }
+    const GrSel sel = make_sel(*g);
+    st = state_reset(ref, 1);
+    if (!st) st = pbc_center_stages(ref, ref_slot, 1, sel, 1);
+    if (!st) st = fetch_states(ref, 1);
+    if (!st) st = frame_status(ref, ref->state_host[0]);
+    if (st) { *status = st; return nullptr; }
+    gr_rmsd_plan *p = new gr_rmsd_plan();
+    p->target = target; p->group = group; p->n_ref = g->n;
+    const uint32_t pofs = sel.contiguous ? (sel.start & 3u) : 0u;
+    const size_t s_pad = ((size_t)g->n + pofs + 7) & ~(size_t)3;
+    bool ok = hipMalloc(&p->p_dev, s_pad * 3 * sizeof(float)) == hipSuccess && hipMalloc(&p->w_dev, s_pad * sizeof(float)) == hipSuccess;
+    if (ok) ok = hipMemsetAsync(p->p_dev, 0, s_pad * 3 * sizeof(float), ref->stream) == hipSuccess &&
+                 hipMemsetAsync(p->w_dev, 0, s_pad * sizeof(float), ref->stream) == hipSuccess;
+    if (!ok) { *status = fail(ref, GR_E_HIP, "plan allocation failed"); gr_rmsd_plan_destroy(p); return nullptr; }
+    const uint32_t nch = chunks_for(sel);
+    k_plan_extract<<<dim3(nch), dim3(GR_WG), 0, ref->stream>>>(ref->frames + (size_t)ref_slot * ref->frame_stride, ref->masses, sel, ref->boxes_dev + ref_slot, ref->state_dev, pofs, p->p_dev, p->w_dev, ref->cen_partials);
+    std::vector<GrCenPartial> parts(nch);
+    if (hipMemcpyAsync(parts.data(), ref->cen_partials, nch * sizeof(GrCenPartial), hipMemcpyDeviceToHost, ref->stream) != hipSuccess ||
+        hipStreamSynchronize(ref->stream) != hipSuccess) {
+        *status = fail(ref, GR_E_HIP, "plan extraction failed"); gr_rmsd_plan_destroy(p); return nullptr;
+    }
+    double s[GR_CEN_K] = { 0 };
+    for (uint32_t k = 0; k < nch; ++k) for (int q = 0; q < GR_CEN_K; ++q) s[q] += parts[k].s[q];
+    p->dev.p = p->p_dev; p->dev.w = p->w_dev;
+    for (int a = 0; a < 3; ++a) { p->dev.sp[a] = s[a]; p->dev.swp[a] = s[3 + a]; p->dev.ref_com[a] = ref->state_host[0].com[a]; }
+    p->dev.swpp = s[6]; p->dev.sw = s[7]; p->dev.n = (uint32_t)g->n; p->dev.w_is_mass = 0;
+    // reference masses of the group in selection order (weights, rmsd.rs:154-155)
+    p->w_host.reserve(g->n);
+    for (uint64_t i : grc::expand(g->blocks)) p->w_host.push_back(ref->masses_host[i]);
+    *status = GR_OK;
+    return p;
+}
+
+uint32_t gr_rmsd_plan_last_fallbacks(const gr_rmsd_plan *p) { return p ? p->last_fallbacks : 0; }
+int gr_rmsd_plan_force_exact(gr_rmsd_plan *p, int on) { if (!p) return GR_E_INVALID_ARG; p->exact = on ? 1 : 0; return GR_OK; }
+
+// multi-pass exact path for `nf` frames starting at first_slot; states [0, nf) must be reset by the caller
+static int rmsd_exact(gr_rmsd_plan *p, gr_ctx *c, const GrSel &sel, uint32_t first_slot, uint32_t nf, int fit) {
+    int st = pbc_center_stages(c, first_slot, nf, sel, 1); if (st) return st;
+    const uint32_t nch = chunks_for(sel);
+    k_rmsd_accum<1><<<dim3(nch, nf), dim3(GR_WG), 0, c->stream>>>(c->frames, c->frame_stride, first_slot, c->masses, sel, c->boxes_dev, p->dev, c->state_dev, c->acc_partials);
+    k_rmsd_finalize<1><<<dim3(nf), dim3(GR_WG), 0, c->stream>>>(c->acc_partials, nch, c->frames, c->frame_stride, first_slot, sel, c->boxes_dev, p->dev, c->state_dev);
+    if (fit) {
+        const uint32_t gx = (uint32_t)std::min<uint64_t>(((c->n >> 2) + GR_WG * 4 - 1) / (GR_WG * 4) + 1, 1024);
+        k_fit<<<dim3(gx, nf), dim3(GR_WG), 0, c->stream>>>(c->frames, c->frame_stride, first_slot, (uint32_t)c->n, c->boxes_dev, p->dev, c->state_dev);
+    }
+    HIPCHK(c, hipGetLastError());
+    return GR_OK;
+}
+
+static int rmsd_batch_impl(gr_rmsd_plan *p, uint32_t first_slot, uint32_t n_frames, float *rmsd_out, int *status_out, float *R_out, int fit) {
+    if (!p || !p->target) return GR_E_INVALID_ARG;
+    gr_ctx *c = p->target;
+    int st = slot_check(c, first_slot, n_frames); if (st) return st;
+    (void)hipSetDevice(c->device);
+    p->last_fallbacks = 0;
+    int first_err = GR_OK; uint64_t first_err_index = 0; std::string first_err_msg; uint64_t first_counts[2] = { 0, 0 };
+    auto note = [&](int s) { if (s != GR_OK && first_err == GR_OK) { first_err = s; first_err_index = c->err_index; first_err_msg = c->err; first_counts[0] = c->counts[0]; first_counts[1] = c->counts[1]; } };
+    const Group *g = find_group(c, p->group.c_str());
+    for (uint32_t b0 = 0; b0 < n_frames; b0 += GR_MAX_BATCH) {
+        const uint32_t nb = std::min<uint32_t>(GR_MAX_BATCH, n_frames - b0);
+        const uint32_t s0 = first_slot + b0;
+        // host-side checks in the reference's order: box (rmsd.rs:430) -> group exists -> non-empty
+        std::vector<int> pre(nb, GR_OK);
+        bool any_ok = false;
+        for (uint32_t f = 0; f < nb; ++f) {
+            int s = box_check(c, s0 + f);
+            if (s == GR_OK && !g) s = fail(c, GR_E_GROUP_NOT_FOUND, p->group);
+            if (s == GR_OK && g->n == 0) s = fail(c, GR_E_EMPTY_GROUP, p->group);
+            pre[f] = s; note(s);
+            any_ok = any_ok || s == GR_OK;
+        }
+        if (any_ok) {
+            const GrSel sel = make_sel(*g);
+            if (!p->resolved) {   // weights identical to the target's masses of the group -> one load serves both
+                bool same = (g->n == p->n_ref);
+                if (same) { size_t k = 0; for (uint64_t i : grc::expand(g->blocks)) { const float a = c->masses_host[i], b = p->w_host[k++]; if (!(a == b)) { same = false; break; } } }
+                p->dev.w_is_mass = same ? 1u : 0u; p->resolved = true;
+            }
+            for (uint32_t f = 0; f < nb; ++f) { GrFrameState z = {}; z.err_index = GR_NOIDX; z.status = pre[f]; c->state_host[f] = z; }
+            HIPCHK(c, hipMemcpyAsync(c->state_dev, c->state_host, nb * sizeof(GrFrameState), hipMemcpyHostToDevice, c->stream));
+            const bool consistent = (g->n == p->n_ref);
+            if (!consistent) {
+                // positions and masses of the target are still checked first (extract_data_from_system runs to
+                // completion before number_of_positions_consistent, rmsd.rs:206-214)
+                st = pbc_center_stages(c, s0, nb, sel, 1); if (st) return st;
+            } else if (p->exact) {
+                st = rmsd_exact(p, c, sel, s0, nb, fit); if (st) return st;
+            } else {
+                const uint32_t nch = chunks_for(sel);
+                k_rmsd_accum<0><<<dim3(nch, nb), dim3(GR_WG), 0, c->stream>>>(c->frames, c->frame_stride, s0, c->masses, sel, c->boxes_dev, p->dev, c->state_dev, c->acc_partials);
+                k_rmsd_finalize<0><<<dim3(nb), dim3(GR_WG), 0, c->stream>>>(c->acc_partials, nch, c->frames, c->frame_stride, s0, sel, c->boxes_dev, p->dev, c->state_dev);
+                if (fit) {
+                    const uint32_t gx = (uint32_t)std::min<uint64_t>(((c->n >> 2) + GR_WG * 4 - 1) / (GR_WG * 4) + 1, 1024);
+                    k_fit<<<dim3(gx, nb), dim3(GR_WG), 0, c->stream>>>(c->frames, c->frame_stride, s0, (uint32_t)c->n, c->boxes_dev, p->dev, c->state_dev);
+                }
+                HIPCHK(c, hipGetLastError());
+            }
+            st = fetch_states(c, nb); if (st) return st;
+            std::vector<GrFrameState> res(c->state_host, c->state_host + nb);
+            // frames whose single-pass image proof failed are redone on the exact path, one by one
+            for (uint32_t f = 0; f < nb; ++f) {
+                if (res[f].status != GR_ST_FALLBACK) continue;
+                p->last_fallbacks++;
+                st = state_reset(c, 1); if (st) return st;
+                st = rmsd_exact(p, c, sel, s0 + f, 1, fit); if (st) return st;
+                st = fetch_states(c, 1); if (st) return st;
+                res[f] = c->state_host[0];
+            }
+            for (uint32_t f = 0; f < nb; ++f) {
+                int s = res[f].status;
+                if (s == GR_OK && !consistent) {
+                    c->counts[0] = p->n_ref; c->counts[1] = g->n;
+                    s = fail(c, GR_E_INCONSISTENT_GROUP, p->group);
+                } else if (s != GR_OK && pre[f] == GR_OK) {
+                    s = frame_status(c, res[f]);
+                }
+                note(s);
+                if (status_out) status_out[b0 + f] = s;
+                if (rmsd_out) rmsd_out[b0 + f] = (s == GR_OK) ? res[f].rmsd : NAN;
+                if (R_out) for (int k = 0; k < 9; ++k) R_out[9 * (size_t)(b0 + f) + k] = (s == GR_OK) ? res[f].R[k] : NAN;
+            }
+        } else {
+            for (uint32_t f = 0; f < nb; ++f) {
+                if (status_out) status_out[b0 + f] = pre[f];
+                if (rmsd_out) rmsd_out[b0 + f] = NAN;
+                if (R_out) for (int k = 0; k < 9; ++k) R_out[9 * (size_t)(b0 + f) + k] = NAN;
+            }
+        }
+    }
+    if (first_err != GR_OK) { c->err = first_err_msg; c->err_index = first_err_index; c->counts[0] = first_counts[0]; c->counts[1] = first_counts[1]; }
+    return first_err;
+}
+
+int gr_rmsd_batch(gr_rmsd_plan *p, uint32_t first_slot, uint32_t n, float *rmsd_out, int *status_out, float *R_out) {
+    return rmsd_batch_impl(p, first_slot, n, rmsd_out, status_out, R_out, 0);
+}
+int gr_rmsd_fit_batch(gr_rmsd_plan *p, uint32_t first_slot, uint32_t n, float *rmsd_out, int *status_out) {
+    return rmsd_batch_impl(p, first_slot, n, rmsd_out, status_out, nullptr, 1);
+}
+
+static int calc_rmsd_impl(gr_ctx *c, uint32_t slot, gr_ctx *ref, uint32_t ref_slot, const char *group, float *rmsd, float *R, int fit) {
+    if (!c || !ref) return GR_E_INVALID_ARG;
+    int st = slot_check(c, slot); if (st) return st;
+    gr_rmsd_plan *p = gr_rmsd_plan_create(ref, ref_slot, c, group, &st);
+    if (!p) {   // reference-side failure: report it on the calling context too
+        if (ref != c) { c->err = ref->err; c->err_index = ref->err_index; }
+        return st;
+    }
+    float r = NAN, Rm[9];
+    st = rmsd_batch_impl(p, slot, 1, &r, nullptr, Rm, fit);
+    gr_rmsd_plan_destroy(p);
+    if (st) return st;
+    if (rmsd) *rmsd = r;
+    if (R) memcpy(R, Rm, sizeof(Rm));
+    return GR_OK;
+}
+int gr_calc_rmsd(gr_ctx *c, uint32_t slot, gr_ctx *ref, uint32_t ref_slot, const char *group, float *rmsd, float *R) {
+    return calc_rmsd_impl(c, slot, ref, ref_slot, group, rmsd, R, 0);
+}
+int gr_calc_rmsd_and_fit(gr_ctx *c, uint32_t slot, gr_ctx *ref, uint32_t ref_slot, const char *group, float *rmsd) {
+    return calc_rmsd_impl(c, slot, ref, ref_slot, group, rmsd, nullptr, 1);
+}
+
+/* ------------------------------------------------------------ measurement / synthetic data */
+int gr_timer_start(gr_ctx *c) { if (!c) return GR_E_INVALID_ARG; HIPCHK(c, hipEventRecord(c->ev0, c->stream)); return GR_OK; }
+int gr_timer_stop(gr_ctx *c, float *ms) {
+    if (!c) return GR_E_INVALID_ARG;
+    HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+    HIPCHK(c, hipEventSynchronize(c->ev1));
+    float t = 0.f;
+    HIPCHK(c, hipEventElapsedTime(&t, c->ev0, c->ev1));
+    if (ms) *ms = t;
+    return GR_OK;
+}
+
+int gr_synth_reference(gr_ctx *c, uint32_t slot, const float *box9, float radius, uint64_t seed) {
+    int st = slot_check(c, slot); if (st) return st;
+    (void)hipSetDevice(c->device);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    st = set_box(c, slot, box9); if (st) return st;
+    st = box_check(c, slot); if (st) return st;
+    k_synth_reference<<<dim3((uint32_t)((c->n + 255) / 256)), dim3(256), 0, c->stream>>>(c->frames + (size_t)slot * c->frame_stride, (uint32_t)c->n, c->boxes_dev + slot, radius, seed);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return GR_OK;
+}
+
+int gr_synth_frames(gr_ctx *c, uint32_t ref_slot, uint32_t first_slot, uint32_t n_frames, uint64_t first_frame_index, float sigma, uint64_t seed) {
+    int st = slot_check(c, ref_slot); if (st) return st;
+    st = slot_check(c, first_slot, n_frames); if (st) return st;
+    if (ref_slot >= first_slot && ref_slot < first_slot + n_frames) return fail(c, GR_E_INVALID_ARG, "reference slot inside the output range");
+    (void)hipSetDevice(c->device);
+    st = box_check(c, ref_slot); if (st) return st;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (uint32_t f = 0; f < n_frames; ++f) { st = set_box(c, first_slot + f, &c->box9_host[9 * (size_t)ref_slot]); if (st) return st; }
+    for (uint32_t f0 = 0; f0 < n_frames; f0 += 1024) {
+        const uint32_t nf = std::min<uint32_t>(1024, n_frames - f0);
+        k_synth_frames<<<dim3((uint32_t)((c->n + 255) / 256), nf), dim3(256), 0, c->stream>>>(c->frames + (size_t)ref_slot * c->frame_stride, c->frames, c->frame_stride, first_slot + f0, (uint32_t)c->n, c->boxes_dev + ref_slot, first_frame_index + f0, sigma, seed);
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return GR_OK;
+}
+
+int gr_synth_uniform(gr_ctx *c, uint32_t slot, const float *box9, uint64_t seed) {
+    int st = slot_check(c, slot); if (st) return st;
+    (void)hipSetDevice(c->device);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    st = set_box(c, slot, box9); if (st) return st;
+    st = box_check(c, slot); if (st) return st;
+    k_synth_uniform<<<dim3((uint32_t)((c->n + 255) / 256)), dim3(256), 0, c->stream>>>(c->frames + (size_t)slot * c->frame_stride, (uint32_t)c->n, c->boxes_dev + slot, seed);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return GR_OK;
+}
+
+}  // extern "C"

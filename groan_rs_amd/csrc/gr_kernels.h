@@ -1,0 +1,790 @@
+// gr_kernels.h -- hand-written HIP kernels for gfx950 (MI355X / CDNA4): 64-wide wavefronts,
+// HBM-bound vector math (no MFMA: nothing here is a dense contraction).
+//
+// Data layout in HBM
+//   frame slot : float xyz[n_pad][3]  (packed 12-byte records exactly as the xtc decoders deliver
+//                them, n_pad = n_atoms rounded up to 4 so 4 atoms = 3 aligned float4 loads)
+//   masses     : float m[n_pad]       (separate array; NaN = no mass)
+//   selection  : one contiguous block  -> {start, n}            (vector path, 4 atoms / lane / trip)
+//                anything else         -> uint32 idx[n] in HBM  (gather path, 1 atom / lane / trip)
+//   plan       : float p[s_pad][3] (reference coordinates minus the reference box centre, stored so
+//                that the float4 groups of p line up with the float4 groups of the frame), float w[s_pad]
+//
+// Reductions: per-lane fp64 accumulators -> wave __shfl_down tree -> LDS across the 4 waves of a
+// workgroup -> one partial record per workgroup in HBM -> a one-workgroup finalize kernel sums the
+// records in a fixed order (no atomics: results are bitwise reproducible run to run).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "gr_math.h"
+
+#define GR_WG 256
+#define GR_NOIDX 0xFFFFFFFFu
+#define GR_ST_FALLBACK 100 /* internal: frame must be redone on the multi-pass exact path */
+
+struct GrSel {
+    uint32_t n;            // atoms in the selection
+    uint32_t contiguous;   // 1: atoms start .. start+n-1
+    uint32_t start;        // first atom (contiguous) / first atom of idx (gather)
+    uint32_t g0;           // contiguous: first float4 group (start / 4)
+    const uint32_t *idx;   // gather list (device), NULL when contiguous
+};
+
+// per-frame state shared by the stages of one analysis (lives in HBM, one record per frame of a batch)
+struct GrFrameState {
+    float center[3];   // centre used for unwrapping (Bai-Breen estimate)
+    float com[3];      // result centre / centre of mass
+    float shift[3];    // box centre - com
+    float R[9];        // optimal rotation, column-major
+    float rmsd;
+    int status;
+    uint32_t err_index;
+    uint32_t pad;
+};
+
+// constants of an RMSD plan (device copy)
+struct GrPlanDev {
+    const float *p;    // [s_pad][3]
+    const float *w;    // [s_pad]
+    double sp[3];      // sum p
+    double swp[3];     // sum w p
+    double swpp;       // sum w |p|^2
+    double sw;         // sum w
+    float ref_com[3];  // reference.group_get_com(group)
+    uint32_t n;        // atoms in the reference group
+    uint32_t w_is_mass; // weights equal the target masses of the group: one load serves both
+};
+
+// ------------------------------------------------------------------------------------------ reductions
+template <int K>
+__device__ __forceinline__ void gr_block_sum(double (&v)[K], double *lds /* [GR_WG/64][K] */) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        double x = v[k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+        v[k] = x;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) lds[wave * K + k] = v[k];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            double s = lds[k];
+            for (int wv = 1; wv < GR_WG / 64; ++wv) s += lds[wv * K + k];
+            v[k] = s;
+        }
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ uint32_t gr_block_min_u32(uint32_t x, uint32_t *lds /* [GR_WG/64] */) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { uint32_t y = __shfl_down(x, off, 64); x = y < x ? y : x; }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) lds[wave] = x;
+    __syncthreads();
+    if (threadIdx.x == 0) for (int wv = 1; wv < GR_WG / 64; ++wv) x = lds[wv] < x ? lds[wv] : x;
+    __syncthreads();
+    return x;
+}
+
+__device__ __forceinline__ float gr_block_min_f32(float x, float *lds) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x = fminf(x, __shfl_down(x, off, 64));
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) lds[wave] = x;
+    __syncthreads();
+    if (threadIdx.x == 0) for (int wv = 1; wv < GR_WG / 64; ++wv) x = fminf(x, lds[wv]);
+    __syncthreads();
+    return x;
+}
+
+// Stage the frame's box into LDS once per workgroup (box + candidate table = 444 bytes).
+__device__ __forceinline__ void gr_stage_box(GrBox *lds_box, const GrBox *g) {
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(g);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(lds_box);
+    for (int i = threadIdx.x; i < (int)(sizeof(GrBox) / 4); i += GR_WG) dst[i] = src[i];
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------ atom streams
+// Calls f(atom_index, ordinal, x, y, z) for every atom of the selection handled by this workgroup.
+// Workgroup `chunk` of `nchunks` takes an interleaved share (grid-stride) so consecutive lanes
+// always touch consecutive memory.
+template <typename F>
+__device__ __forceinline__ void gr_for_each_atom(const GrSel &sel, const float *__restrict__ xyz,
+                                                 uint32_t chunk, uint32_t nchunks, F f) {
+    if (sel.contiguous) {
+        const uint32_t first = sel.start, last = sel.start + sel.n;   // [first, last)
+        const uint32_t g0 = sel.g0, g1 = (last + 3u) >> 2;            // float4 groups [g0, g1)
+        const float4 *f4 = reinterpret_cast<const float4 *>(xyz);
+        for (uint32_t g = g0 + chunk * GR_WG + threadIdx.x; g < g1; g += nchunks * GR_WG) {
+            const float4 a = f4[3 * (size_t)g], b = f4[3 * (size_t)g + 1], c = f4[3 * (size_t)g + 2];
+            const uint32_t i = g << 2;
+            if (i >= first && i < last) f(i, i - first, a.x, a.y, a.z);
+            if (i + 1 >= first && i + 1 < last) f(i + 1, i + 1 - first, a.w, b.x, b.y);
+            if (i + 2 >= first && i + 2 < last) f(i + 2, i + 2 - first, b.z, b.w, c.x);
+            if (i + 3 >= first && i + 3 < last) f(i + 3, i + 3 - first, c.y, c.z, c.w);
+        }
+    } else {
+        for (uint32_t j = chunk * GR_WG + threadIdx.x; j < sel.n; j += nchunks * GR_WG) {
+            const uint32_t i = sel.idx[j];
+            const float *p = xyz + 3 * (size_t)i;
+            f(i, j, p[0], p[1], p[2]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ centres
+// kind 0: naive sums  sum(m x), sum(m) [or count]            iterators.rs:886-903,946-967
+// kind 1: Bai-Breen   sum(m cos th), sum(m sin th) per axis  iterators.rs:1152-1191,1314-1357
+// kind 2: unwrapped about state.center: sum(m (c + vector_to(c, x))), sum(m)   :1237-1266,1404-1438
+// Partial record per workgroup: 8 doubles + {min idx without position, min idx without mass}.
+#define GR_CEN_K 8
+struct GrCenPartial { double s[GR_CEN_K]; uint32_t bad_pos, bad_mass; };
+
+__global__ __launch_bounds__(GR_WG) void k_center_sums(
+    const float *__restrict__ frames, size_t frame_stride, uint32_t first_slot,
+    const float *__restrict__ masses, GrSel sel, const GrBox *__restrict__ boxes,
+    const GrFrameState *__restrict__ state, int kind, int weighted, GrCenPartial *__restrict__ partials) {
+    __shared__ GrBox box;
+    __shared__ double lds[(GR_WG / 64) * GR_CEN_K];
+    __shared__ uint32_t ldsu[GR_WG / 64];
+    const uint32_t frame = blockIdx.y, chunk = blockIdx.x, nchunks = gridDim.x;
+    const float *xyz = frames + (size_t)(first_slot + frame) * frame_stride;
+    gr_stage_box(&box, boxes + first_slot + frame);
+    double acc[GR_CEN_K];
+#pragma unroll
+    for (int k = 0; k < GR_CEN_K; ++k) acc[k] = 0.0;
+    uint32_t bad_pos = GR_NOIDX, bad_mass = GR_NOIDX;
+    const float PI_X2 = 3.14159265358979323846f * 2.0f;   // auxiliary.rs:15
+    const float scx = PI_X2 / box.ax, scy = PI_X2 / box.by, scz = PI_X2 / box.cz;
+    float cx = 0.f, cy = 0.f, cz = 0.f;
+    if (kind == 2) { cx = state[frame].center[0]; cy = state[frame].center[1]; cz = state[frame].center[2]; }
+    gr_for_each_atom(sel, xyz, chunk, nchunks, [&](uint32_t i, uint32_t, float x, float y, float z) {
+        float m = 1.0f;
+        if (weighted) { m = masses[i]; if (m != m) { bad_mass = min(bad_mass, i); m = 0.0f; } }
+        if (x != x) { bad_pos = min(bad_pos, i); return; }
+        if (kind == 0) {
+            acc[0] += (double)(x * m); acc[1] += (double)(y * m); acc[2] += (double)(z * m); acc[3] += (double)m;
+        } else if (kind == 1) {
+            gr_wrap(x, y, z, box);
+            if (!box.ortho) {   // fractional ("u") coordinates, scaled by the box diagonal
+                const float sc = z / box.cz;
+                const float uy = y - sc * box.cy;
+                const float ux = x - (uy / box.by) * box.bx - sc * box.cx;
+                x = ux; y = uy;
+            }
+            float s0, c0, s1, c1, s2, c2;
+            sincosf(x * scx, &s0, &c0); sincosf(y * scy, &s1, &c1); sincosf(z * scz, &s2, &c2);
+            acc[0] += (double)(m * c0); acc[1] += (double)(m * c1); acc[2] += (double)(m * c2);
+            acc[3] += (double)(m * s0); acc[4] += (double)(m * s1); acc[5] += (double)(m * s2);
+            acc[6] += 1.0;
+        } else {
+            float vx, vy, vz;
+            gr_vector_to(cx, cy, cz, x, y, z, box, vx, vy, vz);
+            acc[0] += (double)((cx + vx) * m); acc[1] += (double)((cy + vy) * m); acc[2] += (double)((cz + vz) * m);
+            acc[3] += (double)m;
+        }
+    });
+    gr_block_sum<GR_CEN_K>(acc, lds);
+    bad_pos = gr_block_min_u32(bad_pos, ldsu);
+    bad_mass = gr_block_min_u32(bad_mass, ldsu);
+    if (threadIdx.x == 0) {
+        GrCenPartial &o = partials[(size_t)frame * nchunks + chunk];
+#pragma unroll
+        for (int k = 0; k < GR_CEN_K; ++k) o.s[k] = acc[k];
+        o.bad_pos = bad_pos; o.bad_mass = bad_mass;
+    }
+}
+
+// one workgroup per frame; target: 0 -> state.center, 1 -> state.com (+ shift = box centre - com)
+__global__ __launch_bounds__(GR_WG) void k_center_finalize(
+    const GrCenPartial *__restrict__ partials, uint32_t nchunks, const GrBox *__restrict__ boxes,
+    uint32_t first_slot, int kind, int weighted, int mass_first, int target, uint32_t n_sel,
+    GrFrameState *__restrict__ state) {
+    __shared__ double lds[(GR_WG / 64) * GR_CEN_K];
+    __shared__ uint32_t ldsu[GR_WG / 64];
+    const uint32_t frame = blockIdx.x;
+    double acc[GR_CEN_K];
+#pragma unroll
+    for (int k = 0; k < GR_CEN_K; ++k) acc[k] = 0.0;
+    uint32_t bad_pos = GR_NOIDX, bad_mass = GR_NOIDX;
+    for (uint32_t c = threadIdx.x; c < nchunks; c += GR_WG) {
+        const GrCenPartial &p = partials[(size_t)frame * nchunks + c];
+#pragma unroll
+        for (int k = 0; k < GR_CEN_K; ++k) acc[k] += p.s[k];
+        bad_pos = min(bad_pos, p.bad_pos); bad_mass = min(bad_mass, p.bad_mass);
+    }
+    gr_block_sum<GR_CEN_K>(acc, lds);
+    bad_pos = gr_block_min_u32(bad_pos, ldsu);
+    bad_mass = gr_block_min_u32(bad_mass, ldsu);
+    if (threadIdx.x != 0) return;
+    GrFrameState &st = state[frame];
+    if (st.status != 0) return;   // an earlier stage of this frame already failed
+    const GrBox &b = boxes[first_slot + frame];
+    // error precedence of the reference loops: estimate_com / get_com_naive test per atom
+    // (mass first: iterators.rs:1324-1339; position first: :946-958); get_com runs the unweighted
+    // estimate over all atoms before any mass is read (:1405-1422)
+    if (bad_pos != GR_NOIDX || bad_mass != GR_NOIDX) {
+        bool mass_err;
+        if (bad_mass == GR_NOIDX) mass_err = false;
+        else if (bad_pos == GR_NOIDX) mass_err = true;
+        else mass_err = mass_first ? (bad_mass <= bad_pos) : (bad_mass < bad_pos);
+        st.status = mass_err ? 7 /*GR_E_NO_MASS*/ : 6 /*GR_E_NO_POSITION*/;
+        st.err_index = mass_err ? bad_mass : bad_pos;
+        return;
+    }
+    float r[3];
+    if (kind == 1) {
+        const float PI_F = 3.14159265358979323846f, PI_X2 = PI_F * 2.0f;
+        const float sc[3] = { PI_X2 / b.ax, PI_X2 / b.by, PI_X2 / b.cz };
+        float t[3];
+        for (int a = 0; a < 3; ++a) t[a] = (atan2f(-(float)acc[3 + a], -(float)acc[a]) + PI_F) / sc[a];   // auxiliary.rs:87-99
+        if (b.ortho) { r[0] = t[0]; r[1] = t[1]; r[2] = t[2]; }
+        else {
+            const float s_c = t[2] / b.cz, s_b = t[1] / b.by;
+            r[2] = t[2]; r[1] = t[1] + s_c * b.cy; r[0] = t[0] + s_b * b.bx + s_c * b.cx;
+        }
+    } else {
+        const double div = weighted ? acc[3] : (double)n_sel;
+        r[0] = (float)(acc[0] / div); r[1] = (float)(acc[1] / div); r[2] = (float)(acc[2] / div);
+    }
+    if (target == 0) { st.center[0] = r[0]; st.center[1] = r[1]; st.center[2] = r[2]; }
+    else {
+        st.com[0] = r[0]; st.com[1] = r[1]; st.com[2] = r[2];
+        st.shift[0] = b.bcx - r[0]; st.shift[1] = b.bcy - r[1]; st.shift[2] = b.bcz - r[2];
+    }
+}
+
+__global__ void k_state_reset(GrFrameState *state, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { GrFrameState z = {}; z.err_index = GR_NOIDX; state[i] = z; }
+}
+
+// ------------------------------------------------------------------------------------------ RMSD accumulate
+// One pass over the group: everything kabsch_rmsd (rmsd.rs:547-603) and get_com (iterators.rs:1404-1438)
+// need, as sums that do not depend on the centre of mass:
+//   v_i   = image of x_i nearest to the provisional centre g (= first atom of the group)    [MODE 0]
+//         = wrap(x_i + shift) - box_centre, the reference's own q_i (rmsd.rs:479-492)       [MODE 1]
+//   [0] sum m        [1..3] sum m v      [4..12] A = sum p v^T (unweighted, rmsd.rs:567-570)
+//   [13..21] B = sum w p v^T             [22] sum w |v|^2      [23..25] sum w v
+//   [26..31] Bai-Breen sums of the fractional coordinates of v (MODE 0 only; hardware sin/cos in
+//            revolutions -- the estimate is only used to PROVE that the images chosen about g are
+//            the images the reference chooses about its own centre estimate)
+//   min/max of v per axis, first atom without position / mass.
+#define GR_ACC_K 32
+struct GrAccPartial { double s[GR_ACC_K]; float vmin[3], vmax[3]; uint32_t bad_pos, bad_mass; };
+
+template <int MODE>
+__global__ __launch_bounds__(GR_WG) void k_rmsd_accum(
+    const float *__restrict__ frames, size_t frame_stride, uint32_t first_slot,
+    const float *__restrict__ masses, GrSel sel, const GrBox *__restrict__ boxes,
+    GrPlanDev plan, const GrFrameState *__restrict__ state, GrAccPartial *__restrict__ partials) {
+    __shared__ GrBox box;
+    __shared__ double lds[(GR_WG / 64) * GR_ACC_K];
+    __shared__ uint32_t ldsu[GR_WG / 64];
+    __shared__ float ldsf[GR_WG / 64];
+    const uint32_t frame = blockIdx.y, chunk = blockIdx.x, nchunks = gridDim.x;
+    const float *xyz = frames + (size_t)(first_slot + frame) * frame_stride;
+    gr_stage_box(&box, boxes + first_slot + frame);
+    double acc[GR_ACC_K];
+#pragma unroll
+    for (int k = 0; k < GR_ACC_K; ++k) acc[k] = 0.0;
+    float mn[3] = { 3.0e38f, 3.0e38f, 3.0e38f }, mx[3] = { -3.0e38f, -3.0e38f, -3.0e38f };
+    uint32_t bad_pos = GR_NOIDX, bad_mass = GR_NOIDX;
+    float gx, gy, gz, sx = 0.f, sy = 0.f, sz = 0.f;
+    {
+        const uint32_t i0 = sel.contiguous ? sel.start : sel.idx[0];
+        gx = xyz[3 * (size_t)i0]; gy = xyz[3 * (size_t)i0 + 1]; gz = xyz[3 * (size_t)i0 + 2];
+    }
+    if (MODE == 1) { sx = state[frame].shift[0]; sy = state[frame].shift[1]; sz = state[frame].shift[2]; }
+    const float iax = 1.0f / box.ax, iby = 1.0f / box.by, icz = 1.0f / box.cz;
+    float fsum[6] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
+    auto visit = [&](uint32_t i, float x, float y, float z, float m, float px, float py, float pz, float w) {
+        if (m != m) { bad_mass = min(bad_mass, i); m = 0.0f; }
+        if (x != x) { bad_pos = min(bad_pos, i); return; }
+        float vx, vy, vz;
+        if (MODE == 0) {
+            vx = x - gx; vy = y - gy; vz = z - gz;
+            gr_min_image_vec(vx, vy, vz, box);
+            // fractional coordinates of v in revolutions -> hardware sin/cos
+            const float fc = vz * icz;
+            const float uy = vy - fc * box.cy;
+            const float fb = uy * iby;
+            const float fa = (vx - fb * box.bx - fc * box.cx) * iax;
+            fsum[0] += __builtin_amdgcn_cosf(fa); fsum[1] += __builtin_amdgcn_cosf(fb); fsum[2] += __builtin_amdgcn_cosf(fc);
+            fsum[3] += __builtin_amdgcn_sinf(fa); fsum[4] += __builtin_amdgcn_sinf(fb); fsum[5] += __builtin_amdgcn_sinf(fc);
+        } else {
+            vx = x + sx; vy = y + sy; vz = z + sz;
+            gr_wrap(vx, vy, vz, box);
+            vx -= box.bcx; vy -= box.bcy; vz -= box.bcz;
+        }
+        mn[0] = fminf(mn[0], vx); mn[1] = fminf(mn[1], vy); mn[2] = fminf(mn[2], vz);
+        mx[0] = fmaxf(mx[0], vx); mx[1] = fmaxf(mx[1], vy); mx[2] = fmaxf(mx[2], vz);
+        const double dvx = vx, dvy = vy, dvz = vz, dm = m, dw = w;
+        const double dpx = px, dpy = py, dpz = pz;
+        acc[0] += dm;
+        acc[1] += dm * dvx; acc[2] += dm * dvy; acc[3] += dm * dvz;
+        acc[4] += dpx * dvx; acc[5] += dpx * dvy; acc[6] += dpx * dvz;
+        acc[7] += dpy * dvx; acc[8] += dpy * dvy; acc[9] += dpy * dvz;
+        acc[10] += dpz * dvx; acc[11] += dpz * dvy; acc[12] += dpz * dvz;
+        const double wpx = dw * dpx, wpy = dw * dpy, wpz = dw * dpz;
+        acc[13] += wpx * dvx; acc[14] += wpx * dvy; acc[15] += wpx * dvz;
+        acc[16] += wpy * dvx; acc[17] += wpy * dvy; acc[18] += wpy * dvz;
+        acc[19] += wpz * dvx; acc[20] += wpz * dvy; acc[21] += wpz * dvz;
+        acc[22] += dw * (dvx * dvx + dvy * dvy + dvz * dvz);
+        acc[23] += dw * dvx; acc[24] += dw * dvy; acc[25] += dw * dvz;
+    };
+    if (sel.contiguous) {
+        // 4 atoms per lane per trip: 3 float4 of positions, 3 float4 of reference coordinates,
+        // 1 float4 of masses (+1 of weights when they differ from the masses)
+        const uint32_t first = sel.start, last = sel.start + sel.n;
+        const uint32_t g0 = sel.g0, g1 = (last + 3u) >> 2;
+        const float4 *f4 = reinterpret_cast<const float4 *>(xyz);
+        const float4 *p4 = reinterpret_cast<const float4 *>(plan.p);
+        const float4 *m4 = reinterpret_cast<const float4 *>(masses);
+        const float4 *w4 = reinterpret_cast<const float4 *>(plan.w);
+        for (uint32_t g = g0 + chunk * GR_WG + threadIdx.x; g < g1; g += nchunks * GR_WG) {
+            const float4 a = f4[3 * (size_t)g], b = f4[3 * (size_t)g + 1], c = f4[3 * (size_t)g + 2];
+            const size_t pg = (size_t)(g - g0);
+            const float4 pa = p4[3 * pg], pb = p4[3 * pg + 1], pc = p4[3 * pg + 2];
+            const float4 mm = m4[g];
+            const float4 ww = plan.w_is_mass ? mm : w4[pg];
+            const uint32_t i = g << 2;
+            if (i >= first && i < last) visit(i, a.x, a.y, a.z, mm.x, pa.x, pa.y, pa.z, ww.x);
+            if (i + 1 >= first && i + 1 < last) visit(i + 1, a.w, b.x, b.y, mm.y, pa.w, pb.x, pb.y, ww.y);
+            if (i + 2 >= first && i + 2 < last) visit(i + 2, b.z, b.w, c.x, mm.z, pb.z, pb.w, pc.x, ww.z);
+            if (i + 3 >= first && i + 3 < last) visit(i + 3, c.y, c.z, c.w, mm.w, pc.y, pc.z, pc.w, ww.w);
+        }
+    } else {
+        for (uint32_t j = chunk * GR_WG + threadIdx.x; j < sel.n; j += nchunks * GR_WG) {
+            const uint32_t i = sel.idx[j];
+            const float *q = xyz + 3 * (size_t)i;
+            const float m = masses[i];
+            visit(i, q[0], q[1], q[2], m, plan.p[3 * (size_t)j], plan.p[3 * (size_t)j + 1], plan.p[3 * (size_t)j + 2],
+                  plan.w_is_mass ? m : plan.w[j]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) acc[26 + k] = (double)fsum[k];
+    gr_block_sum<GR_ACC_K>(acc, lds);
+    bad_pos = gr_block_min_u32(bad_pos, ldsu);
+    bad_mass = gr_block_min_u32(bad_mass, ldsu);
+    float rmn[3], rmx[3];
+    for (int a = 0; a < 3; ++a) { rmn[a] = gr_block_min_f32(mn[a], ldsf); rmx[a] = -gr_block_min_f32(-mx[a], ldsf); }
+    if (threadIdx.x == 0) {
+        GrAccPartial &o = partials[(size_t)frame * nchunks + chunk];
+#pragma unroll
+        for (int k = 0; k < GR_ACC_K; ++k) o.s[k] = acc[k];
+        for (int a = 0; a < 3; ++a) { o.vmin[a] = rmn[a]; o.vmax[a] = rmx[a]; }
+        o.bad_pos = bad_pos; o.bad_mass = bad_mass;
+    }
+}
+
+// ---- 3x3 helpers (double) for the finalize kernel
+__device__ inline void gr_jacobi_eig3(double A[3][3], double V[3][3]) {
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) V[i][j] = (i == j) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 32; ++sweep) {
+        const double off = A[0][1] * A[0][1] + A[0][2] * A[0][2] + A[1][2] * A[1][2];
+        const double dg = A[0][0] * A[0][0] + A[1][1] * A[1][1] + A[2][2] * A[2][2];
+        if (off <= 1e-60 || off <= 1e-32 * dg) break;
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                if (A[p][q] == 0.0) continue;
+                const double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < 3; ++k) { const double akp = A[k][p], akq = A[k][q]; A[k][p] = c * akp - s * akq; A[k][q] = s * akp + c * akq; }
+                for (int k = 0; k < 3; ++k) { const double apk = A[p][k], aqk = A[q][k]; A[p][k] = c * apk - s * aqk; A[q][k] = s * apk + c * aqk; }
+                for (int k = 0; k < 3; ++k) { const double vkp = V[k][p], vkq = V[k][q]; V[k][p] = c * vkp - s * vkq; V[k][q] = s * vkp + c * vkq; }
+            }
+    }
+}
+
+// R = U diag(1,1,sign det(U V^T)) V^T of H = U S V^T (rmsd.rs:573-583), from the eigenvectors of H^T H:
+// u_k = H v_k / |H v_k| (k = 1,2), u_3' = u_1 x u_2, R = u_1 v_1^T + u_2 v_2^T + det(V) u_3' v_3^T.
+__device__ inline void gr_kabsch_rotation(const double H[3][3], double R[3][3]) {
+    double HtH[3][3], V[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) HtH[i][j] = H[0][i] * H[0][j] + H[1][i] * H[1][j] + H[2][i] * H[2][j];
+    gr_jacobi_eig3(HtH, V);
+    const double w[3] = { HtH[0][0], HtH[1][1], HtH[2][2] };
+    int o0 = 0, o1 = 1, o2 = 2;
+    if (w[o1] > w[o0]) { int t = o0; o0 = o1; o1 = t; }
+    if (w[o2] > w[o0]) { int t = o0; o0 = o2; o2 = t; }
+    if (w[o2] > w[o1]) { int t = o1; o1 = o2; o2 = t; }
+    double v[3][3];
+    for (int i = 0; i < 3; ++i) { v[0][i] = V[i][o0]; v[1][i] = V[i][o1]; v[2][i] = V[i][o2]; }
+    double u[3][3];
+    for (int k = 0; k < 2; ++k)
+        for (int i = 0; i < 3; ++i) u[k][i] = H[i][0] * v[k][0] + H[i][1] * v[k][1] + H[i][2] * v[k][2];
+    double n0 = sqrt(u[0][0] * u[0][0] + u[0][1] * u[0][1] + u[0][2] * u[0][2]);
+    if (!(n0 >= 1e-300)) { for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) R[i][j] = (i == j) ? 1.0 : 0.0; return; }
+    for (int i = 0; i < 3; ++i) u[0][i] /= n0;
+    const double d01 = u[1][0] * u[0][0] + u[1][1] * u[0][1] + u[1][2] * u[0][2];
+    for (int i = 0; i < 3; ++i) u[1][i] -= d01 * u[0][i];
+    double n1 = sqrt(u[1][0] * u[1][0] + u[1][1] * u[1][1] + u[1][2] * u[1][2]);
+    if (n1 < 1e-12 * n0) {
+        const double a0 = fabs(u[0][0]), a1 = fabs(u[0][1]), a2 = fabs(u[0][2]);
+        const int m = a0 < a1 ? (a0 < a2 ? 0 : 2) : (a1 < a2 ? 1 : 2);
+        double e[3] = { 0, 0, 0 }; e[m] = 1.0;
+        const double d = e[0] * u[0][0] + e[1] * u[0][1] + e[2] * u[0][2];
+        for (int i = 0; i < 3; ++i) u[1][i] = e[i] - d * u[0][i];
+        n1 = sqrt(u[1][0] * u[1][0] + u[1][1] * u[1][1] + u[1][2] * u[1][2]);
+    }
+    for (int i = 0; i < 3; ++i) u[1][i] /= n1;
+    u[2][0] = u[0][1] * u[1][2] - u[0][2] * u[1][1];
+    u[2][1] = u[0][2] * u[1][0] - u[0][0] * u[1][2];
+    u[2][2] = u[0][0] * u[1][1] - u[0][1] * u[1][0];
+    const double detV = v[0][0] * (v[1][1] * v[2][2] - v[1][2] * v[2][1]) - v[0][1] * (v[1][0] * v[2][2] - v[1][2] * v[2][0]) +
+                        v[0][2] * (v[1][0] * v[2][1] - v[1][1] * v[2][0]);
+    const double sg = detV < 0 ? -1.0 : 1.0;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) R[i][j] = u[0][i] * v[0][j] + u[1][i] * v[1][j] + sg * u[2][i] * v[2][j];
+}
+
+// One workgroup per frame: sum the partial records, then lane 0 closes the algebra:
+//   cv = sum(m v)/sum(m)                     (COM relative to the provisional centre; MODE 1: v is already q)
+//   H  = A - (sum p) cv^T,  Hw = B - (sum w p) cv^T,  sum w|q|^2 = sum w|v|^2 - 2 cv.sum(w v) + W |cv|^2
+//   R  from H;  rmsd^2 = (sum w|p|^2 + sum w|q|^2 - 2 sum_ab R_ab Hw_ab) / W      (= rmsd.rs:592-599 expanded)
+// MODE 0 also proves the single-pass images equal the reference's (see DESIGN.md "image proof"):
+// every v_i must lie strictly inside the minimum-image cell about BOTH the Bai-Breen centre and the COM;
+// otherwise the frame is flagged GR_ST_FALLBACK and redone by the multi-pass path.
+template <int MODE>
+__global__ __launch_bounds__(GR_WG) void k_rmsd_finalize(
+    const GrAccPartial *__restrict__ partials, uint32_t nchunks,
+    const float *__restrict__ frames, size_t frame_stride, uint32_t first_slot, GrSel sel,
+    const GrBox *__restrict__ boxes, GrPlanDev plan, GrFrameState *__restrict__ state) {
+    __shared__ double lds[(GR_WG / 64) * GR_ACC_K];
+    __shared__ uint32_t ldsu[GR_WG / 64];
+    __shared__ float ldsf[GR_WG / 64];
+    const uint32_t frame = blockIdx.x;
+    double acc[GR_ACC_K];
+#pragma unroll
+    for (int k = 0; k < GR_ACC_K; ++k) acc[k] = 0.0;
+    float mn[3] = { 3.0e38f, 3.0e38f, 3.0e38f }, mx[3] = { -3.0e38f, -3.0e38f, -3.0e38f };
+    uint32_t bad_pos = GR_NOIDX, bad_mass = GR_NOIDX;
+    for (uint32_t c = threadIdx.x; c < nchunks; c += GR_WG) {
+        const GrAccPartial &p = partials[(size_t)frame * nchunks + c];
+#pragma unroll
+        for (int k = 0; k < GR_ACC_K; ++k) acc[k] += p.s[k];
+        for (int a = 0; a < 3; ++a) { mn[a] = fminf(mn[a], p.vmin[a]); mx[a] = fmaxf(mx[a], p.vmax[a]); }
+        bad_pos = min(bad_pos, p.bad_pos); bad_mass = min(bad_mass, p.bad_mass);
+    }
+    gr_block_sum<GR_ACC_K>(acc, lds);
+    bad_pos = gr_block_min_u32(bad_pos, ldsu);
+    bad_mass = gr_block_min_u32(bad_mass, ldsu);
+    for (int a = 0; a < 3; ++a) { mn[a] = gr_block_min_f32(mn[a], ldsf); mx[a] = -gr_block_min_f32(-mx[a], ldsf); }
+    if (threadIdx.x != 0) return;
+    GrFrameState &st = state[frame];
+    if (st.status != 0) return;
+    const GrBox &b = boxes[first_slot + frame];
+    if (MODE == 0) {
+        // get_com: positions of the whole group are checked before any mass (iterators.rs:1405-1422)
+        if (bad_pos != GR_NOIDX) { st.status = 6; st.err_index = bad_pos; return; }
+        if (bad_mass != GR_NOIDX) { st.status = 7; st.err_index = bad_mass; return; }
+    }
+    const double M = acc[0];
+    double cv[3] = { 0, 0, 0 };
+    if (MODE == 0) { cv[0] = acc[1] / M; cv[1] = acc[2] / M; cv[2] = acc[3] / M; }
+    if (MODE == 0) {
+        const float *xyz = frames + (size_t)(first_slot + frame) * frame_stride;
+        const uint32_t i0 = sel.contiguous ? sel.start : sel.idx[0];
+        const double g[3] = { xyz[3 * (size_t)i0], xyz[3 * (size_t)i0 + 1], xyz[3 * (size_t)i0 + 2] };
+        // Bai-Breen centre of v (fractional circular means -> Cartesian)
+        const double TWO_PI = 6.283185307179586;
+        const double fa = atan2(acc[29], acc[26]) / TWO_PI, fb = atan2(acc[30], acc[27]) / TWO_PI, fc = atan2(acc[31], acc[28]) / TWO_PI;
+        const double ce[3] = { fa * b.ax + fb * b.bx + fc * b.cx, fb * b.by + fc * b.cy, fc * b.cz };
+        const double margin = 1.0e-3;   // nm; >> the error of the hardware sin/cos estimate (~1e-5 nm)
+        bool ok = true;
+        const double *cen[2] = { ce, cv };
+        for (int t = 0; t < 2; ++t) {
+            if (b.ortho) {
+                const double L[3] = { b.ax, b.by, b.cz };
+                for (int a = 0; a < 3; ++a) {
+                    const double far = fmax(fabs((double)mx[a] - cen[t][a]), fabs((double)mn[a] - cen[t][a]));
+                    if (!(far < 0.5 * L[a] - margin)) ok = false;
+                }
+            } else {
+                double r2 = 0;
+                for (int a = 0; a < 3; ++a) {
+                    const double far = fmax(fabs((double)mx[a] - cen[t][a]), fabs((double)mn[a] - cen[t][a]));
+                    r2 += far * far;
+                }
+                if (!(sqrt(r2) < (double)b.r_ws - margin)) ok = false;
+            }
+        }
+        if (!ok) { st.status = GR_ST_FALLBACK; return; }
+        st.center[0] = (float)(g[0] + ce[0]); st.center[1] = (float)(g[1] + ce[1]); st.center[2] = (float)(g[2] + ce[2]);
+        const float com[3] = { (float)(g[0] + cv[0]), (float)(g[1] + cv[1]), (float)(g[2] + cv[2]) };
+        st.com[0] = com[0]; st.com[1] = com[1]; st.com[2] = com[2];
+        st.shift[0] = b.bcx - com[0]; st.shift[1] = b.bcy - com[1]; st.shift[2] = b.bcz - com[2];
+    }
+    double H[3][3], Hw[3][3];
+    for (int a = 0; a < 3; ++a)
+        for (int c = 0; c < 3; ++c) {
+            H[a][c] = acc[4 + 3 * a + c] - plan.sp[a] * cv[c];
+            Hw[a][c] = acc[13 + 3 * a + c] - plan.swp[a] * cv[c];
+        }
+    const double swqq = acc[22] - 2.0 * (cv[0] * acc[23] + cv[1] * acc[24] + cv[2] * acc[25]) +
+                        plan.sw * (cv[0] * cv[0] + cv[1] * cv[1] + cv[2] * cv[2]);
+    double R[3][3];
+    gr_kabsch_rotation(H, R);
+    double tr = 0;
+    for (int a = 0; a < 3; ++a) for (int c = 0; c < 3; ++c) tr += R[a][c] * Hw[a][c];
+    double r2 = (plan.swpp + swqq - 2.0 * tr) / plan.sw;
+    if (r2 < 0.0) r2 = 0.0;
+    st.rmsd = (float)sqrt(r2);
+    for (int a = 0; a < 3; ++a) for (int c = 0; c < 3; ++c) st.R[3 * c + a] = (float)R[a][c];   // column-major
+}
+
+// ------------------------------------------------------------------------------------------ fit (all atoms)
+// fit_structure (rmsd.rs:508-528, atom.rs:498-528,894-903), one streaming read-modify-write pass:
+//   z = R (wrap(x + shift) - box_centre) + reference_group_com
+__global__ __launch_bounds__(GR_WG) void k_fit(
+    float *__restrict__ frames, size_t frame_stride, uint32_t first_slot, uint32_t n_atoms,
+    const GrBox *__restrict__ boxes, GrPlanDev plan, const GrFrameState *__restrict__ state) {
+    __shared__ GrBox box;
+    const uint32_t frame = blockIdx.y;
+    const GrFrameState &st = state[frame];
+    if (st.status != 0) return;   // analysis failed -> frame left unmodified (rmsd.rs:91)
+    float *xyz = frames + (size_t)(first_slot + frame) * frame_stride;
+    gr_stage_box(&box, boxes + first_slot + frame);
+    const float sx = st.shift[0], sy = st.shift[1], sz = st.shift[2];
+    const float r00 = st.R[0], r10 = st.R[1], r20 = st.R[2], r01 = st.R[3], r11 = st.R[4], r21 = st.R[5], r02 = st.R[6], r12 = st.R[7], r22 = st.R[8];
+    const float cx = plan.ref_com[0], cy = plan.ref_com[1], cz = plan.ref_com[2];
+    auto tf = [&](float &x, float &y, float &z) {
+        x += sx; y += sy; z += sz;
+        gr_wrap(x, y, z, box);
+        x -= box.bcx; y -= box.bcy; z -= box.bcz;
+        const float nx = r00 * x + r01 * y + r02 * z;
+        const float ny = r10 * x + r11 * y + r12 * z;
+        const float nz = r20 * x + r21 * y + r22 * z;
+        x = nx + cx; y = ny + cy; z = nz + cz;
+    };
+    float4 *f4 = reinterpret_cast<float4 *>(xyz);
+    const uint32_t ngroups = n_atoms >> 2;   // whole float4 groups
+    for (uint32_t g = blockIdx.x * GR_WG + threadIdx.x; g < ngroups; g += gridDim.x * GR_WG) {
+        float4 a = f4[3 * (size_t)g], b = f4[3 * (size_t)g + 1], c = f4[3 * (size_t)g + 2];
+        tf(a.x, a.y, a.z); tf(a.w, b.x, b.y); tf(b.z, b.w, c.x); tf(c.y, c.z, c.w);
+        f4[3 * (size_t)g] = a; f4[3 * (size_t)g + 1] = b; f4[3 * (size_t)g + 2] = c;
+    }
+    if (blockIdx.x == 0) {   // tail atoms (n_atoms % 4)
+        const uint32_t i = (ngroups << 2) + threadIdx.x;
+        if (i < n_atoms) { float x = xyz[3 * (size_t)i], y = xyz[3 * (size_t)i + 1], z = xyz[3 * (size_t)i + 2]; tf(x, y, z); xyz[3 * (size_t)i] = x; xyz[3 * (size_t)i + 1] = y; xyz[3 * (size_t)i + 2] = z; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ plan extraction
+// extract_data_from_system on the reference (rmsd.rs:425-446): p_i = wrap(x_i + shift) - box_centre,
+// stored at ordinal j + pofs; plus the frame-independent sums [0..2] sum p, [3..5] sum w p, [6] sum w|p|^2, [7] sum w.
+__global__ __launch_bounds__(GR_WG) void k_plan_extract(
+    const float *__restrict__ xyz, const float *__restrict__ masses, GrSel sel, const GrBox *__restrict__ boxp,
+    const GrFrameState *__restrict__ state, uint32_t pofs, float *__restrict__ p_out, float *__restrict__ w_out,
+    GrCenPartial *__restrict__ partials) {
+    __shared__ GrBox box;
+    __shared__ double lds[(GR_WG / 64) * GR_CEN_K];
+    gr_stage_box(&box, boxp);
+    const float sx = state->shift[0], sy = state->shift[1], sz = state->shift[2];
+    double acc[GR_CEN_K];
+#pragma unroll
+    for (int k = 0; k < GR_CEN_K; ++k) acc[k] = 0.0;
+    gr_for_each_atom(sel, xyz, blockIdx.x, gridDim.x, [&](uint32_t i, uint32_t j, float x, float y, float z) {
+        x += sx; y += sy; z += sz;
+        gr_wrap(x, y, z, box);
+        x -= box.bcx; y -= box.bcy; z -= box.bcz;
+        const float w = masses[i];
+        const size_t jj = (size_t)j + pofs;
+        p_out[3 * jj] = x; p_out[3 * jj + 1] = y; p_out[3 * jj + 2] = z; w_out[jj] = w;
+        const double dx = x, dy = y, dz = z, dw = w;
+        acc[0] += dx; acc[1] += dy; acc[2] += dz;
+        acc[3] += dw * dx; acc[4] += dw * dy; acc[5] += dw * dz;
+        acc[6] += dw * (dx * dx + dy * dy + dz * dz); acc[7] += dw;
+    });
+    gr_block_sum<GR_CEN_K>(acc, lds);
+    if (threadIdx.x == 0) {
+        GrCenPartial &o = partials[blockIdx.x];
+#pragma unroll
+        for (int k = 0; k < GR_CEN_K; ++k) o.s[k] = acc[k];
+        o.bad_pos = GR_NOIDX; o.bad_mass = GR_NOIDX;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ translate / wrap
+// MutAtomIteratorWithBox::translate / wrap (iterators.rs:1520-1553; atom.rs:498-545): x <- wrap(x + v)
+__global__ __launch_bounds__(GR_WG) void k_translate_wrap(
+    float *__restrict__ xyz, GrSel sel, const GrBox *__restrict__ boxp, const GrFrameState *__restrict__ state,
+    int use_state_shift, int dim_mask, float tx, float ty, float tz, uint32_t *__restrict__ bad_out) {
+    __shared__ GrBox box;
+    __shared__ uint32_t ldsu[GR_WG / 64];
+    gr_stage_box(&box, boxp);
+    if (use_state_shift) {   // atoms_center: shift = filter(box centre - estimated centre, dim) (utility.rs:116-119)
+        if (state->status != 0) return;
+        tx = (dim_mask & 1) ? box.bcx - state->center[0] : 0.0f;
+        ty = (dim_mask & 2) ? box.bcy - state->center[1] : 0.0f;
+        tz = (dim_mask & 4) ? box.bcz - state->center[2] : 0.0f;
+    }
+    uint32_t bad = GR_NOIDX;
+    auto tf = [&](uint32_t i, float &x, float &y, float &z) {
+        if (x != x) { bad = min(bad, i); return; }
+        x += tx; y += ty; z += tz;
+        gr_wrap(x, y, z, box);
+    };
+    if (sel.contiguous) {
+        const uint32_t first = sel.start, last = sel.start + sel.n;
+        const uint32_t g1 = (last + 3u) >> 2;
+        float4 *f4 = reinterpret_cast<float4 *>(xyz);
+        for (uint32_t g = sel.g0 + blockIdx.x * GR_WG + threadIdx.x; g < g1; g += gridDim.x * GR_WG) {
+            float4 a = f4[3 * (size_t)g], b = f4[3 * (size_t)g + 1], c = f4[3 * (size_t)g + 2];
+            const uint32_t i = g << 2;
+            if (i >= first && i < last) tf(i, a.x, a.y, a.z);
+            if (i + 1 >= first && i + 1 < last) tf(i + 1, a.w, b.x, b.y);
+            if (i + 2 >= first && i + 2 < last) tf(i + 2, b.z, b.w, c.x);
+            if (i + 3 >= first && i + 3 < last) tf(i + 3, c.y, c.z, c.w);
+            f4[3 * (size_t)g] = a; f4[3 * (size_t)g + 1] = b; f4[3 * (size_t)g + 2] = c;
+        }
+    } else {
+        for (uint32_t j = blockIdx.x * GR_WG + threadIdx.x; j < sel.n; j += gridDim.x * GR_WG) {
+            const uint32_t i = sel.idx[j];
+            float *p = xyz + 3 * (size_t)i;
+            float x = p[0], y = p[1], z = p[2];
+            tf(i, x, y, z);
+            p[0] = x; p[1] = y; p[2] = z;
+        }
+    }
+    bad = gr_block_min_u32(bad, ldsu);
+    if (threadIdx.x == 0 && bad != GR_NOIDX) atomicMin(bad_out, bad);
+}
+
+// ------------------------------------------------------------------------------------------ pair distances
+// group_all_distances (analysis.rs:401-427): D[i][j] = distance(x_i, x_j, dim), row-major n1 x n2.
+// Workgroup tile: GR_PD_TI rows x 1024 columns.  Each lane keeps 4 consecutive j atoms in registers,
+// the i atoms of the tile sit in LDS (broadcast reads), and every row is written with one 16-byte
+// store per lane = 1 KiB contiguous per wavefront instruction.  The kernel is bound by the HBM write
+// of the matrix (4 B/pair); orthorhombic boxes need ~15 flop/pair.
+#define GR_PD_TI 32
+__global__ __launch_bounds__(GR_WG) void k_pairdist(
+    const float *__restrict__ xyz, GrSel s1, GrSel s2, const GrBox *__restrict__ boxp, int dim,
+    float *__restrict__ out, uint32_t *__restrict__ bad_out) {
+    __shared__ GrBox box;
+    __shared__ float ti[GR_PD_TI][3];
+    __shared__ uint32_t ldsu[GR_WG / 64];
+    gr_stage_box(&box, boxp);
+    const uint32_t i0 = blockIdx.y * GR_PD_TI, j0 = blockIdx.x * (GR_WG * 4) + threadIdx.x * 4;
+    uint32_t bad = GR_NOIDX, badj = GR_NOIDX;   // first atom without position among the rows / the columns
+    if (threadIdx.x < GR_PD_TI) {
+        const uint32_t i = i0 + threadIdx.x;
+        float x = 0.f, y = 0.f, z = 0.f;
+        if (i < s1.n) {
+            const uint32_t a = s1.contiguous ? s1.start + i : s1.idx[i];
+            x = xyz[3 * (size_t)a]; y = xyz[3 * (size_t)a + 1]; z = xyz[3 * (size_t)a + 2];
+            if (x != x) bad = min(bad, a);
+        }
+        ti[threadIdx.x][0] = x; ti[threadIdx.x][1] = y; ti[threadIdx.x][2] = z;
+    }
+    float jx[4], jy[4], jz[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t j = j0 + k;
+        jx[k] = jy[k] = jz[k] = 0.f;
+        if (j < s2.n) {
+            const uint32_t a = s2.contiguous ? s2.start + j : s2.idx[j];
+            jx[k] = xyz[3 * (size_t)a]; jy[k] = xyz[3 * (size_t)a + 1]; jz[k] = xyz[3 * (size_t)a + 2];
+            if (jx[k] != jx[k]) badj = min(badj, a);
+        }
+    }
+    __syncthreads();
+    const uint32_t ni = min((uint32_t)GR_PD_TI, s1.n > i0 ? s1.n - i0 : 0u);
+    const bool vec_ok = ((s2.n & 3u) == 0u);   // rows stay 16-byte aligned
+    for (uint32_t r = 0; r < ni; ++r) {
+        const float ax_ = ti[r][0], ay_ = ti[r][1], az_ = ti[r][2];
+        float d[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) d[k] = gr_distance(ax_, ay_, az_, jx[k], jy[k], jz[k], dim, box);
+        float *row = out + (size_t)(i0 + r) * s2.n;
+        if (vec_ok && j0 + 3 < s2.n) {
+            *reinterpret_cast<float4 *>(row + j0) = make_float4(d[0], d[1], d[2], d[3]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (j0 + k < s2.n) row[j0 + k] = d[k];
+        }
+    }
+    bad = gr_block_min_u32(bad, ldsu);
+    badj = gr_block_min_u32(badj, ldsu);
+    if (threadIdx.x == 0 && bad != GR_NOIDX) atomicMin(bad_out, bad);
+    if (threadIdx.x == 0 && badj != GR_NOIDX) atomicMin(bad_out + 1, badj);
+}
+
+// ------------------------------------------------------------------------------------------ synthetic frames
+__device__ __forceinline__ uint64_t gr_mix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ float gr_u01(uint64_t seed, uint64_t a, uint64_t b, uint64_t c) {
+    const uint64_t h = gr_mix64(gr_mix64(gr_mix64(seed ^ (a * 0xD1342543DE82EF95ull)) ^ (b * 0xA0761D6478BD642Full)) ^ (c * 0xE7037ED1A0B428DBull));
+    return (float)(h >> 40) * (1.0f / 16777216.0f);
+}
+
+// points uniform in a ball of `radius` about the box centre (rejection from the cube, 16 tries)
+__global__ void k_synth_reference(float *xyz, uint32_t n, const GrBox *boxp, float radius, uint64_t seed) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const GrBox &b = *boxp;
+    float x = 0.f, y = 0.f, z = 0.f;
+    for (uint32_t t = 0; t < 16; ++t) {
+        x = 2.0f * gr_u01(seed, i, 3 * t, 1) - 1.0f; y = 2.0f * gr_u01(seed, i, 3 * t + 1, 1) - 1.0f; z = 2.0f * gr_u01(seed, i, 3 * t + 2, 1) - 1.0f;
+        if (x * x + y * y + z * z <= 1.0f) break;
+        if (t == 15) { x *= 0.5f; y *= 0.5f; z *= 0.5f; }
+    }
+    xyz[3 * (size_t)i] = b.bcx + radius * x; xyz[3 * (size_t)i + 1] = b.bcy + radius * y; xyz[3 * (size_t)i + 2] = b.bcz + radius * z;
+}
+
+// frame f = R_f (x0 - c) + c + t_f + noise, wrapped into the cell
+__global__ void k_synth_frames(const float *ref, float *frames, size_t frame_stride, uint32_t first_slot, uint32_t n,
+                               const GrBox *boxp, uint64_t first_frame_index, float sigma, uint64_t seed) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t f = blockIdx.y;
+    if (i >= n) return;
+    const GrBox &b = *boxp;
+    const uint64_t fi = first_frame_index + f;
+    // random unit quaternion -> rotation
+    float q0 = 2.f * gr_u01(seed, fi, 0, 2) - 1.f, q1 = 2.f * gr_u01(seed, fi, 1, 2) - 1.f, q2 = 2.f * gr_u01(seed, fi, 2, 2) - 1.f, q3 = 2.f * gr_u01(seed, fi, 3, 2) - 1.f;
+    float qn = sqrtf(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3);
+    if (qn < 1e-3f) { q0 = 1.f; q1 = q2 = q3 = 0.f; qn = 1.f; }
+    q0 /= qn; q1 /= qn; q2 /= qn; q3 /= qn;
+    const float R[3][3] = {
+        { 1 - 2 * (q2 * q2 + q3 * q3), 2 * (q1 * q2 - q0 * q3), 2 * (q1 * q3 + q0 * q2) },
+        { 2 * (q1 * q2 + q0 * q3), 1 - 2 * (q1 * q1 + q3 * q3), 2 * (q2 * q3 - q0 * q1) },
+        { 2 * (q1 * q3 - q0 * q2), 2 * (q2 * q3 + q0 * q1), 1 - 2 * (q1 * q1 + q2 * q2) } };
+    // translation anywhere in the cell (fractional)
+    const float fa = gr_u01(seed, fi, 4, 2), fb = gr_u01(seed, fi, 5, 2), fc = gr_u01(seed, fi, 6, 2);
+    const float tx = fa * b.ax + fb * b.bx + fc * b.cx, ty = fb * b.by + fc * b.cy, tz = fc * b.cz;
+    const float x0 = ref[3 * (size_t)i] - b.bcx, y0 = ref[3 * (size_t)i + 1] - b.bcy, z0 = ref[3 * (size_t)i + 2] - b.bcz;
+    // noise: sum of 4 uniforms (variance 1/3) scaled to sigma
+    float nz[3];
+    for (int a = 0; a < 3; ++a) {
+        float s = gr_u01(seed, fi, 16 + 4 * a, 3 + i) + gr_u01(seed, fi, 17 + 4 * a, 3 + i) + gr_u01(seed, fi, 18 + 4 * a, 3 + i) + gr_u01(seed, fi, 19 + 4 * a, 3 + i) - 2.0f;
+        nz[a] = s * 1.7320508f * sigma;
+    }
+    float x = R[0][0] * x0 + R[0][1] * y0 + R[0][2] * z0 + b.bcx + tx + nz[0];
+    float y = R[1][0] * x0 + R[1][1] * y0 + R[1][2] * z0 + b.bcy + ty + nz[1];
+    float z = R[2][0] * x0 + R[2][1] * y0 + R[2][2] * z0 + b.bcz + tz + nz[2];
+    gr_wrap(x, y, z, b);
+    float *o = frames + (size_t)(first_slot + f) * frame_stride + 3 * (size_t)i;
+    o[0] = x; o[1] = y; o[2] = z;
+}
+
+__global__ void k_synth_uniform(float *xyz, uint32_t n, const GrBox *boxp, uint64_t seed) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const GrBox &b = *boxp;
+    const float fa = gr_u01(seed, i, 0, 7), fb = gr_u01(seed, i, 1, 7), fc = gr_u01(seed, i, 2, 7);
+    xyz[3 * (size_t)i] = fa * b.ax + fb * b.bx + fc * b.cx; xyz[3 * (size_t)i + 1] = fb * b.by + fc * b.cy; xyz[3 * (size_t)i + 2] = fc * b.cz;
+}

@@ -1,0 +1,513 @@
+"""Host-side mirror of the groan_rs `System` surface for the per-frame geometry path.
+
+Same method names, argument meaning and error behaviour as the reference (src/system/{mod,analysis,
+rmsd,modifying,utility}.rs); every method is a thin call into libgroan_hip.so through the C ABI
+(include/groan_hip.h).  No arithmetic on atoms happens in Python.
+"""
+import ctypes as C
+from enum import IntEnum
+
+import numpy as np
+
+from . import _lib
+from ._lib import (OK, E_NO_BOX, E_NOT_ORTHOGONAL, E_ZERO_BOX, E_EMPTY_GROUP, E_INCONSISTENT_GROUP,
+                   E_NO_POSITION, E_NO_MASS, E_GROUP_NOT_FOUND, E_OUT_OF_RANGE, E_GROUP_EXISTS)
+
+
+class Dimension(IntEnum):
+    """src/structures/dimension.rs:13-23"""
+    NONE = 0
+    X = 1
+    Y = 2
+    Z = 3
+    XY = 4
+    XZ = 5
+    YZ = 6
+    XYZ = 7
+
+    def is_x(self):
+        return self in (Dimension.X, Dimension.XY, Dimension.XZ, Dimension.XYZ)
+
+    def is_y(self):
+        return self in (Dimension.Y, Dimension.XY, Dimension.YZ, Dimension.XYZ)
+
+    def is_z(self):
+        return self in (Dimension.Z, Dimension.XZ, Dimension.YZ, Dimension.XYZ)
+
+
+# ----------------------------------------------------------------------------- errors (src/errors.rs)
+class GroanError(Exception):
+    """variant = name of the reference's enum variant; detail = its payload."""
+
+    def __init__(self, variant, detail=None, status=None):
+        super().__init__("%s::%s(%r)" % (type(self).__name__, variant, detail))
+        self.variant, self.detail, self.status = variant, detail, status
+
+
+class SimBoxError(GroanError):      # errors.rs:556-566
+    pass
+
+
+class GroupError(GroanError):       # errors.rs:227-256
+    pass
+
+
+class AtomError(GroanError):        # errors.rs:290-305
+    pass
+
+
+class RMSDError(GroanError):        # errors.rs:624-650
+    pass
+
+
+class DeviceError(GroanError):
+    pass
+
+
+def _simbox(status):
+    return SimBoxError({E_NO_BOX: "DoesNotExist", E_NOT_ORTHOGONAL: "NotOrthogonal", E_ZERO_BOX: "ZeroLength"}.get(status, "Invalid"),
+                       status=status)
+
+
+def _as_box9(box):
+    if box is None:
+        return None
+    b = np.ascontiguousarray(box, dtype=np.float32).ravel()
+    if b.size == 3:
+        b = np.concatenate([b, np.zeros(6, np.float32)])
+    if b.size != 9:
+        raise ValueError("box must have 3 or 9 elements (gro order)")
+    if b[3] != 0.0 or b[4] != 0.0 or b[6] != 0.0:
+        # SimBox::from panics on these (simbox.rs:37-39)
+        raise ValueError("Unsupported Gromacs simulation box.")
+    return np.ascontiguousarray(b)
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+# ----------------------------------------------------------------------------- AtomContainer
+class AtomContainer:
+    """src/structures/container.rs -- sorted, merged, inclusive [start, end] blocks (bit-exact)."""
+
+    def __init__(self, blocks=()):
+        self.blocks = [(int(s), int(e)) for s, e in blocks]
+
+    @staticmethod
+    def _out(n):
+        return np.zeros(max(n, 1), np.uint64), np.zeros(max(n, 1), np.uint64)
+
+    @classmethod
+    def from_indices(cls, indices, n_atoms):
+        lib = _lib.load()
+        idx = np.ascontiguousarray(list(indices), dtype=np.uint64)
+        s, e = cls._out(idx.size)
+        nb = lib.gr_container_from_indices(_ptr(idx), idx.size, n_atoms, _ptr(s), _ptr(e))
+        return cls(zip(s[:nb], e[:nb]))
+
+    @classmethod
+    def from_ranges(cls, ranges, n_atoms):
+        lib = _lib.load()
+        r = np.asarray(list(ranges), dtype=np.uint64).reshape(-1, 2)
+        st, en = np.ascontiguousarray(r[:, 0]), np.ascontiguousarray(r[:, 1])
+        s, e = cls._out(r.shape[0])
+        nb = lib.gr_container_from_ranges(_ptr(st), _ptr(en), r.shape[0], n_atoms, _ptr(s), _ptr(e))
+        return cls(zip(s[:nb], e[:nb]))
+
+    def _se(self):
+        b = np.asarray(self.blocks, dtype=np.uint64).reshape(-1, 2)
+        return np.ascontiguousarray(b[:, 0]), np.ascontiguousarray(b[:, 1]), b.shape[0]
+
+    @staticmethod
+    def union(a, b):
+        lib = _lib.load()
+        s1, e1, n1 = a._se(); s2, e2, n2 = b._se()
+        s, e = AtomContainer._out(n1 + n2)
+        nb = lib.gr_container_union(_ptr(s1), _ptr(e1), n1, _ptr(s2), _ptr(e2), n2, _ptr(s), _ptr(e))
+        return AtomContainer(zip(s[:nb], e[:nb]))
+
+    @staticmethod
+    def intersection(a, b):
+        lib = _lib.load()
+        s1, e1, n1 = a._se(); s2, e2, n2 = b._se()
+        s, e = AtomContainer._out(a.get_n_atoms() + 1)
+        nb = lib.gr_container_intersection(_ptr(s1), _ptr(e1), n1, _ptr(s2), _ptr(e2), n2, _ptr(s), _ptr(e))
+        return AtomContainer(zip(s[:nb], e[:nb]))
+
+    def get_n_atoms(self):
+        s, e, n = self._se()
+        return int(_lib.load().gr_container_n_atoms(_ptr(s), _ptr(e), n))
+
+    def isin(self, index):
+        s, e, n = self._se()
+        return bool(_lib.load().gr_container_isin(_ptr(s), _ptr(e), n, index))
+
+    def is_empty(self):
+        return not self.blocks
+
+    def first(self):
+        return self.blocks[0][0] if self.blocks else None
+
+    def last(self):
+        return self.blocks[-1][1] if self.blocks else None
+
+    def __iter__(self):
+        s, e, n = self._se()
+        out = np.zeros(max(self.get_n_atoms(), 1), np.uint64)
+        m = _lib.load().gr_container_expand(_ptr(s), _ptr(e), n, _ptr(out))
+        return iter(int(v) for v in out[:m])
+
+    def __eq__(self, other):
+        return isinstance(other, AtomContainer) and self.blocks == other.blocks
+
+    def __repr__(self):
+        return "AtomContainer(%r)" % (self.blocks,)
+
+
+# ----------------------------------------------------------------------------- System
+class System:
+    """Device mirror of groan_rs `System` (src/system/mod.rs:38-73): atoms' masses, named groups,
+    `n_slots` resident frames (positions + box).  Slot 0 is "the current frame"."""
+
+    def __init__(self, n_atoms, masses=None, box=None, positions=None, device=0, n_slots=1, name="System"):
+        self._lib = _lib.load()
+        st = C.c_int(0)
+        self._ctx = self._lib.gr_ctx_create(int(device), int(n_atoms), int(n_slots), C.byref(st))
+        if not self._ctx:
+            raise DeviceError("ContextCreation", self._lib.gr_status_string(st.value).decode(), st.value)
+        self.name, self.n_atoms, self.n_slots, self.device = name, int(n_atoms), int(n_slots), int(device)
+        self.simulation_step, self.simulation_time = 0, 0.0
+        self._plans = []
+        if masses is not None:
+            self.set_masses(masses)
+        if positions is not None:
+            self.set_frame(positions, box)
+        elif box is not None:
+            self.set_box(box)
+
+    # -- lifetime
+    def close(self):
+        if getattr(self, "_ctx", None):
+            for p in self._plans:
+                p.close()
+            self._lib.gr_ctx_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- error mapping
+    def _err(self, status):
+        lib = self._lib
+        msg = lib.gr_last_error(self._ctx).decode(errors="replace")
+        return status, msg, int(lib.gr_last_error_index(self._ctx))
+
+    def _raise_group(self, status):
+        st, msg, idx = self._err(status)
+        if st == E_GROUP_NOT_FOUND: raise GroupError("NotFound", msg, st)
+        if st == E_EMPTY_GROUP: raise GroupError("EmptyGroup", msg, st)
+        if st in (E_NO_BOX, E_NOT_ORTHOGONAL, E_ZERO_BOX): raise GroupError("InvalidSimBox", _simbox(st), st)
+        if st == E_NO_POSITION: raise GroupError("InvalidPosition", idx, st)
+        if st == E_NO_MASS: raise GroupError("InvalidMass", idx, st)
+        raise DeviceError(self._lib.gr_status_string(st).decode(), msg, st)
+
+    def _raise_atom(self, status):
+        st, msg, idx = self._err(status)
+        if st in (E_NO_BOX, E_NOT_ORTHOGONAL, E_ZERO_BOX): raise AtomError("InvalidSimBox", _simbox(st), st)
+        if st == E_NO_POSITION: raise AtomError("InvalidPosition", idx, st)
+        if st == E_NO_MASS: raise AtomError("InvalidMass", idx, st)
+        if st == E_OUT_OF_RANGE: raise AtomError("OutOfRange", idx, st)
+        raise DeviceError(self._lib.gr_status_string(st).decode(), msg, st)
+
+    def _raise_rmsd(self, status):
+        st, msg, idx = self._err(status)
+        if st == E_GROUP_NOT_FOUND: raise RMSDError("NonexistentGroup", msg, st)
+        if st == E_EMPTY_GROUP: raise RMSDError("EmptyGroup", msg, st)
+        if st in (E_NO_BOX, E_NOT_ORTHOGONAL, E_ZERO_BOX): raise RMSDError("InvalidSimBox", _simbox(st), st)
+        if st == E_NO_POSITION: raise RMSDError("InvalidPosition", idx, st)
+        if st == E_NO_MASS: raise RMSDError("InvalidMass", idx, st)
+        if st == E_INCONSISTENT_GROUP:
+            cnt = (C.c_uint64 * 2)()
+            self._lib.gr_last_error_counts(self._ctx, cnt)
+            raise RMSDError("InconsistentGroup", (msg, int(cnt[0]), int(cnt[1])), st)
+        raise DeviceError(self._lib.gr_status_string(st).decode(), msg, st)
+
+    # -- static data
+    def get_n_atoms(self):
+        return self.n_atoms
+
+    def set_masses(self, masses):
+        m = np.ascontiguousarray(masses, dtype=np.float32)
+        st = self._lib.gr_set_masses(self._ctx, _ptr(m), m.size)
+        if st != OK:
+            raise DeviceError("set_masses", self._err(st)[1], st)
+
+    def set_strict_orthogonal(self, on=True):
+        """reproduce the reference's SimBoxError::NotOrthogonal for non-orthogonal boxes"""
+        self._strict_flag = bool(on)
+        self._lib.gr_ctx_set_strict_orthogonal(self._ctx, int(bool(on)))
+
+    # -- groups (src/system/groups.rs)
+    def group_create_from_ranges(self, name, ranges):
+        r = np.asarray(list(ranges), dtype=np.uint64).reshape(-1, 2)
+        s, e = np.ascontiguousarray(r[:, 0]), np.ascontiguousarray(r[:, 1])
+        st = self._lib.gr_group_create_from_ranges(self._ctx, name.encode(), _ptr(s), _ptr(e), r.shape[0])
+        if st not in (OK, E_GROUP_EXISTS):
+            self._raise_group(st)
+        return st == E_GROUP_EXISTS   # the reference returns AlreadyExistsWarning
+
+    def group_create_from_indices(self, name, indices):
+        idx = np.ascontiguousarray(list(indices), dtype=np.uint64)
+        st = self._lib.gr_group_create_from_indices(self._ctx, name.encode(), _ptr(idx), idx.size)
+        if st not in (OK, E_GROUP_EXISTS):
+            self._raise_group(st)
+        return st == E_GROUP_EXISTS
+
+    def group_create_from_container(self, name, container):
+        return self.group_create_from_ranges(name, container.blocks)
+
+    def group_remove(self, name):
+        st = self._lib.gr_group_remove(self._ctx, name.encode())
+        if st != OK:
+            self._raise_group(st)
+
+    def group_exists(self, name):
+        return bool(self._lib.gr_group_exists(self._ctx, name.encode()))
+
+    def group_get_n_atoms(self, name):
+        n = C.c_uint64(0)
+        st = self._lib.gr_group_n_atoms(self._ctx, name.encode(), C.byref(n))
+        if st != OK:
+            raise GroupError("NotFound", name, st)
+        return int(n.value)
+
+    def group_isempty(self, name):
+        return self.group_get_n_atoms(name) == 0
+
+    def group_container(self, name):
+        nb = C.c_size_t(0)
+        st = self._lib.gr_group_n_blocks(self._ctx, name.encode(), C.byref(nb))
+        if st != OK:
+            raise GroupError("NotFound", name, st)
+        s, e = np.zeros(max(nb.value, 1), np.uint64), np.zeros(max(nb.value, 1), np.uint64)
+        self._lib.gr_group_blocks(self._ctx, name.encode(), _ptr(s), _ptr(e))
+        return AtomContainer(zip(s[:nb.value], e[:nb.value]))
+
+    # -- frames
+    def set_frame(self, positions, box="keep", slot=0, step=None, time=None):
+        """TrajRead::update_system: positions float32 [n_atoms,3] as delivered by the xtc readers."""
+        x = np.ascontiguousarray(positions, dtype=np.float32)
+        if x.shape != (self.n_atoms, 3):
+            raise ValueError("positions must have shape (n_atoms, 3)")
+        if isinstance(box, str) and box == "keep":
+            b = self.get_box(slot)
+        else:
+            b = _as_box9(box)
+        st = self._lib.gr_frame_upload(self._ctx, slot, _ptr(x), _ptr(b))
+        if st != OK:
+            raise DeviceError("frame_upload", self._err(st)[1], st)
+        self._lib.gr_sync(self._ctx)   # x may be a temporary
+        if step is not None: self.simulation_step = step
+        if time is not None: self.simulation_time = time
+
+    def get_positions(self, slot=0):
+        out = np.empty((self.n_atoms, 3), np.float32)
+        st = self._lib.gr_frame_download(self._ctx, slot, _ptr(out))
+        if st != OK:
+            raise DeviceError("frame_download", self._err(st)[1], st)
+        return out
+
+    def set_box(self, box, slot=0):
+        st = self._lib.gr_frame_set_box(self._ctx, slot, _ptr(_as_box9(box)))
+        if st != OK:
+            raise DeviceError("set_box", self._err(st)[1], st)
+
+    def reset_box(self, slot=0):
+        self.set_box(None, slot)
+
+    def get_box(self, slot=0):
+        b = np.zeros(9, np.float32)
+        st = self._lib.gr_frame_get_box(self._ctx, slot, _ptr(b))
+        return b if st == OK else None
+
+    def has_box(self, slot=0):
+        return self.get_box(slot) is not None
+
+    def get_box_center(self, slot=0):
+        """src/system/mod.rs:298-308"""
+        b = self.get_box(slot)
+        if b is None:
+            raise _simbox(E_NO_BOX)
+        ortho = b[5] == 0.0 and b[7] == 0.0 and b[8] == 0.0
+        two = np.float32(2.0)
+        if ortho:
+            return np.array([b[0] / two, b[1] / two, b[2] / two], np.float32)
+        if self._strict():
+            raise _simbox(E_NOT_ORTHOGONAL)
+        return np.array([(b[0] + b[5] + b[7]) / two, (b[1] + b[8]) / two, b[2] / two], np.float32)
+
+    def _strict(self):
+        return getattr(self, "_strict_flag", False)
+
+    def copy_frame(self, dst_slot, src_slot):
+        st = self._lib.gr_frame_copy(self._ctx, dst_slot, src_slot)
+        if st != OK:
+            raise DeviceError("frame_copy", self._err(st)[1], st)
+
+    # -- centres (src/system/analysis.rs:52-320)
+    def _center(self, name, kind, weighted, slot):
+        out = np.zeros(3, np.float32)
+        st = self._lib.gr_group_center(self._ctx, slot, name.encode(), kind, int(weighted), _ptr(out))
+        if st != OK:
+            self._raise_group(st)
+        return out
+
+    def group_get_center_naive(self, name, slot=0): return self._center(name, _lib.CENTER_NAIVE, 0, slot)
+    def group_estimate_center(self, name, slot=0): return self._center(name, _lib.CENTER_ESTIMATE, 0, slot)
+    def group_get_center(self, name, slot=0): return self._center(name, _lib.CENTER_PBC, 0, slot)
+    def group_get_com_naive(self, name, slot=0): return self._center(name, _lib.CENTER_NAIVE, 1, slot)
+    def group_estimate_com(self, name, slot=0): return self._center(name, _lib.CENTER_ESTIMATE, 1, slot)
+    def group_get_com(self, name, slot=0): return self._center(name, _lib.CENTER_PBC, 1, slot)
+
+    # -- distances (analysis.rs:348-471)
+    def group_distance(self, group1, group2, dim=Dimension.XYZ, slot=0):
+        out = C.c_float(0)
+        st = self._lib.gr_group_distance(self._ctx, slot, group1.encode(), group2.encode(), int(dim), C.byref(out))
+        if st != OK:
+            self._raise_group(st)
+        return out.value
+
+    def group_all_distances(self, group1, group2, dim=Dimension.XYZ, slot=0):
+        n1, n2 = self.group_get_n_atoms(group1), self.group_get_n_atoms(group2)
+        out = np.zeros((n1, n2), np.float32)
+        st = self._lib.gr_group_all_distances(self._ctx, slot, group1.encode(), group2.encode(), int(dim), _ptr(out), out.size)
+        if st != OK:
+            self._raise_group(st)
+        return out
+
+    def atoms_distance(self, index1, index2, dim=Dimension.XYZ, slot=0):
+        out = C.c_float(0)
+        st = self._lib.gr_atoms_distance(self._ctx, slot, index1, index2, int(dim), C.byref(out))
+        if st != OK:
+            self._raise_atom(st)
+        return out.value
+
+    # -- translate / wrap / centre (modifying.rs:45-75,201-222; utility.rs:109-185)
+    def atoms_translate(self, vector, slot=0):
+        v = np.ascontiguousarray(vector, dtype=np.float32)
+        st = self._lib.gr_group_translate(self._ctx, slot, None, _ptr(v))
+        if st != OK:
+            self._raise_atom(st)
+
+    def group_translate(self, name, vector, slot=0):
+        v = np.ascontiguousarray(vector, dtype=np.float32)
+        st = self._lib.gr_group_translate(self._ctx, slot, name.encode(), _ptr(v))
+        if st != OK:
+            self._raise_group(st)
+
+    def atoms_wrap(self, slot=0):
+        st = self._lib.gr_group_wrap(self._ctx, slot, None)
+        if st != OK:
+            self._raise_atom(st)
+
+    def group_wrap(self, name, slot=0):
+        st = self._lib.gr_group_wrap(self._ctx, slot, name.encode())
+        if st != OK:
+            self._raise_group(st)
+
+    def atoms_center(self, reference, dimension=Dimension.XYZ, slot=0):
+        st = self._lib.gr_atoms_center(self._ctx, slot, reference.encode(), int(dimension), 0)
+        if st != OK:
+            self._raise_group(st)
+
+    def atoms_center_mass(self, reference, dimension=Dimension.XYZ, slot=0):
+        st = self._lib.gr_atoms_center(self._ctx, slot, reference.encode(), int(dimension), 1)
+        if st != OK:
+            self._raise_group(st)
+
+    # -- RMSD (src/system/rmsd.rs:75-166)
+    def calc_rmsd(self, reference, group, slot=0, ref_slot=0, return_rotation=False):
+        r = C.c_float(0)
+        R = np.zeros(9, np.float32)
+        st = self._lib.gr_calc_rmsd(self._ctx, slot, reference._ctx, ref_slot, group.encode(), C.byref(r), _ptr(R))
+        if st != OK:
+            self._raise_rmsd(st)
+        return (r.value, R.reshape(3, 3).T.copy()) if return_rotation else r.value
+
+    def calc_rmsd_and_fit(self, reference, group, slot=0, ref_slot=0):
+        r = C.c_float(0)
+        st = self._lib.gr_calc_rmsd_and_fit(self._ctx, slot, reference._ctx, ref_slot, group.encode(), C.byref(r))
+        if st != OK:
+            self._raise_rmsd(st)
+        return r.value
+
+    # -- measurement helpers
+    def sync(self):
+        self._lib.gr_sync(self._ctx)
+
+    def timer_start(self):
+        self._lib.gr_timer_start(self._ctx)
+
+    def timer_stop(self):
+        ms = C.c_float(0)
+        self._lib.gr_timer_stop(self._ctx, C.byref(ms))
+        return ms.value
+
+    def synth_reference(self, slot, box, radius, seed):
+        st = self._lib.gr_synth_reference(self._ctx, slot, _ptr(_as_box9(box)), C.c_float(radius), seed)
+        if st != OK:
+            raise DeviceError("synth_reference", self._err(st)[1], st)
+
+    def synth_frames(self, ref_slot, first_slot, n_frames, first_frame_index, noise_sigma, seed):
+        st = self._lib.gr_synth_frames(self._ctx, ref_slot, first_slot, n_frames, first_frame_index, C.c_float(noise_sigma), seed)
+        if st != OK:
+            raise DeviceError("synth_frames", self._err(st)[1], st)
+
+    def synth_uniform(self, slot, box, seed):
+        st = self._lib.gr_synth_uniform(self._ctx, slot, _ptr(_as_box9(box)), seed)
+        if st != OK:
+            raise DeviceError("synth_uniform", self._err(st)[1], st)
+
+
+class RMSDPlan:
+    """Cached reference side of the RMSD calculation = RMSDConverterAnalyzer::new (rmsd.rs:186-203)."""
+
+    def __init__(self, reference, target, group, ref_slot=0):
+        self._lib = _lib.load()
+        st = C.c_int(0)
+        self.target, self.group = target, group
+        self._plan = self._lib.gr_rmsd_plan_create(reference._ctx, ref_slot, target._ctx, group.encode(), C.byref(st))
+        if not self._plan:
+            reference._raise_rmsd(st.value)
+        target._plans.append(self)
+
+    def close(self):
+        if getattr(self, "_plan", None):
+            self._lib.gr_rmsd_plan_destroy(self._plan)
+            self._plan = None
+
+    def force_exact(self, on=True):
+        self._lib.gr_rmsd_plan_force_exact(self._plan, int(bool(on)))
+
+    def last_fallbacks(self):
+        return int(self._lib.gr_rmsd_plan_last_fallbacks(self._plan))
+
+    def rmsd(self, first_slot=0, n_frames=1, return_rotation=False, raise_on_error=True):
+        r = np.zeros(n_frames, np.float32); s = np.zeros(n_frames, np.int32); R = np.zeros((n_frames, 9), np.float32)
+        st = self._lib.gr_rmsd_batch(self._plan, first_slot, n_frames, _ptr(r), _ptr(s), _ptr(R))
+        if st != OK and raise_on_error:
+            self.target._raise_rmsd(st)
+        if return_rotation:
+            return r, s, R.reshape(n_frames, 3, 3).transpose(0, 2, 1).copy()
+        return r, s
+
+    def rmsd_fit(self, first_slot=0, n_frames=1, raise_on_error=True):
+        r = np.zeros(n_frames, np.float32); s = np.zeros(n_frames, np.int32)
+        st = self._lib.gr_rmsd_fit_batch(self._plan, first_slot, n_frames, _ptr(r), _ptr(s))
+        if st != OK and raise_on_error:
+            self.target._raise_rmsd(st)
+        return r, s

@@ -1,0 +1,202 @@
+/*
+ * groan_hip.h -- C ABI of libgroan_hip.so: the MI355X (gfx950) per-frame geometry engine that
+ * replaces groan_rs's CPU hot path (PBC distances, centres of geometry/mass, Kabsch RMSD / RMSD-fit,
+ * translate / wrap / centre).  Plain pointers and sizes only; no C++ or torch types.
+ *
+ * Each entry point names the reference interface it replaces (file:line relative to the groan_rs
+ * v0.11.3 root).  INTEGRATION.md shows the Rust `extern "C"` block + safe wrappers that bind these,
+ * in the style of the reference's existing xdrfile FFI (src/io/xdrfile.rs:27-120).
+ *
+ * Model
+ *   gr_ctx   device mirror of one `System` (src/system/mod.rs:38-73): n_atoms, masses, named groups
+ *            (AtomContainer block lists), and `n_slots` resident frames (positions float[n][3] + box).
+ *            Not re-entrant; distinct contexts are independent (one per worker / per GPU), like the
+ *            per-thread System clones of traj_iter_map_reduce (src/system/parallel.rs:236).
+ *   slot     one frame resident in HBM.  A trajectory reader uploads decoded frames into slots
+ *            (gr_frame_upload takes the rvec[n] + box exactly as xdrfile/molly deliver them,
+ *            src/io/xdrfile.rs:28-36, src/io/xtc_io/molly_xtc.rs:294-307).
+ *   plan     cached reference-side RMSD data = RMSDConverterAnalyzer (src/system/rmsd.rs:170-203).
+ *
+ * Conventions
+ *   box9     gro order v1x v2y v3z v1y v1z v2x v2z v3x v3y (src/structures/simbox.rs:13-26); NULL = no box
+ *   Option   a missing position / mass (Rust None) is NaN in x / in the mass
+ *   matrices rotation matrices are column-major (nalgebra storage)
+ *   status   every call returns an int: 0 = OK (xdrfile convention, src/io/xtc_io/xdrfile_xtc.rs:63-83)
+ *   Non-orthogonal boxes: the reference rejects them (SimBoxError::NotOrthogonal,
+ *   src/structures/simbox.rs:230-236).  By default this library computes with the triclinic extension
+ *   described in DESIGN.md; gr_ctx_set_strict_orthogonal(ctx,1) restores the reference's error.
+ */
+#ifndef GROAN_HIP_H
+#define GROAN_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gr_ctx gr_ctx;
+typedef struct gr_rmsd_plan gr_rmsd_plan;
+
+/* status codes; 1..7 map onto the reference's error enums (src/errors.rs) */
+enum {
+    GR_OK = 0,
+    GR_E_NO_BOX = 1,             /* SimBoxError::DoesNotExist            errors.rs:556-566 */
+    GR_E_NOT_ORTHOGONAL = 2,     /* SimBoxError::NotOrthogonal (strict mode only)           */
+    GR_E_ZERO_BOX = 3,           /* reference panics: vector3d.rs:402-404,576-578           */
+    GR_E_EMPTY_GROUP = 4,        /* GroupError::EmptyGroup / RMSDError::EmptyGroup          */
+    GR_E_INCONSISTENT_GROUP = 5, /* RMSDError::InconsistentGroup(name, n_ref, n_cur)        */
+    GR_E_NO_POSITION = 6,        /* PositionError::NoPosition(index)     errors.rs:570-574 */
+    GR_E_NO_MASS = 7,            /* MassError::NoMass(index)             errors.rs:578-582 */
+    GR_E_GROUP_NOT_FOUND = 8,    /* GroupError::NotFound / RMSDError::NonexistentGroup      */
+    GR_E_OUT_OF_RANGE = 9,       /* AtomError::OutOfRange(index)         errors.rs:290-305 */
+    GR_E_INVALID_ARG = 10,       /* bad slot / NULL pointer / size mismatch (caller bug)    */
+    GR_E_GROUP_EXISTS = 11,      /* GroupError::AlreadyExistsWarning                        */
+    GR_E_HIP = 12,               /* HIP runtime failure: see gr_last_error                  */
+    GR_E_NO_DEVICE = 13,         /* no usable gfx950 device: the library has NO CPU fallback */
+    GR_E_UNSUPPORTED_BOX = 14    /* box too skewed for the minimum-image candidate table    */
+};
+
+/* Dimension (src/structures/dimension.rs:13-23) */
+enum { GR_DIM_NONE = 0, GR_DIM_X, GR_DIM_Y, GR_DIM_Z, GR_DIM_XY, GR_DIM_XZ, GR_DIM_YZ, GR_DIM_XYZ };
+
+/* centre kinds: group_get_center_naive / group_estimate_center / group_get_center and the _com
+ * variants (src/system/analysis.rs:52-320) */
+enum { GR_CENTER_NAIVE = 0, GR_CENTER_ESTIMATE = 1, GR_CENTER_PBC = 2 };
+
+/* ---------------------------------------------------------------- library / context */
+const char *gr_version(void);
+const char *gr_status_string(int status);
+int gr_device_count(int *count);
+
+/* System::new / System::clone per worker.  device = HIP ordinal.  n_slots resident frames. */
+gr_ctx *gr_ctx_create(int device, uint64_t n_atoms, uint32_t n_slots, int *status);
+void gr_ctx_destroy(gr_ctx *ctx);
+const char *gr_last_error(const gr_ctx *ctx);
+/* detail of the last GR_E_NO_POSITION / GR_E_NO_MASS / GR_E_OUT_OF_RANGE (atom index) and of
+ * GR_E_INCONSISTENT_GROUP (n_ref, n_cur): what the reference carries inside its error variants */
+uint64_t gr_last_error_index(const gr_ctx *ctx);
+void gr_last_error_counts(const gr_ctx *ctx, uint64_t counts[2]);
+int gr_ctx_set_strict_orthogonal(gr_ctx *ctx, int on);
+uint64_t gr_n_atoms(const gr_ctx *ctx);
+uint32_t gr_n_slots(const gr_ctx *ctx);
+int gr_sync(gr_ctx *ctx);
+
+/* Atom::set_mass for all atoms (src/structures/atom.rs).  masses[n_atoms], NaN = no mass. */
+int gr_set_masses(gr_ctx *ctx, const float *masses, uint64_t n);
+
+/* ---------------------------------------------------------------- AtomContainer (host, bit-exact)
+ * Pure functions mirroring src/structures/container.rs; blocks are inclusive [start,end].
+ * Each returns the number of blocks written (capacity needed: the number of inputs). */
+size_t gr_container_from_indices(const uint64_t *indices, size_t n, uint64_t n_atoms,
+                                 uint64_t *out_start, uint64_t *out_end);          /* container.rs:51-104  */
+size_t gr_container_from_ranges(const uint64_t *start, const uint64_t *end, size_t n, uint64_t n_atoms,
+                                uint64_t *out_start, uint64_t *out_end);           /* container.rs:122-215 */
+size_t gr_container_union(const uint64_t *s1, const uint64_t *e1, size_t n1,
+                          const uint64_t *s2, const uint64_t *e2, size_t n2,
+                          uint64_t *out_start, uint64_t *out_end);                 /* container.rs:268-276 */
+size_t gr_container_intersection(const uint64_t *s1, const uint64_t *e1, size_t n1,
+                                 const uint64_t *s2, const uint64_t *e2, size_t n2,
+                                 uint64_t *out_start, uint64_t *out_end);          /* container.rs:278-291 */
+uint64_t gr_container_n_atoms(const uint64_t *s, const uint64_t *e, size_t n);     /* container.rs:161-165 */
+size_t gr_container_expand(const uint64_t *s, const uint64_t *e, size_t n, uint64_t *out); /* :381-411 */
+int gr_container_isin(const uint64_t *s, const uint64_t *e, size_t n, uint64_t index);     /* :241-258 */
+
+/* ---------------------------------------------------------------- groups (src/system/groups.rs)
+ * System::group_create_from_ranges / _from_indices.  "all" exists from creation (System::new).
+ * Creating an existing name overwrites it and returns GR_E_GROUP_EXISTS (the reference's warning). */
+int gr_group_create_from_ranges(gr_ctx *ctx, const char *name, const uint64_t *start,
+                                const uint64_t *end_inclusive, size_t n_ranges);
+int gr_group_create_from_indices(gr_ctx *ctx, const char *name, const uint64_t *indices, size_t n);
+int gr_group_remove(gr_ctx *ctx, const char *name);
+int gr_group_exists(const gr_ctx *ctx, const char *name);
+int gr_group_n_atoms(const gr_ctx *ctx, const char *name, uint64_t *n);            /* group_get_n_atoms */
+int gr_group_n_blocks(const gr_ctx *ctx, const char *name, size_t *n_blocks);
+int gr_group_blocks(const gr_ctx *ctx, const char *name, uint64_t *out_start, uint64_t *out_end);
+
+/* ---------------------------------------------------------------- frames
+ * TrajRead::update_system (src/io/traj_read.rs:160-186; molly_xtc.rs:294-307; xdrfile_xtc.rs:88-104):
+ * positions as the xtc readers deliver them (rvec[n_atoms], 12-byte records) + box. Asynchronous on
+ * the context's stream when xyz is pinned host memory (gr_host_alloc); ordered with later calls. */
+int gr_frame_upload(gr_ctx *ctx, uint32_t slot, const float *xyz, const float *box9);
+int gr_frame_download(gr_ctx *ctx, uint32_t slot, float *xyz);        /* blocking */
+int gr_frame_set_box(gr_ctx *ctx, uint32_t slot, const float *box9); /* System::set_box / reset_box (NULL) */
+int gr_frame_get_box(const gr_ctx *ctx, uint32_t slot, float box9[9]); /* GR_E_NO_BOX if none */
+int gr_frame_copy(gr_ctx *ctx, uint32_t dst_slot, uint32_t src_slot);
+/* pinned host staging buffers for the decode -> H2D double buffer */
+void *gr_host_alloc(size_t bytes);
+void gr_host_free(void *p);
+
+/* ---------------------------------------------------------------- centres
+ * System::group_get_center_naive / group_estimate_center / group_get_center (weighted = 0) and
+ * group_get_com_naive / group_estimate_com / group_get_com (weighted = 1): analysis.rs:52-320 over
+ * iterators.rs:886-967,1152-1191,1237-1266,1314-1357,1404-1438.
+ * Check order as in the reference: group exists -> non-empty -> box -> positions/masses. */
+int gr_group_center(gr_ctx *ctx, uint32_t slot, const char *group, int kind, int weighted, float out[3]);
+
+/* ---------------------------------------------------------------- distances
+ * System::group_distance analysis.rs:348-360; atoms_distance :459-471; group_all_distances :401-427
+ * (row-major n1 x n2, signed for 1-D dims).  out_host may be pinned or pageable. */
+int gr_group_distance(gr_ctx *ctx, uint32_t slot, const char *group1, const char *group2, int dim, float *out);
+int gr_atoms_distance(gr_ctx *ctx, uint32_t slot, uint64_t index1, uint64_t index2, int dim, float *out);
+int gr_group_all_distances(gr_ctx *ctx, uint32_t slot, const char *group1, const char *group2, int dim,
+                           float *out_host, size_t out_capacity_floats);
+/* same, result left in HBM (freed by the context; valid until the next call of this function);
+ * *out_dev receives the device pointer, for consumers that keep working on the GPU */
+int gr_group_all_distances_device(gr_ctx *ctx, uint32_t slot, const char *group1, const char *group2, int dim,
+                                  float **out_dev, uint64_t *n1, uint64_t *n2);
+
+/* ---------------------------------------------------------------- translate / wrap / centre
+ * System::atoms_translate / group_translate (modifying.rs:45-75), atoms_wrap / group_wrap (:201-222),
+ * atoms_center / atoms_center_mass (utility.rs:109-185).  group == NULL means all atoms. */
+int gr_group_translate(gr_ctx *ctx, uint32_t slot, const char *group, const float v[3]);
+int gr_group_wrap(gr_ctx *ctx, uint32_t slot, const char *group);
+int gr_atoms_center(gr_ctx *ctx, uint32_t slot, const char *reference_group, int dim, int weighted);
+
+/* ---------------------------------------------------------------- RMSD / RMSD-fit
+ * gr_calc_rmsd / gr_calc_rmsd_and_fit = System::calc_rmsd / calc_rmsd_and_fit (rmsd.rs:75-166):
+ * reference and current frame are two (context, slot) pairs on the same device (they may be the same
+ * context); the group must exist in both; weights are the REFERENCE's masses (rmsd.rs:154-155).
+ * R (optional, may be NULL) = optimal rotation, column-major. */
+int gr_calc_rmsd(gr_ctx *ctx, uint32_t slot, gr_ctx *reference, uint32_t ref_slot, const char *group,
+                 float *rmsd, float *R_colmajor9);
+int gr_calc_rmsd_and_fit(gr_ctx *ctx, uint32_t slot, gr_ctx *reference, uint32_t ref_slot,
+                         const char *group, float *rmsd);
+
+/* RMSDConverterAnalyzer::new (rmsd.rs:186-203): extract + cache the reference side once. */
+gr_rmsd_plan *gr_rmsd_plan_create(gr_ctx *reference, uint32_t ref_slot, gr_ctx *target,
+                                  const char *group, int *status);
+void gr_rmsd_plan_destroy(gr_rmsd_plan *plan);
+/* FrameAnalyze::analyze (rmsd.rs:228-236) on `n_frames` consecutive slots in one batch.
+ * rmsd_out[n_frames]; status_out[n_frames] per-frame status (may be NULL); R_out optional [n][9].
+ * Returns the first non-OK per-frame status (error detail = that frame), else GR_OK. */
+int gr_rmsd_batch(gr_rmsd_plan *plan, uint32_t first_slot, uint32_t n_frames,
+                  float *rmsd_out, int *status_out, float *R_out);
+/* FrameConvertAnalyze::convert_analyze (rmsd.rs:238-251): RMSD + in-place fit of ALL atoms of each
+ * frame; a frame whose analysis fails is left unmodified (rmsd.rs:91). */
+int gr_rmsd_fit_batch(gr_rmsd_plan *plan, uint32_t first_slot, uint32_t n_frames,
+                      float *rmsd_out, int *status_out);
+/* number of frames of the last batch that left the single-pass path for the multi-pass exact path */
+uint32_t gr_rmsd_plan_last_fallbacks(const gr_rmsd_plan *plan);
+/* force the multi-pass exact path (parity testing of both paths) */
+int gr_rmsd_plan_force_exact(gr_rmsd_plan *plan, int on);
+
+/* ---------------------------------------------------------------- measurement / synthetic data
+ * HIP-event timing on the context's stream (the stream the kernels are launched on). */
+int gr_timer_start(gr_ctx *ctx);
+int gr_timer_stop(gr_ctx *ctx, float *milliseconds);
+/* Seeded synthetic workload of SURVEY.md section 8(d), generated directly in HBM:
+ *  gr_synth_reference: n_atoms points uniform in a ball of `radius` about the box centre -> slot
+ *  gr_synth_frames   : frame f = R_f (x0 - c) + c + t_f + noise, wrapped into the cell, for
+ *                      n_frames consecutive slots; R_f, t_f, noise from a counter-based hash of
+ *                      (seed, first_frame_index + f, atom).  The box of every slot is set to box9.
+ *  gr_synth_uniform  : n_atoms points uniform in the unit cell (config 3). */
+int gr_synth_reference(gr_ctx *ctx, uint32_t slot, const float *box9, float radius, uint64_t seed);
+int gr_synth_frames(gr_ctx *ctx, uint32_t ref_slot, uint32_t first_slot, uint32_t n_frames,
+                    uint64_t first_frame_index, float noise_sigma, uint64_t seed);
+int gr_synth_uniform(gr_ctx *ctx, uint32_t slot, const float *box9, uint64_t seed);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GROAN_HIP_H */

@@ -1,0 +1,397 @@
+"""GPU parity: the HIP path (through the C ABI, via the groan_rs_amd host mirror) against the CPU oracle
+on the same inputs, against the committed golden fixtures, and -- at full size -- through
+size-independent properties.  Tolerances: selection indices / counts bit-exact; centres, distances,
+RMSD and fitted coordinates within 1e-5 nm (BASELINE.json north_star).
+"""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from conftest import assert_approx
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5  # nm
+
+
+@pytest.fixture(scope="module")
+def G():
+    import groan_rs_amd as g
+    g._lib.load()
+    return g
+
+
+def blocks_list(b):
+    return [(int(s), int(e)) for s, e in np.asarray(b).tolist()]
+
+
+@pytest.fixture(scope="module")
+def ex_system(G, example):
+    n = example["pos"].shape[0]
+    m = np.full(n, np.nan, np.float32)
+    m[:61] = example["protein_masses"]
+    s = G.System(n, masses=m, box=example["box9"], positions=example["pos"])
+    for name in ("Protein", "Membrane", "W", "ION", "Backbone"):
+        s.group_create_from_ranges(name, blocks_list(example["blocks_" + name]))
+    yield s
+    s.close()
+
+
+def fresh_example(G, example, n_slots=1):
+    n = example["pos"].shape[0]
+    m = np.full(n, np.nan, np.float32)
+    m[:61] = example["protein_masses"]
+    s = G.System(n, masses=m, box=example["box9"], positions=example["pos"], n_slots=n_slots)
+    for name in ("Protein", "Membrane"):
+        s.group_create_from_ranges(name, blocks_list(example["blocks_" + name]))
+    return s
+
+
+# ----------------------------------------------------------------------------- selections (bit-exact)
+def test_groups_bit_exact(G, ex_system, example):
+    for name in ("Protein", "Membrane", "W", "ION", "Backbone"):
+        want = O.container_from_ranges(example["blocks_" + name], 16844)
+        got = ex_system.group_container(name)
+        assert got.blocks == blocks_list(want)
+        assert ex_system.group_get_n_atoms(name) == int(O.container_expand(want).size)
+        assert list(got) == O.container_expand(want).tolist()
+    cx = [11, 1, 2, 3, 20, 5, 0, 5, 4, 18, 6, 19, 1, 13, 20, 27]
+    assert G.AtomContainer.from_indices(cx, 20).blocks == blocks_list(O.container_from_indices(cx, 20))
+    rng = np.random.default_rng(1)
+    for _ in range(50):
+        n_atoms = int(rng.integers(1, 200))
+        idx = rng.integers(0, n_atoms + 20, size=int(rng.integers(0, 60))).tolist()
+        assert G.AtomContainer.from_indices(idx, n_atoms).blocks == blocks_list(O.container_from_indices(idx, n_atoms))
+        r = [(int(a), int(b)) for a, b in rng.integers(0, n_atoms + 20, size=(int(rng.integers(0, 20)), 2))]
+        c1, o1 = G.AtomContainer.from_ranges(r, n_atoms), O.container_from_ranges(r, n_atoms) if r else np.zeros((0, 2))
+        assert c1.blocks == blocks_list(o1)
+        c2, o2 = G.AtomContainer.from_indices(idx, n_atoms), O.container_from_indices(idx, n_atoms)
+        assert G.AtomContainer.union(c1, c2).blocks == blocks_list(O.container_union(o1, o2))
+        assert G.AtomContainer.intersection(c1, c2).blocks == blocks_list(O.container_intersection(o1, o2))
+
+
+# ----------------------------------------------------------------------------- centres
+@pytest.mark.parametrize("group", ["Protein", "Membrane", "W"])
+def test_centers_vs_oracle(ex_system, example, group):
+    pos, box = example["pos"], example["box9"]
+    idx = O.container_expand(example["blocks_" + group])
+    np.testing.assert_allclose(ex_system.group_get_center_naive(group), O.center_naive(pos, idx), atol=TOL, rtol=0)
+    np.testing.assert_allclose(ex_system.group_estimate_center(group), O.estimate_center(pos, idx, box), atol=TOL, rtol=0)
+    np.testing.assert_allclose(ex_system.group_get_center(group), O.get_center(pos, idx, box), atol=TOL, rtol=0)
+
+
+def test_coms_vs_oracle_and_goldens(G, ex_system, example, aa):
+    pos, box = example["pos"], example["box9"]
+    m = np.full(pos.shape[0], np.nan, np.float32); m[:61] = example["protein_masses"]
+    idx = np.arange(61)
+    c = ex_system.group_get_com_naive("Protein")
+    np.testing.assert_allclose(c, O.center_naive(pos, idx, mass=m), atol=TOL, rtol=0)
+    assert_approx(c[0], 9.85456, 1e-4); assert_approx(c[1], 2.44974, 1e-4); assert_approx(c[2], 5.51983, 1e-4)  # analysis.rs:1197-1199
+    np.testing.assert_allclose(ex_system.group_estimate_com("Protein"), O.estimate_center(pos, idx, box, mass=m), atol=TOL, rtol=0)
+    np.testing.assert_allclose(ex_system.group_get_com("Protein"), O.get_center(pos, idx, box, mass=m), atol=TOL, rtol=0)
+    # aa system, element masses: pinned estimate_com values analysis.rs:1016-1029
+    s = G.System(aa["pos"].shape[0], masses=aa["masses"], box=aa["box9"], positions=aa["pos"])
+    s.group_create_from_ranges("Peptide", blocks_list(aa["blocks_peptide"]))
+    s.group_create_from_ranges("Membrane", blocks_list(aa["blocks_membrane"]))
+    c = s.group_estimate_com("Peptide")
+    assert_approx(c[0], 4.047723, 1e-4); assert_approx(c[1], 3.764632, 1e-4); assert_approx(c[2], 3.2633042, 1e-4)
+    c = s.group_estimate_com("Membrane")
+    assert_approx(c[0], 1.44719, 1e-4); assert_approx(c[1], 0.45375, 1e-4); assert_approx(c[2], 3.74161, 1e-4)
+    for name, key in (("Peptide", "blocks_peptide"), ("Membrane", "blocks_membrane")):
+        idx = O.container_expand(aa[key])
+        np.testing.assert_allclose(s.group_get_com(name), O.get_center(aa["pos"], idx, aa["box9"], mass=aa["masses"]), atol=TOL, rtol=0)
+        np.testing.assert_allclose(s.group_estimate_com(name), O.estimate_center(aa["pos"], idx, aa["box9"], mass=aa["masses"]), atol=TOL, rtol=0)
+    s.close()
+
+
+def test_center_small_goldens(G):
+    # analysis.rs:488-629, 813-989
+    pts = np.array([[3.3, 10.3, 2.5], [4.3, 1.2, -0.2], [13.2, 15.6, 0.5], [10.2, -1.0, 6.6], [-1.3, 5.0, 2.4]], np.float32)
+    s = G.System(5, masses=[10.3, 5.4, 3.8, 10.1, 7.6], box=[10.0, 10.0, 10.0], positions=pts)
+    c = s.group_estimate_center("all")
+    assert_approx(c[0], 2.634386, 1e-4); assert_approx(c[1], 9.775156, 1e-4); assert_approx(c[2], 1.1748, 1e-4)
+    c = s.group_estimate_com("all")
+    assert_approx(c[0], 1.9526, 1e-4); assert_approx(c[1], 9.7567, 1e-4); assert_approx(c[2], 1.8812, 1e-4)
+    s.close()
+    s = G.System(2, masses=[12.8, 0.4], box=[10.0, 10.0, 10.0], positions=np.array([[4.5, 3.2, 1.7], [9.8, 9.5, 3.0]], np.float32))
+    c = s.group_get_com("all")
+    assert_approx(c[0], 4.35757, 1e-4); assert_approx(c[1], 3.08788, 1e-4); assert_approx(c[2], 1.7393947, 1e-4)
+    c = s.group_get_center("all")
+    assert_approx(c[0], 2.15, 1e-5); assert_approx(c[1], 1.35, 1e-5); assert_approx(c[2], 2.35, 1e-5)
+    s.close()
+
+
+def test_center_errors_in_reference_order(G, example):
+    s = fresh_example(G, example)
+    with pytest.raises(G.GroupError) as e:
+        s.group_get_center("Nonexistent")
+    assert e.value.variant == "NotFound"
+    s.group_create_from_indices("Empty", [])
+    for fn in (s.group_get_center, s.group_estimate_center, s.group_get_center_naive, s.group_get_com):
+        with pytest.raises(G.GroupError) as e:
+            fn("Empty")
+        assert e.value.variant == "EmptyGroup"
+    pos = example["pos"].copy(); pos[15, 0] = np.nan   # reset_position
+    s.set_frame(pos)
+    for fn in (s.group_get_center, s.group_estimate_center, s.group_get_center_naive):
+        with pytest.raises(G.GroupError) as e:
+            fn("Protein")
+        assert e.value.variant == "InvalidPosition" and e.value.detail == 15
+    with pytest.raises(G.GroupError) as e:
+        s.group_get_com("Membrane")     # membrane atoms have no mass in this fixture
+    assert e.value.variant == "InvalidMass" and e.value.detail == int(example["blocks_Membrane"][0][0])
+    s.reset_box()
+    for fn in (s.group_get_center, s.group_estimate_center):
+        with pytest.raises(G.GroupError) as e:
+            fn("Protein")
+        assert e.value.variant == "InvalidSimBox" and e.value.detail.variant == "DoesNotExist"
+    # naive centre needs no box, but still reports the missing position
+    with pytest.raises(G.GroupError) as e:
+        s.group_get_center_naive("Protein")
+    assert e.value.detail == 15
+    s.close()
+
+
+# ----------------------------------------------------------------------------- distances
+@pytest.mark.parametrize("dim,exp", [("X", 6.3029766), ("Y", -5.566175), ("Z", -0.32046986), ("XY", 8.408913),
+                                     ("XZ", 6.311118), ("YZ", 5.5753927), ("XYZ", 8.415017), ("NONE", 0.0)])
+def test_group_distance(G, ex_system, example, dim, exp):
+    d = ex_system.group_distance("Protein", "Membrane", G.Dimension[dim])
+    assert_approx(d, exp, 1e-4)      # analysis.rs:1268-1354
+    pos, box = example["pos"], example["box9"]
+    c1 = O.get_center(pos, np.arange(61), box); c2 = O.get_center(pos, O.container_expand(example["blocks_Membrane"]), box)
+    assert abs(d - O.distance(c1, c2, dim.lower(), box)) <= TOL
+
+
+@pytest.mark.parametrize("g1,g2,dim", [("Protein", "Protein", "XYZ"), ("Protein", "Protein", "Z"), ("Membrane", "Protein", "XY"),
+                                       ("Protein", "Membrane", "X"), ("Backbone", "ION", "YZ")])
+def test_group_all_distances(G, ex_system, example, g1, g2, dim):
+    pos, box = example["pos"], example["box9"]
+    i1, i2 = O.container_expand(example["blocks_" + g1]), O.container_expand(example["blocks_" + g2])
+    got = ex_system.group_all_distances(g1, g2, G.Dimension[dim])
+    want = O.group_all_distances(pos, i1, i2, dim.lower(), box)
+    assert got.shape == want.shape
+    np.testing.assert_allclose(got, want, atol=2e-6, rtol=0)
+    if (g1, g2, dim) == ("Protein", "Protein", "XYZ"):   # analysis.rs:1420-1451
+        assert_approx(got.max(), 4.597961); assert_approx(got[0, 1], 0.31040135); assert_approx(got[60, 0], 4.266728)
+        assert np.all(np.diag(got) == 0.0)
+    if (g1, g2, dim) == ("Membrane", "Protein", "XY"):   # analysis.rs:1488-1530
+        assert_approx(got.max(), 9.190487, 1e-5); assert_approx(got.min(), 0.02607, 1e-5)
+        assert_approx(got[1240, 12], 3.7207017); assert_approx(got[6143, 60], 4.7850933)
+
+
+def test_atoms_distance(G, ex_system):
+    n = ex_system.n_atoms
+    assert_approx(ex_system.atoms_distance(0, 1), 0.31040135)            # analysis.rs:1595-1619
+    assert_approx(ex_system.atoms_distance(n - 1, 0), 6.664787)
+    assert_approx(ex_system.atoms_distance(n - 1, n - 2), 4.062491)
+    with pytest.raises(G.AtomError) as e:
+        ex_system.atoms_distance(12, 16844, G.Dimension.XY)
+    assert e.value.variant == "OutOfRange" and e.value.detail == 16844
+    with pytest.raises(G.AtomError) as e:
+        ex_system.atoms_distance(197392, 12, G.Dimension.YZ)
+    assert e.value.detail == 197392
+
+
+def test_all_distances_errors(G, example):
+    s = fresh_example(G, example)
+    with pytest.raises(G.GroupError) as e:
+        s.group_all_distances("Nonexistent", "Protein")
+    assert e.value.variant == "NotFound"
+    pos = example["pos"].copy(); pos[15, 0] = np.nan
+    s.set_frame(pos)
+    with pytest.raises(G.GroupError) as e:
+        s.group_all_distances("Membrane", "Protein")
+    assert e.value.variant == "InvalidPosition" and e.value.detail == 15   # analysis.rs:1578-1593
+    s.reset_box()
+    with pytest.raises(G.GroupError) as e:
+        s.group_all_distances("Membrane", "Protein")
+    assert e.value.variant == "InvalidSimBox"
+    s.close()
+
+
+# ----------------------------------------------------------------------------- translate / wrap / centre
+def test_translate_wrap_center(G, example, aa):
+    pos, box = example["pos"], example["box9"]
+    s = fresh_example(G, example)
+    s.atoms_translate([3.5, -1.1, 5.4])
+    got = s.get_positions()
+    np.testing.assert_allclose(got, O.translate(pos, np.arange(pos.shape[0]), [3.5, -1.1, 5.4], box), atol=TOL, rtol=0)
+    assert_approx(got[0, 0], 12.997); assert_approx(got[0, 1], 0.889); assert_approx(got[0, 2], 1.64453)   # modifying.rs:504-524
+    s.set_frame(pos)
+    s.group_translate("Membrane", [-7.0, 20.0, 0.3])
+    mem = O.container_expand(example["blocks_Membrane"])
+    np.testing.assert_allclose(s.get_positions(), O.translate(pos, mem, [-7.0, 20.0, 0.3], box), atol=TOL, rtol=0)
+    moved = pos.copy()
+    moved[[154, 1754, 12345, 4, 37, 0]] += np.array([box[0] * 3, -box[1], 0.0], np.float32)
+    moved[[13, 65, 9853, 16843, 7832, 489]] += np.array([0.0, box[1], -box[2] * 2], np.float32)
+    s.set_frame(moved)
+    s.atoms_wrap()
+    assert np.abs(s.get_positions() - pos).max() <= 1e-5            # modifying.rs:688-735
+    for dim in ("NONE", "X", "Y", "Z", "XY", "XZ", "YZ", "XYZ"):
+        s.set_frame(pos)
+        s.atoms_center("Protein", G.Dimension[dim])
+        np.testing.assert_allclose(s.get_positions(), O.atoms_center(pos, np.arange(61), dim.lower(), box), atol=TOL, rtol=0)
+    got = s.get_positions()
+    assert_approx(got[0, 0], 6.1465545, 1e-5); assert_approx(got[0, 1], 6.033055, 1e-5); assert_approx(got[0, 2], 7.6634398, 1e-5)  # utility.rs:497-522
+    s.close()
+    s = G.System(aa["pos"].shape[0], masses=aa["masses"], box=aa["box9"], positions=aa["pos"])
+    s.group_create_from_ranges("Protein", blocks_list(aa["blocks_peptide"]))
+    s.atoms_center_mass("Protein", G.Dimension.XYZ)
+    got = s.get_positions()
+    np.testing.assert_allclose(got, O.atoms_center(aa["pos"], np.arange(363), "xyz", aa["box9"], mass=aa["masses"]), atol=TOL, rtol=0)
+    assert_approx(got[0, 0], 3.456437, 1e-5); assert_approx(got[0, 1], 3.475028, 1e-5); assert_approx(got[0, 2], 5.4376106, 1e-5)  # utility.rs:735-760
+    s.close()
+
+
+# ----------------------------------------------------------------------------- RMSD
+RMSD_EXPECTED = [0.23669721, 0.2634763, 0.26021627, 0.21364464, 0.22166993, 0.19383307, 0.26422343,
+                 0.27013618, 0.26398134, 0.23475659, 0.24208021]    # rmsd.rs:811-814
+
+
+def short_systems(G, example, short_traj, n_slots=12):
+    keep = short_traj["keep"].astype(np.int64)
+    m = np.full(keep.size, np.nan, np.float32); m[:61] = example["protein_masses"]
+    ref = G.System(keep.size, masses=m, box=example["box9"], positions=short_traj["gro_keep"])
+    cur = G.System(keep.size, masses=m, n_slots=n_slots)
+    for s in (ref, cur):
+        s.group_create_from_ranges("Protein", [(0, 60)])
+    return ref, cur, m
+
+
+@pytest.mark.parametrize("exact", [False, True])
+def test_rmsd_trajectory_goldens(G, example, short_traj, exact):
+    ref, cur, m = short_systems(G, example, short_traj)
+    sel = np.arange(61)
+    for f in range(11):
+        cur.set_frame(short_traj["frames"][f], short_traj["boxes9"][f], slot=f)
+    plan = G.RMSDPlan(ref, cur, "Protein")
+    plan.force_exact(exact)
+    r, st, R = plan.rmsd(0, 11, return_rotation=True)
+    assert np.all(st == 0)
+    if not exact:
+        assert plan.last_fallbacks() == 0
+    for f in range(11):
+        assert abs(r[f] - RMSD_EXPECTED[f]) <= 5e-7, (f, r[f])     # reference's own pinned values
+        ro, Ro = O.calc_rmsd(short_traj["gro_keep"], m, sel, example["box9"], short_traj["frames"][f], m, sel, short_traj["boxes9"][f])
+        assert abs(r[f] - ro) <= 1e-6
+        np.testing.assert_allclose(R[f], Ro, atol=2e-6, rtol=0)
+        # single-frame entry point
+        cur.copy_frame(11, f)
+        assert abs(cur.calc_rmsd(ref, "Protein", slot=11) - ro) <= 1e-6
+    # RMSD-fit: against the oracle and against the reference's golden fitted trajectory
+    tol_file = 0.5 / float(short_traj["precision"]) + 2e-4
+    r2, st2 = plan.rmsd_fit(0, 11)
+    assert np.all(st2 == 0) and np.abs(r2 - r).max() == 0.0
+    for f in range(11):
+        fitted = cur.get_positions(slot=f)
+        _, want = O.calc_rmsd_and_fit(short_traj["gro_keep"], m, sel, example["box9"], short_traj["frames"][f], m, sel, short_traj["boxes9"][f])
+        np.testing.assert_allclose(fitted, want, atol=3e-5, rtol=0)   # |x| up to ~15 nm: f32 ulp ~1e-6, R differs by ~1e-6
+        assert np.abs(fitted - short_traj["fit"][f]).max() <= tol_file
+    ref.close(); cur.close()
+
+
+def test_rmsd_broken_reference_and_iterator(G, example, short_traj):
+    ref, cur, m = short_systems(G, example, short_traj)
+    ref.atoms_translate([3.2, -2.1, -4.6])        # break the peptide at the PBC (rmsd.rs:843-866, 1035-1073)
+    tol_file = 0.5 / float(short_traj["precision"]) + 2e-4
+    frames = [(short_traj["frames"][f], short_traj["boxes9"][f], int(short_traj["steps"][f]), float(short_traj["times"][f])) for f in range(11)]
+    out = []
+    for f, (frame, rmsd) in enumerate(G.TrajReader(cur, frames).calc_rmsd_and_fit(ref, "Protein")):
+        out.append(rmsd)
+        assert frame is cur
+        assert np.abs(cur.get_positions() - short_traj["broken_fit"][f]).max() <= tol_file
+    assert len(out) == 11
+    for f in range(11):
+        assert abs(out[f] - RMSD_EXPECTED[f]) <= 5e-7
+    out2 = [r for _, r in G.TrajReader(cur, frames).calc_rmsd(ref, "Protein")]   # rmsd.rs:1202-1226
+    assert np.abs(np.array(out2) - np.array(out)).max() <= 1e-6
+    ref.close(); cur.close()
+
+
+def test_rmsd_errors(G, example, short_traj):
+    ref, cur, m = short_systems(G, example, short_traj, n_slots=2)
+    cur.set_frame(short_traj["frames"][0], short_traj["boxes9"][0])
+    with pytest.raises(G.RMSDError) as e:
+        cur.calc_rmsd(ref, "Nonexistent")
+    assert e.value.variant == "NonexistentGroup"
+    cur.group_create_from_ranges("Protein", [(0, 59)])
+    with pytest.raises(G.RMSDError) as e:
+        cur.calc_rmsd(ref, "Protein")
+    assert e.value.variant == "InconsistentGroup" and e.value.detail[1:] == (61, 60)
+    cur.group_create_from_ranges("Protein", [(0, 60)])
+    bad = short_traj["frames"][0].copy(); bad[7, 0] = np.nan
+    cur.set_frame(bad, short_traj["boxes9"][0])
+    with pytest.raises(G.RMSDError) as e:
+        cur.calc_rmsd_and_fit(ref, "Protein")
+    assert e.value.variant == "InvalidPosition" and e.value.detail == 7
+    assert np.array_equal(np.isnan(cur.get_positions()), np.isnan(bad))      # not modified on failure (rmsd.rs:91)
+    cur.set_frame(short_traj["frames"][0], None)
+    with pytest.raises(G.RMSDError) as e:
+        cur.calc_rmsd(ref, "Protein")
+    assert e.value.variant == "InvalidSimBox" and e.value.detail.variant == "DoesNotExist"
+    cur.group_create_from_indices("E", []); ref.group_create_from_indices("E", [])
+    cur.set_frame(short_traj["frames"][0], short_traj["boxes9"][0])
+    with pytest.raises(G.RMSDError) as e:
+        cur.calc_rmsd(ref, "E")
+    assert e.value.variant == "EmptyGroup"
+    mm = m.copy(); mm[9] = np.nan
+    cur.set_masses(mm)
+    with pytest.raises(G.RMSDError) as e:
+        cur.calc_rmsd(ref, "Protein")
+    assert e.value.variant == "InvalidMass" and e.value.detail == 9
+    tri = O.box_from_lengths_angles([13.0, 13.0, 11.0], [80.0, 70.0, 120.0])
+    cur.set_masses(m); cur.set_strict_orthogonal(True)
+    cur.set_frame(short_traj["frames"][0], tri)
+    with pytest.raises(G.RMSDError) as e:
+        cur.calc_rmsd(ref, "Protein")
+    assert e.value.detail.variant == "NotOrthogonal"      # system/mod.rs:1120-1124
+    ref.close(); cur.close()
+
+
+# ----------------------------------------------------------------------------- gather-path selections
+def test_indexed_selection_paths(G, example, aa):
+    """multi-block selections take the gather path; compare every operation with the oracle"""
+    pos, box, m = aa["pos"], aa["box9"], aa["masses"]
+    n = pos.shape[0]
+    rng = np.random.default_rng(7)
+    idx = np.unique(np.concatenate([np.arange(5, 300, 3), rng.integers(0, 363, 80), np.arange(340, 363)]))
+    ref = G.System(n, masses=m, box=box, positions=pos)
+    cur = G.System(n, masses=m, n_slots=3)
+    for s in (ref, cur):
+        s.group_create_from_indices("Sel", idx)
+        s.group_create_from_indices("Sel2", np.arange(1000, 3000, 7))
+    assert not ref.group_container("Sel").blocks == [(5, 362)]
+    np.testing.assert_allclose(ref.group_get_com("Sel"), O.get_center(pos, idx, box, mass=m), atol=TOL, rtol=0)
+    np.testing.assert_allclose(ref.group_estimate_center("Sel"), O.estimate_center(pos, idx, box), atol=TOL, rtol=0)
+    i2 = np.arange(1000, 3000, 7)
+    np.testing.assert_allclose(ref.group_all_distances("Sel", "Sel2"), O.group_all_distances(pos, idx, i2, "xyz", box), atol=2e-6, rtol=0)
+    plan = G.RMSDPlan(ref, cur, "Sel")
+    for f in (0, 7, 20):
+        frame = np.concatenate([aa["traj_peptide"][f], pos[363:]])
+        cur.set_frame(frame, aa["traj_boxes9"][f], slot=0)
+        for exact in (False, True):
+            cur.set_frame(frame, aa["traj_boxes9"][f], slot=1)
+            plan.force_exact(exact)
+            r, st = plan.rmsd_fit(1, 1)
+            ro, want = O.calc_rmsd_and_fit(pos, m, idx, box, frame, m, idx, aa["traj_boxes9"][f])
+            assert st[0] == 0 and abs(r[0] - ro) <= 2e-6
+            np.testing.assert_allclose(cur.get_positions(slot=1), want, atol=3e-5, rtol=0)
+    ref.close(); cur.close()
+
+
+def test_rmsd_aa_peptide_trajectory(G, aa):
+    """config[1]: RMSD-to-first-frame of the peptide over the 21 frames (orthorhombic), vs the oracle"""
+    pos, box, m = aa["pos"], aa["box9"], aa["masses"]
+    ref = G.System(363, masses=m[:363], box=aa["traj_boxes9"][0], positions=aa["traj_peptide"][0])
+    cur = G.System(363, masses=m[:363], n_slots=21)
+    sel = np.arange(363)
+    for f in range(21):
+        cur.set_frame(aa["traj_peptide"][f], aa["traj_boxes9"][f], slot=f)
+    plan = G.RMSDPlan(ref, cur, "all")
+    r, st = plan.rmsd(0, 21)
+    assert np.all(st == 0) and plan.last_fallbacks() == 0 and abs(r[0]) <= 2e-4
+    for f in range(21):
+        ro, _ = O.calc_rmsd(aa["traj_peptide"][0], m[:363], sel, aa["traj_boxes9"][0], aa["traj_peptide"][f], m[:363], sel, aa["traj_boxes9"][f])
+        assert abs(r[f] - ro) <= 2e-6, (f, r[f], ro)
+    ref.close(); cur.close()
