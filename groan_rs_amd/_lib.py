@@ -75,7 +75,9 @@ SIGNATURES = {
     "gr_timer_start": (C.c_int, [C.c_void_p]),
     "gr_timer_stop": (C.c_int, [C.c_void_p, c_f32p]),
     "gr_synth_reference": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_float, C.c_uint64]),
-    "gr_synth_frames": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_float, C.c_uint64]),
+    "gr_synth_frames": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, C.c_float, C.c_uint64]),
+    "gr_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "gr_profile_read": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), c_u64p, c_u64p]),
     "gr_synth_uniform": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64]),
 }
 

@@ -7,6 +7,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -55,6 +56,17 @@ struct gr_ctx {
     uint32_t *bad_host = nullptr;         // pinned [4]
     float *pd_out = nullptr; size_t pd_cap = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // per-kernel HIP-event profile of the batched RMSD path (gr_profile_*): 0 accumulate, 1 finalize, 2 fit
+    hipEvent_t pev[4 * GR_MAX_BATCH] = {};
+    // launch geometry of the batched RMSD path (env GR_SUB_BATCH / GR_CHUNKS / GR_FIT_WGS override)
+    uint32_t sub_batch = 8;     // frames per accumulate->finalize->fit group: keeps the group's frames in the
+                                // 256 MiB Infinity Cache so the fit pass re-reads them on-die, not from HBM
+    uint32_t chunks = 0;        // workgroups per frame in the reductions (0 = auto)
+    uint32_t fit_wgs = 0;       // workgroups per frame in k_fit (0 = auto)
+    int profile = 0;
+    double prof_ms[3] = { 0, 0, 0 };
+    uint64_t prof_launches[3] = { 0, 0, 0 };
+    uint64_t prof_frames[3] = { 0, 0, 0 };
     int strict = 0;
     std::string err;
     uint64_t err_index = 0;
@@ -102,6 +114,31 @@ uint32_t chunks_for(const GrSel &s) {
     if (c < 1) c = 1;
     if (c > GR_MAX_CHUNKS) c = GR_MAX_CHUNKS;
     return (uint32_t)c;
+}
+
+// workgroups per frame of the reduction kernels when `nf` frames share one launch: enough workgroups to
+// fill the chip (~3 resident 256-thread workgroups per CU at this register budget), but as few as that
+// allows, so each lane streams many atoms per 32-value fp64 wave reduction
+uint32_t batch_chunks(const gr_ctx *c, const GrSel &s, uint32_t nf) {
+    if (c->chunks) return c->chunks;
+    const uint64_t units = s.contiguous ? ((uint64_t)s.n + 3) / 4 : ((uint64_t)s.n + 3) / 4;
+    uint64_t by_work = units / GR_WG;            // at least one trip per lane
+    if (by_work < 1) by_work = 1;
+    uint64_t want = (1536 + nf - 1) / nf;        // ~2 rounds of 768 resident workgroups
+    if (want < 4) want = 4;
+    uint64_t ch = want < by_work ? want : by_work;
+    if (ch > GR_MAX_CHUNKS) ch = GR_MAX_CHUNKS;
+    return (uint32_t)ch;
+}
+
+uint32_t fit_grid(const gr_ctx *c, uint32_t nf) {
+    if (c->fit_wgs) return c->fit_wgs;
+    const uint64_t groups = c->n >> 2;
+    uint64_t by_work = (groups + GR_WG - 1) / GR_WG;
+    if (by_work < 1) by_work = 1;
+    uint64_t want = (4096 + nf - 1) / nf;
+    uint64_t gx = want < by_work ? want : by_work;
+    return (uint32_t)(gx < 1 ? 1 : gx);
 }
 
 int install_group(gr_ctx *c, const char *name, std::vector<grc::Block> blocks) {
@@ -254,6 +291,10 @@ gr_ctx *gr_ctx_create(int device, uint64_t n_atoms, uint32_t n_slots, int *statu
     ok = ok && hipMalloc(&c->bad_dev, 4 * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipHostMalloc(&c->bad_host, 4 * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess;
     ok = ok && hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess;
+    for (int k = 0; k < 4 * GR_MAX_BATCH; ++k) ok = ok && hipEventCreate(&c->pev[k]) == hipSuccess;
+    if (const char *e = getenv("GR_SUB_BATCH")) { int v = atoi(e); if (v >= 1 && v <= GR_MAX_BATCH) c->sub_batch = (uint32_t)v; }
+    if (const char *e = getenv("GR_CHUNKS")) { int v = atoi(e); if (v >= 1 && v <= GR_MAX_CHUNKS) c->chunks = (uint32_t)v; }
+    if (const char *e = getenv("GR_FIT_WGS")) { int v = atoi(e); if (v >= 1 && v <= 65535) c->fit_wgs = (uint32_t)v; }
     if (!ok) { *status = GR_E_HIP; gr_ctx_destroy(c); return nullptr; }
     // masses undefined (None) until gr_set_masses; padding and frames zero
     std::vector<float> nanv(c->n_pad, NAN);
@@ -290,6 +331,7 @@ void gr_ctx_destroy(gr_ctx *c) {
     if (c->pd_out) (void)hipFree(c->pd_out);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    for (int k = 0; k < 4 * GR_MAX_BATCH; ++k) if (c->pev[k]) (void)hipEventDestroy(c->pev[k]);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -666,6 +708,7 @@ static int rmsd_batch_impl(gr_rmsd_plan *p, uint32_t first_slot, uint32_t n_fram
             for (uint32_t f = 0; f < nb; ++f) { GrFrameState z = {}; z.err_index = GR_NOIDX; z.status = pre[f]; c->state_host[f] = z; }
             HIPCHK(c, hipMemcpyAsync(c->state_dev, c->state_host, nb * sizeof(GrFrameState), hipMemcpyHostToDevice, c->stream));
             const bool consistent = (g->n == p->n_ref);
+            uint32_t n_prof_groups = 0;
             if (!consistent) {
                 // positions and masses of the target are still checked first (extract_data_from_system runs to
                 // completion before number_of_positions_consistent, rmsd.rs:206-214)
@@ -673,16 +716,39 @@ static int rmsd_batch_impl(gr_rmsd_plan *p, uint32_t first_slot, uint32_t n_fram
             } else if (p->exact) {
                 st = rmsd_exact(p, c, sel, s0, nb, fit); if (st) return st;
             } else {
-                const uint32_t nch = chunks_for(sel);
-                k_rmsd_accum<0><<<dim3(nch, nb), dim3(GR_WG), 0, c->stream>>>(c->frames, c->frame_stride, s0, c->masses, sel, c->boxes_dev, p->dev, c->state_dev, c->acc_partials);
-                k_rmsd_finalize<0><<<dim3(nb), dim3(GR_WG), 0, c->stream>>>(c->acc_partials, nch, c->frames, c->frame_stride, s0, sel, c->boxes_dev, p->dev, c->state_dev);
-                if (fit) {
-                    const uint32_t gx = (uint32_t)std::min<uint64_t>(((c->n >> 2) + GR_WG * 4 - 1) / (GR_WG * 4) + 1, 1024);
-                    k_fit<<<dim3(gx, nb), dim3(GR_WG), 0, c->stream>>>(c->frames, c->frame_stride, s0, (uint32_t)c->n, c->boxes_dev, p->dev, c->state_dev);
+                // groups of sub_batch frames: accumulate -> finalize -> fit back to back on the stream, no host
+                // round trip in between; one state fetch for the whole batch afterwards
+                const uint32_t sb = c->sub_batch;
+                uint32_t ng = 0;
+                for (uint32_t f0 = 0; f0 < nb; f0 += sb, ++ng) {
+                    const uint32_t nf = std::min<uint32_t>(sb, nb - f0);
+                    const uint32_t nch = batch_chunks(c, sel, nf);
+                    hipEvent_t *ev = c->pev + 4 * ng;
+                    GrAccPartial *parts = c->acc_partials + (size_t)f0 * GR_MAX_CHUNKS;
+                    if (c->profile) HIPCHK(c, hipEventRecord(ev[0], c->stream));
+                    k_rmsd_accum<0><<<dim3(nch, nf), dim3(GR_WG), 0, c->stream>>>(c->frames, c->frame_stride, s0 + f0, c->masses, sel, c->boxes_dev, p->dev, c->state_dev + f0, parts);
+                    if (c->profile) HIPCHK(c, hipEventRecord(ev[1], c->stream));
+                    k_rmsd_finalize<0><<<dim3(nf), dim3(GR_WG), 0, c->stream>>>(parts, nch, c->frames, c->frame_stride, s0 + f0, sel, c->boxes_dev, p->dev, c->state_dev + f0);
+                    if (c->profile) HIPCHK(c, hipEventRecord(ev[2], c->stream));
+                    if (fit) {
+                        const uint32_t gx = fit_grid(c, nf);
+                        k_fit<<<dim3(gx, nf), dim3(GR_WG), 0, c->stream>>>(c->frames, c->frame_stride, s0 + f0, (uint32_t)c->n, c->boxes_dev, p->dev, c->state_dev + f0);
+                        if (c->profile) HIPCHK(c, hipEventRecord(ev[3], c->stream));
+                    }
                 }
                 HIPCHK(c, hipGetLastError());
+                if (c->profile) n_prof_groups = ng;
             }
             st = fetch_states(c, nb); if (st) return st;
+            for (uint32_t gi = 0; gi < n_prof_groups; ++gi) {   // the stream is idle here: read this batch's event pairs
+                const int nk = fit ? 3 : 2;
+                const uint32_t nf = std::min<uint32_t>(c->sub_batch, nb - gi * c->sub_batch);
+                for (int k = 0; k < nk; ++k) {
+                    float ms = 0.f;
+                    HIPCHK(c, hipEventElapsedTime(&ms, c->pev[4 * gi + k], c->pev[4 * gi + k + 1]));
+                    c->prof_ms[k] += ms; c->prof_launches[k] += 1; c->prof_frames[k] += nf;
+                }
+            }
             std::vector<GrFrameState> res(c->state_host, c->state_host + nb);
             // frames whose single-pass image proof failed are redone on the exact path, one by one
             for (uint32_t f = 0; f < nb; ++f) {
@@ -760,6 +826,20 @@ int gr_timer_stop(gr_ctx *c, float *ms) {
     return GR_OK;
 }
 
+int gr_profile_enable(gr_ctx *c, int on) {
+    if (!c) return GR_E_INVALID_ARG;
+    c->profile = on ? 1 : 0;
+    for (int k = 0; k < 3; ++k) { c->prof_ms[k] = 0; c->prof_launches[k] = 0; c->prof_frames[k] = 0; }
+    return GR_OK;
+}
+int gr_profile_read(const gr_ctx *c, int kernel, double *ms_total, uint64_t *launches, uint64_t *frames) {
+    if (!c || kernel < 0 || kernel > 2) return GR_E_INVALID_ARG;
+    if (ms_total) *ms_total = c->prof_ms[kernel];
+    if (launches) *launches = c->prof_launches[kernel];
+    if (frames) *frames = c->prof_frames[kernel];
+    return GR_OK;
+}
+
 int gr_synth_reference(gr_ctx *c, uint32_t slot, const float *box9, float radius, uint64_t seed) {
     int st = slot_check(c, slot); if (st) return st;
     (void)hipSetDevice(c->device);
@@ -772,7 +852,8 @@ int gr_synth_reference(gr_ctx *c, uint32_t slot, const float *box9, float radius
     return GR_OK;
 }
 
-int gr_synth_frames(gr_ctx *c, uint32_t ref_slot, uint32_t first_slot, uint32_t n_frames, uint64_t first_frame_index, float sigma, uint64_t seed) {
+int gr_synth_frames(gr_ctx *c, uint32_t ref_slot, uint32_t first_slot, uint32_t n_frames, uint64_t first_frame_index,
+                    uint64_t frame_index_stride, float sigma, uint64_t seed) {
     int st = slot_check(c, ref_slot); if (st) return st;
     st = slot_check(c, first_slot, n_frames); if (st) return st;
     if (ref_slot >= first_slot && ref_slot < first_slot + n_frames) return fail(c, GR_E_INVALID_ARG, "reference slot inside the output range");
@@ -782,7 +863,7 @@ int gr_synth_frames(gr_ctx *c, uint32_t ref_slot, uint32_t first_slot, uint32_t 
     for (uint32_t f = 0; f < n_frames; ++f) { st = set_box(c, first_slot + f, &c->box9_host[9 * (size_t)ref_slot]); if (st) return st; }
     for (uint32_t f0 = 0; f0 < n_frames; f0 += 1024) {
         const uint32_t nf = std::min<uint32_t>(1024, n_frames - f0);
-        k_synth_frames<<<dim3((uint32_t)((c->n + 255) / 256), nf), dim3(256), 0, c->stream>>>(c->frames + (size_t)ref_slot * c->frame_stride, c->frames, c->frame_stride, first_slot + f0, (uint32_t)c->n, c->boxes_dev + ref_slot, first_frame_index + f0, sigma, seed);
+        k_synth_frames<<<dim3((uint32_t)((c->n + 255) / 256), nf), dim3(256), 0, c->stream>>>(c->frames + (size_t)ref_slot * c->frame_stride, c->frames, c->frame_stride, first_slot + f0, (uint32_t)c->n, c->boxes_dev + ref_slot, first_frame_index + (uint64_t)f0 * frame_index_stride, frame_index_stride, sigma, seed);
     }
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));

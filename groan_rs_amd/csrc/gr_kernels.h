@@ -304,42 +304,69 @@ __global__ __launch_bounds__(GR_WG) void k_rmsd_accum(
     }
     if (MODE == 1) { sx = state[frame].shift[0]; sy = state[frame].shift[1]; sz = state[frame].shift[2]; }
     const float iax = 1.0f / box.ax, iby = 1.0f / box.by, icz = 1.0f / box.cz;
+    const float rws2 = box.r_ws * box.r_ws;
+    const bool tric = !box.ortho;
     float fsum[6] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
-    auto visit = [&](uint32_t i, float x, float y, float z, float m, float px, float py, float pz, float w) {
-        if (m != m) { bad_mass = min(bad_mass, i); m = 0.0f; }
-        if (x != x) { bad_pos = min(bad_pos, i); return; }
-        float vx, vy, vz;
-        if (MODE == 0) {
-            vx = x - gx; vy = y - gy; vz = z - gz;
-            gr_min_image_vec(vx, vy, vz, box);
-            // fractional coordinates of v in revolutions -> hardware sin/cos
-            const float fc = vz * icz;
-            const float uy = vy - fc * box.cy;
-            const float fb = uy * iby;
-            const float fa = (vx - fb * box.bx - fc * box.cx) * iax;
-            fsum[0] += __builtin_amdgcn_cosf(fa); fsum[1] += __builtin_amdgcn_cosf(fb); fsum[2] += __builtin_amdgcn_cosf(fc);
-            fsum[3] += __builtin_amdgcn_sinf(fa); fsum[4] += __builtin_amdgcn_sinf(fb); fsum[5] += __builtin_amdgcn_sinf(fc);
-        } else {
-            vx = x + sx; vy = y + sy; vz = z + sz;
-            gr_wrap(vx, vy, vz, box);
-            vx -= box.bcx; vy -= box.bcy; vz -= box.bcz;
+
+    // Four atoms at a time: the 26 products-sums of the four atoms are formed in f32 (the operands are
+    // centred, |v|,|p| <= half a box, so a 4-term f32 sum carries ~1e-7 relative rounding, random in
+    // sign) and only the 4-atom partial is added to the fp64 accumulators: 6.5 instead of 26 fp64 adds
+    // per atom.  The long sum -- where sequential f32 loses digits -- stays in fp64.
+    struct A4 { float x[4], y[4], z[4], m[4], px[4], py[4], pz[4], w[4]; uint32_t i[4]; bool ok[4]; };
+    auto flush4 = [&](const A4 &a) {
+        float part[26];
+#pragma unroll
+        for (int k = 0; k < 26; ++k) part[k] = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (!a.ok[q]) continue;
+            float m = a.m[q];
+            if (m != m) { bad_mass = min(bad_mass, a.i[q]); m = 0.0f; }
+            if (a.x[q] != a.x[q]) { bad_pos = min(bad_pos, a.i[q]); continue; }
+            float vx, vy, vz;
+            if (MODE == 0) {
+                // image of x nearest to g: closed-form brick reduction along c, b, a ...
+                vx = a.x[q] - gx; vy = a.y[q] - gy; vz = a.z[q] - gz;
+                const float kc = rintf(vz * icz);
+                vx = fmaf(-kc, box.cx, vx); vy = fmaf(-kc, box.cy, vy); vz = fmaf(-kc, box.cz, vz);
+                const float kb = rintf(vy * iby);
+                vx = fmaf(-kb, box.bx, vx); vy = fmaf(-kb, box.by, vy);
+                const float ka = rintf(vx * iax);
+                vx = fmaf(-ka, box.ax, vx);
+                // ... which is already THE minimum image whenever |v| < r_ws; otherwise search the table
+                if (tric && vx * vx + vy * vy + vz * vz >= rws2) gr_tric_refine(vx, vy, vz, box);
+                // fractional coordinates of v in revolutions -> hardware sin/cos
+                const float fc = vz * icz;
+                const float uy = fmaf(-fc, box.cy, vy);
+                const float fb = uy * iby;
+                const float fa = (vx - fb * box.bx - fc * box.cx) * iax;
+                fsum[0] += __builtin_amdgcn_cosf(fa); fsum[1] += __builtin_amdgcn_cosf(fb); fsum[2] += __builtin_amdgcn_cosf(fc);
+                fsum[3] += __builtin_amdgcn_sinf(fa); fsum[4] += __builtin_amdgcn_sinf(fb); fsum[5] += __builtin_amdgcn_sinf(fc);
+            } else {
+                vx = a.x[q] + sx; vy = a.y[q] + sy; vz = a.z[q] + sz;
+                gr_wrap(vx, vy, vz, box);
+                vx -= box.bcx; vy -= box.bcy; vz -= box.bcz;
+            }
+            mn[0] = fminf(mn[0], vx); mn[1] = fminf(mn[1], vy); mn[2] = fminf(mn[2], vz);
+            mx[0] = fmaxf(mx[0], vx); mx[1] = fmaxf(mx[1], vy); mx[2] = fmaxf(mx[2], vz);
+            const float px = a.px[q], py = a.py[q], pz = a.pz[q], w = a.w[q];
+            part[0] += m;
+            part[1] = fmaf(m, vx, part[1]); part[2] = fmaf(m, vy, part[2]); part[3] = fmaf(m, vz, part[3]);
+            part[4] = fmaf(px, vx, part[4]); part[5] = fmaf(px, vy, part[5]); part[6] = fmaf(px, vz, part[6]);
+            part[7] = fmaf(py, vx, part[7]); part[8] = fmaf(py, vy, part[8]); part[9] = fmaf(py, vz, part[9]);
+            part[10] = fmaf(pz, vx, part[10]); part[11] = fmaf(pz, vy, part[11]); part[12] = fmaf(pz, vz, part[12]);
+            const float wpx = w * px, wpy = w * py, wpz = w * pz;
+            part[13] = fmaf(wpx, vx, part[13]); part[14] = fmaf(wpx, vy, part[14]); part[15] = fmaf(wpx, vz, part[15]);
+            part[16] = fmaf(wpy, vx, part[16]); part[17] = fmaf(wpy, vy, part[17]); part[18] = fmaf(wpy, vz, part[18]);
+            part[19] = fmaf(wpz, vx, part[19]); part[20] = fmaf(wpz, vy, part[20]); part[21] = fmaf(wpz, vz, part[21]);
+            const float wvx = w * vx, wvy = w * vy, wvz = w * vz;
+            part[22] = fmaf(wvx, vx, fmaf(wvy, vy, fmaf(wvz, vz, part[22])));
+            part[23] += wvx; part[24] += wvy; part[25] += wvz;
         }
-        mn[0] = fminf(mn[0], vx); mn[1] = fminf(mn[1], vy); mn[2] = fminf(mn[2], vz);
-        mx[0] = fmaxf(mx[0], vx); mx[1] = fmaxf(mx[1], vy); mx[2] = fmaxf(mx[2], vz);
-        const double dvx = vx, dvy = vy, dvz = vz, dm = m, dw = w;
-        const double dpx = px, dpy = py, dpz = pz;
-        acc[0] += dm;
-        acc[1] += dm * dvx; acc[2] += dm * dvy; acc[3] += dm * dvz;
-        acc[4] += dpx * dvx; acc[5] += dpx * dvy; acc[6] += dpx * dvz;
-        acc[7] += dpy * dvx; acc[8] += dpy * dvy; acc[9] += dpy * dvz;
-        acc[10] += dpz * dvx; acc[11] += dpz * dvy; acc[12] += dpz * dvz;
-        const double wpx = dw * dpx, wpy = dw * dpy, wpz = dw * dpz;
-        acc[13] += wpx * dvx; acc[14] += wpx * dvy; acc[15] += wpx * dvz;
-        acc[16] += wpy * dvx; acc[17] += wpy * dvy; acc[18] += wpy * dvz;
-        acc[19] += wpz * dvx; acc[20] += wpz * dvy; acc[21] += wpz * dvz;
-        acc[22] += dw * (dvx * dvx + dvy * dvy + dvz * dvz);
-        acc[23] += dw * dvx; acc[24] += dw * dvy; acc[25] += dw * dvz;
+#pragma unroll
+        for (int k = 0; k < 26; ++k) acc[k] += (double)part[k];
     };
+
     if (sel.contiguous) {
         // 4 atoms per lane per trip: 3 float4 of positions, 3 float4 of reference coordinates,
         // 1 float4 of masses (+1 of weights when they differ from the masses)
@@ -356,18 +383,33 @@ __global__ __launch_bounds__(GR_WG) void k_rmsd_accum(
             const float4 mm = m4[g];
             const float4 ww = plan.w_is_mass ? mm : w4[pg];
             const uint32_t i = g << 2;
-            if (i >= first && i < last) visit(i, a.x, a.y, a.z, mm.x, pa.x, pa.y, pa.z, ww.x);
-            if (i + 1 >= first && i + 1 < last) visit(i + 1, a.w, b.x, b.y, mm.y, pa.w, pb.x, pb.y, ww.y);
-            if (i + 2 >= first && i + 2 < last) visit(i + 2, b.z, b.w, c.x, mm.z, pb.z, pb.w, pc.x, ww.z);
-            if (i + 3 >= first && i + 3 < last) visit(i + 3, c.y, c.z, c.w, mm.w, pc.y, pc.z, pc.w, ww.w);
+            A4 t;
+            t.x[0] = a.x; t.y[0] = a.y; t.z[0] = a.z; t.x[1] = a.w; t.y[1] = b.x; t.z[1] = b.y;
+            t.x[2] = b.z; t.y[2] = b.w; t.z[2] = c.x; t.x[3] = c.y; t.y[3] = c.z; t.z[3] = c.w;
+            t.px[0] = pa.x; t.py[0] = pa.y; t.pz[0] = pa.z; t.px[1] = pa.w; t.py[1] = pb.x; t.pz[1] = pb.y;
+            t.px[2] = pb.z; t.py[2] = pb.w; t.pz[2] = pc.x; t.px[3] = pc.y; t.py[3] = pc.z; t.pz[3] = pc.w;
+            t.m[0] = mm.x; t.m[1] = mm.y; t.m[2] = mm.z; t.m[3] = mm.w;
+            t.w[0] = ww.x; t.w[1] = ww.y; t.w[2] = ww.z; t.w[3] = ww.w;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { t.i[q] = i + q; t.ok[q] = (i + q >= first) && (i + q < last); }
+            flush4(t);
         }
     } else {
-        for (uint32_t j = chunk * GR_WG + threadIdx.x; j < sel.n; j += nchunks * GR_WG) {
-            const uint32_t i = sel.idx[j];
-            const float *q = xyz + 3 * (size_t)i;
-            const float m = masses[i];
-            visit(i, q[0], q[1], q[2], m, plan.p[3 * (size_t)j], plan.p[3 * (size_t)j + 1], plan.p[3 * (size_t)j + 2],
-                  plan.w_is_mass ? m : plan.w[j]);
+        const uint32_t n4 = (sel.n + 3u) >> 2;
+        for (uint32_t j4 = chunk * GR_WG + threadIdx.x; j4 < n4; j4 += nchunks * GR_WG) {
+            A4 t;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t j = j4 * 4 + q;
+                t.ok[q] = j < sel.n;
+                const uint32_t jj = t.ok[q] ? j : 0u;
+                const uint32_t i = sel.idx[jj];
+                const float *r = xyz + 3 * (size_t)i;
+                t.i[q] = i; t.x[q] = r[0]; t.y[q] = r[1]; t.z[q] = r[2]; t.m[q] = masses[i];
+                t.px[q] = plan.p[3 * (size_t)jj]; t.py[q] = plan.p[3 * (size_t)jj + 1]; t.pz[q] = plan.p[3 * (size_t)jj + 2];
+                t.w[q] = plan.w_is_mass ? t.m[q] : plan.w[jj];
+            }
+            flush4(t);
         }
     }
 #pragma unroll
@@ -748,12 +790,12 @@ __global__ void k_synth_reference(float *xyz, uint32_t n, const GrBox *boxp, flo
 
 // frame f = R_f (x0 - c) + c + t_f + noise, wrapped into the cell
 __global__ void k_synth_frames(const float *ref, float *frames, size_t frame_stride, uint32_t first_slot, uint32_t n,
-                               const GrBox *boxp, uint64_t first_frame_index, float sigma, uint64_t seed) {
+                               const GrBox *boxp, uint64_t first_frame_index, uint64_t frame_index_stride, float sigma, uint64_t seed) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t f = blockIdx.y;
     if (i >= n) return;
     const GrBox &b = *boxp;
-    const uint64_t fi = first_frame_index + f;
+    const uint64_t fi = first_frame_index + (uint64_t)f * frame_index_stride;
     // random unit quaternion -> rotation
     float q0 = 2.f * gr_u01(seed, fi, 0, 2) - 1.f, q1 = 2.f * gr_u01(seed, fi, 1, 2) - 1.f, q2 = 2.f * gr_u01(seed, fi, 2, 2) - 1.f, q3 = 2.f * gr_u01(seed, fi, 3, 2) - 1.f;
     float qn = sqrtf(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3);

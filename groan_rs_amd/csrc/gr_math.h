@@ -60,8 +60,11 @@ GR_HD float gr_min_image(float dx, float L) {
 
 GR_HD float gr_floor_mod(float x, float y) { return fmodf(fmodf(x, y) + y, y); }
 
+// A vector shorter than r_ws (half the shortest lattice vector) is its own unique minimum image
+// (|d + t| >= |t| - |d| > |d| for every lattice vector t), so the table is searched only beyond it.
 GR_HD void gr_tric_refine(float &dx, float &dy, float &dz, const GrBox &b) {
     float best = dx * dx + dy * dy + dz * dz;
+    if (best < b.r_ws * b.r_ws) return;
     float ox = dx, oy = dy, oz = dz;
     for (int m = 0; m < b.ncand; ++m) {
         float x = ox + b.cand[m][0], y = oy + b.cand[m][1], z = oz + b.cand[m][2];

@@ -462,8 +462,21 @@ class System:
         if st != OK:
             raise DeviceError("synth_reference", self._err(st)[1], st)
 
-    def synth_frames(self, ref_slot, first_slot, n_frames, first_frame_index, noise_sigma, seed):
-        st = self._lib.gr_synth_frames(self._ctx, ref_slot, first_slot, n_frames, first_frame_index, C.c_float(noise_sigma), seed)
+    def profile_enable(self, on=True):
+        self._lib.gr_profile_enable(self._ctx, int(bool(on)))
+
+    def profile_read(self):
+        """-> {kernel: (ms_total, launches, frames)} for the batched RMSD path"""
+        out = {}
+        for k, name in enumerate(("k_rmsd_accum", "k_rmsd_finalize", "k_fit")):
+            ms = C.c_double(0); n = C.c_uint64(0); f = C.c_uint64(0)
+            self._lib.gr_profile_read(self._ctx, k, C.byref(ms), C.byref(n), C.byref(f))
+            out[name] = (ms.value, int(n.value), int(f.value))
+        return out
+
+    def synth_frames(self, ref_slot, first_slot, n_frames, first_frame_index, noise_sigma, seed, frame_index_stride=1):
+        st = self._lib.gr_synth_frames(self._ctx, ref_slot, first_slot, n_frames, first_frame_index, frame_index_stride,
+                                       C.c_float(noise_sigma), seed)
         if st != OK:
             raise DeviceError("synth_frames", self._err(st)[1], st)
 

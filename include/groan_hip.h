@@ -185,15 +185,21 @@ int gr_rmsd_plan_force_exact(gr_rmsd_plan *plan, int on);
  * HIP-event timing on the context's stream (the stream the kernels are launched on). */
 int gr_timer_start(gr_ctx *ctx);
 int gr_timer_stop(gr_ctx *ctx, float *milliseconds);
+/* Per-kernel HIP-event profile of the batched RMSD path, recorded on the context's stream around
+ * each launch while enabled: kernel 0 = k_rmsd_accum, 1 = k_rmsd_finalize, 2 = k_fit.  Enabling resets
+ * the counters.  ms_total / launches = average launch duration; frames = frames those launches covered. */
+int gr_profile_enable(gr_ctx *ctx, int on);
+int gr_profile_read(const gr_ctx *ctx, int kernel, double *ms_total, uint64_t *launches, uint64_t *frames);
 /* Seeded synthetic workload of SURVEY.md section 8(d), generated directly in HBM:
  *  gr_synth_reference: n_atoms points uniform in a ball of `radius` about the box centre -> slot
  *  gr_synth_frames   : frame f = R_f (x0 - c) + c + t_f + noise, wrapped into the cell, for
  *                      n_frames consecutive slots; R_f, t_f, noise from a counter-based hash of
- *                      (seed, first_frame_index + f, atom).  The box of every slot is set to box9.
+ *                      (seed, first_frame_index + f*frame_index_stride, atom): a rank of a G-way
+ *                      round-robin shard passes (rank, G).  Every slot inherits the reference slot's box.
  *  gr_synth_uniform  : n_atoms points uniform in the unit cell (config 3). */
 int gr_synth_reference(gr_ctx *ctx, uint32_t slot, const float *box9, float radius, uint64_t seed);
 int gr_synth_frames(gr_ctx *ctx, uint32_t ref_slot, uint32_t first_slot, uint32_t n_frames,
-                    uint64_t first_frame_index, float noise_sigma, uint64_t seed);
+                    uint64_t first_frame_index, uint64_t frame_index_stride, float noise_sigma, uint64_t seed);
 int gr_synth_uniform(gr_ctx *ctx, uint32_t slot, const float *box9, uint64_t seed);
 
 #ifdef __cplusplus

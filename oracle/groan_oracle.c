@@ -24,6 +24,17 @@
 static int g_strict_ortho = 0;
 void go_set_strict_orthogonal(int on) { g_strict_ortho = on; }
 
+/* Accumulator width of the long sums (centres, covariance, RMSD sum, sum of weights).
+ * 0 (default) = f32 sequential, the reference's arithmetic (iterators.rs:1430-1434, rmsd.rs:567-570,592-598).
+ * 1 = the same per-atom f32 terms summed in double.  A sequential f32 sum of S terms carries a rounding
+ * error of up to ~S*2^-24 relative, which exceeds the 1e-5 nm parity bar beyond a few thousand atoms; the
+ * GPU sums in fp64, so large-S parity tests compare against mode 1 and bound mode 0 against mode 1. */
+static int g_acc64 = 0;
+void go_set_accumulate_f64(int on) { g_acc64 = on; }
+#define ACC(name) float name = 0.0f; double name##_d = 0.0
+#define ADD(name, v) do { float v_ = (v); name += v_; name##_d += (double)v_; } while (0)
+#define DIVF(num, den) (g_acc64 ? (float)(num##_d / den##_d) : (num / den))
+
 /* box9 accessors (src/structures/simbox.rs:13-26) */
 #define V1X(b) ((b)[0])
 #define V2Y(b) ((b)[1])
@@ -418,7 +429,7 @@ size_t go_container_intersection(const uint64_t *s1, const uint64_t *e1, size_t 
 /* src/structures/iterators.rs:886-903 (mass==NULL) and :946-967 */
 int go_center_naive(const void *pos, size_t ps, const void *mass, size_t ms,
                     const uint64_t *idx, size_t n, float out[3], uint64_t *err) {
-    float tx = 0.0f, ty = 0.0f, tz = 0.0f, sum = 0.0f;
+    ACC(tx); ACC(ty); ACC(tz); ACC(sum);
     size_t n_atoms = 0;
     for (size_t k = 0; k < n; ++k) {
         const float *p = POS(pos, ps, idx[k]);
@@ -426,15 +437,15 @@ int go_center_naive(const void *pos, size_t ps, const void *mass, size_t ms,
         if (mass) {
             float m = MASS(mass, ms, idx[k]);
             if (isnan(m)) { if (err) *err = idx[k]; return GO_E_NO_MASS; }
-            tx += p[0] * m; ty += p[1] * m; tz += p[2] * m;
-            sum += m;
+            ADD(tx, p[0] * m); ADD(ty, p[1] * m); ADD(tz, p[2] * m);
+            ADD(sum, m);
         } else {
-            tx += p[0]; ty += p[1]; tz += p[2];
+            ADD(tx, p[0]); ADD(ty, p[1]); ADD(tz, p[2]);
             n_atoms += 1;
         }
     }
-    float div = mass ? sum : (float)n_atoms;
-    out[0] = tx / div; out[1] = ty / div; out[2] = tz / div;
+    if (!mass) { sum = (float)n_atoms; sum_d = (double)n_atoms; }
+    out[0] = DIVF(tx, sum); out[1] = DIVF(ty, sum); out[2] = DIVF(tz, sum);
     return GO_OK;
 }
 
@@ -450,6 +461,7 @@ int go_estimate_center(const void *pos, size_t ps, const void *mass, size_t ms,
     float sc[3] = { PI_X2 / V1X(b), PI_X2 / V2Y(b), PI_X2 / V3Z(b) }; /* iterators.rs:1154 */
     int ortho = go_box_is_orthogonal(b);
     float xi[3] = { 0, 0, 0 }, zeta[3] = { 0, 0, 0 };
+    double xi_d[3] = { 0, 0, 0 }, zeta_d[3] = { 0, 0, 0 };
     int empty = 1;
     for (size_t k = 0; k < n; ++k) {
         float m = 1.0f;
@@ -468,11 +480,14 @@ int go_estimate_center(const void *pos, size_t ps, const void *mass, size_t ms,
             w[0] = ux; w[1] = uy;
         }
         float th[3] = { w[0] * sc[0], w[1] * sc[1], w[2] * sc[2] };
-        xi[0] += m * cosf(th[0]); xi[1] += m * cosf(th[1]); xi[2] += m * cosf(th[2]);
-        zeta[0] += m * sinf(th[0]); zeta[1] += m * sinf(th[1]); zeta[2] += m * sinf(th[2]);
+        for (int a = 0; a < 3; ++a) {
+            float c_ = m * cosf(th[a]), s_ = m * sinf(th[a]);
+            xi[a] += c_; zeta[a] += s_; xi_d[a] += (double)c_; zeta_d[a] += (double)s_;
+        }
         empty = 0;
     }
     if (empty) { out[0] = out[1] = out[2] = NAN; return GO_OK; }
+    if (g_acc64) for (int a = 0; a < 3; ++a) { xi[a] = (float)xi_d[a]; zeta[a] = (float)zeta_d[a]; }
     float t[3];
     for (int a = 0; a < 3; ++a) t[a] = (atan2f(-zeta[a], -xi[a]) + PI_F) / sc[a];
     if (ortho) { out[0] = t[0]; out[1] = t[1]; out[2] = t[2]; }
@@ -493,7 +508,7 @@ int go_get_center(const void *pos, size_t ps, const void *mass, size_t ms,
     if (st != GO_OK) return st;
     tric_cand cand; cand.n = 0;
     if (!go_box_is_orthogonal(b)) tric_candidates(b, &cand);
-    float tx = 0.0f, ty = 0.0f, tz = 0.0f, sum = 0.0f;
+    ACC(tx); ACC(ty); ACC(tz); ACC(sum);
     size_t n_atoms = 0;
     for (size_t k = 0; k < n; ++k) {
         const float *p = POS(pos, ps, idx[k]);
@@ -506,11 +521,11 @@ int go_get_center(const void *pos, size_t ps, const void *mass, size_t ms,
         float v[3];
         vector_to_c(c, p, b, &cand, v);
         float np[3] = { c[0] + v[0], c[1] + v[1], c[2] + v[2] };
-        if (mass) { tx += np[0] * m; ty += np[1] * m; tz += np[2] * m; sum += m; }
-        else { tx += np[0]; ty += np[1]; tz += np[2]; n_atoms += 1; }
+        if (mass) { ADD(tx, np[0] * m); ADD(ty, np[1] * m); ADD(tz, np[2] * m); ADD(sum, m); }
+        else { ADD(tx, np[0]); ADD(ty, np[1]); ADD(tz, np[2]); n_atoms += 1; }
     }
-    float div = mass ? sum : (float)n_atoms;
-    out[0] = tx / div; out[1] = ty / div; out[2] = tz / div;
+    if (!mass) { sum = (float)n_atoms; sum_d = (double)n_atoms; }
+    out[0] = DIVF(tx, sum); out[1] = DIVF(ty, sum); out[2] = DIVF(tz, sum);
     return GO_OK;
 }
 
@@ -683,21 +698,23 @@ void go_kabsch_rmsd(const float *p, const float *q, const float *w, size_t n,
         qc[3 * i] = q[3 * i] - cq[0]; qc[3 * i + 1] = q[3 * i + 1] - cq[1]; qc[3 * i + 2] = q[3 * i + 2] - cq[2];
     }
     float H[9] = { 0 }; /* row-major h[a][b] += p_a q_b, :567-570 */
+    double H_d[9] = { 0 };
     for (size_t i = 0; i < n; ++i)
         for (int a = 0; a < 3; ++a)
-            for (int b = 0; b < 3; ++b) H[3 * a + b] += pc[3 * i + a] * qc[3 * i + b];
+            for (int b = 0; b < 3; ++b) { float v_ = pc[3 * i + a] * qc[3 * i + b]; H[3 * a + b] += v_; H_d[3 * a + b] += (double)v_; }
+    if (g_acc64) for (int a = 0; a < 9; ++a) H[a] = (float)H_d[a];
     go_kabsch_rotation(H, R);
     /* p_rotated = R^T p_c (:586-589); rmsd = sqrt(sum w |p_rot - q_c|^2 / sum_w) (:592-599) */
     float *pr = (float *)malloc(3 * n * sizeof(float) + 4);
     for (size_t i = 0; i < n; ++i)
         for (int a = 0; a < 3; ++a) /* (R^T)_{a k} = R_{k a} = R[3*a + k] (column-major) */
             pr[3 * i + a] = R[3 * a + 0] * pc[3 * i] + R[3 * a + 1] * pc[3 * i + 1] + R[3 * a + 2] * pc[3 * i + 2];
-    float sum = 0.0f;
+    ACC(sum);
     for (size_t i = 0; i < n; ++i) {
         float dx = pr[3 * i] - qc[3 * i], dy = pr[3 * i + 1] - qc[3 * i + 1], dz = pr[3 * i + 2] - qc[3 * i + 2];
-        sum += w[i] * (dx * dx + dy * dy + dz * dz);
+        ADD(sum, w[i] * (dx * dx + dy * dy + dz * dz));
     }
-    *rmsd = sqrtf(sum / sum_w);
+    *rmsd = g_acc64 ? (float)sqrt(sum_d / (double)sum_w) : sqrtf(sum / sum_w);
     t[0] = cq[0] - cp[0]; t[1] = cq[1] - cp[1]; t[2] = cq[2] - cp[2];
     free(pc); free(qc); free(pr);
 }
@@ -742,8 +759,9 @@ int go_calc_rmsd(const void *rpos, size_t rps, const void *rmass, size_t rms,
     }
     if (st == GO_OK) {
         float *w = (float *)malloc((nr + 1) * sizeof(float)); /* extract_masses(reference) :154 */
-        float sum_w = 0.0f;
-        for (size_t k = 0; k < nr; ++k) { w[k] = MASS(rmass, rms, ridx[k]); sum_w += w[k]; }
+        ACC(sum_w);
+        for (size_t k = 0; k < nr; ++k) { w[k] = MASS(rmass, rms, ridx[k]); ADD(sum_w, w[k]); }
+        if (g_acc64) sum_w = (float)sum_w_d;
         float t[3];
         go_kabsch_rmsd(rc, cc, w, nr, rbc, cbc, sum_w, R, t, rmsd);
         free(w);
@@ -836,10 +854,12 @@ double go_baseline_rmsd_fit(float *frames, size_t n_frames, size_t n_atoms,
     for (size_t i = 0; i < n_atoms; ++i) all[i] = i;
     /* RMSDConverterAnalyzer::new -- once, untimed */
     float *rc = (float *)malloc(3 * (n_atoms + 1) * sizeof(float));
-    float rbc[3], ref_com[3], sum_w = 0.0f;
+    float rbc[3], ref_com[3];
+    ACC(sum_w);
     uint64_t err0;
     if (go_rmsd_extract(ref_xyz, 12, masses, 4, all, n_atoms, box9, rc, rbc, &err0) != GO_OK) { free(all); free(rc); return -1.0; }
-    for (size_t i = 0; i < n_atoms; ++i) sum_w += masses[i];
+    for (size_t i = 0; i < n_atoms; ++i) ADD(sum_w, masses[i]);
+    if (g_acc64) sum_w = (float)sum_w_d;
     go_get_center(ref_xyz, 12, masses, 4, all, n_atoms, box9, ref_com, &err0);
     double worst = 0.0;
 #ifdef _OPENMP

@@ -50,6 +50,10 @@ enum { GO_DIM_NONE = 0, GO_DIM_X, GO_DIM_Y, GO_DIM_Z, GO_DIM_XY, GO_DIM_XZ, GO_D
 /* when non-zero, non-orthogonal boxes are rejected with GO_E_NOT_ORTHOGONAL exactly as the
  * reference does (simbox_check, simbox.rs:230-236).  Default 0 = triclinic extension enabled. */
 void go_set_strict_orthogonal(int on);
+/* 0 (default): long sums in f32, sequentially, exactly like the reference.  1: the same f32 terms summed
+ * in double (the reference's own sequential-f32 rounding grows ~S*2^-24 and passes 1e-5 nm beyond a few
+ * thousand atoms; large-S GPU parity is checked against mode 1, and mode 0 is bounded against mode 1). */
+void go_set_accumulate_f64(int on);
 
 /* ---- scalar/vector primitives (src/structures/vector3d.rs) ---- */
 float go_floor_mod(float x, float y);                         /* :28-30  */

@@ -76,6 +76,21 @@ def set_strict_orthogonal(on):
     lib().go_set_strict_orthogonal(C.c_int(int(on)))
 
 
+def set_accumulate_f64(on):
+    """long sums in double instead of the reference's sequential f32 (see groan_oracle.h)"""
+    lib().go_set_accumulate_f64(C.c_int(int(on)))
+
+
+class acc64:
+    """with O.acc64(): ... -> oracle sums in double inside the block"""
+
+    def __enter__(self):
+        set_accumulate_f64(True)
+
+    def __exit__(self, *a):
+        set_accumulate_f64(False)
+
+
 # ---------------- primitives ----------------
 def wrap(p, box):
     p = _f(p).copy(); b = _box(box)
