@@ -59,8 +59,8 @@ struct gr_ctx {
     // per-kernel HIP-event profile of the batched RMSD path (gr_profile_*): 0 accumulate, 1 finalize, 2 fit
     hipEvent_t pev[4 * GR_MAX_BATCH] = {};
     // launch geometry of the batched RMSD path (env GR_SUB_BATCH / GR_CHUNKS / GR_FIT_WGS override)
-    uint32_t sub_batch = 8;     // frames per accumulate->finalize->fit group: keeps the group's frames in the
-                                // 256 MiB Infinity Cache so the fit pass re-reads them on-die, not from HBM
+    uint32_t sub_batch = 64;    // frames per accumulate->finalize->fit group (measured: 64 > 32 > 16 > 8; the fit pass gains
+                                // nothing from re-reading a small group out of the Infinity Cache, small launches lose to ramp-up)
     uint32_t chunks = 0;        // workgroups per frame in the reductions (0 = auto)
     uint32_t fit_wgs = 0;       // workgroups per frame in k_fit (0 = auto)
     int profile = 0;
@@ -104,7 +104,7 @@ int fail(gr_ctx *c, int status, const std::string &msg, uint64_t index = 0) {
 
 GrSel make_sel(const Group &g) {
     GrSel s;
-    s.n = (uint32_t)g.n; s.contiguous = g.contiguous ? 1u : 0u; s.start = g.start; s.g0 = g.start >> 2; s.idx = g.idx_dev;
+    s.n = (uint32_t)g.n; s.contiguous = g.contiguous ? 1u : 0u; s.start = g.start; s.g0 = g.start >> 8; s.idx = g.idx_dev;
     return s;
 }
 
@@ -276,7 +276,7 @@ gr_ctx *gr_ctx_create(int device, uint64_t n_atoms, uint32_t n_slots, int *statu
     if (n_atoms == 0 || n_atoms > 0xFFFFFFF0ull || n_slots == 0) { *status = GR_E_INVALID_ARG; return nullptr; }
     if (hipSetDevice(device) != hipSuccess) { *status = GR_E_NO_DEVICE; return nullptr; }
     gr_ctx *c = new gr_ctx();
-    c->device = device; c->n = n_atoms; c->n_pad = (n_atoms + 3) & ~3ull; c->n_slots = n_slots;
+    c->device = device; c->n = n_atoms; c->n_pad = (n_atoms + 255) & ~255ull; c->n_slots = n_slots;   // whole 256-atom wave tiles
     c->frame_stride = (size_t)c->n_pad * 3;
     bool ok = true;
     ok = ok && hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
@@ -551,7 +551,7 @@ int gr_atoms_distance(gr_ctx *c, uint32_t slot, uint64_t i1, uint64_t i2, int di
     if (i2 >= c->n) return fail(c, GR_E_OUT_OF_RANGE, "atom index out of range", i2);
     st = box_check(c, slot); if (st) return st;
     if (dim < 0 || dim > 7) return fail(c, GR_E_INVALID_ARG, "bad dimension");
-    GrSel s1 = { 1u, 1u, (uint32_t)i1, (uint32_t)i1 >> 2, nullptr }, s2 = { 1u, 1u, (uint32_t)i2, (uint32_t)i2 >> 2, nullptr };
+    GrSel s1 = { 1u, 1u, (uint32_t)i1, (uint32_t)i1 >> 8, nullptr }, s2 = { 1u, 1u, (uint32_t)i2, (uint32_t)i2 >> 8, nullptr };
     if (!c->pd_out) { HIPCHK(c, hipMalloc(&c->pd_out, 16 * sizeof(float))); c->pd_cap = 16; }
     st = pairdist_run(c, slot, s1, s2, dim, c->pd_out); if (st) return st;
     float v = 0.f;
@@ -568,7 +568,7 @@ static int translate_impl(gr_ctx *c, uint32_t slot, const char *group, const flo
     if (g->n == 0) return GR_OK;
     const GrSel sel = make_sel(*g);
     HIPCHK(c, hipMemsetAsync(c->bad_dev, 0xFF, 4 * sizeof(uint32_t), c->stream));
-    const uint64_t units = sel.contiguous ? ((uint64_t)sel.n + 3) / 4 + 1 : sel.n;
+    const uint64_t units = sel.contiguous ? ((uint64_t)sel.n + 3) / 4 + 128 : sel.n;
     uint32_t nwg = (uint32_t)std::min<uint64_t>((units + GR_WG - 1) / GR_WG, 4096);
     k_translate_wrap<<<dim3(nwg), dim3(GR_WG), 0, c->stream>>>(c->frames + (size_t)slot * c->frame_stride, sel, c->boxes_dev + slot, c->state_dev, use_state, dim_mask, v ? v[0] : 0.f, v ? v[1] : 0.f, v ? v[2] : 0.f, c->bad_dev);
     HIPCHK(c, hipGetLastError());
@@ -634,8 +634,8 @@ gr_rmsd_plan *gr_rmsd_plan_create(gr_ctx *ref, uint32_t ref_slot, gr_ctx *target
     if (st) { *status = st; return nullptr; }
     gr_rmsd_plan *p = new gr_rmsd_plan();
     p->target = target; p->group = group; p->n_ref = g->n;
-    const uint32_t pofs = sel.contiguous ? (sel.start & 3u) : 0u;
-    const size_t s_pad = ((size_t)g->n + pofs + 7) & ~(size_t)3;
+    const uint32_t pofs = sel.contiguous ? (sel.start & 255u) : 0u;   // tiles of p line up with the frame's tiles
+    const size_t s_pad = ((size_t)g->n + pofs + 511) & ~(size_t)255;
     bool ok = hipMalloc(&p->p_dev, s_pad * 3 * sizeof(float)) == hipSuccess && hipMalloc(&p->w_dev, s_pad * sizeof(float)) == hipSuccess;
     if (ok) ok = hipMemsetAsync(p->p_dev, 0, s_pad * 3 * sizeof(float), ref->stream) == hipSuccess &&
                  hipMemsetAsync(p->w_dev, 0, s_pad * sizeof(float), ref->stream) == hipSuccess;

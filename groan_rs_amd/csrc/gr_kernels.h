@@ -3,12 +3,19 @@
 //
 // Data layout in HBM
 //   frame slot : float xyz[n_pad][3]  (packed 12-byte records exactly as the xtc decoders deliver
-//                them, n_pad = n_atoms rounded up to 4 so 4 atoms = 3 aligned float4 loads)
+//                them; n_pad = n_atoms rounded up to 256 = one wavefront tile)
 //   masses     : float m[n_pad]       (separate array; NaN = no mass)
-//   selection  : one contiguous block  -> {start, n}            (vector path, 4 atoms / lane / trip)
+//   selection  : one contiguous block  -> {start, n}            (tile path, 4 atoms / lane / trip)
 //                anything else         -> uint32 idx[n] in HBM  (gather path, 1 atom / lane / trip)
 //   plan       : float p[s_pad][3] (reference coordinates minus the reference box centre, stored so
-//                that the float4 groups of p line up with the float4 groups of the frame), float w[s_pad]
+//                that the 256-atom tiles of p line up with the tiles of the frame), float w[s_pad]
+//
+// Tile path: a wavefront moves 256 atoms = 3 KiB as three fully contiguous 1-KiB wave loads/stores
+// (16 B per lane) and transposes through its own LDS tile so that lane L ends up with atoms 4L..4L+3.
+// Measured on MI355X for a streaming read-modify-write of 64 x 1e6 atoms (tools/layout_bench.hip):
+//   lanes striding 48 B over packed records 4.7-4.9 TB/s | three planes x[] y[] z[] 5.5-5.6 TB/s |
+//   packed records + LDS transpose 5.8-5.9 TB/s  -> packed xyz stays the HBM layout (no transpose at
+//   ingest either), and the LDS tile is how it is read.
 //
 // Reductions: per-lane fp64 accumulators -> wave __shfl_down tree -> LDS across the 4 waves of a
 // workgroup -> one partial record per workgroup in HBM -> a one-workgroup finalize kernel sums the
@@ -25,7 +32,7 @@ struct GrSel {
     uint32_t n;            // atoms in the selection
     uint32_t contiguous;   // 1: atoms start .. start+n-1
     uint32_t start;        // first atom (contiguous) / first atom of idx (gather)
-    uint32_t g0;           // contiguous: first float4 group (start / 4)
+    uint32_t g0;           // contiguous: first 256-atom tile (start / 256)
     const uint32_t *idx;   // gather list (device), NULL when contiguous
 };
 
@@ -111,20 +118,50 @@ __device__ __forceinline__ void gr_stage_box(GrBox *lds_box, const GrBox *g) {
     __syncthreads();
 }
 
+// ------------------------------------------------------------------------------------------ wave tiles
+#define GR_TILE_ATOMS 256
+#define GR_TILE_F4 192
+__device__ __forceinline__ void gr_wave_sync() {
+    // LDS operations of one wavefront execute in order; this only stops the compiler from moving
+    // LDS accesses across the point where lanes exchange data
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// src = first float4 of a 256-atom tile in HBM; on return lane L holds atoms 4L..4L+3 of the tile:
+// (a.x a.y a.z) (a.w b.x b.y) (b.z b.w c.x) (c.y c.z c.w)
+__device__ __forceinline__ void gr_tile_load(const float4 *__restrict__ src, float4 *tile, uint32_t lane, float4 &a, float4 &b, float4 &c) {
+    const float4 r0 = src[lane], r1 = src[lane + 64], r2 = src[lane + 128];
+    tile[lane] = r0; tile[lane + 64] = r1; tile[lane + 128] = r2;
+    gr_wave_sync();
+    a = tile[3 * lane]; b = tile[3 * lane + 1]; c = tile[3 * lane + 2];
+    gr_wave_sync();
+}
+__device__ __forceinline__ void gr_tile_store(float4 *__restrict__ dst, float4 *tile, uint32_t lane, const float4 &a, const float4 &b, const float4 &c) {
+    tile[3 * lane] = a; tile[3 * lane + 1] = b; tile[3 * lane + 2] = c;
+    gr_wave_sync();
+    const float4 r0 = tile[lane], r1 = tile[lane + 64], r2 = tile[lane + 128];
+    dst[lane] = r0; dst[lane + 64] = r1; dst[lane + 128] = r2;
+    gr_wave_sync();
+}
+
 // ------------------------------------------------------------------------------------------ atom streams
 // Calls f(atom_index, ordinal, x, y, z) for every atom of the selection handled by this workgroup.
 // Workgroup `chunk` of `nchunks` takes an interleaved share (grid-stride) so consecutive lanes
 // always touch consecutive memory.
 template <typename F>
 __device__ __forceinline__ void gr_for_each_atom(const GrSel &sel, const float *__restrict__ xyz,
-                                                 uint32_t chunk, uint32_t nchunks, F f) {
+                                                 uint32_t chunk, uint32_t nchunks, float4 *tiles, F f) {
     if (sel.contiguous) {
         const uint32_t first = sel.start, last = sel.start + sel.n;   // [first, last)
-        const uint32_t g0 = sel.g0, g1 = (last + 3u) >> 2;            // float4 groups [g0, g1)
+        const uint32_t t0 = first >> 8, t1 = (last + 255u) >> 8;      // tiles [t0, t1)
+        const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        float4 *tile = tiles + wave * GR_TILE_F4;
         const float4 *f4 = reinterpret_cast<const float4 *>(xyz);
-        for (uint32_t g = g0 + chunk * GR_WG + threadIdx.x; g < g1; g += nchunks * GR_WG) {
-            const float4 a = f4[3 * (size_t)g], b = f4[3 * (size_t)g + 1], c = f4[3 * (size_t)g + 2];
-            const uint32_t i = g << 2;
+        for (uint32_t t = t0 + chunk * (GR_WG / 64) + wave; t < t1; t += nchunks * (GR_WG / 64)) {
+            float4 a, b, c;
+            gr_tile_load(f4 + (size_t)t * GR_TILE_F4, tile, lane, a, b, c);
+            const uint32_t i = (t << 8) + (lane << 2);
             if (i >= first && i < last) f(i, i - first, a.x, a.y, a.z);
             if (i + 1 >= first && i + 1 < last) f(i + 1, i + 1 - first, a.w, b.x, b.y);
             if (i + 2 >= first && i + 2 < last) f(i + 2, i + 2 - first, b.z, b.w, c.x);
@@ -154,6 +191,7 @@ __global__ __launch_bounds__(GR_WG) void k_center_sums(
     __shared__ GrBox box;
     __shared__ double lds[(GR_WG / 64) * GR_CEN_K];
     __shared__ uint32_t ldsu[GR_WG / 64];
+    __shared__ float4 tiles[(GR_WG / 64) * GR_TILE_F4];
     const uint32_t frame = blockIdx.y, chunk = blockIdx.x, nchunks = gridDim.x;
     const float *xyz = frames + (size_t)(first_slot + frame) * frame_stride;
     gr_stage_box(&box, boxes + first_slot + frame);
@@ -165,7 +203,7 @@ __global__ __launch_bounds__(GR_WG) void k_center_sums(
     const float scx = PI_X2 / box.ax, scy = PI_X2 / box.by, scz = PI_X2 / box.cz;
     float cx = 0.f, cy = 0.f, cz = 0.f;
     if (kind == 2) { cx = state[frame].center[0]; cy = state[frame].center[1]; cz = state[frame].center[2]; }
-    gr_for_each_atom(sel, xyz, chunk, nchunks, [&](uint32_t i, uint32_t, float x, float y, float z) {
+    gr_for_each_atom(sel, xyz, chunk, nchunks, tiles, [&](uint32_t i, uint32_t, float x, float y, float z) {
         float m = 1.0f;
         if (weighted) { m = masses[i]; if (m != m) { bad_mass = min(bad_mass, i); m = 0.0f; } }
         if (x != x) { bad_pos = min(bad_pos, i); return; }
@@ -308,15 +346,18 @@ __global__ __launch_bounds__(GR_WG) void k_rmsd_accum(
     const bool tric = !box.ortho;
     float fsum[6] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
 
-    // Four atoms at a time: the 26 products-sums of the four atoms are formed in f32 (the operands are
-    // centred, |v|,|p| <= half a box, so a 4-term f32 sum carries ~1e-7 relative rounding, random in
-    // sign) and only the 4-atom partial is added to the fp64 accumulators: 6.5 instead of 26 fp64 adds
-    // per atom.  The long sum -- where sequential f32 loses digits -- stays in fp64.
+    // Precision plan.  rmsd^2 is the small difference of sums of size W r^2 (it must come out ~0 for a frame
+    // that is a rigid copy of the reference: the reference's own tests ask |rmsd| <= 1e-4 there, i.e. 1e-9
+    // relative on those sums), so everything that enters it -- B = sum (w p) v^T, sum w|v|^2, sum w v, sum m,
+    // sum m v -- uses exact products (f32 x f32 is exact in fp64) and fp64 sums.  The unweighted covariance A
+    // only steers the rotation; it is formed as a 4-atom f32 partial (operands are centred, ~1e-7 relative,
+    // random in sign) that is then added to its fp64 accumulator: 2.25 instead of 9 fp64 adds per atom.
     struct A4 { float x[4], y[4], z[4], m[4], px[4], py[4], pz[4], w[4]; uint32_t i[4]; bool ok[4]; };
+    const bool wm = plan.w_is_mass != 0;
     auto flush4 = [&](const A4 &a) {
-        float part[26];
+        float part[9];
 #pragma unroll
-        for (int k = 0; k < 26; ++k) part[k] = 0.0f;
+        for (int k = 0; k < 9; ++k) part[k] = 0.0f;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             if (!a.ok[q]) continue;
@@ -349,29 +390,31 @@ __global__ __launch_bounds__(GR_WG) void k_rmsd_accum(
             }
             mn[0] = fminf(mn[0], vx); mn[1] = fminf(mn[1], vy); mn[2] = fminf(mn[2], vz);
             mx[0] = fmaxf(mx[0], vx); mx[1] = fmaxf(mx[1], vy); mx[2] = fmaxf(mx[2], vz);
-            const float px = a.px[q], py = a.py[q], pz = a.pz[q], w = a.w[q];
-            part[0] += m;
-            part[1] = fmaf(m, vx, part[1]); part[2] = fmaf(m, vy, part[2]); part[3] = fmaf(m, vz, part[3]);
-            part[4] = fmaf(px, vx, part[4]); part[5] = fmaf(px, vy, part[5]); part[6] = fmaf(px, vz, part[6]);
-            part[7] = fmaf(py, vx, part[7]); part[8] = fmaf(py, vy, part[8]); part[9] = fmaf(py, vz, part[9]);
-            part[10] = fmaf(pz, vx, part[10]); part[11] = fmaf(pz, vy, part[11]); part[12] = fmaf(pz, vz, part[12]);
-            const float wpx = w * px, wpy = w * py, wpz = w * pz;
-            part[13] = fmaf(wpx, vx, part[13]); part[14] = fmaf(wpx, vy, part[14]); part[15] = fmaf(wpx, vz, part[15]);
-            part[16] = fmaf(wpy, vx, part[16]); part[17] = fmaf(wpy, vy, part[17]); part[18] = fmaf(wpy, vz, part[18]);
-            part[19] = fmaf(wpz, vx, part[19]); part[20] = fmaf(wpz, vy, part[20]); part[21] = fmaf(wpz, vz, part[21]);
-            const float wvx = w * vx, wvy = w * vy, wvz = w * vz;
-            part[22] = fmaf(wvx, vx, fmaf(wvy, vy, fmaf(wvz, vz, part[22])));
-            part[23] += wvx; part[24] += wvy; part[25] += wvz;
+            const float px = a.px[q], py = a.py[q], pz = a.pz[q];
+            part[0] = fmaf(px, vx, part[0]); part[1] = fmaf(px, vy, part[1]); part[2] = fmaf(px, vz, part[2]);
+            part[3] = fmaf(py, vx, part[3]); part[4] = fmaf(py, vy, part[4]); part[5] = fmaf(py, vz, part[5]);
+            part[6] = fmaf(pz, vx, part[6]); part[7] = fmaf(pz, vy, part[7]); part[8] = fmaf(pz, vz, part[8]);
+            const double dvx = vx, dvy = vy, dvz = vz, dm = m, dw = a.w[q];
+            const double wpx = dw * (double)px, wpy = dw * (double)py, wpz = dw * (double)pz;
+            acc[0] += dm;
+            acc[1] = fma(dm, dvx, acc[1]); acc[2] = fma(dm, dvy, acc[2]); acc[3] = fma(dm, dvz, acc[3]);
+            acc[13] = fma(wpx, dvx, acc[13]); acc[14] = fma(wpx, dvy, acc[14]); acc[15] = fma(wpx, dvz, acc[15]);
+            acc[16] = fma(wpy, dvx, acc[16]); acc[17] = fma(wpy, dvy, acc[17]); acc[18] = fma(wpy, dvz, acc[18]);
+            acc[19] = fma(wpz, dvx, acc[19]); acc[20] = fma(wpz, dvy, acc[20]); acc[21] = fma(wpz, dvz, acc[21]);
+            acc[22] = fma(dw, fma(dvx, dvx, fma(dvy, dvy, dvz * dvz)), acc[22]);
+            if (!wm) { acc[23] = fma(dw, dvx, acc[23]); acc[24] = fma(dw, dvy, acc[24]); acc[25] = fma(dw, dvz, acc[25]); }
         }
 #pragma unroll
-        for (int k = 0; k < 26; ++k) acc[k] += (double)part[k];
+        for (int k = 0; k < 9; ++k) acc[4 + k] += (double)part[k];
     };
 
     if (sel.contiguous) {
-        // 4 atoms per lane per trip: 3 float4 of positions, 3 float4 of reference coordinates,
-        // 1 float4 of masses (+1 of weights when they differ from the masses)
+        // 4 atoms per lane per trip: 3 float4 of positions, 3 float4 of reference coordinates, 1 float4 of masses
+        // (+1 of weights when they differ from the masses).  Read-only streams: lanes striding 48 B over the packed
+        // records re-touch each line from L1/L2 at no measurable cost (unlike the read-modify-write of k_fit, which
+        // goes through the LDS tile); the direct loads keep 7 independent 16-B loads per lane in flight.
         const uint32_t first = sel.start, last = sel.start + sel.n;
-        const uint32_t g0 = sel.g0, g1 = (last + 3u) >> 2;
+        const uint32_t g0 = sel.g0 << 6, g1 = (last + 3u) >> 2;      // float4 groups [g0, g1): g0 = first group of the first tile
         const float4 *f4 = reinterpret_cast<const float4 *>(xyz);
         const float4 *p4 = reinterpret_cast<const float4 *>(plan.p);
         const float4 *m4 = reinterpret_cast<const float4 *>(masses);
@@ -381,18 +424,18 @@ __global__ __launch_bounds__(GR_WG) void k_rmsd_accum(
             const size_t pg = (size_t)(g - g0);
             const float4 pa = p4[3 * pg], pb = p4[3 * pg + 1], pc = p4[3 * pg + 2];
             const float4 mm = m4[g];
-            const float4 ww = plan.w_is_mass ? mm : w4[pg];
+            const float4 ww = wm ? mm : w4[pg];
             const uint32_t i = g << 2;
-            A4 t;
-            t.x[0] = a.x; t.y[0] = a.y; t.z[0] = a.z; t.x[1] = a.w; t.y[1] = b.x; t.z[1] = b.y;
-            t.x[2] = b.z; t.y[2] = b.w; t.z[2] = c.x; t.x[3] = c.y; t.y[3] = c.z; t.z[3] = c.w;
-            t.px[0] = pa.x; t.py[0] = pa.y; t.pz[0] = pa.z; t.px[1] = pa.w; t.py[1] = pb.x; t.pz[1] = pb.y;
-            t.px[2] = pb.z; t.py[2] = pb.w; t.pz[2] = pc.x; t.px[3] = pc.y; t.py[3] = pc.z; t.pz[3] = pc.w;
-            t.m[0] = mm.x; t.m[1] = mm.y; t.m[2] = mm.z; t.m[3] = mm.w;
-            t.w[0] = ww.x; t.w[1] = ww.y; t.w[2] = ww.z; t.w[3] = ww.w;
+            A4 q;
+            q.x[0] = a.x; q.y[0] = a.y; q.z[0] = a.z; q.x[1] = a.w; q.y[1] = b.x; q.z[1] = b.y;
+            q.x[2] = b.z; q.y[2] = b.w; q.z[2] = c.x; q.x[3] = c.y; q.y[3] = c.z; q.z[3] = c.w;
+            q.px[0] = pa.x; q.py[0] = pa.y; q.pz[0] = pa.z; q.px[1] = pa.w; q.py[1] = pb.x; q.pz[1] = pb.y;
+            q.px[2] = pb.z; q.py[2] = pb.w; q.pz[2] = pc.x; q.px[3] = pc.y; q.py[3] = pc.z; q.pz[3] = pc.w;
+            q.m[0] = mm.x; q.m[1] = mm.y; q.m[2] = mm.z; q.m[3] = mm.w;
+            q.w[0] = ww.x; q.w[1] = ww.y; q.w[2] = ww.z; q.w[3] = ww.w;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { t.i[q] = i + q; t.ok[q] = (i + q >= first) && (i + q < last); }
-            flush4(t);
+            for (int k = 0; k < 4; ++k) { q.i[k] = i + k; q.ok[k] = (i + k >= first) && (i + k < last); }
+            flush4(q);
         }
     } else {
         const uint32_t n4 = (sel.n + 3u) >> 2;
@@ -414,6 +457,7 @@ __global__ __launch_bounds__(GR_WG) void k_rmsd_accum(
     }
 #pragma unroll
     for (int k = 0; k < 6; ++k) acc[26 + k] = (double)fsum[k];
+    if (wm) { acc[23] = acc[1]; acc[24] = acc[2]; acc[25] = acc[3]; }   // sum w v == sum m v
     gr_block_sum<GR_ACC_K>(acc, lds);
     bad_pos = gr_block_min_u32(bad_pos, ldsu);
     bad_mass = gr_block_min_u32(bad_mass, ldsu);
@@ -609,16 +653,16 @@ __global__ __launch_bounds__(GR_WG) void k_fit(
         const float nz = r20 * x + r21 * y + r22 * z;
         x = nx + cx; y = ny + cy; z = nz + cz;
     };
+    __shared__ float4 tiles[(GR_WG / 64) * GR_TILE_F4];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float4 *tile = tiles + wave * GR_TILE_F4;
     float4 *f4 = reinterpret_cast<float4 *>(xyz);
-    const uint32_t ngroups = n_atoms >> 2;   // whole float4 groups
-    for (uint32_t g = blockIdx.x * GR_WG + threadIdx.x; g < ngroups; g += gridDim.x * GR_WG) {
-        float4 a = f4[3 * (size_t)g], b = f4[3 * (size_t)g + 1], c = f4[3 * (size_t)g + 2];
+    const uint32_t ntiles = (n_atoms + 255u) >> 8;   // the slot is padded to whole tiles; pad atoms are transformed too (harmless)
+    for (uint32_t t = blockIdx.x * (GR_WG / 64) + wave; t < ntiles; t += gridDim.x * (GR_WG / 64)) {
+        float4 a, b, c;
+        gr_tile_load(f4 + (size_t)t * GR_TILE_F4, tile, lane, a, b, c);
         tf(a.x, a.y, a.z); tf(a.w, b.x, b.y); tf(b.z, b.w, c.x); tf(c.y, c.z, c.w);
-        f4[3 * (size_t)g] = a; f4[3 * (size_t)g + 1] = b; f4[3 * (size_t)g + 2] = c;
-    }
-    if (blockIdx.x == 0) {   // tail atoms (n_atoms % 4)
-        const uint32_t i = (ngroups << 2) + threadIdx.x;
-        if (i < n_atoms) { float x = xyz[3 * (size_t)i], y = xyz[3 * (size_t)i + 1], z = xyz[3 * (size_t)i + 2]; tf(x, y, z); xyz[3 * (size_t)i] = x; xyz[3 * (size_t)i + 1] = y; xyz[3 * (size_t)i + 2] = z; }
+        gr_tile_store(f4 + (size_t)t * GR_TILE_F4, tile, lane, a, b, c);
     }
 }
 
@@ -631,12 +675,13 @@ __global__ __launch_bounds__(GR_WG) void k_plan_extract(
     GrCenPartial *__restrict__ partials) {
     __shared__ GrBox box;
     __shared__ double lds[(GR_WG / 64) * GR_CEN_K];
+    __shared__ float4 tiles[(GR_WG / 64) * GR_TILE_F4];
     gr_stage_box(&box, boxp);
     const float sx = state->shift[0], sy = state->shift[1], sz = state->shift[2];
     double acc[GR_CEN_K];
 #pragma unroll
     for (int k = 0; k < GR_CEN_K; ++k) acc[k] = 0.0;
-    gr_for_each_atom(sel, xyz, blockIdx.x, gridDim.x, [&](uint32_t i, uint32_t j, float x, float y, float z) {
+    gr_for_each_atom(sel, xyz, blockIdx.x, gridDim.x, tiles, [&](uint32_t i, uint32_t j, float x, float y, float z) {
         x += sx; y += sy; z += sz;
         gr_wrap(x, y, z, box);
         x -= box.bcx; y -= box.bcy; z -= box.bcz;
@@ -664,6 +709,7 @@ __global__ __launch_bounds__(GR_WG) void k_translate_wrap(
     int use_state_shift, int dim_mask, float tx, float ty, float tz, uint32_t *__restrict__ bad_out) {
     __shared__ GrBox box;
     __shared__ uint32_t ldsu[GR_WG / 64];
+    __shared__ float4 tiles[(GR_WG / 64) * GR_TILE_F4];
     gr_stage_box(&box, boxp);
     if (use_state_shift) {   // atoms_center: shift = filter(box centre - estimated centre, dim) (utility.rs:116-119)
         if (state->status != 0) return;
@@ -679,16 +725,19 @@ __global__ __launch_bounds__(GR_WG) void k_translate_wrap(
     };
     if (sel.contiguous) {
         const uint32_t first = sel.start, last = sel.start + sel.n;
-        const uint32_t g1 = (last + 3u) >> 2;
+        const uint32_t t0 = first >> 8, t1 = (last + 255u) >> 8;
+        const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        float4 *tile = tiles + wave * GR_TILE_F4;
         float4 *f4 = reinterpret_cast<float4 *>(xyz);
-        for (uint32_t g = sel.g0 + blockIdx.x * GR_WG + threadIdx.x; g < g1; g += gridDim.x * GR_WG) {
-            float4 a = f4[3 * (size_t)g], b = f4[3 * (size_t)g + 1], c = f4[3 * (size_t)g + 2];
-            const uint32_t i = g << 2;
+        for (uint32_t t = t0 + blockIdx.x * (GR_WG / 64) + wave; t < t1; t += gridDim.x * (GR_WG / 64)) {
+            float4 a, b, c;
+            gr_tile_load(f4 + (size_t)t * GR_TILE_F4, tile, lane, a, b, c);
+            const uint32_t i = (t << 8) + (lane << 2);
             if (i >= first && i < last) tf(i, a.x, a.y, a.z);
             if (i + 1 >= first && i + 1 < last) tf(i + 1, a.w, b.x, b.y);
             if (i + 2 >= first && i + 2 < last) tf(i + 2, b.z, b.w, c.x);
             if (i + 3 >= first && i + 3 < last) tf(i + 3, c.y, c.z, c.w);
-            f4[3 * (size_t)g] = a; f4[3 * (size_t)g + 1] = b; f4[3 * (size_t)g + 2] = c;
+            gr_tile_store(f4 + (size_t)t * GR_TILE_F4, tile, lane, a, b, c);
         }
     } else {
         for (uint32_t j = blockIdx.x * GR_WG + threadIdx.x; j < sel.n; j += gridDim.x * GR_WG) {

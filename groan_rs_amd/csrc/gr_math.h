@@ -37,24 +37,39 @@ struct GrBox {
     float cand[GR_MAX_CAND][3];
 };
 
-// literal loops of the reference for the first iterations (bit-identical in the common case of a
-// few box lengths), closed form beyond that so a far-away coordinate cannot stall a wavefront
+// Closed forms of the reference's loops (`while w > L: w -= L; while w < 0: w += L`, vector3d.rs:398-417):
+//   t > L : k = ceil(t/L) - 1   (result in (0, L], the upper end stays closed exactly as in the reference)
+//   t < 0 : k = floor(t/L)      (result in [0, L))
+// followed by one conditional correction each way for the case where the f32 quotient rounded across an
+// integer.  For |k| <= 1 this is bit-identical to the loops; beyond that it differs from the repeated f32
+// subtraction by an ulp.  No loop: a far-away coordinate cannot stall or diverge a wavefront.
+GR_HD float gr_wrap_k(float t, float L) {
+    float k = 0.0f;
+    if (t > L) k = ceilf(t / L) - 1.0f;
+    else if (t < 0.0f) k = floorf(t / L);
+    return k;
+}
 GR_HD float gr_wrap_coordinate(float coor, float L) {
-    float w = coor;
-    for (int it = 0; it < 8 && w > L; ++it) w -= L;
-    if (w > L) { w -= L * (ceilf(w / L) - 1.0f); for (int it = 0; it < 2 && w > L; ++it) w -= L; }
-    for (int it = 0; it < 8 && w < 0.0f; ++it) w += L;
-    if (w < 0.0f) { w += L * ceilf(-w / L); for (int it = 0; it < 2 && w < 0.0f; ++it) w += L; }
+    const float k = gr_wrap_k(coor, L);
+    float w = (k == 1.0f) ? coor - L : ((k == -1.0f) ? coor + L : coor - k * L);
+    if (w > L) w -= L;
+    if (w < 0.0f) w += L;
     return w;
 }
 
+// `while d > L/2: d -= L; while d < -L/2: d += L` (vector3d.rs:575-592): result in [-L/2, L/2]
+GR_HD float gr_minimg_k(float d, float L, float h) {
+    float k = 0.0f;
+    if (d > h) k = ceilf((d - h) / L);
+    else if (d < -h) k = -ceilf((-h - d) / L);
+    return k;
+}
 GR_HD float gr_min_image(float dx, float L) {
     const float h = L / 2.0f;
-    float d = dx;
-    for (int it = 0; it < 8 && d > h; ++it) d -= L;
-    if (d > h) { d -= L * ceilf((d - h) / L); for (int it = 0; it < 2 && d > h; ++it) d -= L; }
-    for (int it = 0; it < 8 && d < -h; ++it) d += L;
-    if (d < -h) { d += L * ceilf((-h - d) / L); for (int it = 0; it < 2 && d < -h; ++it) d += L; }
+    const float k = gr_minimg_k(dx, L, h);
+    float d = (k == 1.0f) ? dx - L : ((k == -1.0f) ? dx + L : dx - k * L);
+    if (d > h) d -= L;
+    if (d < -h) d += L;
     return d;
 }
 
@@ -81,16 +96,15 @@ GR_HD void gr_wrap(float &x, float &y, float &z, const GrBox &b) {
         z = gr_wrap_coordinate(z, b.cz);
         return;
     }
-    // along c
-    for (int it = 0; it < 8 && z > b.cz; ++it) { x -= b.cx; y -= b.cy; z -= b.cz; }
-    if (z > b.cz) { float k = ceilf(z / b.cz) - 1.0f; x -= k * b.cx; y -= k * b.cy; z -= k * b.cz; }
-    for (int it = 0; it < 8 && z < 0.0f; ++it) { x += b.cx; y += b.cy; z += b.cz; }
-    if (z < 0.0f) { float k = ceilf(-z / b.cz); x += k * b.cx; y += k * b.cy; z += k * b.cz; }
-    // along b
-    for (int it = 0; it < 8 && y > b.by; ++it) { x -= b.bx; y -= b.by; }
-    if (y > b.by) { float k = ceilf(y / b.by) - 1.0f; x -= k * b.bx; y -= k * b.by; }
-    for (int it = 0; it < 8 && y < 0.0f; ++it) { x += b.bx; y += b.by; }
-    if (y < 0.0f) { float k = ceilf(-y / b.by); x += k * b.bx; y += k * b.by; }
+    // along c, then b, then a
+    float k = gr_wrap_k(z, b.cz);
+    x -= k * b.cx; y -= k * b.cy; z -= k * b.cz;
+    if (z > b.cz) { x -= b.cx; y -= b.cy; z -= b.cz; }
+    if (z < 0.0f) { x += b.cx; y += b.cy; z += b.cz; }
+    k = gr_wrap_k(y, b.by);
+    x -= k * b.bx; y -= k * b.by;
+    if (y > b.by) { x -= b.bx; y -= b.by; }
+    if (y < 0.0f) { x += b.bx; y += b.by; }
     x = gr_wrap_coordinate(x, b.ax);
 }
 
@@ -103,14 +117,14 @@ GR_HD void gr_min_image_vec(float &dx, float &dy, float &dz, const GrBox &b) {
         return;
     }
     const float hz = b.cz / 2.0f, hy = b.by / 2.0f;
-    for (int it = 0; it < 8 && dz > hz; ++it) { dx -= b.cx; dy -= b.cy; dz -= b.cz; }
-    if (dz > hz) { float k = ceilf((dz - hz) / b.cz); dx -= k * b.cx; dy -= k * b.cy; dz -= k * b.cz; }
-    for (int it = 0; it < 8 && dz < -hz; ++it) { dx += b.cx; dy += b.cy; dz += b.cz; }
-    if (dz < -hz) { float k = ceilf((-hz - dz) / b.cz); dx += k * b.cx; dy += k * b.cy; dz += k * b.cz; }
-    for (int it = 0; it < 8 && dy > hy; ++it) { dx -= b.bx; dy -= b.by; }
-    if (dy > hy) { float k = ceilf((dy - hy) / b.by); dx -= k * b.bx; dy -= k * b.by; }
-    for (int it = 0; it < 8 && dy < -hy; ++it) { dx += b.bx; dy += b.by; }
-    if (dy < -hy) { float k = ceilf((-hy - dy) / b.by); dx += k * b.bx; dy += k * b.by; }
+    float k = gr_minimg_k(dz, b.cz, hz);
+    dx -= k * b.cx; dy -= k * b.cy; dz -= k * b.cz;
+    if (dz > hz) { dx -= b.cx; dy -= b.cy; dz -= b.cz; }
+    if (dz < -hz) { dx += b.cx; dy += b.cy; dz += b.cz; }
+    k = gr_minimg_k(dy, b.by, hy);
+    dx -= k * b.bx; dy -= k * b.by;
+    if (dy > hy) { dx -= b.bx; dy -= b.by; }
+    if (dy < -hy) { dx += b.bx; dy += b.by; }
     dx = gr_min_image(dx, b.ax);
     gr_tric_refine(dx, dy, dz, b);
 }
