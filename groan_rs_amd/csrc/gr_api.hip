@@ -17,7 +17,7 @@
 #include "gr_container.h"
 #include "gr_kernels.h"
 
-#define GR_MAX_BATCH 64      // frames per batched launch (workspace is sized for this)
+#define GR_MAX_BATCH 256     // frames per batched call segment (workspace is sized for this)
 #define GR_MAX_CHUNKS 256    // workgroups per frame in the reduction kernels
 
 namespace {
@@ -35,6 +35,10 @@ struct Group {
 struct gr_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;    // second queue: k_fit of group k runs beside k_rmsd_accum of group k+1
+    hipEvent_t ev_grp[GR_MAX_BATCH] = {};   // "finalize of group k done" (stream -> stream2)
+    hipEvent_t ev_join = nullptr;           // "all fits done" (stream2 -> stream)
+    int overlap = 0;   // GR_OVERLAP=1: +5 % frames/s at 256-frame calls (measured), but per-kernel durations then overlap
     uint64_t n = 0, n_pad = 0;
     uint32_t n_slots = 0;
     size_t frame_stride = 0;          // floats per slot
@@ -59,8 +63,9 @@ struct gr_ctx {
     // per-kernel HIP-event profile of the batched RMSD path (gr_profile_*): 0 accumulate, 1 finalize, 2 fit
     hipEvent_t pev[4 * GR_MAX_BATCH] = {};
     // launch geometry of the batched RMSD path (env GR_SUB_BATCH / GR_CHUNKS / GR_FIT_WGS override)
-    uint32_t sub_batch = 64;    // frames per accumulate->finalize->fit group (measured: 64 > 32 > 16 > 8; the fit pass gains
-                                // nothing from re-reading a small group out of the Infinity Cache, small launches lose to ramp-up)
+    uint32_t sub_batch = 64;    // frames per accumulate->finalize->fit group.  k_rmsd_accum is VALU-bound (~70 % VALU busy,
+                                // 13 MB/frame of HBM traffic) and k_fit is HBM-bound (24 MB/frame), so the fit of group k is
+                                // issued on a second stream and shares the chip with the accumulate of group k+1.
     uint32_t chunks = 0;        // workgroups per frame in the reductions (0 = auto)
     uint32_t fit_wgs = 0;       // workgroups per frame in k_fit (0 = auto)
     int profile = 0;
@@ -128,6 +133,12 @@ uint32_t batch_chunks(const gr_ctx *c, const GrSel &s, uint32_t nf) {
     if (want < 4) want = 4;
     uint64_t ch = want < by_work ? want : by_work;
     if (ch > GR_MAX_CHUNKS) ch = GR_MAX_CHUNKS;
+    // XCD-aware: workgroups are dealt round-robin over the 8 XCDs, and block (chunk, frame) has linear id
+    // frame*ch + chunk; with ch a multiple of 8 chunk c lands on XCD c % 8 for EVERY frame, so each XCD's 4 MiB L2
+    // keeps its own eighth of the reference coordinates + masses (16 MB total) resident across all frames of the
+    // launch (measured: 13 MB/frame of HBM fetch for 28 MB/frame algorithmic; chunk counts that are not multiples
+    // of 8 rotate the mapping and run ~25 % slower)
+    if (ch >= 8) ch &= ~(uint64_t)7;
     return (uint32_t)ch;
 }
 
@@ -280,6 +291,10 @@ gr_ctx *gr_ctx_create(int device, uint64_t n_atoms, uint32_t n_slots, int *statu
     c->frame_stride = (size_t)c->n_pad * 3;
     bool ok = true;
     ok = ok && hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) == hipSuccess;
+    for (int k = 0; k < GR_MAX_BATCH; ++k) ok = ok && hipEventCreateWithFlags(&c->ev_grp[k], hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) == hipSuccess;
+    if (const char *e = getenv("GR_OVERLAP")) c->overlap = atoi(e) ? 1 : 0;
     ok = ok && hipMalloc(&c->frames, (size_t)n_slots * c->frame_stride * sizeof(float)) == hipSuccess;
     ok = ok && hipMalloc(&c->masses, c->n_pad * sizeof(float)) == hipSuccess;
     ok = ok && hipMalloc(&c->boxes_dev, n_slots * sizeof(GrBox)) == hipSuccess;
@@ -332,6 +347,9 @@ void gr_ctx_destroy(gr_ctx *c) {
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     for (int k = 0; k < 4 * GR_MAX_BATCH; ++k) if (c->pev[k]) (void)hipEventDestroy(c->pev[k]);
+    for (int k = 0; k < GR_MAX_BATCH; ++k) if (c->ev_grp[k]) (void)hipEventDestroy(c->ev_grp[k]);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -709,6 +727,7 @@ static int rmsd_batch_impl(gr_rmsd_plan *p, uint32_t first_slot, uint32_t n_fram
             HIPCHK(c, hipMemcpyAsync(c->state_dev, c->state_host, nb * sizeof(GrFrameState), hipMemcpyHostToDevice, c->stream));
             const bool consistent = (g->n == p->n_ref);
             uint32_t n_prof_groups = 0;
+            bool prof_two = false;
             if (!consistent) {
                 // positions and masses of the target are still checked first (extract_data_from_system runs to
                 // completion before number_of_positions_consistent, rmsd.rs:206-214)
@@ -720,6 +739,7 @@ static int rmsd_batch_impl(gr_rmsd_plan *p, uint32_t first_slot, uint32_t n_fram
                 // round trip in between; one state fetch for the whole batch afterwards
                 const uint32_t sb = c->sub_batch;
                 uint32_t ng = 0;
+                const bool two = fit && c->overlap && nb > sb;
                 for (uint32_t f0 = 0; f0 < nb; f0 += sb, ++ng) {
                     const uint32_t nf = std::min<uint32_t>(sb, nb - f0);
                     const uint32_t nch = batch_chunks(c, sel, nf);
@@ -729,13 +749,25 @@ static int rmsd_batch_impl(gr_rmsd_plan *p, uint32_t first_slot, uint32_t n_fram
                     k_rmsd_accum<0><<<dim3(nch, nf), dim3(GR_WG), 0, c->stream>>>(c->frames, c->frame_stride, s0 + f0, c->masses, sel, c->boxes_dev, p->dev, c->state_dev + f0, parts);
                     if (c->profile) HIPCHK(c, hipEventRecord(ev[1], c->stream));
                     k_rmsd_finalize<0><<<dim3(nf), dim3(GR_WG), 0, c->stream>>>(parts, nch, c->frames, c->frame_stride, s0 + f0, sel, c->boxes_dev, p->dev, c->state_dev + f0);
-                    if (c->profile) HIPCHK(c, hipEventRecord(ev[2], c->stream));
+                    if (c->profile && !two) HIPCHK(c, hipEventRecord(ev[2], c->stream));
                     if (fit) {
+                        hipStream_t fs = c->stream;
+                        if (two) {
+                            HIPCHK(c, hipEventRecord(c->ev_grp[ng], c->stream));
+                            HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_grp[ng], 0));
+                            fs = c->stream2;
+                            if (c->profile) HIPCHK(c, hipEventRecord(ev[2], fs));
+                        }
                         const uint32_t gx = fit_grid(c, nf);
-                        k_fit<<<dim3(gx, nf), dim3(GR_WG), 0, c->stream>>>(c->frames, c->frame_stride, s0 + f0, (uint32_t)c->n, c->boxes_dev, p->dev, c->state_dev + f0);
-                        if (c->profile) HIPCHK(c, hipEventRecord(ev[3], c->stream));
+                        k_fit<<<dim3(gx, nf), dim3(GR_WG), 0, fs>>>(c->frames, c->frame_stride, s0 + f0, (uint32_t)c->n, c->boxes_dev, p->dev, c->state_dev + f0);
+                        if (c->profile) HIPCHK(c, hipEventRecord(ev[3], fs));
                     }
                 }
+                if (two) {   // join: the state fetch (and the caller) must see every fit finished
+                    HIPCHK(c, hipEventRecord(c->ev_join, c->stream2));
+                    HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
+                }
+                prof_two = two;
                 HIPCHK(c, hipGetLastError());
                 if (c->profile) n_prof_groups = ng;
             }
@@ -744,6 +776,7 @@ static int rmsd_batch_impl(gr_rmsd_plan *p, uint32_t first_slot, uint32_t n_fram
                 const int nk = fit ? 3 : 2;
                 const uint32_t nf = std::min<uint32_t>(c->sub_batch, nb - gi * c->sub_batch);
                 for (int k = 0; k < nk; ++k) {
+                    if (k == 1 && prof_two) continue;   // finalize..fit-start spans two streams: not a kernel duration
                     float ms = 0.f;
                     HIPCHK(c, hipEventElapsedTime(&ms, c->pev[4 * gi + k], c->pev[4 * gi + k + 1]));
                     c->prof_ms[k] += ms; c->prof_launches[k] += 1; c->prof_frames[k] += nf;

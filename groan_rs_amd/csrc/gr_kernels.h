@@ -341,7 +341,7 @@ __global__ __launch_bounds__(GR_WG) void k_rmsd_accum(
         gx = xyz[3 * (size_t)i0]; gy = xyz[3 * (size_t)i0 + 1]; gz = xyz[3 * (size_t)i0 + 2];
     }
     if (MODE == 1) { sx = state[frame].shift[0]; sy = state[frame].shift[1]; sz = state[frame].shift[2]; }
-    const float iax = 1.0f / box.ax, iby = 1.0f / box.by, icz = 1.0f / box.cz;
+    const float iax = box.iax, iby = box.iby, icz = box.icz;
     const float rws2 = box.r_ws * box.r_ws;
     const bool tric = !box.ortho;
     float fsum[6] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };

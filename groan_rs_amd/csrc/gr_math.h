@@ -29,48 +29,45 @@ struct GrBox {
     float ax, by, cz;      // v1x v2y v3z
     float bx, cx, cy;      // v2x v3x v3y
     float bcx, bcy, bcz;   // box centre
+    float iax, iby, icz;   // reciprocals of the diagonal (k-estimates only; every use is followed by an exact correction)
     float r_ws;            // half the shortest non-zero lattice vector: |d| < r_ws => d is its own minimum image
     int ortho;             // v2x == v3x == v3y == 0
     int ncand;             // number of entries in cand
     int valid;             // 0: the frame has no box
-    int pad;
     float cand[GR_MAX_CAND][3];
 };
 
-// Closed forms of the reference's loops (`while w > L: w -= L; while w < 0: w += L`, vector3d.rs:398-417):
-//   t > L : k = ceil(t/L) - 1   (result in (0, L], the upper end stays closed exactly as in the reference)
-//   t < 0 : k = floor(t/L)      (result in [0, L))
-// followed by one conditional correction each way for the case where the f32 quotient rounded across an
-// integer.  For |k| <= 1 this is bit-identical to the loops; beyond that it differs from the repeated f32
-// subtraction by an ulp.  No loop: a far-away coordinate cannot stall or diverge a wavefront.
-GR_HD float gr_wrap_k(float t, float L) {
-    float k = 0.0f;
-    if (t > L) k = ceilf(t / L) - 1.0f;
-    else if (t < 0.0f) k = floorf(t / L);
+// Closed forms of the reference's loops, branch-free.
+//   wrap:      `while w > L: w -= L; while w < 0: w += L` (vector3d.rs:398-417).  For t > 0 the result lies in
+//              (0, L] (the upper end stays closed: t == L is left alone), for t <= 0 in [0, L).
+//              k = floor(t/L), and k - 1 when that lands a positive t exactly on 0.
+//   min_image: `while d > L/2: d -= L; while d < -L/2: d += L` (vector3d.rs:575-592): result in [-L/2, L/2].
+// k is first estimated with the reciprocal of L and then corrected by comparing the actual remainder, so the
+// returned k always puts the result in range whatever the rounding of the estimate.  For |k| <= 1 the result
+// t - k L is bit-identical to the reference's loop; beyond that it differs from the repeated f32 subtraction by
+// an ulp.  No loop and no divide: a far-away coordinate cannot stall or diverge a wavefront.
+GR_HD float gr_wrap_k(float t, float L, float iL) {
+    float k = floorf(t * iL);
+    float r = fmaf(-k, L, t);
+    k += (r < 0.0f) ? -1.0f : 0.0f;
+    k += (r >= L) ? 1.0f : 0.0f;
+    r = fmaf(-k, L, t);
+    k -= (r == 0.0f && t > 0.0f) ? 1.0f : 0.0f;
     return k;
 }
-GR_HD float gr_wrap_coordinate(float coor, float L) {
-    const float k = gr_wrap_k(coor, L);
-    float w = (k == 1.0f) ? coor - L : ((k == -1.0f) ? coor + L : coor - k * L);
-    if (w > L) w -= L;
-    if (w < 0.0f) w += L;
-    return w;
-}
+GR_HD float gr_wrap_coordinate(float coor, float L) { return fmaf(-gr_wrap_k(coor, L, 1.0f / L), L, coor); }
 
-// `while d > L/2: d -= L; while d < -L/2: d += L` (vector3d.rs:575-592): result in [-L/2, L/2]
-GR_HD float gr_minimg_k(float d, float L, float h) {
-    float k = 0.0f;
-    if (d > h) k = ceilf((d - h) / L);
-    else if (d < -h) k = -ceilf((-h - d) / L);
+GR_HD float gr_minimg_k(float d, float L, float iL, float h) {
+    float k = rintf(d * iL);
+    float r = fmaf(-k, L, d);
+    k += (r > h) ? 1.0f : 0.0f;
+    k += (r < -h) ? -1.0f : 0.0f;
     return k;
 }
 GR_HD float gr_min_image(float dx, float L) {
     const float h = L / 2.0f;
-    const float k = gr_minimg_k(dx, L, h);
-    float d = (k == 1.0f) ? dx - L : ((k == -1.0f) ? dx + L : dx - k * L);
-    if (d > h) d -= L;
-    if (d < -h) d += L;
-    return d;
+    // d exactly +-h must stay (the loops use strict comparisons): rint(+-0.5) = 0 keeps it
+    return fmaf(-gr_minimg_k(dx, L, 1.0f / L, h), L, dx);
 }
 
 GR_HD float gr_floor_mod(float x, float y) { return fmodf(fmodf(x, y) + y, y); }
@@ -91,41 +88,34 @@ GR_HD void gr_tric_refine(float &dx, float &dy, float &dz, const GrBox &b) {
 // wrap a position into the unit cell
 GR_HD void gr_wrap(float &x, float &y, float &z, const GrBox &b) {
     if (b.ortho) {
-        x = gr_wrap_coordinate(x, b.ax);
-        y = gr_wrap_coordinate(y, b.by);
-        z = gr_wrap_coordinate(z, b.cz);
+        x = fmaf(-gr_wrap_k(x, b.ax, b.iax), b.ax, x);
+        y = fmaf(-gr_wrap_k(y, b.by, b.iby), b.by, y);
+        z = fmaf(-gr_wrap_k(z, b.cz, b.icz), b.cz, z);
         return;
     }
     // along c, then b, then a
-    float k = gr_wrap_k(z, b.cz);
-    x -= k * b.cx; y -= k * b.cy; z -= k * b.cz;
-    if (z > b.cz) { x -= b.cx; y -= b.cy; z -= b.cz; }
-    if (z < 0.0f) { x += b.cx; y += b.cy; z += b.cz; }
-    k = gr_wrap_k(y, b.by);
-    x -= k * b.bx; y -= k * b.by;
-    if (y > b.by) { x -= b.bx; y -= b.by; }
-    if (y < 0.0f) { x += b.bx; y += b.by; }
-    x = gr_wrap_coordinate(x, b.ax);
+    float k = gr_wrap_k(z, b.cz, b.icz);
+    x = fmaf(-k, b.cx, x); y = fmaf(-k, b.cy, y); z = fmaf(-k, b.cz, z);
+    k = gr_wrap_k(y, b.by, b.iby);
+    x = fmaf(-k, b.bx, x); y = fmaf(-k, b.by, y);
+    k = gr_wrap_k(x, b.ax, b.iax);
+    x = fmaf(-k, b.ax, x);
 }
 
 // minimum-image displacement (in place)
 GR_HD void gr_min_image_vec(float &dx, float &dy, float &dz, const GrBox &b) {
     if (b.ortho) {
-        dx = gr_min_image(dx, b.ax);
-        dy = gr_min_image(dy, b.by);
-        dz = gr_min_image(dz, b.cz);
+        dx = fmaf(-gr_minimg_k(dx, b.ax, b.iax, b.ax / 2.0f), b.ax, dx);
+        dy = fmaf(-gr_minimg_k(dy, b.by, b.iby, b.by / 2.0f), b.by, dy);
+        dz = fmaf(-gr_minimg_k(dz, b.cz, b.icz, b.cz / 2.0f), b.cz, dz);
         return;
     }
-    const float hz = b.cz / 2.0f, hy = b.by / 2.0f;
-    float k = gr_minimg_k(dz, b.cz, hz);
-    dx -= k * b.cx; dy -= k * b.cy; dz -= k * b.cz;
-    if (dz > hz) { dx -= b.cx; dy -= b.cy; dz -= b.cz; }
-    if (dz < -hz) { dx += b.cx; dy += b.cy; dz += b.cz; }
-    k = gr_minimg_k(dy, b.by, hy);
-    dx -= k * b.bx; dy -= k * b.by;
-    if (dy > hy) { dx -= b.bx; dy -= b.by; }
-    if (dy < -hy) { dx += b.bx; dy += b.by; }
-    dx = gr_min_image(dx, b.ax);
+    float k = gr_minimg_k(dz, b.cz, b.icz, b.cz / 2.0f);
+    dx = fmaf(-k, b.cx, dx); dy = fmaf(-k, b.cy, dy); dz = fmaf(-k, b.cz, dz);
+    k = gr_minimg_k(dy, b.by, b.iby, b.by / 2.0f);
+    dx = fmaf(-k, b.bx, dx); dy = fmaf(-k, b.by, dy);
+    k = gr_minimg_k(dx, b.ax, b.iax, b.ax / 2.0f);
+    dx = fmaf(-k, b.ax, dx);
     gr_tric_refine(dx, dy, dz, b);
 }
 
@@ -159,14 +149,17 @@ GR_HD float gr_distance(float ax_, float ay_, float az_, float px, float py, flo
     float dx = ax_ - px, dy = ay_ - py, dz = az_ - pz;
     if (b.ortho) {
         // only the requested components are min-imaged, exactly as vector3d.rs:458-486
+        const float mx = fmaf(-gr_minimg_k(dx, b.ax, b.iax, b.ax / 2.0f), b.ax, dx);
+        const float my = fmaf(-gr_minimg_k(dy, b.by, b.iby, b.by / 2.0f), b.by, dy);
+        const float mz = fmaf(-gr_minimg_k(dz, b.cz, b.icz, b.cz / 2.0f), b.cz, dz);
         switch (dim) {
-        case 1: return gr_min_image(dx, b.ax);
-        case 2: return gr_min_image(dy, b.by);
-        case 3: return gr_min_image(dz, b.cz);
-        case 4: return gr_mag3(gr_min_image(dx, b.ax), gr_min_image(dy, b.by), 0.0f);
-        case 5: return gr_mag3(gr_min_image(dx, b.ax), 0.0f, gr_min_image(dz, b.cz));
-        case 6: return gr_mag3(0.0f, gr_min_image(dy, b.by), gr_min_image(dz, b.cz));
-        default: return gr_mag3(gr_min_image(dx, b.ax), gr_min_image(dy, b.by), gr_min_image(dz, b.cz));
+        case 1: return mx;
+        case 2: return my;
+        case 3: return mz;
+        case 4: return gr_mag3(mx, my, 0.0f);
+        case 5: return gr_mag3(mx, 0.0f, mz);
+        case 6: return gr_mag3(0.0f, my, mz);
+        default: return gr_mag3(mx, my, mz);
         }
     }
     gr_min_image_vec(dx, dy, dz, b);
@@ -184,17 +177,19 @@ GR_HD float gr_distance(float ax_, float ay_, float az_, float px, float py, flo
 // Host-side preparation of a GrBox from the gro-order box9 (simbox.rs:13-26). Returns 0 when the
 // diagonal is not strictly positive / not finite (the reference panics or never terminates there).
 inline int gr_box_setup(const float *box9, GrBox *b) {
-    b->valid = 0; b->ncand = 0; b->pad = 0;
+    b->valid = 0; b->ncand = 0; b->iax = b->iby = b->icz = 0;
     if (!box9) { b->ax = b->by = b->cz = b->bx = b->cx = b->cy = 0; b->ortho = 1; b->bcx = b->bcy = b->bcz = 0; b->r_ws = 0; return 1; }
     b->ax = box9[0]; b->by = box9[1]; b->cz = box9[2];
     b->bx = box9[5]; b->cx = box9[7]; b->cy = box9[8];
     b->ortho = (b->bx == 0.0f && b->cx == 0.0f && b->cy == 0.0f);
     b->valid = 1;
-    if (b->ortho) { b->bcx = b->ax / 2.0f; b->bcy = b->by / 2.0f; b->bcz = b->cz / 2.0f; }
-    else { b->bcx = (b->ax + b->bx + b->cx) / 2.0f; b->bcy = (b->by + b->cy) / 2.0f; b->bcz = b->cz / 2.0f; }
+    // box centre = half the diagonal (system/mod.rs:298-308); for a triclinic box that is the centre of the
+    // rectangular unit cell gr_wrap maps into, so shift-to-centre + wrap keeps a compact group whole
+    b->bcx = b->ax / 2.0f; b->bcy = b->by / 2.0f; b->bcz = b->cz / 2.0f;
     if (!(b->ax > 0.0f) || !(b->by > 0.0f) || !(b->cz > 0.0f) || !isfinite(b->ax) || !isfinite(b->by) || !isfinite(b->cz)) {
         b->r_ws = 0; return 0;
     }
+    b->iax = 1.0f / b->ax; b->iby = 1.0f / b->by; b->icz = 1.0f / b->cz;
     double tmin2 = 1e300;
     for (int k = -2; k <= 2; ++k)
         for (int j = -2; j <= 2; ++j)

@@ -343,12 +343,10 @@ class System:
         if b is None:
             raise _simbox(E_NO_BOX)
         ortho = b[5] == 0.0 and b[7] == 0.0 and b[8] == 0.0
-        two = np.float32(2.0)
-        if ortho:
-            return np.array([b[0] / two, b[1] / two, b[2] / two], np.float32)
-        if self._strict():
+        if not ortho and self._strict():
             raise _simbox(E_NOT_ORTHOGONAL)
-        return np.array([(b[0] + b[5] + b[7]) / two, (b[1] + b[8]) / two, b[2] / two], np.float32)
+        two = np.float32(2.0)
+        return np.array([b[0] / two, b[1] / two, b[2] / two], np.float32)
 
     def _strict(self):
         return getattr(self, "_strict_flag", False)

@@ -85,17 +85,14 @@ void go_box_from_lengths_angles(const float len[3], const float ang[3], float b[
     }
 }
 
-/* src/system/mod.rs:298-308; triclinic extension: (a+b+c)/2 */
+/* src/system/mod.rs:298-308.  Triclinic extension: the same formula -- half the box diagonal -- i.e. the
+ * centre of the rectangular ("brick") unit cell 0<=x<=v1x, 0<=y<=v2y, 0<=z<=v3z that go_wrap maps into
+ * (GROMACS put_atoms_in_box convention), so "shift the group to the box centre, then wrap" keeps a compact
+ * group whole exactly as in the orthorhombic case. */
 void go_box_center(const float b[9], float out[3]) {
-    if (go_box_is_orthogonal(b)) {
-        out[0] = V1X(b) / 2.0f;
-        out[1] = V2Y(b) / 2.0f;
-        out[2] = V3Z(b) / 2.0f;
-    } else {
-        out[0] = (V1X(b) + V2X(b) + V3X(b)) / 2.0f;
-        out[1] = (V2Y(b) + V3Y(b)) / 2.0f;
-        out[2] = V3Z(b) / 2.0f;
-    }
+    out[0] = V1X(b) / 2.0f;
+    out[1] = V2Y(b) / 2.0f;
+    out[2] = V3Z(b) / 2.0f;
 }
 
 /* src/structures/vector3d.rs:28-30 ; Rust f32 `%` is C fmodf */

@@ -1,0 +1,109 @@
+"""CPU-only checks of the product's host side: the C-ABI library loads, exports every symbol that
+include/groan_hip.h declares, its pure-host AtomContainer functions are bit-exact against the reference's
+known answers, and -- with no GPU present -- context creation fails loudly (there is no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def G():
+    import groan_rs_amd as g
+    g._lib.load()
+    return g
+
+
+def declared_functions():
+    txt = open(os.path.join(ROOT, "include", "groan_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(gr_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_abi_exports_every_declared_symbol(G):
+    lib = G._lib.load()
+    names = declared_functions()
+    assert len(names) >= 50
+    for n in names:
+        assert hasattr(lib, n), "libgroan_hip.so does not export %s" % n
+        assert n in G._lib.SIGNATURES, "%s has no ctypes signature" % n
+    assert sorted(G._lib.SIGNATURES) == names
+    assert lib.gr_version().startswith(b"groan_hip")
+    assert lib.gr_status_string(6) == b"atom has undefined position"
+
+
+def test_no_device_fails_loudly(G):
+    lib = G._lib.load()
+    n = C.c_int(-1)
+    st = lib.gr_device_count(C.byref(n))
+    if st == 0 and n.value > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(G.DeviceError) as e:
+        G.System(10)
+    assert e.value.status == G._lib.E_NO_DEVICE
+
+
+def _b(c):
+    return c.blocks
+
+
+def test_container_goldens_through_the_abi(G):
+    """src/structures/container.rs:517-925 (same vectors the oracle is pinned with)"""
+    AC = G.AtomContainer
+    assert _b(AC.from_indices([6, 2, 13, 1, 10, 8, 3, 12, 7, 14, 15], 16)) == [(1, 3), (6, 8), (10, 10), (12, 15)]
+    assert _b(AC.from_indices([], 16)) == []
+    dup = [1, 6, 3, 2, 13, 1, 10, 8, 3, 12, 7, 14, 15, 10]
+    assert _b(AC.from_indices(dup, 16)) == [(1, 3), (6, 8), (10, 10), (12, 15)]
+    assert _b(AC.from_indices(dup, 15)) == [(1, 3), (6, 8), (10, 10), (12, 14)]
+    cx = [11, 1, 2, 3, 20, 5, 0, 5, 4, 18, 6, 19, 1, 13, 20, 27]
+    c1 = AC.from_indices(cx, 20)
+    assert _b(c1) == [(0, 6), (11, 11), (13, 13), (18, 19)]
+    assert c1.get_n_atoms() == 11 and list(c1) == [0, 1, 2, 3, 4, 5, 6, 11, 13, 18, 19]
+    assert c1.first() == 0 and c1.last() == 19 and c1.isin(5) and not c1.isin(12) and not c1.isin(73)
+    assert _b(AC.from_ranges([(64, 128), (5, 32), (1, 25), (129, 133), (133, 200), (35, 78), (10, 15), (1033, 1055)], 1028)) == [(1, 32), (35, 200)]
+    assert _b(AC.from_ranges([(1, 25), (0, 1), (0, 0), (0, 34)], 1028)) == [(0, 34)]
+    assert _b(AC.from_ranges([(32, 25), (14, 17)], 1028)) == [(14, 17)]
+    assert _b(AC.from_ranges([(543, 1020), (1000, 1432)], 1028)) == [(543, 1027)]
+    assert _b(AC.from_ranges([(0, 43), (1006, 1432)], 1028)) == [(0, 43), (1006, 1027)]
+    c2 = AC.from_ranges([(10, 15), (17, 25), (11, 11), (7, 3), (9, 10), (15, 15), (16, 18), (2, 5), (10, 15)], 20)
+    assert _b(c2) == [(2, 5), (9, 19)]
+    assert _b(AC.union(c1, c2)) == [(0, 6), (9, 19)]
+    c3 = AC.from_indices([13, 1, 2, 7, 5, 19, 21, 1, 9, 10, 11], 15)
+    assert _b(AC.intersection(c1, c3)) == [(1, 2), (5, 5), (11, 11), (13, 13)] == _b(AC.intersection(c3, c1))
+    assert _b(AC.intersection(c1, AC())) == [] and _b(AC.intersection(AC(), c1)) == []
+
+
+def test_container_random_against_oracle(G):
+    AC = G.AtomContainer
+    rng = np.random.default_rng(3)
+
+    def bl(x):
+        return [(int(a), int(b)) for a, b in np.asarray(x).tolist()]
+
+    for _ in range(300):
+        n_atoms = int(rng.integers(1, 300))
+        idx = rng.integers(0, n_atoms + 30, size=int(rng.integers(0, 80))).tolist()
+        if idx and min(idx) >= n_atoms:
+            idx.append(0)   # the reference never range-checks the smallest index (container.rs:66): keep it valid
+        r = [(int(a), int(b)) for a, b in rng.integers(0, n_atoms + 30, size=(int(rng.integers(0, 25)), 2))]
+        c1, o1 = AC.from_indices(idx, n_atoms), O.container_from_indices(idx, n_atoms)
+        c2, o2 = AC.from_ranges(r, n_atoms), (O.container_from_ranges(r, n_atoms) if r else np.zeros((0, 2), np.uint64))
+        assert _b(c1) == bl(o1) and _b(c2) == bl(o2)
+        assert c1.get_n_atoms() == O.container_expand(o1).size and list(c1) == O.container_expand(o1).tolist()
+        assert _b(AC.union(c1, c2)) == bl(O.container_union(o1, o2))
+        assert _b(AC.intersection(c1, c2)) == bl(O.container_intersection(o1, o2))
+        for q in rng.integers(0, n_atoms + 30, size=5):
+            assert c1.isin(int(q)) == O.container_isin(o1, int(q))
+
+
+def test_dimension_mirror(G):
+    D = G.Dimension   # src/structures/dimension.rs
+    assert [d.is_x() for d in D] == [False, True, False, False, True, True, False, True]
+    assert [d.is_y() for d in D] == [False, False, True, False, True, False, True, True]
+    assert [d.is_z() for d in D] == [False, False, False, True, False, True, True, True]

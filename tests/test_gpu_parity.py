@@ -74,6 +74,8 @@ def test_groups_bit_exact(G, ex_system, example):
     for _ in range(50):
         n_atoms = int(rng.integers(1, 200))
         idx = rng.integers(0, n_atoms + 20, size=int(rng.integers(0, 60))).tolist()
+        if idx and min(idx) >= n_atoms:
+            idx.append(0)
         assert G.AtomContainer.from_indices(idx, n_atoms).blocks == blocks_list(O.container_from_indices(idx, n_atoms))
         r = [(int(a), int(b)) for a, b in rng.integers(0, n_atoms + 20, size=(int(rng.integers(0, 20)), 2))]
         c1, o1 = G.AtomContainer.from_ranges(r, n_atoms), O.container_from_ranges(r, n_atoms) if r else np.zeros((0, 2))

@@ -1,0 +1,125 @@
+"""The triclinic extension has no reference arithmetic (the reference returns SimBoxError::NotOrthogonal,
+src/structures/simbox.rs:230-236): PARITY UNPINNED.  These CPU tests define and validate it:
+  * minimum image = the shortest of ALL lattice images (fp64 brute force over +-3 cells per axis);
+  * wrap lands in the rectangular unit cell (GROMACS put_atoms_in_box) and differs from the input by a
+    lattice vector; the box centre is the centre of that cell (half the diagonal, as for orthorhombic boxes);
+  * with zero off-diagonals every triclinic code path is bit-identical to the orthorhombic one;
+  * COM / RMSD of a PBC-broken rigid copy equal those of the unbroken one.
+"""
+import itertools
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+BOXES = {
+    "triclinic": ([24.0, 23.0, 22.0], [75.0, 80.0, 70.0]),
+    "dodecahedron": ([24.18, 24.18, 24.18], [60.0, 60.0, 90.0]),
+    "octahedron": ([24.0, 24.0, 24.0], [70.53, 109.47, 70.53]),
+    "small_skew": ([5.0, 4.0, 3.0], [80.0, 70.0, 120.0]),
+}
+
+
+def lattice(box9):
+    b = np.asarray(box9, np.float64)
+    return np.array([[b[0], 0, 0], [b[5], b[1], 0], [b[7], b[8], b[2]]])
+
+
+def brute_min_image(d, box9, rng=6):
+    L = lattice(box9)
+    ks = np.array(list(itertools.product(range(-rng, rng + 1), repeat=3)), np.float64)
+    cand = d[None, :].astype(np.float64) + ks @ L
+    return cand[np.argmin((cand ** 2).sum(1))]
+
+
+@pytest.mark.parametrize("name", list(BOXES))
+def test_min_image_is_the_global_minimum(name):
+    box = O.box_from_lengths_angles(*BOXES[name])
+    rng = np.random.default_rng(11)
+    L = lattice(box)
+    for _ in range(400):
+        a = (rng.uniform(-1.5, 2.5, 3) @ L).astype(np.float32)
+        b = (rng.uniform(-1.5, 2.5, 3) @ L).astype(np.float32)
+        got = O.distance(a, b, "xyz", box)
+        want = np.linalg.norm(brute_min_image(a.astype(np.float64) - b.astype(np.float64), box))
+        assert abs(got - want) <= 2e-5 * max(1.0, want), (a, b, got, want)
+        v = O.vector_to(a, b, box)
+        assert abs(np.linalg.norm(v) - want) <= 2e-5 * max(1.0, want)
+        # components of the 3-D minimum image vector (the extension's definition of the 1-D/2-D dims)
+        dx, dy, dz = (O.distance(a, b, d, box) for d in "xyz")
+        assert abs(np.sqrt(dx * dx + dy * dy + dz * dz) - got) <= 1e-5
+        assert abs(O.distance(a, b, "xy", box) - np.hypot(dx, dy)) <= 1e-5
+
+
+@pytest.mark.parametrize("name", list(BOXES))
+def test_wrap_lands_in_the_cell(name):
+    box = O.box_from_lengths_angles(*BOXES[name])
+    L = lattice(box)
+    Linv = np.linalg.inv(L)
+    rng = np.random.default_rng(5)
+    for _ in range(300):
+        p = (rng.uniform(-3, 4, 3) @ L).astype(np.float32)
+        w = O.wrap(p, box)
+        # the rectangular unit cell of GROMACS' put_atoms_in_box: 0<=x<=v1x, 0<=y<=v2y, 0<=z<=v3z
+        assert np.all(w >= -1e-5) and w[0] <= box[0] + 1e-5 and w[1] <= box[1] + 1e-5 and w[2] <= box[2] + 1e-5, w
+        k = (w.astype(np.float64) - p.astype(np.float64)) @ Linv
+        assert np.abs(k - np.rint(k)).max() <= 1e-4
+
+
+def test_zero_offdiagonals_are_bit_identical_to_orthorhombic():
+    rng = np.random.default_rng(2)
+    for _ in range(200):
+        l = rng.uniform(2, 20, 3).astype(np.float32)
+        ortho = np.array([l[0], l[1], l[2], 0, 0, 0, 0, 0, 0], np.float32)
+        tiny = ortho.copy(); tiny[5] = np.float32(1e-30)   # forces the triclinic code path, numerically a no-op
+        a = rng.uniform(-30, 40, 3).astype(np.float32); b = rng.uniform(-30, 40, 3).astype(np.float32)
+        assert np.array_equal(O.wrap(a, ortho), O.wrap(a, tiny))
+        for dim in ("x", "y", "z", "xy", "xz", "yz", "xyz"):
+            assert O.distance(a, b, dim, ortho) == O.distance(a, b, dim, tiny)
+        assert np.array_equal(O.vector_to(a, b, ortho), O.vector_to(a, b, tiny))
+        assert np.array_equal(O.box_center(ortho), O.box_center(tiny))
+    pts = rng.uniform(0, 8, (200, 3)).astype(np.float32); m = rng.uniform(1, 16, 200).astype(np.float32)
+    ortho = np.array([8, 9, 10, 0, 0, 0, 0, 0, 0], np.float32); tiny = ortho.copy(); tiny[7] = np.float32(1e-30)
+    idx = np.arange(200)
+    for fn in (lambda bx: O.estimate_center(pts, idx, bx), lambda bx: O.estimate_center(pts, idx, bx, mass=m),
+               lambda bx: O.get_center(pts[:40] * 0.3, idx[:40], bx, mass=m), lambda bx: O.translate(pts, idx, [3.3, -20.0, 9.1], bx)):
+        assert np.array_equal(fn(ortho), fn(tiny))
+
+
+@pytest.mark.parametrize("name", ["triclinic", "dodecahedron", "octahedron"])
+def test_com_and_rmsd_of_a_pbc_broken_rigid_copy(name, tric_small):
+    box = O.box_from_lengths_angles(*BOXES[name])
+    L = lattice(box)
+    rng = np.random.default_rng(9)
+    n = 300
+    blob = (O.box_center(box).astype(np.float64) + rng.normal(0, 1.0, (n, 3))).astype(np.float32)
+    m = rng.uniform(1, 16, n).astype(np.float32)
+    idx = np.arange(n)
+    com0 = O.get_center(blob, idx, box, mass=m)
+    naive = (blob.astype(np.float64) * m[:, None]).sum(0) / m.sum()
+    assert np.abs(com0 - naive).max() <= 2e-5
+    t = (rng.uniform(0, 1, 3) @ L).astype(np.float32)
+    moved = O.translate(blob, idx, t, box)                 # wrapped -> broken across the cell faces
+    com1 = O.get_center(moved, idx, box, mass=m)
+    d = brute_min_image(com1.astype(np.float64) - (com0.astype(np.float64) + t), box)
+    assert np.linalg.norm(d) <= 5e-5
+    r, R = O.calc_rmsd(blob, m, idx, box, moved, m, idx, box)
+    assert r <= 2e-4 and np.abs(R - np.eye(3)).max() <= 1e-4
+    # rotate about the box centre, break, fit back
+    q = rng.normal(size=4); q /= np.linalg.norm(q)
+    w, x, y, z = q
+    Rm = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)], [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                   [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+    c = O.box_center(box).astype(np.float64)
+    rot = ((blob.astype(np.float64) - c) @ Rm.T + c).astype(np.float32)
+    rot = O.translate(rot, idx, t, box)
+    r, fitted = O.calc_rmsd_and_fit(blob, m, idx, box, rot, m, idx, box)
+    assert r <= 3e-4
+    assert np.abs(fitted - blob).max() <= 2e-3
+    # the 50-atom fixtures of the reference (IO-only there) at least run through every entry point
+    fr = tric_small[name + "_frames"]; bx = tric_small[name + "_boxes9"]
+    i50 = np.arange(fr.shape[1]); m50 = np.ones(fr.shape[1], np.float32)
+    for f in range(fr.shape[0]):
+        assert np.isfinite(O.get_center(fr[f], i50, bx[f], mass=m50)).all()
+        assert np.isfinite(O.group_all_distances(fr[f], i50, i50, "xyz", bx[f])).all()
