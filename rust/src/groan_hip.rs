@@ -1,0 +1,196 @@
+//! Bindings of libgroan_hip.so (include/groan_hip.h) for groan_rs, in the style of the crate's existing
+//! xdrfile FFI (`src/io/xdrfile.rs:27-120`): raw `extern "C"` declarations, an opaque `#[repr(C)]` handle,
+//! an RAII owner with `Drop`, and safe methods returning the crate's own error enums.
+//!
+//! NOT COMPILED in the build container (no cargo/rustc there).  Feature-gate as `hip` in Cargo.toml and
+//! link with `println!("cargo:rustc-link-lib=dylib=groan_hip")` from build.rs.
+#![allow(non_camel_case_types)]
+
+use std::ffi::{c_char, c_float, c_int, CString};
+use std::marker::PhantomData;
+
+use crate::errors::{AtomError, GroupError, MassError, PositionError, RMSDError, SimBoxError};
+use crate::structures::{container::AtomContainer, dimension::Dimension, simbox::SimBox, vector3d::Vector3D};
+use crate::system::System;
+use crate::structures::traj_convert::{FrameAnalyze, FrameConvertAnalyze};
+
+#[repr(C)] pub struct gr_ctx { _private: [u8; 0] }
+#[repr(C)] pub struct gr_rmsd_plan { _private: [u8; 0] }
+
+pub const GR_OK: c_int = 0;
+pub const GR_E_NO_BOX: c_int = 1;
+pub const GR_E_NOT_ORTHOGONAL: c_int = 2;
+pub const GR_E_ZERO_BOX: c_int = 3;
+pub const GR_E_EMPTY_GROUP: c_int = 4;
+pub const GR_E_INCONSISTENT_GROUP: c_int = 5;
+pub const GR_E_NO_POSITION: c_int = 6;
+pub const GR_E_NO_MASS: c_int = 7;
+pub const GR_E_GROUP_NOT_FOUND: c_int = 8;
+
+extern "C" {
+    pub fn gr_ctx_create(device: c_int, n_atoms: u64, n_slots: u32, status: *mut c_int) -> *mut gr_ctx;
+    pub fn gr_ctx_destroy(ctx: *mut gr_ctx);
+    pub fn gr_last_error_index(ctx: *const gr_ctx) -> u64;
+    pub fn gr_last_error_counts(ctx: *const gr_ctx, counts: *mut u64);
+    pub fn gr_ctx_set_strict_orthogonal(ctx: *mut gr_ctx, on: c_int) -> c_int;
+    pub fn gr_set_masses(ctx: *mut gr_ctx, masses: *const c_float, n: u64) -> c_int;
+    pub fn gr_group_create_from_ranges(ctx: *mut gr_ctx, name: *const c_char, start: *const u64, end: *const u64, n: usize) -> c_int;
+    pub fn gr_frame_upload(ctx: *mut gr_ctx, slot: u32, xyz: *const c_float, box9: *const c_float) -> c_int;
+    pub fn gr_frame_download(ctx: *mut gr_ctx, slot: u32, xyz: *mut c_float) -> c_int;
+    pub fn gr_group_center(ctx: *mut gr_ctx, slot: u32, group: *const c_char, kind: c_int, weighted: c_int, out: *mut c_float) -> c_int;
+    pub fn gr_group_distance(ctx: *mut gr_ctx, slot: u32, g1: *const c_char, g2: *const c_char, dim: c_int, out: *mut c_float) -> c_int;
+    pub fn gr_group_all_distances(ctx: *mut gr_ctx, slot: u32, g1: *const c_char, g2: *const c_char, dim: c_int, out: *mut c_float, cap: usize) -> c_int;
+    pub fn gr_group_translate(ctx: *mut gr_ctx, slot: u32, group: *const c_char, v: *const c_float) -> c_int;
+    pub fn gr_group_wrap(ctx: *mut gr_ctx, slot: u32, group: *const c_char) -> c_int;
+    pub fn gr_atoms_center(ctx: *mut gr_ctx, slot: u32, group: *const c_char, dim: c_int, weighted: c_int) -> c_int;
+    pub fn gr_rmsd_plan_create(reference: *mut gr_ctx, ref_slot: u32, target: *mut gr_ctx, group: *const c_char, status: *mut c_int) -> *mut gr_rmsd_plan;
+    pub fn gr_rmsd_plan_destroy(plan: *mut gr_rmsd_plan);
+    pub fn gr_rmsd_batch(plan: *mut gr_rmsd_plan, first_slot: u32, n: u32, rmsd: *mut c_float, status: *mut c_int, rot: *mut c_float) -> c_int;
+    pub fn gr_rmsd_fit_batch(plan: *mut gr_rmsd_plan, first_slot: u32, n: u32, rmsd: *mut c_float, status: *mut c_int) -> c_int;
+}
+
+/// Device mirror of one `System` (one per worker thread / per GPU, like the clones of `traj_iter_map_reduce`).
+pub struct HipSystem { ctx: *mut gr_ctx, n_atoms: usize, _not_sync: PhantomData<*mut ()> }
+unsafe impl Send for HipSystem {}
+
+impl Drop for HipSystem { fn drop(&mut self) { unsafe { gr_ctx_destroy(self.ctx) } } }
+
+fn simbox_err(status: c_int) -> SimBoxError {
+    if status == GR_E_NOT_ORTHOGONAL { SimBoxError::NotOrthogonal } else { SimBoxError::DoesNotExist }
+}
+
+impl HipSystem {
+    /// Mirror masses and groups of `system` on `device`; positions follow with `upload`.
+    pub fn new(system: &System, device: i32, n_slots: u32) -> Option<Self> {
+        let mut st = 0;
+        let n = system.get_n_atoms();
+        let ctx = unsafe { gr_ctx_create(device, n as u64, n_slots, &mut st) };
+        if ctx.is_null() { return None; }
+        let masses: Vec<f32> = system.atoms_iter().map(|a| a.get_mass().unwrap_or(f32::NAN)).collect();
+        unsafe { gr_set_masses(ctx, masses.as_ptr(), n as u64) };
+        let me = HipSystem { ctx, n_atoms: n, _not_sync: PhantomData };
+        for (name, group) in system.get_groups().iter() {
+            me.group_from_container(name, group.get_atoms());
+        }
+        Some(me)
+    }
+
+    pub fn group_from_container(&self, name: &str, container: &AtomContainer) {
+        let (s, e): (Vec<u64>, Vec<u64>) = container.blocks().map(|(a, b)| (a as u64, b as u64)).unzip();
+        let cname = CString::new(name).unwrap();
+        unsafe { gr_group_create_from_ranges(self.ctx, cname.as_ptr(), s.as_ptr(), e.as_ptr(), s.len()) };
+    }
+
+    /// `TrajRead::update_system` for the device copy: `coords` is the `[[f32; 3]]` the xtc readers produce.
+    pub fn upload(&self, slot: u32, coords: &[[f32; 3]], simbox: Option<&SimBox>) {
+        assert_eq!(coords.len(), self.n_atoms);
+        let b9 = simbox.map(|b| [b.v1x, b.v2y, b.v3z, b.v1y, b.v1z, b.v2x, b.v2z, b.v3x, b.v3y]);
+        let bp = b9.as_ref().map_or(std::ptr::null(), |b| b.as_ptr());
+        unsafe { gr_frame_upload(self.ctx, slot, coords.as_ptr() as *const c_float, bp) };
+    }
+
+    fn group_error(&self, status: c_int, name: &str) -> GroupError {
+        let idx = unsafe { gr_last_error_index(self.ctx) } as usize;
+        match status {
+            GR_E_GROUP_NOT_FOUND => GroupError::NotFound(name.to_owned()),
+            GR_E_EMPTY_GROUP => GroupError::EmptyGroup(name.to_owned()),
+            GR_E_NO_POSITION => GroupError::InvalidPosition(PositionError::NoPosition(idx)),
+            GR_E_NO_MASS => GroupError::InvalidMass(MassError::NoMass(idx)),
+            s => GroupError::InvalidSimBox(simbox_err(s)),
+        }
+    }
+
+    /// `System::group_get_com` (src/system/analysis.rs:258-274)
+    pub fn group_get_com(&self, slot: u32, name: &str) -> Result<Vector3D, GroupError> {
+        let cname = CString::new(name).unwrap();
+        let mut out = [0f32; 3];
+        match unsafe { gr_group_center(self.ctx, slot, cname.as_ptr(), 2, 1, out.as_mut_ptr()) } {
+            GR_OK => Ok(Vector3D::new(out[0], out[1], out[2])),
+            s => Err(self.group_error(s, name)),
+        }
+    }
+
+    /// `System::group_distance` (analysis.rs:348-360)
+    pub fn group_distance(&self, slot: u32, g1: &str, g2: &str, dim: Dimension) -> Result<f32, GroupError> {
+        let (a, b) = (CString::new(g1).unwrap(), CString::new(g2).unwrap());
+        let mut out = 0f32;
+        match unsafe { gr_group_distance(self.ctx, slot, a.as_ptr(), b.as_ptr(), dim as c_int, &mut out) } {
+            GR_OK => Ok(out),
+            s => Err(self.group_error(s, g1)),
+        }
+    }
+}
+
+/// `RMSDConverterAnalyzer` (src/system/rmsd.rs:170-251) on the GPU: same trait impls, so
+/// `system.xtc_iter(f)?.analyze(HipRmsd::new(..)?)` / `.convert_and_analyze(..)` work unchanged.
+pub struct HipRmsd { plan: *mut gr_rmsd_plan, target: HipSystem, _reference: HipSystem, group: String, scratch: Vec<[f32; 3]> }
+
+impl Drop for HipRmsd { fn drop(&mut self) { unsafe { gr_rmsd_plan_destroy(self.plan) } } }
+
+impl HipRmsd {
+    pub fn new(reference: &System, target: &System, group: &str, device: i32) -> Result<Self, RMSDError> {
+        let r = HipSystem::new(reference, device, 1).ok_or_else(|| RMSDError::NonexistentGroup(group.to_owned()))?;
+        let t = HipSystem::new(target, device, 1).ok_or_else(|| RMSDError::NonexistentGroup(group.to_owned()))?;
+        let coords: Vec<[f32; 3]> = reference.atoms_iter().map(|a| a.get_position().map_or([f32::NAN; 3], |p| [p.x, p.y, p.z])).collect();
+        r.upload(0, &coords, reference.get_box());
+        let cname = CString::new(group).unwrap();
+        let mut st = 0;
+        let plan = unsafe { gr_rmsd_plan_create(r.ctx, 0, t.ctx, cname.as_ptr(), &mut st) };
+        if plan.is_null() { return Err(rmsd_error(&r, st, group)); }
+        Ok(HipRmsd { plan, target: t, _reference: r, group: group.to_owned(), scratch: Vec::new() })
+    }
+
+    fn stage(&mut self, system: &System) {
+        self.scratch.clear();
+        self.scratch.extend(system.atoms_iter().map(|a| a.get_position().map_or([f32::NAN; 3], |p| [p.x, p.y, p.z])));
+        self.target.upload(0, &self.scratch, system.get_box());
+    }
+}
+
+fn rmsd_error(sys: &HipSystem, status: c_int, group: &str) -> RMSDError {
+    let idx = unsafe { gr_last_error_index(sys.ctx) } as usize;
+    match status {
+        GR_E_GROUP_NOT_FOUND => RMSDError::NonexistentGroup(group.to_owned()),
+        GR_E_EMPTY_GROUP => RMSDError::EmptyGroup(group.to_owned()),
+        GR_E_NO_POSITION => RMSDError::InvalidPosition(PositionError::NoPosition(idx)),
+        GR_E_NO_MASS => RMSDError::InvalidMass(MassError::NoMass(idx)),
+        GR_E_INCONSISTENT_GROUP => {
+            let mut c = [0u64; 2];
+            unsafe { gr_last_error_counts(sys.ctx, c.as_mut_ptr()) };
+            RMSDError::InconsistentGroup(group.to_owned(), c[0] as usize, c[1] as usize)
+        }
+        s => RMSDError::InvalidSimBox(simbox_err(s)),
+    }
+}
+
+impl FrameAnalyze for HipRmsd {
+    type Error = RMSDError;
+    type AnalysisResult = f32;
+    fn analyze(&mut self, system: &System) -> Result<f32, RMSDError> {
+        self.stage(system);
+        let (mut r, mut st) = (0f32, 0);
+        match unsafe { gr_rmsd_batch(self.plan, 0, 1, &mut r, &mut st, std::ptr::null_mut()) } {
+            GR_OK => Ok(r),
+            s => Err(rmsd_error(&self.target, s, &self.group)),
+        }
+    }
+}
+
+impl FrameConvertAnalyze for HipRmsd {
+    type Error = RMSDError;
+    type AnalysisResult = f32;
+    fn convert_analyze(&mut self, system: &mut System) -> Result<f32, RMSDError> {
+        self.stage(system);
+        let (mut r, mut st) = (0f32, 0);
+        match unsafe { gr_rmsd_fit_batch(self.plan, 0, 1, &mut r, &mut st) } {
+            GR_OK => {
+                unsafe { gr_frame_download(self.target.ctx, 0, self.scratch.as_mut_ptr() as *mut c_float) };
+                for (atom, p) in system.atoms_iter_mut().zip(self.scratch.iter()) {
+                    atom.set_position(Vector3D::new(p[0], p[1], p[2]));
+                }
+                Ok(r)
+            }
+            s => Err(rmsd_error(&self.target, s, &self.group)),
+        }
+    }
+}

@@ -1,0 +1,124 @@
+// tests/cpp/test_host.cpp -- the C++ host mirror (include/groan_hip.hpp) exercised the way the reference's own
+// unit tests exercise the Rust API.  Built by __graft_entry__.build() (g++, links libgroan_hip.so), run on the
+// GPU box by tests/test_gpu_cpp_host.py which passes a directory of raw little-endian fixtures:
+//   gro_keep.f32 [261][3]  frames.f32 [11][261][3]  boxes.f32 [11][9]  box0.f32 [9]  masses.f32 [261]
+#include <cmath>
+#include <cstdio>
+#include <fstream>
+#include <string>
+#include <vector>
+
+#include "../../include/groan_hip.hpp"
+
+using namespace groan;
+static int failures = 0;
+#define CHECK(...) do { if (!(__VA_ARGS__)) { printf("FAIL %s:%d  %s\n", __FILE__, __LINE__, #__VA_ARGS__); ++failures; } } while (0)
+#define NEAR(a, b, eps) CHECK(std::fabs((double)(a) - (double)(b)) <= (eps))
+
+static std::vector<float> load(const std::string &path) {
+    std::ifstream f(path, std::ios::binary | std::ios::ate);
+    if (!f) { printf("cannot open %s\n", path.c_str()); exit(2); }
+    std::vector<float> v((size_t)f.tellg() / 4);
+    f.seekg(0);
+    f.read(reinterpret_cast<char *>(v.data()), (std::streamsize)v.size() * 4);
+    return v;
+}
+
+struct RmsdData {   // ParallelTrajData (parallel.rs:31-49)
+    std::vector<std::pair<uint64_t, float>> values;
+    size_t worker = 0;
+    void initialize(size_t thread_id) { worker = thread_id; }
+    static RmsdData reduce(std::vector<RmsdData> data) {
+        RmsdData out;
+        for (auto &d : data) out.values.insert(out.values.end(), d.values.begin(), d.values.end());
+        return out;
+    }
+};
+
+int main(int argc, char **argv) {
+    if (argc < 2) { printf("usage: test_host <fixture dir>\n"); return 2; }
+    const std::string dir = argv[1];
+    // ---- analysis.rs:895-929 get_com_two_atoms_pbc
+    {
+        System s(2);
+        s.set_masses({12.8f, 0.4f});
+        const float xyz[6] = {4.5f, 3.2f, 1.7f, 9.8f, 9.5f, 3.0f};
+        const Box9 box = {10, 10, 10, 0, 0, 0, 0, 0, 0};
+        s.set_frame(xyz, &box);
+        Vector3D c = s.group_get_com("all");
+        NEAR(c[0], 4.35757, 1e-4); NEAR(c[1], 3.08788, 1e-4); NEAR(c[2], 1.7393947, 1e-4);
+        c = s.group_get_center("all");
+        NEAR(c[0], 2.15, 1e-5); NEAR(c[1], 1.35, 1e-5); NEAR(c[2], 2.35, 1e-5);
+        NEAR(s.atoms_distance(0, 1, Dimension::X), 4.7, 1e-5);   // 4.5 - 9.8 = -5.3 -> +10
+        try { s.group_get_center("Nonexistent"); CHECK(false); } catch (const Error &e) { CHECK(e.kind == "GroupError" && e.variant == "NotFound"); }
+        try { s.atoms_distance(0, 7, Dimension::XYZ); CHECK(false); } catch (const Error &e) { CHECK(e.variant == "OutOfRange" && e.index == 7); }
+        s.set_box(nullptr);
+        try { s.group_get_com("all"); CHECK(false); } catch (const Error &e) { CHECK(e.variant == "InvalidSimBox(DoesNotExist)"); }
+    }
+    // ---- container.rs:517-573
+    {
+        AtomContainer c = AtomContainer::from_indices({11, 1, 2, 3, 20, 5, 0, 5, 4, 18, 6, 19, 1, 13, 20, 27}, 20);
+        CHECK(c.blocks.size() == 4 && c.blocks[0] == std::make_pair<uint64_t, uint64_t>(0, 6) && c.blocks[3] == std::make_pair<uint64_t, uint64_t>(18, 19));
+        CHECK(c.get_n_atoms() == 11 && c.isin(5) && !c.isin(12));
+        AtomContainer r = AtomContainer::from_ranges({{543, 1020}, {1000, 1432}}, 1028);
+        CHECK(r.blocks.size() == 1 && r.blocks[0].second == 1027);
+    }
+    // ---- rmsd.rs:795-820 + 1202-1226: RMSD of the Protein over short_trajectory.xtc
+    const float expected[11] = {0.23669721f, 0.2634763f, 0.26021627f, 0.21364464f, 0.22166993f, 0.19383307f, 0.26422343f,
+                                0.27013618f, 0.26398134f, 0.23475659f, 0.24208021f};
+    std::vector<float> gro = load(dir + "/gro_keep.f32"), frames = load(dir + "/frames.f32"), boxes = load(dir + "/boxes.f32"),
+                       box0 = load(dir + "/box0.f32"), masses = load(dir + "/masses.f32");
+    const uint64_t n = masses.size();
+    CHECK(gro.size() == 3 * n && frames.size() == 11 * 3 * n && boxes.size() == 99);
+    Box9 b0; for (int k = 0; k < 9; ++k) b0[k] = box0[k];
+    System reference(n);
+    reference.set_masses(masses);
+    reference.group_create_from_ranges("Protein", {{0, 60}});
+    reference.set_frame(gro.data(), &b0);
+    {
+        System system(n, 0, 11);
+        system.set_masses(masses);
+        system.group_create_from_ranges("Protein", {{0, 60}});
+        RMSDConverterAnalyzer analyzer(reference, system, "Protein");
+        uint64_t next = 0;
+        std::vector<float> got;
+        auto source = [&](Frame &f) {
+            if (next >= 11) return false;
+            static Box9 bx; for (int k = 0; k < 9; ++k) bx[k] = boxes[9 * next + k];
+            f = Frame{frames.data() + next * 3 * n, &bx, next, (float)next}; ++next; return true;
+        };
+        for_each_frame_analyze<float>(system, source, analyzer, [&](const Frame &, float r) { got.push_back(r); });
+        CHECK(got.size() == 11);
+        for (int f = 0; f < 11 && f < (int)got.size(); ++f) NEAR(got[f], expected[f], 5e-7);
+        // calc_rmsd_and_fit via the System method, then the fitted frame is optimally superposed
+        Box9 bx; for (int k = 0; k < 9; ++k) bx[k] = boxes[k];
+        system.set_frame(frames.data(), &bx);
+        NEAR(system.calc_rmsd_and_fit(reference, "Protein"), expected[0], 5e-7);
+        NEAR(system.calc_rmsd(reference, "Protein"), expected[0], 2e-6);
+        // error variants (rmsd.rs:1075-1275)
+        try { system.calc_rmsd(reference, "Nonexistent"); CHECK(false); } catch (const Error &e) { CHECK(e.variant == "NonexistentGroup"); }
+        system.group_create_from_ranges("Protein", {{0, 59}});
+        try { system.calc_rmsd(reference, "Protein"); CHECK(false); } catch (const Error &e) { CHECK(e.variant == "InconsistentGroup" && e.counts[0] == 61 && e.counts[1] == 60); }
+    }
+    // ---- traj_iter_map_reduce (parallel.rs:208-481): two workers (both on device 0), frames round-robin
+    {
+        auto make_system = [&](int device) {
+            System s(n, device, 1);
+            s.set_masses(masses);
+            s.group_create_from_ranges("Protein", {{0, 60}});
+            return s;
+        };
+        std::vector<Box9> bxs(11);
+        for (int f = 0; f < 11; ++f) for (int k = 0; k < 9; ++k) bxs[f][k] = boxes[9 * f + k];
+        auto read_frame = [&](uint64_t f, Frame &out) { out = Frame{frames.data() + f * 3 * n, &bxs[f], f, (float)f}; return true; };
+        auto body = [&](System &s, RmsdData &d) { d.values.emplace_back(d.values.size() * 2 + d.worker, s.calc_rmsd(reference, "Protein")); };
+        RmsdData all = traj_iter_map_reduce<RmsdData>({0, 0}, 11, make_system, read_frame, body, RmsdData{});
+        CHECK(all.values.size() == 11);
+        for (auto &kv : all.values) NEAR(kv.second, expected[kv.first], 5e-7);
+        // an error in one worker surfaces as an error of the whole call
+        auto bad_body = [&](System &s, RmsdData &) { s.calc_rmsd(reference, "Nonexistent"); };
+        try { traj_iter_map_reduce<RmsdData>({0, 0}, 11, make_system, read_frame, bad_body, RmsdData{}); CHECK(false); } catch (const std::runtime_error &) {}
+    }
+    printf(failures ? "test_host: %d FAILED\n" : "test_host: all passed\n", failures);
+    return failures ? 1 : 0;
+}
