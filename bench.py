@@ -146,8 +146,22 @@ def main():
     avg_ms = ms_total / max(launches, 1)
     bytes_per_launch = alg_bytes[dom] * (frames / max(launches, 1))
     achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (separate --pmc runs,
+    # FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; profiles/*_pmc_summary.json) -- only when the launch shape matches
+    traffic, traffic_src = None, None
+    try:
+        import glob
+        for pf in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")), reverse=True):
+            pj = json.load(open(pf))
+            if pj.get("n_atoms") == n and pj.get("frames_per_launch") == frames / max(launches, 1):
+                key = [k for k in pj["traffic"] if k.startswith(dom)]
+                if key:
+                    traffic = pj["traffic"][key[0]]["hbm_bytes_per_launch"]; traffic_src = os.path.basename(pf)
+                    break
+    except Exception:
+        pass
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "avg_launch_ms": round(avg_ms, 4), "launches": launches, "frames_per_launch": frames / max(launches, 1),
                 "algorithmic_bytes_per_launch": bytes_per_launch}
     kernels = {k: {"ms_total": round(v[0], 3), "launches": v[1], "us_per_frame": round(1e3 * v[0] / max(v[2], 1), 3)} for k, v in prof.items()}

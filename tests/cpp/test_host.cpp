@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdio>
 #include <fstream>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -111,12 +112,18 @@ int main(int argc, char **argv) {
         std::vector<Box9> bxs(11);
         for (int f = 0; f < 11; ++f) for (int k = 0; k < 9; ++k) bxs[f][k] = boxes[9 * f + k];
         auto read_frame = [&](uint64_t f, Frame &out) { out = Frame{frames.data() + f * 3 * n, &bxs[f], f, (float)f}; return true; };
-        auto body = [&](System &s, RmsdData &d) { d.values.emplace_back(d.values.size() * 2 + d.worker, s.calc_rmsd(reference, "Protein")); };
+        // a context is not re-entrant, and calc_rmsd uses the REFERENCE context's workspace to extract the reference
+        // side: workers that share one reference System serialise on it (or build one RMSDConverterAnalyzer each)
+        std::mutex ref_mutex;
+        auto body = [&](System &s, RmsdData &d) {
+            std::lock_guard<std::mutex> lock(ref_mutex);
+            d.values.emplace_back(d.values.size() * 2 + d.worker, s.calc_rmsd(reference, "Protein"));
+        };
         RmsdData all = traj_iter_map_reduce<RmsdData>({0, 0}, 11, make_system, read_frame, body, RmsdData{});
         CHECK(all.values.size() == 11);
         for (auto &kv : all.values) NEAR(kv.second, expected[kv.first], 5e-7);
         // an error in one worker surfaces as an error of the whole call
-        auto bad_body = [&](System &s, RmsdData &) { s.calc_rmsd(reference, "Nonexistent"); };
+        auto bad_body = [&](System &s, RmsdData &) { std::lock_guard<std::mutex> lock(ref_mutex); s.calc_rmsd(reference, "Nonexistent"); };
         try { traj_iter_map_reduce<RmsdData>({0, 0}, 11, make_system, read_frame, bad_body, RmsdData{}); CHECK(false); } catch (const std::runtime_error &) {}
     }
     printf(failures ? "test_host: %d FAILED\n" : "test_host: all passed\n", failures);
