@@ -7,14 +7,14 @@ it), but every operation does and fails loudly when the library is missing.
 """
 from . import _lib
 from .system import (AtomContainer, AtomError, DeviceError, Dimension, GroanError, GroupError, RMSDError,
-                     RMSDPlan, SimBoxError, System)
+                     RMSDPlan, SimBoxError, System, pinned_array, pinned_free)
 from .traj import (FrameAnalyze, FrameConvert, FrameConvertAnalyze, RMSDConverterAnalyzer, TrajAnalyzer,
                    TrajAnalysisError, TrajConverter, TrajConverterAnalyzer, TrajReader)
 from .parallel import ParallelTrajData, gather_per_frame, interleave, shard_frames, traj_iter_map_reduce
 
 __all__ = [
     "AtomContainer", "AtomError", "DeviceError", "Dimension", "GroanError", "GroupError", "RMSDError", "RMSDPlan",
-    "SimBoxError", "System", "FrameAnalyze", "FrameConvert", "FrameConvertAnalyze", "RMSDConverterAnalyzer",
+    "SimBoxError", "System", "pinned_array", "pinned_free", "FrameAnalyze", "FrameConvert", "FrameConvertAnalyze", "RMSDConverterAnalyzer",
     "TrajAnalyzer", "TrajAnalysisError", "TrajConverter", "TrajConverterAnalyzer", "TrajReader",
     "ParallelTrajData", "gather_per_frame", "interleave", "shard_frames", "traj_iter_map_reduce",
 ]

@@ -50,6 +50,7 @@ SIGNATURES = {
     "gr_group_n_blocks": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_size_t)]),
     "gr_group_blocks": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p]),
     "gr_frame_upload": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
+    "gr_frame_upload_wait": (C.c_int, [C.c_void_p, C.c_uint32]),
     "gr_frame_download": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p]),
     "gr_frame_set_box": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p]),
     "gr_frame_get_box": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p]),
@@ -70,6 +71,8 @@ SIGNATURES = {
     "gr_rmsd_plan_destroy": (None, [C.c_void_p]),
     "gr_rmsd_batch": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gr_rmsd_fit_batch": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
+    "gr_rmsd_batch_begin": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int]),
+    "gr_rmsd_batch_end": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gr_rmsd_plan_last_fallbacks": (C.c_uint32, [C.c_void_p]),
     "gr_rmsd_plan_force_exact": (C.c_int, [C.c_void_p, C.c_int]),
     "gr_timer_start": (C.c_int, [C.c_void_p]),

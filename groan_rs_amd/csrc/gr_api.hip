@@ -36,6 +36,14 @@ struct gr_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;    // second queue: k_fit of group k runs beside k_rmsd_accum of group k+1
+    // H2D double buffering: uploads run on their own stream; per-slot "upload done" events gate the compute
+    // stream, and a ring of "compute done" events gates the next upload into a slot that kernels still read
+    hipStream_t copy_stream = nullptr;
+    std::vector<hipEvent_t> ev_ready;       // per slot, created on first upload
+    std::vector<uint8_t> upload_pending;    // per slot: the compute stream has not yet waited on ev_ready
+    hipEvent_t ev_done_ring[64] = {};
+    uint64_t done_gen = 0;
+    std::vector<uint64_t> slot_gen;         // per slot: generation of the last compute call that touched it
     hipEvent_t ev_grp[GR_MAX_BATCH] = {};   // "finalize of group k done" (stream -> stream2)
     hipEvent_t ev_join = nullptr;           // "all fits done" (stream2 -> stream)
     int overlap = 0;   // GR_OVERLAP=1: +5 % frames/s at 256-frame calls (measured), but per-kernel durations then overlap
@@ -78,8 +86,18 @@ struct gr_ctx {
     uint64_t counts[2] = { 0, 0 };
 };
 
+struct Pending {   // a segment between gr_rmsd_batch_begin and gr_rmsd_batch_end
+    bool active = false, any_ok = false, consistent = true, prof_two = false;
+    uint32_t s0 = 0, nb = 0, n_prof_groups = 0;
+    int fit = 0;
+    std::vector<int> pre;
+    std::vector<uint64_t> pre_idx;
+    std::vector<std::string> pre_msg;
+};
+
 struct gr_rmsd_plan {
     gr_ctx *target = nullptr;
+    Pending pend;
     std::string group;
     uint64_t n_ref = 0;
     float *p_dev = nullptr, *w_dev = nullptr;
@@ -192,7 +210,24 @@ int slot_check(gr_ctx *c, uint32_t slot, uint32_t n = 1) {
     return GR_OK;
 }
 
-int set_box(gr_ctx *c, uint32_t slot, const float *box9) {
+// Every API call that reads or writes frame slots on the compute stream brackets itself with a SlotUse:
+// entry  -> the compute stream waits for uploads still in flight into those slots
+// exit   -> a "compute done" event is recorded and remembered per slot, so a later upload into the same slot
+//           (the other half of a double buffer) starts only after the kernels that read it have finished.
+struct SlotUse {
+    gr_ctx *c; uint32_t first, n;
+    SlotUse(gr_ctx *ctx, uint32_t first_slot, uint32_t count = 1) : c(ctx), first(first_slot), n(count) {
+        for (uint32_t s = first; s < first + n && s < c->n_slots; ++s)
+            if (c->upload_pending[s]) { (void)hipStreamWaitEvent(c->stream, c->ev_ready[s], 0); c->upload_pending[s] = 0; }
+    }
+    ~SlotUse() {
+        const uint64_t gen = ++c->done_gen;
+        (void)hipEventRecord(c->ev_done_ring[gen % 64], c->stream);
+        for (uint32_t s = first; s < first + n && s < c->n_slots; ++s) c->slot_gen[s] = gen;
+    }
+};
+
+int set_box(gr_ctx *c, uint32_t slot, const float *box9, hipStream_t on = nullptr) {
     GrBox &b = c->boxes_host[slot];
     if (!box9) {
         gr_box_setup(nullptr, &b);
@@ -206,7 +241,7 @@ int set_box(gr_ctx *c, uint32_t slot, const float *box9) {
         else if (b.ncand >= GR_MAX_CAND) c->box_status[slot] = GR_E_UNSUPPORTED_BOX;
         else c->box_status[slot] = GR_OK;
     }
-    HIPCHK(c, hipMemcpyAsync(c->boxes_dev + slot, &b, sizeof(GrBox), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->boxes_dev + slot, &b, sizeof(GrBox), hipMemcpyHostToDevice, on ? on : c->stream));
     return GR_OK;
 }
 
@@ -292,6 +327,9 @@ gr_ctx *gr_ctx_create(int device, uint64_t n_atoms, uint32_t n_slots, int *statu
     bool ok = true;
     ok = ok && hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
     ok = ok && hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) == hipSuccess;
+    for (int k = 0; k < 64; ++k) ok = ok && hipEventCreateWithFlags(&c->ev_done_ring[k], hipEventDisableTiming) == hipSuccess;
+    c->ev_ready.assign(n_slots, nullptr); c->upload_pending.assign(n_slots, 0); c->slot_gen.assign(n_slots, 0);
     for (int k = 0; k < GR_MAX_BATCH; ++k) ok = ok && hipEventCreateWithFlags(&c->ev_grp[k], hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) == hipSuccess;
     if (const char *e = getenv("GR_OVERLAP")) c->overlap = atoi(e) ? 1 : 0;
@@ -331,7 +369,9 @@ gr_ctx *gr_ctx_create(int device, uint64_t n_atoms, uint32_t n_slots, int *statu
 void gr_ctx_destroy(gr_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->stream2) (void)hipStreamSynchronize(c->stream2);
     for (auto &kv : c->groups) if (kv.second.idx_dev) (void)hipFree(kv.second.idx_dev);
     if (c->frames) (void)hipFree(c->frames);
     if (c->masses) (void)hipFree(c->masses);
@@ -349,6 +389,9 @@ void gr_ctx_destroy(gr_ctx *c) {
     for (int k = 0; k < 4 * GR_MAX_BATCH; ++k) if (c->pev[k]) (void)hipEventDestroy(c->pev[k]);
     for (int k = 0; k < GR_MAX_BATCH; ++k) if (c->ev_grp[k]) (void)hipEventDestroy(c->ev_grp[k]);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    for (hipEvent_t e : c->ev_ready) if (e) (void)hipEventDestroy(e);
+    for (int k = 0; k < 64; ++k) if (c->ev_done_ring[k]) (void)hipEventDestroy(c->ev_done_ring[k]);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -363,7 +406,9 @@ uint32_t gr_n_slots(const gr_ctx *c) { return c ? c->n_slots : 0; }
 
 int gr_sync(gr_ctx *c) {
     if (!c) return GR_E_INVALID_ARG;
+    HIPCHK(c, hipStreamSynchronize(c->copy_stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream2));
     return GR_OK;
 }
 
@@ -442,13 +487,27 @@ int gr_frame_upload(gr_ctx *c, uint32_t slot, const float *xyz, const float *box
     int st = slot_check(c, slot); if (st) return st;
     if (!xyz) return fail(c, GR_E_INVALID_ARG, "xyz is NULL");
     (void)hipSetDevice(c->device);
-    HIPCHK(c, hipMemcpyAsync(c->frames + (size_t)slot * c->frame_stride, xyz, c->n * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream));
-    return set_box(c, slot, box9);
+    if (!c->ev_ready[slot]) HIPCHK(c, hipEventCreateWithFlags(&c->ev_ready[slot], hipEventDisableTiming));
+    // the slot may still be read by kernels issued earlier: order the copy behind the last compute call that used it
+    // (events of one stream complete in order, so a recycled ring entry only makes the wait conservative)
+    if (c->slot_gen[slot]) HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->ev_done_ring[c->slot_gen[slot] % 64], 0));
+    if (c->upload_pending[slot]) HIPCHK(c, hipEventSynchronize(c->ev_ready[slot]));   // boxes_host[slot] is about to be rewritten
+    HIPCHK(c, hipMemcpyAsync(c->frames + (size_t)slot * c->frame_stride, xyz, c->n * 3 * sizeof(float), hipMemcpyHostToDevice, c->copy_stream));
+    st = set_box(c, slot, box9, c->copy_stream); if (st) return st;
+    HIPCHK(c, hipEventRecord(c->ev_ready[slot], c->copy_stream));
+    c->upload_pending[slot] = 1;
+    return GR_OK;
+}
+int gr_frame_upload_wait(gr_ctx *c, uint32_t slot) {
+    int st = slot_check(c, slot); if (st) return st;
+    if (c->ev_ready[slot]) HIPCHK(c, hipEventSynchronize(c->ev_ready[slot]));
+    return GR_OK;
 }
 int gr_frame_download(gr_ctx *c, uint32_t slot, float *xyz) {
     int st = slot_check(c, slot); if (st) return st;
     if (!xyz) return fail(c, GR_E_INVALID_ARG, "xyz is NULL");
     (void)hipSetDevice(c->device);
+    SlotUse use(c, slot);
     HIPCHK(c, hipMemcpyAsync(xyz, c->frames + (size_t)slot * c->frame_stride, c->n * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return GR_OK;
@@ -456,6 +515,7 @@ int gr_frame_download(gr_ctx *c, uint32_t slot, float *xyz) {
 int gr_frame_set_box(gr_ctx *c, uint32_t slot, const float *box9) {
     int st = slot_check(c, slot); if (st) return st;
     (void)hipSetDevice(c->device);
+    HIPCHK(c, hipStreamSynchronize(c->copy_stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));   // boxes_host[slot] may still feed an earlier async copy
     return set_box(c, slot, box9);
 }
@@ -469,6 +529,7 @@ int gr_frame_copy(gr_ctx *c, uint32_t dst, uint32_t src) {
     int st = slot_check(c, dst); if (st) return st;
     st = slot_check(c, src); if (st) return st;
     (void)hipSetDevice(c->device);
+    SlotUse use_src(c, src), use_dst(c, dst);
     HIPCHK(c, hipMemcpyAsync(c->frames + (size_t)dst * c->frame_stride, c->frames + (size_t)src * c->frame_stride,
                              c->frame_stride * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -485,6 +546,7 @@ int gr_group_center(gr_ctx *c, uint32_t slot, const char *group, int kind, int w
     if (!g) return fail(c, GR_E_GROUP_NOT_FOUND, group ? group : "(null)");
     if (g->n == 0) return fail(c, GR_E_EMPTY_GROUP, group);               // analysis.rs:52-55
     if (kind != GR_CENTER_NAIVE) { st = box_check(c, slot); if (st) return st; }
+    SlotUse use(c, slot);
     const GrSel sel = make_sel(*g);
     st = state_reset(c, 1); if (st) return st;
     if (kind == GR_CENTER_NAIVE) st = center_stage(c, slot, 1, sel, 0, weighted, 0, 1);          // position first (:946-958)
@@ -510,6 +572,7 @@ int gr_group_distance(gr_ctx *c, uint32_t slot, const char *g1, const char *g2, 
 }
 
 static int pairdist_run(gr_ctx *c, uint32_t slot, const GrSel &s1, const GrSel &s2, int dim, float *out_dev) {
+    SlotUse use(c, slot);
     HIPCHK(c, hipMemsetAsync(c->bad_dev, 0xFF, 4 * sizeof(uint32_t), c->stream));
     if (s1.n && s2.n) {
         dim3 grid((s2.n + GR_WG * 4 - 1) / (GR_WG * 4), (s1.n + GR_PD_TI - 1) / GR_PD_TI);
@@ -585,6 +648,7 @@ static int translate_impl(gr_ctx *c, uint32_t slot, const char *group, const flo
     int st = box_check(c, slot); if (st) return st;
     if (g->n == 0) return GR_OK;
     const GrSel sel = make_sel(*g);
+    SlotUse use(c, slot);
     HIPCHK(c, hipMemsetAsync(c->bad_dev, 0xFF, 4 * sizeof(uint32_t), c->stream));
     const uint64_t units = sel.contiguous ? ((uint64_t)sel.n + 3) / 4 + 128 : sel.n;
     uint32_t nwg = (uint32_t)std::min<uint64_t>((units + GR_WG - 1) / GR_WG, 4096);
@@ -617,6 +681,7 @@ int gr_atoms_center(gr_ctx *c, uint32_t slot, const char *ref_group, int dim, in
     st = box_check(c, slot); if (st) return st;
     if (dim < 0 || dim > 7) return fail(c, GR_E_INVALID_ARG, "bad dimension");
     static const int mask[8] = { 0, 1, 2, 4, 3, 5, 6, 7 };
+    { SlotUse use(c, slot); }   // the estimate below and translate_impl each bracket themselves; this orders a pending upload first
     st = state_reset(c, 1); if (st) return st;
     st = center_stage(c, slot, 1, make_sel(*g), 1, weighted, 1, 0); if (st) return st;   // group_estimate_center / _com
     st = fetch_states(c, 1); if (st) return st;
@@ -645,6 +710,7 @@ gr_rmsd_plan *gr_rmsd_plan_create(gr_ctx *ref, uint32_t ref_slot, gr_ctx *target
     if (!g) { *status = fail(ref, GR_E_GROUP_NOT_FOUND, group); return nullptr; }
     if (g->n == 0) { *status = fail(ref, GR_E_EMPTY_GROUP, group); return nullptr; }
     const GrSel sel = make_sel(*g);
+    SlotUse use(ref, ref_slot);
     st = state_reset(ref, 1);
     if (!st) st = pbc_center_stages(ref, ref_slot, 1, sel, 1);
     if (!st) st = fetch_states(ref, 1);
@@ -694,127 +760,180 @@ static int rmsd_exact(gr_rmsd_plan *p, gr_ctx *c, const GrSel &sel, uint32_t fir
     return GR_OK;
 }
 
+// ---- one segment (<= GR_MAX_BATCH frames) in two halves, so a caller can overlap the GPU work of one segment with
+// uploads (gr_frame_upload on the copy stream) and host work for the next:
+//   segment_begin : host checks in the reference's order, state upload, all launches, async state read-back
+//   segment_end   : wait, per-kernel event read-out, exact-path redo of frames whose image proof failed, results
+static int segment_begin(gr_rmsd_plan *p, uint32_t s0, uint32_t nb, int fit) {
+    gr_ctx *c = p->target;
+    Pending &q = p->pend;
+    q = Pending();
+    q.s0 = s0; q.nb = nb; q.fit = fit; q.active = true;
+    SlotUse use(c, s0, nb);
+    const Group *g = find_group(c, p->group.c_str());
+    // host-side checks in the reference's order: box (rmsd.rs:430) -> group exists -> non-empty
+    q.pre.assign(nb, GR_OK); q.pre_idx.assign(nb, 0); q.pre_msg.assign(nb, std::string());
+    for (uint32_t f = 0; f < nb; ++f) {
+        int s = box_check(c, s0 + f);
+        if (s == GR_OK && !g) s = fail(c, GR_E_GROUP_NOT_FOUND, p->group);
+        if (s == GR_OK && g->n == 0) s = fail(c, GR_E_EMPTY_GROUP, p->group);
+        q.pre[f] = s;
+        if (s != GR_OK) { q.pre_msg[f] = c->err; q.pre_idx[f] = c->err_index; }
+        q.any_ok = q.any_ok || s == GR_OK;
+    }
+    if (!q.any_ok) return GR_OK;
+    const GrSel sel = make_sel(*g);
+    if (!p->resolved) {   // weights identical to the target's masses of the group -> one load serves both
+        bool same = (g->n == p->n_ref);
+        if (same) { size_t k = 0; for (uint64_t i : grc::expand(g->blocks)) { const float a = c->masses_host[i], b = p->w_host[k++]; if (!(a == b)) { same = false; break; } } }
+        p->dev.w_is_mass = same ? 1u : 0u; p->resolved = true;
+    }
+    for (uint32_t f = 0; f < nb; ++f) { GrFrameState z = {}; z.err_index = GR_NOIDX; z.status = q.pre[f]; c->state_host[f] = z; }
+    HIPCHK(c, hipMemcpyAsync(c->state_dev, c->state_host, nb * sizeof(GrFrameState), hipMemcpyHostToDevice, c->stream));
+    q.consistent = (g->n == p->n_ref);
+    int st;
+    if (!q.consistent) {
+        // positions and masses of the target are still checked first (extract_data_from_system runs to
+        // completion before number_of_positions_consistent, rmsd.rs:206-214)
+        st = pbc_center_stages(c, s0, nb, sel, 1); if (st) return st;
+    } else if (p->exact) {
+        st = rmsd_exact(p, c, sel, s0, nb, fit); if (st) return st;
+    } else {
+        // groups of sub_batch frames: accumulate -> finalize -> fit back to back on the stream, no host
+        // round trip in between; one state fetch for the whole segment afterwards
+        const uint32_t sb = c->sub_batch;
+        uint32_t ng = 0;
+        const bool two = fit && c->overlap && nb > sb;
+        for (uint32_t f0 = 0; f0 < nb; f0 += sb, ++ng) {
+            const uint32_t nf = std::min<uint32_t>(sb, nb - f0);
+            const uint32_t nch = batch_chunks(c, sel, nf);
+            hipEvent_t *ev = c->pev + 4 * ng;
+            GrAccPartial *parts = c->acc_partials + (size_t)f0 * GR_MAX_CHUNKS;
+            if (c->profile) HIPCHK(c, hipEventRecord(ev[0], c->stream));
+            k_rmsd_accum<0><<<dim3(nch, nf), dim3(GR_WG), 0, c->stream>>>(c->frames, c->frame_stride, s0 + f0, c->masses, sel, c->boxes_dev, p->dev, c->state_dev + f0, parts);
+            if (c->profile) HIPCHK(c, hipEventRecord(ev[1], c->stream));
+            k_rmsd_finalize<0><<<dim3(nf), dim3(GR_WG), 0, c->stream>>>(parts, nch, c->frames, c->frame_stride, s0 + f0, sel, c->boxes_dev, p->dev, c->state_dev + f0);
+            if (c->profile && !two) HIPCHK(c, hipEventRecord(ev[2], c->stream));
+            if (fit) {
+                hipStream_t fs = c->stream;
+                if (two) {
+                    HIPCHK(c, hipEventRecord(c->ev_grp[ng], c->stream));
+                    HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_grp[ng], 0));
+                    fs = c->stream2;
+                    if (c->profile) HIPCHK(c, hipEventRecord(ev[2], fs));
+                }
+                const uint32_t gx = fit_grid(c, nf);
+                k_fit<<<dim3(gx, nf), dim3(GR_WG), 0, fs>>>(c->frames, c->frame_stride, s0 + f0, (uint32_t)c->n, c->boxes_dev, p->dev, c->state_dev + f0);
+                if (c->profile) HIPCHK(c, hipEventRecord(ev[3], fs));
+            }
+        }
+        if (two) {   // join: the state fetch (and the caller) must see every fit finished
+            HIPCHK(c, hipEventRecord(c->ev_join, c->stream2));
+            HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
+        }
+        q.prof_two = two;
+        HIPCHK(c, hipGetLastError());
+        if (c->profile) q.n_prof_groups = ng;
+    }
+    HIPCHK(c, hipMemcpyAsync(c->state_host, c->state_dev, nb * sizeof(GrFrameState), hipMemcpyDeviceToHost, c->stream));
+    return GR_OK;
+}
+
+static int segment_end(gr_rmsd_plan *p, float *rmsd_out, int *status_out, float *R_out) {
+    gr_ctx *c = p->target;
+    Pending &q = p->pend;
+    if (!q.active) return fail(c, GR_E_INVALID_ARG, "no batch in flight");
+    q.active = false;
+    const uint32_t nb = q.nb, s0 = q.s0;
+    const int fit = q.fit;
+    int first_err = GR_OK; uint64_t first_err_index = 0; std::string first_err_msg; uint64_t first_counts[2] = { 0, 0 };
+    auto note = [&](int s) { if (s != GR_OK && first_err == GR_OK) { first_err = s; first_err_index = c->err_index; first_err_msg = c->err; first_counts[0] = c->counts[0]; first_counts[1] = c->counts[1]; } };
+    if (!q.any_ok) {
+        for (uint32_t f = 0; f < nb; ++f) {
+            c->err = q.pre_msg[f]; c->err_index = q.pre_idx[f]; note(q.pre[f]);
+            if (status_out) status_out[f] = q.pre[f];
+            if (rmsd_out) rmsd_out[f] = NAN;
+            if (R_out) for (int k = 0; k < 9; ++k) R_out[9 * (size_t)f + k] = NAN;
+        }
+    } else {
+        const Group *g = find_group(c, p->group.c_str());
+        const GrSel sel = make_sel(*g);
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        for (uint32_t gi = 0; gi < q.n_prof_groups; ++gi) {   // the stream is idle here: read this segment's event pairs
+            const int nk = fit ? 3 : 2;
+            const uint32_t nf = std::min<uint32_t>(c->sub_batch, nb - gi * c->sub_batch);
+            for (int k = 0; k < nk; ++k) {
+                if (k == 1 && q.prof_two) continue;   // finalize..fit-start spans two streams: not a kernel duration
+                float ms = 0.f;
+                HIPCHK(c, hipEventElapsedTime(&ms, c->pev[4 * gi + k], c->pev[4 * gi + k + 1]));
+                c->prof_ms[k] += ms; c->prof_launches[k] += 1; c->prof_frames[k] += nf;
+            }
+        }
+        std::vector<GrFrameState> res(c->state_host, c->state_host + nb);
+        // frames whose single-pass image proof failed are redone on the exact path, one by one
+        for (uint32_t f = 0; f < nb; ++f) {
+            if (res[f].status != GR_ST_FALLBACK) continue;
+            p->last_fallbacks++;
+            SlotUse use(c, s0 + f);
+            int st = state_reset(c, 1); if (st) return st;
+            st = rmsd_exact(p, c, sel, s0 + f, 1, fit); if (st) return st;
+            st = fetch_states(c, 1); if (st) return st;
+            res[f] = c->state_host[0];
+        }
+        for (uint32_t f = 0; f < nb; ++f) {
+            int s = res[f].status;
+            if (q.pre[f] != GR_OK) { s = q.pre[f]; c->err = q.pre_msg[f]; c->err_index = q.pre_idx[f]; }
+            else if (s == GR_OK && !q.consistent) {
+                c->counts[0] = p->n_ref; c->counts[1] = g->n;
+                s = fail(c, GR_E_INCONSISTENT_GROUP, p->group);
+            } else if (s != GR_OK) {
+                s = frame_status(c, res[f]);
+            }
+            note(s);
+            if (status_out) status_out[f] = s;
+            if (rmsd_out) rmsd_out[f] = (s == GR_OK) ? res[f].rmsd : NAN;
+            if (R_out) for (int k = 0; k < 9; ++k) R_out[9 * (size_t)f + k] = (s == GR_OK) ? res[f].R[k] : NAN;
+        }
+    }
+    if (first_err != GR_OK) { c->err = first_err_msg; c->err_index = first_err_index; c->counts[0] = first_counts[0]; c->counts[1] = first_counts[1]; }
+    return first_err;
+}
+
 static int rmsd_batch_impl(gr_rmsd_plan *p, uint32_t first_slot, uint32_t n_frames, float *rmsd_out, int *status_out, float *R_out, int fit) {
     if (!p || !p->target) return GR_E_INVALID_ARG;
     gr_ctx *c = p->target;
     int st = slot_check(c, first_slot, n_frames); if (st) return st;
     (void)hipSetDevice(c->device);
+    if (p->pend.active) return fail(c, GR_E_INVALID_ARG, "a batch begun with gr_rmsd_batch_begin is still in flight");
     p->last_fallbacks = 0;
-    int first_err = GR_OK; uint64_t first_err_index = 0; std::string first_err_msg; uint64_t first_counts[2] = { 0, 0 };
-    auto note = [&](int s) { if (s != GR_OK && first_err == GR_OK) { first_err = s; first_err_index = c->err_index; first_err_msg = c->err; first_counts[0] = c->counts[0]; first_counts[1] = c->counts[1]; } };
-    const Group *g = find_group(c, p->group.c_str());
+    int first_err = GR_OK; uint64_t e_idx = 0; std::string e_msg; uint64_t e_cnt[2] = { 0, 0 };
     for (uint32_t b0 = 0; b0 < n_frames; b0 += GR_MAX_BATCH) {
         const uint32_t nb = std::min<uint32_t>(GR_MAX_BATCH, n_frames - b0);
-        const uint32_t s0 = first_slot + b0;
-        // host-side checks in the reference's order: box (rmsd.rs:430) -> group exists -> non-empty
-        std::vector<int> pre(nb, GR_OK);
-        bool any_ok = false;
-        for (uint32_t f = 0; f < nb; ++f) {
-            int s = box_check(c, s0 + f);
-            if (s == GR_OK && !g) s = fail(c, GR_E_GROUP_NOT_FOUND, p->group);
-            if (s == GR_OK && g->n == 0) s = fail(c, GR_E_EMPTY_GROUP, p->group);
-            pre[f] = s; note(s);
-            any_ok = any_ok || s == GR_OK;
-        }
-        if (any_ok) {
-            const GrSel sel = make_sel(*g);
-            if (!p->resolved) {   // weights identical to the target's masses of the group -> one load serves both
-                bool same = (g->n == p->n_ref);
-                if (same) { size_t k = 0; for (uint64_t i : grc::expand(g->blocks)) { const float a = c->masses_host[i], b = p->w_host[k++]; if (!(a == b)) { same = false; break; } } }
-                p->dev.w_is_mass = same ? 1u : 0u; p->resolved = true;
-            }
-            for (uint32_t f = 0; f < nb; ++f) { GrFrameState z = {}; z.err_index = GR_NOIDX; z.status = pre[f]; c->state_host[f] = z; }
-            HIPCHK(c, hipMemcpyAsync(c->state_dev, c->state_host, nb * sizeof(GrFrameState), hipMemcpyHostToDevice, c->stream));
-            const bool consistent = (g->n == p->n_ref);
-            uint32_t n_prof_groups = 0;
-            bool prof_two = false;
-            if (!consistent) {
-                // positions and masses of the target are still checked first (extract_data_from_system runs to
-                // completion before number_of_positions_consistent, rmsd.rs:206-214)
-                st = pbc_center_stages(c, s0, nb, sel, 1); if (st) return st;
-            } else if (p->exact) {
-                st = rmsd_exact(p, c, sel, s0, nb, fit); if (st) return st;
-            } else {
-                // groups of sub_batch frames: accumulate -> finalize -> fit back to back on the stream, no host
-                // round trip in between; one state fetch for the whole batch afterwards
-                const uint32_t sb = c->sub_batch;
-                uint32_t ng = 0;
-                const bool two = fit && c->overlap && nb > sb;
-                for (uint32_t f0 = 0; f0 < nb; f0 += sb, ++ng) {
-                    const uint32_t nf = std::min<uint32_t>(sb, nb - f0);
-                    const uint32_t nch = batch_chunks(c, sel, nf);
-                    hipEvent_t *ev = c->pev + 4 * ng;
-                    GrAccPartial *parts = c->acc_partials + (size_t)f0 * GR_MAX_CHUNKS;
-                    if (c->profile) HIPCHK(c, hipEventRecord(ev[0], c->stream));
-                    k_rmsd_accum<0><<<dim3(nch, nf), dim3(GR_WG), 0, c->stream>>>(c->frames, c->frame_stride, s0 + f0, c->masses, sel, c->boxes_dev, p->dev, c->state_dev + f0, parts);
-                    if (c->profile) HIPCHK(c, hipEventRecord(ev[1], c->stream));
-                    k_rmsd_finalize<0><<<dim3(nf), dim3(GR_WG), 0, c->stream>>>(parts, nch, c->frames, c->frame_stride, s0 + f0, sel, c->boxes_dev, p->dev, c->state_dev + f0);
-                    if (c->profile && !two) HIPCHK(c, hipEventRecord(ev[2], c->stream));
-                    if (fit) {
-                        hipStream_t fs = c->stream;
-                        if (two) {
-                            HIPCHK(c, hipEventRecord(c->ev_grp[ng], c->stream));
-                            HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_grp[ng], 0));
-                            fs = c->stream2;
-                            if (c->profile) HIPCHK(c, hipEventRecord(ev[2], fs));
-                        }
-                        const uint32_t gx = fit_grid(c, nf);
-                        k_fit<<<dim3(gx, nf), dim3(GR_WG), 0, fs>>>(c->frames, c->frame_stride, s0 + f0, (uint32_t)c->n, c->boxes_dev, p->dev, c->state_dev + f0);
-                        if (c->profile) HIPCHK(c, hipEventRecord(ev[3], fs));
-                    }
-                }
-                if (two) {   // join: the state fetch (and the caller) must see every fit finished
-                    HIPCHK(c, hipEventRecord(c->ev_join, c->stream2));
-                    HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
-                }
-                prof_two = two;
-                HIPCHK(c, hipGetLastError());
-                if (c->profile) n_prof_groups = ng;
-            }
-            st = fetch_states(c, nb); if (st) return st;
-            for (uint32_t gi = 0; gi < n_prof_groups; ++gi) {   // the stream is idle here: read this batch's event pairs
-                const int nk = fit ? 3 : 2;
-                const uint32_t nf = std::min<uint32_t>(c->sub_batch, nb - gi * c->sub_batch);
-                for (int k = 0; k < nk; ++k) {
-                    if (k == 1 && prof_two) continue;   // finalize..fit-start spans two streams: not a kernel duration
-                    float ms = 0.f;
-                    HIPCHK(c, hipEventElapsedTime(&ms, c->pev[4 * gi + k], c->pev[4 * gi + k + 1]));
-                    c->prof_ms[k] += ms; c->prof_launches[k] += 1; c->prof_frames[k] += nf;
-                }
-            }
-            std::vector<GrFrameState> res(c->state_host, c->state_host + nb);
-            // frames whose single-pass image proof failed are redone on the exact path, one by one
-            for (uint32_t f = 0; f < nb; ++f) {
-                if (res[f].status != GR_ST_FALLBACK) continue;
-                p->last_fallbacks++;
-                st = state_reset(c, 1); if (st) return st;
-                st = rmsd_exact(p, c, sel, s0 + f, 1, fit); if (st) return st;
-                st = fetch_states(c, 1); if (st) return st;
-                res[f] = c->state_host[0];
-            }
-            for (uint32_t f = 0; f < nb; ++f) {
-                int s = res[f].status;
-                if (s == GR_OK && !consistent) {
-                    c->counts[0] = p->n_ref; c->counts[1] = g->n;
-                    s = fail(c, GR_E_INCONSISTENT_GROUP, p->group);
-                } else if (s != GR_OK && pre[f] == GR_OK) {
-                    s = frame_status(c, res[f]);
-                }
-                note(s);
-                if (status_out) status_out[b0 + f] = s;
-                if (rmsd_out) rmsd_out[b0 + f] = (s == GR_OK) ? res[f].rmsd : NAN;
-                if (R_out) for (int k = 0; k < 9; ++k) R_out[9 * (size_t)(b0 + f) + k] = (s == GR_OK) ? res[f].R[k] : NAN;
-            }
-        } else {
-            for (uint32_t f = 0; f < nb; ++f) {
-                if (status_out) status_out[b0 + f] = pre[f];
-                if (rmsd_out) rmsd_out[b0 + f] = NAN;
-                if (R_out) for (int k = 0; k < 9; ++k) R_out[9 * (size_t)(b0 + f) + k] = NAN;
-            }
-        }
+        st = segment_begin(p, first_slot + b0, nb, fit); if (st) { p->pend.active = false; return st; }
+        st = segment_end(p, rmsd_out ? rmsd_out + b0 : nullptr, status_out ? status_out + b0 : nullptr, R_out ? R_out + 9 * (size_t)b0 : nullptr);
+        if (st == GR_E_HIP) return st;
+        if (st != GR_OK && first_err == GR_OK) { first_err = st; e_idx = c->err_index; e_msg = c->err; e_cnt[0] = c->counts[0]; e_cnt[1] = c->counts[1]; }
     }
-    if (first_err != GR_OK) { c->err = first_err_msg; c->err_index = first_err_index; c->counts[0] = first_counts[0]; c->counts[1] = first_counts[1]; }
+    if (first_err != GR_OK) { c->err = e_msg; c->err_index = e_idx; c->counts[0] = e_cnt[0]; c->counts[1] = e_cnt[1]; }
     return first_err;
+}
+
+int gr_rmsd_batch_begin(gr_rmsd_plan *p, uint32_t first_slot, uint32_t n, int fit) {
+    if (!p || !p->target) return GR_E_INVALID_ARG;
+    gr_ctx *c = p->target;
+    int st = slot_check(c, first_slot, n); if (st) return st;
+    if (n > GR_MAX_BATCH) return fail(c, GR_E_INVALID_ARG, "at most 256 frames per asynchronous batch");
+    if (p->pend.active) return fail(c, GR_E_INVALID_ARG, "a batch is already in flight on this plan");
+    (void)hipSetDevice(c->device);
+    p->last_fallbacks = 0;
+    st = segment_begin(p, first_slot, n, fit ? 1 : 0);
+    if (st) p->pend.active = false;
+    return st;
+}
+int gr_rmsd_batch_end(gr_rmsd_plan *p, float *rmsd_out, int *status_out, float *R_out) {
+    if (!p || !p->target) return GR_E_INVALID_ARG;
+    (void)hipSetDevice(p->target->device);
+    return segment_end(p, rmsd_out, status_out, R_out);
 }
 
 int gr_rmsd_batch(gr_rmsd_plan *p, uint32_t first_slot, uint32_t n, float *rmsd_out, int *status_out, float *R_out) {
@@ -876,6 +995,7 @@ int gr_profile_read(const gr_ctx *c, int kernel, double *ms_total, uint64_t *lau
 int gr_synth_reference(gr_ctx *c, uint32_t slot, const float *box9, float radius, uint64_t seed) {
     int st = slot_check(c, slot); if (st) return st;
     (void)hipSetDevice(c->device);
+    HIPCHK(c, hipStreamSynchronize(c->copy_stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     st = set_box(c, slot, box9); if (st) return st;
     st = box_check(c, slot); if (st) return st;
@@ -893,6 +1013,7 @@ int gr_synth_frames(gr_ctx *c, uint32_t ref_slot, uint32_t first_slot, uint32_t 
     (void)hipSetDevice(c->device);
     st = box_check(c, ref_slot); if (st) return st;
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->copy_stream));
     for (uint32_t f = 0; f < n_frames; ++f) { st = set_box(c, first_slot + f, &c->box9_host[9 * (size_t)ref_slot]); if (st) return st; }
     for (uint32_t f0 = 0; f0 < n_frames; f0 += 1024) {
         const uint32_t nf = std::min<uint32_t>(1024, n_frames - f0);
@@ -906,6 +1027,7 @@ int gr_synth_frames(gr_ctx *c, uint32_t ref_slot, uint32_t first_slot, uint32_t 
 int gr_synth_uniform(gr_ctx *c, uint32_t slot, const float *box9, uint64_t seed) {
     int st = slot_check(c, slot); if (st) return st;
     (void)hipSetDevice(c->device);
+    HIPCHK(c, hipStreamSynchronize(c->copy_stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     st = set_box(c, slot, box9); if (st) return st;
     st = box_check(c, slot); if (st) return st;

@@ -314,6 +314,15 @@ class System:
         if step is not None: self.simulation_step = step
         if time is not None: self.simulation_time = time
 
+    def upload_async(self, host_array, box, slot):
+        """gr_frame_upload without waiting: host_array must stay valid (use pinned_array) until upload_wait/sync"""
+        st = self._lib.gr_frame_upload(self._ctx, slot, _ptr(host_array), _ptr(_as_box9(box)))
+        if st != OK:
+            raise DeviceError("frame_upload", self._err(st)[1], st)
+
+    def upload_wait(self, slot):
+        self._lib.gr_frame_upload_wait(self._ctx, slot)
+
     def get_positions(self, slot=0):
         out = np.empty((self.n_atoms, 3), np.float32)
         st = self._lib.gr_frame_download(self._ctx, slot, _ptr(out))
@@ -484,6 +493,22 @@ class System:
             raise DeviceError("synth_uniform", self._err(st)[1], st)
 
 
+def pinned_array(shape, dtype=np.float32):
+    """numpy array over pinned host memory (gr_host_alloc): asynchronous H2D source for upload_async"""
+    lib = _lib.load()
+    n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    ptr = lib.gr_host_alloc(n)
+    if not ptr:
+        raise MemoryError("gr_host_alloc failed")
+    buf = (C.c_char * n).from_address(ptr)
+    arr = np.frombuffer(buf, dtype=dtype).reshape(shape)
+    return arr, ptr
+
+
+def pinned_free(ptr):
+    _lib.load().gr_host_free(ptr)
+
+
 class RMSDPlan:
     """Cached reference side of the RMSD calculation = RMSDConverterAnalyzer::new (rmsd.rs:186-203)."""
 
@@ -514,6 +539,21 @@ class RMSDPlan:
             self.target._raise_rmsd(st)
         if return_rotation:
             return r, s, R.reshape(n_frames, 3, 3).transpose(0, 2, 1).copy()
+        return r, s
+
+    def begin(self, first_slot, n_frames, fit):
+        """issue the whole batch and return at once (gr_rmsd_batch_begin); pair with end()"""
+        st = self._lib.gr_rmsd_batch_begin(self._plan, first_slot, n_frames, int(bool(fit)))
+        if st != OK:
+            self.target._raise_rmsd(st)
+        self._pending_n = n_frames
+
+    def end(self, raise_on_error=True):
+        n = self._pending_n
+        r = np.zeros(n, np.float32); s = np.zeros(n, np.int32)
+        st = self._lib.gr_rmsd_batch_end(self._plan, _ptr(r), _ptr(s), None)
+        if st != OK and raise_on_error:
+            self.target._raise_rmsd(st)
         return r, s
 
     def rmsd_fit(self, first_slot=0, n_frames=1, raise_on_error=True):

@@ -116,9 +116,13 @@ int gr_group_blocks(const gr_ctx *ctx, const char *name, uint64_t *out_start, ui
 
 /* ---------------------------------------------------------------- frames
  * TrajRead::update_system (src/io/traj_read.rs:160-186; molly_xtc.rs:294-307; xdrfile_xtc.rs:88-104):
- * positions as the xtc readers deliver them (rvec[n_atoms], 12-byte records) + box. Asynchronous on
- * the context's stream when xyz is pinned host memory (gr_host_alloc); ordered with later calls. */
+ * positions as the xtc readers deliver them (rvec[n_atoms], 12-byte records) + box.  The copy runs on the
+ * context's own copy stream, asynchronously when xyz is pinned host memory (gr_host_alloc): kernels on other
+ * slots keep running (double buffering); any later call that touches `slot` waits for it, and the copy itself
+ * waits for kernels that still read the slot.  Keep xyz valid until gr_frame_upload_wait / gr_sync. */
 int gr_frame_upload(gr_ctx *ctx, uint32_t slot, const float *xyz, const float *box9);
+/* block until the upload into `slot` has left the host buffer (the staging buffer may then be reused) */
+int gr_frame_upload_wait(gr_ctx *ctx, uint32_t slot);
 int gr_frame_download(gr_ctx *ctx, uint32_t slot, float *xyz);        /* blocking */
 int gr_frame_set_box(gr_ctx *ctx, uint32_t slot, const float *box9); /* System::set_box / reset_box (NULL) */
 int gr_frame_get_box(const gr_ctx *ctx, uint32_t slot, float box9[9]); /* GR_E_NO_BOX if none */
@@ -176,6 +180,12 @@ int gr_rmsd_batch(gr_rmsd_plan *plan, uint32_t first_slot, uint32_t n_frames,
  * frame; a frame whose analysis fails is left unmodified (rmsd.rs:91). */
 int gr_rmsd_fit_batch(gr_rmsd_plan *plan, uint32_t first_slot, uint32_t n_frames,
                       float *rmsd_out, int *status_out);
+/* The same in two halves, for pipelines that keep the GPU busy while the host decodes / uploads the next frames:
+ * begin issues every launch for `n_frames` (<= 256) consecutive slots and returns without waiting; end waits and
+ * delivers the results.  One batch in flight per plan; between the two calls the context may be used for
+ * gr_frame_upload / gr_frame_upload_wait / gr_host_* only (uploads run on the copy stream beside the kernels). */
+int gr_rmsd_batch_begin(gr_rmsd_plan *plan, uint32_t first_slot, uint32_t n_frames, int fit);
+int gr_rmsd_batch_end(gr_rmsd_plan *plan, float *rmsd_out, int *status_out, float *R_out);
 /* number of frames of the last batch that left the single-pass path for the multi-pass exact path */
 uint32_t gr_rmsd_plan_last_fallbacks(const gr_rmsd_plan *plan);
 /* force the multi-pass exact path (parity testing of both paths) */
