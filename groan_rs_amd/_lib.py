@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgroan_hip.so")
+LIB_PATH = os.environ.get("GR_LIB_PATH") or os.path.join(_HERE, "libgroan_hip.so")   # GR_LIB_PATH: A/B builds only
 
 c_u64p = C.POINTER(C.c_uint64)
 c_f32p = C.POINTER(C.c_float)

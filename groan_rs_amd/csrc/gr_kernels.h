@@ -311,15 +311,18 @@ __global__ void k_state_reset(GrFrameState *state, uint32_t n) {
 //         = wrap(x_i + shift) - box_centre, the reference's own q_i (rmsd.rs:479-492)       [MODE 1]
 //   [0] sum m        [1..3] sum m v      [4..12] A = sum p v^T (unweighted, rmsd.rs:567-570)
 //   [13..21] B = sum w p v^T             [22] sum w |v|^2      [23..25] sum w v
-//   [26..31] Bai-Breen sums of the fractional coordinates of v (MODE 0 only; hardware sin/cos in
-//            revolutions -- the estimate is only used to PROVE that the images chosen about g are
-//            the images the reference chooses about its own centre estimate)
-//   min/max of v per axis, first atom without position / mass.
+//   [26..31] first and second moments of the fractional coordinates of v (MODE 0 only): with the fractional
+//            extent they BOUND where the reference's Bai-Breen centre estimate can lie, which is what proves
+//            that the images chosen about g are the images the reference chooses about its own centre
+//   min/max of v per axis (Cartesian and fractional), first atom without position / mass.
 #define GR_ACC_K 32
-struct GrAccPartial { double s[GR_ACC_K]; float vmin[3], vmax[3]; uint32_t bad_pos, bad_mass; };
+struct GrAccPartial { double s[GR_ACC_K]; float vmin[3], vmax[3], fmin[3], fmax[3]; uint32_t bad_pos, bad_mass; };
 
+#ifndef GR_ACC_MIN_WAVES
+#define GR_ACC_MIN_WAVES 1
+#endif
 template <int MODE>
-__global__ __launch_bounds__(GR_WG) void k_rmsd_accum(
+__global__ __launch_bounds__(GR_WG, GR_ACC_MIN_WAVES) void k_rmsd_accum(
     const float *__restrict__ frames, size_t frame_stride, uint32_t first_slot,
     const float *__restrict__ masses, GrSel sel, const GrBox *__restrict__ boxes,
     GrPlanDev plan, const GrFrameState *__restrict__ state, GrAccPartial *__restrict__ partials) {
@@ -345,6 +348,7 @@ __global__ __launch_bounds__(GR_WG) void k_rmsd_accum(
     const float rws2 = box.r_ws * box.r_ws;
     const bool tric = !box.ortho;
     float fsum[6] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
+    float fmn[3] = { 3.0e38f, 3.0e38f, 3.0e38f }, fmx[3] = { -3.0e38f, -3.0e38f, -3.0e38f };   // fractional extent of v
 
     // Precision plan.  rmsd^2 is the small difference of sums of size W r^2 (it must come out ~0 for a frame
     // that is a rigid copy of the reference: the reference's own tests ask |rmsd| <= 1e-4 there, i.e. 1e-9
@@ -354,16 +358,22 @@ __global__ __launch_bounds__(GR_WG) void k_rmsd_accum(
     // random in sign) that is then added to its fp64 accumulator: 2.25 instead of 9 fp64 adds per atom.
     struct A4 { float x[4], y[4], z[4], m[4], px[4], py[4], pz[4], w[4]; uint32_t i[4]; bool ok[4]; };
     const bool wm = plan.w_is_mass != 0;
-    auto flush4 = [&](const A4 &a) {
+    // `checked` = the group straddles the ends of the selection (or comes from the gather path's tail): per-atom
+    // validity + NaN tests.  Interior groups skip them: a NaN position or mass then simply poisons the fp64 sums,
+    // which the finalize kernel detects and answers by sending the frame to the multi-pass path, whose kernels
+    // report the first atom without position / mass in the reference's order.
+    auto flush4 = [&](const A4 &a, const bool checked) {
         float part[9];
 #pragma unroll
         for (int k = 0; k < 9; ++k) part[k] = 0.0f;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            if (!a.ok[q]) continue;
             float m = a.m[q];
-            if (m != m) { bad_mass = min(bad_mass, a.i[q]); m = 0.0f; }
-            if (a.x[q] != a.x[q]) { bad_pos = min(bad_pos, a.i[q]); continue; }
+            if (checked) {
+                if (!a.ok[q]) continue;
+                if (m != m) { bad_mass = min(bad_mass, a.i[q]); m = 0.0f; }
+                if (a.x[q] != a.x[q]) { bad_pos = min(bad_pos, a.i[q]); continue; }
+            }
             float vx, vy, vz;
             if (MODE == 0) {
                 // image of x nearest to g: closed-form brick reduction along c, b, a ...
@@ -376,13 +386,15 @@ __global__ __launch_bounds__(GR_WG) void k_rmsd_accum(
                 vx = fmaf(-ka, box.ax, vx);
                 // ... which is already THE minimum image whenever |v| < r_ws; otherwise search the table
                 if (tric && vx * vx + vy * vy + vz * vz >= rws2) gr_tric_refine(vx, vy, vz, box);
-                // fractional coordinates of v in revolutions -> hardware sin/cos
+                // fractional coordinates of v: first and second moments (image proof, see k_rmsd_finalize)
                 const float fc = vz * icz;
                 const float uy = fmaf(-fc, box.cy, vy);
                 const float fb = uy * iby;
                 const float fa = (vx - fb * box.bx - fc * box.cx) * iax;
-                fsum[0] += __builtin_amdgcn_cosf(fa); fsum[1] += __builtin_amdgcn_cosf(fb); fsum[2] += __builtin_amdgcn_cosf(fc);
-                fsum[3] += __builtin_amdgcn_sinf(fa); fsum[4] += __builtin_amdgcn_sinf(fb); fsum[5] += __builtin_amdgcn_sinf(fc);
+                fsum[0] += fa; fsum[1] += fb; fsum[2] += fc;
+                fsum[3] = fmaf(fa, fa, fsum[3]); fsum[4] = fmaf(fb, fb, fsum[4]); fsum[5] = fmaf(fc, fc, fsum[5]);
+                fmn[0] = fminf(fmn[0], fa); fmn[1] = fminf(fmn[1], fb); fmn[2] = fminf(fmn[2], fc);
+                fmx[0] = fmaxf(fmx[0], fa); fmx[1] = fmaxf(fmx[1], fb); fmx[2] = fmaxf(fmx[2], fc);
             } else {
                 vx = a.x[q] + sx; vy = a.y[q] + sy; vz = a.z[q] + sz;
                 gr_wrap(vx, vy, vz, box);
@@ -435,7 +447,7 @@ __global__ __launch_bounds__(GR_WG) void k_rmsd_accum(
             q.w[0] = ww.x; q.w[1] = ww.y; q.w[2] = ww.z; q.w[3] = ww.w;
 #pragma unroll
             for (int k = 0; k < 4; ++k) { q.i[k] = i + k; q.ok[k] = (i + k >= first) && (i + k < last); }
-            flush4(q);
+            if (MODE == 0 && i >= first && i + 3 < last) flush4(q, false); else flush4(q, true);
         }
     } else {
         const uint32_t n4 = (sel.n + 3u) >> 2;
@@ -452,7 +464,7 @@ __global__ __launch_bounds__(GR_WG) void k_rmsd_accum(
                 t.px[q] = plan.p[3 * (size_t)jj]; t.py[q] = plan.p[3 * (size_t)jj + 1]; t.pz[q] = plan.p[3 * (size_t)jj + 2];
                 t.w[q] = plan.w_is_mass ? t.m[q] : plan.w[jj];
             }
-            flush4(t);
+            if (MODE == 0 && j4 * 4 + 3 < sel.n) flush4(t, false); else flush4(t, true);
         }
     }
 #pragma unroll
@@ -461,13 +473,16 @@ __global__ __launch_bounds__(GR_WG) void k_rmsd_accum(
     gr_block_sum<GR_ACC_K>(acc, lds);
     bad_pos = gr_block_min_u32(bad_pos, ldsu);
     bad_mass = gr_block_min_u32(bad_mass, ldsu);
-    float rmn[3], rmx[3];
-    for (int a = 0; a < 3; ++a) { rmn[a] = gr_block_min_f32(mn[a], ldsf); rmx[a] = -gr_block_min_f32(-mx[a], ldsf); }
+    float rmn[3], rmx[3], rfmn[3], rfmx[3];
+    for (int a = 0; a < 3; ++a) {
+        rmn[a] = gr_block_min_f32(mn[a], ldsf); rmx[a] = -gr_block_min_f32(-mx[a], ldsf);
+        rfmn[a] = gr_block_min_f32(fmn[a], ldsf); rfmx[a] = -gr_block_min_f32(-fmx[a], ldsf);
+    }
     if (threadIdx.x == 0) {
         GrAccPartial &o = partials[(size_t)frame * nchunks + chunk];
 #pragma unroll
         for (int k = 0; k < GR_ACC_K; ++k) o.s[k] = acc[k];
-        for (int a = 0; a < 3; ++a) { o.vmin[a] = rmn[a]; o.vmax[a] = rmx[a]; }
+        for (int a = 0; a < 3; ++a) { o.vmin[a] = rmn[a]; o.vmax[a] = rmx[a]; o.fmin[a] = rfmn[a]; o.fmax[a] = rfmx[a]; }
         o.bad_pos = bad_pos; o.bad_mass = bad_mass;
     }
 }
@@ -539,8 +554,9 @@ __device__ inline void gr_kabsch_rotation(const double H[3][3], double R[3][3]) 
 //   H  = A - (sum p) cv^T,  Hw = B - (sum w p) cv^T,  sum w|q|^2 = sum w|v|^2 - 2 cv.sum(w v) + W |cv|^2
 //   R  from H;  rmsd^2 = (sum w|p|^2 + sum w|q|^2 - 2 sum_ab R_ab Hw_ab) / W      (= rmsd.rs:592-599 expanded)
 // MODE 0 also proves the single-pass images equal the reference's (see DESIGN.md "image proof"):
-// every v_i must lie strictly inside the minimum-image cell about BOTH the Bai-Breen centre and the COM;
-// otherwise the frame is flagged GR_ST_FALLBACK and redone by the multi-pass path.
+// every v_i must lie strictly inside the minimum-image cell about BOTH the reference's Bai-Breen centre estimate
+// (wherever in its rigorously bounded region it is) and the COM; otherwise the frame is flagged GR_ST_FALLBACK
+// and redone by the multi-pass path.
 template <int MODE>
 __global__ __launch_bounds__(GR_WG) void k_rmsd_finalize(
     const GrAccPartial *__restrict__ partials, uint32_t nchunks,
@@ -554,18 +570,25 @@ __global__ __launch_bounds__(GR_WG) void k_rmsd_finalize(
 #pragma unroll
     for (int k = 0; k < GR_ACC_K; ++k) acc[k] = 0.0;
     float mn[3] = { 3.0e38f, 3.0e38f, 3.0e38f }, mx[3] = { -3.0e38f, -3.0e38f, -3.0e38f };
+    float fmn[3] = { 3.0e38f, 3.0e38f, 3.0e38f }, fmx[3] = { -3.0e38f, -3.0e38f, -3.0e38f };
     uint32_t bad_pos = GR_NOIDX, bad_mass = GR_NOIDX;
     for (uint32_t c = threadIdx.x; c < nchunks; c += GR_WG) {
         const GrAccPartial &p = partials[(size_t)frame * nchunks + c];
 #pragma unroll
         for (int k = 0; k < GR_ACC_K; ++k) acc[k] += p.s[k];
-        for (int a = 0; a < 3; ++a) { mn[a] = fminf(mn[a], p.vmin[a]); mx[a] = fmaxf(mx[a], p.vmax[a]); }
+        for (int a = 0; a < 3; ++a) {
+            mn[a] = fminf(mn[a], p.vmin[a]); mx[a] = fmaxf(mx[a], p.vmax[a]);
+            fmn[a] = fminf(fmn[a], p.fmin[a]); fmx[a] = fmaxf(fmx[a], p.fmax[a]);
+        }
         bad_pos = min(bad_pos, p.bad_pos); bad_mass = min(bad_mass, p.bad_mass);
     }
     gr_block_sum<GR_ACC_K>(acc, lds);
     bad_pos = gr_block_min_u32(bad_pos, ldsu);
     bad_mass = gr_block_min_u32(bad_mass, ldsu);
-    for (int a = 0; a < 3; ++a) { mn[a] = gr_block_min_f32(mn[a], ldsf); mx[a] = -gr_block_min_f32(-mx[a], ldsf); }
+    for (int a = 0; a < 3; ++a) {
+        mn[a] = gr_block_min_f32(mn[a], ldsf); mx[a] = -gr_block_min_f32(-mx[a], ldsf);
+        fmn[a] = gr_block_min_f32(fmn[a], ldsf); fmx[a] = -gr_block_min_f32(-fmx[a], ldsf);
+    }
     if (threadIdx.x != 0) return;
     GrFrameState &st = state[frame];
     if (st.status != 0) return;
@@ -574,6 +597,11 @@ __global__ __launch_bounds__(GR_WG) void k_rmsd_finalize(
         // get_com: positions of the whole group are checked before any mass (iterators.rs:1405-1422)
         if (bad_pos != GR_NOIDX) { st.status = 6; st.err_index = bad_pos; return; }
         if (bad_mass != GR_NOIDX) { st.status = 7; st.err_index = bad_mass; return; }
+        // interior groups are not NaN-tested atom by atom: a missing position / mass shows up here as a NaN sum
+        // and the frame goes to the multi-pass path, which names the atom
+        bool poisoned = false;
+        for (int k = 0; k < 26; ++k) if (acc[k] != acc[k]) poisoned = true;
+        if (poisoned) { st.status = GR_ST_FALLBACK; return; }
     }
     const double M = acc[0];
     double cv[3] = { 0, 0, 0 };
@@ -582,18 +610,39 @@ __global__ __launch_bounds__(GR_WG) void k_rmsd_finalize(
         const float *xyz = frames + (size_t)(first_slot + frame) * frame_stride;
         const uint32_t i0 = sel.contiguous ? sel.start : sel.idx[0];
         const double g[3] = { xyz[3 * (size_t)i0], xyz[3 * (size_t)i0 + 1], xyz[3 * (size_t)i0 + 2] };
-        // Bai-Breen centre of v (fractional circular means -> Cartesian)
+        // Where can the reference's Bai-Breen centre estimate c' lie?  Per fractional axis it is the circular mean
+        // of the f_i.  With mu = mean f, theta_i = 2 pi (f_i - mu) (sum theta_i = 0), |theta_i| <= Theta = 2 pi E
+        // (E = fractional extent, must be < 1/2), T = sum theta_i^2:
+        //   |sum sin theta_i| = |sum (sin theta_i - theta_i)| <= Theta T / 6,   sum cos theta_i >= n - T / 2
+        //   => |c'_a - mu_a| <= atan((Theta T / 6) / (n - T / 2)) / (2 pi) =: eps_a          (rigorous, no sin/cos)
+        // so c' = mu + e with |e| <= sum_a eps_a |box_a|.
         const double TWO_PI = 6.283185307179586;
-        const double fa = atan2(acc[29], acc[26]) / TWO_PI, fb = atan2(acc[30], acc[27]) / TWO_PI, fc = atan2(acc[31], acc[28]) / TWO_PI;
-        const double ce[3] = { fa * b.ax + fb * b.bx + fc * b.cx, fb * b.by + fc * b.cy, fc * b.cz };
-        const double margin = 1.0e-3;   // nm; >> the error of the hardware sin/cos estimate (~1e-5 nm)
+        const double nsel = (double)sel.n;
+        double mu[3], eps[3];
         bool ok = true;
+        for (int a = 0; a < 3; ++a) {
+            mu[a] = acc[26 + a] / nsel;
+            const double E = (double)fmx[a] - (double)fmn[a];
+            double T = TWO_PI * TWO_PI * (acc[29 + a] - nsel * mu[a] * mu[a]);
+            if (T < 0) T = 0;
+            T *= 1.0 + 1e-4; T += 1e-3;                       // f32 rounding of the two moments
+            const double Theta = TWO_PI * E * (1.0 + 1e-6);
+            const double den = nsel - 0.5 * T;
+            if (!(E < 0.4999) || !(den > 0.0)) { ok = false; eps[a] = 0; continue; }
+            eps[a] = atan((Theta * T / 6.0) / den) / TWO_PI;
+        }
+        // centre candidate in Cartesian coordinates and the radius of the region c' is confined to
+        const double ce[3] = { mu[0] * b.ax + mu[1] * b.bx + mu[2] * b.cx, mu[1] * b.by + mu[2] * b.cy, mu[2] * b.cz };
+        const double la = b.ax, lb = sqrt((double)b.bx * b.bx + (double)b.by * b.by), lc = sqrt((double)b.cx * b.cx + (double)b.cy * b.cy + (double)b.cz * b.cz);
+        const double slack_tric = eps[0] * la + eps[1] * lb + eps[2] * lc;
+        const double slack_ortho[3] = { eps[0] * b.ax, eps[1] * b.by, eps[2] * b.cz };
+        const double margin = 1.0e-3;   // nm
         const double *cen[2] = { ce, cv };
         for (int t = 0; t < 2; ++t) {
             if (b.ortho) {
                 const double L[3] = { b.ax, b.by, b.cz };
                 for (int a = 0; a < 3; ++a) {
-                    const double far = fmax(fabs((double)mx[a] - cen[t][a]), fabs((double)mn[a] - cen[t][a]));
+                    const double far = fmax(fabs((double)mx[a] - cen[t][a]), fabs((double)mn[a] - cen[t][a])) + (t == 0 ? slack_ortho[a] : 0.0);
                     if (!(far < 0.5 * L[a] - margin)) ok = false;
                 }
             } else {
@@ -602,7 +651,7 @@ __global__ __launch_bounds__(GR_WG) void k_rmsd_finalize(
                     const double far = fmax(fabs((double)mx[a] - cen[t][a]), fabs((double)mn[a] - cen[t][a]));
                     r2 += far * far;
                 }
-                if (!(sqrt(r2) < (double)b.r_ws - margin)) ok = false;
+                if (!(sqrt(r2) + (t == 0 ? slack_tric : 0.0) < (double)b.r_ws - margin)) ok = false;
             }
         }
         if (!ok) { st.status = GR_ST_FALLBACK; return; }

@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""config[2]: 1e6 atoms uniform in a triclinic cell, min-image distances for a 1e4 x 1e4 selection, result left in HBM.
+Algorithmic bytes = 4*S1*S2 written (+ 12*(S1+S2) read); reports GB/s of the matrix write and frames/s."""
+import ctypes as C
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import groan_rs_amd as G
+import oracle_lib as O
+
+n, S, reps = 1_000_000, int(sys.argv[1]) if len(sys.argv) > 1 else 10_000, 20
+out = {}
+for name, (l, a) in {"triclinic": ([24.0, 23.0, 22.0], [75.0, 80.0, 70.0]), "dodecahedron": ([24.18] * 3, [60.0, 60.0, 90.0]),
+                     "orthorhombic": ([24.0, 23.0, 22.0], [90.0, 90.0, 90.0])}.items():
+    box = O.box_from_lengths_angles(l, a)
+    s = G.System(n, n_slots=1)
+    s.synth_uniform(0, box, 20260424)
+    s.group_create_from_ranges("S", [(0, S - 1)])
+    lib = s._lib
+    dev = C.c_void_p(); n1 = C.c_uint64(); n2 = C.c_uint64()
+    for dim in (7, 4):
+        lib.gr_group_all_distances_device(s._ctx, 0, b"S", b"S", dim, C.byref(dev), C.byref(n1), C.byref(n2))   # warm-up + alloc
+        s.sync(); s.timer_start()
+        for _ in range(reps):
+            st = lib.gr_group_all_distances_device(s._ctx, 0, b"S", b"S", dim, C.byref(dev), C.byref(n1), C.byref(n2))
+            assert st == 0
+        ms = s.timer_stop() / reps
+        out["%s/%s" % (name, "XYZ" if dim == 7 else "XY")] = {"ms_per_frame": round(ms, 4), "frames_per_s": round(1e3 / ms, 1),
+                                                             "write_GBps": round(4.0 * S * S / (ms * 1e-3) / 1e9, 1)}
+    s.close()
+print(json.dumps(out, indent=1))
