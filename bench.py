@@ -54,13 +54,24 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     torch = None
+    backend = os.environ.get("GROAN_DIST_BACKEND", "nccl")   # "gloo": CPU rehearsal of the multi-rank path (ranks may share a GPU)
+    tdev = None
     if world > 1 or args.with_torch:
         # torch first: its bundled HIP runtime (SONAME libamdhip64.so.7) is then the one libgroan_hip.so binds to
         import torch
-        if world > 1:
+        for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29517"), ("RANK", "0"), ("WORLD_SIZE", "1")):
+            os.environ.setdefault(k, v)   # plain `python bench.py --with-torch` (no launcher)
+        ndev = max(torch.cuda.device_count(), 1)
+        local_rank = local_rank % ndev
+        if world > 1 or args.with_torch:
             import torch.distributed as dist
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            if backend == "nccl":
+                torch.cuda.set_device(local_rank)
+                tdev = torch.device("cuda", local_rank)
+                dist.init_process_group(backend="nccl", device_id=tdev)
+            else:
+                tdev = torch.device("cpu")
+                dist.init_process_group(backend=backend)
 
     import numpy as np
     import groan_rs_amd as G
@@ -103,7 +114,7 @@ def main():
         cur.sync()
         if dist is not None:
             dist.barrier()
-        if torch is not None:
+        if torch is not None and torch.cuda.is_available():
             torch.cuda.synchronize()
 
     rmsd_all = np.zeros((K, B), np.float32)
@@ -125,7 +136,7 @@ def main():
     gathered = None
     if dist is not None:
         # final gather of the per-frame RMSDs (K*B floats per rank) over RCCL, restored to global frame order
-        gathered = G.gather_per_frame(rmsd_all.reshape(-1), K * B * world, dist=dist, device=torch.device("cuda", local_rank))
+        gathered = G.gather_per_frame(rmsd_all.reshape(-1), K * B * world, dist=dist, device=tdev)
     gpu_ms = cur.timer_stop()
     barrier()
     t1 = time.perf_counter()
@@ -133,7 +144,7 @@ def main():
     cur.profile_enable(False)
     elapsed = t1 - t0
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=torch.device("cuda", local_rank))
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=tdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     assert np.isfinite(rmsd_all).all()

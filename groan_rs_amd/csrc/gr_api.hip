@@ -238,7 +238,7 @@ int set_box(gr_ctx *c, uint32_t slot, const float *box9, hipStream_t on = nullpt
         memcpy(&c->box9_host[9 * (size_t)slot], box9, 9 * sizeof(float));
         c->box9_set[slot] = 1;
         if (!ok) c->box_status[slot] = GR_E_ZERO_BOX;
-        else if (b.ncand >= GR_MAX_CAND) c->box_status[slot] = GR_E_UNSUPPORTED_BOX;
+        else if (b.ncand > GR_MAX_CAND) c->box_status[slot] = GR_E_UNSUPPORTED_BOX;
         else c->box_status[slot] = GR_OK;
     }
     HIPCHK(c, hipMemcpyAsync(c->boxes_dev + slot, &b, sizeof(GrBox), hipMemcpyHostToDevice, on ? on : c->stream));
@@ -576,7 +576,12 @@ static int pairdist_run(gr_ctx *c, uint32_t slot, const GrSel &s1, const GrSel &
     HIPCHK(c, hipMemsetAsync(c->bad_dev, 0xFF, 4 * sizeof(uint32_t), c->stream));
     if (s1.n && s2.n) {
         dim3 grid((s2.n + GR_WG * 4 - 1) / (GR_WG * 4), (s1.n + GR_PD_TI - 1) / GR_PD_TI);
-        k_pairdist<<<grid, dim3(GR_WG), 0, c->stream>>>(c->frames + (size_t)slot * c->frame_stride, s1, s2, c->boxes_dev + slot, dim, out_dev, c->bad_dev);
+        const float *fr = c->frames + (size_t)slot * c->frame_stride;
+        const GrBox &bx = c->boxes_host[slot];
+        // unrolled length of the minimum-image table: the smallest of 4 / 8 / 16 that holds this box's entries
+        if (bx.ncand <= 4) k_pairdist<4><<<grid, dim3(GR_WG), 0, c->stream>>>(fr, s1, s2, bx, dim, out_dev, c->bad_dev);
+        else if (bx.ncand <= 8) k_pairdist<8><<<grid, dim3(GR_WG), 0, c->stream>>>(fr, s1, s2, bx, dim, out_dev, c->bad_dev);
+        else k_pairdist<16><<<grid, dim3(GR_WG), 0, c->stream>>>(fr, s1, s2, bx, dim, out_dev, c->bad_dev);
         HIPCHK(c, hipGetLastError());
     }
     HIPCHK(c, hipMemcpyAsync(c->bad_host, c->bad_dev, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));

@@ -110,7 +110,7 @@ __device__ __forceinline__ float gr_block_min_f32(float x, float *lds) {
     return x;
 }
 
-// Stage the frame's box into LDS once per workgroup (box + candidate table = 444 bytes).
+// Stage the frame's box into LDS once per workgroup (box + image table = 316 bytes).
 __device__ __forceinline__ void gr_stage_box(GrBox *lds_box, const GrBox *g) {
     const uint32_t *src = reinterpret_cast<const uint32_t *>(g);
     uint32_t *dst = reinterpret_cast<uint32_t *>(lds_box);
@@ -808,13 +808,14 @@ __global__ __launch_bounds__(GR_WG) void k_translate_wrap(
 // store per lane = 1 KiB contiguous per wavefront instruction.  The kernel is bound by the HBM write
 // of the matrix (4 B/pair); orthorhombic boxes need ~15 flop/pair.
 #define GR_PD_TI 32
+// The box (with its image table) comes in BY VALUE: kernel arguments are read with scalar loads, so the table
+// entries are SGPR operands of the FMAs instead of per-lane LDS reads.
+template <int NC>
 __global__ __launch_bounds__(GR_WG) void k_pairdist(
-    const float *__restrict__ xyz, GrSel s1, GrSel s2, const GrBox *__restrict__ boxp, int dim,
+    const float *__restrict__ xyz, GrSel s1, GrSel s2, const GrBox box, int dim,
     float *__restrict__ out, uint32_t *__restrict__ bad_out) {
-    __shared__ GrBox box;
-    __shared__ float ti[GR_PD_TI][3];
+    __shared__ float ti[GR_PD_TI][4];
     __shared__ uint32_t ldsu[GR_WG / 64];
-    gr_stage_box(&box, boxp);
     const uint32_t i0 = blockIdx.y * GR_PD_TI, j0 = blockIdx.x * (GR_WG * 4) + threadIdx.x * 4;
     uint32_t bad = GR_NOIDX, badj = GR_NOIDX;   // first atom without position among the rows / the columns
     if (threadIdx.x < GR_PD_TI) {
@@ -825,7 +826,7 @@ __global__ __launch_bounds__(GR_WG) void k_pairdist(
             x = xyz[3 * (size_t)a]; y = xyz[3 * (size_t)a + 1]; z = xyz[3 * (size_t)a + 2];
             if (x != x) bad = min(bad, a);
         }
-        ti[threadIdx.x][0] = x; ti[threadIdx.x][1] = y; ti[threadIdx.x][2] = z;
+        ti[threadIdx.x][0] = x; ti[threadIdx.x][1] = y; ti[threadIdx.x][2] = z; ti[threadIdx.x][3] = 0.f;
     }
     float jx[4], jy[4], jz[4];
 #pragma unroll
@@ -842,10 +843,10 @@ __global__ __launch_bounds__(GR_WG) void k_pairdist(
     const uint32_t ni = min((uint32_t)GR_PD_TI, s1.n > i0 ? s1.n - i0 : 0u);
     const bool vec_ok = ((s2.n & 3u) == 0u);   // rows stay 16-byte aligned
     for (uint32_t r = 0; r < ni; ++r) {
-        const float ax_ = ti[r][0], ay_ = ti[r][1], az_ = ti[r][2];
+        const float4 t = *reinterpret_cast<const float4 *>(&ti[r][0]);
         float d[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) d[k] = gr_distance(ax_, ay_, az_, jx[k], jy[k], jz[k], dim, box);
+        for (int k = 0; k < 4; ++k) d[k] = gr_distance<NC>(t.x, t.y, t.z, jx[k], jy[k], jz[k], dim, box);
         float *row = out + (size_t)(i0 + r) * s2.n;
         if (vec_ok && j0 + 3 < s2.n) {
             *reinterpret_cast<float4 *>(row + j0) = make_float4(d[0], d[1], d[2], d[3]);

@@ -22,7 +22,7 @@
 #define GR_HD inline
 #endif
 
-#define GR_MAX_CAND 32
+#define GR_MAX_CAND 16   // half-set: one of each +-t pair
 
 // Per-frame simulation box, prepared on the host (gr_box_setup) and read by the kernels.
 struct GrBox {
@@ -34,7 +34,8 @@ struct GrBox {
     int ortho;             // v2x == v3x == v3y == 0
     int ncand;             // number of entries in cand
     int valid;             // 0: the frame has no box
-    float cand[GR_MAX_CAND][3];
+    float cand[GR_MAX_CAND][3];   // one of each +-t pair; unused entries are 0 with cand_t2 = 1e30 (never win)
+    float cand_t2[GR_MAX_CAND];   // |t|^2
 };
 
 // Closed forms of the reference's loops, branch-free.
@@ -74,15 +75,39 @@ GR_HD float gr_floor_mod(float x, float y) { return fmodf(fmodf(x, y) + y, y); }
 
 // A vector shorter than r_ws (half the shortest lattice vector) is its own unique minimum image
 // (|d + t| >= |t| - |d| > |d| for every lattice vector t), so the table is searched only beyond it.
+// |d +- t|^2 - |d|^2 = |t|^2 +- 2 d.t, and the table holds one of each +-t pair, so the better sign of a pair costs
+// one dot product: gain = |t|^2 - 2|d.t|.
+// (rolled over the real entry count: the search is rarely taken and must not bloat its callers)
 GR_HD void gr_tric_refine(float &dx, float &dy, float &dz, const GrBox &b) {
-    float best = dx * dx + dy * dy + dz * dz;
-    if (best < b.r_ws * b.r_ws) return;
-    float ox = dx, oy = dy, oz = dz;
+    const float r2 = dx * dx + dy * dy + dz * dz;
+    if (r2 < b.r_ws * b.r_ws) return;
+    float best = 0.0f, sx = 0.0f, sy = 0.0f, sz = 0.0f;
+#pragma unroll 1
     for (int m = 0; m < b.ncand; ++m) {
-        float x = ox + b.cand[m][0], y = oy + b.cand[m][1], z = oz + b.cand[m][2];
-        float r2 = x * x + y * y + z * z;
-        if (r2 < best) { best = r2; dx = x; dy = y; dz = z; }
+        const float tx = b.cand[m][0], ty = b.cand[m][1], tz = b.cand[m][2];
+        const float dt = fmaf(tx, dx, fmaf(ty, dy, tz * dz));
+        const float g = fmaf(-2.0f, fabsf(dt), b.cand_t2[m]);
+        const bool win = g < best;
+        const float sg = dt < 0.0f ? 1.0f : -1.0f;   // add t when d.t < 0, subtract it otherwise
+        best = win ? g : best;
+        sx = win ? sg * tx : sx; sy = win ? sg * ty : sy; sz = win ? sg * tz : sz;
     }
+    dx += sx; dy += sy; dz += sz;
+}
+
+// squared length of the minimum image of an already brick-reduced d: no vector needed, 5 ops per +-pair, fixed trip
+// count (padding entries never win) and fully unrolled -- with the box a by-value kernel argument (k_pairdist) the
+// table entries are SGPR operands
+template <int NC = GR_MAX_CAND>
+GR_HD float gr_tric_refine_r2(float dx, float dy, float dz, const GrBox &b) {
+    const float r2 = dx * dx + dy * dy + dz * dz;
+    float best = 0.0f;
+#pragma unroll
+    for (int m = 0; m < NC; ++m) {
+        const float dt = fmaf(b.cand[m][0], dx, fmaf(b.cand[m][1], dy, b.cand[m][2] * dz));
+        best = fminf(best, fmaf(-2.0f, fabsf(dt), b.cand_t2[m]));
+    }
+    return fmaxf(r2 + best, 0.0f);
 }
 
 // wrap a position into the unit cell
@@ -142,8 +167,17 @@ GR_HD void gr_vector_to(float fx, float fy, float fz, float tx, float ty, float 
 }
 
 // Dimension: 0 None 1 X 2 Y 3 Z 4 XY 5 XZ 6 YZ 7 XYZ (src/structures/dimension.rs:13-23)
-GR_HD float gr_mag3(float x, float y, float z) { return sqrtf(x * x + y * y + z * z); }
+// device: the hardware square root (1 ulp) instead of the correctly rounded sequence -- 1e-7 nm at 1 nm
+GR_HD float gr_mag3(float x, float y, float z) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_sqrtf(x * x + y * y + z * z);
+#else
+    return sqrtf(x * x + y * y + z * z);
+#endif
+}
 
+// NC = unrolled image-table length for the magnitude-only path (>= b.ncand; the table is padded with never-winning entries)
+template <int NC = GR_MAX_CAND>
 GR_HD float gr_distance(float ax_, float ay_, float az_, float px, float py, float pz, int dim, const GrBox &b) {
     if (dim == 0) return 0.0f;
     float dx = ax_ - px, dy = ay_ - py, dz = az_ - pz;
@@ -161,6 +195,19 @@ GR_HD float gr_distance(float ax_, float ay_, float az_, float px, float py, flo
         case 6: return gr_mag3(0.0f, my, mz);
         default: return gr_mag3(mx, my, mz);
         }
+    }
+    if (dim == 7) {   // magnitude only: brick reduction + gain search, the image vector itself is never formed
+        float k = gr_minimg_k(dz, b.cz, b.icz, b.cz / 2.0f);
+        dx = fmaf(-k, b.cx, dx); dy = fmaf(-k, b.cy, dy); dz = fmaf(-k, b.cz, dz);
+        k = gr_minimg_k(dy, b.by, b.iby, b.by / 2.0f);
+        dx = fmaf(-k, b.bx, dx); dy = fmaf(-k, b.by, dy);
+        k = gr_minimg_k(dx, b.ax, b.iax, b.ax / 2.0f);
+        dx = fmaf(-k, b.ax, dx);
+#if defined(__HIP_DEVICE_COMPILE__)
+        return __builtin_amdgcn_sqrtf(gr_tric_refine_r2<NC>(dx, dy, dz, b));
+#else
+        return sqrtf(gr_tric_refine_r2<NC>(dx, dy, dz, b));
+#endif
     }
     gr_min_image_vec(dx, dy, dz, b);
     switch (dim) {
@@ -191,6 +238,8 @@ inline int gr_box_setup(const float *box9, GrBox *b) {
     }
     b->iax = 1.0f / b->ax; b->iby = 1.0f / b->by; b->icz = 1.0f / b->cz;
     double tmin2 = 1e300;
+    for (int q = 0; q < GR_MAX_CAND; ++q) { b->cand[q][0] = b->cand[q][1] = b->cand[q][2] = 0.0f; b->cand_t2[q] = 1.0e30f; }
+    int overflow = 0;
     for (int k = -2; k <= 2; ++k)
         for (int j = -2; j <= 2; ++j)
             for (int i = -2; i <= 2; ++i) {
@@ -201,12 +250,18 @@ inline int gr_box_setup(const float *box9, GrBox *b) {
                 double t2 = tx * tx + ty * ty + tz * tz;
                 if (t2 < tmin2) tmin2 = t2;
                 if (b->ortho) continue;
+                // one representative of each +-t pair: the first non-zero of (k, j, i) is positive
+                if (k < 0 || (k == 0 && (j < 0 || (j == 0 && i < 0)))) continue;
                 double lhs = fabs(tx) * b->ax + fabs(ty) * b->by + fabs(tz) * b->cz;
-                if (lhs > t2 * (1.0 + 1e-6) && b->ncand < GR_MAX_CAND) {
-                    b->cand[b->ncand][0] = (float)tx; b->cand[b->ncand][1] = (float)ty; b->cand[b->ncand][2] = (float)tz;
-                    b->ncand++;
+                if (lhs > t2 * (1.0 + 1e-6)) {
+                    if (b->ncand < GR_MAX_CAND) {
+                        b->cand[b->ncand][0] = (float)tx; b->cand[b->ncand][1] = (float)ty; b->cand[b->ncand][2] = (float)tz;
+                        b->cand_t2[b->ncand] = (float)t2;
+                        b->ncand++;
+                    } else overflow = 1;
                 }
             }
+    if (overflow) b->ncand = GR_MAX_CAND + 1;   // too skewed for the table -> GR_E_UNSUPPORTED_BOX
     b->r_ws = (float)(0.5 * sqrt(tmin2));
     return 1;
 }

@@ -45,7 +45,7 @@ def gather_per_frame(local_values, n_total, dist=None, device=None):
     With torch.distributed initialised this is ONE all_gather of ceil(n_total/G) rows per rank
     (RCCL over xGMI when the backend is nccl); without it (single process) it is the identity."""
     local = np.ascontiguousarray(local_values)
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized():
         return interleave([local], n_total)
     import torch
     world = dist.get_world_size()
