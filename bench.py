@@ -49,6 +49,12 @@ def main():
     ap.add_argument("--with-torch", action="store_true", help="import torch first even at N=1 (coexistence check)")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE JSON line: everything else any library prints there (RCCL prints a version banner on
+    # init) is sent to stderr by pointing fd 1 at fd 2 until the result is written to the saved descriptor
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -233,7 +239,8 @@ def main():
     if rank == 0:
         if gathered is not None:
             out["config"]["gathered_frames"] = int(gathered.shape[0])
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     plan.close(); ref.close(); cur.close()
     if dist is not None:
         dist.destroy_process_group()
