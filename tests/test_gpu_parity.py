@@ -414,3 +414,56 @@ def test_rmsd_aa_peptide_trajectory(G, aa):
         ro, _ = O.calc_rmsd(aa["traj_peptide"][0], m[:363], sel, aa["traj_boxes9"][0], aa["traj_peptide"][f], m[:363], sel, aa["traj_boxes9"][f])
         assert abs(r[f] - ro) <= 2e-6, (f, r[f], ro)
     ref.close(); cur.close()
+
+
+# ----------------------------------------------------------------------------- ragged sizes / offsets
+@pytest.mark.parametrize("seed", range(6))
+def test_ragged_sizes_and_selection_offsets(G, seed):
+    """atom counts that are not multiples of the 4-atom / 256-atom tiles, selections starting anywhere, single atoms,
+    whole-system and gather-path selections: every operation against the oracle"""
+    rng = np.random.default_rng(100 + seed)
+    n = int(rng.choice([1, 2, 3, 5, 63, 64, 65, 255, 256, 257, 511, 777, 1023, 1500, 2049]))
+    box = np.array([rng.uniform(5, 9), rng.uniform(5, 9), rng.uniform(5, 9), 0, 0, 0, 0, 0, 0], np.float32)
+    if seed % 2:
+        box = O.box_from_lengths_angles([7.0, 6.5, 6.0], [75.0, 80.0, 70.0])
+    pos = (O.box_center(box) + rng.normal(0, 0.5, (n, 3))).astype(np.float32)
+    pos = O.translate(pos, np.arange(n), rng.uniform(-9, 9, 3).astype(np.float32), box)     # PBC-broken blob
+    m = rng.uniform(1, 16, n).astype(np.float32)
+    a = int(rng.integers(0, n)); b = int(rng.integers(a, n))
+    sels = {"range": np.arange(a, b + 1), "all": np.arange(n), "one": np.array([int(rng.integers(0, n))])}
+    if n >= 5:
+        sels["gather"] = np.unique(rng.integers(0, n, size=max(2, n // 3)))
+    ref = G.System(n, masses=m, box=box, positions=pos)
+    cur = G.System(n, masses=m, n_slots=2)
+    q = rng.normal(size=4); q /= np.linalg.norm(q); w, x, y, z = q
+    Rm = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)], [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                   [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+    c = O.box_center(box).astype(np.float64)
+    unb = O.translate(pos, np.arange(n), np.zeros(3, np.float32), box)
+    moved = (((O.get_center(pos, np.arange(n), box)[None] * 0 + pos.astype(np.float64)) - c) @ Rm.T + c + rng.normal(0, 0.03, (n, 3))).astype(np.float32)
+    moved = O.translate(moved, np.arange(n), rng.uniform(-5, 5, 3).astype(np.float32), box)
+    for name, idx in sels.items():
+        for s in (ref, cur):
+            if name == "gather":
+                s.group_create_from_indices(name, idx)
+            elif name != "all":
+                s.group_create_from_ranges(name, [(int(idx[0]), int(idx[-1]))])
+        cur.set_frame(pos, box, slot=0)
+        np.testing.assert_allclose(cur.group_get_center(name), O.get_center(pos, idx, box), atol=TOL, rtol=0, err_msg=name)
+        np.testing.assert_allclose(cur.group_get_com(name), O.get_center(pos, idx, box, mass=m), atol=TOL, rtol=0, err_msg=name)
+        np.testing.assert_allclose(cur.group_estimate_com(name), O.estimate_center(pos, idx, box, mass=m), atol=TOL, rtol=0)
+        np.testing.assert_allclose(cur.group_get_com_naive(name), O.center_naive(pos, idx, mass=m), atol=TOL, rtol=0)
+        cur.group_translate(name, [1.5, -2.5, 0.25])
+        np.testing.assert_allclose(cur.get_positions(), O.translate(pos, idx, [1.5, -2.5, 0.25], box), atol=TOL, rtol=0)
+        if idx.size >= 3:      # a rotation needs three non-collinear atoms to be defined
+            cur.set_frame(moved, box, slot=1)
+            for exact in (False, True):
+                cur.set_frame(moved, box, slot=1)
+                plan = G.RMSDPlan(ref, cur, name)
+                plan.force_exact(exact)
+                r, st = plan.rmsd_fit(1, 1)
+                ro, want = O.calc_rmsd_and_fit(pos, m, idx, box, moved, m, idx, box)
+                assert st[0] == 0 and abs(r[0] - ro) <= TOL, (name, exact, r[0], ro)
+                np.testing.assert_allclose(cur.get_positions(1), want, atol=5e-5, rtol=0, err_msg="%s exact=%s" % (name, exact))
+                plan.close()
+    ref.close(); cur.close()
