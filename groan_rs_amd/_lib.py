@@ -16,7 +16,7 @@ c_i32p = C.POINTER(C.c_int)
 
 # status codes (include/groan_hip.h)
 (OK, E_NO_BOX, E_NOT_ORTHOGONAL, E_ZERO_BOX, E_EMPTY_GROUP, E_INCONSISTENT_GROUP, E_NO_POSITION, E_NO_MASS,
- E_GROUP_NOT_FOUND, E_OUT_OF_RANGE, E_INVALID_ARG, E_GROUP_EXISTS, E_HIP, E_NO_DEVICE, E_UNSUPPORTED_BOX) = range(15)
+ E_GROUP_NOT_FOUND, E_OUT_OF_RANGE, E_INVALID_ARG, E_GROUP_EXISTS, E_HIP, E_NO_DEVICE, E_UNSUPPORTED_BOX, E_IO, E_FORMAT) = range(17)
 
 CENTER_NAIVE, CENTER_ESTIMATE, CENTER_PBC = 0, 1, 2
 
@@ -75,6 +75,12 @@ SIGNATURES = {
     "gr_rmsd_batch_end": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gr_rmsd_plan_last_fallbacks": (C.c_uint32, [C.c_void_p]),
     "gr_rmsd_plan_force_exact": (C.c_int, [C.c_void_p, C.c_int]),
+    "gr_xtc_open": (C.c_void_p, [C.c_char_p, c_i32p]),
+    "gr_xtc_close": (None, [C.c_void_p]),
+    "gr_xtc_n_atoms": (C.c_uint64, [C.c_void_p]),
+    "gr_xtc_n_frames": (C.c_uint64, [C.c_void_p]),
+    "gr_xtc_frame_info": (C.c_int, [C.c_void_p, C.c_uint64, c_u64p, c_f32p, C.c_void_p, c_f32p]),
+    "gr_xtc_read_frame": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, c_u64p, c_f32p, c_f32p]),
     "gr_timer_start": (C.c_int, [C.c_void_p]),
     "gr_timer_stop": (C.c_int, [C.c_void_p, c_f32p]),
     "gr_synth_reference": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_float, C.c_uint64]),

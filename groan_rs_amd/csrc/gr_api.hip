@@ -16,6 +16,7 @@
 #include "../../include/groan_hip.h"
 #include "gr_container.h"
 #include "gr_kernels.h"
+#include "gr_xtc.h"
 
 #define GR_MAX_BATCH 256     // frames per batched call segment (workspace is sized for this)
 #define GR_MAX_CHUNKS 256    // workgroups per frame in the reduction kernels
@@ -304,6 +305,8 @@ const char *gr_status_string(int s) {
     case GR_E_HIP: return "HIP runtime error";
     case GR_E_NO_DEVICE: return "no usable HIP device";
     case GR_E_UNSUPPORTED_BOX: return "box too skewed for the minimum-image table";
+    case GR_E_IO: return "file could not be opened or read";
+    case GR_E_FORMAT: return "not a valid xtc file";
     default: return "unknown status";
     }
 }
@@ -969,6 +972,49 @@ int gr_calc_rmsd(gr_ctx *c, uint32_t slot, gr_ctx *ref, uint32_t ref_slot, const
 }
 int gr_calc_rmsd_and_fit(gr_ctx *c, uint32_t slot, gr_ctx *ref, uint32_t ref_slot, const char *group, float *rmsd) {
     return calc_rmsd_impl(c, slot, ref, ref_slot, group, rmsd, nullptr, 1);
+}
+
+/* ------------------------------------------------------------ xtc reader (host; NEXT-1 of SURVEY.md section 8f) */
+struct gr_xtc { grx::File f; };
+
+static int xtc_status(int s) { return s == grx::XTC_OK ? GR_OK : (s == grx::XTC_E_IO ? GR_E_IO : (s == grx::XTC_E_BOX ? GR_E_UNSUPPORTED_BOX : GR_E_FORMAT)); }
+
+gr_xtc *gr_xtc_open(const char *path, int *status) {
+    int dummy; if (!status) status = &dummy;
+    if (!path) { *status = GR_E_INVALID_ARG; return nullptr; }
+    gr_xtc *x = new gr_xtc();
+    const int s = grx::open_file(x->f, path);
+    if (s != grx::XTC_OK) { *status = xtc_status(s); if (x->f.fd >= 0) ::close(x->f.fd); delete x; return nullptr; }
+    *status = GR_OK;
+    return x;
+}
+void gr_xtc_close(gr_xtc *x) { if (!x) return; if (x->f.fd >= 0) ::close(x->f.fd); delete x; }
+uint64_t gr_xtc_n_atoms(const gr_xtc *x) { return x ? x->f.natoms : 0; }
+uint64_t gr_xtc_n_frames(const gr_xtc *x) { return x ? x->f.frames.size() : 0; }
+
+// box matrix (rows = box vectors) -> gro-order box9; rejects boxes GROMACS does not produce (src/io/xdrfile.rs:170-187)
+static int xtc_box9(const float m[9], float box9[9]) {
+    if (m[1] != 0.0f || m[2] != 0.0f || m[5] != 0.0f) return GR_E_UNSUPPORTED_BOX;
+    box9[0] = m[0]; box9[1] = m[4]; box9[2] = m[8]; box9[3] = m[1]; box9[4] = m[2]; box9[5] = m[3]; box9[6] = m[5]; box9[7] = m[6]; box9[8] = m[7];
+    return GR_OK;
+}
+
+int gr_xtc_frame_info(const gr_xtc *x, uint64_t frame, uint64_t *step, float *time, float box9[9], float *precision) {
+    if (!x) return GR_E_INVALID_ARG;
+    if (frame >= x->f.frames.size()) return GR_E_OUT_OF_RANGE;
+    const grx::FrameIndex &fi = x->f.frames[frame];
+    if (step) *step = (uint64_t)(uint32_t)fi.step;   // i32 -> u32 -> u64 like src/io/xtc_io/xdrfile_xtc.rs:98-100
+    if (time) *time = fi.time;
+    if (precision) *precision = fi.precision;
+    return box9 ? xtc_box9(fi.box, box9) : GR_OK;
+}
+
+int gr_xtc_read_frame(const gr_xtc *x, uint64_t frame, float *xyz, float box9[9], uint64_t *step, float *time, float *precision) {
+    if (!x || !xyz) return GR_E_INVALID_ARG;
+    int st = gr_xtc_frame_info(x, frame, step, time, box9, precision);
+    if (st != GR_OK) return st;
+    static thread_local std::vector<unsigned char> scratch;   // one bit-stream buffer per decoding thread
+    return xtc_status(grx::decode_frame(x->f, x->f.frames[frame], xyz, scratch));
 }
 
 /* ------------------------------------------------------------ measurement / synthetic data */

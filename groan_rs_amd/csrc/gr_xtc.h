@@ -1,0 +1,236 @@
+// gr_xtc.h -- GROMACS .xtc trajectory decoder (host side, thread-safe random access), written for this project.
+//
+// This is the stage immediately in front of the geometry path (NEXT-1): the reference reads xtc
+// through the `molly` crate or the vendored C xdrfile (src/io/xtc_io/molly_xtc.rs:268-308, src/io/xtc_io/xdrfile_xtc.rs:42-104,
+// external/xdrfile/xdrfile.c:742-948).  Only the FILE FORMAT is shared with those; the implementation is new:
+//   * the file is indexed once (frame offsets from the fixed-size headers), so any frame can be decoded by any thread
+//     with pread() -- one frame per host thread is the unit of parallelism (the bit stream is serial within a frame);
+//   * bits are pulled from a 64-bit window; the three packed integers of an atom are recovered from ONE integer
+//     (<= 64 bits in a machine word, otherwise unsigned __int128) with two divisions instead of byte-wise long division;
+//   * coordinates are written straight into the caller's buffer -- typically pinned memory that gr_frame_upload then
+//     copies to the GPU on the copy stream while other threads decode the next frames.
+//
+// Format recap (XDR, big-endian): magic (1995, or 2023 with a 64-bit byte count), natoms, step, time, box[3][3], natoms;
+// natoms <= 9: raw floats.  Otherwise: precision, minint[3], maxint[3], smallidx, nbytes, bit stream (padded to 4 bytes).
+// Per atom: the full-range triple (mixed radix sizeint[] in `bitsize` bits, or three fixed-width fields when a range
+// exceeds 24 bits), a flag bit, optionally 5 bits (run length of following "small" atoms + a -1/0/+1 change of the
+// small-range index); small atoms are deltas in the mixed radix magic[smallidx]^3; the first small atom of a run is
+// swapped with its predecessor (water oxygens/hydrogens).  magic[] is the format's table of ~2^(i/3) (with its
+// historical irregular entries).
+#pragma once
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace grx {
+
+static const int kMagic[] = {
+    0, 0, 0, 0, 0, 0, 0, 0, 0, 8, 10, 12, 16, 20, 25, 32, 40, 50, 64, 80, 101, 128, 161, 203, 256, 322, 406, 512, 645, 812, 1024, 1290, 1625,
+    2048, 2580, 3250, 4096, 5060, 6501, 8192, 10321, 13003, 16384, 20642, 26007, 32768, 41285, 52015, 65536, 82570, 104031, 131072,
+    165140, 208063, 262144, 330280, 416127, 524287, 660561, 832255, 1048576, 1321122, 1664510, 2097152, 2642245, 3329021, 4194304,
+    5284491, 6658042, 8388607, 10568983, 13316085, 16777216 };
+static const int kFirstIdx = 9;
+static const int kLastIdx = (int)(sizeof(kMagic) / sizeof(kMagic[0]));
+
+enum { XTC_OK = 0, XTC_E_IO = 1, XTC_E_FORMAT = 2, XTC_E_RANGE = 3, XTC_E_BOX = 4 };
+
+inline uint32_t be32(const unsigned char *p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | (uint32_t)p[3]; }
+inline float bef(const unsigned char *p) { uint32_t u = be32(p); float f; memcpy(&f, &u, 4); return f; }
+inline uint64_t be64(const unsigned char *p) { return ((uint64_t)be32(p) << 32) | be32(p + 4); }
+inline int bit_length(unsigned __int128 v) { int n = 0; while (v) { ++n; v >>= 1; } return n; }
+
+struct FrameIndex {
+    uint64_t offset;      // of the frame's magic number
+    uint64_t data_offset; // of the bit stream (or of the raw floats when natoms <= 9)
+    uint64_t nbytes;      // bit stream length
+    int32_t step; float time; float box[9]; float precision;
+    int32_t minint[3], maxint[3], smallidx;
+};
+
+struct File {
+    int fd = -1;
+    uint64_t size = 0;
+    uint32_t natoms = 0;
+    std::vector<FrameIndex> frames;
+    std::string error;
+};
+
+// MSB-first bit reader over a byte buffer (the buffer carries 8 bytes of zero padding behind the stream)
+struct Bits {
+    const unsigned char *p; size_t pos = 0;   // next byte to pull
+    uint64_t win = 0; int have = 0;           // `have` valid bits at the bottom of win
+    explicit Bits(const unsigned char *buf) : p(buf) {}
+    inline uint32_t get(int n) {              // 0 <= n <= 32
+        if (n == 0) return 0;
+        while (have < n) { win = (win << 8) | p[pos++]; have += 8; }
+        have -= n;
+        return (uint32_t)((win >> have) & ((n == 32) ? 0xFFFFFFFFull : ((1ull << n) - 1)));
+    }
+    // the integer that packs three mixed-radix digits: bytes in read order are its little-endian bytes, the trailing
+    // partial byte is the most significant
+    inline unsigned __int128 get_packed(int nbits) {
+        unsigned __int128 v = 0;
+        int shift = 0;
+        while (nbits > 8) { v |= (unsigned __int128)get(8) << shift; shift += 8; nbits -= 8; }
+        if (nbits > 0) v |= (unsigned __int128)get(nbits) << shift;
+        return v;
+    }
+    inline uint64_t get_packed64(int nbits) {  // nbits <= 64
+        uint64_t v = 0;
+        int shift = 0;
+        while (nbits > 8) { v |= (uint64_t)get(8) << shift; shift += 8; nbits -= 8; }
+        if (nbits > 0) v |= (uint64_t)get(nbits) << shift;
+        return v;
+    }
+};
+
+inline void unpack3(Bits &b, int nbits, const uint32_t sz[3], int out[3]) {
+    if (nbits <= 64) {
+        uint64_t v = b.get_packed64(nbits);
+        const uint64_t q2 = v / sz[2]; out[2] = (int)(v - q2 * sz[2]);
+        const uint64_t q1 = q2 / sz[1]; out[1] = (int)(q2 - q1 * sz[1]);
+        out[0] = (int)(uint32_t)q1;
+    } else {
+        unsigned __int128 v = b.get_packed(nbits);
+        const unsigned __int128 q2 = v / sz[2]; out[2] = (int)(uint64_t)(v - q2 * sz[2]);
+        const unsigned __int128 q1 = q2 / sz[1]; out[1] = (int)(uint64_t)(q2 - q1 * sz[1]);
+        out[0] = (int)(uint32_t)(uint64_t)q1;
+    }
+}
+
+inline bool pread_all(int fd, void *buf, size_t n, uint64_t off) {
+    unsigned char *p = (unsigned char *)buf;
+    while (n) {
+        ssize_t r = pread(fd, p, n, (off_t)off);
+        if (r <= 0) return false;
+        p += r; n -= (size_t)r; off += (uint64_t)r;
+    }
+    return true;
+}
+
+// index the whole file: every frame's header is read, its payload skipped
+inline int open_file(File &f, const char *path) {
+    f.fd = ::open(path, O_RDONLY);
+    if (f.fd < 0) { f.error = std::string("cannot open ") + path; return XTC_E_IO; }
+    struct stat st;
+    if (fstat(f.fd, &st) != 0) { f.error = "fstat failed"; return XTC_E_IO; }
+    f.size = (uint64_t)st.st_size;
+    uint64_t off = 0;
+    unsigned char h[128];
+    while (off + 16 <= f.size) {
+        if (!pread_all(f.fd, h, 16, off)) { f.error = "short read in frame header"; return XTC_E_IO; }
+        const uint32_t magic = be32(h);
+        if (magic != 1995 && magic != 2023) { f.error = "bad magic number"; return XTC_E_FORMAT; }
+        FrameIndex fi; memset(&fi, 0, sizeof(fi));
+        fi.offset = off;
+        const uint32_t natoms = be32(h + 4);
+        if (f.frames.empty()) f.natoms = natoms;
+        else if (natoms != f.natoms) { f.error = "number of atoms changes between frames"; return XTC_E_FORMAT; }
+        fi.step = (int32_t)be32(h + 8); fi.time = bef(h + 12);
+        uint64_t p = off + 16;
+        if (!pread_all(f.fd, h, 40, p)) { f.error = "short read in box"; return XTC_E_IO; }
+        for (int k = 0; k < 9; ++k) fi.box[k] = bef(h + 4 * k);
+        if (be32(h + 36) != natoms) { f.error = "atom count mismatch inside a frame"; return XTC_E_FORMAT; }
+        p += 40;
+        if (natoms <= 9) {
+            fi.data_offset = p; fi.nbytes = (uint64_t)natoms * 12; fi.precision = 0.0f;
+            p += fi.nbytes;
+        } else {
+            const size_t hl = (magic == 2023) ? 40 : 36;
+            if (!pread_all(f.fd, h, hl, p)) { f.error = "short read in compression header"; return XTC_E_IO; }
+            fi.precision = bef(h);
+            for (int k = 0; k < 3; ++k) { fi.minint[k] = (int32_t)be32(h + 4 + 4 * k); fi.maxint[k] = (int32_t)be32(h + 16 + 4 * k); }
+            fi.smallidx = (int32_t)be32(h + 28);
+            fi.nbytes = (magic == 2023) ? be64(h + 32) : (uint64_t)be32(h + 32);
+            p += hl;
+            fi.data_offset = p;
+            p += (fi.nbytes + 3) & ~(uint64_t)3;
+            if (fi.smallidx < kFirstIdx || fi.smallidx >= kLastIdx) { f.error = "small-range index out of the table"; return XTC_E_FORMAT; }
+        }
+        if (p > f.size) { f.error = "truncated frame"; return XTC_E_FORMAT; }
+        f.frames.push_back(fi);
+        off = p;
+    }
+    return XTC_OK;
+}
+
+// decode one frame into xyz[natoms][3]; scratch is grown as needed (one per calling thread)
+inline int decode_frame(const File &f, const FrameIndex &fi, float *xyz, std::vector<unsigned char> &scratch) {
+    const uint32_t n = f.natoms;
+    scratch.resize((size_t)fi.nbytes + 16);
+    if (!pread_all(f.fd, scratch.data(), (size_t)fi.nbytes, fi.data_offset)) return XTC_E_IO;
+    memset(scratch.data() + fi.nbytes, 0, 16);
+    if (n <= 9) {
+        for (uint32_t k = 0; k < 3 * n; ++k) xyz[k] = bef(scratch.data() + 4 * k);
+        return XTC_OK;
+    }
+    uint32_t sizeint[3];
+    for (int k = 0; k < 3; ++k) sizeint[k] = (uint32_t)(fi.maxint[k] - fi.minint[k] + 1);
+    int bitsizeint[3] = { 0, 0, 0 }, bitsize;
+    if ((sizeint[0] | sizeint[1] | sizeint[2]) > 0xffffffu) {
+        for (int k = 0; k < 3; ++k) { int b = bit_length(sizeint[k]); bitsizeint[k] = b > 32 ? 32 : b; }
+        bitsize = 0;
+    } else {
+        bitsize = bit_length((unsigned __int128)sizeint[0] * sizeint[1] * sizeint[2]);
+    }
+    int smallidx = fi.smallidx;
+    int smaller = kMagic[smallidx - 1 > kFirstIdx ? smallidx - 1 : kFirstIdx] / 2;
+    int smallnum = kMagic[smallidx] / 2;
+    uint32_t sizesmall[3] = { (uint32_t)kMagic[smallidx], (uint32_t)kMagic[smallidx], (uint32_t)kMagic[smallidx] };
+    const float inv_precision = (float)(1.0 / (double)fi.precision);
+    Bits bits(scratch.data());
+    const size_t limit = (size_t)fi.nbytes + 8;
+    float *out = xyz;
+    int run = 0;
+    uint32_t i = 0;
+    while (i < n) {
+        int cur[3];
+        if (bitsize == 0) { cur[0] = (int)bits.get(bitsizeint[0]); cur[1] = (int)bits.get(bitsizeint[1]); cur[2] = (int)bits.get(bitsizeint[2]); }
+        else unpack3(bits, bitsize, sizeint, cur);
+        cur[0] += fi.minint[0]; cur[1] += fi.minint[1]; cur[2] += fi.minint[2];
+        ++i;
+        int change = 0;
+        if (bits.get(1)) {
+            run = (int)bits.get(5);
+            change = run % 3;
+            run -= change;
+            change -= 1;
+        }
+        if (run > 0) {
+            if ((uint64_t)i + (uint64_t)(run / 3) > n) return XTC_E_FORMAT;   // a run must not overshoot the frame
+            int prev[3] = { cur[0], cur[1], cur[2] };
+            for (int k = 0; k < run; k += 3) {
+                int d[3];
+                unpack3(bits, smallidx, sizesmall, d);
+                int nxt[3] = { d[0] + prev[0] - smallnum, d[1] + prev[1] - smallnum, d[2] + prev[2] - smallnum };
+                ++i;
+                if (k == 0) {
+                    // the first small atom is stored AFTER its successor (water: O H H -> H O H): emit it first
+                    *out++ = nxt[0] * inv_precision; *out++ = nxt[1] * inv_precision; *out++ = nxt[2] * inv_precision;
+                    *out++ = prev[0] * inv_precision; *out++ = prev[1] * inv_precision; *out++ = prev[2] * inv_precision;
+                    prev[0] = nxt[0]; prev[1] = nxt[1]; prev[2] = nxt[2];   // the delta chain continues from the decoded atom
+                } else {
+                    *out++ = nxt[0] * inv_precision; *out++ = nxt[1] * inv_precision; *out++ = nxt[2] * inv_precision;
+                    prev[0] = nxt[0]; prev[1] = nxt[1]; prev[2] = nxt[2];
+                }
+            }
+        } else {
+            *out++ = cur[0] * inv_precision; *out++ = cur[1] * inv_precision; *out++ = cur[2] * inv_precision;
+        }
+        if (bits.pos > limit) return XTC_E_FORMAT;
+        smallidx += change;
+        if (smallidx < kFirstIdx || smallidx >= kLastIdx) return XTC_E_FORMAT;
+        if (change < 0) { smallnum = smaller; smaller = smallidx > kFirstIdx ? kMagic[smallidx - 1] / 2 : 0; }
+        else if (change > 0) { smaller = smallnum; smallnum = kMagic[smallidx] / 2; }
+        sizesmall[0] = sizesmall[1] = sizesmall[2] = (uint32_t)kMagic[smallidx];
+    }
+    return XTC_OK;
+}
+
+}  // namespace grx

@@ -1,0 +1,69 @@
+"""xtc trajectory reader on top of gr_xtc_* (the library's own decoder, groan_rs_amd/csrc/gr_xtc.h).
+
+Mirrors what the reference's XtcReader gives the path (src/io/xtc_io/mod.rs; TrajRead::update_system,
+src/io/traj_read.rs:160-186): frames as (positions[n,3] float32, box9, step, time), random access by index
+(the reference's with_range / with_step / per-thread skipping), thread-safe decoding into caller buffers."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+class XtcError(Exception):
+    def __init__(self, status, what):
+        super().__init__("%s (status %d)" % (what, status))
+        self.status = status
+
+
+class XtcFile:
+    def __init__(self, path):
+        self._lib = _lib.load()
+        st = C.c_int(0)
+        self._x = self._lib.gr_xtc_open(str(path).encode(), C.byref(st))
+        if not self._x:
+            raise XtcError(st.value, "cannot open %s: %s" % (path, self._lib.gr_status_string(st.value).decode()))
+        self.n_atoms = int(self._lib.gr_xtc_n_atoms(self._x))
+        self.n_frames = int(self._lib.gr_xtc_n_frames(self._x))
+
+    def close(self):
+        if getattr(self, "_x", None):
+            self._lib.gr_xtc_close(self._x)
+            self._x = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __len__(self):
+        return self.n_frames
+
+    def frame_info(self, i):
+        step = C.c_uint64(0); time = C.c_float(0); prec = C.c_float(0); box = np.zeros(9, np.float32)
+        st = self._lib.gr_xtc_frame_info(self._x, i, C.byref(step), C.byref(time), box.ctypes.data_as(C.c_void_p), C.byref(prec))
+        if st != _lib.OK:
+            raise XtcError(st, "frame_info(%d)" % i)
+        return int(step.value), float(time.value), box, float(prec.value)
+
+    def read_frame(self, i, out=None):
+        """-> (positions, box9, step, time, precision); `out` may be any C-contiguous float32 [n_atoms,3] buffer (e.g. pinned)"""
+        if out is None:
+            out = np.empty((self.n_atoms, 3), np.float32)
+        step = C.c_uint64(0); time = C.c_float(0); prec = C.c_float(0); box = np.zeros(9, np.float32)
+        st = self._lib.gr_xtc_read_frame(self._x, i, out.ctypes.data_as(C.c_void_p), box.ctypes.data_as(C.c_void_p),
+                                         C.byref(step), C.byref(time), C.byref(prec))
+        if st != _lib.OK:
+            raise XtcError(st, "read_frame(%d)" % i)
+        return out, box, int(step.value), float(time.value), float(prec.value)
+
+    def frames(self, start=0, stop=None, step=1):
+        """iterable for TrajReader: (positions, box9, step, time) -- `xtc_iter(..).with_range/with_step` in frame indices"""
+        stop = self.n_frames if stop is None else min(stop, self.n_frames)
+        for i in range(start, stop, step):
+            p, b, s, t, _ = self.read_frame(i)
+            yield p, b, s, t
+
+    def __iter__(self):
+        return self.frames()

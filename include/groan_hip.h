@@ -37,6 +37,7 @@ extern "C" {
 
 typedef struct gr_ctx gr_ctx;
 typedef struct gr_rmsd_plan gr_rmsd_plan;
+typedef struct gr_xtc gr_xtc;
 
 /* status codes; 1..7 map onto the reference's error enums (src/errors.rs) */
 enum {
@@ -54,7 +55,9 @@ enum {
     GR_E_GROUP_EXISTS = 11,      /* GroupError::AlreadyExistsWarning                        */
     GR_E_HIP = 12,               /* HIP runtime failure: see gr_last_error                  */
     GR_E_NO_DEVICE = 13,         /* no usable gfx950 device: the library has NO CPU fallback */
-    GR_E_UNSUPPORTED_BOX = 14    /* box too skewed for the minimum-image candidate table    */
+    GR_E_UNSUPPORTED_BOX = 14,   /* box too skewed for the minimum-image candidate table    */
+    GR_E_IO = 15,                /* ReadTrajError::FileNotFound / read failure              */
+    GR_E_FORMAT = 16             /* ReadTrajError::NotXtc / FrameNotFound (corrupt stream)  */
 };
 
 /* Dimension (src/structures/dimension.rs:13-23) */
@@ -190,6 +193,20 @@ int gr_rmsd_batch_end(gr_rmsd_plan *plan, float *rmsd_out, int *status_out, floa
 uint32_t gr_rmsd_plan_last_fallbacks(const gr_rmsd_plan *plan);
 /* force the multi-pass exact path (parity testing of both paths) */
 int gr_rmsd_plan_force_exact(gr_rmsd_plan *plan, int on);
+
+/* ---------------------------------------------------------------- xtc reader (host side)
+ * The stage in front of the path: XtcReader (src/io/xtc_io/mod.rs, molly_xtc.rs:96-308, xdrfile_xtc.rs:42-104).
+ * gr_xtc_open indexes the file (frame offsets, steps, times, boxes) so frames are random-access -- what the
+ * reference's with_range / with_step / per-thread skipping (traj_read.rs:215-246, parallel.rs:424-448) need -- and
+ * gr_xtc_read_frame is thread-safe: one frame per host thread, decoded straight into the caller's buffer
+ * (pinned memory from gr_host_alloc feeds gr_frame_upload without another copy).
+ * step is the u32-wrapped simulation step (xdrfile_xtc.rs:98-100); box9 in gro order (xdrfile.rs:170-187). */
+gr_xtc *gr_xtc_open(const char *path, int *status);
+void gr_xtc_close(gr_xtc *xtc);
+uint64_t gr_xtc_n_atoms(const gr_xtc *xtc);
+uint64_t gr_xtc_n_frames(const gr_xtc *xtc);
+int gr_xtc_frame_info(const gr_xtc *xtc, uint64_t frame, uint64_t *step, float *time, float box9[9], float *precision);
+int gr_xtc_read_frame(const gr_xtc *xtc, uint64_t frame, float *xyz, float box9[9], uint64_t *step, float *time, float *precision);
 
 /* ---------------------------------------------------------------- measurement / synthetic data
  * HIP-event timing on the context's stream (the stream the kernels are launched on). */

@@ -186,8 +186,21 @@ def main():
         tri[name + "_gro_pos"] = gp
         tri[name + "_gro_box9"] = gb
     np.savez_compressed(os.path.join(HERE, "tric_small.npz"), **tri)
+    # ---------------- xtc data files for the decoder tests (reference data files, not source) ----------------
+    import hashlib
+    import shutil
+    sums = {}
+    for name in ("triclinic_trajectory.xtc", "octahedron_trajectory.xtc", "dodecahedron_trajectory.xtc", "short_trajectory.xtc"):
+        shutil.copyfile(os.path.join(TF, name), os.path.join(HERE, name))
+        os.chmod(os.path.join(HERE, name), 0o644)
+        FX, FB, fs, ft, fp = read_xtc(os.path.join(TF, name))
+        sums[name] = {"sha256_coords_f32le": hashlib.sha256(FX.astype("<f4").tobytes()).hexdigest(), "n_frames": int(FX.shape[0]),
+                      "n_atoms": int(FX.shape[1]), "steps": [int(v) for v in fs], "times": [float(v) for v in ft], "precision": float(fp),
+                      "boxes_rowmajor": [[float(v) for v in b.ravel()] for b in FB]}
+    import json
+    json.dump(sums, open(os.path.join(HERE, "xtc_expected.json"), "w"), indent=1)
     for f in sorted(os.listdir(HERE)):
-        if f.endswith(".npz"):
+        if f.endswith(".npz") or f.endswith(".xtc"):
             print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
 
 

@@ -1,0 +1,126 @@
+"""config[4]-style pipeline on the GPU box: host xtc decode (the library's decoder, one frame per thread, straight into
+pinned buffers) overlapped with H2D on the copy stream and the GPU COM + centre/wrap work, double-buffered.
+The 5e5-atom truncated-octahedron trajectory is written at run time with the reference's xdrfile writer (oracle/_ref,
+test infrastructure).  Parity: per-frame COM and wrapped coordinates against the oracle; throughput and the stage times
+go to gpurun_out/xtc_pipeline.json."""
+import json
+import os
+import queue
+import threading
+import time
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from test_xtc_decoder import REF_SO, write_with_ref
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_decode_upload_com_wrap_pipeline(tmp_path):
+    if not os.path.exists(REF_SO):
+        pytest.skip("oracle/_ref not built")
+    import groan_rs_amd as G
+    n, n_frames, n_threads, n_buf = 500_000, 32, 8, 8
+    box9 = O.box_from_lengths_angles([18.0, 18.0, 18.0], [70.53, 109.47, 70.53])     # truncated octahedron (simbox.rs:329-342)
+    boxm = np.array([[box9[0], 0, 0], [box9[5], box9[1], 0], [box9[7], box9[8], box9[2]]], np.float32)
+    rng = np.random.default_rng(5)
+    nm = n // 3
+    mol = rng.uniform(0, 1, (nm, 3)) @ boxm.astype(np.float64)
+    base = (np.repeat(mol, 3, axis=0) + rng.normal(0, 0.06, (nm * 3, 3)))
+    base = np.concatenate([base, rng.uniform(0, 1, (n - 3 * nm, 3)) @ boxm.astype(np.float64)])
+    prot = slice(0, 30_000)                                                        # a compact "solute" to take the COM of
+    base[prot] = O.box_center(box9) + rng.normal(0, 1.2, (30_000, 3))
+    frames = []
+    for f in range(4):                                                             # 4 distinct frames, cycled
+        fr = base + rng.normal(0, 0.02, base.shape)
+        fr[prot] += rng.uniform(-6, 6, 3)                                          # solute drifts through the periodic boundary
+        frames.append(O.wrap_atoms(fr.astype(np.float32), np.arange(n), box9))
+    path = tmp_path / "octa_5e5.xtc"
+    t0 = time.time()
+    write_with_ref(path, [frames[f % 4] for f in range(n_frames)], boxm, 1000.0)
+    t_write = time.time() - t0
+    masses = np.array([15.999, 1.008, 1.008], np.float32)[np.arange(n) % 3]
+
+    x = G.XtcFile(path)
+    assert x.n_atoms == n and x.n_frames == n_frames
+    sysd = G.System(n, masses=masses, n_slots=n_buf)
+    sysd.group_create_from_ranges("Solute", [(0, 29_999)])
+    staging = [G.pinned_array((n, 3)) for _ in range(n_buf)]
+
+    # ---- stage times alone
+    t0 = time.perf_counter()
+    for f in range(8):
+        x.read_frame(f, out=staging[f % n_buf][0])
+    t_dec1 = (time.perf_counter() - t0) / 8                                          # one thread, seconds per frame
+
+    # ---- pipeline: decoder threads fill pinned buffers; the main thread uploads (copy stream) and runs the GPU work
+    free_q, ready = queue.Queue(), {}
+    cond = threading.Condition()
+    for b in range(n_buf):
+        free_q.put(b)
+    next_frame = [0]
+    lock = threading.Lock()
+
+    def decoder():
+        while True:
+            with lock:
+                f = next_frame[0]
+                if f >= n_frames:
+                    return
+                next_frame[0] += 1
+            b = free_q.get()
+            _, box, step, tm, _ = x.read_frame(f, out=staging[b][0])
+            with cond:
+                ready[f] = (b, box)
+                cond.notify_all()
+
+    ths = [threading.Thread(target=decoder) for _ in range(n_threads)]
+    t0 = time.perf_counter()
+    [t.start() for t in ths]
+    coms, wrapped_first = [], None
+    pending = None
+    for f in range(n_frames):
+        with cond:
+            while f not in ready:
+                cond.wait()
+            b, box = ready.pop(f)
+        slot = f % n_buf
+        sysd.upload_async(staging[b][0], box, slot)                                 # H2D on the copy stream
+        if pending is not None:                                                     # the previous staging buffer is free once its copy is done
+            pb, pslot = pending
+            sysd.upload_wait(pslot); free_q.put(pb)
+        pending = (b, slot)
+        coms.append(sysd.group_get_com("Solute", slot=slot))                        # GPU: Bai-Breen + unwrap + COM
+        sysd.atoms_center_mass("Solute", G.Dimension.XYZ, slot=slot)                # GPU: centre on the solute + wrap everything
+        if f == 1:
+            wrapped_first = sysd.get_positions(slot)
+    sysd.sync()
+    t_all = time.perf_counter() - t0
+    [t.join() for t in ths]
+
+    # ---- parity against the oracle on the decoded frames (decode is bit-exact, see tests/test_xtc_decoder.py)
+    idx = np.arange(30_000)
+    O.set_accumulate_f64(True)
+    try:
+        for f in (0, 1, 5, 31):
+            dec = x.read_frame(f)[0]
+            want = O.get_center(dec, idx, box9, mass=masses)
+            assert np.abs(coms[f] - want).max() <= 1e-5, (f, coms[f], want)
+        dec = x.read_frame(1)[0]
+        want = O.atoms_center(dec, idx, "xyz", box9, mass=masses)
+        assert np.abs(wrapped_first - want).max() <= 2e-5
+    finally:
+        O.set_accumulate_f64(False)
+    out = {"n_atoms": n, "n_frames": n_frames, "decode_threads": n_threads, "file_MB": round(os.path.getsize(path) / 1e6, 1),
+           "decode_one_thread_frames_per_s": round(1.0 / t_dec1, 1), "pipeline_frames_per_s": round(n_frames / t_all, 1),
+           "pipeline_wall_s": round(t_all, 3), "reference_writer_s": round(t_write, 2),
+           "stages": "xtc decode (host threads) || H2D copy stream || group_get_com + atoms_center_mass (all atoms) on the GPU"}
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    json.dump(out, open(os.path.join(ROOT, "gpurun_out", "xtc_pipeline.json"), "w"), indent=1)
+    print(out)
+    for _, ptr in staging:
+        G.pinned_free(ptr)
+    x.close(); sysd.close()
