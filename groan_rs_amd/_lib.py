@@ -75,6 +75,8 @@ SIGNATURES = {
     "gr_rmsd_batch_end": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gr_rmsd_plan_last_fallbacks": (C.c_uint32, [C.c_void_p]),
     "gr_rmsd_plan_force_exact": (C.c_int, [C.c_void_p, C.c_int]),
+    "gr_ctx_set_persistent": (C.c_int, [C.c_void_p, C.c_int]),
+    "gr_rmsd_plan_last_persistent": (C.c_int, [C.c_void_p]),
     "gr_xtc_open": (C.c_void_p, [C.c_char_p, c_i32p]),
     "gr_xtc_close": (None, [C.c_void_p]),
     "gr_xtc_n_atoms": (C.c_uint64, [C.c_void_p]),

@@ -17,6 +17,7 @@
 #include "gr_container.h"
 #include "gr_kernels.h"
 #include "gr_xtc.h"
+#include "gr_persist.h"
 
 #define GR_MAX_BATCH 256     // frames per batched call segment (workspace is sized for this)
 #define GR_MAX_CHUNKS 256    // workgroups per frame in the reduction kernels
@@ -78,9 +79,15 @@ struct gr_ctx {
     uint32_t chunks = 0;        // workgroups per frame in the reductions (0 = auto)
     uint32_t fit_wgs = 0;       // workgroups per frame in k_fit (0 = auto)
     int profile = 0;
-    double prof_ms[3] = { 0, 0, 0 };
-    uint64_t prof_launches[3] = { 0, 0, 0 };
-    uint64_t prof_frames[3] = { 0, 0, 0 };
+    double prof_ms[4] = { 0, 0, 0, 0 };        // 3 = k_rmsd_fit_persist
+    uint64_t prof_launches[4] = { 0, 0, 0, 0 };
+    uint64_t prof_frames[4] = { 0, 0, 0, 0 };
+    // persistent RMSD-fit kernel (gr_persist.h)
+    int persist = 0;                  // GR_PERSIST=1 / gr_ctx_set_persistent: persistent kernel for large fit batches
+    uint32_t n_cus = 0;
+    double *ps_partials = nullptr;    // [GR_MAX_BATCH][n_cus][GR_PS_REC]
+    uint32_t *ps_sync = nullptr;      // [2 + 2 * GR_MAX_BATCH]
+    uint32_t *ps_sync_host = nullptr; // pinned [2]
     int strict = 0;
     std::string err;
     uint64_t err_index = 0;
@@ -88,7 +95,7 @@ struct gr_ctx {
 };
 
 struct Pending {   // a segment between gr_rmsd_batch_begin and gr_rmsd_batch_end
-    bool active = false, any_ok = false, consistent = true, prof_two = false;
+    bool active = false, any_ok = false, consistent = true, prof_two = false, persist = false;
     uint32_t s0 = 0, nb = 0, n_prof_groups = 0;
     int fit = 0;
     std::vector<int> pre;
@@ -106,7 +113,7 @@ struct gr_rmsd_plan {
     GrPlanDev dev = {};
     int exact = 0;
     uint32_t last_fallbacks = 0;
-    bool resolved = false;
+    bool resolved = false, last_persist = false;
 };
 
 namespace {
@@ -159,6 +166,18 @@ uint32_t batch_chunks(const gr_ctx *c, const GrSel &s, uint32_t nf) {
     // of 8 rotate the mapping and run ~25 % slower)
     if (ch >= 8) ch &= ~(uint64_t)7;
     return (uint32_t)ch;
+}
+
+// Can the persistent kernel take this batch?  Contiguous selection, at least one tile per workgroup, a ring of 3 (else 2)
+// frame slices per workgroup inside the 160 KiB of LDS.
+bool persist_plan(const gr_ctx *c, const GrSel &s, uint32_t nf, uint32_t *T, uint32_t *D) {
+    if (!c->persist || !s.contiguous || c->n_cus == 0 || nf < 2) return false;
+    const uint32_t ntiles = (uint32_t)((c->n + 255) >> 8);
+    if (ntiles < c->n_cus) return false;                       // small systems: the batched three-kernel path
+    const uint32_t t = (ntiles + c->n_cus - 1) / c->n_cus;
+    for (uint32_t d = 3; d >= 2; --d)
+        if (gr_persist_lds_bytes(t, d) <= 160u * 1024u) { *T = t; *D = d; return true; }
+    return false;
 }
 
 uint32_t fit_grid(const gr_ctx *c, uint32_t nf) {
@@ -336,6 +355,10 @@ gr_ctx *gr_ctx_create(int device, uint64_t n_atoms, uint32_t n_slots, int *statu
     for (int k = 0; k < GR_MAX_BATCH; ++k) ok = ok && hipEventCreateWithFlags(&c->ev_grp[k], hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) == hipSuccess;
     if (const char *e = getenv("GR_OVERLAP")) c->overlap = atoi(e) ? 1 : 0;
+    if (const char *e = getenv("GR_PERSIST")) c->persist = atoi(e) ? 1 : 0;
+    { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cus = (uint32_t)prop.multiProcessorCount; }
+    ok = ok && hipMalloc(&c->ps_sync, (2 + 2 * GR_MAX_BATCH) * sizeof(uint32_t)) == hipSuccess;
+    ok = ok && hipHostMalloc(&c->ps_sync_host, 2 * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess;
     ok = ok && hipMalloc(&c->frames, (size_t)n_slots * c->frame_stride * sizeof(float)) == hipSuccess;
     ok = ok && hipMalloc(&c->masses, c->n_pad * sizeof(float)) == hipSuccess;
     ok = ok && hipMalloc(&c->boxes_dev, n_slots * sizeof(GrBox)) == hipSuccess;
@@ -387,6 +410,9 @@ void gr_ctx_destroy(gr_ctx *c) {
     if (c->bad_dev) (void)hipFree(c->bad_dev);
     if (c->bad_host) (void)hipHostFree(c->bad_host);
     if (c->pd_out) (void)hipFree(c->pd_out);
+    if (c->ps_partials) (void)hipFree(c->ps_partials);
+    if (c->ps_sync) (void)hipFree(c->ps_sync);
+    if (c->ps_sync_host) (void)hipHostFree(c->ps_sync_host);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     for (int k = 0; k < 4 * GR_MAX_BATCH; ++k) if (c->pev[k]) (void)hipEventDestroy(c->pev[k]);
@@ -753,6 +779,8 @@ gr_rmsd_plan *gr_rmsd_plan_create(gr_ctx *ref, uint32_t ref_slot, gr_ctx *target
 
 uint32_t gr_rmsd_plan_last_fallbacks(const gr_rmsd_plan *p) { return p ? p->last_fallbacks : 0; }
 int gr_rmsd_plan_force_exact(gr_rmsd_plan *p, int on) { if (!p) return GR_E_INVALID_ARG; p->exact = on ? 1 : 0; return GR_OK; }
+int gr_ctx_set_persistent(gr_ctx *c, int on) { if (!c) return GR_E_INVALID_ARG; c->persist = on ? 1 : 0; return GR_OK; }
+int gr_rmsd_plan_last_persistent(const gr_rmsd_plan *p) { return p && p->last_persist ? 1 : 0; }
 
 // multi-pass exact path for `nf` frames starting at first_slot; states [0, nf) must be reset by the caller
 static int rmsd_exact(gr_rmsd_plan *p, gr_ctx *c, const GrSel &sel, uint32_t first_slot, uint32_t nf, int fit) {
@@ -776,6 +804,7 @@ static int segment_begin(gr_rmsd_plan *p, uint32_t s0, uint32_t nb, int fit) {
     gr_ctx *c = p->target;
     Pending &q = p->pend;
     q = Pending();
+    if (fit) p->last_persist = false;
     q.s0 = s0; q.nb = nb; q.fit = fit; q.active = true;
     SlotUse use(c, s0, nb);
     const Group *g = find_group(c, p->group.c_str());
@@ -800,12 +829,29 @@ static int segment_begin(gr_rmsd_plan *p, uint32_t s0, uint32_t nb, int fit) {
     HIPCHK(c, hipMemcpyAsync(c->state_dev, c->state_host, nb * sizeof(GrFrameState), hipMemcpyHostToDevice, c->stream));
     q.consistent = (g->n == p->n_ref);
     int st;
+    uint32_t ps_T = 0, ps_D = 0;
     if (!q.consistent) {
         // positions and masses of the target are still checked first (extract_data_from_system runs to
         // completion before number_of_positions_consistent, rmsd.rs:206-214)
         st = pbc_center_stages(c, s0, nb, sel, 1); if (st) return st;
     } else if (p->exact) {
         st = rmsd_exact(p, c, sel, s0, nb, fit); if (st) return st;
+    } else if (fit && persist_plan(c, sel, nb, &ps_T, &ps_D)) {
+        // persistent pipelined kernel: every frame is read from HBM once (its slices wait in LDS for the rotation)
+        if (!c->ps_partials) HIPCHK(c, hipMalloc(&c->ps_partials, (size_t)GR_MAX_BATCH * c->n_cus * GR_PS_REC * sizeof(double)));
+        HIPCHK(c, hipMemsetAsync(c->ps_sync, 0, (2 + 2 * (size_t)nb) * sizeof(uint32_t), c->stream));
+        GrPersistArgs a;
+        a.frames = c->frames; a.frame_stride = c->frame_stride; a.first_slot = s0; a.n_frames = nb; a.n_atoms = (uint32_t)c->n;
+        a.masses = c->masses; a.sel = sel; a.boxes = c->boxes_dev; a.plan = p->dev; a.state = c->state_dev;
+        a.partials = c->ps_partials; a.sync = c->ps_sync; a.tiles_per_wg = ps_T; a.depth = ps_D;
+        const size_t lds = gr_persist_lds_bytes(ps_T, ps_D);
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rmsd_fit_persist), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (c->profile) HIPCHK(c, hipEventRecord(c->pev[0], c->stream));
+        k_rmsd_fit_persist<<<dim3(c->n_cus), dim3(GR_PS_THREADS), lds, c->stream>>>(a);
+        if (c->profile) HIPCHK(c, hipEventRecord(c->pev[1], c->stream));
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync(c->ps_sync_host, c->ps_sync, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        q.persist = true; p->last_persist = true;
     } else {
         // groups of sub_batch frames: accumulate -> finalize -> fit back to back on the stream, no host
         // round trip in between; one state fetch for the whole segment afterwards
@@ -867,6 +913,14 @@ static int segment_end(gr_rmsd_plan *p, float *rmsd_out, int *status_out, float 
         const Group *g = find_group(c, p->group.c_str());
         const GrSel sel = make_sel(*g);
         HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (q.persist) {
+            if (c->ps_sync_host[1] != 0) return fail(c, GR_E_HIP, "persistent RMSD-fit kernel timed out waiting for its workgroups (GPU shared with another process?); set GR_PERSIST=0");
+            if (c->profile) {
+                float ms = 0.f;
+                HIPCHK(c, hipEventElapsedTime(&ms, c->pev[0], c->pev[1]));
+                c->prof_ms[3] += ms; c->prof_launches[3] += 1; c->prof_frames[3] += nb;
+            }
+        }
         for (uint32_t gi = 0; gi < q.n_prof_groups; ++gi) {   // the stream is idle here: read this segment's event pairs
             const int nk = fit ? 3 : 2;
             const uint32_t nf = std::min<uint32_t>(c->sub_batch, nb - gi * c->sub_batch);
@@ -1032,11 +1086,11 @@ int gr_timer_stop(gr_ctx *c, float *ms) {
 int gr_profile_enable(gr_ctx *c, int on) {
     if (!c) return GR_E_INVALID_ARG;
     c->profile = on ? 1 : 0;
-    for (int k = 0; k < 3; ++k) { c->prof_ms[k] = 0; c->prof_launches[k] = 0; c->prof_frames[k] = 0; }
+    for (int k = 0; k < 4; ++k) { c->prof_ms[k] = 0; c->prof_launches[k] = 0; c->prof_frames[k] = 0; }
     return GR_OK;
 }
 int gr_profile_read(const gr_ctx *c, int kernel, double *ms_total, uint64_t *launches, uint64_t *frames) {
-    if (!c || kernel < 0 || kernel > 2) return GR_E_INVALID_ARG;
+    if (!c || kernel < 0 || kernel > 3) return GR_E_INVALID_ARG;
     if (ms_total) *ms_total = c->prof_ms[kernel];
     if (launches) *launches = c->prof_launches[kernel];
     if (frames) *frames = c->prof_frames[kernel];

@@ -318,6 +318,121 @@ __global__ void k_state_reset(GrFrameState *state, uint32_t n) {
 #define GR_ACC_K 32
 struct GrAccPartial { double s[GR_ACC_K]; float vmin[3], vmax[3], fmin[3], fmax[3]; uint32_t bad_pos, bad_mass; };
 
+// ---- per-lane state and per-atom arithmetic of the single pass (shared by k_rmsd_accum and the persistent kernel)
+struct GrA4 { float x[4], y[4], z[4], m[4], px[4], py[4], pz[4], w[4]; uint32_t i[4]; bool ok[4]; };   // four atoms of one lane
+
+struct GrLaneAcc {
+    double acc[GR_ACC_K];
+    float fsum[6];                       // first / second moments of the fractional coordinates
+    float mn[3], mx[3], fmn[3], fmx[3];  // Cartesian and fractional extent of v
+    uint32_t bad_pos, bad_mass;
+    __device__ __forceinline__ void reset() {
+#pragma unroll
+        for (int k = 0; k < GR_ACC_K; ++k) acc[k] = 0.0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) fsum[k] = 0.0f;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { mn[a] = fmn[a] = 3.0e38f; mx[a] = fmx[a] = -3.0e38f; }
+        bad_pos = bad_mass = GR_NOIDX;
+    }
+    // fold the f32 moment sums into their fp64 slots (call once, before the cross-lane reduction)
+    __device__ __forceinline__ void close(bool w_is_mass) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) acc[26 + k] = (double)fsum[k];
+        if (w_is_mass) { acc[23] = acc[1]; acc[24] = acc[2]; acc[25] = acc[3]; }   // sum w v == sum m v
+    }
+};
+
+struct GrFrameConst {   // wave-uniform per-frame constants
+    float gx, gy, gz;    // provisional centre (MODE 0)
+    float sx, sy, sz;    // shift = box centre - COM (MODE 1)
+    float iax, iby, icz, rws2;
+    bool tric, wm;
+};
+
+// Precision plan.  rmsd^2 is the small difference of sums of size W r^2 (it must come out ~0 for a frame that is a
+// rigid copy of the reference: the reference's own tests ask |rmsd| <= 1e-4 there, i.e. 1e-9 relative on those sums),
+// so everything that enters it -- B = sum (w p) v^T, sum w|v|^2, sum w v, sum m, sum m v -- uses exact products
+// (f32 x f32 is exact in fp64) and fp64 sums.  The unweighted covariance A only steers the rotation; it is formed as
+// a 4-atom f32 partial (operands are centred, ~1e-7 relative, random in sign) that is then added to its fp64
+// accumulator: 2.25 instead of 9 fp64 adds per atom.
+// `checked` = the group straddles the ends of the selection (or is the gather path's tail): per-atom validity + NaN
+// tests.  Interior groups skip them: a NaN position or mass then simply poisons the fp64 sums, which the finalize step
+// detects and answers by sending the frame to the multi-pass path, whose kernels report the first atom without
+// position / mass in the reference's order.
+template <int MODE>
+__device__ __forceinline__ void gr_flush4(GrLaneAcc &L, const GrA4 &a, const bool checked, const GrBox &box, const GrFrameConst &fc) {
+    float part[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) part[k] = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float m = a.m[q];
+        if (checked) {
+            if (!a.ok[q]) continue;
+            if (m != m) { L.bad_mass = min(L.bad_mass, a.i[q]); m = 0.0f; }
+            if (a.x[q] != a.x[q]) { L.bad_pos = min(L.bad_pos, a.i[q]); continue; }
+        }
+        float vx, vy, vz;
+        if (MODE == 0) {
+            // image of x nearest to g: closed-form brick reduction along c, b, a ...
+            vx = a.x[q] - fc.gx; vy = a.y[q] - fc.gy; vz = a.z[q] - fc.gz;
+            const float kc = rintf(vz * fc.icz);
+            vx = fmaf(-kc, box.cx, vx); vy = fmaf(-kc, box.cy, vy); vz = fmaf(-kc, box.cz, vz);
+            const float kb = rintf(vy * fc.iby);
+            vx = fmaf(-kb, box.bx, vx); vy = fmaf(-kb, box.by, vy);
+            const float ka = rintf(vx * fc.iax);
+            vx = fmaf(-ka, box.ax, vx);
+            // ... which is already THE minimum image whenever |v| < r_ws; otherwise search the table
+            if (fc.tric && vx * vx + vy * vy + vz * vz >= fc.rws2) gr_tric_refine(vx, vy, vz, box);
+            // fractional coordinates of v: first and second moments (image proof, see gr_finalize_math)
+            const float f_c = vz * fc.icz;
+            const float uy = fmaf(-f_c, box.cy, vy);
+            const float f_b = uy * fc.iby;
+            const float f_a = (vx - f_b * box.bx - f_c * box.cx) * fc.iax;
+            L.fsum[0] += f_a; L.fsum[1] += f_b; L.fsum[2] += f_c;
+            L.fsum[3] = fmaf(f_a, f_a, L.fsum[3]); L.fsum[4] = fmaf(f_b, f_b, L.fsum[4]); L.fsum[5] = fmaf(f_c, f_c, L.fsum[5]);
+            L.fmn[0] = fminf(L.fmn[0], f_a); L.fmn[1] = fminf(L.fmn[1], f_b); L.fmn[2] = fminf(L.fmn[2], f_c);
+            L.fmx[0] = fmaxf(L.fmx[0], f_a); L.fmx[1] = fmaxf(L.fmx[1], f_b); L.fmx[2] = fmaxf(L.fmx[2], f_c);
+        } else {
+            vx = a.x[q] + fc.sx; vy = a.y[q] + fc.sy; vz = a.z[q] + fc.sz;
+            gr_wrap(vx, vy, vz, box);
+            vx -= box.bcx; vy -= box.bcy; vz -= box.bcz;
+        }
+        L.mn[0] = fminf(L.mn[0], vx); L.mn[1] = fminf(L.mn[1], vy); L.mn[2] = fminf(L.mn[2], vz);
+        L.mx[0] = fmaxf(L.mx[0], vx); L.mx[1] = fmaxf(L.mx[1], vy); L.mx[2] = fmaxf(L.mx[2], vz);
+        const float px = a.px[q], py = a.py[q], pz = a.pz[q];
+        part[0] = fmaf(px, vx, part[0]); part[1] = fmaf(px, vy, part[1]); part[2] = fmaf(px, vz, part[2]);
+        part[3] = fmaf(py, vx, part[3]); part[4] = fmaf(py, vy, part[4]); part[5] = fmaf(py, vz, part[5]);
+        part[6] = fmaf(pz, vx, part[6]); part[7] = fmaf(pz, vy, part[7]); part[8] = fmaf(pz, vz, part[8]);
+        const double dvx = vx, dvy = vy, dvz = vz, dm = m, dw = a.w[q];
+        const double wpx = dw * (double)px, wpy = dw * (double)py, wpz = dw * (double)pz;
+        double *acc = L.acc;
+        acc[0] += dm;
+        acc[1] = fma(dm, dvx, acc[1]); acc[2] = fma(dm, dvy, acc[2]); acc[3] = fma(dm, dvz, acc[3]);
+        acc[13] = fma(wpx, dvx, acc[13]); acc[14] = fma(wpx, dvy, acc[14]); acc[15] = fma(wpx, dvz, acc[15]);
+        acc[16] = fma(wpy, dvx, acc[16]); acc[17] = fma(wpy, dvy, acc[17]); acc[18] = fma(wpy, dvz, acc[18]);
+        acc[19] = fma(wpz, dvx, acc[19]); acc[20] = fma(wpz, dvy, acc[20]); acc[21] = fma(wpz, dvz, acc[21]);
+        acc[22] = fma(dw, fma(dvx, dvx, fma(dvy, dvy, dvz * dvz)), acc[22]);
+        if (!fc.wm) { acc[23] = fma(dw, dvx, acc[23]); acc[24] = fma(dw, dvy, acc[24]); acc[25] = fma(dw, dvz, acc[25]); }
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) L.acc[4 + k] += (double)part[k];
+}
+
+// unpack the three float4 of positions / reference coordinates + masses / weights of one lane into four atoms
+__device__ __forceinline__ void gr_unpack4(GrA4 &q, const float4 &a, const float4 &b, const float4 &c, const float4 &pa, const float4 &pb,
+                                           const float4 &pc, const float4 &mm, const float4 &ww, uint32_t i, uint32_t first, uint32_t last) {
+    q.x[0] = a.x; q.y[0] = a.y; q.z[0] = a.z; q.x[1] = a.w; q.y[1] = b.x; q.z[1] = b.y;
+    q.x[2] = b.z; q.y[2] = b.w; q.z[2] = c.x; q.x[3] = c.y; q.y[3] = c.z; q.z[3] = c.w;
+    q.px[0] = pa.x; q.py[0] = pa.y; q.pz[0] = pa.z; q.px[1] = pa.w; q.py[1] = pb.x; q.pz[1] = pb.y;
+    q.px[2] = pb.z; q.py[2] = pb.w; q.pz[2] = pc.x; q.px[3] = pc.y; q.py[3] = pc.z; q.pz[3] = pc.w;
+    q.m[0] = mm.x; q.m[1] = mm.y; q.m[2] = mm.z; q.m[3] = mm.w;
+    q.w[0] = ww.x; q.w[1] = ww.y; q.w[2] = ww.z; q.w[3] = ww.w;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { q.i[k] = i + k; q.ok[k] = (i + k >= first) && (i + k < last); }
+}
+
 #ifndef GR_ACC_MIN_WAVES
 #define GR_ACC_MIN_WAVES 1
 #endif
@@ -333,92 +448,20 @@ __global__ __launch_bounds__(GR_WG, GR_ACC_MIN_WAVES) void k_rmsd_accum(
     const uint32_t frame = blockIdx.y, chunk = blockIdx.x, nchunks = gridDim.x;
     const float *xyz = frames + (size_t)(first_slot + frame) * frame_stride;
     gr_stage_box(&box, boxes + first_slot + frame);
-    double acc[GR_ACC_K];
-#pragma unroll
-    for (int k = 0; k < GR_ACC_K; ++k) acc[k] = 0.0;
-    float mn[3] = { 3.0e38f, 3.0e38f, 3.0e38f }, mx[3] = { -3.0e38f, -3.0e38f, -3.0e38f };
-    uint32_t bad_pos = GR_NOIDX, bad_mass = GR_NOIDX;
-    float gx, gy, gz, sx = 0.f, sy = 0.f, sz = 0.f;
+    GrLaneAcc L;
+    L.reset();
+    GrFrameConst fc;
     {
         const uint32_t i0 = sel.contiguous ? sel.start : sel.idx[0];
-        gx = xyz[3 * (size_t)i0]; gy = xyz[3 * (size_t)i0 + 1]; gz = xyz[3 * (size_t)i0 + 2];
+        fc.gx = xyz[3 * (size_t)i0]; fc.gy = xyz[3 * (size_t)i0 + 1]; fc.gz = xyz[3 * (size_t)i0 + 2];
     }
-    if (MODE == 1) { sx = state[frame].shift[0]; sy = state[frame].shift[1]; sz = state[frame].shift[2]; }
-    const float iax = box.iax, iby = box.iby, icz = box.icz;
-    const float rws2 = box.r_ws * box.r_ws;
-    const bool tric = !box.ortho;
-    float fsum[6] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
-    float fmn[3] = { 3.0e38f, 3.0e38f, 3.0e38f }, fmx[3] = { -3.0e38f, -3.0e38f, -3.0e38f };   // fractional extent of v
-
-    // Precision plan.  rmsd^2 is the small difference of sums of size W r^2 (it must come out ~0 for a frame
-    // that is a rigid copy of the reference: the reference's own tests ask |rmsd| <= 1e-4 there, i.e. 1e-9
-    // relative on those sums), so everything that enters it -- B = sum (w p) v^T, sum w|v|^2, sum w v, sum m,
-    // sum m v -- uses exact products (f32 x f32 is exact in fp64) and fp64 sums.  The unweighted covariance A
-    // only steers the rotation; it is formed as a 4-atom f32 partial (operands are centred, ~1e-7 relative,
-    // random in sign) that is then added to its fp64 accumulator: 2.25 instead of 9 fp64 adds per atom.
-    struct A4 { float x[4], y[4], z[4], m[4], px[4], py[4], pz[4], w[4]; uint32_t i[4]; bool ok[4]; };
-    const bool wm = plan.w_is_mass != 0;
-    // `checked` = the group straddles the ends of the selection (or comes from the gather path's tail): per-atom
-    // validity + NaN tests.  Interior groups skip them: a NaN position or mass then simply poisons the fp64 sums,
-    // which the finalize kernel detects and answers by sending the frame to the multi-pass path, whose kernels
-    // report the first atom without position / mass in the reference's order.
-    auto flush4 = [&](const A4 &a, const bool checked) {
-        float part[9];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) part[k] = 0.0f;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            float m = a.m[q];
-            if (checked) {
-                if (!a.ok[q]) continue;
-                if (m != m) { bad_mass = min(bad_mass, a.i[q]); m = 0.0f; }
-                if (a.x[q] != a.x[q]) { bad_pos = min(bad_pos, a.i[q]); continue; }
-            }
-            float vx, vy, vz;
-            if (MODE == 0) {
-                // image of x nearest to g: closed-form brick reduction along c, b, a ...
-                vx = a.x[q] - gx; vy = a.y[q] - gy; vz = a.z[q] - gz;
-                const float kc = rintf(vz * icz);
-                vx = fmaf(-kc, box.cx, vx); vy = fmaf(-kc, box.cy, vy); vz = fmaf(-kc, box.cz, vz);
-                const float kb = rintf(vy * iby);
-                vx = fmaf(-kb, box.bx, vx); vy = fmaf(-kb, box.by, vy);
-                const float ka = rintf(vx * iax);
-                vx = fmaf(-ka, box.ax, vx);
-                // ... which is already THE minimum image whenever |v| < r_ws; otherwise search the table
-                if (tric && vx * vx + vy * vy + vz * vz >= rws2) gr_tric_refine(vx, vy, vz, box);
-                // fractional coordinates of v: first and second moments (image proof, see k_rmsd_finalize)
-                const float fc = vz * icz;
-                const float uy = fmaf(-fc, box.cy, vy);
-                const float fb = uy * iby;
-                const float fa = (vx - fb * box.bx - fc * box.cx) * iax;
-                fsum[0] += fa; fsum[1] += fb; fsum[2] += fc;
-                fsum[3] = fmaf(fa, fa, fsum[3]); fsum[4] = fmaf(fb, fb, fsum[4]); fsum[5] = fmaf(fc, fc, fsum[5]);
-                fmn[0] = fminf(fmn[0], fa); fmn[1] = fminf(fmn[1], fb); fmn[2] = fminf(fmn[2], fc);
-                fmx[0] = fmaxf(fmx[0], fa); fmx[1] = fmaxf(fmx[1], fb); fmx[2] = fmaxf(fmx[2], fc);
-            } else {
-                vx = a.x[q] + sx; vy = a.y[q] + sy; vz = a.z[q] + sz;
-                gr_wrap(vx, vy, vz, box);
-                vx -= box.bcx; vy -= box.bcy; vz -= box.bcz;
-            }
-            mn[0] = fminf(mn[0], vx); mn[1] = fminf(mn[1], vy); mn[2] = fminf(mn[2], vz);
-            mx[0] = fmaxf(mx[0], vx); mx[1] = fmaxf(mx[1], vy); mx[2] = fmaxf(mx[2], vz);
-            const float px = a.px[q], py = a.py[q], pz = a.pz[q];
-            part[0] = fmaf(px, vx, part[0]); part[1] = fmaf(px, vy, part[1]); part[2] = fmaf(px, vz, part[2]);
-            part[3] = fmaf(py, vx, part[3]); part[4] = fmaf(py, vy, part[4]); part[5] = fmaf(py, vz, part[5]);
-            part[6] = fmaf(pz, vx, part[6]); part[7] = fmaf(pz, vy, part[7]); part[8] = fmaf(pz, vz, part[8]);
-            const double dvx = vx, dvy = vy, dvz = vz, dm = m, dw = a.w[q];
-            const double wpx = dw * (double)px, wpy = dw * (double)py, wpz = dw * (double)pz;
-            acc[0] += dm;
-            acc[1] = fma(dm, dvx, acc[1]); acc[2] = fma(dm, dvy, acc[2]); acc[3] = fma(dm, dvz, acc[3]);
-            acc[13] = fma(wpx, dvx, acc[13]); acc[14] = fma(wpx, dvy, acc[14]); acc[15] = fma(wpx, dvz, acc[15]);
-            acc[16] = fma(wpy, dvx, acc[16]); acc[17] = fma(wpy, dvy, acc[17]); acc[18] = fma(wpy, dvz, acc[18]);
-            acc[19] = fma(wpz, dvx, acc[19]); acc[20] = fma(wpz, dvy, acc[20]); acc[21] = fma(wpz, dvz, acc[21]);
-            acc[22] = fma(dw, fma(dvx, dvx, fma(dvy, dvy, dvz * dvz)), acc[22]);
-            if (!wm) { acc[23] = fma(dw, dvx, acc[23]); acc[24] = fma(dw, dvy, acc[24]); acc[25] = fma(dw, dvz, acc[25]); }
-        }
-#pragma unroll
-        for (int k = 0; k < 9; ++k) acc[4 + k] += (double)part[k];
-    };
+    fc.sx = fc.sy = fc.sz = 0.f;
+    if (MODE == 1) { fc.sx = state[frame].shift[0]; fc.sy = state[frame].shift[1]; fc.sz = state[frame].shift[2]; }
+    fc.iax = box.iax; fc.iby = box.iby; fc.icz = box.icz;
+    fc.rws2 = box.r_ws * box.r_ws;
+    fc.tric = !box.ortho;
+    fc.wm = plan.w_is_mass != 0;
+    const bool wm = fc.wm;
 
     if (sel.contiguous) {
         // 4 atoms per lane per trip: 3 float4 of positions, 3 float4 of reference coordinates, 1 float4 of masses
@@ -438,21 +481,14 @@ __global__ __launch_bounds__(GR_WG, GR_ACC_MIN_WAVES) void k_rmsd_accum(
             const float4 mm = m4[g];
             const float4 ww = wm ? mm : w4[pg];
             const uint32_t i = g << 2;
-            A4 q;
-            q.x[0] = a.x; q.y[0] = a.y; q.z[0] = a.z; q.x[1] = a.w; q.y[1] = b.x; q.z[1] = b.y;
-            q.x[2] = b.z; q.y[2] = b.w; q.z[2] = c.x; q.x[3] = c.y; q.y[3] = c.z; q.z[3] = c.w;
-            q.px[0] = pa.x; q.py[0] = pa.y; q.pz[0] = pa.z; q.px[1] = pa.w; q.py[1] = pb.x; q.pz[1] = pb.y;
-            q.px[2] = pb.z; q.py[2] = pb.w; q.pz[2] = pc.x; q.px[3] = pc.y; q.py[3] = pc.z; q.pz[3] = pc.w;
-            q.m[0] = mm.x; q.m[1] = mm.y; q.m[2] = mm.z; q.m[3] = mm.w;
-            q.w[0] = ww.x; q.w[1] = ww.y; q.w[2] = ww.z; q.w[3] = ww.w;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { q.i[k] = i + k; q.ok[k] = (i + k >= first) && (i + k < last); }
-            if (MODE == 0 && i >= first && i + 3 < last) flush4(q, false); else flush4(q, true);
+            GrA4 q;
+            gr_unpack4(q, a, b, c, pa, pb, pc, mm, ww, i, first, last);
+            if (MODE == 0 && i >= first && i + 3 < last) gr_flush4<MODE>(L, q, false, box, fc); else gr_flush4<MODE>(L, q, true, box, fc);
         }
     } else {
         const uint32_t n4 = (sel.n + 3u) >> 2;
         for (uint32_t j4 = chunk * GR_WG + threadIdx.x; j4 < n4; j4 += nchunks * GR_WG) {
-            A4 t;
+            GrA4 t;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const uint32_t j = j4 * 4 + q;
@@ -462,26 +498,24 @@ __global__ __launch_bounds__(GR_WG, GR_ACC_MIN_WAVES) void k_rmsd_accum(
                 const float *r = xyz + 3 * (size_t)i;
                 t.i[q] = i; t.x[q] = r[0]; t.y[q] = r[1]; t.z[q] = r[2]; t.m[q] = masses[i];
                 t.px[q] = plan.p[3 * (size_t)jj]; t.py[q] = plan.p[3 * (size_t)jj + 1]; t.pz[q] = plan.p[3 * (size_t)jj + 2];
-                t.w[q] = plan.w_is_mass ? t.m[q] : plan.w[jj];
+                t.w[q] = wm ? t.m[q] : plan.w[jj];
             }
-            if (MODE == 0 && j4 * 4 + 3 < sel.n) flush4(t, false); else flush4(t, true);
+            if (MODE == 0 && j4 * 4 + 3 < sel.n) gr_flush4<MODE>(L, t, false, box, fc); else gr_flush4<MODE>(L, t, true, box, fc);
         }
     }
-#pragma unroll
-    for (int k = 0; k < 6; ++k) acc[26 + k] = (double)fsum[k];
-    if (wm) { acc[23] = acc[1]; acc[24] = acc[2]; acc[25] = acc[3]; }   // sum w v == sum m v
-    gr_block_sum<GR_ACC_K>(acc, lds);
-    bad_pos = gr_block_min_u32(bad_pos, ldsu);
-    bad_mass = gr_block_min_u32(bad_mass, ldsu);
+    L.close(wm);
+    gr_block_sum<GR_ACC_K>(L.acc, lds);
+    const uint32_t bad_pos = gr_block_min_u32(L.bad_pos, ldsu);
+    const uint32_t bad_mass = gr_block_min_u32(L.bad_mass, ldsu);
     float rmn[3], rmx[3], rfmn[3], rfmx[3];
     for (int a = 0; a < 3; ++a) {
-        rmn[a] = gr_block_min_f32(mn[a], ldsf); rmx[a] = -gr_block_min_f32(-mx[a], ldsf);
-        rfmn[a] = gr_block_min_f32(fmn[a], ldsf); rfmx[a] = -gr_block_min_f32(-fmx[a], ldsf);
+        rmn[a] = gr_block_min_f32(L.mn[a], ldsf); rmx[a] = -gr_block_min_f32(-L.mx[a], ldsf);
+        rfmn[a] = gr_block_min_f32(L.fmn[a], ldsf); rfmx[a] = -gr_block_min_f32(-L.fmx[a], ldsf);
     }
     if (threadIdx.x == 0) {
         GrAccPartial &o = partials[(size_t)frame * nchunks + chunk];
 #pragma unroll
-        for (int k = 0; k < GR_ACC_K; ++k) o.s[k] = acc[k];
+        for (int k = 0; k < GR_ACC_K; ++k) o.s[k] = L.acc[k];
         for (int a = 0; a < 3; ++a) { o.vmin[a] = rmn[a]; o.vmax[a] = rmx[a]; o.fmin[a] = rfmn[a]; o.fmax[a] = rfmx[a]; }
         o.bad_pos = bad_pos; o.bad_mass = bad_mass;
     }
@@ -557,42 +591,11 @@ __device__ inline void gr_kabsch_rotation(const double H[3][3], double R[3][3]) 
 // every v_i must lie strictly inside the minimum-image cell about BOTH the reference's Bai-Breen centre estimate
 // (wherever in its rigorously bounded region it is) and the COM; otherwise the frame is flagged GR_ST_FALLBACK
 // and redone by the multi-pass path.
+// Closing algebra of the single pass for one frame (one lane).  `st` receives centre / com / shift / R / rmsd / status.
 template <int MODE>
-__global__ __launch_bounds__(GR_WG) void k_rmsd_finalize(
-    const GrAccPartial *__restrict__ partials, uint32_t nchunks,
-    const float *__restrict__ frames, size_t frame_stride, uint32_t first_slot, GrSel sel,
-    const GrBox *__restrict__ boxes, GrPlanDev plan, GrFrameState *__restrict__ state) {
-    __shared__ double lds[(GR_WG / 64) * GR_ACC_K];
-    __shared__ uint32_t ldsu[GR_WG / 64];
-    __shared__ float ldsf[GR_WG / 64];
-    const uint32_t frame = blockIdx.x;
-    double acc[GR_ACC_K];
-#pragma unroll
-    for (int k = 0; k < GR_ACC_K; ++k) acc[k] = 0.0;
-    float mn[3] = { 3.0e38f, 3.0e38f, 3.0e38f }, mx[3] = { -3.0e38f, -3.0e38f, -3.0e38f };
-    float fmn[3] = { 3.0e38f, 3.0e38f, 3.0e38f }, fmx[3] = { -3.0e38f, -3.0e38f, -3.0e38f };
-    uint32_t bad_pos = GR_NOIDX, bad_mass = GR_NOIDX;
-    for (uint32_t c = threadIdx.x; c < nchunks; c += GR_WG) {
-        const GrAccPartial &p = partials[(size_t)frame * nchunks + c];
-#pragma unroll
-        for (int k = 0; k < GR_ACC_K; ++k) acc[k] += p.s[k];
-        for (int a = 0; a < 3; ++a) {
-            mn[a] = fminf(mn[a], p.vmin[a]); mx[a] = fmaxf(mx[a], p.vmax[a]);
-            fmn[a] = fminf(fmn[a], p.fmin[a]); fmx[a] = fmaxf(fmx[a], p.fmax[a]);
-        }
-        bad_pos = min(bad_pos, p.bad_pos); bad_mass = min(bad_mass, p.bad_mass);
-    }
-    gr_block_sum<GR_ACC_K>(acc, lds);
-    bad_pos = gr_block_min_u32(bad_pos, ldsu);
-    bad_mass = gr_block_min_u32(bad_mass, ldsu);
-    for (int a = 0; a < 3; ++a) {
-        mn[a] = gr_block_min_f32(mn[a], ldsf); mx[a] = -gr_block_min_f32(-mx[a], ldsf);
-        fmn[a] = gr_block_min_f32(fmn[a], ldsf); fmx[a] = -gr_block_min_f32(-fmx[a], ldsf);
-    }
-    if (threadIdx.x != 0) return;
-    GrFrameState &st = state[frame];
-    if (st.status != 0) return;
-    const GrBox &b = boxes[first_slot + frame];
+__device__ inline void gr_finalize_math(const double *acc, const float mn[3], const float mx[3], const float fmn[3], const float fmx[3],
+                                        uint32_t bad_pos, uint32_t bad_mass, const GrBox &b, const GrPlanDev &plan,
+                                        const double g[3], uint32_t n_sel, GrFrameState &st) {
     if (MODE == 0) {
         // get_com: positions of the whole group are checked before any mass (iterators.rs:1405-1422)
         if (bad_pos != GR_NOIDX) { st.status = 6; st.err_index = bad_pos; return; }
@@ -607,9 +610,6 @@ __global__ __launch_bounds__(GR_WG) void k_rmsd_finalize(
     double cv[3] = { 0, 0, 0 };
     if (MODE == 0) { cv[0] = acc[1] / M; cv[1] = acc[2] / M; cv[2] = acc[3] / M; }
     if (MODE == 0) {
-        const float *xyz = frames + (size_t)(first_slot + frame) * frame_stride;
-        const uint32_t i0 = sel.contiguous ? sel.start : sel.idx[0];
-        const double g[3] = { xyz[3 * (size_t)i0], xyz[3 * (size_t)i0 + 1], xyz[3 * (size_t)i0 + 2] };
         // Where can the reference's Bai-Breen centre estimate c' lie?  Per fractional axis it is the circular mean
         // of the f_i.  With mu = mean f, theta_i = 2 pi (f_i - mu) (sum theta_i = 0), |theta_i| <= Theta = 2 pi E
         // (E = fractional extent, must be < 1/2), T = sum theta_i^2:
@@ -617,7 +617,7 @@ __global__ __launch_bounds__(GR_WG) void k_rmsd_finalize(
         //   => |c'_a - mu_a| <= atan((Theta T / 6) / (n - T / 2)) / (2 pi) =: eps_a          (rigorous, no sin/cos)
         // so c' = mu + e with |e| <= sum_a eps_a |box_a|.
         const double TWO_PI = 6.283185307179586;
-        const double nsel = (double)sel.n;
+        const double nsel = (double)n_sel;
         double mu[3], eps[3];
         bool ok = true;
         for (int a = 0; a < 3; ++a) {
@@ -676,6 +676,47 @@ __global__ __launch_bounds__(GR_WG) void k_rmsd_finalize(
     if (r2 < 0.0) r2 = 0.0;
     st.rmsd = (float)sqrt(r2);
     for (int a = 0; a < 3; ++a) for (int c = 0; c < 3; ++c) st.R[3 * c + a] = (float)R[a][c];   // column-major
+}
+
+template <int MODE>
+__global__ __launch_bounds__(GR_WG) void k_rmsd_finalize(
+    const GrAccPartial *__restrict__ partials, uint32_t nchunks,
+    const float *__restrict__ frames, size_t frame_stride, uint32_t first_slot, GrSel sel,
+    const GrBox *__restrict__ boxes, GrPlanDev plan, GrFrameState *__restrict__ state) {
+    __shared__ double lds[(GR_WG / 64) * GR_ACC_K];
+    __shared__ uint32_t ldsu[GR_WG / 64];
+    __shared__ float ldsf[GR_WG / 64];
+    const uint32_t frame = blockIdx.x;
+    double acc[GR_ACC_K];
+#pragma unroll
+    for (int k = 0; k < GR_ACC_K; ++k) acc[k] = 0.0;
+    float mn[3] = { 3.0e38f, 3.0e38f, 3.0e38f }, mx[3] = { -3.0e38f, -3.0e38f, -3.0e38f };
+    float fmn[3] = { 3.0e38f, 3.0e38f, 3.0e38f }, fmx[3] = { -3.0e38f, -3.0e38f, -3.0e38f };
+    uint32_t bad_pos = GR_NOIDX, bad_mass = GR_NOIDX;
+    for (uint32_t c = threadIdx.x; c < nchunks; c += GR_WG) {
+        const GrAccPartial &p = partials[(size_t)frame * nchunks + c];
+#pragma unroll
+        for (int k = 0; k < GR_ACC_K; ++k) acc[k] += p.s[k];
+        for (int a = 0; a < 3; ++a) {
+            mn[a] = fminf(mn[a], p.vmin[a]); mx[a] = fmaxf(mx[a], p.vmax[a]);
+            fmn[a] = fminf(fmn[a], p.fmin[a]); fmx[a] = fmaxf(fmx[a], p.fmax[a]);
+        }
+        bad_pos = min(bad_pos, p.bad_pos); bad_mass = min(bad_mass, p.bad_mass);
+    }
+    gr_block_sum<GR_ACC_K>(acc, lds);
+    bad_pos = gr_block_min_u32(bad_pos, ldsu);
+    bad_mass = gr_block_min_u32(bad_mass, ldsu);
+    for (int a = 0; a < 3; ++a) {
+        mn[a] = gr_block_min_f32(mn[a], ldsf); mx[a] = -gr_block_min_f32(-mx[a], ldsf);
+        fmn[a] = gr_block_min_f32(fmn[a], ldsf); fmx[a] = -gr_block_min_f32(-fmx[a], ldsf);
+    }
+    if (threadIdx.x != 0) return;
+    GrFrameState &st = state[frame];
+    if (st.status != 0) return;
+    const float *xyz = frames + (size_t)(first_slot + frame) * frame_stride;
+    const uint32_t i0 = sel.contiguous ? sel.start : sel.idx[0];
+    const double g[3] = { xyz[3 * (size_t)i0], xyz[3 * (size_t)i0 + 1], xyz[3 * (size_t)i0 + 2] };
+    gr_finalize_math<MODE>(acc, mn, mx, fmn, fmx, bad_pos, bad_mass, boxes[first_slot + frame], plan, g, sel.n, st);
 }
 
 // ------------------------------------------------------------------------------------------ fit (all atoms)

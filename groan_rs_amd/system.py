@@ -246,6 +246,10 @@ class System:
         if st != OK:
             raise DeviceError("set_masses", self._err(st)[1], st)
 
+    def set_persistent(self, on=True):
+        """large RMSD-fit batches as one persistent kernel (default) or as accumulate -> finalize -> fit"""
+        self._lib.gr_ctx_set_persistent(self._ctx, int(bool(on)))
+
     def set_strict_orthogonal(self, on=True):
         """reproduce the reference's SimBoxError::NotOrthogonal for non-orthogonal boxes"""
         self._strict_flag = bool(on)
@@ -475,7 +479,7 @@ class System:
     def profile_read(self):
         """-> {kernel: (ms_total, launches, frames)} for the batched RMSD path"""
         out = {}
-        for k, name in enumerate(("k_rmsd_accum", "k_rmsd_finalize", "k_fit")):
+        for k, name in enumerate(("k_rmsd_accum", "k_rmsd_finalize", "k_fit", "k_rmsd_fit_persist")):
             ms = C.c_double(0); n = C.c_uint64(0); f = C.c_uint64(0)
             self._lib.gr_profile_read(self._ctx, k, C.byref(ms), C.byref(n), C.byref(f))
             out[name] = (ms.value, int(n.value), int(f.value))
@@ -531,6 +535,10 @@ class RMSDPlan:
 
     def last_fallbacks(self):
         return int(self._lib.gr_rmsd_plan_last_fallbacks(self._plan))
+
+    def last_persistent(self):
+        """True when the last fit batch ran as the persistent LDS-resident kernel"""
+        return bool(self._lib.gr_rmsd_plan_last_persistent(self._plan))
 
     def rmsd(self, first_slot=0, n_frames=1, return_rotation=False, raise_on_error=True):
         r = np.zeros(n_frames, np.float32); s = np.zeros(n_frames, np.int32); R = np.zeros((n_frames, 9), np.float32)

@@ -193,6 +193,11 @@ int gr_rmsd_batch_end(gr_rmsd_plan *plan, float *rmsd_out, int *status_out, floa
 uint32_t gr_rmsd_plan_last_fallbacks(const gr_rmsd_plan *plan);
 /* force the multi-pass exact path (parity testing of both paths) */
 int gr_rmsd_plan_force_exact(gr_rmsd_plan *plan, int on);
+/* RMSD-fit batches of large systems run as ONE persistent kernel that keeps each frame in LDS between the sums and the
+ * transform; on = 0 selects the accumulate -> finalize -> fit kernels instead (also: GR_PERSIST=0).
+ * gr_rmsd_plan_last_persistent: 1 when the last fit batch of the plan took the persistent kernel. */
+int gr_ctx_set_persistent(gr_ctx *ctx, int on);
+int gr_rmsd_plan_last_persistent(const gr_rmsd_plan *plan);
 
 /* ---------------------------------------------------------------- xtc reader (host side)
  * The stage in front of the path: XtcReader (src/io/xtc_io/mod.rs, molly_xtc.rs:96-308, xdrfile_xtc.rs:42-104).
@@ -213,7 +218,7 @@ int gr_xtc_read_frame(const gr_xtc *xtc, uint64_t frame, float *xyz, float box9[
 int gr_timer_start(gr_ctx *ctx);
 int gr_timer_stop(gr_ctx *ctx, float *milliseconds);
 /* Per-kernel HIP-event profile of the batched RMSD path, recorded on the context's stream around
- * each launch while enabled: kernel 0 = k_rmsd_accum, 1 = k_rmsd_finalize, 2 = k_fit.  Enabling resets
+ * each launch while enabled: kernel 0 = k_rmsd_accum, 1 = k_rmsd_finalize, 2 = k_fit, 3 = k_rmsd_fit_persist.  Enabling resets
  * the counters.  ms_total / launches = average launch duration; frames = frames those launches covered. */
 int gr_profile_enable(gr_ctx *ctx, int on);
 int gr_profile_read(const gr_ctx *ctx, int kernel, double *ms_total, uint64_t *launches, uint64_t *frames);
