@@ -64,6 +64,9 @@ struct gr_ctx {
     // workspace
     GrCenPartial *cen_partials = nullptr;
     GrAccPartial *acc_partials = nullptr;
+    double *fit_partials = nullptr;   // [frames of a segment][fit workgroups per frame]: sum w |R q - p|^2 of k_fit<true>
+    size_t fit_partials_cap = 0;
+    int two_pass = 1;                 // GR_TWO_PASS=0: RMSD-fit keeps the closed-form single-pass rmsd (k_rmsd_accum<0,false>)
     GrFrameState *state_dev = nullptr;
     GrFrameState *state_host = nullptr;   // pinned
     uint32_t *bad_dev = nullptr;          // [4]
@@ -88,6 +91,8 @@ struct gr_ctx {
     double *ps_partials = nullptr;    // [GR_MAX_BATCH][n_cus][GR_PS_REC]
     uint32_t *ps_sync = nullptr;      // [2 + 2 * GR_MAX_BATCH]
     uint32_t *ps_sync_host = nullptr; // pinned [2]
+    unsigned long long *ps_trace = nullptr;   // GR_PS_TRACE=<file>: time stamps of the last persistent launch, dumped to <file>
+    std::string ps_trace_path;
     int strict = 0;
     std::string err;
     uint64_t err_index = 0;
@@ -356,6 +361,8 @@ gr_ctx *gr_ctx_create(int device, uint64_t n_atoms, uint32_t n_slots, int *statu
     ok = ok && hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) == hipSuccess;
     if (const char *e = getenv("GR_OVERLAP")) c->overlap = atoi(e) ? 1 : 0;
     if (const char *e = getenv("GR_PERSIST")) c->persist = atoi(e) ? 1 : 0;
+    if (const char *e = getenv("GR_TWO_PASS")) c->two_pass = atoi(e) ? 1 : 0;
+    if (const char *e = getenv("GR_PS_TRACE")) c->ps_trace_path = e;
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cus = (uint32_t)prop.multiProcessorCount; }
     ok = ok && hipMalloc(&c->ps_sync, (2 + 2 * GR_MAX_BATCH) * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipHostMalloc(&c->ps_sync_host, 2 * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess;
@@ -405,6 +412,7 @@ void gr_ctx_destroy(gr_ctx *c) {
     if (c->boxes_host) (void)hipHostFree(c->boxes_host);
     if (c->cen_partials) (void)hipFree(c->cen_partials);
     if (c->acc_partials) (void)hipFree(c->acc_partials);
+    if (c->fit_partials) (void)hipFree(c->fit_partials);
     if (c->state_dev) (void)hipFree(c->state_dev);
     if (c->state_host) (void)hipHostFree(c->state_host);
     if (c->bad_dev) (void)hipFree(c->bad_dev);
@@ -412,6 +420,7 @@ void gr_ctx_destroy(gr_ctx *c) {
     if (c->pd_out) (void)hipFree(c->pd_out);
     if (c->ps_partials) (void)hipFree(c->ps_partials);
     if (c->ps_sync) (void)hipFree(c->ps_sync);
+    if (c->ps_trace) (void)hipFree(c->ps_trace);
     if (c->ps_sync_host) (void)hipHostFree(c->ps_sync_host);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -790,7 +799,7 @@ static int rmsd_exact(gr_rmsd_plan *p, gr_ctx *c, const GrSel &sel, uint32_t fir
     k_rmsd_finalize<1><<<dim3(nf), dim3(GR_WG), 0, c->stream>>>(c->acc_partials, nch, c->frames, c->frame_stride, first_slot, sel, c->boxes_dev, p->dev, c->state_dev);
     if (fit) {
         const uint32_t gx = (uint32_t)std::min<uint64_t>(((c->n >> 2) + GR_WG * 4 - 1) / (GR_WG * 4) + 1, 1024);
-        k_fit<<<dim3(gx, nf), dim3(GR_WG), 0, c->stream>>>(c->frames, c->frame_stride, first_slot, (uint32_t)c->n, c->boxes_dev, p->dev, c->state_dev);
+        k_fit<false><<<dim3(gx, nf), dim3(GR_WG), 0, c->stream>>>(c->frames, c->frame_stride, first_slot, (uint32_t)c->n, c->boxes_dev, p->dev, c->state_dev, c->masses, sel, nullptr);
     }
     HIPCHK(c, hipGetLastError());
     return GR_OK;
@@ -844,6 +853,13 @@ static int segment_begin(gr_rmsd_plan *p, uint32_t s0, uint32_t nb, int fit) {
         a.frames = c->frames; a.frame_stride = c->frame_stride; a.first_slot = s0; a.n_frames = nb; a.n_atoms = (uint32_t)c->n;
         a.masses = c->masses; a.sel = sel; a.boxes = c->boxes_dev; a.plan = p->dev; a.state = c->state_dev;
         a.partials = c->ps_partials; a.sync = c->ps_sync; a.tiles_per_wg = ps_T; a.depth = ps_D;
+        a.trace = nullptr;
+        if (!c->ps_trace_path.empty()) {
+            const size_t tb = (size_t)GR_MAX_BATCH * c->n_cus * GR_PS_TRACE_N * sizeof(unsigned long long);
+            if (!c->ps_trace) HIPCHK(c, hipMalloc(&c->ps_trace, tb));
+            HIPCHK(c, hipMemsetAsync(c->ps_trace, 0, tb, c->stream));
+            a.trace = c->ps_trace;
+        }
         const size_t lds = gr_persist_lds_bytes(ps_T, ps_D);
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rmsd_fit_persist), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         if (c->profile) HIPCHK(c, hipEventRecord(c->pev[0], c->stream));
@@ -858,15 +874,30 @@ static int segment_begin(gr_rmsd_plan *p, uint32_t s0, uint32_t nb, int fit) {
         const uint32_t sb = c->sub_batch;
         uint32_t ng = 0;
         const bool two = fit && c->overlap && nb > sb;
+        // RMSD-fit of a contiguous selection: the sums pass only steers R and the centre, the fit pass evaluates
+        // sum w |R q - p|^2 on the way (k_fit<true>) and k_rmsd_close turns it into the rmsd
+        const bool lite = fit && sel.contiguous && c->two_pass;
+        if (lite) {
+            size_t need = 0;
+            for (uint32_t f0 = 0; f0 < nb; f0 += sb) need = std::max(need, (size_t)nb * fit_grid(c, std::min<uint32_t>(sb, nb - f0)));
+            if (need > c->fit_partials_cap) {
+                if (c->fit_partials) (void)hipFree(c->fit_partials);
+                c->fit_partials = nullptr; c->fit_partials_cap = 0;
+                HIPCHK(c, hipMalloc(&c->fit_partials, need * sizeof(double)));
+                c->fit_partials_cap = need;
+            }
+        }
         for (uint32_t f0 = 0; f0 < nb; f0 += sb, ++ng) {
             const uint32_t nf = std::min<uint32_t>(sb, nb - f0);
             const uint32_t nch = batch_chunks(c, sel, nf);
             hipEvent_t *ev = c->pev + 4 * ng;
             GrAccPartial *parts = c->acc_partials + (size_t)f0 * GR_MAX_CHUNKS;
             if (c->profile) HIPCHK(c, hipEventRecord(ev[0], c->stream));
-            k_rmsd_accum<0><<<dim3(nch, nf), dim3(GR_WG), 0, c->stream>>>(c->frames, c->frame_stride, s0 + f0, c->masses, sel, c->boxes_dev, p->dev, c->state_dev + f0, parts);
+            if (lite) k_rmsd_accum<0, true><<<dim3(nch, nf), dim3(GR_WG), 0, c->stream>>>(c->frames, c->frame_stride, s0 + f0, c->masses, sel, c->boxes_dev, p->dev, c->state_dev + f0, parts);
+            else k_rmsd_accum<0><<<dim3(nch, nf), dim3(GR_WG), 0, c->stream>>>(c->frames, c->frame_stride, s0 + f0, c->masses, sel, c->boxes_dev, p->dev, c->state_dev + f0, parts);
             if (c->profile) HIPCHK(c, hipEventRecord(ev[1], c->stream));
-            k_rmsd_finalize<0><<<dim3(nf), dim3(GR_WG), 0, c->stream>>>(parts, nch, c->frames, c->frame_stride, s0 + f0, sel, c->boxes_dev, p->dev, c->state_dev + f0);
+            if (lite) k_rmsd_finalize<0, true><<<dim3(nf), dim3(GR_WG), 0, c->stream>>>(parts, nch, c->frames, c->frame_stride, s0 + f0, sel, c->boxes_dev, p->dev, c->state_dev + f0);
+            else k_rmsd_finalize<0><<<dim3(nf), dim3(GR_WG), 0, c->stream>>>(parts, nch, c->frames, c->frame_stride, s0 + f0, sel, c->boxes_dev, p->dev, c->state_dev + f0);
             if (c->profile && !two) HIPCHK(c, hipEventRecord(ev[2], c->stream));
             if (fit) {
                 hipStream_t fs = c->stream;
@@ -877,8 +908,15 @@ static int segment_begin(gr_rmsd_plan *p, uint32_t s0, uint32_t nb, int fit) {
                     if (c->profile) HIPCHK(c, hipEventRecord(ev[2], fs));
                 }
                 const uint32_t gx = fit_grid(c, nf);
-                k_fit<<<dim3(gx, nf), dim3(GR_WG), 0, fs>>>(c->frames, c->frame_stride, s0 + f0, (uint32_t)c->n, c->boxes_dev, p->dev, c->state_dev + f0);
-                if (c->profile) HIPCHK(c, hipEventRecord(ev[3], fs));
+                if (lite) {
+                    double *fp = c->fit_partials + (size_t)f0 * gx;
+                    k_fit<true><<<dim3(gx, nf), dim3(GR_WG), 0, fs>>>(c->frames, c->frame_stride, s0 + f0, (uint32_t)c->n, c->boxes_dev, p->dev, c->state_dev + f0, c->masses, sel, fp);
+                    if (c->profile) HIPCHK(c, hipEventRecord(ev[3], fs));
+                    k_rmsd_close<<<dim3(nf), dim3(64), 0, fs>>>(fp, gx, p->dev.sw, c->state_dev + f0);
+                } else {
+                    k_fit<false><<<dim3(gx, nf), dim3(GR_WG), 0, fs>>>(c->frames, c->frame_stride, s0 + f0, (uint32_t)c->n, c->boxes_dev, p->dev, c->state_dev + f0, c->masses, sel, nullptr);
+                    if (c->profile) HIPCHK(c, hipEventRecord(ev[3], fs));
+                }
             }
         }
         if (two) {   // join: the state fetch (and the caller) must see every fit finished
@@ -914,6 +952,15 @@ static int segment_end(gr_rmsd_plan *p, float *rmsd_out, int *status_out, float 
         const GrSel sel = make_sel(*g);
         HIPCHK(c, hipStreamSynchronize(c->stream));
         if (q.persist) {
+            if (c->ps_trace) {
+                const size_t cnt = (size_t)nb * c->n_cus * GR_PS_TRACE_N;
+                std::vector<unsigned long long> h(cnt);
+                HIPCHK(c, hipMemcpy(h.data(), c->ps_trace, cnt * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+                if (FILE *fp = fopen(c->ps_trace_path.c_str(), "wb")) {
+                    const unsigned long long hdr[4] = { nb, c->n_cus, GR_PS_TRACE_N, 0 };
+                    fwrite(hdr, sizeof(hdr), 1, fp); fwrite(h.data(), sizeof(unsigned long long), cnt, fp); fclose(fp);
+                }
+            }
             if (c->ps_sync_host[1] != 0) return fail(c, GR_E_HIP, "persistent RMSD-fit kernel timed out waiting for its workgroups (GPU shared with another process?); set GR_PERSIST=0");
             if (c->profile) {
                 float ms = 0.f;

@@ -23,6 +23,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "gr_math.h"
+#include "gr_rotation.h"
 
 #define GR_WG 256
 #define GR_NOIDX 0xFFFFFFFFu
@@ -86,6 +87,12 @@ __device__ __forceinline__ void gr_block_sum(double (&v)[K], double *lds /* [GR_
         }
     }
     __syncthreads();
+}
+
+__device__ __forceinline__ double gr_wave_sum(double x) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+    return x;   // lane 0 holds the total
 }
 
 __device__ __forceinline__ uint32_t gr_block_min_u32(uint32_t x, uint32_t *lds /* [GR_WG/64] */) {
@@ -360,9 +367,12 @@ struct GrFrameConst {   // wave-uniform per-frame constants
 // tests.  Interior groups skip them: a NaN position or mass then simply poisons the fp64 sums, which the finalize step
 // detects and answers by sending the frame to the multi-pass path, whose kernels report the first atom without
 // position / mass in the reference's order.
-template <int MODE>
+// LITE (RMSD-fit of a contiguous selection): the fit pass evaluates sum w |R q - p|^2 directly once R is known
+// (k_fit<true>), exactly the reference's own final loop (rmsd.rs:592-599), so this pass only needs what steers the
+// rotation and the centre -- sum m, sum m v, A -- and all of it tolerates 4-atom f32 partials: no per-atom fp64 at all.
+template <int MODE, bool LITE = false>
 __device__ __forceinline__ void gr_flush4(GrLaneAcc &L, const GrA4 &a, const bool checked, const GrBox &box, const GrFrameConst &fc) {
-    float part[9];
+    float part[9], pm[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
 #pragma unroll
     for (int k = 0; k < 9; ++k) part[k] = 0.0f;
 #pragma unroll
@@ -405,6 +415,10 @@ __device__ __forceinline__ void gr_flush4(GrLaneAcc &L, const GrA4 &a, const boo
         part[0] = fmaf(px, vx, part[0]); part[1] = fmaf(px, vy, part[1]); part[2] = fmaf(px, vz, part[2]);
         part[3] = fmaf(py, vx, part[3]); part[4] = fmaf(py, vy, part[4]); part[5] = fmaf(py, vz, part[5]);
         part[6] = fmaf(pz, vx, part[6]); part[7] = fmaf(pz, vy, part[7]); part[8] = fmaf(pz, vz, part[8]);
+        if (LITE) {
+            pm[0] += m; pm[1] = fmaf(m, vx, pm[1]); pm[2] = fmaf(m, vy, pm[2]); pm[3] = fmaf(m, vz, pm[3]);
+            continue;
+        }
         const double dvx = vx, dvy = vy, dvz = vz, dm = m, dw = a.w[q];
         const double wpx = dw * (double)px, wpy = dw * (double)py, wpz = dw * (double)pz;
         double *acc = L.acc;
@@ -418,6 +432,10 @@ __device__ __forceinline__ void gr_flush4(GrLaneAcc &L, const GrA4 &a, const boo
     }
 #pragma unroll
     for (int k = 0; k < 9; ++k) L.acc[4 + k] += (double)part[k];
+    if (LITE) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) L.acc[k] += (double)pm[k];
+    }
 }
 
 // unpack the three float4 of positions / reference coordinates + masses / weights of one lane into four atoms
@@ -436,7 +454,7 @@ __device__ __forceinline__ void gr_unpack4(GrA4 &q, const float4 &a, const float
 #ifndef GR_ACC_MIN_WAVES
 #define GR_ACC_MIN_WAVES 1
 #endif
-template <int MODE>
+template <int MODE, bool LITE = false>
 __global__ __launch_bounds__(GR_WG, GR_ACC_MIN_WAVES) void k_rmsd_accum(
     const float *__restrict__ frames, size_t frame_stride, uint32_t first_slot,
     const float *__restrict__ masses, GrSel sel, const GrBox *__restrict__ boxes,
@@ -479,11 +497,11 @@ __global__ __launch_bounds__(GR_WG, GR_ACC_MIN_WAVES) void k_rmsd_accum(
             const size_t pg = (size_t)(g - g0);
             const float4 pa = p4[3 * pg], pb = p4[3 * pg + 1], pc = p4[3 * pg + 2];
             const float4 mm = m4[g];
-            const float4 ww = wm ? mm : w4[pg];
+            const float4 ww = (wm || LITE) ? mm : w4[pg];
             const uint32_t i = g << 2;
             GrA4 q;
             gr_unpack4(q, a, b, c, pa, pb, pc, mm, ww, i, first, last);
-            if (MODE == 0 && i >= first && i + 3 < last) gr_flush4<MODE>(L, q, false, box, fc); else gr_flush4<MODE>(L, q, true, box, fc);
+            if (MODE == 0 && i >= first && i + 3 < last) gr_flush4<MODE, LITE>(L, q, false, box, fc); else gr_flush4<MODE, LITE>(L, q, true, box, fc);
         }
     } else {
         const uint32_t n4 = (sel.n + 3u) >> 2;
@@ -503,8 +521,24 @@ __global__ __launch_bounds__(GR_WG, GR_ACC_MIN_WAVES) void k_rmsd_accum(
             if (MODE == 0 && j4 * 4 + 3 < sel.n) gr_flush4<MODE>(L, t, false, box, fc); else gr_flush4<MODE>(L, t, true, box, fc);
         }
     }
-    L.close(wm);
-    gr_block_sum<GR_ACC_K>(L.acc, lds);
+    L.close(wm && !LITE);
+    if (LITE) {
+        // only sum m, sum m v, A and the six moments are live: reduce those 19, the rest of the record is zero
+        double c19[19];
+#pragma unroll
+        for (int k = 0; k < 13; ++k) c19[k] = L.acc[k];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) c19[13 + k] = L.acc[26 + k];
+        gr_block_sum<19>(c19, lds);
+#pragma unroll
+        for (int k = 0; k < GR_ACC_K; ++k) L.acc[k] = 0.0;
+#pragma unroll
+        for (int k = 0; k < 13; ++k) L.acc[k] = c19[k];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) L.acc[26 + k] = c19[13 + k];
+    } else {
+        gr_block_sum<GR_ACC_K>(L.acc, lds);
+    }
     const uint32_t bad_pos = gr_block_min_u32(L.bad_pos, ldsu);
     const uint32_t bad_mass = gr_block_min_u32(L.bad_mass, ldsu);
     float rmn[3], rmx[3], rfmn[3], rfmx[3];
@@ -521,67 +555,7 @@ __global__ __launch_bounds__(GR_WG, GR_ACC_MIN_WAVES) void k_rmsd_accum(
     }
 }
 
-// ---- 3x3 helpers (double) for the finalize kernel
-__device__ inline void gr_jacobi_eig3(double A[3][3], double V[3][3]) {
-    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) V[i][j] = (i == j) ? 1.0 : 0.0;
-    for (int sweep = 0; sweep < 32; ++sweep) {
-        const double off = A[0][1] * A[0][1] + A[0][2] * A[0][2] + A[1][2] * A[1][2];
-        const double dg = A[0][0] * A[0][0] + A[1][1] * A[1][1] + A[2][2] * A[2][2];
-        if (off <= 1e-60 || off <= 1e-32 * dg) break;
-        for (int p = 0; p < 2; ++p)
-            for (int q = p + 1; q < 3; ++q) {
-                if (A[p][q] == 0.0) continue;
-                const double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
-                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-                const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
-                for (int k = 0; k < 3; ++k) { const double akp = A[k][p], akq = A[k][q]; A[k][p] = c * akp - s * akq; A[k][q] = s * akp + c * akq; }
-                for (int k = 0; k < 3; ++k) { const double apk = A[p][k], aqk = A[q][k]; A[p][k] = c * apk - s * aqk; A[q][k] = s * apk + c * aqk; }
-                for (int k = 0; k < 3; ++k) { const double vkp = V[k][p], vkq = V[k][q]; V[k][p] = c * vkp - s * vkq; V[k][q] = s * vkp + c * vkq; }
-            }
-    }
-}
-
-// R = U diag(1,1,sign det(U V^T)) V^T of H = U S V^T (rmsd.rs:573-583), from the eigenvectors of H^T H:
-// u_k = H v_k / |H v_k| (k = 1,2), u_3' = u_1 x u_2, R = u_1 v_1^T + u_2 v_2^T + det(V) u_3' v_3^T.
-__device__ inline void gr_kabsch_rotation(const double H[3][3], double R[3][3]) {
-    double HtH[3][3], V[3][3];
-    for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) HtH[i][j] = H[0][i] * H[0][j] + H[1][i] * H[1][j] + H[2][i] * H[2][j];
-    gr_jacobi_eig3(HtH, V);
-    const double w[3] = { HtH[0][0], HtH[1][1], HtH[2][2] };
-    int o0 = 0, o1 = 1, o2 = 2;
-    if (w[o1] > w[o0]) { int t = o0; o0 = o1; o1 = t; }
-    if (w[o2] > w[o0]) { int t = o0; o0 = o2; o2 = t; }
-    if (w[o2] > w[o1]) { int t = o1; o1 = o2; o2 = t; }
-    double v[3][3];
-    for (int i = 0; i < 3; ++i) { v[0][i] = V[i][o0]; v[1][i] = V[i][o1]; v[2][i] = V[i][o2]; }
-    double u[3][3];
-    for (int k = 0; k < 2; ++k)
-        for (int i = 0; i < 3; ++i) u[k][i] = H[i][0] * v[k][0] + H[i][1] * v[k][1] + H[i][2] * v[k][2];
-    double n0 = sqrt(u[0][0] * u[0][0] + u[0][1] * u[0][1] + u[0][2] * u[0][2]);
-    if (!(n0 >= 1e-300)) { for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) R[i][j] = (i == j) ? 1.0 : 0.0; return; }
-    for (int i = 0; i < 3; ++i) u[0][i] /= n0;
-    const double d01 = u[1][0] * u[0][0] + u[1][1] * u[0][1] + u[1][2] * u[0][2];
-    for (int i = 0; i < 3; ++i) u[1][i] -= d01 * u[0][i];
-    double n1 = sqrt(u[1][0] * u[1][0] + u[1][1] * u[1][1] + u[1][2] * u[1][2]);
-    if (n1 < 1e-12 * n0) {
-        const double a0 = fabs(u[0][0]), a1 = fabs(u[0][1]), a2 = fabs(u[0][2]);
-        const int m = a0 < a1 ? (a0 < a2 ? 0 : 2) : (a1 < a2 ? 1 : 2);
-        double e[3] = { 0, 0, 0 }; e[m] = 1.0;
-        const double d = e[0] * u[0][0] + e[1] * u[0][1] + e[2] * u[0][2];
-        for (int i = 0; i < 3; ++i) u[1][i] = e[i] - d * u[0][i];
-        n1 = sqrt(u[1][0] * u[1][0] + u[1][1] * u[1][1] + u[1][2] * u[1][2]);
-    }
-    for (int i = 0; i < 3; ++i) u[1][i] /= n1;
-    u[2][0] = u[0][1] * u[1][2] - u[0][2] * u[1][1];
-    u[2][1] = u[0][2] * u[1][0] - u[0][0] * u[1][2];
-    u[2][2] = u[0][0] * u[1][1] - u[0][1] * u[1][0];
-    const double detV = v[0][0] * (v[1][1] * v[2][2] - v[1][2] * v[2][1]) - v[0][1] * (v[1][0] * v[2][2] - v[1][2] * v[2][0]) +
-                        v[0][2] * (v[1][0] * v[2][1] - v[1][1] * v[2][0]);
-    const double sg = detV < 0 ? -1.0 : 1.0;
-    for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) R[i][j] = u[0][i] * v[0][j] + u[1][i] * v[1][j] + sg * u[2][i] * v[2][j];
-}
+// 3x3 rotation helpers (Jacobi eigen-solver, Kabsch rotation, Newton polar iteration): gr_rotation.h
 
 // One workgroup per frame: sum the partial records, then lane 0 closes the algebra:
 //   cv = sum(m v)/sum(m)                     (COM relative to the provisional centre; MODE 1: v is already q)
@@ -592,7 +566,7 @@ __device__ inline void gr_kabsch_rotation(const double H[3][3], double R[3][3]) 
 // (wherever in its rigorously bounded region it is) and the COM; otherwise the frame is flagged GR_ST_FALLBACK
 // and redone by the multi-pass path.
 // Closing algebra of the single pass for one frame (one lane).  `st` receives centre / com / shift / R / rmsd / status.
-template <int MODE>
+template <int MODE, bool LITE = false>
 __device__ inline void gr_finalize_math(const double *acc, const float mn[3], const float mx[3], const float fmn[3], const float fmx[3],
                                         uint32_t bad_pos, uint32_t bad_mass, const GrBox &b, const GrPlanDev &plan,
                                         const double g[3], uint32_t n_sel, GrFrameState &st) {
@@ -614,7 +588,7 @@ __device__ inline void gr_finalize_math(const double *acc, const float mn[3], co
         // of the f_i.  With mu = mean f, theta_i = 2 pi (f_i - mu) (sum theta_i = 0), |theta_i| <= Theta = 2 pi E
         // (E = fractional extent, must be < 1/2), T = sum theta_i^2:
         //   |sum sin theta_i| = |sum (sin theta_i - theta_i)| <= Theta T / 6,   sum cos theta_i >= n - T / 2
-        //   => |c'_a - mu_a| <= atan((Theta T / 6) / (n - T / 2)) / (2 pi) =: eps_a          (rigorous, no sin/cos)
+        //   => |c'_a - mu_a| <= atan((Theta T / 6) / (n - T / 2)) / (2 pi) <= (Theta T / 6) / (n - T / 2) / (2 pi) =: eps_a
         // so c' = mu + e with |e| <= sum_a eps_a |box_a|.
         const double TWO_PI = 6.283185307179586;
         const double nsel = (double)n_sel;
@@ -629,7 +603,7 @@ __device__ inline void gr_finalize_math(const double *acc, const float mn[3], co
             const double Theta = TWO_PI * E * (1.0 + 1e-6);
             const double den = nsel - 0.5 * T;
             if (!(E < 0.4999) || !(den > 0.0)) { ok = false; eps[a] = 0; continue; }
-            eps[a] = atan((Theta * T / 6.0) / den) / TWO_PI;
+            eps[a] = (Theta * T / 6.0) / den / TWO_PI;        // atan(x) <= x for x >= 0: a (slightly) larger, still rigorous radius
         }
         // centre candidate in Cartesian coordinates and the radius of the region c' is confined to
         const double ce[3] = { mu[0] * b.ax + mu[1] * b.bx + mu[2] * b.cx, mu[1] * b.by + mu[2] * b.cy, mu[2] * b.cz };
@@ -669,16 +643,18 @@ __device__ inline void gr_finalize_math(const double *acc, const float mn[3], co
     const double swqq = acc[22] - 2.0 * (cv[0] * acc[23] + cv[1] * acc[24] + cv[2] * acc[25]) +
                         plan.sw * (cv[0] * cv[0] + cv[1] * cv[1] + cv[2] * cv[2]);
     double R[3][3];
-    gr_kabsch_rotation(H, R);
-    double tr = 0;
-    for (int a = 0; a < 3; ++a) for (int c = 0; c < 3; ++c) tr += R[a][c] * Hw[a][c];
-    double r2 = (plan.swpp + swqq - 2.0 * tr) / plan.sw;
-    if (r2 < 0.0) r2 = 0.0;
-    st.rmsd = (float)sqrt(r2);
+    gr_best_rotation(H, R);
+    if (!LITE) {
+        double tr = 0;
+        for (int a = 0; a < 3; ++a) for (int c = 0; c < 3; ++c) tr += R[a][c] * Hw[a][c];
+        double r2 = (plan.swpp + swqq - 2.0 * tr) / plan.sw;
+        if (r2 < 0.0) r2 = 0.0;
+        st.rmsd = (float)sqrt(r2);
+    }   // LITE: the fit pass sums w |R q - p|^2 and k_rmsd_close writes the rmsd
     for (int a = 0; a < 3; ++a) for (int c = 0; c < 3; ++c) st.R[3 * c + a] = (float)R[a][c];   // column-major
 }
 
-template <int MODE>
+template <int MODE, bool LITE = false>
 __global__ __launch_bounds__(GR_WG) void k_rmsd_finalize(
     const GrAccPartial *__restrict__ partials, uint32_t nchunks,
     const float *__restrict__ frames, size_t frame_stride, uint32_t first_slot, GrSel sel,
@@ -716,16 +692,24 @@ __global__ __launch_bounds__(GR_WG) void k_rmsd_finalize(
     const float *xyz = frames + (size_t)(first_slot + frame) * frame_stride;
     const uint32_t i0 = sel.contiguous ? sel.start : sel.idx[0];
     const double g[3] = { xyz[3 * (size_t)i0], xyz[3 * (size_t)i0 + 1], xyz[3 * (size_t)i0 + 2] };
-    gr_finalize_math<MODE>(acc, mn, mx, fmn, fmx, bad_pos, bad_mass, boxes[first_slot + frame], plan, g, sel.n, st);
+    gr_finalize_math<MODE, LITE>(acc, mn, mx, fmn, fmx, bad_pos, bad_mass, boxes[first_slot + frame], plan, g, sel.n, st);
 }
 
 // ------------------------------------------------------------------------------------------ fit (all atoms)
 // fit_structure (rmsd.rs:508-528, atom.rs:498-528,894-903), one streaming read-modify-write pass:
 //   z = R (wrap(x + shift) - box_centre) + reference_group_com
+// RMSD = true (contiguous selection) also evaluates the reference's final loop while the atoms are in registers:
+//   sum_i w_i |R q_i - p_i|^2   (rmsd.rs:592-599; |R^T p - q| = |p - R q|), q_i = wrap(x_i + shift) - box_centre
+// as 4-atom f32 partials -> fp64 per lane -> one fp64 partial per workgroup in fit_partials[frame][blockIdx.x];
+// k_rmsd_close sums them in a fixed order.  d = R q - p is a difference of O(nm) numbers with ~1e-7 relative rounding,
+// so a rigid copy of the reference gives rmsd ~ 1e-6 nm instead of the cancellation-limited closed form.
+template <bool RMSD>
 __global__ __launch_bounds__(GR_WG) void k_fit(
     float *__restrict__ frames, size_t frame_stride, uint32_t first_slot, uint32_t n_atoms,
-    const GrBox *__restrict__ boxes, GrPlanDev plan, const GrFrameState *__restrict__ state) {
+    const GrBox *__restrict__ boxes, GrPlanDev plan, const GrFrameState *__restrict__ state,
+    const float *__restrict__ masses, GrSel sel, double *__restrict__ fit_partials) {
     __shared__ GrBox box;
+    __shared__ double lds[GR_WG / 64];
     const uint32_t frame = blockIdx.y;
     const GrFrameState &st = state[frame];
     if (st.status != 0) return;   // analysis failed -> frame left unmodified (rmsd.rs:91)
@@ -734,26 +718,76 @@ __global__ __launch_bounds__(GR_WG) void k_fit(
     const float sx = st.shift[0], sy = st.shift[1], sz = st.shift[2];
     const float r00 = st.R[0], r10 = st.R[1], r20 = st.R[2], r01 = st.R[3], r11 = st.R[4], r21 = st.R[5], r02 = st.R[6], r12 = st.R[7], r22 = st.R[8];
     const float cx = plan.ref_com[0], cy = plan.ref_com[1], cz = plan.ref_com[2];
-    auto tf = [&](float &x, float &y, float &z) {
+    // x,y,z <- R q (q = wrap(x + shift) - box centre); the caller adds the reference COM
+    auto rot = [&](float &x, float &y, float &z) {
         x += sx; y += sy; z += sz;
         gr_wrap(x, y, z, box);
         x -= box.bcx; y -= box.bcy; z -= box.bcz;
         const float nx = r00 * x + r01 * y + r02 * z;
         const float ny = r10 * x + r11 * y + r12 * z;
         const float nz = r20 * x + r21 * y + r22 * z;
-        x = nx + cx; y = ny + cy; z = nz + cz;
+        x = nx; y = ny; z = nz;
     };
     __shared__ float4 tiles[(GR_WG / 64) * GR_TILE_F4];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float4 *tile = tiles + wave * GR_TILE_F4;
     float4 *f4 = reinterpret_cast<float4 *>(xyz);
+    const float4 *p4 = reinterpret_cast<const float4 *>(plan.p);
+    const float4 *w4 = plan.w_is_mass ? reinterpret_cast<const float4 *>(masses) : reinterpret_cast<const float4 *>(plan.w);
+    const uint32_t first = sel.start, last = sel.start + sel.n, g0 = sel.g0 << 6;
+    const uint32_t wofs = plan.w_is_mass ? 0u : g0;        // masses are indexed by atom group, plan.w by selection group
+    double rs = 0.0;
     const uint32_t ntiles = (n_atoms + 255u) >> 8;   // the slot is padded to whole tiles; pad atoms are transformed too (harmless)
     for (uint32_t t = blockIdx.x * (GR_WG / 64) + wave; t < ntiles; t += gridDim.x * (GR_WG / 64)) {
         float4 a, b, c;
         gr_tile_load(f4 + (size_t)t * GR_TILE_F4, tile, lane, a, b, c);
-        tf(a.x, a.y, a.z); tf(a.w, b.x, b.y); tf(b.z, b.w, c.x); tf(c.y, c.z, c.w);
+        rot(a.x, a.y, a.z); rot(a.w, b.x, b.y); rot(b.z, b.w, c.x); rot(c.y, c.z, c.w);
+        if (RMSD) {
+            const uint32_t g = (t << 6) + lane, i = g << 2;
+            if (i + 3 >= first && i < last) {
+                const size_t pg = (size_t)(g - g0);
+                const float4 pa = p4[3 * pg], pb = p4[3 * pg + 1], pc = p4[3 * pg + 2];
+                const float4 ww = w4[g - wofs];
+                auto d2 = [](float x, float y, float z, float px, float py, float pz) { const float dx = x - px, dy = y - py, dz = z - pz; return fmaf(dx, dx, fmaf(dy, dy, dz * dz)); };
+                float part = 0.0f;
+                if (i >= first && i + 3 < last) {
+                    part = ww.x * d2(a.x, a.y, a.z, pa.x, pa.y, pa.z);
+                    part = fmaf(ww.y, d2(a.w, b.x, b.y, pa.w, pb.x, pb.y), part);
+                    part = fmaf(ww.z, d2(b.z, b.w, c.x, pb.z, pb.w, pc.x), part);
+                    part = fmaf(ww.w, d2(c.y, c.z, c.w, pc.y, pc.z, pc.w), part);
+                } else {
+                    if (i >= first && i < last) part = ww.x * d2(a.x, a.y, a.z, pa.x, pa.y, pa.z);
+                    if (i + 1 >= first && i + 1 < last) part = fmaf(ww.y, d2(a.w, b.x, b.y, pa.w, pb.x, pb.y), part);
+                    if (i + 2 >= first && i + 2 < last) part = fmaf(ww.z, d2(b.z, b.w, c.x, pb.z, pb.w, pc.x), part);
+                    if (i + 3 >= first && i + 3 < last) part = fmaf(ww.w, d2(c.y, c.z, c.w, pc.y, pc.z, pc.w), part);
+                }
+                rs += (double)part;
+            }
+        }
+        a.x += cx; a.y += cy; a.z += cz; a.w += cx; b.x += cy; b.y += cz; b.z += cx; b.w += cy; c.x += cz; c.y += cx; c.z += cy; c.w += cz;
         gr_tile_store(f4 + (size_t)t * GR_TILE_F4, tile, lane, a, b, c);
     }
+    if (RMSD) {
+        rs = gr_wave_sum(rs);
+        if (lane == 0) lds[wave] = rs;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double tot = 0.0;
+#pragma unroll
+            for (int k = 0; k < GR_WG / 64; ++k) tot += lds[k];
+            fit_partials[(size_t)frame * gridDim.x + blockIdx.x] = tot;
+        }
+    }
+}
+
+// rmsd = sqrt(sum of the fit pass's workgroup partials / sum w)  (rmsd.rs:599); one wave per frame, fixed summation order
+__global__ __launch_bounds__(64) void k_rmsd_close(const double *__restrict__ fit_partials, uint32_t nparts, double sum_w, GrFrameState *__restrict__ state) {
+    const uint32_t frame = blockIdx.x;
+    if (state[frame].status != 0) return;
+    double s = 0.0;
+    for (uint32_t k = threadIdx.x; k < nparts; k += 64) s += fit_partials[(size_t)frame * nparts + k];
+    s = gr_wave_sum(s);
+    if (threadIdx.x == 0) state[frame].rmsd = (float)sqrt(fmax(s, 0.0) / sum_w);
 }
 
 // ------------------------------------------------------------------------------------------ plan extraction

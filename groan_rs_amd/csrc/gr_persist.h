@@ -41,7 +41,12 @@ struct GrPersistArgs {
     double *partials;          // [n_frames][n_wg][GR_PS_REC]
     uint32_t *sync;            // [0] present counter, [1] abort flag, [2 + f] arrivals of frame f, [2 + n_frames + f] ready flag of frame f
     uint32_t tiles_per_wg, depth;
+    unsigned long long *trace; // debugging (GR_PS_TRACE): [n_frames][n_wg][GR_PS_TRACE_N] s_memrealtime stamps, or nullptr
 };
+#define GR_PS_TRACE_N 10
+// stamp k of (frame f, workgroup w): 0 A start, 1 sums done, 2 arrived, 3 C wait start, 4 ready seen, 5 C done,
+// finalizer only: 6 records summed, 7 math done, 8 published
+#define GR_PS_STAMP(f, k) do { if (A.trace && lane == 0 && (wave == 0)) A.trace[((size_t)(f) * nwg + w) * GR_PS_TRACE_N + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 
 __device__ __forceinline__ uint32_t gr_ld_u32(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void gr_st_u32(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -132,6 +137,7 @@ __global__ __launch_bounds__(GR_PS_THREADS) void k_rmsd_fit_persist(const GrPers
         // ================================================================ A(k)
         if (k < F) {
             const uint32_t f = k, slot = f % D;
+            GR_PS_STAMP(f, 0);
             float4 *buf = ring + (size_t)slot * T * GR_TILE_F4;
             float *xyz = A.frames + (size_t)(A.first_slot + f) * A.frame_stride;
             const float4 *f4 = reinterpret_cast<const float4 *>(xyz);
@@ -161,6 +167,7 @@ __global__ __launch_bounds__(GR_PS_THREADS) void k_rmsd_fit_persist(const GrPers
                 }
             }
             L.close(wm);
+            GR_PS_STAMP(f, 1);
             if (L.bad_pos != GR_NOIDX || L.bad_mass != GR_NOIDX) L.acc[0] = __builtin_nan("");   // -> poisoned -> multi-pass path names the atom
             // ---- workgroup reduction: wave reduce-scatter -> LDS -> wave 0
             const double tot = gr_wave_reduce_scatter32(L.acc, lane);
@@ -189,6 +196,7 @@ __global__ __launch_bounds__(GR_PS_THREADS) void k_rmsd_fit_persist(const GrPers
                 uint32_t old = 0;
                 if (lane == 0) old = __hip_atomic_fetch_add(arrive + f, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 old = __builtin_amdgcn_readfirstlane(old);
+                GR_PS_STAMP(f, 2);
                 if (old == nwg - 1) {
                     // ---- I am the last to arrive: close frame f
                     double s[32];
@@ -204,6 +212,7 @@ __global__ __launch_bounds__(GR_PS_THREADS) void k_rmsd_fit_persist(const GrPers
 #pragma unroll
                         for (int q = 0; q < 12; ++q) e[q] = fmaxf(e[q], (float)gr_ld_f64(src + 32 + q));
                     }
+                    GR_PS_STAMP(f, 6);
                     const double ts = gr_wave_reduce_scatter32(s, lane);
                     const float te = gr_wave_max_scatter16(e, lane);
                     if ((lane & 1u) == 0) fin[lane >> 1] = ts;
@@ -219,11 +228,13 @@ __global__ __launch_bounds__(GR_PS_THREADS) void k_rmsd_fit_persist(const GrPers
                             const double g[3] = { fc.gx, fc.gy, fc.gz };
                             gr_finalize_math<0>(fin, mn, mx, fmn, fmx, GR_NOIDX, GR_NOIDX, A.boxes[A.first_slot + f], A.plan, g, A.sel.n, st);
                         }
+                        GR_PS_STAMP(f, 7);
                         uint32_t *dst = reinterpret_cast<uint32_t *>(A.state + f);
                         const uint32_t *srcw = reinterpret_cast<const uint32_t *>(&st);
                         for (uint32_t q = 0; q < sizeof(GrFrameState) / 4; ++q) gr_st_u32(dst + q, srcw[q]);
                         gr_drain_stores();
                         gr_st_u32(ready + f, 1u);
+                        GR_PS_STAMP(f, 8);
                     }
                 }
             }
@@ -231,9 +242,11 @@ __global__ __launch_bounds__(GR_PS_THREADS) void k_rmsd_fit_persist(const GrPers
         // ================================================================ C(k - D + 1)
         if (k + 1 >= D) {
             const uint32_t f = k + 1 - D, slot = f % D;
+            GR_PS_STAMP(f, 3);
             if (threadIdx.x == 0) flag_l[1] = gr_wait_ge(ready + f, 1u, abort_flag) ? 1 : 0;
             __syncthreads();
             const int okflag = flag_l[1];
+            GR_PS_STAMP(f, 4);
             if (okflag && threadIdx.x < sizeof(GrFrameState) / 4)
                 st_l[slot * 32 + threadIdx.x] = gr_ld_u32(reinterpret_cast<const uint32_t *>(A.state + f) + threadIdx.x);
             __syncthreads();
@@ -262,6 +275,7 @@ __global__ __launch_bounds__(GR_PS_THREADS) void k_rmsd_fit_persist(const GrPers
                     gr_tile_store(f4 + (size_t)t * GR_TILE_F4, tile, lane, a, b, c);
                 }
             }
+            GR_PS_STAMP(f, 5);
         }
     }
 }

@@ -298,7 +298,8 @@ def test_rmsd_trajectory_goldens(G, example, short_traj, exact):
     # RMSD-fit: against the oracle and against the reference's golden fitted trajectory
     tol_file = 0.5 / float(short_traj["precision"]) + 2e-4
     r2, st2 = plan.rmsd_fit(0, 11)
-    assert np.all(st2 == 0) and np.abs(r2 - r).max() == 0.0
+    # the fit batch evaluates the reference's final loop sum w|R q - p|^2 directly (rmsd.rs:592-599), rmsd() its closed form
+    assert np.all(st2 == 0) and np.abs(r2 - r).max() <= 1e-7 and np.abs(r2 - np.array(RMSD_EXPECTED, np.float32)).max() <= 5e-7
     for f in range(11):
         fitted = cur.get_positions(slot=f)
         _, want = O.calc_rmsd_and_fit(short_traj["gro_keep"], m, sel, example["box9"], short_traj["frames"][f], m, sel, short_traj["boxes9"][f])

@@ -121,6 +121,7 @@ def test_persistent_back_to_back_batches_and_begin_end(G):
     n, nf = 70_000, 9
     box = O.box_from_lengths_angles([8.0, 8.0, 8.0], [60.0, 60.0, 90.0])
     ref, cur, masses, ref_pos = blob(G, n, box, nf)
+    cur.set_persistent(True)
     plan = G.RMSDPlan(ref, cur, "all")
     first, _ = plan.rmsd_fit(0, nf)
     assert plan.last_persistent()
