@@ -89,6 +89,7 @@ struct gr_ctx {
     int persist = 0;                  // GR_PERSIST=1 / gr_ctx_set_persistent: persistent kernel for large fit batches
     uint32_t n_cus = 0;
     double *ps_partials = nullptr;    // [GR_MAX_BATCH][n_cus][GR_PS_REC]
+    double *ps_rmsd = nullptr;        // [GR_MAX_BATCH][n_cus * GR_PS_WAVES]
     uint32_t *ps_sync = nullptr;      // [2 + 2 * GR_MAX_BATCH]
     uint32_t *ps_sync_host = nullptr; // pinned [2]
     unsigned long long *ps_trace = nullptr;   // GR_PS_TRACE=<file>: time stamps of the last persistent launch, dumped to <file>
@@ -173,15 +174,18 @@ uint32_t batch_chunks(const gr_ctx *c, const GrSel &s, uint32_t nf) {
     return (uint32_t)ch;
 }
 
-// Can the persistent kernel take this batch?  Contiguous selection, at least one tile per workgroup, a ring of 3 (else 2)
-// frame slices per workgroup inside the 160 KiB of LDS.
+// Can the persistent kernel take this batch?  Contiguous selection, one tile per wave (<= 16 tiles per workgroup), a ring
+// of 3 (else 2) frame slices per workgroup inside the 160 KiB of LDS.  persist == 1 asks for it only where it pays (at
+// least 8 tiles per workgroup); persist == 2 takes it whenever it is possible (tests).
 bool persist_plan(const gr_ctx *c, const GrSel &s, uint32_t nf, uint32_t *T, uint32_t *D) {
-    if (!c->persist || !s.contiguous || c->n_cus == 0 || nf < 2) return false;
+    if (!c->persist || !s.contiguous || c->n_cus == 0 || (c->n_cus % 32u) != 0 || nf < 2) return false;
     const uint32_t ntiles = (uint32_t)((c->n + 255) >> 8);
     if (ntiles < c->n_cus) return false;                       // small systems: the batched three-kernel path
-    const uint32_t t = (ntiles + c->n_cus - 1) / c->n_cus;
+    const uint32_t ncomp = c->n_cus - 1;                        // one workgroup finalizes, the others stream
+    const uint32_t t = (ntiles + ncomp - 1) / ncomp;
+    if (t > GR_PS_WAVES || (c->persist == 1 && t < 8)) return false;
     for (uint32_t d = 3; d >= 2; --d)
-        if (gr_persist_lds_bytes(t, d) <= 160u * 1024u) { *T = t; *D = d; return true; }
+        if (GrPersistLds(t, d).total <= 160u * 1024u) { *T = t; *D = d; return true; }
     return false;
 }
 
@@ -360,7 +364,7 @@ gr_ctx *gr_ctx_create(int device, uint64_t n_atoms, uint32_t n_slots, int *statu
     for (int k = 0; k < GR_MAX_BATCH; ++k) ok = ok && hipEventCreateWithFlags(&c->ev_grp[k], hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) == hipSuccess;
     if (const char *e = getenv("GR_OVERLAP")) c->overlap = atoi(e) ? 1 : 0;
-    if (const char *e = getenv("GR_PERSIST")) c->persist = atoi(e) ? 1 : 0;
+    if (const char *e = getenv("GR_PERSIST")) { const int v = atoi(e); c->persist = v < 0 ? 0 : (v > 2 ? 2 : v); }
     if (const char *e = getenv("GR_TWO_PASS")) c->two_pass = atoi(e) ? 1 : 0;
     if (const char *e = getenv("GR_PS_TRACE")) c->ps_trace_path = e;
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cus = (uint32_t)prop.multiProcessorCount; }
@@ -419,6 +423,7 @@ void gr_ctx_destroy(gr_ctx *c) {
     if (c->bad_host) (void)hipHostFree(c->bad_host);
     if (c->pd_out) (void)hipFree(c->pd_out);
     if (c->ps_partials) (void)hipFree(c->ps_partials);
+    if (c->ps_rmsd) (void)hipFree(c->ps_rmsd);
     if (c->ps_sync) (void)hipFree(c->ps_sync);
     if (c->ps_trace) (void)hipFree(c->ps_trace);
     if (c->ps_sync_host) (void)hipHostFree(c->ps_sync_host);
@@ -788,7 +793,7 @@ gr_rmsd_plan *gr_rmsd_plan_create(gr_ctx *ref, uint32_t ref_slot, gr_ctx *target
 
 uint32_t gr_rmsd_plan_last_fallbacks(const gr_rmsd_plan *p) { return p ? p->last_fallbacks : 0; }
 int gr_rmsd_plan_force_exact(gr_rmsd_plan *p, int on) { if (!p) return GR_E_INVALID_ARG; p->exact = on ? 1 : 0; return GR_OK; }
-int gr_ctx_set_persistent(gr_ctx *c, int on) { if (!c) return GR_E_INVALID_ARG; c->persist = on ? 1 : 0; return GR_OK; }
+int gr_ctx_set_persistent(gr_ctx *c, int mode) { if (!c || mode < 0 || mode > 2) return GR_E_INVALID_ARG; c->persist = mode; return GR_OK; }
 int gr_rmsd_plan_last_persistent(const gr_rmsd_plan *p) { return p && p->last_persist ? 1 : 0; }
 
 // multi-pass exact path for `nf` frames starting at first_slot; states [0, nf) must be reset by the caller
@@ -848,11 +853,13 @@ static int segment_begin(gr_rmsd_plan *p, uint32_t s0, uint32_t nb, int fit) {
     } else if (fit && persist_plan(c, sel, nb, &ps_T, &ps_D)) {
         // persistent pipelined kernel: every frame is read from HBM once (its slices wait in LDS for the rotation)
         if (!c->ps_partials) HIPCHK(c, hipMalloc(&c->ps_partials, (size_t)GR_MAX_BATCH * c->n_cus * GR_PS_REC * sizeof(double)));
+        if (!c->ps_rmsd) HIPCHK(c, hipMalloc(&c->ps_rmsd, (size_t)GR_MAX_BATCH * c->n_cus * GR_PS_WAVES * sizeof(double)));
+        HIPCHK(c, hipMemsetAsync(c->ps_rmsd, 0, (size_t)nb * c->n_cus * GR_PS_WAVES * sizeof(double), c->stream));
         HIPCHK(c, hipMemsetAsync(c->ps_sync, 0, (2 + 2 * (size_t)nb) * sizeof(uint32_t), c->stream));
         GrPersistArgs a;
         a.frames = c->frames; a.frame_stride = c->frame_stride; a.first_slot = s0; a.n_frames = nb; a.n_atoms = (uint32_t)c->n;
         a.masses = c->masses; a.sel = sel; a.boxes = c->boxes_dev; a.plan = p->dev; a.state = c->state_dev;
-        a.partials = c->ps_partials; a.sync = c->ps_sync; a.tiles_per_wg = ps_T; a.depth = ps_D;
+        a.partials = c->ps_partials; a.rmsd_partials = c->ps_rmsd; a.sync = c->ps_sync; a.tiles_per_wg = ps_T; a.depth = ps_D;
         a.trace = nullptr;
         if (!c->ps_trace_path.empty()) {
             const size_t tb = (size_t)GR_MAX_BATCH * c->n_cus * GR_PS_TRACE_N * sizeof(unsigned long long);
@@ -860,12 +867,13 @@ static int segment_begin(gr_rmsd_plan *p, uint32_t s0, uint32_t nb, int fit) {
             HIPCHK(c, hipMemsetAsync(c->ps_trace, 0, tb, c->stream));
             a.trace = c->ps_trace;
         }
-        const size_t lds = gr_persist_lds_bytes(ps_T, ps_D);
+        const size_t lds = GrPersistLds(ps_T, ps_D).total;
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rmsd_fit_persist), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         if (c->profile) HIPCHK(c, hipEventRecord(c->pev[0], c->stream));
         k_rmsd_fit_persist<<<dim3(c->n_cus), dim3(GR_PS_THREADS), lds, c->stream>>>(a);
         if (c->profile) HIPCHK(c, hipEventRecord(c->pev[1], c->stream));
         HIPCHK(c, hipGetLastError());
+        k_rmsd_close<<<dim3(nb), dim3(64), 0, c->stream>>>(c->ps_rmsd, c->n_cus * GR_PS_WAVES, p->dev.sw, c->state_dev);
         HIPCHK(c, hipMemcpyAsync(c->ps_sync_host, c->ps_sync, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
         q.persist = true; p->last_persist = true;
     } else {

@@ -108,11 +108,11 @@ __device__ __forceinline__ uint32_t gr_block_min_u32(uint32_t x, uint32_t *lds /
 
 __device__ __forceinline__ float gr_block_min_f32(float x, float *lds) {
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) x = fminf(x, __shfl_down(x, off, 64));
+    for (int off = 32; off > 0; off >>= 1) x = gr_fminf(x, __shfl_down(x, off, 64));
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (lane == 0) lds[wave] = x;
     __syncthreads();
-    if (threadIdx.x == 0) for (int wv = 1; wv < GR_WG / 64; ++wv) x = fminf(x, lds[wv]);
+    if (threadIdx.x == 0) for (int wv = 1; wv < GR_WG / 64; ++wv) x = gr_fminf(x, lds[wv]);
     __syncthreads();
     return x;
 }
@@ -357,6 +357,28 @@ struct GrFrameConst {   // wave-uniform per-frame constants
     bool tric, wm;
 };
 
+// v = the image of (x - g) nearest to the provisional centre g, and its fractional coordinates (single pass, MODE 0)
+// (`box` supplies the cell, `cand_box` the minimum-image table: the same object, except where the caller keeps the
+// cell in registers and leaves the rarely needed table in memory)
+__device__ __forceinline__ void gr_image_about(float &vx, float &vy, float &vz, float &f_a, float &f_b, float &f_c,
+                                               float x, float y, float z, const GrBox &box, const GrBox &cand_box, const GrFrameConst &fc) {
+    // closed-form brick reduction along c, b, a ...
+    vx = x - fc.gx; vy = y - fc.gy; vz = z - fc.gz;
+    const float kc = rintf(vz * fc.icz);
+    vx = fmaf(-kc, box.cx, vx); vy = fmaf(-kc, box.cy, vy); vz = fmaf(-kc, box.cz, vz);
+    const float kb = rintf(vy * fc.iby);
+    vx = fmaf(-kb, box.bx, vx); vy = fmaf(-kb, box.by, vy);
+    const float ka = rintf(vx * fc.iax);
+    vx = fmaf(-ka, box.ax, vx);
+    // ... which is already THE minimum image whenever |v| < r_ws; otherwise search the table
+    if (fc.tric && vx * vx + vy * vy + vz * vz >= fc.rws2) gr_tric_refine(vx, vy, vz, cand_box);
+    // fractional coordinates of v: first and second moments feed the image proof (see gr_finalize_math)
+    f_c = vz * fc.icz;
+    const float uy = fmaf(-f_c, box.cy, vy);
+    f_b = uy * fc.iby;
+    f_a = (vx - f_b * box.bx - f_c * box.cx) * fc.iax;
+}
+
 // Precision plan.  rmsd^2 is the small difference of sums of size W r^2 (it must come out ~0 for a frame that is a
 // rigid copy of the reference: the reference's own tests ask |rmsd| <= 1e-4 there, i.e. 1e-9 relative on those sums),
 // so everything that enters it -- B = sum (w p) v^T, sum w|v|^2, sum w v, sum m, sum m v -- uses exact products
@@ -385,32 +407,19 @@ __device__ __forceinline__ void gr_flush4(GrLaneAcc &L, const GrA4 &a, const boo
         }
         float vx, vy, vz;
         if (MODE == 0) {
-            // image of x nearest to g: closed-form brick reduction along c, b, a ...
-            vx = a.x[q] - fc.gx; vy = a.y[q] - fc.gy; vz = a.z[q] - fc.gz;
-            const float kc = rintf(vz * fc.icz);
-            vx = fmaf(-kc, box.cx, vx); vy = fmaf(-kc, box.cy, vy); vz = fmaf(-kc, box.cz, vz);
-            const float kb = rintf(vy * fc.iby);
-            vx = fmaf(-kb, box.bx, vx); vy = fmaf(-kb, box.by, vy);
-            const float ka = rintf(vx * fc.iax);
-            vx = fmaf(-ka, box.ax, vx);
-            // ... which is already THE minimum image whenever |v| < r_ws; otherwise search the table
-            if (fc.tric && vx * vx + vy * vy + vz * vz >= fc.rws2) gr_tric_refine(vx, vy, vz, box);
-            // fractional coordinates of v: first and second moments (image proof, see gr_finalize_math)
-            const float f_c = vz * fc.icz;
-            const float uy = fmaf(-f_c, box.cy, vy);
-            const float f_b = uy * fc.iby;
-            const float f_a = (vx - f_b * box.bx - f_c * box.cx) * fc.iax;
+            float f_a, f_b, f_c;
+            gr_image_about(vx, vy, vz, f_a, f_b, f_c, a.x[q], a.y[q], a.z[q], box, box, fc);
             L.fsum[0] += f_a; L.fsum[1] += f_b; L.fsum[2] += f_c;
             L.fsum[3] = fmaf(f_a, f_a, L.fsum[3]); L.fsum[4] = fmaf(f_b, f_b, L.fsum[4]); L.fsum[5] = fmaf(f_c, f_c, L.fsum[5]);
-            L.fmn[0] = fminf(L.fmn[0], f_a); L.fmn[1] = fminf(L.fmn[1], f_b); L.fmn[2] = fminf(L.fmn[2], f_c);
-            L.fmx[0] = fmaxf(L.fmx[0], f_a); L.fmx[1] = fmaxf(L.fmx[1], f_b); L.fmx[2] = fmaxf(L.fmx[2], f_c);
+            L.fmn[0] = gr_fminf(L.fmn[0], f_a); L.fmn[1] = gr_fminf(L.fmn[1], f_b); L.fmn[2] = gr_fminf(L.fmn[2], f_c);
+            L.fmx[0] = gr_fmaxf(L.fmx[0], f_a); L.fmx[1] = gr_fmaxf(L.fmx[1], f_b); L.fmx[2] = gr_fmaxf(L.fmx[2], f_c);
         } else {
             vx = a.x[q] + fc.sx; vy = a.y[q] + fc.sy; vz = a.z[q] + fc.sz;
             gr_wrap(vx, vy, vz, box);
             vx -= box.bcx; vy -= box.bcy; vz -= box.bcz;
         }
-        L.mn[0] = fminf(L.mn[0], vx); L.mn[1] = fminf(L.mn[1], vy); L.mn[2] = fminf(L.mn[2], vz);
-        L.mx[0] = fmaxf(L.mx[0], vx); L.mx[1] = fmaxf(L.mx[1], vy); L.mx[2] = fmaxf(L.mx[2], vz);
+        L.mn[0] = gr_fminf(L.mn[0], vx); L.mn[1] = gr_fminf(L.mn[1], vy); L.mn[2] = gr_fminf(L.mn[2], vz);
+        L.mx[0] = gr_fmaxf(L.mx[0], vx); L.mx[1] = gr_fmaxf(L.mx[1], vy); L.mx[2] = gr_fmaxf(L.mx[2], vz);
         const float px = a.px[q], py = a.py[q], pz = a.pz[q];
         part[0] = fmaf(px, vx, part[0]); part[1] = fmaf(px, vy, part[1]); part[2] = fmaf(px, vz, part[2]);
         part[3] = fmaf(py, vx, part[3]); part[4] = fmaf(py, vy, part[4]); part[5] = fmaf(py, vz, part[5]);
@@ -492,6 +501,8 @@ __global__ __launch_bounds__(GR_WG, GR_ACC_MIN_WAVES) void k_rmsd_accum(
         const float4 *p4 = reinterpret_cast<const float4 *>(plan.p);
         const float4 *m4 = reinterpret_cast<const float4 *>(masses);
         const float4 *w4 = reinterpret_cast<const float4 *>(plan.w);
+        // (requesting the NEXT trip's positions before this trip's arithmetic was measured 6 % slower: the loop is bound
+        // by VALU issue, not by bytes in flight)
         for (uint32_t g = g0 + chunk * GR_WG + threadIdx.x; g < g1; g += nchunks * GR_WG) {
             const float4 a = f4[3 * (size_t)g], b = f4[3 * (size_t)g + 1], c = f4[3 * (size_t)g + 2];
             const size_t pg = (size_t)(g - g0);
@@ -674,8 +685,8 @@ __global__ __launch_bounds__(GR_WG) void k_rmsd_finalize(
 #pragma unroll
         for (int k = 0; k < GR_ACC_K; ++k) acc[k] += p.s[k];
         for (int a = 0; a < 3; ++a) {
-            mn[a] = fminf(mn[a], p.vmin[a]); mx[a] = fmaxf(mx[a], p.vmax[a]);
-            fmn[a] = fminf(fmn[a], p.fmin[a]); fmx[a] = fmaxf(fmx[a], p.fmax[a]);
+            mn[a] = gr_fminf(mn[a], p.vmin[a]); mx[a] = gr_fmaxf(mx[a], p.vmax[a]);
+            fmn[a] = gr_fminf(fmn[a], p.fmin[a]); fmx[a] = gr_fmaxf(fmx[a], p.fmax[a]);
         }
         bad_pos = min(bad_pos, p.bad_pos); bad_mass = min(bad_mass, p.bad_mass);
     }

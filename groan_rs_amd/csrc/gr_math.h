@@ -24,6 +24,17 @@
 
 #define GR_MAX_CAND 16   // half-set: one of each +-t pair
 
+// fminf / fmaxf without the canonicalising `v_max_f32 x, x, x` the compiler puts in front of every IEEE minnum / maxnum
+// whose operand is a loop-carried value: one instruction instead of two or three.  v_min_f32 / v_max_f32 return the
+// other operand when one is NaN, like fminf / fmaxf.  (Device only; the host build of this header keeps libm.)
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ float gr_fminf(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float gr_fmaxf(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+#else
+GR_HD float gr_fminf(float a, float b) { return fminf(a, b); }
+GR_HD float gr_fmaxf(float a, float b) { return fmaxf(a, b); }
+#endif
+
 // Per-frame simulation box, prepared on the host (gr_box_setup) and read by the kernels.
 struct GrBox {
     float ax, by, cz;      // v1x v2y v3z
@@ -105,7 +116,7 @@ GR_HD float gr_tric_refine_r2(float dx, float dy, float dz, const GrBox &b) {
 #pragma unroll
     for (int m = 0; m < NC; ++m) {
         const float dt = fmaf(b.cand[m][0], dx, fmaf(b.cand[m][1], dy, b.cand[m][2] * dz));
-        best = fminf(best, fmaf(-2.0f, fabsf(dt), b.cand_t2[m]));
+        best = gr_fminf(best, fmaf(-2.0f, fabsf(dt), b.cand_t2[m]));
     }
     return fmaxf(r2 + best, 0.0f);
 }

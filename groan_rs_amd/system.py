@@ -246,9 +246,9 @@ class System:
         if st != OK:
             raise DeviceError("set_masses", self._err(st)[1], st)
 
-    def set_persistent(self, on=True):
-        """large RMSD-fit batches as one persistent kernel (default) or as accumulate -> finalize -> fit"""
-        self._lib.gr_ctx_set_persistent(self._ctx, int(bool(on)))
+    def set_persistent(self, mode=1):
+        """RMSD-fit batches as one persistent LDS-resident kernel: 0 never, 1 where it pays, 2 whenever possible"""
+        self._lib.gr_ctx_set_persistent(self._ctx, int(mode))
 
     def set_strict_orthogonal(self, on=True):
         """reproduce the reference's SimBoxError::NotOrthogonal for non-orthogonal boxes"""

@@ -193,10 +193,11 @@ int gr_rmsd_batch_end(gr_rmsd_plan *plan, float *rmsd_out, int *status_out, floa
 uint32_t gr_rmsd_plan_last_fallbacks(const gr_rmsd_plan *plan);
 /* force the multi-pass exact path (parity testing of both paths) */
 int gr_rmsd_plan_force_exact(gr_rmsd_plan *plan, int on);
-/* RMSD-fit batches of large systems run as ONE persistent kernel that keeps each frame in LDS between the sums and the
- * transform; on = 0 selects the accumulate -> finalize -> fit kernels instead (also: GR_PERSIST=0).
+/* RMSD-fit batches can run as ONE persistent kernel that keeps each frame in LDS between the sums and the transform
+ * (DESIGN.md): mode 0 = never (accumulate -> finalize -> fit kernels), 1 = where it pays (contiguous selection, at least
+ * 8 x 256 atoms per compute unit), 2 = whenever it is possible (testing).  Also: environment GR_PERSIST=0/1/2.
  * gr_rmsd_plan_last_persistent: 1 when the last fit batch of the plan took the persistent kernel. */
-int gr_ctx_set_persistent(gr_ctx *ctx, int on);
+int gr_ctx_set_persistent(gr_ctx *ctx, int mode);
 int gr_rmsd_plan_last_persistent(const gr_rmsd_plan *plan);
 
 /* ---------------------------------------------------------------- xtc reader (host side)

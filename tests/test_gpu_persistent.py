@@ -38,13 +38,13 @@ def run_both(G, ref, cur, nf, group, frames, boxes=None):
     for persistent in (True, False):
         for f in range(nf):
             cur.set_frame(frames[f], "keep" if boxes is None else boxes[f], slot=f)
-        cur.set_persistent(persistent)
+        cur.set_persistent(2 if persistent else 0)
         plan = G.RMSDPlan(ref, cur, group)
         r, st = plan.rmsd_fit(0, nf, raise_on_error=False)
         assert plan.last_persistent() == persistent
         out.append((r, st, [cur.get_positions(f) for f in range(nf)], plan.last_fallbacks()))
         plan.close()
-    cur.set_persistent(True)
+    cur.set_persistent(0)
     return out
 
 
@@ -121,7 +121,7 @@ def test_persistent_back_to_back_batches_and_begin_end(G):
     n, nf = 70_000, 9
     box = O.box_from_lengths_angles([8.0, 8.0, 8.0], [60.0, 60.0, 90.0])
     ref, cur, masses, ref_pos = blob(G, n, box, nf)
-    cur.set_persistent(True)
+    cur.set_persistent(2)
     plan = G.RMSDPlan(ref, cur, "all")
     first, _ = plan.rmsd_fit(0, nf)
     assert plan.last_persistent()

@@ -23,7 +23,7 @@ def main():
     box = O.box_from_lengths_angles([24.18, 24.18, 24.18], [60.0, 60.0, 90.0])
     masses = np.array([1.008, 12.011, 14.007, 15.999], np.float32)[np.arange(n) % 4]
     cur = G.System(n, masses=masses, n_slots=nf + 1)
-    cur.set_persistent(True)
+    cur.set_persistent(2)
     cur.synth_reference(nf, box, 0.2 * float(min(box[:3])), 1)
     ref = G.System(n, masses=masses, box=box, positions=cur.get_positions(nf))
     plan = G.RMSDPlan(ref, cur, "all")
@@ -34,29 +34,35 @@ def main():
     raw = np.fromfile(path, dtype=np.uint64)
     F, W, K = int(raw[0]), int(raw[1]), int(raw[2])
     t = raw[4:].reshape(F, W, K).astype(np.float64) * 0.01    # us
+    laps = t[:, : W - 1, 9:15].copy()                         # stamps 9.. are durations of wave 15's phases, not times
+    t = t[:, :, :9]
     t0 = t[t > 0].min()
     t = np.where(t > 0, t - t0, np.nan)
     total = np.nanmax(t)
-    print("frames %d  workgroups %d  total %.1f us  -> %.2f us/frame" % (F, W, total, total / F))
+    print("frames %d  workgroups %d (last = finalizers)  total %.1f us  -> %.2f us/frame" % (F, W, total, total / F))
     def stat(name, x):
         x = x[np.isfinite(x)]
-        print("  %-38s mean %7.2f  p50 %7.2f  p95 %7.2f  max %7.2f us" % (name, x.mean(), np.median(x), np.percentile(x, 95), x.max()))
-    stat("A: load + sums (0->1)", t[:, :, 1] - t[:, :, 0])
-    stat("A: wg reduce + publish + arrive (1->2)", t[:, :, 2] - t[:, :, 1])
-    stat("C: wait for ready (3->4)", t[:, :, 4] - t[:, :, 3])
-    stat("C: transform + store (4->5)", t[:, :, 5] - t[:, :, 4])
-    last = np.nanmax(t[:, :, 2], axis=1)
-    first = np.nanmin(t[:, :, 2], axis=1)
+        print("  %-44s mean %7.2f  p50 %7.2f  p95 %7.2f  max %7.2f us" % (name, x.mean(), np.median(x), np.percentile(x, 95), x.max()))
+    c = t[:, : W - 1, :]                                      # compute workgroups (comm wave stamps)
+    fz = t[:, W - 1, :]                                       # finalizer stamps
+    for k, name in enumerate(("tile landed in LDS", "sums of 4 atoms/lane", "wave reduce + LDS arrive", "wait for LDS ready", "transform + rmsd terms", "store + rmsd wave sum")):
+        stat("wave 15: " + name, laps[:, :, k])
+    stat("wave 15: all phases", laps.sum(axis=2))
+    stat("comm: A start -> all waves arrived (0->1)", c[:, :, 1] - c[:, :, 0])
+    stat("comm: publish record + arrive (1->2)", c[:, :, 2] - c[:, :, 1])
+    stat("comm: wait for ready (3->4)", c[:, :, 4] - c[:, :, 3])
+    stat("comm: own C phase (4->5)", c[:, :, 5] - c[:, :, 4])
+    stat("comm: whole iteration (0 -> next 0)", np.diff(c[:, :, 0], axis=0))
+    last = np.nanmax(c[:, :, 2], axis=1); first = np.nanmin(c[:, :, 2], axis=1)
     stat("arrival skew per frame (first->last)", (last - first)[:, None])
-    fin6 = np.nanmax(t[:, :, 6], axis=1); fin7 = np.nanmax(t[:, :, 7], axis=1); fin8 = np.nanmax(t[:, :, 8], axis=1)
-    stat("finalizer: sum 256 records (2->6)", (fin6 - last)[:, None])
-    stat("finalizer: math (6->7)", (fin7 - fin6)[:, None])
-    stat("finalizer: publish (7->8)", (fin8 - fin7)[:, None])
-    seen = np.nanmin(t[:, :, 4], axis=1)
-    stat("published -> first wg sees ready", (seen - fin8)[:, None])
-    stat("published -> last wg sees ready", (np.nanmax(t[:, :, 4], axis=1) - fin8)[:, None])
-    per = np.diff(fin8)
-    stat("frame period (publish to publish)", per[:, None])
+    stat("last arrival -> finalizer sees it", (fz[:, 2] - last)[:, None])
+    stat("finalizer: sum records (2->6)", (fz[:, 6] - fz[:, 2])[:, None])
+    stat("finalizer: math (6->7)", (fz[:, 7] - fz[:, 6])[:, None])
+    stat("finalizer: publish (7->8)", (fz[:, 8] - fz[:, 7])[:, None])
+    stat("published -> first wg sees ready", (np.nanmin(c[:, :, 4], axis=1) - fz[:, 8])[:, None])
+    stat("published -> last wg sees ready", (np.nanmax(c[:, :, 4], axis=1) - fz[:, 8])[:, None])
+    stat("last arrival -> published (latency L)", (fz[:, 8] - last)[:, None])
+    stat("frame period (publish to publish)", np.diff(fz[:, 8])[:, None])
 
 
 if __name__ == "__main__":
