@@ -137,8 +137,33 @@ __device__ __forceinline__ void gr_wave_sync() {
 }
 // src = first float4 of a 256-atom tile in HBM; on return lane L holds atoms 4L..4L+3 of the tile:
 // (a.x a.y a.z) (a.w b.x b.y) (b.z b.w c.x) (c.y c.z c.w)
+// Frame data is streamed (each byte is touched once per pass): the non-temporal hint keeps it from pushing the
+// reference coordinates / masses, which every frame re-reads, out of the 4 MiB L2 of the XCD (GR_STREAM_NT=0 to compare).
+#ifndef GR_STREAM_NT_LD
+#define GR_STREAM_NT_LD 1
+#endif
+#ifndef GR_STREAM_NT_ST
+#define GR_STREAM_NT_ST 1
+#endif
+typedef float gr_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 gr_stream_load(const float4 *p) {
+#if GR_STREAM_NT_LD
+    const gr_f4 v = __builtin_nontemporal_load(reinterpret_cast<const gr_f4 *>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ void gr_stream_store(float4 *p, const float4 &v) {
+#if GR_STREAM_NT_ST
+    gr_f4 t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+    __builtin_nontemporal_store(t, reinterpret_cast<gr_f4 *>(p));
+#else
+    *p = v;
+#endif
+}
 __device__ __forceinline__ void gr_tile_load(const float4 *__restrict__ src, float4 *tile, uint32_t lane, float4 &a, float4 &b, float4 &c) {
-    const float4 r0 = src[lane], r1 = src[lane + 64], r2 = src[lane + 128];
+    const float4 r0 = gr_stream_load(src + lane), r1 = gr_stream_load(src + lane + 64), r2 = gr_stream_load(src + lane + 128);
     tile[lane] = r0; tile[lane + 64] = r1; tile[lane + 128] = r2;
     gr_wave_sync();
     a = tile[3 * lane]; b = tile[3 * lane + 1]; c = tile[3 * lane + 2];
@@ -148,7 +173,7 @@ __device__ __forceinline__ void gr_tile_store(float4 *__restrict__ dst, float4 *
     tile[3 * lane] = a; tile[3 * lane + 1] = b; tile[3 * lane + 2] = c;
     gr_wave_sync();
     const float4 r0 = tile[lane], r1 = tile[lane + 64], r2 = tile[lane + 128];
-    dst[lane] = r0; dst[lane + 64] = r1; dst[lane + 128] = r2;
+    gr_stream_store(dst + lane, r0); gr_stream_store(dst + lane + 64, r1); gr_stream_store(dst + lane + 128, r2);
     gr_wave_sync();
 }
 
@@ -331,6 +356,7 @@ struct GrA4 { float x[4], y[4], z[4], m[4], px[4], py[4], pz[4], w[4]; uint32_t 
 struct GrLaneAcc {
     double acc[GR_ACC_K];
     float fsum[6];                       // first / second moments of the fractional coordinates
+    float facc[13];                      // LITE: sum m, sum m v, A as f32 lane sums, moved to acc after the loop
     float mn[3], mx[3], fmn[3], fmx[3];  // Cartesian and fractional extent of v
     uint32_t bad_pos, bad_mass;
     __device__ __forceinline__ void reset() {
@@ -339,8 +365,15 @@ struct GrLaneAcc {
 #pragma unroll
         for (int k = 0; k < 6; ++k) fsum[k] = 0.0f;
 #pragma unroll
+        for (int k = 0; k < 13; ++k) facc[k] = 0.0f;
+#pragma unroll
         for (int a = 0; a < 3; ++a) { mn[a] = fmn[a] = 3.0e38f; mx[a] = fmx[a] = -3.0e38f; }
         bad_pos = bad_mass = GR_NOIDX;
+    }
+    // LITE: move the f32 lane sums into their fp64 slots (once, after the loop)
+    __device__ __forceinline__ void fold() {
+#pragma unroll
+        for (int k = 0; k < 13; ++k) { acc[k] += (double)facc[k]; facc[k] = 0.0f; }
     }
     // fold the f32 moment sums into their fp64 slots (call once, before the cross-lane reduction)
     __device__ __forceinline__ void close(bool w_is_mass) {
@@ -439,11 +472,16 @@ __device__ __forceinline__ void gr_flush4(GrLaneAcc &L, const GrA4 &a, const boo
         acc[22] = fma(dw, fma(dvx, dvx, fma(dvy, dvy, dvz * dvz)), acc[22]);
         if (!fc.wm) { acc[23] = fma(dw, dvx, acc[23]); acc[24] = fma(dw, dvy, acc[24]); acc[25] = fma(dw, dvz, acc[25]); }
     }
-#pragma unroll
-    for (int k = 0; k < 9; ++k) L.acc[4 + k] += (double)part[k];
     if (LITE) {
+        // f32 lane sums: a lane sees n / (256 * chunks) atoms (~160 at 1e6 atoms, <= ~1500 at 1e8): ~1e-6 relative per
+        // lane, independent over 1e4..1e5 lanes, so the frame sums keep ~1e-8; the rmsd no longer comes from these sums
 #pragma unroll
-        for (int k = 0; k < 4; ++k) L.acc[k] += (double)pm[k];
+        for (int k = 0; k < 4; ++k) L.facc[k] += pm[k];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) L.facc[4 + k] += part[k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) L.acc[4 + k] += (double)part[k];
     }
 }
 
@@ -533,6 +571,7 @@ __global__ __launch_bounds__(GR_WG, GR_ACC_MIN_WAVES) void k_rmsd_accum(
         }
     }
     L.close(wm && !LITE);
+    if (LITE) L.fold();
     if (LITE) {
         // only sum m, sum m v, A and the six moments are live: reduce those 19, the rest of the record is zero
         double c19[19];
