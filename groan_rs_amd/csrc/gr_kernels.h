@@ -125,6 +125,32 @@ __device__ __forceinline__ void gr_stage_box(GrBox *lds_box, const GrBox *g) {
     __syncthreads();
 }
 
+// Wave reduce-scatter of 32 floats: afterwards lane l holds the wave total of value (l >> 1).  Each step halves the
+// values a lane still carries (it sends the half its partner keeps): 16+8+4+2+1+1 exchanges instead of 32 x 6.
+// Steps are template instances so every register-array index is a compile-time constant.
+template <int HALF, int MASK, bool MAX>
+__device__ __forceinline__ void gr_rs_step(float (&a)[32], const uint32_t lane) {
+    const bool hi = (lane & MASK) != 0;
+#pragma unroll
+    for (int k = 0; k < HALF; ++k) {
+        const float send = hi ? a[k] : a[k + HALF];
+        const float keep = hi ? a[k + HALF] : a[k];
+        const float got = __shfl_xor(send, MASK, 64);
+        a[k] = MAX ? gr_fmaxf(keep, got) : keep + got;
+    }
+}
+__device__ __forceinline__ float gr_wave_sum_scatter32(float (&a)[32], const uint32_t lane) {
+    gr_rs_step<16, 32, false>(a, lane); gr_rs_step<8, 16, false>(a, lane); gr_rs_step<4, 8, false>(a, lane);
+    gr_rs_step<2, 4, false>(a, lane); gr_rs_step<1, 2, false>(a, lane);
+    return a[0] + __shfl_xor(a[0], 1, 64);
+}
+// the same with max over the first 16 floats: lane l ends with the wave maximum of value (l >> 2)
+__device__ __forceinline__ float gr_wave_max_scatter16(float (&a)[32], const uint32_t lane) {
+    gr_rs_step<8, 32, true>(a, lane); gr_rs_step<4, 16, true>(a, lane); gr_rs_step<2, 8, true>(a, lane); gr_rs_step<1, 4, true>(a, lane);
+    const float m = gr_fmaxf(a[0], __shfl_xor(a[0], 2, 64));
+    return gr_fmaxf(m, __shfl_xor(m, 1, 64));
+}
+
 // ------------------------------------------------------------------------------------------ wave tiles
 #define GR_TILE_ATOMS 256
 #define GR_TILE_F4 192
@@ -162,8 +188,10 @@ __device__ __forceinline__ void gr_stream_store(float4 *p, const float4 &v) {
     *p = v;
 #endif
 }
+template <bool NT = true>
 __device__ __forceinline__ void gr_tile_load(const float4 *__restrict__ src, float4 *tile, uint32_t lane, float4 &a, float4 &b, float4 &c) {
-    const float4 r0 = gr_stream_load(src + lane), r1 = gr_stream_load(src + lane + 64), r2 = gr_stream_load(src + lane + 128);
+    const float4 r0 = NT ? gr_stream_load(src + lane) : src[lane], r1 = NT ? gr_stream_load(src + lane + 64) : src[lane + 64],
+                 r2 = NT ? gr_stream_load(src + lane + 128) : src[lane + 128];
     tile[lane] = r0; tile[lane + 64] = r1; tile[lane + 128] = r2;
     gr_wave_sync();
     a = tile[3 * lane]; b = tile[3 * lane + 1]; c = tile[3 * lane + 2];
@@ -498,6 +526,12 @@ __device__ __forceinline__ void gr_unpack4(GrA4 &q, const float4 &a, const float
     for (int k = 0; k < 4; ++k) { q.i[k] = i + k; q.ok[k] = (i + k >= first) && (i + k < last); }
 }
 
+#ifndef GR_ACC_TILE
+#define GR_ACC_TILE 0
+#endif
+#ifndef GR_ACC_TILE_NT
+#define GR_ACC_TILE_NT false
+#endif
 #ifndef GR_ACC_MIN_WAVES
 #define GR_ACC_MIN_WAVES 1
 #endif
@@ -510,6 +544,7 @@ __global__ __launch_bounds__(GR_WG, GR_ACC_MIN_WAVES) void k_rmsd_accum(
     __shared__ double lds[(GR_WG / 64) * GR_ACC_K];
     __shared__ uint32_t ldsu[GR_WG / 64];
     __shared__ float ldsf[GR_WG / 64];
+    __shared__ float4 acc_tiles[GR_ACC_TILE ? (GR_WG / 64) * GR_TILE_F4 : 1];
     const uint32_t frame = blockIdx.y, chunk = blockIdx.x, nchunks = gridDim.x;
     const float *xyz = frames + (size_t)(first_slot + frame) * frame_stride;
     gr_stage_box(&box, boxes + first_slot + frame);
@@ -541,8 +576,18 @@ __global__ __launch_bounds__(GR_WG, GR_ACC_MIN_WAVES) void k_rmsd_accum(
         const float4 *w4 = reinterpret_cast<const float4 *>(plan.w);
         // (requesting the NEXT trip's positions before this trip's arithmetic was measured 6 % slower: the loop is bound
         // by VALU issue, not by bytes in flight)
-        for (uint32_t g = g0 + chunk * GR_WG + threadIdx.x; g < g1; g += nchunks * GR_WG) {
-            const float4 a = f4[3 * (size_t)g], b = f4[3 * (size_t)g + 1], c = f4[3 * (size_t)g + 2];
+        for (uint32_t g = g0 + chunk * GR_WG + threadIdx.x; g - (threadIdx.x & 63u) < g1; g += nchunks * GR_WG) {
+            float4 a, b, c;
+            if (GR_ACC_TILE) {
+                // compile-time experiment (-DGR_ACC_TILE=1): a wave's 64 groups are one 256-atom tile, so the positions could
+                // come in as three coalesced 1-KiB loads + an LDS transpose like the read-modify-write kernels.  Measured
+                // SLOWER here (3.1 vs 2.8 us/frame): this loop is not bound by the load pattern, and the transpose costs issue slots.
+                gr_tile_load<GR_ACC_TILE_NT>(f4 + 3 * (size_t)(g - (threadIdx.x & 63u)), acc_tiles + (threadIdx.x >> 6) * GR_TILE_F4, threadIdx.x & 63u, a, b, c);
+                if (g >= g1) continue;
+            } else {
+                if (g >= g1) continue;
+                a = f4[3 * (size_t)g]; b = f4[3 * (size_t)g + 1]; c = f4[3 * (size_t)g + 2];
+            }
             const size_t pg = (size_t)(g - g0);
             const float4 pa = p4[3 * pg], pb = p4[3 * pg + 1], pc = p4[3 * pg + 2];
             const float4 mm = m4[g];
@@ -570,25 +615,50 @@ __global__ __launch_bounds__(GR_WG, GR_ACC_MIN_WAVES) void k_rmsd_accum(
             if (MODE == 0 && j4 * 4 + 3 < sel.n) gr_flush4<MODE>(L, t, false, box, fc); else gr_flush4<MODE>(L, t, true, box, fc);
         }
     }
-    L.close(wm && !LITE);
-    if (LITE) L.fold();
     if (LITE) {
-        // only sum m, sum m v, A and the six moments are live: reduce those 19, the rest of the record is zero
-        double c19[19];
+        // Cheap epilogue: every live lane sum is f32, so each wave reduce-scatters its 19 sums and 12 extents (49
+        // exchanges instead of 31 x 6), the four waves meet in LDS once, and 33 lanes of wave 0 write the record.
+        const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        float s32[32], e32[32];
 #pragma unroll
-        for (int k = 0; k < 13; ++k) c19[k] = L.acc[k];
+        for (int k = 0; k < 32; ++k) { s32[k] = 0.0f; e32[k] = -3.0e38f; }
 #pragma unroll
-        for (int k = 0; k < 6; ++k) c19[13 + k] = L.acc[26 + k];
-        gr_block_sum<19>(c19, lds);
+        for (int k = 0; k < 13; ++k) s32[k] = L.facc[k];
 #pragma unroll
-        for (int k = 0; k < GR_ACC_K; ++k) L.acc[k] = 0.0;
+        for (int k = 0; k < 6; ++k) s32[13 + k] = L.fsum[k];
 #pragma unroll
-        for (int k = 0; k < 13; ++k) L.acc[k] = c19[k];
+        for (int k = 0; k < 3; ++k) { e32[k] = -L.mn[k]; e32[3 + k] = L.mx[k]; e32[6 + k] = -L.fmn[k]; e32[9 + k] = L.fmx[k]; }
+        const float tot = gr_wave_sum_scatter32(s32, lane);
+        const float emax = gr_wave_max_scatter16(e32, lane);
+        uint32_t bp = L.bad_pos, bm = L.bad_mass;
 #pragma unroll
-        for (int k = 0; k < 6; ++k) L.acc[26 + k] = c19[13 + k];
-    } else {
-        gr_block_sum<GR_ACC_K>(L.acc, lds);
+        for (int off = 32; off > 0; off >>= 1) { bp = min(bp, (uint32_t)__shfl_xor((int)bp, off, 64)); bm = min(bm, (uint32_t)__shfl_xor((int)bm, off, 64)); }
+        float *wsum = reinterpret_cast<float *>(lds);            // [4 waves][32 sums | 16 maxima | 2 indices]
+        if ((lane & 1u) == 0) wsum[wave * 50 + (lane >> 1)] = tot;
+        if ((lane & 3u) == 0) wsum[wave * 50 + 32 + (lane >> 2)] = emax;
+        if (lane == 0) { reinterpret_cast<uint32_t *>(wsum)[wave * 50 + 48] = bp; reinterpret_cast<uint32_t *>(wsum)[wave * 50 + 49] = bm; }
+        __syncthreads();
+        if (wave == 0) {
+            GrAccPartial &o = partials[(size_t)frame * nchunks + chunk];
+            if (lane < 19) {
+                const double v = (double)wsum[lane] + (double)wsum[50 + lane] + (double)wsum[100 + lane] + (double)wsum[150 + lane];
+                o.s[lane < 13 ? lane : 13 + lane] = v;           // sums 13..18 are the moments: record slots 26..31
+            } else if (lane < 32) {
+                o.s[lane - 6] = 0.0;                              // slots 13..25 are not used by the two-pass sums
+            } else if (lane < 44) {
+                const uint32_t q = lane - 32;
+                const float m = gr_fmaxf(gr_fmaxf(wsum[32 + q], wsum[50 + 32 + q]), gr_fmaxf(wsum[100 + 32 + q], wsum[150 + 32 + q]));
+                if (q < 3) o.vmin[q] = -m; else if (q < 6) o.vmax[q - 3] = m; else if (q < 9) o.fmin[q - 6] = -m; else o.fmax[q - 9] = m;
+            } else if (lane == 44) {
+                const uint32_t *u = reinterpret_cast<const uint32_t *>(wsum);
+                o.bad_pos = min(min(u[48], u[98]), min(u[148], u[198]));
+                o.bad_mass = min(min(u[49], u[99]), min(u[149], u[199]));
+            }
+        }
+        return;
     }
+    L.close(wm);
+    gr_block_sum<GR_ACC_K>(L.acc, lds);
     const uint32_t bad_pos = gr_block_min_u32(L.bad_pos, ldsu);
     const uint32_t bad_mass = gr_block_min_u32(L.bad_mass, ldsu);
     float rmn[3], rmx[3], rfmn[3], rfmx[3];

@@ -107,32 +107,6 @@ __device__ __forceinline__ bool gr_wait_lds_ge(const uint32_t *flag, uint32_t wa
     }
 }
 
-// Wave reduce-scatter of 32 floats: afterwards lane l holds the wave total of value (l >> 1).  Each step halves the
-// values a lane still carries (it sends the half its partner keeps): 16+8+4+2+1+1 exchanges instead of 32 x 6.
-// Steps are template instances so every register-array index is a compile-time constant.
-template <int HALF, int MASK, bool MAX>
-__device__ __forceinline__ void gr_rs_step(float (&a)[32], const uint32_t lane) {
-    const bool hi = (lane & MASK) != 0;
-#pragma unroll
-    for (int k = 0; k < HALF; ++k) {
-        const float send = hi ? a[k] : a[k + HALF];
-        const float keep = hi ? a[k + HALF] : a[k];
-        const float got = __shfl_xor(send, MASK, 64);
-        a[k] = MAX ? gr_fmaxf(keep, got) : keep + got;
-    }
-}
-__device__ __forceinline__ float gr_wave_sum_scatter32(float (&a)[32], const uint32_t lane) {
-    gr_rs_step<16, 32, false>(a, lane); gr_rs_step<8, 16, false>(a, lane); gr_rs_step<4, 8, false>(a, lane);
-    gr_rs_step<2, 4, false>(a, lane); gr_rs_step<1, 2, false>(a, lane);
-    return a[0] + __shfl_xor(a[0], 1, 64);
-}
-// the same with max over the first 16 floats: lane l ends with the wave maximum of value (l >> 2)
-__device__ __forceinline__ float gr_wave_max_scatter16(float (&a)[32], const uint32_t lane) {
-    gr_rs_step<8, 32, true>(a, lane); gr_rs_step<4, 16, true>(a, lane); gr_rs_step<2, 8, true>(a, lane); gr_rs_step<1, 4, true>(a, lane);
-    const float m = gr_fmaxf(a[0], __shfl_xor(a[0], 2, 64));
-    return gr_fmaxf(m, __shfl_xor(m, 1, 64));
-}
-
 // LDS carve-up (bytes), shared by the kernel and the host
 struct GrPersistLds {
     uint32_t ring, wsum, wmax, fin, st, ctl, total;
