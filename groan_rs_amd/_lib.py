@@ -16,7 +16,8 @@ c_i32p = C.POINTER(C.c_int)
 
 # status codes (include/groan_hip.h)
 (OK, E_NO_BOX, E_NOT_ORTHOGONAL, E_ZERO_BOX, E_EMPTY_GROUP, E_INCONSISTENT_GROUP, E_NO_POSITION, E_NO_MASS,
- E_GROUP_NOT_FOUND, E_OUT_OF_RANGE, E_INVALID_ARG, E_GROUP_EXISTS, E_HIP, E_NO_DEVICE, E_UNSUPPORTED_BOX, E_IO, E_FORMAT) = range(17)
+ E_GROUP_NOT_FOUND, E_OUT_OF_RANGE, E_INVALID_ARG, E_GROUP_EXISTS, E_HIP, E_NO_DEVICE, E_UNSUPPORTED_BOX, E_IO, E_FORMAT,
+ E_INVALID_NAME) = range(18)
 
 CENTER_NAIVE, CENTER_ESTIMATE, CENTER_PBC = 0, 1, 2
 
@@ -76,6 +77,12 @@ SIGNATURES = {
     "gr_rmsd_plan_last_fallbacks": (C.c_uint32, [C.c_void_p]),
     "gr_rmsd_plan_force_exact": (C.c_int, [C.c_void_p, C.c_int]),
     "gr_ctx_set_persistent": (C.c_int, [C.c_void_p, C.c_int]),
+    "gr_shape_sphere": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float]),
+    "gr_shape_rectangular": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float]),
+    "gr_shape_cylinder": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int]),
+    "gr_shape_triangular_prism": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float]),
+    "gr_shape_inside": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
+    "gr_group_create_from_geometries": (C.c_int, [C.c_void_p, C.c_uint32, C.c_char_p, C.c_char_p, C.c_void_p, C.c_size_t, C.c_int]),
     "gr_rmsd_plan_last_persistent": (C.c_int, [C.c_void_p]),
     "gr_xtc_open": (C.c_void_p, [C.c_char_p, c_i32p]),
     "gr_xtc_close": (None, [C.c_void_p]),

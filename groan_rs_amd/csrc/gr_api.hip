@@ -18,6 +18,7 @@
 #include "gr_kernels.h"
 #include "gr_xtc.h"
 #include "gr_persist.h"
+#include "gr_shape.h"
 
 #define GR_MAX_BATCH 256     // frames per batched call segment (workspace is sized for this)
 #define GR_MAX_CHUNKS 256    // workgroups per frame in the reduction kernels
@@ -338,6 +339,7 @@ const char *gr_status_string(int s) {
     case GR_E_UNSUPPORTED_BOX: return "box too skewed for the minimum-image table";
     case GR_E_IO: return "file could not be opened or read";
     case GR_E_FORMAT: return "not a valid xtc file";
+    case GR_E_INVALID_NAME: return "invalid group name";
     default: return "unknown status";
     }
 }
@@ -690,6 +692,101 @@ int gr_atoms_distance(gr_ctx *c, uint32_t slot, uint64_t i1, uint64_t i2, int di
     HIPCHK(c, hipMemcpy(&v, c->pd_out, sizeof(float), hipMemcpyDeviceToHost));
     if (out) *out = v;
     return GR_OK;
+}
+
+/* ------------------------------------------------------------ geometry selection */
+static bool name_is_valid(const char *name) {   // auxiliary.rs:37-51
+    if (!name) return false;
+    bool blank = true;
+    for (const char *p = name; *p; ++p) {
+        if (strchr("'\"&|!@()<>=", *p)) return false;
+        if (!isspace((unsigned char)*p)) blank = false;
+    }
+    return !blank;
+}
+int gr_shape_sphere(gr_shape *s, const float pos[3], float radius) {
+    if (!s || !pos) return GR_E_INVALID_ARG;
+    memset(s, 0, sizeof *s); s->kind = GR_SHAPE_SPHERE; memcpy(s->position, pos, 12); s->size[0] = radius; return GR_OK;
+}
+int gr_shape_rectangular(gr_shape *s, const float pos[3], float x, float y, float z) {
+    if (!s || !pos) return GR_E_INVALID_ARG;
+    memset(s, 0, sizeof *s); s->kind = GR_SHAPE_RECTANGULAR; memcpy(s->position, pos, 12); s->size[0] = x; s->size[1] = y; s->size[2] = z; return GR_OK;
+}
+int gr_shape_cylinder(gr_shape *s, const float pos[3], float radius, float height, int orientation) {
+    if (!s || !pos || orientation < GR_DIM_X || orientation > GR_DIM_Z) return GR_E_INVALID_ARG;
+    memset(s, 0, sizeof *s); s->kind = GR_SHAPE_CYLINDER; memcpy(s->position, pos, 12); s->size[0] = radius; s->size[1] = height;
+    s->orientation = orientation;
+    s->plane = orientation == GR_DIM_X ? GR_DIM_YZ : (orientation == GR_DIM_Y ? GR_DIM_XZ : GR_DIM_XY);
+    return GR_OK;
+}
+int gr_shape_triangular_prism(gr_shape *s, const float b1[3], const float b2[3], const float b3[3], float height) {
+    if (!s || !b1 || !b2 || !b3) return GR_E_INVALID_ARG;
+    static const int orient[3] = { GR_DIM_X, GR_DIM_Y, GR_DIM_Z }, plane[3] = { GR_DIM_YZ, GR_DIM_XZ, GR_DIM_XY };
+    int found = -1;
+    for (int a = 0; a < 3; ++a)
+        if (b1[a] == b2[a] && b2[a] == b3[a]) { if (found >= 0) return GR_E_INVALID_ARG; found = a; }
+    if (found < 0) return GR_E_INVALID_ARG;
+    memset(s, 0, sizeof *s); s->kind = GR_SHAPE_TRIANGULAR_PRISM;
+    memcpy(s->position, b1, 12); memcpy(s->base2, b2, 12); memcpy(s->base3, b3, 12); s->size[0] = height;
+    s->orientation = orient[found]; s->plane = plane[found];
+    return GR_OK;
+}
+static bool shape_to_dev(const gr_shape &h, int naive, GrShapeDev *d) {
+    if (h.kind < GR_SHAPE_SPHERE || h.kind > GR_SHAPE_TRIANGULAR_PRISM) return false;
+    if (naive && h.kind == GR_SHAPE_TRIANGULAR_PRISM) return false;                 // no NaiveShape for the prism (shape.rs:466-505)
+    if (h.kind >= GR_SHAPE_CYLINDER && (h.orientation < GR_DIM_X || h.orientation > GR_DIM_Z || h.plane < GR_DIM_XY || h.plane > GR_DIM_YZ)) return false;
+    d->kind = h.kind; d->px = h.position[0]; d->py = h.position[1]; d->pz = h.position[2];
+    d->a = h.size[0]; d->b = h.size[1]; d->c = h.size[2];
+    d->b2x = h.base2[0]; d->b2y = h.base2[1]; d->b2z = h.base2[2]; d->b3x = h.base3[0]; d->b3y = h.base3[1]; d->b3z = h.base3[2];
+    d->orientation = h.orientation; d->plane = h.plane;
+    return true;
+}
+int gr_shape_inside(const gr_shape *s, const float point[3], const float box9[9], int naive, int *inside) {
+    if (!s || !point || !inside || (!naive && !box9)) return GR_E_INVALID_ARG;
+    GrShapeDev d;
+    if (!shape_to_dev(*s, naive, &d)) return GR_E_INVALID_ARG;
+    if (naive) { *inside = gr_shape_inside_naive(d, point[0], point[1], point[2]) ? 1 : 0; return GR_OK; }
+    GrBox b;
+    if (!gr_box_setup(box9, &b)) return GR_E_ZERO_BOX;
+    if (!b.ortho) return GR_E_NOT_ORTHOGONAL;
+    *inside = gr_shape_inside_pbc(d, point[0], point[1], point[2], b) ? 1 : 0;
+    return GR_OK;
+}
+int gr_group_create_from_geometries(gr_ctx *c, uint32_t slot, const char *name, const char *source, const gr_shape *shapes, size_t ns, int naive) {
+    int st = slot_check(c, slot); if (st) return st;
+    (void)hipSetDevice(c->device);
+    if (!name_is_valid(name)) return fail(c, GR_E_INVALID_NAME, name ? name : "(null)");                 // groups.rs:100-102
+    if (c->box_status[slot] == GR_E_NO_BOX) return fail(c, GR_E_NO_BOX, "simulation box does not exist");   // :104-106
+    if (c->box_status[slot] != GR_OK) return fail(c, c->box_status[slot], "invalid simulation box");
+    if (!c->boxes_host[slot].ortho) return fail(c, GR_E_NOT_ORTHOGONAL, "simulation box is not orthogonal"); // :108-110
+    const Group *g = find_group(c, source);
+    if (!g) return fail(c, GR_E_GROUP_NOT_FOUND, source ? source : "(null)");                               // InvalidQuery(GroupNotFound)
+    if (ns > GR_MAX_SHAPES || (ns && !shapes)) return fail(c, GR_E_INVALID_ARG, "too many shapes");
+    GrShapeSet set; set.n = (int)ns; set.naive = naive ? 1 : 0;
+    for (size_t q = 0; q < ns; ++q) if (!shape_to_dev(shapes[q], naive, &set.s[q])) return fail(c, GR_E_INVALID_ARG, "invalid shape");
+    std::vector<uint64_t> picked;
+    if (g->n) {
+        const GrSel sel = make_sel(*g);
+        const size_t words = ((size_t)g->n + 63) / 64;
+        unsigned long long *mask_dev = nullptr;
+        HIPCHK(c, hipMalloc(&mask_dev, words * sizeof(unsigned long long)));
+        {
+            SlotUse use(c, slot);
+            k_shape_mask<<<dim3((unsigned)((g->n + 255) / 256)), dim3(256), 0, c->stream>>>(c->frames + (size_t)slot * c->frame_stride, sel, c->boxes_host[slot], set, mask_dev);
+        }
+        std::vector<unsigned long long> mask(words);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(mask.data(), mask_dev, words * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        (void)hipFree(mask_dev);
+        if (e != hipSuccess) { c->err = std::string("geometry selection: ") + hipGetErrorString(e); return GR_E_HIP; }
+        // ordinal -> atom index in the source group's iteration order (AtomContainer::iter, container.rs:381-411)
+        size_t j = 0;
+        for (const auto &blk : g->blocks)
+            for (uint64_t a = blk.first; a <= blk.second; ++a, ++j)
+                if ((mask[j >> 6] >> (j & 63)) & 1ull) picked.push_back(a);
+    }
+    return install_group(c, name, grc::from_indices(picked, c->n));
 }
 
 /* ------------------------------------------------------------ translate / wrap / centre */

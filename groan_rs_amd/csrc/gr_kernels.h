@@ -1002,7 +1002,12 @@ __global__ __launch_bounds__(GR_WG) void k_translate_wrap(
 // the i atoms of the tile sit in LDS (broadcast reads), and every row is written with one 16-byte
 // store per lane = 1 KiB contiguous per wavefront instruction.  The kernel is bound by the HBM write
 // of the matrix (4 B/pair); orthorhombic boxes need ~15 flop/pair.
-#define GR_PD_TI 32
+#ifndef GR_PD_TI
+#define GR_PD_TI 16
+#endif
+#ifndef GR_PD_NT
+#define GR_PD_NT 1
+#endif
 // The box (with its image table) comes in BY VALUE: kernel arguments are read with scalar loads, so the table
 // entries are SGPR operands of the FMAs instead of per-lane LDS reads.
 template <int NC>
@@ -1044,7 +1049,11 @@ __global__ __launch_bounds__(GR_WG) void k_pairdist(
         for (int k = 0; k < 4; ++k) d[k] = gr_distance<NC>(t.x, t.y, t.z, jx[k], jy[k], jz[k], dim, box);
         float *row = out + (size_t)(i0 + r) * s2.n;
         if (vec_ok && j0 + 3 < s2.n) {
+#if GR_PD_NT
+            gr_stream_store(reinterpret_cast<float4 *>(row + j0), make_float4(d[0], d[1], d[2], d[3]));   // written once, read by nobody here
+#else
             *reinterpret_cast<float4 *>(row + j0) = make_float4(d[0], d[1], d[2], d[3]);
+#endif
         } else {
 #pragma unroll
             for (int k = 0; k < 4; ++k) if (j0 + k < s2.n) row[j0 + k] = d[k];

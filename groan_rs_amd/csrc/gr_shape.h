@@ -1,0 +1,109 @@
+// gr_shape.h -- geometry-selection predicates (host + device).
+// Reference: Shape::inside for Sphere / Rectangular / Cylinder / TriangularPrism (src/structures/shape.rs:110-185,
+// 252-276, 431-461), the PBC-free NaiveShape variants (:466-505) and Group::apply_geometries
+// (src/structures/group.rs:119-175: an atom without a position is inside nothing; with several shapes it must be inside
+// all of them).  The predicates are compositions of gr_distance (1-D distances are signed), so their truth values are
+// the reference's wherever gr_distance is bit-compatible (orthorhombic boxes, which is all the reference accepts here:
+// src/system/groups.rs:104-110).
+#pragma once
+#include "gr_math.h"
+
+enum { GR_SH_SPHERE = 1, GR_SH_RECTANGULAR = 2, GR_SH_CYLINDER = 3, GR_SH_PRISM = 4 };
+#define GR_MAX_SHAPES 8
+
+struct GrShapeDev {
+    int kind;
+    float px, py, pz;          // sphere centre / box origin / centre of the cylinder base / base1 of the prism
+    float a, b, c;             // sphere: radius ; rectangular: x y z ; cylinder: radius height ; prism: height
+    float b2x, b2y, b2z, b3x, b3y, b3z;
+    int orientation, plane;    // GR_DIM_* ordinals (1 X, 2 Y, 3 Z, 4 XY, 5 XZ, 6 YZ)
+};
+struct GrShapeSet { int n, naive; GrShapeDev s[GR_MAX_SHAPES]; };
+
+GR_HD float gr_box_len(const GrBox &b, int dim) { return dim == 1 ? b.ax : (dim == 2 ? b.by : b.cz); }
+
+// vector3d.rs:522-533
+GR_HD float gr_distance_naive(float ax_, float ay_, float az_, float px, float py, float pz, int dim) {
+    const float dx = ax_ - px, dy = ay_ - py, dz = az_ - pz;
+    switch (dim) {
+    case 0: return 0.0f;
+    case 1: return dx;
+    case 2: return dy;
+    case 3: return dz;
+    case 4: return gr_mag3(dx, dy, 0.0f);
+    case 5: return gr_mag3(dx, 0.0f, dz);
+    case 6: return gr_mag3(0.0f, dy, dz);
+    default: return gr_mag3(dx, dy, dz);
+    }
+}
+
+// TriangularPrism::sign (shape.rs:408-428)
+GR_HD float gr_prism_sign(float u1, float v1, float u2, float v2, float u3, float v3) { return (u1 - u3) * (v2 - v3) - (u2 - u3) * (v1 - v3); }
+
+template <int NC = GR_MAX_CAND>
+GR_HD bool gr_shape_inside_pbc(const GrShapeDev &s, float x, float y, float z, const GrBox &box) {
+    switch (s.kind) {
+    case GR_SH_SPHERE:   // :114-116
+        return gr_distance<NC>(x, y, z, s.px, s.py, s.pz, 7, box) < s.a;
+    case GR_SH_RECTANGULAR: {   // :169-184
+        float dx = gr_distance<NC>(x, y, z, s.px, s.py, s.pz, 1, box); if (dx < 0.0f) dx += box.ax;
+        float dy = gr_distance<NC>(x, y, z, s.px, s.py, s.pz, 2, box); if (dy < 0.0f) dy += box.by;
+        float dz = gr_distance<NC>(x, y, z, s.px, s.py, s.pz, 3, box); if (dz < 0.0f) dz += box.cz;
+        return dx <= s.a && dy <= s.b && dz <= s.c;
+    }
+    case GR_SH_CYLINDER: {   // :256-275
+        float da = gr_distance<NC>(x, y, z, s.px, s.py, s.pz, s.orientation, box);
+        if (da < 0.0f) da += gr_box_len(box, s.orientation);
+        return !(da > s.b || gr_distance<NC>(x, y, z, s.px, s.py, s.pz, s.plane, box) > s.a);
+    }
+    case GR_SH_PRISM: {   // :435-460 (the base itself is not periodic, the height is)
+        float d = gr_distance<NC>(x, y, z, s.px, s.py, s.pz, s.orientation, box);
+        if (d < 0.0f) d += gr_box_len(box, s.orientation);
+        if (d >= s.a) return false;
+        float pu, pv, u1, v1, u2, v2, u3, v3;
+        if (s.plane == 4) { pu = x; pv = y; u1 = s.px; v1 = s.py; u2 = s.b2x; v2 = s.b2y; u3 = s.b3x; v3 = s.b3y; }
+        else if (s.plane == 5) { pu = x; pv = z; u1 = s.px; v1 = s.pz; u2 = s.b2x; v2 = s.b2z; u3 = s.b3x; v3 = s.b3z; }
+        else { pu = y; pv = z; u1 = s.py; v1 = s.pz; u2 = s.b2y; v2 = s.b2z; u3 = s.b3y; v3 = s.b3z; }
+        const float d1 = gr_prism_sign(pu, pv, u1, v1, u2, v2), d2 = gr_prism_sign(pu, pv, u2, v2, u3, v3), d3 = gr_prism_sign(pu, pv, u3, v3, u1, v1);
+        const bool has_neg = (d1 < 0.0f) || (d2 < 0.0f) || (d3 < 0.0f), has_pos = (d1 > 0.0f) || (d2 > 0.0f) || (d3 > 0.0f);
+        return !(has_neg && has_pos);
+    }
+    }
+    return false;
+}
+
+GR_HD bool gr_shape_inside_naive(const GrShapeDev &s, float x, float y, float z) {
+    switch (s.kind) {
+    case GR_SH_SPHERE:   // :473-475
+        return gr_distance_naive(x, y, z, s.px, s.py, s.pz, 7) < s.a;
+    case GR_SH_CYLINDER: {   // :482-487
+        const float d = gr_distance_naive(x, y, z, s.px, s.py, s.pz, s.orientation);
+        return d >= 0.0f && d < s.b && gr_distance_naive(x, y, z, s.px, s.py, s.pz, s.plane) < s.a;
+    }
+    case GR_SH_RECTANGULAR: {   // :494-500
+        const float dx = x - s.px, dy = y - s.py, dz = z - s.pz;
+        return dx >= 0.0f && dx <= s.a && dy >= 0.0f && dy <= s.b && dz >= 0.0f && dz <= s.c;
+    }
+    }
+    return false;   // the reference has no naive triangular prism (rejected on the host)
+}
+
+#if defined(__HIPCC__)
+// One bit per atom of the selection (ordinal order): has a position and lies inside every shape.  The host turns the
+// mask into AtomContainer blocks -- groups are host objects; the mask is n/8 bytes (125 KB per 1e6 atoms).
+// The box and the shapes come in by value: scalar loads, SGPR operands.
+__global__ __launch_bounds__(256) void k_shape_mask(const float *__restrict__ xyz, GrSel sel, const GrBox box, const GrShapeSet shapes,
+                                                     unsigned long long *__restrict__ mask) {
+    const uint32_t j = blockIdx.x * 256u + threadIdx.x;
+    bool in = false;
+    if (j < sel.n) {
+        const uint32_t a = sel.contiguous ? sel.start + j : sel.idx[j];
+        const float x = xyz[3 * (size_t)a], y = xyz[3 * (size_t)a + 1], z = xyz[3 * (size_t)a + 2];
+        in = (x == x);
+        for (int q = 0; q < shapes.n && in; ++q)
+            in = shapes.naive ? gr_shape_inside_naive(shapes.s[q], x, y, z) : gr_shape_inside_pbc(shapes.s[q], x, y, z, box);
+    }
+    const unsigned long long bits = __ballot(in);
+    if ((threadIdx.x & 63u) == 0) mask[j >> 6] = bits;
+}
+#endif

@@ -11,7 +11,7 @@ import numpy as np
 
 from . import _lib
 from ._lib import (OK, E_NO_BOX, E_NOT_ORTHOGONAL, E_ZERO_BOX, E_EMPTY_GROUP, E_INCONSISTENT_GROUP,
-                   E_NO_POSITION, E_NO_MASS, E_GROUP_NOT_FOUND, E_OUT_OF_RANGE, E_GROUP_EXISTS)
+                   E_NO_POSITION, E_NO_MASS, E_GROUP_NOT_FOUND, E_OUT_OF_RANGE, E_GROUP_EXISTS, E_INVALID_NAME)
 
 
 class Dimension(IntEnum):
@@ -209,6 +209,7 @@ class System:
     def _raise_group(self, status):
         st, msg, idx = self._err(status)
         if st == E_GROUP_NOT_FOUND: raise GroupError("NotFound", msg, st)
+        if st == E_INVALID_NAME: raise GroupError("InvalidName", msg, st)
         if st == E_EMPTY_GROUP: raise GroupError("EmptyGroup", msg, st)
         if st in (E_NO_BOX, E_NOT_ORTHOGONAL, E_ZERO_BOX): raise GroupError("InvalidSimBox", _simbox(st), st)
         if st == E_NO_POSITION: raise GroupError("InvalidPosition", idx, st)
@@ -267,6 +268,22 @@ class System:
     def group_create_from_indices(self, name, indices):
         idx = np.ascontiguousarray(list(indices), dtype=np.uint64)
         st = self._lib.gr_group_create_from_indices(self._ctx, name.encode(), _ptr(idx), idx.size)
+        if st not in (OK, E_GROUP_EXISTS):
+            self._raise_group(st)
+        return st == E_GROUP_EXISTS
+
+    def group_create_from_geometry(self, name, source_group, geometry, slot=0, naive=False):
+        """System::group_create_from_geometry (groups.rs:94-118) with a source GROUP in place of the query string"""
+        return self.group_create_from_geometries(name, source_group, [geometry], slot=slot, naive=naive)
+
+    def group_create_from_geometries(self, name, source_group, geometries, slot=0, naive=False):
+        """System::group_create_from_geometries (groups.rs:164-188): atoms of `source_group` that have a position and
+        lie inside every shape, in the source order; needs an orthogonal box"""
+        from .shapes import pack
+        arr, n = pack(geometries)
+        st = self._lib.gr_group_create_from_geometries(self._ctx, slot, name.encode(), source_group.encode(), arr, n, int(bool(naive)))
+        if st == E_GROUP_NOT_FOUND:
+            raise GroupError("InvalidQuery", ("GroupNotFound", source_group), st)      # SelectError::GroupNotFound
         if st not in (OK, E_GROUP_EXISTS):
             self._raise_group(st)
         return st == E_GROUP_EXISTS

@@ -57,7 +57,8 @@ enum {
     GR_E_NO_DEVICE = 13,         /* no usable gfx950 device: the library has NO CPU fallback */
     GR_E_UNSUPPORTED_BOX = 14,   /* box too skewed for the minimum-image candidate table    */
     GR_E_IO = 15,                /* ReadTrajError::FileNotFound / read failure              */
-    GR_E_FORMAT = 16             /* ReadTrajError::NotXtc / FrameNotFound (corrupt stream)  */
+    GR_E_FORMAT = 16,            /* ReadTrajError::NotXtc / FrameNotFound (corrupt stream)  */
+    GR_E_INVALID_NAME = 17       /* GroupError::InvalidName (auxiliary.rs:37-51)            */
 };
 
 /* Dimension (src/structures/dimension.rs:13-23) */
@@ -199,6 +200,34 @@ int gr_rmsd_plan_force_exact(gr_rmsd_plan *plan, int on);
  * gr_rmsd_plan_last_persistent: 1 when the last fit batch of the plan took the persistent kernel. */
 int gr_ctx_set_persistent(gr_ctx *ctx, int mode);
 int gr_rmsd_plan_last_persistent(const gr_rmsd_plan *plan);
+
+/* ---------------------------------------------------------------- geometry selection
+ * Shape::inside of Sphere / Rectangular / Cylinder / TriangularPrism (src/structures/shape.rs:110-185,252-276,431-461),
+ * the PBC-free NaiveShape variants (:466-505), and System::group_create_from_geometry / _geometries
+ * (src/system/groups.rs:94-188 over Group::apply_geometries, src/structures/group.rs:119-175): the new group holds, in
+ * the source group's order, the atoms that have a position and lie inside EVERY shape.  Like the reference this needs an
+ * orthogonal box (GR_E_NO_BOX / GR_E_NOT_ORTHOGONAL); the name must be valid (GR_E_INVALID_NAME: empty, or one of
+ * '"&|!@()<>= , auxiliary.rs:37-51); an existing group is replaced and GR_E_GROUP_EXISTS returned (the reference's
+ * AlreadyExistsWarning).  The predicate runs on the device (one ballot bit per atom), the blocks are built on the host. */
+enum { GR_SHAPE_SPHERE = 1, GR_SHAPE_RECTANGULAR = 2, GR_SHAPE_CYLINDER = 3, GR_SHAPE_TRIANGULAR_PRISM = 4 };
+#define GR_MAX_SHAPES 8
+typedef struct gr_shape {
+    int kind;
+    float position[3];         /* sphere centre / box origin / centre of the cylinder's base / first vertex of the prism's base */
+    float size[3];             /* sphere: radius ; rectangular: x y z ; cylinder: radius, height ; prism: height */
+    float base2[3], base3[3];  /* prism: the other two vertices of the base */
+    int orientation, plane;    /* GR_DIM_* ; cylinder and prism (filled by the constructors) */
+} gr_shape;
+int gr_shape_sphere(gr_shape *s, const float position[3], float radius);                                   /* Sphere::new :95-97 */
+int gr_shape_rectangular(gr_shape *s, const float position[3], float x, float y, float z);                 /* Rectangular::new :141-143 */
+/* Cylinder::new :211-229 -- orientation GR_DIM_X / _Y / _Z, anything else is GR_E_INVALID_ARG (the reference panics) */
+int gr_shape_cylinder(gr_shape *s, const float position[3], float radius, float height, int orientation);
+/* TriangularPrism::new :343-378 -- GR_E_INVALID_ARG where the reference panics (base not in a coordinate plane / degenerate) */
+int gr_shape_triangular_prism(gr_shape *s, const float base1[3], const float base2[3], const float base3[3], float height);
+/* Shape::inside / NaiveShape::inside_naive for one point (host; box9 may be NULL when naive) */
+int gr_shape_inside(const gr_shape *s, const float point[3], const float box9[9], int naive, int *inside);
+int gr_group_create_from_geometries(gr_ctx *ctx, uint32_t slot, const char *name, const char *source_group,
+                                    const gr_shape *shapes, size_t n_shapes, int naive);
 
 /* ---------------------------------------------------------------- xtc reader (host side)
  * The stage in front of the path: XtcReader (src/io/xtc_io/mod.rs, molly_xtc.rs:96-308, xdrfile_xtc.rs:42-104).

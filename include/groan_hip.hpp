@@ -6,6 +6,7 @@
 //   System::new / clone per worker                       groan::System(n_atoms, device, n_slots)
 //   TrajRead::update_system                              System::set_frame(xyz, box9)
 //   system.group_create_from_ranges / _from_indices      same
+//   Sphere / Rectangular / Cylinder / TriangularPrism    groan::Shape factories; system.group_create_from_geometry(-ies)
 //   system.group_get_center / _com / estimate_* / naive  same (return Vector3D)
 //   system.group_distance / atoms_distance / group_all_distances
 //   system.atoms_translate / atoms_wrap / group_* / atoms_center(_mass)
@@ -86,6 +87,23 @@ struct AtomContainer {
 };
 
 // ---- System (src/system/mod.rs:38-73)
+// Shape (src/structures/shape.rs): a value type over gr_shape; the factories throw where the reference panics.
+struct Shape {
+    gr_shape c{};
+    static Shape sphere(const Vector3D &pos, float radius) { Shape s; check(gr_shape_sphere(&s.c, pos.data(), radius), "Sphere::new"); return s; }
+    static Shape rectangular(const Vector3D &pos, float x, float y, float z) { Shape s; check(gr_shape_rectangular(&s.c, pos.data(), x, y, z), "Rectangular::new"); return s; }
+    static Shape cylinder(const Vector3D &pos, float radius, float height, Dimension orientation) {
+        Shape s; check(gr_shape_cylinder(&s.c, pos.data(), radius, height, (int)orientation), "Cylinder::new | Unsupported orientation dimension"); return s;
+    }
+    static Shape triangular_prism(const Vector3D &b1, const Vector3D &b2, const Vector3D &b3, float height) {
+        Shape s; check(gr_shape_triangular_prism(&s.c, b1.data(), b2.data(), b3.data(), height), "TriangularPrism::new | invalid base"); return s;
+    }
+    bool inside(const Vector3D &point, const Box9 &box) const { int in = 0; check(gr_shape_inside(&c, point.data(), box.data(), 0, &in), "Shape::inside"); return in != 0; }
+    bool inside_naive(const Vector3D &point) const { int in = 0; check(gr_shape_inside(&c, point.data(), nullptr, 1, &in), "NaiveShape::inside_naive"); return in != 0; }
+private:
+    static void check(int st, const char *what) { if (st != GR_OK) throw std::invalid_argument(std::string("FATAL GROAN ERROR | ") + what); }
+};
+
 class System {
   public:
     System(uint64_t n_atoms, int device = 0, uint32_t n_slots = 1) : n_(n_atoms), device_(device) {
@@ -127,6 +145,19 @@ class System {
         int st = gr_group_create_from_indices(ctx_, name.c_str(), idx.data(), idx.size());
         if (st != GR_OK && st != GR_E_GROUP_EXISTS) group_error(st, name);
         return st == GR_E_GROUP_EXISTS;
+    }
+    // System::group_create_from_geometry / _geometries (groups.rs:94-188) with a source group in place of the query
+    bool group_create_from_geometries(const std::string &name, const std::string &source, const std::vector<Shape> &shapes, uint32_t slot = 0, bool naive = false) {
+        std::vector<gr_shape> raw;
+        for (const Shape &s : shapes) raw.push_back(s.c);
+        int st = gr_group_create_from_geometries(ctx_, slot, name.c_str(), source.c_str(), raw.data(), raw.size(), naive ? 1 : 0);
+        if (st == GR_E_GROUP_NOT_FOUND) throw Error("GroupError", "InvalidQuery", st);
+        if (st == GR_E_INVALID_NAME) throw Error("GroupError", "InvalidName", st);
+        if (st != GR_OK && st != GR_E_GROUP_EXISTS) group_error(st, name);
+        return st == GR_E_GROUP_EXISTS;
+    }
+    bool group_create_from_geometry(const std::string &name, const std::string &source, const Shape &shape, uint32_t slot = 0) {
+        return group_create_from_geometries(name, source, { shape }, slot);
     }
     uint64_t group_get_n_atoms(const std::string &name) const {
         uint64_t n = 0;

@@ -916,3 +916,95 @@ double go_baseline_rmsd_fit(float *frames, size_t n_frames, size_t n_atoms,
     free(all); free(rc);
     return worst;
 }
+
+/* ================================================================== geometry selection */
+/* src/structures/shape.rs:343-378 */
+int go_shape_prism_init(go_shape *s, const float b1[3], const float b2[3], const float b3[3], float height) {
+    static const int orient[3] = { GO_DIM_X, GO_DIM_Y, GO_DIM_Z }, plane[3] = { GO_DIM_YZ, GO_DIM_XZ, GO_DIM_XY };
+    int found = -1;
+    for (int a = 0; a < 3; ++a)
+        if (b1[a] == b2[a] && b2[a] == b3[a]) {
+            if (found >= 0) return 2; /* "can not be constructed" */
+            found = a;
+        }
+    if (found < 0) return 1; /* "does not lie in xy, xz, nor yz plane" */
+    memset(s, 0, sizeof *s);
+    s->kind = GO_SHAPE_TRIANGULAR_PRISM;
+    for (int a = 0; a < 3; ++a) { s->position[a] = b1[a]; s->base2[a] = b2[a]; s->base3[a] = b3[a]; }
+    s->size[0] = height;
+    s->orientation = orient[found]; s->plane = plane[found];
+    return 0;
+}
+
+/* TriangularPrism::sign :408-428 */
+static float prism_sign(const float p1[3], const float p2[3], const float p3[3], int plane) {
+    int u = 0, v = 1;
+    if (plane == GO_DIM_XZ) { u = 0; v = 2; }
+    else if (plane == GO_DIM_YZ) { u = 1; v = 2; }
+    return (p1[u] - p3[u]) * (p2[v] - p3[v]) - (p2[u] - p3[u]) * (p1[v] - p3[v]);
+}
+
+static float box_len(const float *b, int dim) { return dim == GO_DIM_X ? V1X(b) : (dim == GO_DIM_Y ? V2Y(b) : V3Z(b)); }
+
+int go_shape_inside(const go_shape *s, const float pt[3], const float *b) {
+    switch (s->kind) {
+    case GO_SHAPE_SPHERE: /* :114-116 */
+        return go_distance(pt, s->position, GO_DIM_XYZ, b) < s->size[0];
+    case GO_SHAPE_RECTANGULAR: { /* :169-184 */
+        float dx = go_distance(pt, s->position, GO_DIM_X, b); if (dx < 0.0f) dx += V1X(b);
+        float dy = go_distance(pt, s->position, GO_DIM_Y, b); if (dy < 0.0f) dy += V2Y(b);
+        float dz = go_distance(pt, s->position, GO_DIM_Z, b); if (dz < 0.0f) dz += V3Z(b);
+        return dx <= s->size[0] && dy <= s->size[1] && dz <= s->size[2];
+    }
+    case GO_SHAPE_CYLINDER: { /* :256-275 */
+        float da = go_distance(pt, s->position, s->orientation, b);
+        if (da < 0.0f) da += box_len(b, s->orientation);
+        if (da > s->size[1] || go_distance(pt, s->position, s->plane, b) > s->size[0]) return 0;
+        return 1;
+    }
+    case GO_SHAPE_TRIANGULAR_PRISM: { /* :435-460 */
+        float d = go_distance(pt, s->position, s->orientation, b);
+        if (d < 0.0f) d += box_len(b, s->orientation);
+        if (d >= s->size[0]) return 0;
+        float d1 = prism_sign(pt, s->position, s->base2, s->plane);
+        float d2 = prism_sign(pt, s->base2, s->base3, s->plane);
+        float d3 = prism_sign(pt, s->base3, s->position, s->plane);
+        int has_neg = (d1 < 0.0f) || (d2 < 0.0f) || (d3 < 0.0f);
+        int has_pos = (d1 > 0.0f) || (d2 > 0.0f) || (d3 > 0.0f);
+        return !(has_neg && has_pos);
+    }
+    }
+    return 0;
+}
+
+int go_shape_inside_naive(const go_shape *s, const float pt[3]) {
+    switch (s->kind) {
+    case GO_SHAPE_SPHERE: /* :473-475 */
+        return go_distance_naive(pt, s->position, GO_DIM_XYZ) < s->size[0];
+    case GO_SHAPE_CYLINDER: { /* :482-487 */
+        float d = go_distance_naive(pt, s->position, s->orientation);
+        return d >= 0.0f && d < s->size[1] && go_distance_naive(pt, s->position, s->plane) < s->size[0];
+    }
+    case GO_SHAPE_RECTANGULAR: { /* :494-500 */
+        float dx = go_distance_naive(pt, s->position, GO_DIM_X), dy = go_distance_naive(pt, s->position, GO_DIM_Y),
+              dz = go_distance_naive(pt, s->position, GO_DIM_Z);
+        return dx >= 0.0f && dx <= s->size[0] && dy >= 0.0f && dy <= s->size[1] && dz >= 0.0f && dz <= s->size[2];
+    }
+    }
+    return -1;
+}
+
+/* src/structures/group.rs:119-175 */
+size_t go_group_from_geometries(const void *pos, size_t ps, const uint64_t *idx, size_t n, const float *b,
+                                const go_shape *shapes, size_t ns, int naive, uint64_t *out) {
+    size_t cnt = 0;
+    for (size_t k = 0; k < n; ++k) {
+        const float *p = POS(pos, ps, idx[k]);
+        if (isnan(p[0])) continue; /* atoms that have no positions are not inside the shape */
+        int inside = 1;
+        for (size_t q = 0; q < ns && inside; ++q)
+            inside = naive ? (go_shape_inside_naive(&shapes[q], p) == 1) : go_shape_inside(&shapes[q], p, b);
+        if (inside) out[cnt++] = idx[k];
+    }
+    return cnt;
+}

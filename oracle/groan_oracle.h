@@ -159,6 +159,25 @@ double go_baseline_rmsd_fit(float *frames, size_t n_frames, size_t n_atoms,
                             const float *ref_xyz, const float *masses,
                             const float *box9, int n_threads, int layout, float *rmsd_out);
 
+/* ---- geometry selection: src/structures/shape.rs:110-185,252-276,431-461 (PBC), :466-505 (naive);
+ * Group::apply_geometry / apply_geometries src/structures/group.rs:119-175 ---- */
+enum { GO_SHAPE_SPHERE = 1, GO_SHAPE_RECTANGULAR = 2, GO_SHAPE_CYLINDER = 3, GO_SHAPE_TRIANGULAR_PRISM = 4 };
+typedef struct go_shape {
+    int kind;
+    float position[3];        /* sphere centre / box origin / centre of the cylinder base / base1 of the prism */
+    float size[3];            /* sphere: radius ; rectangular: x y z ; cylinder: radius height ; prism: height */
+    float base2[3], base3[3]; /* prism */
+    int orientation, plane;   /* GO_DIM_* ; cylinder and prism */
+} go_shape;
+/* TriangularPrism::new (:343-378): derives orientation / plane; returns 0, or 1 / 2 where the reference panics
+ * ("does not lie in xy, xz, nor yz plane" / "can not be constructed") */
+int go_shape_prism_init(go_shape *s, const float b1[3], const float b2[3], const float b3[3], float height);
+int go_shape_inside(const go_shape *s, const float point[3], const float box9[9]);
+int go_shape_inside_naive(const go_shape *s, const float point[3]);   /* -1: the reference has no naive prism */
+/* atoms of idx[] (in order) that have a position and lie inside ALL shapes; returns the count */
+size_t go_group_from_geometries(const void *pos, size_t pos_stride, const uint64_t *idx, size_t n, const float *box9,
+                                const go_shape *shapes, size_t n_shapes, int naive, uint64_t *out_idx);
+
 #ifdef __cplusplus
 }
 #endif

@@ -76,6 +76,25 @@ int main(int argc, char **argv) {
     reference.set_masses(masses);
     reference.group_create_from_ranges("Protein", {{0, 60}});
     reference.set_frame(gro.data(), &b0);
+    {   // ---- geometry selection (groups.rs:94-188, shape.rs): device result == the host predicate applied atom by atom
+        const Shape sphere = Shape::sphere({0.5f, 4.5f, 3.5f}, 4.6f), cyl = Shape::cylinder({5.0f, 8.0f, 3.0f}, 3.0f, 6.0f, Dimension::Y);
+        CHECK(Shape::sphere({1.0f, 2.0f, 4.5f}, 1.5f).inside({4.8f, 2.1f, 0.3f}, Box9{5, 5, 5, 0, 0, 0, 0, 0, 0}));          // shape.rs:532-539
+        CHECK(!Shape::sphere({1.0f, 2.0f, 4.5f}, 1.5f).inside_naive({4.8f, 2.1f, 0.3f}));                                     // :583-586
+        try { Shape::cylinder({1, 2, 3}, 1, 1, Dimension::XY); CHECK(false); } catch (const std::invalid_argument &) {}      // Cylinder::new panics
+        try { Shape::triangular_prism({3, 4, 2}, {7, 5, 1.8f}, {4, 3, 2}, 4.3f); CHECK(false); } catch (const std::invalid_argument &) {}   // :948-957
+        CHECK(!reference.group_create_from_geometries("Picked", "all", {sphere}));
+        CHECK(!reference.group_create_from_geometries("Picked2", "all", {sphere, cyl}));
+        uint64_t want = 0, want2 = 0;
+        for (uint64_t i = 0; i < n; ++i) {
+            const Vector3D p{gro[3 * i], gro[3 * i + 1], gro[3 * i + 2]};
+            if (sphere.inside(p, b0)) ++want;
+            if (sphere.inside(p, b0) && cyl.inside(p, b0)) ++want2;
+        }
+        CHECK(reference.group_get_n_atoms("Picked") == want && want > 0 && want < n);
+        CHECK(reference.group_get_n_atoms("Picked2") == want2);
+        try { reference.group_create_from_geometry("Pi>cked", "all", sphere); CHECK(false); } catch (const Error &e) { CHECK(e.variant == "InvalidName"); }
+        try { reference.group_create_from_geometry("Picked", "nothing", sphere); CHECK(false); } catch (const Error &e) { CHECK(e.variant == "InvalidQuery"); }
+    }
     {
         System system(n, 0, 11);
         system.set_masses(masses);

@@ -283,3 +283,54 @@ def baseline_rmsd_fit(frames, ref_xyz, masses, box, n_threads, layout):
     sec = lib().go_baseline_rmsd_fit(_p(frames), C.c_size_t(F), C.c_size_t(N), _p(ref), _p(m), _p(_box(box)),
                                      C.c_int(n_threads), C.c_int(layout), _p(out))
     return float(sec), out
+
+
+# ---------------- geometry selection ----------------
+class GoShape(C.Structure):
+    _fields_ = [("kind", C.c_int), ("position", C.c_float * 3), ("size", C.c_float * 3), ("base2", C.c_float * 3),
+                ("base3", C.c_float * 3), ("orientation", C.c_int), ("plane", C.c_int)]
+
+
+SHAPE_SPHERE, SHAPE_RECTANGULAR, SHAPE_CYLINDER, SHAPE_PRISM = 1, 2, 3, 4
+_PLANE_OF = {"x": "yz", "y": "xz", "z": "xy"}
+
+
+def shape(spec):
+    """spec = dict(kind='sphere'|'rectangular'|'cylinder'|'prism', ...) as in tests/golden/shape_cases.json"""
+    s = GoShape()
+    k = spec["kind"]
+    if k == "sphere":
+        s.kind = SHAPE_SPHERE; s.position[:] = spec["position"]; s.size[0] = spec["radius"]
+    elif k == "rectangular":
+        s.kind = SHAPE_RECTANGULAR; s.position[:] = spec["position"]; s.size[:] = spec["size"]
+    elif k == "cylinder":
+        s.kind = SHAPE_CYLINDER; s.position[:] = spec["position"]; s.size[0] = spec["radius"]; s.size[1] = spec["height"]
+        o = spec["orientation"].lower(); s.orientation = DIM[o]; s.plane = DIM[_PLANE_OF[o]]
+    elif k == "prism":
+        b1, b2, b3 = (_f(spec[n]) for n in ("base1", "base2", "base3"))
+        st = lib().go_shape_prism_init(C.byref(s), _p(b1), _p(b2), _p(b3), C.c_float(spec["height"]))
+        if st != 0:
+            raise OracleError(100 + st)
+    else:
+        raise ValueError(k)
+    return s
+
+
+def shape_inside(spec, point, box):
+    s = spec if isinstance(spec, GoShape) else shape(spec)
+    return bool(lib().go_shape_inside(C.byref(s), _p(_f(point)), _p(_box(box))))
+
+
+def shape_inside_naive(spec, point):
+    s = spec if isinstance(spec, GoShape) else shape(spec)
+    return lib().go_shape_inside_naive(C.byref(s), _p(_f(point))) == 1
+
+
+def group_from_geometries(pos, idx, box, specs, naive=False):
+    pos = _f(pos); idx = _u(idx)
+    arr = (GoShape * len(specs))(*[s if isinstance(s, GoShape) else shape(s) for s in specs])
+    out = np.zeros(idx.size, np.uint64)
+    lib().go_group_from_geometries.restype = C.c_size_t
+    n = lib().go_group_from_geometries(_p(pos), C.c_size_t(12), _p(idx), C.c_size_t(idx.size), _p(_box(box)), arr,
+                                       C.c_size_t(len(specs)), C.c_int(int(naive)), _p(out))
+    return out[:n]
