@@ -19,6 +19,9 @@
 #include "gr_xtc.h"
 #include "gr_persist.h"
 #include "gr_shape.h"
+#include "gr_xtc_dev.h"
+#include <thread>
+#include <atomic>
 
 #define GR_MAX_BATCH 256     // frames per batched call segment (workspace is sized for this)
 #define GR_MAX_CHUNKS 256    // workgroups per frame in the reduction kernels
@@ -94,6 +97,9 @@ struct gr_ctx {
     uint32_t *ps_sync = nullptr;      // [2 + 2 * GR_MAX_BATCH]
     uint32_t *ps_sync_host = nullptr; // pinned [2]
     unsigned long long *ps_trace = nullptr;   // GR_PS_TRACE=<file>: time stamps of the last persistent launch, dumped to <file>
+    // device-side xtc unpacking (gr_xtc_read_frames_device): grow-only staging, pinned host mirror + device copy
+    unsigned char *xtc_host = nullptr, *xtc_dev = nullptr; size_t xtc_cap = 0;
+    hipEvent_t xtc_ev = nullptr;      // the previous batch's H2D has consumed the pinned staging buffer
     std::string ps_trace_path;
     int strict = 0;
     std::string err;
@@ -431,6 +437,9 @@ void gr_ctx_destroy(gr_ctx *c) {
     if (c->ps_rmsd) (void)hipFree(c->ps_rmsd);
     if (c->ps_sync) (void)hipFree(c->ps_sync);
     if (c->ps_trace) (void)hipFree(c->ps_trace);
+    if (c->xtc_host) (void)hipHostFree(c->xtc_host);
+    if (c->xtc_dev) (void)hipFree(c->xtc_dev);
+    if (c->xtc_ev) (void)hipEventDestroy(c->xtc_ev);
     if (c->ps_sync_host) (void)hipHostFree(c->ps_sync_host);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -1224,6 +1233,102 @@ int gr_xtc_read_frame(const gr_xtc *x, uint64_t frame, float *xyz, float box9[9]
     if (st != GR_OK) return st;
     static thread_local std::vector<unsigned char> scratch;   // one bit-stream buffer per decoding thread
     return xtc_status(grx::decode_frame(x->f, x->f.frames[frame], xyz, scratch));
+}
+
+int gr_xtc_read_frames_device(const gr_xtc *x, uint64_t first_frame, uint32_t n_frames, uint64_t frame_step, gr_ctx *c,
+                              uint32_t first_slot, int host_threads, uint64_t *steps, float *times) {
+    if (!x || !c) return GR_E_INVALID_ARG;
+    int st = slot_check(c, first_slot, n_frames); if (st) return st;
+    if (frame_step == 0) frame_step = 1;
+    if (first_frame + (uint64_t)(n_frames - 1) * frame_step >= x->f.frames.size()) return fail(c, GR_E_OUT_OF_RANGE, "xtc frame out of range", first_frame);
+    if (x->f.natoms != c->n) return fail(c, GR_E_INVALID_ARG, "the trajectory's atom count differs from the context's");
+    (void)hipSetDevice(c->device);
+    const uint32_t n = x->f.natoms;
+    if (n <= 9) {   // uncompressed frames: nothing to unpack
+        std::vector<float> xyz(3 * (size_t)n);
+        for (uint32_t k = 0; k < n_frames; ++k) {
+            float box9[9];
+            st = gr_xtc_read_frame(x, first_frame + k * frame_step, xyz.data(), box9, steps ? steps + k : nullptr, times ? times + k : nullptr, nullptr); if (st) return st;
+            st = gr_frame_upload(c, first_slot + k, xyz.data(), box9); if (st) return st;
+            st = gr_frame_upload_wait(c, first_slot + k); if (st) return st;
+        }
+        return GR_OK;
+    }
+    // ---- layout of the batch's staging buffer: [streams (16-byte aligned, 16 zero bytes behind each)] [descs] [slots] [checkpoints]
+    const uint32_t ncp = (n + GR_XTC_CP_ATOMS - 1) / GR_XTC_CP_ATOMS;
+    std::vector<size_t> soff(n_frames);
+    size_t bytes = 0;
+    for (uint32_t k = 0; k < n_frames; ++k) {
+        const grx::FrameIndex &fi = x->f.frames[first_frame + k * frame_step];
+        soff[k] = bytes; bytes += ((size_t)fi.nbytes + 16 + 15) & ~(size_t)15;
+    }
+    const size_t off_desc = bytes;  bytes += (size_t)n_frames * sizeof(grx::FrameDesc);
+    const size_t off_slot = bytes;  bytes += (((size_t)n_frames * sizeof(uint32_t)) + 15) & ~(size_t)15;
+    const size_t off_cp = bytes;    bytes += (size_t)n_frames * ncp * sizeof(grx::Checkpoint);
+    if (c->xtc_ev) HIPCHK(c, hipEventSynchronize(c->xtc_ev));       // the previous batch has left the pinned buffer
+    else HIPCHK(c, hipEventCreateWithFlags(&c->xtc_ev, hipEventDisableTiming));
+    if (bytes > c->xtc_cap) {
+        HIPCHK(c, hipStreamSynchronize(c->copy_stream));
+        if (c->xtc_host) (void)hipHostFree(c->xtc_host);
+        if (c->xtc_dev) (void)hipFree(c->xtc_dev);
+        c->xtc_host = nullptr; c->xtc_dev = nullptr; c->xtc_cap = 0;
+        const size_t cap = bytes + bytes / 4;
+        HIPCHK(c, hipHostMalloc(&c->xtc_host, cap, hipHostMallocDefault));
+        HIPCHK(c, hipMalloc(&c->xtc_dev, cap));
+        c->xtc_cap = cap;
+    }
+    unsigned char *H = c->xtc_host;
+    grx::FrameDesc *descs = reinterpret_cast<grx::FrameDesc *>(H + off_desc);
+    uint32_t *slots = reinterpret_cast<uint32_t *>(H + off_slot);
+    grx::Checkpoint *cps = reinterpret_cast<grx::Checkpoint *>(H + off_cp);
+    // ---- host: read + skim, one frame per worker at a time
+    std::atomic<uint32_t> next(0);
+    std::atomic<int> bad(grx::XTC_OK);
+    auto work = [&]() {
+        std::vector<grx::Checkpoint> local;
+        for (;;) {
+            const uint32_t k = next.fetch_add(1);
+            if (k >= n_frames) return;
+            const grx::FrameIndex &fi = x->f.frames[first_frame + k * frame_step];
+            unsigned char *dst = H + soff[k];
+            if (!grx::pread_all(x->f.fd, dst, (size_t)fi.nbytes, fi.data_offset)) { bad = grx::XTC_E_IO; return; }
+            memset(dst + fi.nbytes, 0, (((size_t)fi.nbytes + 16 + 15) & ~(size_t)15) - (size_t)fi.nbytes);
+            grx::FrameDesc d; memset(&d, 0, sizeof d);
+            d.stream_off = soff[k]; d.cp_off = (uint64_t)k * ncp;
+            const int r = grx::skim_frame(dst, fi, n, d, local);
+            if (r != grx::XTC_OK || local.size() != ncp) { bad = r != grx::XTC_OK ? r : (int)grx::XTC_E_FORMAT; return; }
+            memcpy(cps + (size_t)k * ncp, local.data(), ncp * sizeof(grx::Checkpoint));
+            descs[k] = d; slots[k] = first_slot + k;
+        }
+    };
+    uint32_t nt = host_threads > 0 ? (uint32_t)host_threads : std::min<uint32_t>(n_frames, 16u);
+    nt = std::max<uint32_t>(1u, std::min<uint32_t>(nt, n_frames));
+    if (nt == 1) work();
+    else { std::vector<std::thread> th; for (uint32_t t = 0; t < nt; ++t) th.emplace_back(work); for (auto &t : th) t.join(); }
+    if (bad.load() != grx::XTC_OK) return fail(c, xtc_status(bad.load()), "corrupt or unreadable xtc frame");
+    // ---- device: behind the last kernels that still read these slots; boxes like gr_frame_upload
+    for (uint32_t k = 0; k < n_frames; ++k) {
+        const uint32_t slot = first_slot + k;
+        if (!c->ev_ready[slot]) HIPCHK(c, hipEventCreateWithFlags(&c->ev_ready[slot], hipEventDisableTiming));
+        if (c->slot_gen[slot]) HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->ev_done_ring[c->slot_gen[slot] % 64], 0));
+        if (c->upload_pending[slot]) HIPCHK(c, hipEventSynchronize(c->ev_ready[slot]));
+    }
+    HIPCHK(c, hipMemcpyAsync(c->xtc_dev, H, bytes, hipMemcpyHostToDevice, c->copy_stream));
+    HIPCHK(c, hipEventRecord(c->xtc_ev, c->copy_stream));
+    k_xtc_unpack<<<dim3((ncp + 255) / 256, n_frames), dim3(256), 0, c->copy_stream>>>(
+        c->xtc_dev, reinterpret_cast<const grx::FrameDesc *>(c->xtc_dev + off_desc), reinterpret_cast<const grx::Checkpoint *>(c->xtc_dev + off_cp),
+        c->frames, c->frame_stride, reinterpret_cast<const uint32_t *>(c->xtc_dev + off_slot), n);
+    HIPCHK(c, hipGetLastError());
+    for (uint32_t k = 0; k < n_frames; ++k) {
+        const uint64_t fr = first_frame + k * frame_step;
+        float box9[9];
+        st = gr_xtc_frame_info(x, fr, steps ? steps + k : nullptr, times ? times + k : nullptr, box9, nullptr);
+        if (st != GR_OK) return fail(c, st, "unsupported box in xtc frame", fr);
+        st = set_box(c, first_slot + k, box9, c->copy_stream); if (st) return st;
+        HIPCHK(c, hipEventRecord(c->ev_ready[first_slot + k], c->copy_stream));
+        c->upload_pending[first_slot + k] = 1;
+    }
+    return GR_OK;
 }
 
 /* ------------------------------------------------------------ measurement / synthetic data */

@@ -233,4 +233,79 @@ inline int decode_frame(const File &f, const FrameIndex &fi, float *xyz, std::ve
     return XTC_OK;
 }
 
+
+// ---- GPU-side unpacking (gr_xtc_dev.h): the host only SKIMS a frame's bit stream -- group boundaries depend on the
+// flag / run-length fields alone, no unpacking, no division -- and records the decoder state every GR_XTC_CP_ATOMS
+// atoms; the device then unpacks all the segments of all the frames of a batch in parallel.
+#define GR_XTC_CP_ATOMS 32
+struct Checkpoint { uint32_t bitpos, atom, state; };   // state = smallidx | run << 8, at the first group that starts at atom >= 32 m
+struct FrameDesc {                                      // one per frame of a batch (plain data, copied to the device)
+    uint64_t stream_off;       // byte offset of the frame's bit stream in the batch's stream buffer (16-byte aligned, zero padded)
+    uint64_t cp_off;           // index of the frame's first checkpoint
+    uint32_t nbytes, n_cp;
+    int32_t minint[3]; uint32_t sizeint[3];
+    int32_t bitsize, bitsizeint[3];
+    float inv_precision;
+    uint32_t pad;
+};
+
+inline uint32_t peek_bits(const unsigned char *p, uint64_t bitpos, int n) {   // n <= 32; p is padded by >= 8 bytes
+    const uint64_t w = be64(p + (bitpos >> 3));
+    return (uint32_t)((w >> (64 - (int)(bitpos & 7) - n)) & ((n == 32) ? 0xFFFFFFFFull : ((1ull << n) - 1)));
+}
+
+// Walk the groups of one frame (natoms > 9): fills the descriptor's decoding constants and the checkpoints.
+inline int skim_frame(const unsigned char *stream, const FrameIndex &fi, uint32_t n, FrameDesc &d, std::vector<Checkpoint> &cps) {
+    for (int k = 0; k < 3; ++k) { d.minint[k] = fi.minint[k]; d.sizeint[k] = (uint32_t)(fi.maxint[k] - fi.minint[k] + 1); }
+    d.bitsizeint[0] = d.bitsizeint[1] = d.bitsizeint[2] = 0;
+    int large_bits;
+    if ((d.sizeint[0] | d.sizeint[1] | d.sizeint[2]) > 0xffffffu) {
+        for (int k = 0; k < 3; ++k) { int b = bit_length(d.sizeint[k]); d.bitsizeint[k] = b > 32 ? 32 : b; }
+        d.bitsize = 0;
+        large_bits = d.bitsizeint[0] + d.bitsizeint[1] + d.bitsizeint[2];
+    } else {
+        d.bitsize = bit_length((unsigned __int128)d.sizeint[0] * d.sizeint[1] * d.sizeint[2]);
+        large_bits = d.bitsize;
+    }
+    d.inv_precision = (float)(1.0 / (double)fi.precision);
+    d.nbytes = (uint32_t)fi.nbytes;
+    if (fi.nbytes >= (1ull << 29)) return XTC_E_FORMAT;        // bit positions are 32-bit
+    const uint64_t limit_bits = (fi.nbytes + 8) * 8;
+    cps.clear();
+    int smallidx = fi.smallidx, run = 0;
+    uint64_t bitpos = 0;
+    uint32_t i = 0, next_cp = 0;
+    while (i < n) {
+        if (i >= next_cp) {
+            while (next_cp <= i) { cps.push_back(Checkpoint{ (uint32_t)bitpos, i, (uint32_t)smallidx | ((uint32_t)run << 8) }); next_cp += GR_XTC_CP_ATOMS; }
+        }
+        bitpos += (uint64_t)large_bits;
+        ++i;
+        int change = 0;
+        if (peek_bits(stream, bitpos, 1)) {
+            run = (int)peek_bits(stream, bitpos + 1, 5);
+            bitpos += 6;
+            change = run % 3;
+            run -= change;
+            change -= 1;
+        } else {
+            bitpos += 1;
+        }
+        if (run > 0) {
+            if ((uint64_t)i + (uint64_t)(run / 3) > n) return XTC_E_FORMAT;
+            bitpos += (uint64_t)(run / 3) * (uint64_t)smallidx;
+            i += (uint32_t)(run / 3);
+        }
+        if (bitpos > limit_bits) return XTC_E_FORMAT;
+        smallidx += change;
+        if (smallidx < kFirstIdx || smallidx >= kLastIdx) return XTC_E_FORMAT;
+    }
+    // one checkpoint per started window of 32 atoms, whether or not a group starts inside it (it always does: a group
+    // holds at most 9 atoms); pad so that the count is exactly ceil(n / 32)
+    const uint32_t want = (n + GR_XTC_CP_ATOMS - 1) / GR_XTC_CP_ATOMS;
+    while (cps.size() < want) cps.push_back(Checkpoint{ (uint32_t)bitpos, n, (uint32_t)smallidx });
+    d.n_cp = (uint32_t)cps.size();
+    return XTC_OK;
+}
+
 }  // namespace grx

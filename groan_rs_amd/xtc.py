@@ -58,6 +58,17 @@ class XtcFile:
             raise XtcError(st, "read_frame(%d)" % i)
         return out, box, int(step.value), float(time.value), float(prec.value)
 
+    def read_frames_device(self, system, first_frame, n_frames, first_slot=0, frame_step=1, host_threads=0):
+        """frames first_frame, first_frame + frame_step, ... -> slots first_slot.. of `system`, unpacked on the GPU
+        (gr_xtc_read_frames_device): only the compressed stream crosses PCIe.  Asynchronous like upload_async.
+        -> (steps uint64[n], times float32[n])"""
+        steps = np.zeros(n_frames, np.uint64); times = np.zeros(n_frames, np.float32)
+        st = self._lib.gr_xtc_read_frames_device(self._x, first_frame, n_frames, frame_step, system._ctx, first_slot, host_threads,
+                                                 steps.ctypes.data_as(C.c_void_p), times.ctypes.data_as(C.c_void_p))
+        if st != _lib.OK:
+            raise XtcError(st, "read_frames_device(%d, %d): %s" % (first_frame, n_frames, self._lib.gr_last_error(system._ctx).decode(errors="replace")))
+        return steps, times
+
     def frames(self, start=0, stop=None, step=1):
         """iterable for TrajReader: (positions, box9, step, time) -- `xtc_iter(..).with_range/with_step` in frame indices"""
         stop = self.n_frames if stop is None else min(stop, self.n_frames)

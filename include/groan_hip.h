@@ -242,6 +242,14 @@ uint64_t gr_xtc_n_atoms(const gr_xtc *xtc);
 uint64_t gr_xtc_n_frames(const gr_xtc *xtc);
 int gr_xtc_frame_info(const gr_xtc *xtc, uint64_t frame, uint64_t *step, float *time, float box9[9], float *precision);
 int gr_xtc_read_frame(const gr_xtc *xtc, uint64_t frame, float *xyz, float box9[9], uint64_t *step, float *time, float *precision);
+/* The same for a batch, unpacked ON THE DEVICE: frames first_frame, first_frame + frame_step, ... (n_frames of them) land
+ * in slots first_slot .. first_slot + n_frames - 1 of `ctx` with their boxes, like n gr_frame_upload calls -- but what
+ * crosses PCIe is the compressed bit stream (~3.5 B/atom instead of 12) and the host only skims the group framing
+ * (`host_threads` workers, 0 = one per frame up to 16), the unpacking of all frames runs as one kernel on the copy stream.
+ * Asynchronous like gr_frame_upload (kernels that use the slots are ordered behind it; gr_frame_upload_wait to block).
+ * Results are bit-identical to gr_xtc_read_frame.  steps / times may be NULL. */
+int gr_xtc_read_frames_device(const gr_xtc *xtc, uint64_t first_frame, uint32_t n_frames, uint64_t frame_step, gr_ctx *ctx,
+                              uint32_t first_slot, int host_threads, uint64_t *steps, float *times);
 
 /* ---------------------------------------------------------------- measurement / synthetic data
  * HIP-event timing on the context's stream (the stream the kernels are launched on). */

@@ -1,0 +1,80 @@
+"""Device-side xtc unpacking (gr_xtc_read_frames_device: host skims the framing, k_xtc_unpack decodes every 32-atom segment
+of every frame of the batch in parallel) must be BIT-IDENTICAL to the host decoder (gr_xtc_read_frame), which is
+bit-identical to the reference's decoders (tests/test_xtc_decoder.py).  Reference: XtcReader / update_system
+(src/io/xtc_io/mod.rs, molly_xtc.rs:268-308, xdrfile_xtc.rs:42-104)."""
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+from test_xtc_decoder import GOLD, REF_SO, water_like, write_with_ref
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def G():
+    import groan_rs_amd as g
+    g._lib.load()
+    return g
+
+
+def check_file(G, path, batch=None, frame_step=1, host_threads=0):
+    x = G.XtcFile(path)
+    idx = list(range(0, x.n_frames, frame_step))
+    nb = len(idx) if batch is None else batch
+    s = G.System(x.n_atoms, n_slots=nb)
+    for b0 in range(0, len(idx), nb):
+        part = idx[b0:b0 + nb]
+        steps, times = x.read_frames_device(s, part[0], len(part), first_slot=0, frame_step=frame_step, host_threads=host_threads)
+        for k, fr in enumerate(part):
+            pos, box, step, time, _ = x.read_frame(fr)
+            got = s.get_positions(k)
+            assert np.array_equal(got.view(np.uint32), pos.view(np.uint32)), (path, fr, np.abs(got - pos).max())
+            assert np.array_equal(s.get_box(k), box) and steps[k] == step and times[k] == np.float32(time)
+    s.close(); x.close()
+
+
+@pytest.mark.parametrize("name", ["triclinic_trajectory.xtc", "octahedron_trajectory.xtc", "dodecahedron_trajectory.xtc", "short_trajectory.xtc"])
+def test_reference_data_files(G, name):
+    check_file(G, os.path.join(GOLD, name))
+    check_file(G, os.path.join(GOLD, name), batch=4, frame_step=2, host_threads=3)    # ragged last batch, strided frames, slot reuse
+
+
+@pytest.mark.parametrize("case", ["tiny9", "water", "gas", "wide_range", "wide_product", "high_precision", "mixed", "big_water"])
+def test_every_branch_of_the_format(G, tmp_path, case):
+    if not os.path.exists(REF_SO):
+        pytest.skip("oracle/_ref not built (reference tree absent)")
+    rng = np.random.default_rng(zlib.crc32(case.encode()))
+    box = np.array([[30, 0, 0], [0, 30, 0], [10, 10, 25]], np.float32)
+    prec = 1000.0
+    if case == "tiny9": frames = [rng.uniform(0, 5, (9, 3)).astype(np.float32)] * 3
+    elif case == "water": frames = [water_like(rng, 30000, 20.0) for _ in range(3)]
+    elif case == "gas": frames = [rng.uniform(-50, 50, (5000, 3)).astype(np.float32) for _ in range(3)]
+    elif case == "wide_range": frames = [np.concatenate([rng.uniform(0, 10, (4000, 3)), [[20000.0, 3.0, 4.0]]]).astype(np.float32) for _ in range(2)]
+    elif case == "wide_product": frames = [rng.uniform(0, 8000, (3000, 3)).astype(np.float32) for _ in range(2)]
+    elif case == "high_precision":
+        prec = 100000.0
+        frames = [water_like(rng, 3000, 6.0) for _ in range(3)]
+    elif case == "big_water": frames = [water_like(rng, 500_000, 17.0) for _ in range(2)]                  # config 5 size
+    else: frames = [np.concatenate([water_like(rng, 9000, 12.0), rng.uniform(0, 12, (1000, 3)).astype(np.float32), water_like(rng, 2001, 3.0)]) for _ in range(4)]
+    path = tmp_path / (case + ".xtc")
+    write_with_ref(path, frames, box, prec)
+    check_file(G, path)
+
+
+def test_decoded_slots_feed_the_kernels(G, short_traj, example):
+    """decode -> (no host copy) -> centre of geometry of the Protein per frame == the same through read_frame + set_frame"""
+    x = G.XtcFile(os.path.join(GOLD, "short_trajectory.xtc"))
+    s = G.System(x.n_atoms, n_slots=x.n_frames)
+    s.group_create_from_ranges("Protein", [(0, 60)])
+    x.read_frames_device(s, 0, x.n_frames)
+    got = [s.group_get_center("Protein", slot=f) for f in range(x.n_frames)]           # ordered behind the unpack by the slot events
+    t = G.System(x.n_atoms, n_slots=1)
+    t.group_create_from_ranges("Protein", [(0, 60)])
+    for f in range(x.n_frames):
+        pos, box, _, _, _ = x.read_frame(f)
+        t.set_frame(pos, box)
+        assert np.array_equal(t.group_get_center("Protein"), got[f])
+    s.close(); t.close(); x.close()

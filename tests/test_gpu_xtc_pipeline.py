@@ -118,6 +118,35 @@ def test_decode_upload_com_wrap_pipeline(tmp_path):
            "decode_one_thread_frames_per_s": round(1.0 / t_dec1, 1), "pipeline_frames_per_s": round(n_frames / t_all, 1),
            "pipeline_wall_s": round(t_all, 3), "reference_writer_s": round(t_write, 2),
            "stages": "xtc decode (host threads) || H2D copy stream || group_get_com + atoms_center_mass (all atoms) on the GPU"}
+    # ---- the same pipeline with the frames unpacked ON THE DEVICE: host skims the framing (n_threads workers), the
+    # compressed stream crosses PCIe, k_xtc_unpack decodes a batch of frames in one launch on the copy stream
+    B = n_buf
+    t0 = time.perf_counter()
+    for f0 in range(0, 2 * B, B):                                                    # warm-up (staging buffers, first launch)
+        x.read_frames_device(sysd, f0, B, first_slot=0, host_threads=n_threads)
+    sysd.sync()
+    t_skim = time.perf_counter()
+    for f0 in range(0, n_frames, B):
+        x.read_frames_device(sysd, f0, B, first_slot=0, host_threads=n_threads)
+    for s_ in range(B):
+        sysd.upload_wait(s_)
+    t_unpack_only = (time.perf_counter() - t_skim) / n_frames                        # skim + H2D + unpack, no analysis
+    coms_dev, wrapped_dev = [], None
+    t0 = time.perf_counter()
+    for f0 in range(0, n_frames, B):
+        x.read_frames_device(sysd, f0, B, first_slot=0, host_threads=n_threads)
+        for k in range(B):
+            coms_dev.append(sysd.group_get_com("Solute", slot=k))
+            sysd.atoms_center_mass("Solute", G.Dimension.XYZ, slot=k)
+            if f0 + k == 1:
+                wrapped_dev = sysd.get_positions(k)
+    sysd.sync()
+    t_dev = time.perf_counter() - t0
+    assert np.array_equal(np.array(coms_dev), np.array(coms))                        # same decoded bits -> same results
+    assert np.array_equal(wrapped_dev, wrapped_first)
+    out["device_unpack_pipeline_frames_per_s"] = round(n_frames / t_dev, 1)
+    out["device_unpack_only_frames_per_s"] = round(1.0 / t_unpack_only, 1)
+    out["device_unpack_batch"] = B
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     json.dump(out, open(os.path.join(ROOT, "gpurun_out", "xtc_pipeline.json"), "w"), indent=1)
     print(out)
