@@ -51,6 +51,8 @@ struct gr_ctx {
     uint64_t done_gen = 0;
     std::vector<uint64_t> slot_gen;         // per slot: generation of the last compute call that touched it
     hipEvent_t ev_grp[GR_MAX_BATCH] = {};   // "finalize of group k done" (stream -> stream2)
+    hipEvent_t ev_skew[3 * GR_MAX_BATCH] = {};   // skewed order: [3g] sums of group g done, [3g+1] finalize done, [3g+2] fit done
+    int skew = 0;                     // GR_SKEW=1: small kernels on the second stream beside the next group's sums pass (measured slower)
     hipEvent_t ev_join = nullptr;           // "all fits done" (stream2 -> stream)
     int overlap = 0;   // GR_OVERLAP=1: +5 % frames/s at 256-frame calls (measured), but per-kernel durations then overlap
     uint64_t n = 0, n_pad = 0;
@@ -78,7 +80,7 @@ struct gr_ctx {
     float *pd_out = nullptr; size_t pd_cap = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // per-kernel HIP-event profile of the batched RMSD path (gr_profile_*): 0 accumulate, 1 finalize, 2 fit
-    hipEvent_t pev[4 * GR_MAX_BATCH] = {};
+    hipEvent_t pev[6 * GR_MAX_BATCH] = {};   // per group: begin / end of the sums, finalize and fit kernels
     // launch geometry of the batched RMSD path (env GR_SUB_BATCH / GR_CHUNKS / GR_FIT_WGS override)
     uint32_t sub_batch = 64;    // frames per accumulate->finalize->fit group.  k_rmsd_accum is VALU-bound (~70 % VALU busy,
                                 // 13 MB/frame of HBM traffic) and k_fit is HBM-bound (24 MB/frame), so the fit of group k is
@@ -368,7 +370,11 @@ gr_ctx *gr_ctx_create(int device, uint64_t n_atoms, uint32_t n_slots, int *statu
     c->frame_stride = (size_t)c->n_pad * 3;
     bool ok = true;
     ok = ok && hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
-    ok = ok && hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) == hipSuccess;
+    {   // the second queue carries the small latency-critical kernels of the skewed order: highest priority
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        ok = ok && hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, hi) == hipSuccess;
+    }
     ok = ok && hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) == hipSuccess;
     for (int k = 0; k < 64; ++k) ok = ok && hipEventCreateWithFlags(&c->ev_done_ring[k], hipEventDisableTiming) == hipSuccess;
     c->ev_ready.assign(n_slots, nullptr); c->upload_pending.assign(n_slots, 0); c->slot_gen.assign(n_slots, 0);
@@ -377,6 +383,7 @@ gr_ctx *gr_ctx_create(int device, uint64_t n_atoms, uint32_t n_slots, int *statu
     if (const char *e = getenv("GR_OVERLAP")) c->overlap = atoi(e) ? 1 : 0;
     if (const char *e = getenv("GR_PERSIST")) { const int v = atoi(e); c->persist = v < 0 ? 0 : (v > 2 ? 2 : v); }
     if (const char *e = getenv("GR_TWO_PASS")) c->two_pass = atoi(e) ? 1 : 0;
+    if (const char *e = getenv("GR_SKEW")) c->skew = atoi(e) ? 1 : 0;
     if (const char *e = getenv("GR_PS_TRACE")) c->ps_trace_path = e;
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cus = (uint32_t)prop.multiProcessorCount; }
     ok = ok && hipMalloc(&c->ps_sync, (2 + 2 * GR_MAX_BATCH) * sizeof(uint32_t)) == hipSuccess;
@@ -392,7 +399,8 @@ gr_ctx *gr_ctx_create(int device, uint64_t n_atoms, uint32_t n_slots, int *statu
     ok = ok && hipMalloc(&c->bad_dev, 4 * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipHostMalloc(&c->bad_host, 4 * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess;
     ok = ok && hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess;
-    for (int k = 0; k < 4 * GR_MAX_BATCH; ++k) ok = ok && hipEventCreate(&c->pev[k]) == hipSuccess;
+    for (int k = 0; k < 6 * GR_MAX_BATCH; ++k) ok = ok && hipEventCreate(&c->pev[k]) == hipSuccess;
+    for (int k = 0; k < 3 * GR_MAX_BATCH; ++k) ok = ok && hipEventCreateWithFlags(&c->ev_skew[k], hipEventDisableTiming) == hipSuccess;
     if (const char *e = getenv("GR_SUB_BATCH")) { int v = atoi(e); if (v >= 1 && v <= GR_MAX_BATCH) c->sub_batch = (uint32_t)v; }
     if (const char *e = getenv("GR_CHUNKS")) { int v = atoi(e); if (v >= 1 && v <= GR_MAX_CHUNKS) c->chunks = (uint32_t)v; }
     if (const char *e = getenv("GR_FIT_WGS")) { int v = atoi(e); if (v >= 1 && v <= 65535) c->fit_wgs = (uint32_t)v; }
@@ -443,7 +451,8 @@ void gr_ctx_destroy(gr_ctx *c) {
     if (c->ps_sync_host) (void)hipHostFree(c->ps_sync_host);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
-    for (int k = 0; k < 4 * GR_MAX_BATCH; ++k) if (c->pev[k]) (void)hipEventDestroy(c->pev[k]);
+    for (int k = 0; k < 6 * GR_MAX_BATCH; ++k) if (c->pev[k]) (void)hipEventDestroy(c->pev[k]);
+    for (int k = 0; k < 3 * GR_MAX_BATCH; ++k) if (c->ev_skew[k]) (void)hipEventDestroy(c->ev_skew[k]);
     for (int k = 0; k < GR_MAX_BATCH; ++k) if (c->ev_grp[k]) (void)hipEventDestroy(c->ev_grp[k]);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     for (hipEvent_t e : c->ev_ready) if (e) (void)hipEventDestroy(e);
@@ -1004,42 +1013,92 @@ static int segment_begin(gr_rmsd_plan *p, uint32_t s0, uint32_t nb, int fit) {
                 c->fit_partials_cap = need;
             }
         }
-        for (uint32_t f0 = 0; f0 < nb; f0 += sb, ++ng) {
-            const uint32_t nf = std::min<uint32_t>(sb, nb - f0);
-            const uint32_t nch = batch_chunks(c, sel, nf);
-            hipEvent_t *ev = c->pev + 4 * ng;
+        const uint32_t n_groups = (nb + sb - 1) / sb;
+        // The kernels of one group, each bracketed by its own pair of profiling events on the stream it runs on
+        auto group_nf = [&](uint32_t g) { return std::min<uint32_t>(sb, nb - g * sb); };
+        auto launch_sums = [&](uint32_t g, hipStream_t on) -> int {
+            const uint32_t f0 = g * sb, nf = group_nf(g), nch = batch_chunks(c, sel, nf);
             GrAccPartial *parts = c->acc_partials + (size_t)f0 * GR_MAX_CHUNKS;
-            if (c->profile) HIPCHK(c, hipEventRecord(ev[0], c->stream));
-            if (lite) k_rmsd_accum<0, true><<<dim3(nch, nf), dim3(GR_WG), 0, c->stream>>>(c->frames, c->frame_stride, s0 + f0, c->masses, sel, c->boxes_dev, p->dev, c->state_dev + f0, parts);
-            else k_rmsd_accum<0><<<dim3(nch, nf), dim3(GR_WG), 0, c->stream>>>(c->frames, c->frame_stride, s0 + f0, c->masses, sel, c->boxes_dev, p->dev, c->state_dev + f0, parts);
-            if (c->profile) HIPCHK(c, hipEventRecord(ev[1], c->stream));
-            if (lite) k_rmsd_finalize<0, true><<<dim3(nf), dim3(GR_WG), 0, c->stream>>>(parts, nch, c->frames, c->frame_stride, s0 + f0, sel, c->boxes_dev, p->dev, c->state_dev + f0);
-            else k_rmsd_finalize<0><<<dim3(nf), dim3(GR_WG), 0, c->stream>>>(parts, nch, c->frames, c->frame_stride, s0 + f0, sel, c->boxes_dev, p->dev, c->state_dev + f0);
-            if (c->profile && !two) HIPCHK(c, hipEventRecord(ev[2], c->stream));
-            if (fit) {
-                hipStream_t fs = c->stream;
-                if (two) {
-                    HIPCHK(c, hipEventRecord(c->ev_grp[ng], c->stream));
-                    HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_grp[ng], 0));
-                    fs = c->stream2;
-                    if (c->profile) HIPCHK(c, hipEventRecord(ev[2], fs));
-                }
-                const uint32_t gx = fit_grid(c, nf);
-                if (lite) {
-                    double *fp = c->fit_partials + (size_t)f0 * gx;
-                    k_fit<true><<<dim3(gx, nf), dim3(GR_WG), 0, fs>>>(c->frames, c->frame_stride, s0 + f0, (uint32_t)c->n, c->boxes_dev, p->dev, c->state_dev + f0, c->masses, sel, fp);
-                    if (c->profile) HIPCHK(c, hipEventRecord(ev[3], fs));
-                    k_rmsd_close<<<dim3(nf), dim3(64), 0, fs>>>(fp, gx, p->dev.sw, c->state_dev + f0);
-                } else {
-                    k_fit<false><<<dim3(gx, nf), dim3(GR_WG), 0, fs>>>(c->frames, c->frame_stride, s0 + f0, (uint32_t)c->n, c->boxes_dev, p->dev, c->state_dev + f0, c->masses, sel, nullptr);
-                    if (c->profile) HIPCHK(c, hipEventRecord(ev[3], fs));
+            if (c->profile) HIPCHK(c, hipEventRecord(c->pev[6 * g], on));
+            if (lite) k_rmsd_accum<0, true><<<dim3(nch, nf), dim3(GR_WG), 0, on>>>(c->frames, c->frame_stride, s0 + f0, c->masses, sel, c->boxes_dev, p->dev, c->state_dev + f0, parts);
+            else k_rmsd_accum<0><<<dim3(nch, nf), dim3(GR_WG), 0, on>>>(c->frames, c->frame_stride, s0 + f0, c->masses, sel, c->boxes_dev, p->dev, c->state_dev + f0, parts);
+            if (c->profile) HIPCHK(c, hipEventRecord(c->pev[6 * g + 1], on));
+            return GR_OK;
+        };
+        auto launch_finalize = [&](uint32_t g, hipStream_t on) -> int {
+            const uint32_t f0 = g * sb, nf = group_nf(g), nch = batch_chunks(c, sel, nf);
+            GrAccPartial *parts = c->acc_partials + (size_t)f0 * GR_MAX_CHUNKS;
+            if (c->profile) HIPCHK(c, hipEventRecord(c->pev[6 * g + 2], on));
+            if (lite) k_rmsd_finalize_lite<<<dim3(nf), dim3(64), 0, on>>>(parts, nch, c->frames, c->frame_stride, s0 + f0, sel, c->boxes_dev, p->dev, c->state_dev + f0);
+            else k_rmsd_finalize<0><<<dim3(nf), dim3(GR_WG), 0, on>>>(parts, nch, c->frames, c->frame_stride, s0 + f0, sel, c->boxes_dev, p->dev, c->state_dev + f0);
+            if (c->profile) HIPCHK(c, hipEventRecord(c->pev[6 * g + 3], on));
+            return GR_OK;
+        };
+        auto launch_fit = [&](uint32_t g, hipStream_t on) -> int {
+            const uint32_t f0 = g * sb, nf = group_nf(g), gx = fit_grid(c, nf);
+            if (c->profile) HIPCHK(c, hipEventRecord(c->pev[6 * g + 4], on));
+            if (lite) k_fit<true><<<dim3(gx, nf), dim3(GR_WG), 0, on>>>(c->frames, c->frame_stride, s0 + f0, (uint32_t)c->n, c->boxes_dev, p->dev, c->state_dev + f0, c->masses, sel, c->fit_partials + (size_t)f0 * gx);
+            else k_fit<false><<<dim3(gx, nf), dim3(GR_WG), 0, on>>>(c->frames, c->frame_stride, s0 + f0, (uint32_t)c->n, c->boxes_dev, p->dev, c->state_dev + f0, c->masses, sel, nullptr);
+            if (c->profile) HIPCHK(c, hipEventRecord(c->pev[6 * g + 5], on));
+            return GR_OK;
+        };
+        auto launch_close = [&](uint32_t g, hipStream_t on) -> int {
+            if (!lite) return GR_OK;
+            const uint32_t f0 = g * sb, nf = group_nf(g), gx = fit_grid(c, nf);
+            k_rmsd_close<<<dim3(nf), dim3(64), 0, on>>>(c->fit_partials + (size_t)f0 * gx, gx, p->dev.sw, c->state_dev + f0);
+            return GR_OK;
+        };
+        hipStream_t S = c->stream, B = c->stream2;
+        if (fit && !two && c->skew && n_groups > 1) {
+            // Skewed order (GR_SKEW=1, off by default).  The two small kernels of a group (finalize: one workgroup per
+            // frame, ~17 us; close: one wave per frame) leave the chip idle when they sit between the big ones on one
+            // stream.  Here they run on the second stream BESIDE the next group's sums pass, and the fit of group g follows
+            // the sums of group g + 1.  Measured: the finalize kernel then starves behind the sums pass's workgroups
+            // (17 -> 100-200 us per launch, even on a high-priority stream) and delays the fit: 130 k vs 134 k frames/s.
+            //   S: sums(0) sums(1) fit(0) sums(2) fit(1) ...            B: fin(0) fin(1) close(0) fin(2) close(1) ...
+            for (uint32_t g = 0; g < n_groups; ++g) {
+                st = launch_sums(g, S); if (st) return st;
+                HIPCHK(c, hipEventRecord(c->ev_skew[3 * g], S));
+                HIPCHK(c, hipStreamWaitEvent(B, c->ev_skew[3 * g], 0));
+                st = launch_finalize(g, B); if (st) return st;
+                HIPCHK(c, hipEventRecord(c->ev_skew[3 * g + 1], B));
+                if (g > 0) {
+                    HIPCHK(c, hipStreamWaitEvent(S, c->ev_skew[3 * (g - 1) + 1], 0));
+                    st = launch_fit(g - 1, S); if (st) return st;
+                    HIPCHK(c, hipEventRecord(c->ev_skew[3 * (g - 1) + 2], S));
+                    HIPCHK(c, hipStreamWaitEvent(B, c->ev_skew[3 * (g - 1) + 2], 0));
+                    st = launch_close(g - 1, B); if (st) return st;
                 }
             }
+            const uint32_t g = n_groups - 1;
+            HIPCHK(c, hipStreamWaitEvent(S, c->ev_skew[3 * g + 1], 0));
+            st = launch_fit(g, S); if (st) return st;
+            HIPCHK(c, hipEventRecord(c->ev_skew[3 * g + 2], S));
+            HIPCHK(c, hipStreamWaitEvent(B, c->ev_skew[3 * g + 2], 0));
+            st = launch_close(g, B); if (st) return st;
+            HIPCHK(c, hipEventRecord(c->ev_join, B));
+            HIPCHK(c, hipStreamWaitEvent(S, c->ev_join, 0));
+        } else {
+            for (uint32_t g = 0; g < n_groups; ++g) {
+                st = launch_sums(g, S); if (st) return st;
+                st = launch_finalize(g, S); if (st) return st;
+                if (fit) {
+                    hipStream_t fs = S;
+                    if (two) {   // GR_OVERLAP=1: the whole fit of group g beside the sums of group g + 1
+                        HIPCHK(c, hipEventRecord(c->ev_grp[g], S));
+                        HIPCHK(c, hipStreamWaitEvent(B, c->ev_grp[g], 0));
+                        fs = B;
+                    }
+                    st = launch_fit(g, fs); if (st) return st;
+                    st = launch_close(g, fs); if (st) return st;
+                }
+            }
+            if (two) {   // join: the state fetch (and the caller) must see every fit finished
+                HIPCHK(c, hipEventRecord(c->ev_join, B));
+                HIPCHK(c, hipStreamWaitEvent(S, c->ev_join, 0));
+            }
         }
-        if (two) {   // join: the state fetch (and the caller) must see every fit finished
-            HIPCHK(c, hipEventRecord(c->ev_join, c->stream2));
-            HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
-        }
+        ng = n_groups;
         q.prof_two = two;
         HIPCHK(c, hipGetLastError());
         if (c->profile) q.n_prof_groups = ng;
@@ -1089,9 +1148,8 @@ static int segment_end(gr_rmsd_plan *p, float *rmsd_out, int *status_out, float 
             const int nk = fit ? 3 : 2;
             const uint32_t nf = std::min<uint32_t>(c->sub_batch, nb - gi * c->sub_batch);
             for (int k = 0; k < nk; ++k) {
-                if (k == 1 && q.prof_two) continue;   // finalize..fit-start spans two streams: not a kernel duration
                 float ms = 0.f;
-                HIPCHK(c, hipEventElapsedTime(&ms, c->pev[4 * gi + k], c->pev[4 * gi + k + 1]));
+                HIPCHK(c, hipEventElapsedTime(&ms, c->pev[6 * gi + 2 * k], c->pev[6 * gi + 2 * k + 1]));
                 c->prof_ms[k] += ms; c->prof_launches[k] += 1; c->prof_frames[k] += nf;
             }
         }

@@ -139,6 +139,22 @@ __device__ __forceinline__ void gr_rs_step(float (&a)[32], const uint32_t lane) 
         a[k] = MAX ? gr_fmaxf(keep, got) : keep + got;
     }
 }
+template <int HALF, int MASK>
+__device__ __forceinline__ void gr_rs_step_f64(double (&a)[32], const uint32_t lane) {
+    const bool hi = (lane & MASK) != 0;
+#pragma unroll
+    for (int k = 0; k < HALF; ++k) {
+        const double send = hi ? a[k] : a[k + HALF];
+        const double keep = hi ? a[k + HALF] : a[k];
+        a[k] = keep + __shfl_xor(send, MASK, 64);
+    }
+}
+// 32 doubles: afterwards lane l holds the wave total of value (l >> 1)
+__device__ __forceinline__ double gr_wave_sum_scatter32_f64(double (&a)[32], const uint32_t lane) {
+    gr_rs_step_f64<16, 32>(a, lane); gr_rs_step_f64<8, 16>(a, lane); gr_rs_step_f64<4, 8>(a, lane);
+    gr_rs_step_f64<2, 4>(a, lane); gr_rs_step_f64<1, 2>(a, lane);
+    return a[0] + __shfl_xor(a[0], 1, 64);
+}
 __device__ __forceinline__ float gr_wave_sum_scatter32(float (&a)[32], const uint32_t lane) {
     gr_rs_step<16, 32, false>(a, lane); gr_rs_step<8, 16, false>(a, lane); gr_rs_step<4, 8, false>(a, lane);
     gr_rs_step<2, 4, false>(a, lane); gr_rs_step<1, 2, false>(a, lane);
@@ -815,6 +831,55 @@ __global__ __launch_bounds__(GR_WG) void k_rmsd_finalize(
     gr_finalize_math<MODE, LITE>(acc, mn, mx, fmn, fmx, bad_pos, bad_mass, boxes[first_slot + frame], plan, g, sel.n, st);
 }
 
+// The same for the two-pass sums records, ONE WAVE per frame and no barrier: lane c sums the records c, c + 64, ..., a
+// reduce-scatter leaves the 19 totals / 12 extents spread over the lanes, LDS hands them to lane 0.
+__global__ __launch_bounds__(64) void k_rmsd_finalize_lite(
+    const GrAccPartial *__restrict__ partials, uint32_t nchunks,
+    const float *__restrict__ frames, size_t frame_stride, uint32_t first_slot, GrSel sel,
+    const GrBox *__restrict__ boxes, GrPlanDev plan, GrFrameState *__restrict__ state) {
+    __shared__ double tot[32];
+    __shared__ float ext[16];
+    const uint32_t frame = blockIdx.x, lane = threadIdx.x;
+    double s[32];
+    float e[32];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) { s[k] = 0.0; e[k] = -3.0e38f; }
+    uint32_t bad_pos = GR_NOIDX, bad_mass = GR_NOIDX;
+    for (uint32_t c = lane; c < nchunks; c += 64) {
+        const GrAccPartial &p = partials[(size_t)frame * nchunks + c];
+#pragma unroll
+        for (int k = 0; k < 13; ++k) s[k] += p.s[k];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) s[13 + k] += p.s[26 + k];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            e[a] = gr_fmaxf(e[a], -p.vmin[a]); e[3 + a] = gr_fmaxf(e[3 + a], p.vmax[a]);
+            e[6 + a] = gr_fmaxf(e[6 + a], -p.fmin[a]); e[9 + a] = gr_fmaxf(e[9 + a], p.fmax[a]);
+        }
+        bad_pos = min(bad_pos, p.bad_pos); bad_mass = min(bad_mass, p.bad_mass);
+    }
+    const double t = gr_wave_sum_scatter32_f64(s, lane);
+    const float m = gr_wave_max_scatter16(e, lane);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { bad_pos = min(bad_pos, (uint32_t)__shfl_xor((int)bad_pos, off, 64)); bad_mass = min(bad_mass, (uint32_t)__shfl_xor((int)bad_mass, off, 64)); }
+    if ((lane & 1u) == 0) tot[lane >> 1] = t;
+    if ((lane & 3u) == 0) ext[lane >> 2] = m;
+    gr_wave_sync();
+    if (lane != 0) return;
+    GrFrameState &st = state[frame];
+    if (st.status != 0) return;
+    double acc[GR_ACC_K];
+    for (int k = 0; k < GR_ACC_K; ++k) acc[k] = 0.0;
+    for (int k = 0; k < 13; ++k) acc[k] = tot[k];
+    for (int k = 0; k < 6; ++k) acc[26 + k] = tot[13 + k];
+    const float mn[3] = { -ext[0], -ext[1], -ext[2] }, mx[3] = { ext[3], ext[4], ext[5] };
+    const float fmn[3] = { -ext[6], -ext[7], -ext[8] }, fmx[3] = { ext[9], ext[10], ext[11] };
+    const float *xyz = frames + (size_t)(first_slot + frame) * frame_stride;
+    const uint32_t i0 = sel.contiguous ? sel.start : sel.idx[0];
+    const double g[3] = { xyz[3 * (size_t)i0], xyz[3 * (size_t)i0 + 1], xyz[3 * (size_t)i0 + 2] };
+    gr_finalize_math<0, true>(acc, mn, mx, fmn, fmx, bad_pos, bad_mass, boxes[first_slot + frame], plan, g, sel.n, st);
+}
+
 // ------------------------------------------------------------------------------------------ fit (all atoms)
 // fit_structure (rmsd.rs:508-528, atom.rs:498-528,894-903), one streaming read-modify-write pass:
 //   z = R (wrap(x + shift) - box_centre) + reference_group_com
@@ -904,9 +969,13 @@ __global__ __launch_bounds__(GR_WG) void k_fit(
 __global__ __launch_bounds__(64) void k_rmsd_close(const double *__restrict__ fit_partials, uint32_t nparts, double sum_w, GrFrameState *__restrict__ state) {
     const uint32_t frame = blockIdx.x;
     if (state[frame].status != 0) return;
-    double s = 0.0;
-    for (uint32_t k = threadIdx.x; k < nparts; k += 64) s += fit_partials[(size_t)frame * nparts + k];
-    s = gr_wave_sum(s);
+    // four independent chains per lane: the loads of a lane do not wait for one another
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    const double *p = fit_partials + (size_t)frame * nparts;
+    uint32_t k = threadIdx.x;
+    for (; k + 192 < nparts; k += 256) { s0 += p[k]; s1 += p[k + 64]; s2 += p[k + 128]; s3 += p[k + 192]; }
+    for (; k < nparts; k += 64) s0 += p[k];
+    const double s = gr_wave_sum((s0 + s1) + (s2 + s3));
     if (threadIdx.x == 0) state[frame].rmsd = (float)sqrt(fmax(s, 0.0) / sum_w);
 }
 
