@@ -52,6 +52,8 @@ struct gr_ctx {
     std::vector<uint64_t> slot_gen;         // per slot: generation of the last compute call that touched it
     hipEvent_t ev_grp[GR_MAX_BATCH] = {};   // "finalize of group k done" (stream -> stream2)
     hipEvent_t ev_skew[3 * GR_MAX_BATCH] = {};   // skewed order: [3g] sums of group g done, [3g+1] finalize done, [3g+2] fit done
+    uint32_t *fuse_cnt = nullptr;     // [2 * GR_MAX_BATCH] arrival counters of the fused finalize / close tails (self-resetting)
+    int fuse = 1;                     // GR_FUSE=0: separate k_rmsd_finalize_lite / k_rmsd_close launches
     int skew = 0;                     // GR_SKEW=1: small kernels on the second stream beside the next group's sums pass (measured slower)
     hipEvent_t ev_join = nullptr;           // "all fits done" (stream2 -> stream)
     int overlap = 0;   // GR_OVERLAP=1: +5 % frames/s at 256-frame calls (measured), but per-kernel durations then overlap
@@ -110,7 +112,7 @@ struct gr_ctx {
 };
 
 struct Pending {   // a segment between gr_rmsd_batch_begin and gr_rmsd_batch_end
-    bool active = false, any_ok = false, consistent = true, prof_two = false, persist = false;
+    bool active = false, any_ok = false, consistent = true, prof_two = false, persist = false, fused = false;
     uint32_t s0 = 0, nb = 0, n_prof_groups = 0;
     int fit = 0;
     std::vector<int> pre;
@@ -384,6 +386,9 @@ gr_ctx *gr_ctx_create(int device, uint64_t n_atoms, uint32_t n_slots, int *statu
     if (const char *e = getenv("GR_PERSIST")) { const int v = atoi(e); c->persist = v < 0 ? 0 : (v > 2 ? 2 : v); }
     if (const char *e = getenv("GR_TWO_PASS")) c->two_pass = atoi(e) ? 1 : 0;
     if (const char *e = getenv("GR_SKEW")) c->skew = atoi(e) ? 1 : 0;
+    if (const char *e = getenv("GR_FUSE")) c->fuse = atoi(e) ? 1 : 0;
+    ok = ok && hipMalloc(&c->fuse_cnt, 2 * GR_MAX_BATCH * sizeof(uint32_t)) == hipSuccess;
+    ok = ok && hipMemset(c->fuse_cnt, 0, 2 * GR_MAX_BATCH * sizeof(uint32_t)) == hipSuccess;
     if (const char *e = getenv("GR_PS_TRACE")) c->ps_trace_path = e;
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cus = (uint32_t)prop.multiProcessorCount; }
     ok = ok && hipMalloc(&c->ps_sync, (2 + 2 * GR_MAX_BATCH) * sizeof(uint32_t)) == hipSuccess;
@@ -436,6 +441,7 @@ void gr_ctx_destroy(gr_ctx *c) {
     if (c->cen_partials) (void)hipFree(c->cen_partials);
     if (c->acc_partials) (void)hipFree(c->acc_partials);
     if (c->fit_partials) (void)hipFree(c->fit_partials);
+    if (c->fuse_cnt) (void)hipFree(c->fuse_cnt);
     if (c->state_dev) (void)hipFree(c->state_dev);
     if (c->state_host) (void)hipHostFree(c->state_host);
     if (c->bad_dev) (void)hipFree(c->bad_dev);
@@ -1014,18 +1020,22 @@ static int segment_begin(gr_rmsd_plan *p, uint32_t s0, uint32_t nb, int fit) {
             }
         }
         const uint32_t n_groups = (nb + sb - 1) / sb;
+        const bool fused = lite && c->fuse;   // the finalize rides on the tail of the sums kernel
+        q.fused = fused;
         // The kernels of one group, each bracketed by its own pair of profiling events on the stream it runs on
         auto group_nf = [&](uint32_t g) { return std::min<uint32_t>(sb, nb - g * sb); };
         auto launch_sums = [&](uint32_t g, hipStream_t on) -> int {
             const uint32_t f0 = g * sb, nf = group_nf(g), nch = batch_chunks(c, sel, nf);
             GrAccPartial *parts = c->acc_partials + (size_t)f0 * GR_MAX_CHUNKS;
             if (c->profile) HIPCHK(c, hipEventRecord(c->pev[6 * g], on));
-            if (lite) k_rmsd_accum<0, true><<<dim3(nch, nf), dim3(GR_WG), 0, on>>>(c->frames, c->frame_stride, s0 + f0, c->masses, sel, c->boxes_dev, p->dev, c->state_dev + f0, parts);
+            if (lite) k_rmsd_accum<0, true><<<dim3(nch, nf), dim3(GR_WG), 0, on>>>(c->frames, c->frame_stride, s0 + f0, c->masses, sel, c->boxes_dev, p->dev, c->state_dev + f0, parts,
+                                                                                  fused ? c->fuse_cnt + f0 : nullptr, c->state_dev + f0);
             else k_rmsd_accum<0><<<dim3(nch, nf), dim3(GR_WG), 0, on>>>(c->frames, c->frame_stride, s0 + f0, c->masses, sel, c->boxes_dev, p->dev, c->state_dev + f0, parts);
             if (c->profile) HIPCHK(c, hipEventRecord(c->pev[6 * g + 1], on));
             return GR_OK;
         };
         auto launch_finalize = [&](uint32_t g, hipStream_t on) -> int {
+            if (fused) return GR_OK;   // the sums kernel's last workgroup per frame has closed it
             const uint32_t f0 = g * sb, nf = group_nf(g), nch = batch_chunks(c, sel, nf);
             GrAccPartial *parts = c->acc_partials + (size_t)f0 * GR_MAX_CHUNKS;
             if (c->profile) HIPCHK(c, hipEventRecord(c->pev[6 * g + 2], on));
@@ -1037,7 +1047,8 @@ static int segment_begin(gr_rmsd_plan *p, uint32_t s0, uint32_t nb, int fit) {
         auto launch_fit = [&](uint32_t g, hipStream_t on) -> int {
             const uint32_t f0 = g * sb, nf = group_nf(g), gx = fit_grid(c, nf);
             if (c->profile) HIPCHK(c, hipEventRecord(c->pev[6 * g + 4], on));
-            if (lite) k_fit<true><<<dim3(gx, nf), dim3(GR_WG), 0, on>>>(c->frames, c->frame_stride, s0 + f0, (uint32_t)c->n, c->boxes_dev, p->dev, c->state_dev + f0, c->masses, sel, c->fit_partials + (size_t)f0 * gx);
+            if (lite) k_fit<true><<<dim3(gx, nf), dim3(GR_WG), 0, on>>>(c->frames, c->frame_stride, s0 + f0, (uint32_t)c->n, c->boxes_dev, p->dev, c->state_dev + f0, c->masses, sel, c->fit_partials + (size_t)f0 * gx,
+                                                                        nullptr, c->state_dev + f0);   // (a fused close makes every one of the 62 k workgroups drain its stores: 3x slower)
             else k_fit<false><<<dim3(gx, nf), dim3(GR_WG), 0, on>>>(c->frames, c->frame_stride, s0 + f0, (uint32_t)c->n, c->boxes_dev, p->dev, c->state_dev + f0, c->masses, sel, nullptr);
             if (c->profile) HIPCHK(c, hipEventRecord(c->pev[6 * g + 5], on));
             return GR_OK;
@@ -1148,6 +1159,7 @@ static int segment_end(gr_rmsd_plan *p, float *rmsd_out, int *status_out, float 
             const int nk = fit ? 3 : 2;
             const uint32_t nf = std::min<uint32_t>(c->sub_batch, nb - gi * c->sub_batch);
             for (int k = 0; k < nk; ++k) {
+                if (k == 1 && q.fused) continue;   // no finalize launch: the sums kernel closed the frames
                 float ms = 0.f;
                 HIPCHK(c, hipEventElapsedTime(&ms, c->pev[6 * gi + 2 * k], c->pev[6 * gi + 2 * k + 1]));
                 c->prof_ms[k] += ms; c->prof_launches[k] += 1; c->prof_frames[k] += nf;

@@ -551,11 +551,22 @@ __device__ __forceinline__ void gr_unpack4(GrA4 &q, const float4 &a, const float
 #ifndef GR_ACC_MIN_WAVES
 #define GR_ACC_MIN_WAVES 1
 #endif
+__device__ __forceinline__ void gr_finalize_frame_lite(const GrAccPartial *partials, uint32_t nchunks, uint32_t frame, const float *frames, size_t frame_stride,
+                                                       uint32_t first_slot, const GrSel &sel, const GrBox *boxes, const GrPlanDev &plan, GrFrameState *state,
+                                                       double *tot, float *ext, uint32_t lane);
+
+// agent-scope (sc1, write-through) stores for records another workgroup of the same launch will read
+template <typename T> __device__ __forceinline__ void gr_st_agent(T *p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// `fuse` (LITE only): per-frame arrival counters, zero between launches.  The workgroup that completes a frame's records
+// closes the frame itself (gr_finalize_frame_lite) -- no separate finalize launch, no idle chip between the two passes.
+// Non-blocking: nobody waits; records are written with agent-scope stores and drained before the counter is bumped, the
+// closing wave invalidates its L2 view (acquire fence) before it reads them.
 template <int MODE, bool LITE = false>
 __global__ __launch_bounds__(GR_WG, GR_ACC_MIN_WAVES) void k_rmsd_accum(
     const float *__restrict__ frames, size_t frame_stride, uint32_t first_slot,
     const float *__restrict__ masses, GrSel sel, const GrBox *__restrict__ boxes,
-    GrPlanDev plan, const GrFrameState *__restrict__ state, GrAccPartial *__restrict__ partials) {
+    GrPlanDev plan, const GrFrameState *state, GrAccPartial *partials, uint32_t *fuse = nullptr, GrFrameState *state_out = nullptr) {
     __shared__ GrBox box;
     __shared__ double lds[(GR_WG / 64) * GR_ACC_K];
     __shared__ uint32_t ldsu[GR_WG / 64];
@@ -658,17 +669,29 @@ __global__ __launch_bounds__(GR_WG, GR_ACC_MIN_WAVES) void k_rmsd_accum(
             GrAccPartial &o = partials[(size_t)frame * nchunks + chunk];
             if (lane < 19) {
                 const double v = (double)wsum[lane] + (double)wsum[50 + lane] + (double)wsum[100 + lane] + (double)wsum[150 + lane];
-                o.s[lane < 13 ? lane : 13 + lane] = v;           // sums 13..18 are the moments: record slots 26..31
+                gr_st_agent(&o.s[lane < 13 ? lane : 13 + lane], v);           // sums 13..18 are the moments: record slots 26..31
             } else if (lane < 32) {
-                o.s[lane - 6] = 0.0;                              // slots 13..25 are not used by the two-pass sums
+                gr_st_agent(&o.s[lane - 6], 0.0);                             // slots 13..25 are not used by the two-pass sums
             } else if (lane < 44) {
                 const uint32_t q = lane - 32;
                 const float m = gr_fmaxf(gr_fmaxf(wsum[32 + q], wsum[50 + 32 + q]), gr_fmaxf(wsum[100 + 32 + q], wsum[150 + 32 + q]));
-                if (q < 3) o.vmin[q] = -m; else if (q < 6) o.vmax[q - 3] = m; else if (q < 9) o.fmin[q - 6] = -m; else o.fmax[q - 9] = m;
+                if (q < 3) gr_st_agent(&o.vmin[q], -m); else if (q < 6) gr_st_agent(&o.vmax[q - 3], m); else if (q < 9) gr_st_agent(&o.fmin[q - 6], -m); else gr_st_agent(&o.fmax[q - 9], m);
             } else if (lane == 44) {
                 const uint32_t *u = reinterpret_cast<const uint32_t *>(wsum);
-                o.bad_pos = min(min(u[48], u[98]), min(u[148], u[198]));
-                o.bad_mass = min(min(u[49], u[99]), min(u[149], u[199]));
+                gr_st_agent(&o.bad_pos, min(min(u[48], u[98]), min(u[148], u[198])));
+                gr_st_agent(&o.bad_mass, min(min(u[49], u[99]), min(u[149], u[199])));
+            }
+            if (fuse) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // every lane's record stores have left
+                uint32_t old = 0;
+                if (lane == 0) old = __hip_atomic_fetch_add(fuse + frame, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__builtin_amdgcn_readfirstlane(old) == nchunks - 1) {     // this frame's records are complete: close it
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    double *tot = lds;                                        // wsum (same LDS) has been consumed by this wave
+                    float *ext = reinterpret_cast<float *>(lds + 32);
+                    gr_finalize_frame_lite(partials, nchunks, frame, frames, frame_stride, first_slot, sel, boxes, plan, state_out, tot, ext, lane);
+                    if (lane == 0) fuse[frame] = 0u;
+                }
             }
         }
         return;
@@ -833,13 +856,10 @@ __global__ __launch_bounds__(GR_WG) void k_rmsd_finalize(
 
 // The same for the two-pass sums records, ONE WAVE per frame and no barrier: lane c sums the records c, c + 64, ..., a
 // reduce-scatter leaves the 19 totals / 12 extents spread over the lanes, LDS hands them to lane 0.
-__global__ __launch_bounds__(64) void k_rmsd_finalize_lite(
-    const GrAccPartial *__restrict__ partials, uint32_t nchunks,
-    const float *__restrict__ frames, size_t frame_stride, uint32_t first_slot, GrSel sel,
-    const GrBox *__restrict__ boxes, GrPlanDev plan, GrFrameState *__restrict__ state) {
-    __shared__ double tot[32];
-    __shared__ float ext[16];
-    const uint32_t frame = blockIdx.x, lane = threadIdx.x;
+// (tot: 32 doubles, ext: 16 floats of LDS owned by the calling wave)
+__device__ __forceinline__ void gr_finalize_frame_lite(const GrAccPartial *partials, uint32_t nchunks, uint32_t frame, const float *frames, size_t frame_stride,
+                                                       uint32_t first_slot, const GrSel &sel, const GrBox *boxes, const GrPlanDev &plan, GrFrameState *state,
+                                                       double *tot, float *ext, uint32_t lane) {
     double s[32];
     float e[32];
 #pragma unroll
@@ -880,6 +900,15 @@ __global__ __launch_bounds__(64) void k_rmsd_finalize_lite(
     gr_finalize_math<0, true>(acc, mn, mx, fmn, fmx, bad_pos, bad_mass, boxes[first_slot + frame], plan, g, sel.n, st);
 }
 
+__global__ __launch_bounds__(64) void k_rmsd_finalize_lite(
+    const GrAccPartial *__restrict__ partials, uint32_t nchunks,
+    const float *__restrict__ frames, size_t frame_stride, uint32_t first_slot, GrSel sel,
+    const GrBox *__restrict__ boxes, GrPlanDev plan, GrFrameState *__restrict__ state) {
+    __shared__ double tot[32];
+    __shared__ float ext[16];
+    gr_finalize_frame_lite(partials, nchunks, blockIdx.x, frames, frame_stride, first_slot, sel, boxes, plan, state, tot, ext, threadIdx.x);
+}
+
 // ------------------------------------------------------------------------------------------ fit (all atoms)
 // fit_structure (rmsd.rs:508-528, atom.rs:498-528,894-903), one streaming read-modify-write pass:
 //   z = R (wrap(x + shift) - box_centre) + reference_group_com
@@ -888,13 +917,16 @@ __global__ __launch_bounds__(64) void k_rmsd_finalize_lite(
 // as 4-atom f32 partials -> fp64 per lane -> one fp64 partial per workgroup in fit_partials[frame][blockIdx.x];
 // k_rmsd_close sums them in a fixed order.  d = R q - p is a difference of O(nm) numbers with ~1e-7 relative rounding,
 // so a rigid copy of the reference gives rmsd ~ 1e-6 nm instead of the cancellation-limited closed form.
+// `fuse` (RMSD only): per-frame arrival counters, zero between launches; the workgroup that delivers a frame's last partial
+// sums them in a fixed order and writes the rmsd (what k_rmsd_close does otherwise).
 template <bool RMSD>
 __global__ __launch_bounds__(GR_WG) void k_fit(
     float *__restrict__ frames, size_t frame_stride, uint32_t first_slot, uint32_t n_atoms,
-    const GrBox *__restrict__ boxes, GrPlanDev plan, const GrFrameState *__restrict__ state,
-    const float *__restrict__ masses, GrSel sel, double *__restrict__ fit_partials) {
+    const GrBox *__restrict__ boxes, GrPlanDev plan, const GrFrameState *state,
+    const float *__restrict__ masses, GrSel sel, double *fit_partials, uint32_t *fuse = nullptr, GrFrameState *state_out = nullptr) {
     __shared__ GrBox box;
     __shared__ double lds[GR_WG / 64];
+    __shared__ uint32_t last_flag;
     const uint32_t frame = blockIdx.y;
     const GrFrameState &st = state[frame];
     if (st.status != 0) return;   // analysis failed -> frame left unmodified (rmsd.rs:91)
@@ -960,7 +992,31 @@ __global__ __launch_bounds__(GR_WG) void k_fit(
             double tot = 0.0;
 #pragma unroll
             for (int k = 0; k < GR_WG / 64; ++k) tot += lds[k];
-            fit_partials[(size_t)frame * gridDim.x + blockIdx.x] = tot;
+            gr_st_agent(&fit_partials[(size_t)frame * gridDim.x + blockIdx.x], tot);
+            if (fuse) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                last_flag = (__hip_atomic_fetch_add(fuse + frame, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) ? 1u : 0u;
+            }
+        }
+        if (fuse) {
+            __syncthreads();
+            if (last_flag) {   // workgroup-uniform
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                const double *p = fit_partials + (size_t)frame * gridDim.x;
+                double s = 0.0;
+                for (uint32_t k = threadIdx.x; k < gridDim.x; k += GR_WG) s += p[k];
+                s = gr_wave_sum(s);
+                __syncthreads();
+                if (lane == 0) lds[wave] = s;
+                __syncthreads();
+                if (threadIdx.x == 0) {
+                    double tot = 0.0;
+#pragma unroll
+                    for (int k = 0; k < GR_WG / 64; ++k) tot += lds[k];
+                    state_out[frame].rmsd = (float)sqrt(fmax(tot, 0.0) / plan.sw);
+                    fuse[frame] = 0u;
+                }
+            }
         }
     }
 }
