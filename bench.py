@@ -40,7 +40,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--atoms", type=int, default=1_000_000)
-    ap.add_argument("--frames-per-step", type=int, default=256)
+    ap.add_argument("--frames-per-step", type=int, default=1024)
     ap.add_argument("--max-pool-gb", type=float, default=160.0)
     ap.add_argument("--cpu-frames-per-thread", type=int, default=2)
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = min(host cores visible, 16): "

@@ -23,7 +23,7 @@
 #include <thread>
 #include <atomic>
 
-#define GR_MAX_BATCH 256     // frames per batched call segment (workspace is sized for this)
+#define GR_MAX_BATCH 1024    // frames per batched call segment (workspace is sized for this; 82 MB of partial records)
 #define GR_MAX_CHUNKS 256    // workgroups per frame in the reduction kernels
 
 namespace {
@@ -288,6 +288,14 @@ int set_box(gr_ctx *c, uint32_t slot, const float *box9, hipStream_t on = nullpt
     return GR_OK;
 }
 
+// events of the batched paths are created when first needed
+int ensure_event(gr_ctx *c, hipEvent_t *ev, bool timing) {
+    if (*ev) return GR_OK;
+    HIPCHK(c, timing ? hipEventCreate(ev) : hipEventCreateWithFlags(ev, hipEventDisableTiming));
+    return GR_OK;
+}
+#define EVREC(ctx, ev, timing, stream) do { int s_ = ensure_event((ctx), &(ev), (timing)); if (s_) return s_; HIPCHK((ctx), hipEventRecord((ev), (stream))); } while (0)
+
 int state_reset(gr_ctx *c, uint32_t n) {
     k_state_reset<<<dim3((n + 63) / 64), dim3(64), 0, c->stream>>>(c->state_dev, n);
     HIPCHK(c, hipGetLastError());
@@ -380,7 +388,7 @@ gr_ctx *gr_ctx_create(int device, uint64_t n_atoms, uint32_t n_slots, int *statu
     ok = ok && hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) == hipSuccess;
     for (int k = 0; k < 64; ++k) ok = ok && hipEventCreateWithFlags(&c->ev_done_ring[k], hipEventDisableTiming) == hipSuccess;
     c->ev_ready.assign(n_slots, nullptr); c->upload_pending.assign(n_slots, 0); c->slot_gen.assign(n_slots, 0);
-    for (int k = 0; k < GR_MAX_BATCH; ++k) ok = ok && hipEventCreateWithFlags(&c->ev_grp[k], hipEventDisableTiming) == hipSuccess;
+    // ev_grp / ev_skew / pev are created on first use (ensure_event): thousands of events per context otherwise
     ok = ok && hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) == hipSuccess;
     if (const char *e = getenv("GR_OVERLAP")) c->overlap = atoi(e) ? 1 : 0;
     if (const char *e = getenv("GR_PERSIST")) { const int v = atoi(e); c->persist = v < 0 ? 0 : (v > 2 ? 2 : v); }
@@ -404,8 +412,7 @@ gr_ctx *gr_ctx_create(int device, uint64_t n_atoms, uint32_t n_slots, int *statu
     ok = ok && hipMalloc(&c->bad_dev, 4 * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipHostMalloc(&c->bad_host, 4 * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess;
     ok = ok && hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess;
-    for (int k = 0; k < 6 * GR_MAX_BATCH; ++k) ok = ok && hipEventCreate(&c->pev[k]) == hipSuccess;
-    for (int k = 0; k < 3 * GR_MAX_BATCH; ++k) ok = ok && hipEventCreateWithFlags(&c->ev_skew[k], hipEventDisableTiming) == hipSuccess;
+
     if (const char *e = getenv("GR_SUB_BATCH")) { int v = atoi(e); if (v >= 1 && v <= GR_MAX_BATCH) c->sub_batch = (uint32_t)v; }
     if (const char *e = getenv("GR_CHUNKS")) { int v = atoi(e); if (v >= 1 && v <= GR_MAX_CHUNKS) c->chunks = (uint32_t)v; }
     if (const char *e = getenv("GR_FIT_WGS")) { int v = atoi(e); if (v >= 1 && v <= 65535) c->fit_wgs = (uint32_t)v; }
@@ -993,9 +1000,9 @@ static int segment_begin(gr_rmsd_plan *p, uint32_t s0, uint32_t nb, int fit) {
         }
         const size_t lds = GrPersistLds(ps_T, ps_D).total;
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rmsd_fit_persist), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        if (c->profile) HIPCHK(c, hipEventRecord(c->pev[0], c->stream));
+        if (c->profile) EVREC(c, c->pev[0], true, c->stream);
         k_rmsd_fit_persist<<<dim3(c->n_cus), dim3(GR_PS_THREADS), lds, c->stream>>>(a);
-        if (c->profile) HIPCHK(c, hipEventRecord(c->pev[1], c->stream));
+        if (c->profile) EVREC(c, c->pev[1], true, c->stream);
         HIPCHK(c, hipGetLastError());
         k_rmsd_close<<<dim3(nb), dim3(64), 0, c->stream>>>(c->ps_rmsd, c->n_cus * GR_PS_WAVES, p->dev.sw, c->state_dev);
         HIPCHK(c, hipMemcpyAsync(c->ps_sync_host, c->ps_sync, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
@@ -1027,30 +1034,30 @@ static int segment_begin(gr_rmsd_plan *p, uint32_t s0, uint32_t nb, int fit) {
         auto launch_sums = [&](uint32_t g, hipStream_t on) -> int {
             const uint32_t f0 = g * sb, nf = group_nf(g), nch = batch_chunks(c, sel, nf);
             GrAccPartial *parts = c->acc_partials + (size_t)f0 * GR_MAX_CHUNKS;
-            if (c->profile) HIPCHK(c, hipEventRecord(c->pev[6 * g], on));
+            if (c->profile) EVREC(c, c->pev[6 * g], true, on);
             if (lite) k_rmsd_accum<0, true><<<dim3(nch, nf), dim3(GR_WG), 0, on>>>(c->frames, c->frame_stride, s0 + f0, c->masses, sel, c->boxes_dev, p->dev, c->state_dev + f0, parts,
                                                                                   fused ? c->fuse_cnt + f0 : nullptr, c->state_dev + f0);
             else k_rmsd_accum<0><<<dim3(nch, nf), dim3(GR_WG), 0, on>>>(c->frames, c->frame_stride, s0 + f0, c->masses, sel, c->boxes_dev, p->dev, c->state_dev + f0, parts);
-            if (c->profile) HIPCHK(c, hipEventRecord(c->pev[6 * g + 1], on));
+            if (c->profile) EVREC(c, c->pev[6 * g + 1], true, on);
             return GR_OK;
         };
         auto launch_finalize = [&](uint32_t g, hipStream_t on) -> int {
             if (fused) return GR_OK;   // the sums kernel's last workgroup per frame has closed it
             const uint32_t f0 = g * sb, nf = group_nf(g), nch = batch_chunks(c, sel, nf);
             GrAccPartial *parts = c->acc_partials + (size_t)f0 * GR_MAX_CHUNKS;
-            if (c->profile) HIPCHK(c, hipEventRecord(c->pev[6 * g + 2], on));
+            if (c->profile) EVREC(c, c->pev[6 * g + 2], true, on);
             if (lite) k_rmsd_finalize_lite<<<dim3(nf), dim3(64), 0, on>>>(parts, nch, c->frames, c->frame_stride, s0 + f0, sel, c->boxes_dev, p->dev, c->state_dev + f0);
             else k_rmsd_finalize<0><<<dim3(nf), dim3(GR_WG), 0, on>>>(parts, nch, c->frames, c->frame_stride, s0 + f0, sel, c->boxes_dev, p->dev, c->state_dev + f0);
-            if (c->profile) HIPCHK(c, hipEventRecord(c->pev[6 * g + 3], on));
+            if (c->profile) EVREC(c, c->pev[6 * g + 3], true, on);
             return GR_OK;
         };
         auto launch_fit = [&](uint32_t g, hipStream_t on) -> int {
             const uint32_t f0 = g * sb, nf = group_nf(g), gx = fit_grid(c, nf);
-            if (c->profile) HIPCHK(c, hipEventRecord(c->pev[6 * g + 4], on));
+            if (c->profile) EVREC(c, c->pev[6 * g + 4], true, on);
             if (lite) k_fit<true><<<dim3(gx, nf), dim3(GR_WG), 0, on>>>(c->frames, c->frame_stride, s0 + f0, (uint32_t)c->n, c->boxes_dev, p->dev, c->state_dev + f0, c->masses, sel, c->fit_partials + (size_t)f0 * gx,
                                                                         nullptr, c->state_dev + f0);   // (a fused close makes every one of the 62 k workgroups drain its stores: 3x slower)
             else k_fit<false><<<dim3(gx, nf), dim3(GR_WG), 0, on>>>(c->frames, c->frame_stride, s0 + f0, (uint32_t)c->n, c->boxes_dev, p->dev, c->state_dev + f0, c->masses, sel, nullptr);
-            if (c->profile) HIPCHK(c, hipEventRecord(c->pev[6 * g + 5], on));
+            if (c->profile) EVREC(c, c->pev[6 * g + 5], true, on);
             return GR_OK;
         };
         auto launch_close = [&](uint32_t g, hipStream_t on) -> int {
@@ -1069,14 +1076,14 @@ static int segment_begin(gr_rmsd_plan *p, uint32_t s0, uint32_t nb, int fit) {
             //   S: sums(0) sums(1) fit(0) sums(2) fit(1) ...            B: fin(0) fin(1) close(0) fin(2) close(1) ...
             for (uint32_t g = 0; g < n_groups; ++g) {
                 st = launch_sums(g, S); if (st) return st;
-                HIPCHK(c, hipEventRecord(c->ev_skew[3 * g], S));
+                EVREC(c, c->ev_skew[3 * g], false, S);
                 HIPCHK(c, hipStreamWaitEvent(B, c->ev_skew[3 * g], 0));
                 st = launch_finalize(g, B); if (st) return st;
-                HIPCHK(c, hipEventRecord(c->ev_skew[3 * g + 1], B));
+                EVREC(c, c->ev_skew[3 * g + 1], false, B);
                 if (g > 0) {
                     HIPCHK(c, hipStreamWaitEvent(S, c->ev_skew[3 * (g - 1) + 1], 0));
                     st = launch_fit(g - 1, S); if (st) return st;
-                    HIPCHK(c, hipEventRecord(c->ev_skew[3 * (g - 1) + 2], S));
+                    EVREC(c, c->ev_skew[3 * (g - 1) + 2], false, S);
                     HIPCHK(c, hipStreamWaitEvent(B, c->ev_skew[3 * (g - 1) + 2], 0));
                     st = launch_close(g - 1, B); if (st) return st;
                 }
@@ -1084,7 +1091,7 @@ static int segment_begin(gr_rmsd_plan *p, uint32_t s0, uint32_t nb, int fit) {
             const uint32_t g = n_groups - 1;
             HIPCHK(c, hipStreamWaitEvent(S, c->ev_skew[3 * g + 1], 0));
             st = launch_fit(g, S); if (st) return st;
-            HIPCHK(c, hipEventRecord(c->ev_skew[3 * g + 2], S));
+            EVREC(c, c->ev_skew[3 * g + 2], false, S);
             HIPCHK(c, hipStreamWaitEvent(B, c->ev_skew[3 * g + 2], 0));
             st = launch_close(g, B); if (st) return st;
             HIPCHK(c, hipEventRecord(c->ev_join, B));
@@ -1096,7 +1103,7 @@ static int segment_begin(gr_rmsd_plan *p, uint32_t s0, uint32_t nb, int fit) {
                 if (fit) {
                     hipStream_t fs = S;
                     if (two) {   // GR_OVERLAP=1: the whole fit of group g beside the sums of group g + 1
-                        HIPCHK(c, hipEventRecord(c->ev_grp[g], S));
+                        EVREC(c, c->ev_grp[g], false, S);
                         HIPCHK(c, hipStreamWaitEvent(B, c->ev_grp[g], 0));
                         fs = B;
                     }
@@ -1218,7 +1225,7 @@ int gr_rmsd_batch_begin(gr_rmsd_plan *p, uint32_t first_slot, uint32_t n, int fi
     if (!p || !p->target) return GR_E_INVALID_ARG;
     gr_ctx *c = p->target;
     int st = slot_check(c, first_slot, n); if (st) return st;
-    if (n > GR_MAX_BATCH) return fail(c, GR_E_INVALID_ARG, "at most 256 frames per asynchronous batch");
+    if (n > GR_MAX_BATCH) return fail(c, GR_E_INVALID_ARG, "at most 1024 frames per asynchronous batch");
     if (p->pend.active) return fail(c, GR_E_INVALID_ARG, "a batch is already in flight on this plan");
     (void)hipSetDevice(c->device);
     p->last_fallbacks = 0;

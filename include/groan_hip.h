@@ -185,7 +185,7 @@ int gr_rmsd_batch(gr_rmsd_plan *plan, uint32_t first_slot, uint32_t n_frames,
 int gr_rmsd_fit_batch(gr_rmsd_plan *plan, uint32_t first_slot, uint32_t n_frames,
                       float *rmsd_out, int *status_out);
 /* The same in two halves, for pipelines that keep the GPU busy while the host decodes / uploads the next frames:
- * begin issues every launch for `n_frames` (<= 256) consecutive slots and returns without waiting; end waits and
+ * begin issues every launch for `n_frames` (<= 1024) consecutive slots and returns without waiting; end waits and
  * delivers the results.  One batch in flight per plan; between the two calls the context may be used for
  * gr_frame_upload / gr_frame_upload_wait / gr_host_* only (uploads run on the copy stream beside the kernels). */
 int gr_rmsd_batch_begin(gr_rmsd_plan *plan, uint32_t first_slot, uint32_t n_frames, int fit);
