@@ -47,7 +47,26 @@ extern "C" {
     pub fn gr_rmsd_plan_destroy(plan: *mut gr_rmsd_plan);
     pub fn gr_rmsd_batch(plan: *mut gr_rmsd_plan, first_slot: u32, n: u32, rmsd: *mut c_float, status: *mut c_int, rot: *mut c_float) -> c_int;
     pub fn gr_rmsd_fit_batch(plan: *mut gr_rmsd_plan, first_slot: u32, n: u32, rmsd: *mut c_float, status: *mut c_int) -> c_int;
+    // geometry selection (src/structures/shape.rs, src/system/groups.rs:94-188)
+    pub fn gr_shape_sphere(s: *mut gr_shape, position: *const c_float, radius: c_float) -> c_int;
+    pub fn gr_shape_rectangular(s: *mut gr_shape, position: *const c_float, x: c_float, y: c_float, z: c_float) -> c_int;
+    pub fn gr_shape_cylinder(s: *mut gr_shape, position: *const c_float, radius: c_float, height: c_float, orientation: c_int) -> c_int;
+    pub fn gr_shape_triangular_prism(s: *mut gr_shape, b1: *const c_float, b2: *const c_float, b3: *const c_float, height: c_float) -> c_int;
+    pub fn gr_group_create_from_geometries(ctx: *mut gr_ctx, slot: u32, name: *const c_char, source: *const c_char,
+                                           shapes: *const gr_shape, n: usize, naive: c_int) -> c_int;
+    // xtc frames unpacked on the device straight into frame slots (src/io/xtc_io/*: XtcReader + update_system)
+    pub fn gr_xtc_open(path: *const c_char, status: *mut c_int) -> *mut gr_xtc;
+    pub fn gr_xtc_close(xtc: *mut gr_xtc);
+    pub fn gr_xtc_read_frames_device(xtc: *const gr_xtc, first_frame: u64, n_frames: u32, frame_step: u64, ctx: *mut gr_ctx,
+                                     first_slot: u32, host_threads: c_int, steps: *mut u64, times: *mut c_float) -> c_int;
 }
+
+#[repr(C)] pub struct gr_xtc { _private: [u8; 0] }
+/// `gr_shape` of include/groan_hip.h: filled by the `gr_shape_*` constructors from the fields of
+/// `Sphere` / `Rectangular` / `Cylinder` / `TriangularPrism` (src/structures/shape.rs:17-68).
+#[repr(C)] #[derive(Clone, Copy, Default)]
+pub struct gr_shape { pub kind: c_int, pub position: [c_float; 3], pub size: [c_float; 3], pub base2: [c_float; 3], pub base3: [c_float; 3],
+                      pub orientation: c_int, pub plane: c_int }
 
 /// Device mirror of one `System` (one per worker thread / per GPU, like the clones of `traj_iter_map_reduce`).
 pub struct HipSystem { ctx: *mut gr_ctx, n_atoms: usize, _not_sync: PhantomData<*mut ()> }
