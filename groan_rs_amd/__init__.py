@@ -10,7 +10,7 @@ from .system import (AtomContainer, AtomError, DeviceError, Dimension, GroanErro
                      RMSDPlan, SimBoxError, System, pinned_array, pinned_free)
 from .traj import (FrameAnalyze, FrameConvert, FrameConvertAnalyze, RMSDConverterAnalyzer, TrajAnalyzer,
                    TrajAnalysisError, TrajConverter, TrajConverterAnalyzer, TrajReader)
-from .xtc import XtcError, XtcFile
+from .xtc import XtcError, XtcFile, XtcWriter
 from .shapes import Cylinder, Rectangular, Shape, Sphere, TriangularPrism
 from .parallel import ParallelTrajData, gather_per_frame, interleave, shard_frames, traj_iter_map_reduce
 
@@ -18,5 +18,5 @@ __all__ = [
     "AtomContainer", "AtomError", "DeviceError", "Dimension", "GroanError", "GroupError", "RMSDError", "RMSDPlan",
     "SimBoxError", "System", "pinned_array", "pinned_free", "FrameAnalyze", "FrameConvert", "FrameConvertAnalyze", "RMSDConverterAnalyzer",
     "TrajAnalyzer", "TrajAnalysisError", "TrajConverter", "TrajConverterAnalyzer", "TrajReader",
-    "XtcError", "XtcFile", "Cylinder", "Rectangular", "Shape", "Sphere", "TriangularPrism", "ParallelTrajData", "gather_per_frame", "interleave", "shard_frames", "traj_iter_map_reduce",
+    "XtcError", "XtcFile", "XtcWriter", "Cylinder", "Rectangular", "Shape", "Sphere", "TriangularPrism", "ParallelTrajData", "gather_per_frame", "interleave", "shard_frames", "traj_iter_map_reduce",
 ]

@@ -104,6 +104,7 @@ struct gr_ctx {
     // device-side xtc unpacking (gr_xtc_read_frames_device): grow-only staging, pinned host mirror + device copy
     unsigned char *xtc_host = nullptr, *xtc_dev = nullptr; size_t xtc_cap = 0;
     hipEvent_t xtc_ev = nullptr;      // the previous batch's H2D has consumed the pinned staging buffer
+    float *wr_host = nullptr; size_t wr_cap = 0;   // pinned landing buffer of gr_xtc_write_slots (grow-only)
     std::string ps_trace_path;
     int strict = 0;
     std::string err;
@@ -459,6 +460,7 @@ void gr_ctx_destroy(gr_ctx *c) {
     if (c->ps_sync) (void)hipFree(c->ps_sync);
     if (c->ps_trace) (void)hipFree(c->ps_trace);
     if (c->xtc_host) (void)hipHostFree(c->xtc_host);
+    if (c->wr_host) (void)hipHostFree(c->wr_host);
     if (c->xtc_dev) (void)hipFree(c->xtc_dev);
     if (c->xtc_ev) (void)hipEventDestroy(c->xtc_ev);
     if (c->ps_sync_host) (void)hipHostFree(c->ps_sync_host);
@@ -1405,6 +1407,100 @@ int gr_xtc_read_frames_device(const gr_xtc *x, uint64_t first_frame, uint32_t n_
         HIPCHK(c, hipEventRecord(c->ev_ready[first_slot + k], c->copy_stream));
         c->upload_pending[first_slot + k] = 1;
     }
+    return GR_OK;
+}
+
+/* ------------------------------------------------------------ xtc writer */
+struct gr_xtc_writer { FILE *fp = nullptr; };
+
+gr_xtc_writer *gr_xtc_writer_open(const char *path, int *status) {
+    int dummy; if (!status) status = &dummy;
+    if (!path) { *status = GR_E_INVALID_ARG; return nullptr; }
+    FILE *fp = fopen(path, "wb");
+    if (!fp) { *status = GR_E_IO; return nullptr; }
+    gr_xtc_writer *w = new gr_xtc_writer(); w->fp = fp; *status = GR_OK;
+    return w;
+}
+int gr_xtc_writer_close(gr_xtc_writer *w) {
+    if (!w) return GR_E_INVALID_ARG;
+    const int rc = w->fp ? fclose(w->fp) : 0;
+    delete w;
+    return rc == 0 ? GR_OK : GR_E_IO;
+}
+// gro-order box9 -> rows = box vectors (simbox2matrix, xdrfile.rs:188-200); NULL -> zero matrix
+static void box9_rows(const float *b, float m[9]) {
+    if (!b) { memset(m, 0, 9 * sizeof(float)); return; }
+    m[0] = b[0]; m[1] = b[3]; m[2] = b[4]; m[3] = b[5]; m[4] = b[1]; m[5] = b[6]; m[6] = b[7]; m[7] = b[8]; m[8] = b[2];
+}
+int gr_xtc_write_frame(gr_xtc_writer *w, uint64_t n, const float *xyz, const float box9[9], int64_t step, float time, float precision) {
+    if (!w || !w->fp || (!xyz && n) || n > 0x7fffffffull) return GR_E_INVALID_ARG;
+    float m[9]; box9_rows(box9, m);
+    std::vector<unsigned char> out; grx::EncodedFrame sc; std::vector<int> ints;
+    grx::serialise_frame(out, (uint32_t)n, (int32_t)step, time, m, xyz, precision, sc, ints);
+    return fwrite(out.data(), 1, out.size(), w->fp) == out.size() ? GR_OK : GR_E_IO;
+}
+int gr_xtc_write_slots(gr_xtc_writer *w, gr_ctx *c, uint32_t first_slot, uint32_t n_frames, const char *group,
+                       const int64_t *steps, const float *times, float precision, int host_threads) {
+    if (!w || !w->fp || !c) return GR_E_INVALID_ARG;
+    int st = slot_check(c, first_slot, n_frames); if (st) return st;
+    (void)hipSetDevice(c->device);
+    const Group *g = nullptr;
+    std::vector<uint64_t> members;
+    if (group) {
+        g = find_group(c, group);
+        if (!g) return fail(c, GR_E_GROUP_NOT_FOUND, group);     // WriteTrajError::GroupNotFound
+        members = grc::expand(g->blocks);
+    }
+    const uint64_t n_out = g ? g->n : c->n;
+    const size_t fb = (size_t)c->n * 3 * sizeof(float);
+    // D2H of the whole batch on the compute stream into one pinned buffer (frames are ordered behind the kernels that wrote them);
+    // per-frame events let the encoders start as soon as their frame has landed
+    if (fb * n_frames > c->wr_cap) {
+        if (c->wr_host) (void)hipHostFree(c->wr_host);
+        c->wr_host = nullptr; c->wr_cap = 0;
+        HIPCHK(c, hipHostMalloc(&c->wr_host, fb * n_frames, hipHostMallocDefault));
+        c->wr_cap = fb * n_frames;
+    }
+    float *host = c->wr_host;
+    std::vector<hipEvent_t> ev(n_frames, nullptr);
+    {
+        SlotUse use(c, first_slot, n_frames);
+        for (uint32_t k = 0; k < n_frames; ++k) {
+            hipError_t e = hipMemcpyAsync(host + (size_t)k * c->n * 3, c->frames + (size_t)(first_slot + k) * c->frame_stride, fb, hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&ev[k], hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventRecord(ev[k], c->stream);
+            if (e != hipSuccess) { for (auto x : ev) if (x) (void)hipEventDestroy(x); c->err = hipGetErrorString(e); return GR_E_HIP; }
+        }
+    }
+    std::vector<std::vector<unsigned char>> frames_out(n_frames);
+    std::atomic<uint32_t> next(0);
+    std::atomic<int> bad(0);
+    const int dev = c->device;
+    auto work = [&]() {
+        (void)hipSetDevice(dev);
+        grx::EncodedFrame sc; std::vector<int> ints; std::vector<float> gathered;
+        for (;;) {
+            const uint32_t k = next.fetch_add(1);
+            if (k >= n_frames) return;
+            if (hipEventSynchronize(ev[k]) != hipSuccess) { bad = 1; return; }
+            const float *src = host + (size_t)k * c->n * 3;
+            if (g) {
+                gathered.resize(3 * (size_t)n_out);
+                for (size_t j = 0; j < members.size(); ++j) memcpy(&gathered[3 * j], src + 3 * members[j], 12);
+                src = gathered.data();
+            }
+            float m[9]; box9_rows(c->box9_set[first_slot + k] ? &c->box9_host[9 * (size_t)(first_slot + k)] : nullptr, m);
+            grx::serialise_frame(frames_out[k], (uint32_t)n_out, (int32_t)(steps ? steps[k] : 0), times ? times[k] : 0.0f, m, src, precision, sc, ints);
+        }
+    };
+    uint32_t nt = host_threads > 0 ? (uint32_t)host_threads : std::min<uint32_t>(n_frames, 8u);
+    nt = std::max<uint32_t>(1u, std::min<uint32_t>(nt, n_frames));
+    if (nt == 1) work();
+    else { std::vector<std::thread> th; for (uint32_t t = 0; t < nt; ++t) th.emplace_back(work); for (auto &t : th) t.join(); }
+    for (auto x : ev) if (x) (void)hipEventDestroy(x);
+    if (bad.load()) return fail(c, GR_E_HIP, "device-to-host copy failed while writing frames");
+    for (uint32_t k = 0; k < n_frames; ++k)
+        if (fwrite(frames_out[k].data(), 1, frames_out[k].size(), w->fp) != frames_out[k].size()) return fail(c, GR_E_IO, "short write");
     return GR_OK;
 }
 

@@ -18,6 +18,9 @@
 // swapped with its predecessor (water oxygens/hydrogens).  magic[] is the format's table of ~2^(i/3) (with its
 // historical irregular entries).
 #pragma once
+#include <climits>
+#include <algorithm>
+#include <cstdlib>
 #include <fcntl.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -306,6 +309,171 @@ inline int skim_frame(const unsigned char *stream, const FrameIndex &fi, uint32_
     while (cps.size() < want) cps.push_back(Checkpoint{ (uint32_t)bitpos, n, (uint32_t)smallidx });
     d.n_cp = (uint32_t)cps.size();
     return XTC_OK;
+}
+
+
+// ================================================================================================ writer
+// The encoder of the same format (what the reference's XtcWriter produces through xdrfile's write_xtc,
+// src/io/xtc_io/mod.rs:256-331): byte-for-byte the stream GROMACS' xdr3dfcoord writes for the same coordinates, because a
+// reader cannot tell which of several valid encodings a writer chose and the reference's golden fitted trajectories
+// (short_trajectory_fit.xtc) are compared as files.  The choices that shape the stream:
+//   * quantisation q = trunc(x * precision +- 0.5) in single precision (the 0.5 is added in double, the sum rounded to float);
+//   * the starting small-range index = first table entry >= the smallest L1 step between consecutive atoms;
+//   * an atom whose successor lies within the small range is SWAPPED with it (water: O H H is stored H O H) and opens a
+//     run of up to 8 small atoms; the range index moves down by one when a whole group stayed inside the next smaller
+//     range, up by one when the group's first atom was near its predecessor ("larger" range) ...
+//   * ... signalled by one flag bit + 5 bits (run length * 3 + change + 1) only when run length or index change.
+// MSB-first bit writer
+struct BitWriter {
+    std::vector<unsigned char> &out; unsigned char *p; uint64_t acc = 0; int nacc = 0;
+    // `o` must already be sized for the worst case (encode_coords: 16 bytes per atom); finish() trims it
+    explicit BitWriter(std::vector<unsigned char> &o) : out(o), p(o.data()) {}
+    inline void put(int nbits, uint32_t v) {   // 0 <= nbits <= 32, v < 2^nbits
+        if (nbits == 0) return;
+        acc = (acc << nbits) | (uint64_t)v; nacc += nbits;
+        while (nacc >= 8) { *p++ = (unsigned char)(acc >> (nacc - 8)); nacc -= 8; }
+        acc &= (nacc == 0) ? 0ull : ((1ull << nacc) - 1ull);
+    }
+    // a packed integer of `nbits` bits: its bytes go out least significant first, the last (partial) chunk holds the top bits
+    inline void put_packed(int nbits, unsigned __int128 v) {
+        while (nbits >= 8) { put(8, (uint32_t)(v & 0xff)); v >>= 8; nbits -= 8; }
+        if (nbits > 0) put(nbits, (uint32_t)(v & ((1u << nbits) - 1u)));
+    }
+    inline void finish() { if (nacc > 0) { *p++ = (unsigned char)(acc << (8 - nacc)); nacc = 0; acc = 0; } out.resize((size_t)(p - out.data())); }
+};
+
+struct EncodedFrame {
+    float precision; int32_t minint[3], maxint[3], smallidx;
+    std::vector<unsigned char> bytes;   // the bit stream (not yet padded to 4 bytes)
+};
+
+inline int quantise(float x, float precision) {
+    const float prod = x * precision;
+    const float lf = (float)((double)prod + (x >= 0.0f ? 0.5 : -0.5));
+    return (int)lf;
+}
+
+// xyz[n][3] (n > 9) -> header integers + bit stream; `ints` is scratch (3 n ints)
+inline void encode_coords(const float *xyz, uint32_t n, float precision, EncodedFrame &e, std::vector<int> &ints) {
+    if (!(precision > 0.0f)) precision = 1000.0f;
+    e.precision = precision;
+    ints.resize(3 * (size_t)n);
+    int mn[3] = { INT_MAX, INT_MAX, INT_MAX }, mx[3] = { INT_MIN, INT_MIN, INT_MIN };
+    long long mindiff = INT_MAX;
+    int old[3] = { 0, 0, 0 };
+    for (uint32_t i = 0; i < n; ++i) {
+        int q[3];
+        const bool missing = xyz[3 * (size_t)i] != xyz[3 * (size_t)i];   // None travels as NaN in x: written as the origin (xtc_io/mod.rs:296-301)
+        for (int a = 0; a < 3; ++a) {
+            const float x = missing ? 0.0f : xyz[3 * (size_t)i + a];
+            q[a] = quantise(x, precision);
+            if (q[a] < mn[a]) mn[a] = q[a];
+            if (q[a] > mx[a]) mx[a] = q[a];
+            ints[3 * (size_t)i + a] = q[a];
+        }
+        const long long diff = llabs((long long)old[0] - q[0]) + llabs((long long)old[1] - q[1]) + llabs((long long)old[2] - q[2]);
+        if (i > 0 && diff < mindiff) mindiff = diff;
+        old[0] = q[0]; old[1] = q[1]; old[2] = q[2];
+    }
+    uint32_t sizeint[3];
+    for (int a = 0; a < 3; ++a) { e.minint[a] = mn[a]; e.maxint[a] = mx[a]; sizeint[a] = (uint32_t)(mx[a] - mn[a] + 1); }
+    int bitsizeint[3] = { 0, 0, 0 }, bitsize;
+    if ((sizeint[0] | sizeint[1] | sizeint[2]) > 0xffffffu) {
+        for (int a = 0; a < 3; ++a) { int b = bit_length(sizeint[a]); bitsizeint[a] = b > 32 ? 32 : b; }
+        bitsize = 0;
+    } else {
+        bitsize = bit_length((unsigned __int128)sizeint[0] * sizeint[1] * sizeint[2]);
+    }
+    int smallidx = kFirstIdx;
+    while (smallidx < kLastIdx && kMagic[smallidx < kLastIdx ? smallidx : kLastIdx - 1] < mindiff) ++smallidx;
+    if (smallidx > kLastIdx - 1) smallidx = kLastIdx - 1;   // (the C code would index one past its table here; unreachable for real data)
+    e.smallidx = smallidx;
+    int maxidx = std::min(kLastIdx - 1, smallidx + 8);
+    const int minidx = maxidx - 8;
+    int smaller = kMagic[std::max(kFirstIdx, smallidx - 1)] / 2;
+    int smallnum = kMagic[smallidx] / 2;
+    uint32_t sizesmall = (uint32_t)kMagic[smallidx];
+    const int larger = kMagic[maxidx] / 2;
+    e.bytes.resize((size_t)n * 16 + 16);   // worst case: 96 bits + 6 flag bits per atom
+    BitWriter bw(e.bytes);
+    int prev[3] = { 0, 0, 0 };
+    int prevrun = -1;
+    uint32_t i = 0;
+    auto near = [](const int *a, const int *b, int lim) { return std::abs(a[0] - b[0]) < lim && std::abs(a[1] - b[1]) < lim && std::abs(a[2] - b[2]) < lim; };
+    while (i < n) {
+        int *cur = &ints[3 * (size_t)i];
+        int is_smaller = 0, is_small = 0;
+        if (smallidx < maxidx && i >= 1 && near(cur, prev, larger)) is_smaller = 1;
+        else if (smallidx > minidx) is_smaller = -1;
+        if (i + 1 < n && near(cur, cur + 3, smallnum)) {
+            for (int a = 0; a < 3; ++a) std::swap(cur[a], cur[3 + a]);
+            is_small = 1;
+        }
+        if (bitsize == 0) {
+            for (int a = 0; a < 3; ++a) bw.put(bitsizeint[a], (uint32_t)(cur[a] - mn[a]));
+        } else {
+            const unsigned __int128 v = ((unsigned __int128)(uint32_t)(cur[0] - mn[0]) * sizeint[1] + (uint32_t)(cur[1] - mn[1])) * sizeint[2] + (uint32_t)(cur[2] - mn[2]);
+            bw.put_packed(bitsize, v);
+        }
+        prev[0] = cur[0]; prev[1] = cur[1]; prev[2] = cur[2];
+        cur += 3; ++i;
+        int run = 0;
+        uint32_t small[24];
+        if (is_small == 0 && is_smaller == -1) is_smaller = 0;
+        while (is_small && run < 24) {
+            // the C code does this test in 32-bit ints; beyond ~46 k quanta per step the squares wrap, and a byte-compatible
+            // stream has to wrap with them
+            uint32_t usum = 0;
+            for (int a = 0; a < 3; ++a) { const uint32_t d = (uint32_t)(cur[a] - prev[a]); usum += d * d; }
+            if (is_smaller == -1 && (int32_t)usum >= (int32_t)((uint32_t)smaller * (uint32_t)smaller)) is_smaller = 0;
+            for (int a = 0; a < 3; ++a) small[run++] = (uint32_t)(cur[a] - prev[a] + smallnum);
+            prev[0] = cur[0]; prev[1] = cur[1]; prev[2] = cur[2];
+            ++i; cur += 3;
+            is_small = (i < n && near(cur, prev, smallnum)) ? 1 : 0;
+        }
+        if (run != prevrun || is_smaller != 0) {
+            prevrun = run;
+            bw.put(1, 1u);
+            bw.put(5, (uint32_t)(run + is_smaller + 1));
+        } else {
+            bw.put(1, 0u);
+        }
+        for (int k = 0; k < run; k += 3) {
+            const unsigned __int128 v = ((unsigned __int128)small[k] * sizesmall + small[k + 1]) * sizesmall + small[k + 2];
+            bw.put_packed(smallidx, v);
+        }
+        if (is_smaller != 0) {
+            smallidx += is_smaller;
+            if (is_smaller < 0) { smallnum = smaller; smaller = kMagic[smallidx - 1] / 2; }
+            else { smaller = smallnum; smallnum = kMagic[smallidx] / 2; }
+            sizesmall = (uint32_t)kMagic[smallidx];
+        }
+    }
+    bw.finish();
+}
+
+inline void put_be32(std::vector<unsigned char> &o, uint32_t v) { o.push_back((unsigned char)(v >> 24)); o.push_back((unsigned char)(v >> 16)); o.push_back((unsigned char)(v >> 8)); o.push_back((unsigned char)v); }
+inline void put_bef(std::vector<unsigned char> &o, float f) { uint32_t u; memcpy(&u, &f, 4); put_be32(o, u); }
+
+// one whole frame as it appears in the file (magic 1995): header, box (rows = box vectors), coordinates
+inline void serialise_frame(std::vector<unsigned char> &o, uint32_t natoms, int32_t step, float time, const float box_rows[9], const float *xyz,
+                            float precision, EncodedFrame &scratch, std::vector<int> &ints) {
+    o.clear();
+    put_be32(o, 1995u); put_be32(o, natoms); put_be32(o, (uint32_t)step); put_bef(o, time);
+    for (int k = 0; k < 9; ++k) put_bef(o, box_rows[k]);
+    put_be32(o, natoms);
+    if (natoms <= 9) {
+        for (uint32_t k = 0; k < 3 * natoms; ++k) put_bef(o, (xyz[3 * (k / 3)] != xyz[3 * (k / 3)]) ? 0.0f : xyz[k]);
+        return;
+    }
+    encode_coords(xyz, natoms, precision, scratch, ints);
+    put_bef(o, scratch.precision);
+    for (int a = 0; a < 3; ++a) put_be32(o, (uint32_t)scratch.minint[a]);
+    for (int a = 0; a < 3; ++a) put_be32(o, (uint32_t)scratch.maxint[a]);
+    put_be32(o, (uint32_t)scratch.smallidx);
+    put_be32(o, (uint32_t)scratch.bytes.size());
+    o.insert(o.end(), scratch.bytes.begin(), scratch.bytes.end());
+    while (o.size() & 3u) o.push_back(0);
 }
 
 }  // namespace grx

@@ -78,3 +78,51 @@ class XtcFile:
 
     def __iter__(self):
         return self.frames()
+
+
+class XtcWriter:
+    """XtcWriter (src/io/xtc_io/mod.rs:256-331) over gr_xtc_writer_*: the library's own encoder, byte-compatible with the
+    reference's writer.  `write_frame` takes host coordinates, `write_slots` streams device frames out (fitted trajectories)."""
+
+    def __init__(self, path):
+        self._lib = _lib.load()
+        st = C.c_int(0)
+        self._w = self._lib.gr_xtc_writer_open(str(path).encode(), C.byref(st))
+        if not self._w:
+            raise XtcError(st.value, "cannot create %s" % path)
+
+    def write_frame(self, positions, box9, step=0, time=0.0, precision=1000.0):
+        x = np.ascontiguousarray(positions, np.float32)
+        b = None if box9 is None else np.ascontiguousarray(box9, np.float32)
+        st = self._lib.gr_xtc_write_frame(self._w, x.shape[0], x.ctypes.data_as(C.c_void_p), None if b is None else b.ctypes.data_as(C.c_void_p),
+                                          int(step), C.c_float(time), C.c_float(precision))
+        if st != _lib.OK:
+            raise XtcError(st, "write_frame")
+
+    def write_slots(self, system, first_slot, n_frames, group=None, steps=None, times=None, precision=1000.0, host_threads=0):
+        s = None if steps is None else np.ascontiguousarray(steps, np.int64)
+        t = None if times is None else np.ascontiguousarray(times, np.float32)
+        st = self._lib.gr_xtc_write_slots(self._w, system._ctx, first_slot, n_frames, None if group is None else group.encode(),
+                                          None if s is None else s.ctypes.data_as(C.c_void_p), None if t is None else t.ctypes.data_as(C.c_void_p),
+                                          C.c_float(precision), host_threads)
+        if st != _lib.OK:
+            raise XtcError(st, "write_slots: %s" % self._lib.gr_last_error(system._ctx).decode(errors="replace"))
+
+    def close(self):
+        if getattr(self, "_w", None):
+            st = self._lib.gr_xtc_writer_close(self._w)
+            self._w = None
+            if st != _lib.OK:
+                raise XtcError(st, "close")
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

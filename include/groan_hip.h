@@ -201,6 +201,20 @@ int gr_rmsd_plan_force_exact(gr_rmsd_plan *plan, int on);
 int gr_ctx_set_persistent(gr_ctx *ctx, int mode);
 int gr_rmsd_plan_last_persistent(const gr_rmsd_plan *plan);
 
+/* ---------------------------------------------------------------- xtc writer (host side; the step after calc_rmsd_and_fit)
+ * XtcWriter::new / write_frame (src/io/xtc_io/mod.rs:256-331 over xdrfile's write_xtc): the library's own encoder, byte for
+ * byte the stream the reference writes for the same coordinates (the reference's golden fitted trajectories are files).
+ * Atoms without a position are written as the origin, a frame without box as a zero matrix (xdrfile.rs:188-200).
+ * gr_xtc_write_slots streams device frames out: D2H of slot k+1 overlaps the encoding of slot k (`host_threads` encoders,
+ * 0 = up to 8), frames are written in slot order; `group` = NULL writes every atom, else the group's atoms in its order
+ * (xtc_group_writer_init). */
+typedef struct gr_xtc_writer gr_xtc_writer;
+gr_xtc_writer *gr_xtc_writer_open(const char *path, int *status);
+int gr_xtc_writer_close(gr_xtc_writer *w);
+int gr_xtc_write_frame(gr_xtc_writer *w, uint64_t n_atoms, const float *xyz, const float box9[9], int64_t step, float time, float precision);
+int gr_xtc_write_slots(gr_xtc_writer *w, gr_ctx *ctx, uint32_t first_slot, uint32_t n_frames, const char *group,
+                       const int64_t *steps, const float *times, float precision, int host_threads);
+
 /* ---------------------------------------------------------------- geometry selection
  * Shape::inside of Sphere / Rectangular / Cylinder / TriangularPrism (src/structures/shape.rs:110-185,252-276,431-461),
  * the PBC-free NaiveShape variants (:466-505), and System::group_create_from_geometry / _geometries

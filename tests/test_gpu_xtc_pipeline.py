@@ -144,6 +144,19 @@ def test_decode_upload_com_wrap_pipeline(tmp_path):
     t_dev = time.perf_counter() - t0
     assert np.array_equal(np.array(coms_dev), np.array(coms))                        # same decoded bits -> same results
     assert np.array_equal(wrapped_dev, wrapped_first)
+    # ---- and out again: D2H + the library's encoder (fitted-trajectory output, NEXT-4), n_threads encoders
+    wpath = tmp_path / "rewritten.xtc"
+    x.read_frames_device(sysd, 0, B, first_slot=0, host_threads=n_threads)
+    with G.XtcWriter(wpath) as w:
+        w.write_slots(sysd, 0, B, precision=1000.0, host_threads=n_threads)          # warm-up
+        t0 = time.perf_counter()
+        for _ in range(3):
+            w.write_slots(sysd, 0, B, precision=1000.0, host_threads=n_threads)
+        t_write_ours = (time.perf_counter() - t0) / (3 * B)
+    y = G.XtcFile(wpath)
+    assert y.n_frames == 4 * B and np.array_equal(y.read_frame(B + 1)[0], x.read_frame(1)[0])   # decode(encode(decode)) is a fixed point
+    y.close()
+    out["write_slots_frames_per_s"] = round(1.0 / t_write_ours, 1)
     out["device_unpack_pipeline_frames_per_s"] = round(n_frames / t_dev, 1)
     out["device_unpack_only_frames_per_s"] = round(1.0 / t_unpack_only, 1)
     out["device_unpack_batch"] = B

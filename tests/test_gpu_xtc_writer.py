@@ -1,0 +1,80 @@
+"""Fitted-trajectory output on the GPU box: xtc decode -> RMSD-fit on the device -> gr_xtc_write_slots (D2H + the library's
+encoder) against the reference's golden fitted trajectory (short_trajectory_fit.xtc, src/system/rmsd.rs:950-1073; the kept
+atoms are in tests/golden/short_traj.npz) and, byte for byte, against the reference's own writer on the same coordinates."""
+import os
+
+import numpy as np
+import pytest
+
+from test_xtc_decoder import GOLD, REF_SO, write_with_ref
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def G():
+    import groan_rs_amd as g
+    g._lib.load()
+    return g
+
+
+def test_decode_fit_write_matches_the_reference_fit_golden(G, tmp_path, example, short_traj):
+    x = G.XtcFile(os.path.join(GOLD, "short_trajectory.xtc"))
+    n, nf = x.n_atoms, x.n_frames
+    masses = np.full(n, np.nan, np.float32); masses[:61] = example["protein_masses"]
+    ref = G.System(n, masses=masses, box=example["box9"], positions=example["pos"])
+    cur = G.System(n, masses=masses, n_slots=nf)
+    for s in (ref, cur):
+        s.group_create_from_ranges("Protein", [(0, 60)])
+    steps, times = x.read_frames_device(cur, 0, nf)
+    plan = G.RMSDPlan(ref, cur, "Protein")
+    r, st = plan.rmsd_fit(0, nf)
+    assert (st == 0).all()
+    prec = x.frame_info(0)[3]
+    out = tmp_path / "fit.xtc"
+    with G.XtcWriter(out) as w:
+        w.write_slots(cur, 0, nf, steps=steps.astype(np.int64), times=times, precision=prec)
+    y = G.XtcFile(out)
+    assert y.n_atoms == n and y.n_frames == nf
+    keep = short_traj["keep"].astype(np.int64)
+    # both files hold QUANTISED coordinates whose sources agree to ~1e-4 nm (the reference's own f32 SVD noise, see
+    # test_oracle_golden.py): almost every coordinate is identical, a source that sits on a rounding boundary lands one
+    # quantum apart
+    flips = total = 0
+    for f in range(nf):
+        pos, box, step, time, p = y.read_frame(f)
+        assert step == steps[f] and time == times[f] and p == np.float32(prec)
+        assert np.array_equal(box, x.frame_info(f)[2])
+        d = np.abs(pos[keep] - short_traj["fit"][f])
+        assert d.max() <= 1.0 / prec + 1e-6
+        flips += int((d > 1e-6).sum()); total += d.size
+        # what was written is the quantised device frame
+        assert np.abs(pos - cur.get_positions(f)).max() <= 0.5 / prec + 1e-6
+    assert flips <= 0.03 * total, (flips, total)
+    # the same frames through the host entry point: identical bytes
+    out2 = tmp_path / "fit_host.xtc"
+    with G.XtcWriter(out2) as w:
+        for f in range(nf):
+            w.write_frame(cur.get_positions(f), cur.get_box(f), step=int(steps[f]), time=float(times[f]), precision=prec)
+    assert open(out, "rb").read() == open(out2, "rb").read()
+    # a group writer (xtc_group_writer_init): only the group's atoms, in its order
+    out3 = tmp_path / "fit_protein.xtc"
+    with G.XtcWriter(out3) as w:
+        w.write_slots(cur, 0, nf, group="Protein", steps=steps.astype(np.int64), times=times, precision=prec, host_threads=3)
+    z = G.XtcFile(out3)
+    assert z.n_atoms == 61 and z.n_frames == nf
+    for f in (0, nf - 1):
+        assert np.array_equal(z.read_frame(f)[0], y.read_frame(f)[0][:61])
+    with pytest.raises(G.XtcError):
+        G.XtcWriter(tmp_path / "x.xtc").write_slots(cur, 0, 1, group="nope")
+    if os.path.exists(REF_SO):                                          # and against the reference's writer on the same coordinates
+        frames = [cur.get_positions(f) for f in range(nf)]
+        b9 = cur.get_box(0)
+        boxm = np.array([[b9[0], b9[3], b9[4]], [b9[5], b9[1], b9[6]], [b9[7], b9[8], b9[2]]], np.float32)
+        refp, ours = tmp_path / "ref.xtc", tmp_path / "ours.xtc"
+        write_with_ref(refp, frames, boxm, prec)
+        with G.XtcWriter(ours) as w:
+            for i, fr in enumerate(frames):
+                w.write_frame(fr, b9, step=i * 10, time=i * 0.5, precision=prec)
+        assert open(refp, "rb").read() == open(ours, "rb").read()
+    x.close(); y.close(); z.close(); ref.close(); cur.close()

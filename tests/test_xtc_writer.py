@@ -1,0 +1,81 @@
+"""The library's own xtc ENCODER (groan_rs_amd/csrc/gr_xtc.h, host code) must write byte for byte what the reference's
+writer writes (XtcWriter over xdrfile's write_xtc, src/io/xtc_io/mod.rs:256-331) -- the reference's golden fitted
+trajectories are compared as files.
+  (1) known answers: the committed data files of the reference's test suite.  Decoding is exact (test_xtc_decoder.py), and
+      re-quantising a decoded coordinate returns its integer, so encode(decode(file)) has to reproduce the file itself;
+  (2) when oracle/_ref is built: synthetic coordinates through the reference's writer and through ours, same bytes, over
+      every branch of the format (raw <= 9 atoms, water runs, wide ranges, > 64-bit packing, precision 1e5, negative coordinates).
+CPU only (host code)."""
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+from test_xtc_decoder import GOLD, REF_SO, water_like, write_with_ref
+
+
+@pytest.fixture(scope="module")
+def G():
+    import groan_rs_amd as g
+    g._lib.load()
+    return g
+
+
+def rows_to_box9(m):
+    m = np.asarray(m, np.float32).ravel()
+    return np.array([m[0], m[4], m[8], m[1], m[2], m[3], m[5], m[6], m[7]], np.float32)
+
+
+@pytest.mark.parametrize("name", ["triclinic_trajectory.xtc", "octahedron_trajectory.xtc", "dodecahedron_trajectory.xtc", "short_trajectory.xtc"])
+def test_reencoding_the_reference_files_reproduces_them(G, tmp_path, name):
+    src = os.path.join(GOLD, name)
+    x = G.XtcFile(src)
+    out = tmp_path / name
+    with G.XtcWriter(out) as w:
+        for i in range(x.n_frames):
+            pos, box, step, time, prec = x.read_frame(i)
+            w.write_frame(pos, box, step=step, time=time, precision=prec)
+    x.close()
+    assert open(out, "rb").read() == open(src, "rb").read()
+
+
+@pytest.mark.parametrize("case", ["tiny9", "water", "gas", "negative", "wide_range", "wide_product", "high_precision", "mixed", "no_box_nan"])
+def test_same_bytes_as_the_reference_writer(G, tmp_path, case):
+    if not os.path.exists(REF_SO):
+        pytest.skip("oracle/_ref not built (reference tree absent)")
+    rng = np.random.default_rng(zlib.crc32(case.encode()) + 1)
+    boxm = np.array([[30, 0, 0], [0, 30, 0], [10, 10, 25]], np.float32)
+    prec = 1000.0
+    if case == "tiny9": frames = [rng.uniform(-5, 5, (9, 3)).astype(np.float32) for _ in range(3)]
+    elif case == "water": frames = [water_like(rng, 30000, 20.0) for _ in range(3)]
+    elif case == "gas": frames = [rng.uniform(0, 50, (5000, 3)).astype(np.float32) for _ in range(3)]
+    elif case == "negative": frames = [(water_like(rng, 6000, 8.0) - 4.0).astype(np.float32) for _ in range(3)]
+    elif case == "wide_range": frames = [np.concatenate([rng.uniform(0, 10, (4000, 3)), [[20000.0, 3.0, 4.0]]]).astype(np.float32) for _ in range(2)]
+    elif case == "wide_product": frames = [rng.uniform(0, 8000, (3000, 3)).astype(np.float32) for _ in range(2)]
+    elif case == "high_precision":
+        prec = 100000.0
+        frames = [water_like(rng, 3000, 6.0) for _ in range(3)]
+    elif case == "no_box_nan":
+        frames = [water_like(rng, 999, 5.0) for _ in range(2)]
+        boxm = np.zeros((3, 3), np.float32)
+    else:
+        frames = [np.concatenate([water_like(rng, 9000, 12.0), rng.uniform(0, 12, (1000, 3)).astype(np.float32), water_like(rng, 2001, 3.0)]) for _ in range(4)]
+    ref_path, our_path = tmp_path / "ref.xtc", tmp_path / "ours.xtc"
+    write_with_ref(ref_path, frames, boxm, prec)
+    with G.XtcWriter(our_path) as w:
+        for i, f in enumerate(frames):
+            g = f.copy()
+            if case == "no_box_nan":
+                g[5, 0] = np.nan                      # an atom without position is written as the origin
+                frames[i][5] = 0.0
+            w.write_frame(g, None if case == "no_box_nan" else rows_to_box9(boxm), step=i * 10, time=i * 0.5, precision=prec)
+    if case == "no_box_nan":
+        write_with_ref(ref_path, frames, boxm, prec)
+    a, b = open(our_path, "rb").read(), open(ref_path, "rb").read()
+    assert len(a) == len(b) and a == b, (case, len(a), len(b), next((k for k in range(min(len(a), len(b))) if a[k] != b[k]), None))
+
+
+def test_errors(G, tmp_path):
+    with pytest.raises(G.XtcError):
+        G.XtcWriter(tmp_path / "no_such_dir" / "x.xtc")
