@@ -77,8 +77,8 @@ struct gr_ctx {
     int two_pass = 1;                 // GR_TWO_PASS=0: RMSD-fit keeps the closed-form single-pass rmsd (k_rmsd_accum<0,false>)
     GrFrameState *state_dev = nullptr;
     GrFrameState *state_host = nullptr;   // pinned
-    uint32_t *bad_dev = nullptr;          // [4]
-    uint32_t *bad_host = nullptr;         // pinned [4]
+    uint32_t *bad_dev = nullptr;          // [4 * GR_MAX_BATCH]: per frame, first atom without position (rows / columns)
+    uint32_t *bad_host = nullptr;         // pinned, same size
     float *pd_out = nullptr; size_t pd_cap = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // per-kernel HIP-event profile of the batched RMSD path (gr_profile_*): 0 accumulate, 1 finalize, 2 fit
@@ -410,8 +410,8 @@ gr_ctx *gr_ctx_create(int device, uint64_t n_atoms, uint32_t n_slots, int *statu
     ok = ok && hipMalloc(&c->acc_partials, (size_t)GR_MAX_BATCH * GR_MAX_CHUNKS * sizeof(GrAccPartial)) == hipSuccess;
     ok = ok && hipMalloc(&c->state_dev, GR_MAX_BATCH * sizeof(GrFrameState)) == hipSuccess;
     ok = ok && hipHostMalloc(&c->state_host, GR_MAX_BATCH * sizeof(GrFrameState), hipHostMallocDefault) == hipSuccess;
-    ok = ok && hipMalloc(&c->bad_dev, 4 * sizeof(uint32_t)) == hipSuccess;
-    ok = ok && hipHostMalloc(&c->bad_host, 4 * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipMalloc(&c->bad_dev, 4 * GR_MAX_BATCH * sizeof(uint32_t)) == hipSuccess;
+    ok = ok && hipHostMalloc(&c->bad_host, 4 * GR_MAX_BATCH * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess;
     ok = ok && hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess;
 
     if (const char *e = getenv("GR_SUB_BATCH")) { int v = atoi(e); if (v >= 1 && v <= GR_MAX_BATCH) c->sub_batch = (uint32_t)v; }
@@ -833,7 +833,7 @@ static int translate_impl(gr_ctx *c, uint32_t slot, const char *group, const flo
     HIPCHK(c, hipMemsetAsync(c->bad_dev, 0xFF, 4 * sizeof(uint32_t), c->stream));
     const uint64_t units = sel.contiguous ? ((uint64_t)sel.n + 3) / 4 + 128 : sel.n;
     uint32_t nwg = (uint32_t)std::min<uint64_t>((units + GR_WG - 1) / GR_WG, 4096);
-    k_translate_wrap<<<dim3(nwg), dim3(GR_WG), 0, c->stream>>>(c->frames + (size_t)slot * c->frame_stride, sel, c->boxes_dev + slot, c->state_dev, use_state, dim_mask, v ? v[0] : 0.f, v ? v[1] : 0.f, v ? v[2] : 0.f, c->bad_dev);
+    k_translate_wrap<<<dim3(nwg), dim3(GR_WG), 0, c->stream>>>(c->frames + (size_t)slot * c->frame_stride, c->frame_stride, sel, c->boxes_dev + slot, c->state_dev, use_state, dim_mask, v ? v[0] : 0.f, v ? v[1] : 0.f, v ? v[2] : 0.f, c->bad_dev);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(c->bad_host, c->bad_dev, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -868,6 +868,119 @@ int gr_atoms_center(gr_ctx *c, uint32_t slot, const char *ref_group, int dim, in
     st = fetch_states(c, 1); if (st) return st;
     st = frame_status(c, c->state_host[0]); if (st) return st;
     return translate_impl(c, slot, "all", nullptr, 1, mask[dim]);
+}
+
+/* ------------------------------------------------------------ the same per-frame calls over a batch of slots */
+// host checks of one batch in the reference's order; pre[f] = GR_OK or the frame's error (messages kept for the first)
+static void batch_prechecks(gr_ctx *c, uint32_t s0, uint32_t nb, bool need_box, std::vector<int> &pre, std::vector<std::string> &msg) {
+    pre.assign(nb, GR_OK); msg.assign(nb, std::string());
+    for (uint32_t f = 0; f < nb; ++f) {
+        if (!need_box) continue;
+        const int s = box_check(c, s0 + f);
+        pre[f] = s;
+        if (s != GR_OK) msg[f] = c->err;
+    }
+}
+int gr_group_center_batch(gr_ctx *c, uint32_t first_slot, uint32_t n_frames, const char *group, int kind, int weighted, float *out, int *status_out) {
+    int st = slot_check(c, first_slot, n_frames); if (st) return st;
+    (void)hipSetDevice(c->device);
+    const Group *g = find_group(c, group);
+    if (!g) return fail(c, GR_E_GROUP_NOT_FOUND, group ? group : "(null)");
+    if (g->n == 0) return fail(c, GR_E_EMPTY_GROUP, group);
+    if (kind != GR_CENTER_NAIVE && kind != GR_CENTER_ESTIMATE && kind != GR_CENTER_PBC) return fail(c, GR_E_INVALID_ARG, "unknown centre kind");
+    const GrSel sel = make_sel(*g);
+    int first_err = GR_OK; std::string first_msg; uint64_t first_idx = 0;
+    for (uint32_t b0 = 0; b0 < n_frames; b0 += GR_MAX_BATCH) {
+        const uint32_t nb = std::min<uint32_t>(GR_MAX_BATCH, n_frames - b0), s0 = first_slot + b0;
+        std::vector<int> pre; std::vector<std::string> msg;
+        batch_prechecks(c, s0, nb, kind != GR_CENTER_NAIVE, pre, msg);
+        SlotUse use(c, s0, nb);
+        for (uint32_t f = 0; f < nb; ++f) { GrFrameState z = {}; z.err_index = GR_NOIDX; z.status = pre[f]; c->state_host[f] = z; }
+        HIPCHK(c, hipMemcpyAsync(c->state_dev, c->state_host, nb * sizeof(GrFrameState), hipMemcpyHostToDevice, c->stream));
+        if (kind == GR_CENTER_NAIVE) st = center_stage(c, s0, nb, sel, 0, weighted, 0, 1);
+        else if (kind == GR_CENTER_ESTIMATE) st = center_stage(c, s0, nb, sel, 1, weighted, 1, 1);
+        else st = pbc_center_stages(c, s0, nb, sel, weighted);
+        if (st) return st;
+        st = fetch_states(c, nb); if (st) return st;
+        for (uint32_t f = 0; f < nb; ++f) {
+            int s = pre[f];
+            if (s != GR_OK) c->err = msg[f];
+            else s = frame_status(c, c->state_host[f]);
+            if (s != GR_OK && first_err == GR_OK) { first_err = s; first_msg = c->err; first_idx = c->err_index; }
+            if (status_out) status_out[b0 + f] = s;
+            if (out) for (int k = 0; k < 3; ++k) out[3 * (size_t)(b0 + f) + k] = (s == GR_OK) ? c->state_host[f].com[k] : NAN;
+        }
+    }
+    if (first_err != GR_OK) { c->err = first_msg; c->err_index = first_idx; }
+    return first_err;
+}
+// translate / wrap / centre a batch of frames: pre[] carries the host checks, frames that failed are left untouched
+static int translate_batch(gr_ctx *c, uint32_t s0, uint32_t nb, const Group *g, const float *v, int mode, int dim_mask,
+                           const std::vector<int> &pre, const std::vector<std::string> &msg, int *status_out, int &first_err, std::string &first_msg, uint64_t &first_idx) {
+    const GrSel sel = make_sel(*g);
+    HIPCHK(c, hipMemsetAsync(c->bad_dev, 0xFF, 4 * (size_t)nb * sizeof(uint32_t), c->stream));
+    if (g->n) {
+        const uint64_t units = sel.contiguous ? ((uint64_t)sel.n + 3) / 4 + 128 : sel.n;
+        const uint32_t nwg = (uint32_t)std::min<uint64_t>((units + GR_WG - 1) / GR_WG, 4096);
+        k_translate_wrap<<<dim3(nwg, nb), dim3(GR_WG), 0, c->stream>>>(c->frames + (size_t)s0 * c->frame_stride, c->frame_stride, sel, c->boxes_dev + s0, c->state_dev, mode, dim_mask,
+                                                                       v ? v[0] : 0.f, v ? v[1] : 0.f, v ? v[2] : 0.f, c->bad_dev);
+        HIPCHK(c, hipGetLastError());
+    }
+    HIPCHK(c, hipMemcpyAsync(c->bad_host, c->bad_dev, 4 * (size_t)nb * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->state_host, c->state_dev, nb * sizeof(GrFrameState), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (uint32_t f = 0; f < nb; ++f) {
+        int s = pre[f];
+        if (s != GR_OK) c->err = msg[f];
+        else if (mode == 1 && c->state_host[f].status != GR_OK) s = frame_status(c, c->state_host[f]);
+        else if (c->bad_host[4 * f] != GR_NOIDX) s = fail(c, GR_E_NO_POSITION, "atom has no position", c->bad_host[4 * f]);
+        if (s != GR_OK && first_err == GR_OK) { first_err = s; first_msg = c->err; first_idx = c->err_index; }
+        if (status_out) status_out[f] = s;
+    }
+    return GR_OK;
+}
+static int translate_batch_api(gr_ctx *c, uint32_t first_slot, uint32_t n_frames, const char *group, const float *v, const char *center_group, int dim, int weighted, int *status_out) {
+    int st = slot_check(c, first_slot, n_frames); if (st) return st;
+    (void)hipSetDevice(c->device);
+    const Group *g = find_group(c, group ? group : "all");
+    if (!g) return fail(c, GR_E_GROUP_NOT_FOUND, group);
+    const Group *cg = nullptr;
+    if (center_group) {
+        cg = find_group(c, center_group);
+        if (!cg) return fail(c, GR_E_GROUP_NOT_FOUND, center_group);
+        if (cg->n == 0) return fail(c, GR_E_EMPTY_GROUP, center_group);
+        if (dim < 0 || dim > 7) return fail(c, GR_E_INVALID_ARG, "bad dimension");
+    }
+    static const int mask[8] = { 0, 1, 2, 4, 3, 5, 6, 7 };
+    int first_err = GR_OK; std::string first_msg; uint64_t first_idx = 0;
+    for (uint32_t b0 = 0; b0 < n_frames; b0 += GR_MAX_BATCH) {
+        const uint32_t nb = std::min<uint32_t>(GR_MAX_BATCH, n_frames - b0), s0 = first_slot + b0;
+        std::vector<int> pre; std::vector<std::string> msg;
+        batch_prechecks(c, s0, nb, true, pre, msg);
+        SlotUse use(c, s0, nb);
+        for (uint32_t f = 0; f < nb; ++f) { GrFrameState z = {}; z.err_index = GR_NOIDX; z.status = pre[f]; c->state_host[f] = z; }
+        HIPCHK(c, hipMemcpyAsync(c->state_dev, c->state_host, nb * sizeof(GrFrameState), hipMemcpyHostToDevice, c->stream));
+        if (cg) { st = center_stage(c, s0, nb, make_sel(*cg), 1, weighted, 1, 0); if (st) return st; }   // group_estimate_center / _com per frame
+        st = translate_batch(c, s0, nb, g, v, cg ? 1 : 2, cg ? mask[dim] : 7, pre, msg, status_out ? status_out + b0 : nullptr, first_err, first_msg, first_idx);
+        if (st) return st;
+    }
+    if (first_err != GR_OK) { c->err = first_msg; c->err_index = first_idx; }
+    return first_err;
+}
+int gr_group_translate_batch(gr_ctx *c, uint32_t first_slot, uint32_t n_frames, const char *group, const float v[3], int *status_out) {
+    if (!c) return GR_E_INVALID_ARG;
+    if (!v) return fail(c, GR_E_INVALID_ARG, "vector is NULL");
+    return translate_batch_api(c, first_slot, n_frames, group, v, nullptr, 7, 0, status_out);
+}
+int gr_group_wrap_batch(gr_ctx *c, uint32_t first_slot, uint32_t n_frames, const char *group, int *status_out) {
+    if (!c) return GR_E_INVALID_ARG;
+    const float z[3] = { 0.f, 0.f, 0.f };
+    return translate_batch_api(c, first_slot, n_frames, group, z, nullptr, 7, 0, status_out);
+}
+int gr_atoms_center_batch(gr_ctx *c, uint32_t first_slot, uint32_t n_frames, const char *ref_group, int dim, int weighted, int *status_out) {
+    if (!c) return GR_E_INVALID_ARG;
+    if (!ref_group) return fail(c, GR_E_GROUP_NOT_FOUND, "(null)");
+    return translate_batch_api(c, first_slot, n_frames, "all", nullptr, ref_group, dim, weighted, status_out);
 }
 
 /* ------------------------------------------------------------ RMSD */

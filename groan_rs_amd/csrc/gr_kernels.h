@@ -1073,14 +1073,19 @@ __global__ __launch_bounds__(GR_WG) void k_plan_extract(
 
 // ------------------------------------------------------------------------------------------ translate / wrap
 // MutAtomIteratorWithBox::translate / wrap (iterators.rs:1520-1553; atom.rs:498-545): x <- wrap(x + v)
+// One frame per blockIdx.y (frames `frame_stride` floats apart; boxes, states and the 4-word "first atom without position"
+// records follow the frame index).  use_state_shift: 0 = plain translate, 1 = atoms_center (shift from the frame's state),
+// 2 = plain translate of the frames whose state carries no earlier error (batched calls: frames without a box are skipped).
 __global__ __launch_bounds__(GR_WG) void k_translate_wrap(
-    float *__restrict__ xyz, GrSel sel, const GrBox *__restrict__ boxp, const GrFrameState *__restrict__ state,
+    float *__restrict__ xyz, size_t frame_stride, GrSel sel, const GrBox *__restrict__ boxp, const GrFrameState *__restrict__ state,
     int use_state_shift, int dim_mask, float tx, float ty, float tz, uint32_t *__restrict__ bad_out) {
     __shared__ GrBox box;
     __shared__ uint32_t ldsu[GR_WG / 64];
     __shared__ float4 tiles[(GR_WG / 64) * GR_TILE_F4];
+    xyz += (size_t)blockIdx.y * frame_stride; boxp += blockIdx.y; state += blockIdx.y; bad_out += 4 * blockIdx.y;
     gr_stage_box(&box, boxp);
-    if (use_state_shift) {   // atoms_center: shift = filter(box centre - estimated centre, dim) (utility.rs:116-119)
+    if (use_state_shift == 2 && state->status != 0) return;
+    if (use_state_shift == 1) {   // atoms_center: shift = filter(box centre - estimated centre, dim) (utility.rs:116-119)
         if (state->status != 0) return;
         tx = (dim_mask & 1) ? box.bcx - state->center[0] : 0.0f;
         ty = (dim_mask & 2) ? box.bcy - state->center[1] : 0.0f;

@@ -401,6 +401,40 @@ class System:
     def group_estimate_com(self, name, slot=0): return self._center(name, _lib.CENTER_ESTIMATE, 1, slot)
     def group_get_com(self, name, slot=0): return self._center(name, _lib.CENTER_PBC, 1, slot)
 
+    # -- the same over a batch of resident frames (gr_*_batch): one set of launches, one read-back
+    def group_center_batch(self, name, kind, weighted, first_slot, n_frames, raise_on_error=True):
+        """-> (centres float32 [n_frames, 3] (NaN rows for failed frames), status int32 [n_frames])"""
+        out = np.zeros((n_frames, 3), np.float32); st_arr = np.zeros(n_frames, np.int32)
+        st = self._lib.gr_group_center_batch(self._ctx, first_slot, n_frames, name.encode(), kind, int(bool(weighted)), _ptr(out), _ptr(st_arr))
+        if st != OK and raise_on_error:
+            self._raise_group(st)
+        return out, st_arr
+
+    def group_get_com_batch(self, name, first_slot, n_frames, **kw): return self.group_center_batch(name, _lib.CENTER_PBC, 1, first_slot, n_frames, **kw)
+    def group_get_center_batch(self, name, first_slot, n_frames, **kw): return self.group_center_batch(name, _lib.CENTER_PBC, 0, first_slot, n_frames, **kw)
+    def group_estimate_com_batch(self, name, first_slot, n_frames, **kw): return self.group_center_batch(name, _lib.CENTER_ESTIMATE, 1, first_slot, n_frames, **kw)
+
+    def atoms_center_batch(self, reference, first_slot, n_frames, dimension=Dimension.XYZ, weighted=False, raise_on_error=True):
+        st_arr = np.zeros(n_frames, np.int32)
+        st = self._lib.gr_atoms_center_batch(self._ctx, first_slot, n_frames, reference.encode(), int(dimension), int(bool(weighted)), _ptr(st_arr))
+        if st != OK and raise_on_error:
+            self._raise_group(st)
+        return st_arr
+
+    def group_wrap_batch(self, name, first_slot, n_frames, raise_on_error=True):
+        st_arr = np.zeros(n_frames, np.int32)
+        st = self._lib.gr_group_wrap_batch(self._ctx, first_slot, n_frames, name.encode() if name else None, _ptr(st_arr))
+        if st != OK and raise_on_error:
+            self._raise_group(st)
+        return st_arr
+
+    def group_translate_batch(self, name, vector, first_slot, n_frames, raise_on_error=True):
+        v = np.ascontiguousarray(vector, np.float32); st_arr = np.zeros(n_frames, np.int32)
+        st = self._lib.gr_group_translate_batch(self._ctx, first_slot, n_frames, name.encode() if name else None, _ptr(v), _ptr(st_arr))
+        if st != OK and raise_on_error:
+            self._raise_group(st)
+        return st_arr
+
     # -- distances (analysis.rs:348-471)
     def group_distance(self, group1, group2, dim=Dimension.XYZ, slot=0):
         out = C.c_float(0)

@@ -201,6 +201,17 @@ int gr_rmsd_plan_force_exact(gr_rmsd_plan *plan, int on);
 int gr_ctx_set_persistent(gr_ctx *ctx, int mode);
 int gr_rmsd_plan_last_persistent(const gr_rmsd_plan *plan);
 
+/* ---------------------------------------------------------------- per-frame analyses over a batch of slots
+ * The calls above for `n_frames` consecutive slots in ONE set of launches and one read-back (a trajectory loop of
+ * group_get_com / atoms_center / atoms_wrap over resident frames; per-frame calls cost a launch + a synchronisation each).
+ * Every frame is judged on its own: status_out[f] (may be NULL) receives the frame's status, a failed frame yields NaN /
+ * is left untouched, and the return value is the first frame's error (message and index as for the single calls). */
+int gr_group_center_batch(gr_ctx *ctx, uint32_t first_slot, uint32_t n_frames, const char *group, int kind, int weighted,
+                          float *out /* [n_frames][3] */, int *status_out);
+int gr_group_translate_batch(gr_ctx *ctx, uint32_t first_slot, uint32_t n_frames, const char *group, const float v[3], int *status_out);
+int gr_group_wrap_batch(gr_ctx *ctx, uint32_t first_slot, uint32_t n_frames, const char *group, int *status_out);
+int gr_atoms_center_batch(gr_ctx *ctx, uint32_t first_slot, uint32_t n_frames, const char *ref_group, int dim, int weighted, int *status_out);
+
 /* ---------------------------------------------------------------- xtc writer (host side; the step after calc_rmsd_and_fit)
  * XtcWriter::new / write_frame (src/io/xtc_io/mod.rs:256-331 over xdrfile's write_xtc): the library's own encoder, byte for
  * byte the stream the reference writes for the same coordinates (the reference's golden fitted trajectories are files).

@@ -144,6 +144,18 @@ def test_decode_upload_com_wrap_pipeline(tmp_path):
     t_dev = time.perf_counter() - t0
     assert np.array_equal(np.array(coms_dev), np.array(coms))                        # same decoded bits -> same results
     assert np.array_equal(wrapped_dev, wrapped_first)
+    # ---- the same with the per-frame analyses batched too (gr_group_center_batch / gr_atoms_center_batch)
+    coms_b = []
+    t0 = time.perf_counter()
+    for f0 in range(0, n_frames, B):
+        x.read_frames_device(sysd, f0, B, first_slot=0, host_threads=n_threads)
+        cb, _ = sysd.group_get_com_batch("Solute", 0, B)
+        coms_b.append(cb)
+        sysd.atoms_center_batch("Solute", 0, B, G.Dimension.XYZ, weighted=True)
+    sysd.sync()
+    t_devb = time.perf_counter() - t0
+    assert np.array_equal(np.concatenate(coms_b), np.array(coms))
+    out["device_unpack_batched_analysis_frames_per_s"] = round(n_frames / t_devb, 1)
     # ---- and out again: D2H + the library's encoder (fitted-trajectory output, NEXT-4), n_threads encoders
     wpath = tmp_path / "rewritten.xtc"
     x.read_frames_device(sysd, 0, B, first_slot=0, host_threads=n_threads)
