@@ -77,6 +77,7 @@ SIGNATURES = {
     "gr_rmsd_plan_last_fallbacks": (C.c_uint32, [C.c_void_p]),
     "gr_rmsd_plan_force_exact": (C.c_int, [C.c_void_p, C.c_int]),
     "gr_ctx_set_persistent": (C.c_int, [C.c_void_p, C.c_int]),
+    "gr_group_pairs_within": (C.c_int, [C.c_void_p, C.c_uint32, C.c_char_p, C.c_char_p, C.c_float, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]),
     "gr_group_center_batch": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "gr_group_translate_batch": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_char_p, C.c_void_p, C.c_void_p]),
     "gr_group_wrap_batch": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_char_p, C.c_void_p]),

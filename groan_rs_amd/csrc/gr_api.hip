@@ -20,6 +20,7 @@
 #include "gr_persist.h"
 #include "gr_shape.h"
 #include "gr_xtc_dev.h"
+#include "gr_cellgrid.h"
 #include <thread>
 #include <atomic>
 
@@ -868,6 +869,83 @@ int gr_atoms_center(gr_ctx *c, uint32_t slot, const char *ref_group, int dim, in
     st = fetch_states(c, 1); if (st) return st;
     st = frame_status(c, c->state_host[0]); if (st) return st;
     return translate_impl(c, slot, "all", nullptr, 1, mask[dim]);
+}
+
+/* ------------------------------------------------------------ cut-off pair search */
+int gr_group_pairs_within(gr_ctx *c, uint32_t slot, const char *g1, const char *g2, float cutoff, uint64_t max_pairs,
+                          uint32_t *i_out, uint32_t *j_out, float *d_out, uint64_t *n_pairs) {
+    int st = slot_check(c, slot); if (st) return st;
+    (void)hipSetDevice(c->device);
+    const Group *a = find_group(c, g1); if (!a) return fail(c, GR_E_GROUP_NOT_FOUND, g1 ? g1 : "(null)");
+    const Group *b = find_group(c, g2); if (!b) return fail(c, GR_E_GROUP_NOT_FOUND, g2 ? g2 : "(null)");
+    if (!(cutoff > 0.0f)) return fail(c, GR_E_INVALID_ARG, "cell size (cut-off) must be positive");              // cellgrid.rs:323-325
+    if (c->box_status[slot] == GR_E_NO_BOX) return fail(c, GR_E_NO_BOX, "simulation box does not exist");            // check_box :411-430
+    if (c->box_status[slot] != GR_OK) return fail(c, c->box_status[slot], "invalid simulation box");
+    if (!c->boxes_host[slot].ortho) return fail(c, GR_E_NOT_ORTHOGONAL, "simulation box is not orthogonal");
+    if (n_pairs) *n_pairs = 0;
+    if (a->n == 0 || b->n == 0) return GR_OK;
+    const GrBox &box = c->boxes_host[slot];
+    const GrCellGrid grid = gr_cellgrid_make(box, cutoff);
+    const GrSel s1 = make_sel(*a), s2 = make_sel(*b);
+    const uint32_t n1 = (uint32_t)a->n, n2 = (uint32_t)b->n;
+    const float *xyz = c->frames + (size_t)slot * c->frame_stride;
+    // one device allocation carved up: keys/vals in + out, cell starts, counts + offsets, 2 error words, sort / scan scratch
+    size_t tmp_sort = 0, tmp_scan = 0;
+    (void)rocprim::radix_sort_pairs(nullptr, tmp_sort, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, n2, 0, 32, c->stream);
+    (void)rocprim::exclusive_scan(nullptr, tmp_scan, (unsigned long long *)nullptr, (unsigned long long *)nullptr, 0ull, n1, rocprim::plus<unsigned long long>(), c->stream);
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t o_keys = 0, o_vals = o_keys + al(4 * (size_t)n2), o_skeys = o_vals + al(4 * (size_t)n2), o_svals = o_skeys + al(4 * (size_t)n2),
+                 o_starts = o_svals + al(4 * (size_t)n2), o_counts = o_starts + al(4 * ((size_t)grid.ncells + 1)), o_offs = o_counts + al(8 * (size_t)n1),
+                 o_bad = o_offs + al(8 * (size_t)n1), o_tmp = o_bad + 256, total_bytes = o_tmp + al(std::max(tmp_sort, tmp_scan));
+    unsigned char *ws = nullptr;
+    HIPCHK(c, hipMalloc(&ws, total_bytes));
+    uint32_t *keys = (uint32_t *)(ws + o_keys), *vals = (uint32_t *)(ws + o_vals), *skeys = (uint32_t *)(ws + o_skeys), *svals = (uint32_t *)(ws + o_svals),
+             *starts = (uint32_t *)(ws + o_starts), *bad = (uint32_t *)(ws + o_bad);
+    unsigned long long *counts = (unsigned long long *)(ws + o_counts), *offs = (unsigned long long *)(ws + o_offs);
+    uint32_t *oi = nullptr, *oj = nullptr; float *od = nullptr;
+    auto cleanup = [&]() { (void)hipFree(ws); if (oi) (void)hipFree(oi); if (oj) (void)hipFree(oj); if (od) (void)hipFree(od); };
+    auto herr = [&](hipError_t e, const char *what) { c->err = std::string(what) + ": " + hipGetErrorString(e); cleanup(); return GR_E_HIP; };
+    SlotUse use(c, slot);
+    hipError_t e = hipMemsetAsync(bad, 0xFF, 8, c->stream);
+    if (e != hipSuccess) return herr(e, "memset");
+    k_cg_assign<<<dim3((n2 + 255) / 256), dim3(256), 0, c->stream>>>(xyz, s2, box, grid, keys, vals, bad);
+    size_t tsz = std::max(tmp_sort, tmp_scan);
+    e = rocprim::radix_sort_pairs(ws + o_tmp, tsz, keys, skeys, vals, svals, n2, 0, 32, c->stream);
+    if (e != hipSuccess) return herr(e, "radix_sort_pairs");
+    k_cg_starts<<<dim3((grid.ncells + 1 + 255) / 256), dim3(256), 0, c->stream>>>(skeys, n2, grid.ncells, starts);
+    k_cg_pairs<false><<<dim3((n1 + 255) / 256), dim3(256), 0, c->stream>>>(xyz, s1, box, grid, cutoff, svals, starts, counts, nullptr, 0ull, nullptr, nullptr, nullptr, bad);
+    tsz = std::max(tmp_sort, tmp_scan);
+    e = rocprim::exclusive_scan(ws + o_tmp, tsz, counts, offs, 0ull, (size_t)n1, rocprim::plus<unsigned long long>(), c->stream);
+    if (e != hipSuccess) return herr(e, "exclusive_scan");
+    unsigned long long last[2] = { 0, 0 }; uint32_t badh[2] = { GR_NOIDX, GR_NOIDX };
+    e = hipMemcpyAsync(&last[0], offs + (n1 - 1), 8, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(&last[1], counts + (n1 - 1), 8, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(badh, bad, 8, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) return herr(e, "pair count read-back");
+    if (badh[0] != GR_NOIDX || badh[1] != GR_NOIDX) {   // ordinals -> atom indices, group2 (grid construction) first
+        const bool second = badh[0] != GR_NOIDX;
+        const uint64_t ord = second ? badh[0] : badh[1];
+        uint64_t atom = 0, k = 0;
+        for (const auto &blk : (second ? b : a)->blocks) { const uint64_t len = blk.second - blk.first + 1; if (ord < k + len) { atom = blk.first + (ord - k); break; } k += len; }
+        cleanup();
+        return fail(c, GR_E_NO_POSITION, "atom has no position", atom);
+    }
+    const unsigned long long total = last[0] + last[1];
+    if (n_pairs) *n_pairs = total;
+    const unsigned long long cap = std::min<unsigned long long>(total, max_pairs);
+    if (cap > 0 && i_out && j_out && d_out) {
+        e = hipMalloc(&oi, cap * 4); if (e == hipSuccess) e = hipMalloc(&oj, cap * 4); if (e == hipSuccess) e = hipMalloc(&od, cap * 4);
+        if (e != hipSuccess) return herr(e, "pair buffers");
+        k_cg_pairs<true><<<dim3((n1 + 255) / 256), dim3(256), 0, c->stream>>>(xyz, s1, box, grid, cutoff, svals, starts, counts, offs, cap, oi, oj, od, bad);
+        e = hipMemcpyAsync(i_out, oi, cap * 4, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(j_out, oj, cap * 4, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_out, od, cap * 4, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) return herr(e, "pair read-back");
+    }
+    cleanup();
+    return GR_OK;
 }
 
 /* ------------------------------------------------------------ the same per-frame calls over a batch of slots */

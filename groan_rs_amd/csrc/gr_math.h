@@ -187,8 +187,20 @@ GR_HD float gr_mag3(float x, float y, float z) {
 #endif
 }
 
+// the reference's own arithmetic, bit for bit: every product and sum rounded on its own (Rust never contracts to FMA) and a
+// correctly rounded square root -- for the places where a distance is COMPARED with a threshold (shapes, cut-off pairs) and
+// one ulp decides membership
+GR_HD float gr_mag3_exact(float x, float y, float z) {
+#pragma clang fp contract(off)
+    const float xx = x * x, yy = y * y, zz = z * z;
+    const float s = (xx + yy) + zz;
+    return sqrtf(s);
+}
+template <bool EXACT> GR_HD float gr_mag3_sel(float x, float y, float z) { return EXACT ? gr_mag3_exact(x, y, z) : gr_mag3(x, y, z); }
+
 // NC = unrolled image-table length for the magnitude-only path (>= b.ncand; the table is padded with never-winning entries)
-template <int NC = GR_MAX_CAND>
+// EXACT = gr_mag3_exact instead of the fast magnitude
+template <int NC = GR_MAX_CAND, bool EXACT = false>
 GR_HD float gr_distance(float ax_, float ay_, float az_, float px, float py, float pz, int dim, const GrBox &b) {
     if (dim == 0) return 0.0f;
     float dx = ax_ - px, dy = ay_ - py, dz = az_ - pz;
@@ -201,13 +213,13 @@ GR_HD float gr_distance(float ax_, float ay_, float az_, float px, float py, flo
         case 1: return mx;
         case 2: return my;
         case 3: return mz;
-        case 4: return gr_mag3(mx, my, 0.0f);
-        case 5: return gr_mag3(mx, 0.0f, mz);
-        case 6: return gr_mag3(0.0f, my, mz);
-        default: return gr_mag3(mx, my, mz);
+        case 4: return gr_mag3_sel<EXACT>(mx, my, 0.0f);
+        case 5: return gr_mag3_sel<EXACT>(mx, 0.0f, mz);
+        case 6: return gr_mag3_sel<EXACT>(0.0f, my, mz);
+        default: return gr_mag3_sel<EXACT>(mx, my, mz);
         }
     }
-    if (dim == 7) {   // magnitude only: brick reduction + gain search, the image vector itself is never formed
+    if (dim == 7 && !EXACT) {   // magnitude only: brick reduction + gain search, the image vector itself is never formed
         float k = gr_minimg_k(dz, b.cz, b.icz, b.cz / 2.0f);
         dx = fmaf(-k, b.cx, dx); dy = fmaf(-k, b.cy, dy); dz = fmaf(-k, b.cz, dz);
         k = gr_minimg_k(dy, b.by, b.iby, b.by / 2.0f);
@@ -225,10 +237,10 @@ GR_HD float gr_distance(float ax_, float ay_, float az_, float px, float py, flo
     case 1: return dx;
     case 2: return dy;
     case 3: return dz;
-    case 4: return gr_mag3(dx, dy, 0.0f);
-    case 5: return gr_mag3(dx, 0.0f, dz);
-    case 6: return gr_mag3(0.0f, dy, dz);
-    default: return gr_mag3(dx, dy, dz);
+    case 4: return gr_mag3_sel<EXACT>(dx, dy, 0.0f);
+    case 5: return gr_mag3_sel<EXACT>(dx, 0.0f, dz);
+    case 6: return gr_mag3_sel<EXACT>(0.0f, dy, dz);
+    default: return gr_mag3_sel<EXACT>(dx, dy, dz);
     }
 }
 

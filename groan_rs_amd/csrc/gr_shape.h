@@ -44,20 +44,20 @@ template <int NC = GR_MAX_CAND>
 GR_HD bool gr_shape_inside_pbc(const GrShapeDev &s, float x, float y, float z, const GrBox &box) {
     switch (s.kind) {
     case GR_SH_SPHERE:   // :114-116
-        return gr_distance<NC>(x, y, z, s.px, s.py, s.pz, 7, box) < s.a;
+        return gr_distance<NC, true>(x, y, z, s.px, s.py, s.pz, 7, box) < s.a;
     case GR_SH_RECTANGULAR: {   // :169-184
-        float dx = gr_distance<NC>(x, y, z, s.px, s.py, s.pz, 1, box); if (dx < 0.0f) dx += box.ax;
-        float dy = gr_distance<NC>(x, y, z, s.px, s.py, s.pz, 2, box); if (dy < 0.0f) dy += box.by;
-        float dz = gr_distance<NC>(x, y, z, s.px, s.py, s.pz, 3, box); if (dz < 0.0f) dz += box.cz;
+        float dx = gr_distance<NC, true>(x, y, z, s.px, s.py, s.pz, 1, box); if (dx < 0.0f) dx += box.ax;
+        float dy = gr_distance<NC, true>(x, y, z, s.px, s.py, s.pz, 2, box); if (dy < 0.0f) dy += box.by;
+        float dz = gr_distance<NC, true>(x, y, z, s.px, s.py, s.pz, 3, box); if (dz < 0.0f) dz += box.cz;
         return dx <= s.a && dy <= s.b && dz <= s.c;
     }
     case GR_SH_CYLINDER: {   // :256-275
-        float da = gr_distance<NC>(x, y, z, s.px, s.py, s.pz, s.orientation, box);
+        float da = gr_distance<NC, true>(x, y, z, s.px, s.py, s.pz, s.orientation, box);
         if (da < 0.0f) da += gr_box_len(box, s.orientation);
-        return !(da > s.b || gr_distance<NC>(x, y, z, s.px, s.py, s.pz, s.plane, box) > s.a);
+        return !(da > s.b || gr_distance<NC, true>(x, y, z, s.px, s.py, s.pz, s.plane, box) > s.a);
     }
     case GR_SH_PRISM: {   // :435-460 (the base itself is not periodic, the height is)
-        float d = gr_distance<NC>(x, y, z, s.px, s.py, s.pz, s.orientation, box);
+        float d = gr_distance<NC, true>(x, y, z, s.px, s.py, s.pz, s.orientation, box);
         if (d < 0.0f) d += gr_box_len(box, s.orientation);
         if (d >= s.a) return false;
         float pu, pv, u1, v1, u2, v2, u3, v3;

@@ -401,6 +401,21 @@ class System:
     def group_estimate_com(self, name, slot=0): return self._center(name, _lib.CENTER_ESTIMATE, 1, slot)
     def group_get_com(self, name, slot=0): return self._center(name, _lib.CENTER_PBC, 1, slot)
 
+    def group_pairs_within(self, group1, group2, cutoff, slot=0):
+        """all pairs (i in group1, j in group2, i != j) with distance <= cutoff through a device cell grid
+        (CellGrid + distance filter, cellgrid.rs:301-409 / hbonds.rs:248-265) -> (i uint32[n], j uint32[n], d float32[n]) by i then j"""
+        n = C.c_uint64(0)
+        st = self._lib.gr_group_pairs_within(self._ctx, slot, group1.encode(), group2.encode(), C.c_float(cutoff), 0, None, None, None, C.byref(n))
+        if st != OK:
+            self._raise_group(st)
+        m = int(n.value)
+        i = np.zeros(max(m, 1), np.uint32); j = np.zeros(max(m, 1), np.uint32); d = np.zeros(max(m, 1), np.float32)
+        if m:
+            st = self._lib.gr_group_pairs_within(self._ctx, slot, group1.encode(), group2.encode(), C.c_float(cutoff), m, _ptr(i), _ptr(j), _ptr(d), C.byref(n))
+            if st != OK:
+                self._raise_group(st)
+        return i[:m], j[:m], d[:m]
+
     # -- the same over a batch of resident frames (gr_*_batch): one set of launches, one read-back
     def group_center_batch(self, name, kind, weighted, first_slot, n_frames, raise_on_error=True):
         """-> (centres float32 [n_frames, 3] (NaN rows for failed frames), status int32 [n_frames])"""

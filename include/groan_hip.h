@@ -201,6 +201,18 @@ int gr_rmsd_plan_force_exact(gr_rmsd_plan *plan, int on);
 int gr_ctx_set_persistent(gr_ctx *ctx, int mode);
 int gr_rmsd_plan_last_persistent(const gr_rmsd_plan *plan);
 
+/* ---------------------------------------------------------------- cut-off pair search (cell grid on the device)
+ * What a CellGrid walk with a distance filter produces (CellGrid::new + neighbors_iter, src/structures/cellgrid.rs:301-409,
+ * as src/system/hbonds.rs:248-265 uses them): all pairs (i in group1, j in group2, i != j) with distance(x_j, x_i) <= cutoff,
+ * ordered by i then j (the reference leaves the order undefined).  The grid (cells of at least `cutoff`, periodic 27-cell
+ * neighbourhood) is built on the device; it replaces the S1 x S2 distance matrix when only near pairs are wanted.
+ * Needs an orthogonal box (GR_E_NO_BOX / GR_E_NOT_ORTHOGONAL), cutoff > 0 (GR_E_INVALID_ARG, the reference's
+ * CellGridError::InvalidCellSize), positions for every atom of both groups (GR_E_NO_POSITION + index: group2 is checked
+ * first, as the grid is built before it is queried).  *n_pairs receives the number of pairs found; at most max_pairs are
+ * written -- when *n_pairs > max_pairs call again with larger buffers (the buffers may be NULL to just count). */
+int gr_group_pairs_within(gr_ctx *ctx, uint32_t slot, const char *group1, const char *group2, float cutoff, uint64_t max_pairs,
+                          uint32_t *i_out, uint32_t *j_out, float *dist_out, uint64_t *n_pairs);
+
 /* ---------------------------------------------------------------- per-frame analyses over a batch of slots
  * The calls above for `n_frames` consecutive slots in ONE set of launches and one read-back (a trajectory loop of
  * group_get_com / atoms_center / atoms_wrap over resident frames; per-frame calls cost a launch + a synchronisation each).

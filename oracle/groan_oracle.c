@@ -1008,3 +1008,21 @@ size_t go_group_from_geometries(const void *pos, size_t ps, const uint64_t *idx,
     }
     return cnt;
 }
+
+/* ================================================================== cut-off pair search (brute force) */
+size_t go_pairs_within(const void *pos, size_t ps, const uint64_t *idx1, size_t n1, const uint64_t *idx2, size_t n2,
+                       const float *b, float cutoff, size_t max_pairs, uint64_t *out_i, uint64_t *out_j, float *out_d) {
+    size_t cnt = 0;
+    for (size_t a = 0; a < n1; ++a) {
+        const float *pi = POS(pos, ps, idx1[a]);
+        for (size_t c = 0; c < n2; ++c) {
+            if (idx2[c] == idx1[a]) continue; /* hbonds.rs:250 */
+            const float *pj = POS(pos, ps, idx2[c]);
+            const float d = go_distance(pj, pi, GO_DIM_XYZ, b); /* acceptor.distance(donor) :261 */
+            if (d > cutoff) continue;                           /* :262-264 */
+            if (cnt < max_pairs) { out_i[cnt] = idx1[a]; out_j[cnt] = idx2[c]; out_d[cnt] = d; }
+            ++cnt;
+        }
+    }
+    return cnt;
+}

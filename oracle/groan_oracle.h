@@ -178,6 +178,13 @@ int go_shape_inside_naive(const go_shape *s, const float point[3]);   /* -1: the
 size_t go_group_from_geometries(const void *pos, size_t pos_stride, const uint64_t *idx, size_t n, const float *box9,
                                 const go_shape *shapes, size_t n_shapes, int naive, uint64_t *out_idx);
 
+/* ---- cut-off pair search: what a CellGrid walk + distance filter produces (src/structures/cellgrid.rs:301-409 as used by
+ * src/system/hbonds.rs:248-265: candidates from the neighbouring cells, kept when distance <= cutoff, self pairs skipped).
+ * Brute force over all pairs here -- the grid only prunes, it never changes the set.  Pairs come out by i (order of idx1)
+ * then j (order of idx2).  Returns the number of pairs (writes at most max_pairs). */
+size_t go_pairs_within(const void *pos, size_t pos_stride, const uint64_t *idx1, size_t n1, const uint64_t *idx2, size_t n2,
+                       const float *box9, float cutoff, size_t max_pairs, uint64_t *out_i, uint64_t *out_j, float *out_d);
+
 #ifdef __cplusplus
 }
 #endif

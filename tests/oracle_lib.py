@@ -334,3 +334,16 @@ def group_from_geometries(pos, idx, box, specs, naive=False):
     n = lib().go_group_from_geometries(_p(pos), C.c_size_t(12), _p(idx), C.c_size_t(idx.size), _p(_box(box)), arr,
                                        C.c_size_t(len(specs)), C.c_int(int(naive)), _p(out))
     return out[:n]
+
+
+# ---------------- cut-off pair search ----------------
+def pairs_within(pos, idx1, idx2, box, cutoff):
+    pos = _f(pos); i1 = _u(idx1); i2 = _u(idx2)
+    L = lib(); L.go_pairs_within.restype = C.c_size_t
+    args = lambda cap, oi, oj, od: (_p(pos), C.c_size_t(12), _p(i1), C.c_size_t(i1.size), _p(i2), C.c_size_t(i2.size), _p(_box(box)), C.c_float(cutoff),
+                                    C.c_size_t(cap), _p(oi), _p(oj), _p(od))
+    e = np.zeros(1, np.uint64); ef = np.zeros(1, np.float32)
+    n = L.go_pairs_within(*args(0, e, e, ef))
+    oi = np.zeros(max(n, 1), np.uint64); oj = np.zeros(max(n, 1), np.uint64); od = np.zeros(max(n, 1), np.float32)
+    L.go_pairs_within(*args(n, oi, oj, od))
+    return oi[:n], oj[:n], od[:n]
