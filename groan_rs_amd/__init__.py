@@ -11,6 +11,7 @@ from .system import (AtomContainer, AtomError, DeviceError, Dimension, GroanErro
 from .traj import (FrameAnalyze, FrameConvert, FrameConvertAnalyze, RMSDConverterAnalyzer, TrajAnalyzer,
                    TrajAnalysisError, TrajConverter, TrajConverterAnalyzer, TrajReader)
 from .xtc import XtcError, XtcFile, XtcWriter
+from .textio import ParseGroError, ParseNdxError, Structure, read_ndx_groups, system_from_gro, system_read_ndx
 from .shapes import Cylinder, Rectangular, Shape, Sphere, TriangularPrism
 from .parallel import ParallelTrajData, gather_per_frame, interleave, shard_frames, traj_iter_map_reduce
 
@@ -18,5 +19,5 @@ __all__ = [
     "AtomContainer", "AtomError", "DeviceError", "Dimension", "GroanError", "GroupError", "RMSDError", "RMSDPlan",
     "SimBoxError", "System", "pinned_array", "pinned_free", "FrameAnalyze", "FrameConvert", "FrameConvertAnalyze", "RMSDConverterAnalyzer",
     "TrajAnalyzer", "TrajAnalysisError", "TrajConverter", "TrajConverterAnalyzer", "TrajReader",
-    "XtcError", "XtcFile", "XtcWriter", "Cylinder", "Rectangular", "Shape", "Sphere", "TriangularPrism", "ParallelTrajData", "gather_per_frame", "interleave", "shard_frames", "traj_iter_map_reduce",
+    "XtcError", "XtcFile", "XtcWriter", "ParseGroError", "ParseNdxError", "Structure", "read_ndx_groups", "system_from_gro", "system_read_ndx", "Cylinder", "Rectangular", "Shape", "Sphere", "TriangularPrism", "ParallelTrajData", "gather_per_frame", "interleave", "shard_frames", "traj_iter_map_reduce",
 ]

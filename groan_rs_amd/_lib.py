@@ -77,6 +77,21 @@ SIGNATURES = {
     "gr_rmsd_plan_last_fallbacks": (C.c_uint32, [C.c_void_p]),
     "gr_rmsd_plan_force_exact": (C.c_int, [C.c_void_p, C.c_int]),
     "gr_ctx_set_persistent": (C.c_int, [C.c_void_p, C.c_int]),
+    "gr_gro_read": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_char_p, C.c_size_t]),
+    "gr_structure_free": (None, [C.c_void_p]),
+    "gr_structure_n_atoms": (C.c_uint64, [C.c_void_p]),
+    "gr_structure_title": (C.c_char_p, [C.c_void_p]),
+    "gr_structure_box": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "gr_structure_positions": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "gr_structure_velocities": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "gr_structure_atom": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_char_p, C.c_char_p]),
+    "gr_ndx_read": (C.c_int, [C.c_char_p, C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_char_p, C.c_size_t]),
+    "gr_ndx_free": (None, [C.c_void_p]),
+    "gr_ndx_n_groups": (C.c_size_t, [C.c_void_p]),
+    "gr_ndx_group_name": (C.c_char_p, [C.c_void_p, C.c_size_t]),
+    "gr_ndx_group_size": (C.c_size_t, [C.c_void_p, C.c_size_t]),
+    "gr_ndx_group_indices": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p]),
+    "gr_ndx_install": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "gr_group_pairs_within": (C.c_int, [C.c_void_p, C.c_uint32, C.c_char_p, C.c_char_p, C.c_float, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]),
     "gr_group_center_batch": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "gr_group_translate_batch": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_char_p, C.c_void_p, C.c_void_p]),

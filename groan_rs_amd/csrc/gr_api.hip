@@ -21,6 +21,8 @@
 #include "gr_shape.h"
 #include "gr_xtc_dev.h"
 #include "gr_cellgrid.h"
+#include "gr_textio.h"
+#include <set>
 #include <thread>
 #include <atomic>
 
@@ -1598,6 +1600,87 @@ int gr_xtc_read_frames_device(const gr_xtc *x, uint64_t first_frame, uint32_t n_
         HIPCHK(c, hipEventRecord(c->ev_ready[first_slot + k], c->copy_stream));
         c->upload_pending[first_slot + k] = 1;
     }
+    return GR_OK;
+}
+
+/* ------------------------------------------------------------ text front end */
+struct gr_structure { grt::Structure s; };
+struct gr_ndx { std::vector<grt::NdxGroup> g; };
+static int parse_result(int rc, const std::string &d, int *code, char *detail, size_t cap) {
+    if (code) *code = rc;
+    if (detail && cap) { const size_t n = std::min(cap - 1, d.size()); memcpy(detail, d.data(), n); detail[n] = 0; }
+    return rc == grt::P_OK ? GR_OK : (rc == grt::P_FILE_NOT_FOUND ? GR_E_IO : GR_E_FORMAT);
+}
+int gr_gro_read(const char *path, gr_structure **out, int *code, char *detail, size_t cap) {
+    if (!path || !out) return GR_E_INVALID_ARG;
+    *out = nullptr;
+    gr_structure *s = new gr_structure();
+    std::string d;
+    const int rc = grt::read_gro(path, s->s, d);
+    if (rc != grt::P_OK) { delete s; return parse_result(rc, d, code, detail, cap); }
+    *out = s;
+    return parse_result(rc, d, code, detail, cap);
+}
+void gr_structure_free(gr_structure *s) { delete s; }
+uint64_t gr_structure_n_atoms(const gr_structure *s) { return s ? s->s.atoms.size() : 0; }
+const char *gr_structure_title(const gr_structure *s) { return s ? s->s.title.c_str() : ""; }
+int gr_structure_box(const gr_structure *s, float box9[9]) {
+    if (!s || !box9) return GR_E_INVALID_ARG;
+    if (!s->s.has_box) return GR_E_NO_BOX;
+    memcpy(box9, s->s.box9, 9 * sizeof(float));
+    return GR_OK;
+}
+int gr_structure_positions(const gr_structure *s, float *xyz) {
+    if (!s || !xyz) return GR_E_INVALID_ARG;
+    for (size_t i = 0; i < s->s.atoms.size(); ++i) memcpy(xyz + 3 * i, s->s.atoms[i].pos, 12);
+    return GR_OK;
+}
+int gr_structure_velocities(const gr_structure *s, float *vel) {
+    if (!s || !vel) return GR_E_INVALID_ARG;
+    for (size_t i = 0; i < s->s.atoms.size(); ++i) memcpy(vel + 3 * i, s->s.atoms[i].vel, 12);
+    return GR_OK;
+}
+int gr_structure_atom(const gr_structure *s, uint64_t i, uint64_t *resid, uint64_t *atomid, char resname[8], char atomname[8]) {
+    if (!s) return GR_E_INVALID_ARG;
+    if (i >= s->s.atoms.size()) return GR_E_OUT_OF_RANGE;
+    const grt::Atom &a = s->s.atoms[i];
+    if (resid) *resid = a.resid;
+    if (atomid) *atomid = a.atomid;
+    if (resname) { strncpy(resname, a.resname.c_str(), 7); resname[7] = 0; }
+    if (atomname) { strncpy(atomname, a.atomname.c_str(), 7); atomname[7] = 0; }
+    return GR_OK;
+}
+int gr_ndx_read(const char *path, uint64_t n_atoms, gr_ndx **out, int *code, char *detail, size_t cap) {
+    if (!path || !out) return GR_E_INVALID_ARG;
+    *out = nullptr;
+    gr_ndx *x = new gr_ndx();
+    std::string d; uint64_t bad = 0;
+    const int rc = grt::read_ndx(path, n_atoms, x->g, d, bad);
+    if (rc != grt::P_OK) { delete x; return parse_result(rc, d, code, detail, cap); }
+    *out = x;
+    return parse_result(rc, d, code, detail, cap);
+}
+void gr_ndx_free(gr_ndx *x) { delete x; }
+size_t gr_ndx_n_groups(const gr_ndx *x) { return x ? x->g.size() : 0; }
+const char *gr_ndx_group_name(const gr_ndx *x, size_t g) { return (x && g < x->g.size()) ? x->g[g].name.c_str() : ""; }
+size_t gr_ndx_group_size(const gr_ndx *x, size_t g) { return (x && g < x->g.size()) ? x->g[g].indices.size() : 0; }
+int gr_ndx_group_indices(const gr_ndx *x, size_t g, uint64_t *out) {
+    if (!x || g >= x->g.size() || !out) return GR_E_INVALID_ARG;
+    memcpy(out, x->g[g].indices.data(), x->g[g].indices.size() * sizeof(uint64_t));
+    return GR_OK;
+}
+int gr_ndx_install(const gr_ndx *x, gr_ctx *c, size_t *n_invalid, size_t *n_dup) {
+    if (!x || !c) return GR_E_INVALID_ARG;
+    (void)hipSetDevice(c->device);
+    std::set<std::string> invalid, dup;
+    for (const auto &g : x->g) {
+        if (!name_is_valid(g.name.c_str())) { invalid.insert(g.name); continue; }                       // Groups::add -> InvalidName: not added
+        const int st = install_group(c, g.name.c_str(), grc::from_indices(g.indices, c->n));
+        if (st == GR_E_GROUP_EXISTS) dup.insert(g.name);
+        else if (st != GR_OK) return st;
+    }
+    if (n_invalid) *n_invalid = invalid.size();
+    if (n_dup) *n_dup = dup.size();
     return GR_OK;
 }
 

@@ -201,6 +201,33 @@ int gr_rmsd_plan_force_exact(gr_rmsd_plan *plan, int on);
 int gr_ctx_set_persistent(gr_ctx *ctx, int mode);
 int gr_rmsd_plan_last_persistent(const gr_rmsd_plan *plan);
 
+/* ---------------------------------------------------------------- text front end: gro structures, ndx index groups (host side)
+ * read_gro (src/io/gro_io/structure.rs:120-231, gro_io/mod.rs:21-72) and Groups::from_ndx (src/io/ndx_io.rs:104-230): what is
+ * needed to run the path from files -- positions, box, atom / residue names and numbers, index groups.  A failed parse returns
+ * GR_E_IO (file not found) or GR_E_FORMAT with *detail_code = the reference's error variant and `detail` = its payload
+ * (the offending line / number), exactly as the reference's tests pin them. */
+enum { GR_PARSE_OK = 0, GR_PARSE_FILE_NOT_FOUND, GR_PARSE_LINE_NOT_FOUND, GR_PARSE_LINE, GR_PARSE_ATOM_LINE, GR_PARSE_BOX_LINE,
+       GR_PARSE_UNSUPPORTED_BOX, GR_PARSE_INVALID_FLOAT, GR_PARSE_GROUP_NAME, GR_PARSE_INVALID_ATOM_INDEX };
+typedef struct gr_structure gr_structure;
+int gr_gro_read(const char *path, gr_structure **out, int *detail_code, char *detail, size_t detail_cap);
+void gr_structure_free(gr_structure *s);
+uint64_t gr_structure_n_atoms(const gr_structure *s);
+const char *gr_structure_title(const gr_structure *s);
+int gr_structure_box(const gr_structure *s, float box9[9]);          /* GR_E_NO_BOX when the box line is all zeros */
+int gr_structure_positions(const gr_structure *s, float *xyz);       /* [n][3] */
+int gr_structure_velocities(const gr_structure *s, float *vel);      /* [n][3], NaN rows for atoms without velocity */
+int gr_structure_atom(const gr_structure *s, uint64_t i, uint64_t *resid, uint64_t *atomid, char resname[8], char atomname[8]);
+typedef struct gr_ndx gr_ndx;
+int gr_ndx_read(const char *path, uint64_t n_atoms, gr_ndx **out, int *detail_code, char *detail, size_t detail_cap);
+void gr_ndx_free(gr_ndx *x);
+size_t gr_ndx_n_groups(const gr_ndx *x);                             /* groups in file order (a repeated name appears again) */
+const char *gr_ndx_group_name(const gr_ndx *x, size_t g);
+size_t gr_ndx_group_size(const gr_ndx *x, size_t g);                 /* indices as written: 0-based, file order, duplicates kept */
+int gr_ndx_group_indices(const gr_ndx *x, size_t g, uint64_t *out);
+/* System::read_ndx: create the groups on a context (Group::from_indices); a group with an invalid name is skipped and counted,
+ * a repeated / already existing name is overwritten and counted (the reference's two warnings) */
+int gr_ndx_install(const gr_ndx *x, gr_ctx *ctx, size_t *n_invalid_names, size_t *n_duplicate_names);
+
 /* ---------------------------------------------------------------- cut-off pair search (cell grid on the device)
  * What a CellGrid walk with a distance filter produces (CellGrid::new + neighbors_iter, src/structures/cellgrid.rs:301-409,
  * as src/system/hbonds.rs:248-265 uses them): all pairs (i in group1, j in group2, i != j) with distance(x_j, x_i) <= cutoff,
