@@ -86,10 +86,16 @@ struct gr_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // per-kernel HIP-event profile of the batched RMSD path (gr_profile_*): 0 accumulate, 1 finalize, 2 fit
     hipEvent_t pev[6 * GR_MAX_BATCH] = {};   // per group: begin / end of the sums, finalize and fit kernels
+    hipEvent_t pev_fit[2 * GR_MAX_BATCH] = {};   // begin / end of every k_fit launch when a group's fit is split (fit_sub)
+    uint32_t fit_sub = 0;       // frames per k_fit launch inside a group (GR_FIT_SUB); 0 = the whole group in one launch.
+                                // Measured at 1e6 atoms, 1024 frames per call, groups of 256: 0 -> 148.9 k frames/s, 128 -> 149.7 k,
+                                // 64 -> 148.8 k, 32 -> 144.4 k: no gain from decoupling the two passes' launch lengths.
     // launch geometry of the batched RMSD path (env GR_SUB_BATCH / GR_CHUNKS / GR_FIT_WGS override)
-    uint32_t sub_batch = 64;    // frames per accumulate->finalize->fit group.  k_rmsd_accum is VALU-bound (~70 % VALU busy,
-                                // 13 MB/frame of HBM traffic) and k_fit is HBM-bound (24 MB/frame), so the fit of group k is
-                                // issued on a second stream and shares the chip with the accumulate of group k+1.
+    uint32_t sub_batch = 256;   // frames per sums->fit group.  The group's frames (12 MB each) leave the L2 / Infinity Cache
+                                // between the two passes at any size worth launching, so the size only trades launch
+                                // boundaries (6-11 us each) against the sums pass's chunk count per frame.  Measured at 1e6
+                                // atoms, 1024 frames per call: 16 -> 116 k frames/s, 32 -> 134 k, 64 -> 145.6 k, 128 -> 148.3 k,
+                                // 256 -> 150.5 k, 512 -> 121 k (one launch of 512 x 976 workgroups dispatches slower).
     uint32_t chunks = 0;        // workgroups per frame in the reductions (0 = auto)
     uint32_t fit_wgs = 0;       // workgroups per frame in k_fit (0 = auto)
     int profile = 0;
@@ -120,6 +126,7 @@ struct Pending {   // a segment between gr_rmsd_batch_begin and gr_rmsd_batch_en
     uint32_t s0 = 0, nb = 0, n_prof_groups = 0;
     int fit = 0;
     std::vector<int> pre;
+    std::vector<uint32_t> fit_launch_frames;   // profiling: frames of every k_fit launch of the segment, in pev_fit order
     std::vector<uint64_t> pre_idx;
     std::vector<std::string> pre_msg;
 };
@@ -417,6 +424,7 @@ gr_ctx *gr_ctx_create(int device, uint64_t n_atoms, uint32_t n_slots, int *statu
     ok = ok && hipHostMalloc(&c->bad_host, 4 * GR_MAX_BATCH * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess;
     ok = ok && hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess;
 
+    if (const char *e = getenv("GR_FIT_SUB")) { int v = atoi(e); if (v >= 0 && v <= GR_MAX_BATCH) c->fit_sub = (uint32_t)v; }
     if (const char *e = getenv("GR_SUB_BATCH")) { int v = atoi(e); if (v >= 1 && v <= GR_MAX_BATCH) c->sub_batch = (uint32_t)v; }
     if (const char *e = getenv("GR_CHUNKS")) { int v = atoi(e); if (v >= 1 && v <= GR_MAX_CHUNKS) c->chunks = (uint32_t)v; }
     if (const char *e = getenv("GR_FIT_WGS")) { int v = atoi(e); if (v >= 1 && v <= 65535) c->fit_wgs = (uint32_t)v; }
@@ -470,6 +478,7 @@ void gr_ctx_destroy(gr_ctx *c) {
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     for (int k = 0; k < 6 * GR_MAX_BATCH; ++k) if (c->pev[k]) (void)hipEventDestroy(c->pev[k]);
+    for (int k = 0; k < 2 * GR_MAX_BATCH; ++k) if (c->pev_fit[k]) (void)hipEventDestroy(c->pev_fit[k]);
     for (int k = 0; k < 3 * GR_MAX_BATCH; ++k) if (c->ev_skew[k]) (void)hipEventDestroy(c->ev_skew[k]);
     for (int k = 0; k < GR_MAX_BATCH; ++k) if (c->ev_grp[k]) (void)hipEventDestroy(c->ev_grp[k]);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
@@ -1222,6 +1231,7 @@ static int segment_begin(gr_rmsd_plan *p, uint32_t s0, uint32_t nb, int fit) {
             }
         }
         const uint32_t n_groups = (nb + sb - 1) / sb;
+        q.fit_launch_frames.clear();
         const bool fused = lite && c->fuse;   // the finalize rides on the tail of the sums kernel
         q.fused = fused;
         // The kernels of one group, each bracketed by its own pair of profiling events on the stream it runs on
@@ -1247,12 +1257,17 @@ static int segment_begin(gr_rmsd_plan *p, uint32_t s0, uint32_t nb, int fit) {
             return GR_OK;
         };
         auto launch_fit = [&](uint32_t g, hipStream_t on) -> int {
-            const uint32_t f0 = g * sb, nf = group_nf(g), gx = fit_grid(c, nf);
-            if (c->profile) EVREC(c, c->pev[6 * g + 4], true, on);
-            if (lite) k_fit<true><<<dim3(gx, nf), dim3(GR_WG), 0, on>>>(c->frames, c->frame_stride, s0 + f0, (uint32_t)c->n, c->boxes_dev, p->dev, c->state_dev + f0, c->masses, sel, c->fit_partials + (size_t)f0 * gx,
-                                                                        nullptr, c->state_dev + f0);   // (a fused close makes every one of the 62 k workgroups drain its stores: 3x slower)
-            else k_fit<false><<<dim3(gx, nf), dim3(GR_WG), 0, on>>>(c->frames, c->frame_stride, s0 + f0, (uint32_t)c->n, c->boxes_dev, p->dev, c->state_dev + f0, c->masses, sel, nullptr);
-            if (c->profile) EVREC(c, c->pev[6 * g + 5], true, on);
+            const uint32_t g0 = g * sb, gn = group_nf(g), gx = fit_grid(c, gn);
+            const uint32_t step = (c->fit_sub && c->fit_sub < gn) ? c->fit_sub : gn;   // the sums pass likes long groups, the fit pass short ones
+            for (uint32_t h0 = 0; h0 < gn; h0 += step) {
+                const uint32_t f0 = g0 + h0, nf = std::min<uint32_t>(step, gn - h0);
+                const uint32_t e = 2 * (uint32_t)q.fit_launch_frames.size();
+                if (c->profile) EVREC(c, c->pev_fit[e], true, on);
+                if (lite) k_fit<true><<<dim3(gx, nf), dim3(GR_WG), 0, on>>>(c->frames, c->frame_stride, s0 + f0, (uint32_t)c->n, c->boxes_dev, p->dev, c->state_dev + f0, c->masses, sel, c->fit_partials + (size_t)f0 * gx,
+                                                                            nullptr, c->state_dev + f0);   // (a fused close makes every one of the 62 k workgroups drain its stores: 3x slower)
+                else k_fit<false><<<dim3(gx, nf), dim3(GR_WG), 0, on>>>(c->frames, c->frame_stride, s0 + f0, (uint32_t)c->n, c->boxes_dev, p->dev, c->state_dev + f0, c->masses, sel, nullptr);
+                if (c->profile) { EVREC(c, c->pev_fit[e + 1], true, on); q.fit_launch_frames.push_back(nf); }
+            }
             return GR_OK;
         };
         auto launch_close = [&](uint32_t g, hipStream_t on) -> int {
@@ -1358,7 +1373,7 @@ static int segment_end(gr_rmsd_plan *p, float *rmsd_out, int *status_out, float 
             }
         }
         for (uint32_t gi = 0; gi < q.n_prof_groups; ++gi) {   // the stream is idle here: read this segment's event pairs
-            const int nk = fit ? 3 : 2;
+            const int nk = 2;
             const uint32_t nf = std::min<uint32_t>(c->sub_batch, nb - gi * c->sub_batch);
             for (int k = 0; k < nk; ++k) {
                 if (k == 1 && q.fused) continue;   // no finalize launch: the sums kernel closed the frames
@@ -1367,6 +1382,12 @@ static int segment_end(gr_rmsd_plan *p, float *rmsd_out, int *status_out, float 
                 c->prof_ms[k] += ms; c->prof_launches[k] += 1; c->prof_frames[k] += nf;
             }
         }
+        for (size_t h = 0; h < q.fit_launch_frames.size(); ++h) {
+            float ms = 0.f;
+            HIPCHK(c, hipEventElapsedTime(&ms, c->pev_fit[2 * h], c->pev_fit[2 * h + 1]));
+            c->prof_ms[2] += ms; c->prof_launches[2] += 1; c->prof_frames[2] += q.fit_launch_frames[h];
+        }
+        q.fit_launch_frames.clear();
         std::vector<GrFrameState> res(c->state_host, c->state_host + nb);
         // frames whose single-pass image proof failed are redone on the exact path, one by one
         for (uint32_t f = 0; f < nb; ++f) {

@@ -927,7 +927,11 @@ __global__ __launch_bounds__(GR_WG) void k_fit(
     __shared__ GrBox box;
     __shared__ double lds[GR_WG / 64];
     __shared__ uint32_t last_flag;
+#if defined(GR_FIT_REVERSE) && GR_FIT_REVERSE
+    const uint32_t frame = gridDim.y - 1 - blockIdx.y;
+#else
     const uint32_t frame = blockIdx.y;
+#endif
     const GrFrameState &st = state[frame];
     if (st.status != 0) return;   // analysis failed -> frame left unmodified (rmsd.rs:91)
     float *xyz = frames + (size_t)(first_slot + frame) * frame_stride;
