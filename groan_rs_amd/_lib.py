@@ -63,6 +63,8 @@ SIGNATURES = {
     "gr_atoms_distance": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64, C.c_int, c_f32p]),
     "gr_group_all_distances": (C.c_int, [C.c_void_p, C.c_uint32, C.c_char_p, C.c_char_p, C.c_int, C.c_void_p, C.c_size_t]),
     "gr_group_all_distances_device": (C.c_int, [C.c_void_p, C.c_uint32, C.c_char_p, C.c_char_p, C.c_int, C.POINTER(C.c_void_p), c_u64p, c_u64p]),
+    "gr_group_all_distances_batch_device": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_char_p, C.c_char_p, C.c_int, C.POINTER(C.c_void_p), c_u64p, c_u64p, C.c_void_p]),
+    "gr_device_read": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "gr_group_translate": (C.c_int, [C.c_void_p, C.c_uint32, C.c_char_p, C.c_void_p]),
     "gr_group_wrap": (C.c_int, [C.c_void_p, C.c_uint32, C.c_char_p]),
     "gr_atoms_center": (C.c_int, [C.c_void_p, C.c_uint32, C.c_char_p, C.c_int, C.c_int]),

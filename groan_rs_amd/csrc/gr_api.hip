@@ -664,30 +664,78 @@ int gr_group_distance(gr_ctx *c, uint32_t slot, const char *g1, const char *g2, 
     return GR_OK;
 }
 
-static int pairdist_run(gr_ctx *c, uint32_t slot, const GrSel &s1, const GrSel &s2, int dim, float *out_dev) {
-    SlotUse use(c, slot);
-    HIPCHK(c, hipMemsetAsync(c->bad_dev, 0xFF, 4 * sizeof(uint32_t), c->stream));
+static void batch_prechecks(gr_ctx *c, uint32_t s0, uint32_t nb, bool need_box, std::vector<int> &pre, std::vector<std::string> &msg);
+// pair distances of `nb` consecutive slots in one launch; matrices `out_stride` floats apart; -> bad_host[4 f + 0 / 1]
+static int pairdist_launch(gr_ctx *c, uint32_t s0, uint32_t nb, const GrSel &s1, const GrSel &s2, int dim, float *out_dev, size_t out_stride) {
+    SlotUse use(c, s0, nb);
+    HIPCHK(c, hipMemsetAsync(c->bad_dev, 0xFF, 4 * (size_t)nb * sizeof(uint32_t), c->stream));
     if (s1.n && s2.n) {
-        dim3 grid((s2.n + GR_WG * 4 - 1) / (GR_WG * 4), (s1.n + GR_PD_TI - 1) / GR_PD_TI);
-        const float *fr = c->frames + (size_t)slot * c->frame_stride;
-        const GrBox &bx = c->boxes_host[slot];
-        // unrolled length of the minimum-image table: the smallest of 4 / 8 / 16 that holds this box's entries
-        if (bx.ncand <= 4) k_pairdist<4><<<grid, dim3(GR_WG), 0, c->stream>>>(fr, s1, s2, bx, dim, out_dev, c->bad_dev);
-        else if (bx.ncand <= 8) k_pairdist<8><<<grid, dim3(GR_WG), 0, c->stream>>>(fr, s1, s2, bx, dim, out_dev, c->bad_dev);
-        else k_pairdist<16><<<grid, dim3(GR_WG), 0, c->stream>>>(fr, s1, s2, bx, dim, out_dev, c->bad_dev);
+        dim3 grid((s2.n + GR_WG * 4 - 1) / (GR_WG * 4), (s1.n + GR_PD_TI - 1) / GR_PD_TI, nb);
+        const float *fr = c->frames + (size_t)s0 * c->frame_stride;
+        // unrolled length of the minimum-image table: the smallest of 4 / 8 / 16 that holds every frame's entries
+        int ncand = 0;
+        for (uint32_t f = 0; f < nb; ++f) ncand = std::max(ncand, c->boxes_host[s0 + f].ncand);
+        if (ncand <= 4) k_pairdist<4><<<grid, dim3(GR_WG), 0, c->stream>>>(fr, c->frame_stride, s1, s2, c->boxes_dev + s0, dim, out_dev, out_stride, c->bad_dev);
+        else if (ncand <= 8) k_pairdist<8><<<grid, dim3(GR_WG), 0, c->stream>>>(fr, c->frame_stride, s1, s2, c->boxes_dev + s0, dim, out_dev, out_stride, c->bad_dev);
+        else k_pairdist<16><<<grid, dim3(GR_WG), 0, c->stream>>>(fr, c->frame_stride, s1, s2, c->boxes_dev + s0, dim, out_dev, out_stride, c->bad_dev);
         HIPCHK(c, hipGetLastError());
     }
-    HIPCHK(c, hipMemcpyAsync(c->bad_host, c->bad_dev, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->bad_host, c->bad_dev, 4 * (size_t)nb * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    // loop order of analysis.rs:414-424 with atom.rs:780-790: row atom first, then the column atoms of that row
-    if (c->bad_host[0] != GR_NOIDX || c->bad_host[1] != GR_NOIDX) {
-        const uint32_t b1 = c->bad_host[0], b2 = c->bad_host[1];
-        uint32_t first1 = s1.start;
-        uint32_t idx;
-        if (b1 == first1) idx = b1; else if (b2 != GR_NOIDX) idx = b2; else idx = b1;
-        return fail(c, GR_E_NO_POSITION, "atom has no position", idx);
+    return GR_OK;
+}
+// loop order of analysis.rs:414-424 with atom.rs:780-790: row atom first, then the column atoms of that row
+static int pairdist_status(gr_ctx *c, uint32_t f, const GrSel &s1) {
+    const uint32_t b1 = c->bad_host[4 * f], b2 = c->bad_host[4 * f + 1];
+    if (b1 == GR_NOIDX && b2 == GR_NOIDX) return GR_OK;
+    uint32_t idx;
+    if (b1 == s1.start) idx = b1; else if (b2 != GR_NOIDX) idx = b2; else idx = b1;
+    return fail(c, GR_E_NO_POSITION, "atom has no position", idx);
+}
+static int pairdist_run(gr_ctx *c, uint32_t slot, const GrSel &s1, const GrSel &s2, int dim, float *out_dev) {
+    int st = pairdist_launch(c, slot, 1, s1, s2, dim, out_dev, 0); if (st) return st;
+    return pairdist_status(c, 0, s1);
+}
+
+static int pairdist_reserve(gr_ctx *c, size_t need) {
+    if (need > c->pd_cap) {
+        if (c->pd_out) (void)hipFree(c->pd_out);
+        c->pd_out = nullptr; c->pd_cap = 0;
+        HIPCHK(c, hipMalloc(&c->pd_out, (need ? need : 1) * sizeof(float)));
+        c->pd_cap = need;
     }
     return GR_OK;
+}
+
+int gr_group_all_distances_batch_device(gr_ctx *c, uint32_t first_slot, uint32_t n_frames, const char *g1, const char *g2, int dim,
+                                        float **out_dev, uint64_t *n1, uint64_t *n2, int *status_out) {
+    int st = slot_check(c, first_slot, n_frames); if (st) return st;
+    (void)hipSetDevice(c->device);
+    const Group *a = find_group(c, g1); if (!a) return fail(c, GR_E_GROUP_NOT_FOUND, g1 ? g1 : "(null)");
+    const Group *b = find_group(c, g2); if (!b) return fail(c, GR_E_GROUP_NOT_FOUND, g2 ? g2 : "(null)");
+    if (dim < 0 || dim > 7) return fail(c, GR_E_INVALID_ARG, "bad dimension");
+    const size_t per = (size_t)a->n * b->n;
+    st = pairdist_reserve(c, per * n_frames); if (st) return st;
+    const GrSel s1 = make_sel(*a), s2 = make_sel(*b);
+    int first_err = GR_OK; std::string first_msg; uint64_t first_idx = 0;
+    for (uint32_t b0 = 0; b0 < n_frames; b0 += GR_MAX_BATCH) {
+        const uint32_t nb = std::min<uint32_t>(GR_MAX_BATCH, n_frames - b0), s0 = first_slot + b0;
+        std::vector<int> pre; std::vector<std::string> msg;
+        batch_prechecks(c, s0, nb, true, pre, msg);
+        st = pairdist_launch(c, s0, nb, s1, s2, dim, c->pd_out + (size_t)b0 * per, per); if (st) return st;
+        for (uint32_t f = 0; f < nb; ++f) {
+            int s = pre[f];
+            if (s != GR_OK) c->err = msg[f];
+            else s = pairdist_status(c, f, s1);
+            if (s != GR_OK && first_err == GR_OK) { first_err = s; first_msg = c->err; first_idx = c->err_index; }
+            if (status_out) status_out[b0 + f] = s;
+        }
+    }
+    if (out_dev) *out_dev = c->pd_out;
+    if (n1) *n1 = a->n;
+    if (n2) *n2 = b->n;
+    if (first_err != GR_OK) { c->err = first_msg; c->err_index = first_idx; }
+    return first_err;
 }
 
 int gr_group_all_distances_device(gr_ctx *c, uint32_t slot, const char *g1, const char *g2, int dim,
@@ -698,17 +746,20 @@ int gr_group_all_distances_device(gr_ctx *c, uint32_t slot, const char *g1, cons
     const Group *b = find_group(c, g2); if (!b) return fail(c, GR_E_GROUP_NOT_FOUND, g2 ? g2 : "(null)");
     st = box_check(c, slot); if (st) return st;
     if (dim < 0 || dim > 7) return fail(c, GR_E_INVALID_ARG, "bad dimension");
-    const size_t need = (size_t)a->n * b->n;
-    if (need > c->pd_cap) {
-        if (c->pd_out) (void)hipFree(c->pd_out);
-        c->pd_out = nullptr; c->pd_cap = 0;
-        HIPCHK(c, hipMalloc(&c->pd_out, (need ? need : 1) * sizeof(float)));
-        c->pd_cap = need;
-    }
+    st = pairdist_reserve(c, (size_t)a->n * b->n); if (st) return st;
     st = pairdist_run(c, slot, make_sel(*a), make_sel(*b), dim, c->pd_out); if (st) return st;
     if (out_dev) *out_dev = c->pd_out;
     if (n1) *n1 = a->n;
     if (n2) *n2 = b->n;
+    return GR_OK;
+}
+
+int gr_device_read(gr_ctx *c, const void *dev, void *host, size_t bytes) {
+    if (!c) return GR_E_INVALID_ARG;
+    if (!dev || !host) return fail(c, GR_E_INVALID_ARG, "NULL pointer");
+    (void)hipSetDevice(c->device);
+    HIPCHK(c, hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return GR_OK;
 }
 

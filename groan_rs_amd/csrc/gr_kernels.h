@@ -1137,21 +1137,89 @@ __global__ __launch_bounds__(GR_WG) void k_translate_wrap(
 // store per lane = 1 KiB contiguous per wavefront instruction.  The kernel is bound by the HBM write
 // of the matrix (4 B/pair); orthorhombic boxes need ~15 flop/pair.
 #ifndef GR_PD_TI
-#define GR_PD_TI 16
+#define GR_PD_TI 8      // 8 rows: 94.6 us per 1e4 x 1e4 orthorhombic call, 16: 98.0, 32: 108 (more, smaller workgroups keep more stores in flight)
 #endif
 #ifndef GR_PD_NT
 #define GR_PD_NT 1
 #endif
-// The box (with its image table) comes in BY VALUE: kernel arguments are read with scalar loads, so the table
-// entries are SGPR operands of the FMAs instead of per-lane LDS reads.
+// One frame per blockIdx.z (frames `frame_stride` floats, matrices `out_stride` floats, boxes one GrBox, error words 4 apart).
+// The frame's box (with its image table) is read through a uniform, read-only pointer: scalar loads, so the table entries
+// are SGPR operands of the FMAs instead of per-lane LDS reads.
+//
+// XYZ distances (the matrix the reference's users ask for) are VALU-bound, not write-bound, on this chip: a store-only
+// kernel of the same shape writes the 400 MB matrix of config 3 in 63 us (tools/microbench/write_bw.hip, 6.5 TB/s), the
+// generic distance needs ~40 VALU slots per orthorhombic pair (~100 us) and ~80 per triclinic pair (~200 us).  So XYZ has
+// its own inner loops, two columns at a time in packed-f32 registers (v_pk_add/mul/fma_f32):
+//   orthorhombic, every atom of the tile within [-L/4, 5L/4] (checked once per workgroup): |d| <= 1.5 L, so the
+//     reference's loops (vector3d.rs:575-592) run at most once and `|d| > L/2 ? d - copysign(L, d) : d` is the same single
+//     f32 rounding -- bit-identical, 5 slots per axis instead of 11; anything else takes the generic closed form;
+//   triclinic (our extension): brick reduction with k = rint(d/L) per axis (an ulp outside the brick is harmless, the
+//     image table covers it), then gain = |t|^2 - 2|d.t| per table entry with two entries per v_min3.
+typedef float gr_v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ gr_v2f gr_v2(float a) { gr_v2f r = { a, a }; return r; }
+__device__ __forceinline__ gr_v2f gr_v2_fma(gr_v2f a, gr_v2f b, gr_v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ float gr_min3f(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float gr_mi_near(float d, float L, float h) {
+    const float s = d - __builtin_copysignf(L, d);
+    return __builtin_fabsf(d) > h ? s : d;
+}
+__device__ __forceinline__ gr_v2f gr_mi_near2(gr_v2f d, float L, float h) {
+    gr_v2f cs = { __builtin_copysignf(L, d.x), __builtin_copysignf(L, d.y) };
+    const gr_v2f s = d - cs;
+    gr_v2f r = { __builtin_fabsf(d.x) > h ? s.x : d.x, __builtin_fabsf(d.y) > h ? s.y : d.y };
+    return r;
+}
+template <int DIM>   // Dimension (src/structures/dimension.rs:13-23): only the requested components are min-imaged (vector3d.rs:458-486)
+__device__ __forceinline__ gr_v2f gr_pd_ortho_near2(const float4 t, gr_v2f jx, gr_v2f jy, gr_v2f jz, const GrBox &b, float hx, float hy, float hz) {
+    gr_v2f mx = { 0.0f, 0.0f }, my = mx, mz = mx;
+    if (DIM == 1 || DIM == 4 || DIM == 5 || DIM == 7) mx = gr_mi_near2(gr_v2(t.x) - jx, b.ax, hx);
+    if (DIM == 2 || DIM == 4 || DIM == 6 || DIM == 7) my = gr_mi_near2(gr_v2(t.y) - jy, b.by, hy);
+    if (DIM == 3 || DIM == 5 || DIM == 6 || DIM == 7) mz = gr_mi_near2(gr_v2(t.z) - jz, b.cz, hz);
+    if (DIM == 1) return mx;
+    if (DIM == 2) return my;
+    if (DIM == 3) return mz;
+    const gr_v2f r2 = mx * mx + my * my + mz * mz;   // contracted like gr_mag3's x*x + y*y + z*z
+    gr_v2f r = { __builtin_amdgcn_sqrtf(r2.x), __builtin_amdgcn_sqrtf(r2.y) };
+    return r;
+}
+template <int NC>
+__device__ __forceinline__ gr_v2f gr_pd_tric2(const float4 t, gr_v2f jx, gr_v2f jy, gr_v2f jz, const GrBox &b) {
+    gr_v2f dx = gr_v2(t.x) - jx, dy = gr_v2(t.y) - jy, dz = gr_v2(t.z) - jz;
+    gr_v2f q = dz * gr_v2(b.icz);
+    gr_v2f k = { -rintf(q.x), -rintf(q.y) };
+    dx = gr_v2_fma(k, gr_v2(b.cx), dx); dy = gr_v2_fma(k, gr_v2(b.cy), dy); dz = gr_v2_fma(k, gr_v2(b.cz), dz);
+    q = dy * gr_v2(b.iby); k.x = -rintf(q.x); k.y = -rintf(q.y);
+    dx = gr_v2_fma(k, gr_v2(b.bx), dx); dy = gr_v2_fma(k, gr_v2(b.by), dy);
+    q = dx * gr_v2(b.iax); k.x = -rintf(q.x); k.y = -rintf(q.y);
+    dx = gr_v2_fma(k, gr_v2(b.ax), dx);
+    const gr_v2f r2 = dx * dx + dy * dy + dz * dz;
+    gr_v2f best = { 0.0f, 0.0f };
+    static_assert(NC % 2 == 0, "image table is searched two entries at a time");
+#pragma unroll
+    for (int m = 0; m < NC; m += 2) {
+        const gr_v2f d0 = gr_v2_fma(gr_v2(b.cand[m][0]), dx, gr_v2_fma(gr_v2(b.cand[m][1]), dy, gr_v2(b.cand[m][2]) * dz));
+        const gr_v2f d1 = gr_v2_fma(gr_v2(b.cand[m + 1][0]), dx, gr_v2_fma(gr_v2(b.cand[m + 1][1]), dy, gr_v2(b.cand[m + 1][2]) * dz));
+        best.x = gr_min3f(best.x, fmaf(-2.0f, __builtin_fabsf(d0.x), b.cand_t2[m]), fmaf(-2.0f, __builtin_fabsf(d1.x), b.cand_t2[m + 1]));
+        best.y = gr_min3f(best.y, fmaf(-2.0f, __builtin_fabsf(d0.y), b.cand_t2[m]), fmaf(-2.0f, __builtin_fabsf(d1.y), b.cand_t2[m + 1]));
+    }
+    const gr_v2f s = r2 + best;
+    gr_v2f r = { __builtin_amdgcn_sqrtf(fmaxf(s.x, 0.0f)), __builtin_amdgcn_sqrtf(fmaxf(s.y, 0.0f)) };
+    return r;
+}
+
 template <int NC>
 __global__ __launch_bounds__(GR_WG) void k_pairdist(
-    const float *__restrict__ xyz, GrSel s1, GrSel s2, const GrBox box, int dim,
-    float *__restrict__ out, uint32_t *__restrict__ bad_out) {
+    const float *__restrict__ xyz, size_t frame_stride, GrSel s1, GrSel s2, const GrBox *__restrict__ boxes, int dim,
+    float *__restrict__ out, size_t out_stride, uint32_t *__restrict__ bad_out) {
+    const GrBox &box = boxes[blockIdx.z];
+    xyz += (size_t)blockIdx.z * frame_stride; out += (size_t)blockIdx.z * out_stride; bad_out += 4 * blockIdx.z;
     __shared__ float ti[GR_PD_TI][4];
     __shared__ uint32_t ldsu[GR_WG / 64];
     const uint32_t i0 = blockIdx.y * GR_PD_TI, j0 = blockIdx.x * (GR_WG * 4) + threadIdx.x * 4;
     uint32_t bad = GR_NOIDX, badj = GR_NOIDX;   // first atom without position among the rows / the columns
+    // every coordinate of the tile within a quarter box of the cell (NaN fails the test): licence for gr_mi_near
+    const float lx = -0.25f * box.ax, ux = 1.25f * box.ax, ly = -0.25f * box.by, uy = 1.25f * box.by, lz = -0.25f * box.cz, uz = 1.25f * box.cz;
+    int far = 0;
     if (threadIdx.x < GR_PD_TI) {
         const uint32_t i = i0 + threadIdx.x;
         float x = 0.f, y = 0.f, z = 0.f;
@@ -1159,28 +1227,38 @@ __global__ __launch_bounds__(GR_WG) void k_pairdist(
             const uint32_t a = s1.contiguous ? s1.start + i : s1.idx[i];
             x = xyz[3 * (size_t)a]; y = xyz[3 * (size_t)a + 1]; z = xyz[3 * (size_t)a + 2];
             if (x != x) bad = min(bad, a);
+            far |= !(x >= lx && x <= ux && y >= ly && y <= uy && z >= lz && z <= uz);
         }
         ti[threadIdx.x][0] = x; ti[threadIdx.x][1] = y; ti[threadIdx.x][2] = z; ti[threadIdx.x][3] = 0.f;
     }
     float jx[4], jy[4], jz[4];
+    if (s2.contiguous && j0 + 3 < s2.n && ((s2.start + j0) & 3u) == 0u && (frame_stride & 3u) == 0u) {
+        // the lane's 4 atoms are 48 consecutive, 16-byte aligned bytes: three 16-byte loads instead of twelve 4-byte ones
+        const float4 *q = reinterpret_cast<const float4 *>(xyz + 3 * (size_t)(s2.start + j0));
+        const float4 a = q[0], b = q[1], c = q[2];
+        jx[0] = a.x; jy[0] = a.y; jz[0] = a.z; jx[1] = a.w; jy[1] = b.x; jz[1] = b.y; jx[2] = b.z; jy[2] = b.w; jz[2] = c.x; jx[3] = c.y; jy[3] = c.z; jz[3] = c.w;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const uint32_t j = j0 + k;
-        jx[k] = jy[k] = jz[k] = 0.f;
-        if (j < s2.n) {
-            const uint32_t a = s2.contiguous ? s2.start + j : s2.idx[j];
-            jx[k] = xyz[3 * (size_t)a]; jy[k] = xyz[3 * (size_t)a + 1]; jz[k] = xyz[3 * (size_t)a + 2];
-            if (jx[k] != jx[k]) badj = min(badj, a);
+        for (int k = 0; k < 4; ++k) if (jx[k] != jx[k]) badj = min(badj, s2.start + j0 + k);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t j = j0 + k;
+            jx[k] = jy[k] = jz[k] = 0.f;
+            if (j < s2.n) {
+                const uint32_t a = s2.contiguous ? s2.start + j : s2.idx[j];
+                jx[k] = xyz[3 * (size_t)a]; jy[k] = xyz[3 * (size_t)a + 1]; jz[k] = xyz[3 * (size_t)a + 2];
+                if (jx[k] != jx[k]) badj = min(badj, a);
+            }
         }
     }
-    __syncthreads();
+    if (box.ortho) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) far |= !(jx[k] >= lx && jx[k] <= ux && jy[k] >= ly && jy[k] <= uy && jz[k] >= lz && jz[k] <= uz);
+    }
+    far = __syncthreads_or(far);   // (also publishes ti)
     const uint32_t ni = min((uint32_t)GR_PD_TI, s1.n > i0 ? s1.n - i0 : 0u);
     const bool vec_ok = ((s2.n & 3u) == 0u);   // rows stay 16-byte aligned
-    for (uint32_t r = 0; r < ni; ++r) {
-        const float4 t = *reinterpret_cast<const float4 *>(&ti[r][0]);
-        float d[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) d[k] = gr_distance<NC>(t.x, t.y, t.z, jx[k], jy[k], jz[k], dim, box);
+    auto put = [&](uint32_t r, const float (&d)[4]) {
         float *row = out + (size_t)(i0 + r) * s2.n;
         if (vec_ok && j0 + 3 < s2.n) {
 #if GR_PD_NT
@@ -1191,6 +1269,43 @@ __global__ __launch_bounds__(GR_WG) void k_pairdist(
         } else {
 #pragma unroll
             for (int k = 0; k < 4; ++k) if (j0 + k < s2.n) row[j0 + k] = d[k];
+        }
+    };
+    const gr_v2f jx01 = { jx[0], jx[1] }, jy01 = { jy[0], jy[1] }, jz01 = { jz[0], jz[1] };
+    const gr_v2f jx23 = { jx[2], jx[3] }, jy23 = { jy[2], jy[3] }, jz23 = { jz[2], jz[3] };
+    if (dim != 0 && box.ortho && !far) {
+        const float hx = box.ax / 2.0f, hy = box.by / 2.0f, hz = box.cz / 2.0f;
+        auto rows = [&](auto D) {
+            for (uint32_t r = 0; r < ni; ++r) {
+                const float4 t = *reinterpret_cast<const float4 *>(&ti[r][0]);
+                const gr_v2f a = gr_pd_ortho_near2<decltype(D)::value>(t, jx01, jy01, jz01, box, hx, hy, hz), b = gr_pd_ortho_near2<decltype(D)::value>(t, jx23, jy23, jz23, box, hx, hy, hz);
+                const float d[4] = { a.x, a.y, b.x, b.y };
+                put(r, d);
+            }
+        };
+        switch (dim) {
+        case 1: rows(std::integral_constant<int, 1>()); break;
+        case 2: rows(std::integral_constant<int, 2>()); break;
+        case 3: rows(std::integral_constant<int, 3>()); break;
+        case 4: rows(std::integral_constant<int, 4>()); break;
+        case 5: rows(std::integral_constant<int, 5>()); break;
+        case 6: rows(std::integral_constant<int, 6>()); break;
+        default: rows(std::integral_constant<int, 7>()); break;
+        }
+    } else if (dim == 7 && !box.ortho) {
+        for (uint32_t r = 0; r < ni; ++r) {
+            const float4 t = *reinterpret_cast<const float4 *>(&ti[r][0]);
+            const gr_v2f a = gr_pd_tric2<NC>(t, jx01, jy01, jz01, box), b = gr_pd_tric2<NC>(t, jx23, jy23, jz23, box);
+            const float d[4] = { a.x, a.y, b.x, b.y };
+            put(r, d);
+        }
+    } else {
+        for (uint32_t r = 0; r < ni; ++r) {
+            const float4 t = *reinterpret_cast<const float4 *>(&ti[r][0]);
+            float d[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) d[k] = gr_distance<NC>(t.x, t.y, t.z, jx[k], jy[k], jz[k], dim, box);
+            put(r, d);
         }
     }
     bad = gr_block_min_u32(bad, ldsu);

@@ -466,6 +466,25 @@ class System:
             self._raise_group(st)
         return out
 
+    def group_all_distances_batch_device(self, group1, group2, first_slot, n_frames, dim=Dimension.XYZ, raise_on_error=True):
+        """group_all_distances for `n_frames` consecutive resident slots in one launch; the matrices stay in HBM.
+        -> (device pointer, n1, n2, status[n_frames]); matrix f starts f * n1 * n2 floats in; `device_read` fetches"""
+        dev = C.c_void_p(); n1 = C.c_uint64(); n2 = C.c_uint64()
+        status = np.zeros(n_frames, np.int32)
+        st = self._lib.gr_group_all_distances_batch_device(self._ctx, first_slot, n_frames, group1.encode(), group2.encode(), int(dim),
+                                                           C.byref(dev), C.byref(n1), C.byref(n2), _ptr(status))
+        if st != OK and raise_on_error:
+            self._raise_group(st)
+        return dev, int(n1.value), int(n2.value), status
+
+    def device_read(self, dev, offset_floats, shape):
+        """host copy of `shape` float32 values starting `offset_floats` into a device buffer handed out by the library"""
+        out = np.zeros(shape, np.float32)
+        st = self._lib.gr_device_read(self._ctx, C.c_void_p(dev.value + 4 * int(offset_floats)), _ptr(out), out.nbytes)
+        if st != OK:
+            self._raise_group(st)
+        return out
+
     def atoms_distance(self, index1, index2, dim=Dimension.XYZ, slot=0):
         out = C.c_float(0)
         st = self._lib.gr_atoms_distance(self._ctx, slot, index1, index2, int(dim), C.byref(out))

@@ -153,6 +153,15 @@ int gr_group_all_distances(gr_ctx *ctx, uint32_t slot, const char *group1, const
  * *out_dev receives the device pointer, for consumers that keep working on the GPU */
 int gr_group_all_distances_device(gr_ctx *ctx, uint32_t slot, const char *group1, const char *group2, int dim,
                                   float **out_dev, uint64_t *n1, uint64_t *n2);
+/* the matrices of `n_frames` consecutive slots in one launch and one synchronisation (a trajectory loop of
+ * group_all_distances over resident frames): matrix f starts at *out_dev + f * n1 * n2.  The caller bounds the memory
+ * through n_frames (4 * n1 * n2 bytes each).  status_out[f] (may be NULL) is the frame's status -- a failed frame's
+ * matrix is undefined -- and the return value is the first frame's error, as for the other batch calls. */
+int gr_group_all_distances_batch_device(gr_ctx *ctx, uint32_t first_slot, uint32_t n_frames, const char *group1, const char *group2, int dim,
+                                        float **out_dev, uint64_t *n1, uint64_t *n2, int *status_out);
+/* copy `bytes` from a device pointer this library handed out (e.g. *out_dev above) into host memory, after the
+ * context's stream has drained */
+int gr_device_read(gr_ctx *ctx, const void *dev, void *host, size_t bytes);
 
 /* ---------------------------------------------------------------- translate / wrap / centre
  * System::atoms_translate / group_translate (modifying.rs:45-75), atoms_wrap / group_wrap (:201-222),

@@ -6,7 +6,7 @@
 //! link with `println!("cargo:rustc-link-lib=dylib=groan_hip")` from build.rs.
 #![allow(non_camel_case_types)]
 
-use std::ffi::{c_char, c_float, c_int, CString};
+use std::ffi::{c_char, c_float, c_int, c_void, CString};
 use std::marker::PhantomData;
 
 use crate::errors::{AtomError, GroupError, MassError, PositionError, RMSDError, SimBoxError};
@@ -40,6 +40,9 @@ extern "C" {
     pub fn gr_group_center(ctx: *mut gr_ctx, slot: u32, group: *const c_char, kind: c_int, weighted: c_int, out: *mut c_float) -> c_int;
     pub fn gr_group_distance(ctx: *mut gr_ctx, slot: u32, g1: *const c_char, g2: *const c_char, dim: c_int, out: *mut c_float) -> c_int;
     pub fn gr_group_all_distances(ctx: *mut gr_ctx, slot: u32, g1: *const c_char, g2: *const c_char, dim: c_int, out: *mut c_float, cap: usize) -> c_int;
+    pub fn gr_group_all_distances_batch_device(ctx: *mut gr_ctx, first_slot: u32, n_frames: u32, g1: *const c_char, g2: *const c_char, dim: c_int,
+                                               out_dev: *mut *mut c_float, n1: *mut u64, n2: *mut u64, status_out: *mut c_int) -> c_int;
+    pub fn gr_device_read(ctx: *mut gr_ctx, dev: *const c_void, host: *mut c_void, bytes: usize) -> c_int;
     pub fn gr_group_translate(ctx: *mut gr_ctx, slot: u32, group: *const c_char, v: *const c_float) -> c_int;
     pub fn gr_group_wrap(ctx: *mut gr_ctx, slot: u32, group: *const c_char) -> c_int;
     pub fn gr_atoms_center(ctx: *mut gr_ctx, slot: u32, group: *const c_char, dim: c_int, weighted: c_int) -> c_int;

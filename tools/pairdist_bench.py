@@ -13,12 +13,14 @@ import groan_rs_amd as G
 import oracle_lib as O
 
 n, S, reps = 1_000_000, int(sys.argv[1]) if len(sys.argv) > 1 else 10_000, 20
+NB = 16   # frames per batched call (16 x 400 MB of matrices)
 out = {}
 for name, (l, a) in {"triclinic": ([24.0, 23.0, 22.0], [75.0, 80.0, 70.0]), "dodecahedron": ([24.18] * 3, [60.0, 60.0, 90.0]),
                      "orthorhombic": ([24.0, 23.0, 22.0], [90.0, 90.0, 90.0])}.items():
     box = O.box_from_lengths_angles(l, a)
-    s = G.System(n, n_slots=1)
-    s.synth_uniform(0, box, 20260424)
+    s = G.System(n, n_slots=NB)
+    for f in range(NB):
+        s.synth_uniform(f, box, 20260424 + f)
     s.group_create_from_ranges("S", [(0, S - 1)])
     lib = s._lib
     dev = C.c_void_p(); n1 = C.c_uint64(); n2 = C.c_uint64()
@@ -31,5 +33,15 @@ for name, (l, a) in {"triclinic": ([24.0, 23.0, 22.0], [75.0, 80.0, 70.0]), "dod
         ms = s.timer_stop() / reps
         out["%s/%s" % (name, "XYZ" if dim == 7 else "XY")] = {"ms_per_frame": round(ms, 4), "frames_per_s": round(1e3 / ms, 1),
                                                              "write_GBps": round(4.0 * S * S / (ms * 1e-3) / 1e9, 1)}
+        if dim == 7:   # the same matrices for NB resident frames per call: one launch, one synchronisation
+            status = (C.c_int * NB)()
+            lib.gr_group_all_distances_batch_device(s._ctx, 0, NB, b"S", b"S", dim, C.byref(dev), C.byref(n1), C.byref(n2), status)
+            s.sync(); s.timer_start()
+            for _ in range(4):
+                st = lib.gr_group_all_distances_batch_device(s._ctx, 0, NB, b"S", b"S", dim, C.byref(dev), C.byref(n1), C.byref(n2), status)
+                assert st == 0
+            ms = s.timer_stop() / (4 * NB)
+            out["%s/XYZ batch of %d" % (name, NB)] = {"ms_per_frame": round(ms, 4), "frames_per_s": round(1e3 / ms, 1),
+                                                       "write_GBps": round(4.0 * S * S / (ms * 1e-3) / 1e9, 1)}
     s.close()
 print(json.dumps(out, indent=1))
