@@ -25,6 +25,7 @@
 #include <set>
 #include <thread>
 #include <atomic>
+#include <chrono>
 
 #define GR_MAX_BATCH 1024    // frames per batched call segment (workspace is sized for this; 82 MB of partial records)
 #define GR_MAX_CHUNKS 256    // workgroups per frame in the reduction kernels
@@ -111,8 +112,13 @@ struct gr_ctx {
     uint32_t *ps_sync_host = nullptr; // pinned [2]
     unsigned long long *ps_trace = nullptr;   // GR_PS_TRACE=<file>: time stamps of the last persistent launch, dumped to <file>
     // device-side xtc unpacking (gr_xtc_read_frames_device): grow-only staging, pinned host mirror + device copy
-    unsigned char *xtc_host = nullptr, *xtc_dev = nullptr; size_t xtc_cap = 0;
-    hipEvent_t xtc_ev = nullptr;      // the previous batch's H2D has consumed the pinned staging buffer
+    // two pinned staging banks used in turn: the host reads + skims batch k + 1 while the H2D copy of batch k drains the other
+    // and two device banks: the H2D copy of batch k + 1 (copy stream) runs beside k_xtc_unpack of batch k (unpack stream)
+    unsigned char *xtc_host[2] = { nullptr, nullptr }, *xtc_dev[2] = { nullptr, nullptr }; size_t xtc_host_cap[2] = { 0, 0 }, xtc_dev_cap[2] = { 0, 0 };
+    hipEvent_t xtc_ev[2] = { nullptr, nullptr };        // the bank's last H2D has left the pinned bank / filled the device bank
+    hipEvent_t xtc_unpacked[2] = { nullptr, nullptr };  // the bank's last unpack kernel has finished with the device bank
+    hipStream_t unpack_stream = nullptr;
+    uint32_t xtc_bank = 0;
     float *wr_host = nullptr; size_t wr_cap = 0;   // pinned landing buffer of gr_xtc_write_slots (grow-only)
     std::string ps_trace_path;
     int strict = 0;
@@ -281,7 +287,14 @@ struct SlotUse {
     }
 };
 
-int set_box(gr_ctx *c, uint32_t slot, const float *box9, hipStream_t on = nullptr) {
+// both ingest streams idle: the H2D copy stream and the xtc unpack stream
+static hipError_t sync_ingest(gr_ctx *c) {
+    hipError_t e = hipStreamSynchronize(c->copy_stream);
+    if (e == hipSuccess && c->unpack_stream) e = hipStreamSynchronize(c->unpack_stream);
+    return e;
+}
+// host half of set_box: boxes_host[slot] + the slot's box status; the caller copies boxes_host to boxes_dev
+void box_fill(gr_ctx *c, uint32_t slot, const float *box9) {
     GrBox &b = c->boxes_host[slot];
     if (!box9) {
         gr_box_setup(nullptr, &b);
@@ -295,7 +308,10 @@ int set_box(gr_ctx *c, uint32_t slot, const float *box9, hipStream_t on = nullpt
         else if (b.ncand > GR_MAX_CAND) c->box_status[slot] = GR_E_UNSUPPORTED_BOX;
         else c->box_status[slot] = GR_OK;
     }
-    HIPCHK(c, hipMemcpyAsync(c->boxes_dev + slot, &b, sizeof(GrBox), hipMemcpyHostToDevice, on ? on : c->stream));
+}
+int set_box(gr_ctx *c, uint32_t slot, const float *box9, hipStream_t on = nullptr) {
+    box_fill(c, slot, box9);
+    HIPCHK(c, hipMemcpyAsync(c->boxes_dev + slot, &c->boxes_host[slot], sizeof(GrBox), hipMemcpyHostToDevice, on ? on : c->stream));
     return GR_OK;
 }
 
@@ -329,7 +345,11 @@ int frame_status(gr_ctx *c, const GrFrameState &st) {
 // launch one centre stage (sums + finalize) for `nf` frames starting at first_slot
 int center_stage(gr_ctx *c, uint32_t first_slot, uint32_t nf, const GrSel &sel, int kind, int weighted,
                  int mass_first, int target) {
-    const uint32_t nch = chunks_for(sel);
+    // batches: a multiple of 8 chunks per frame, so that chunk c of every frame runs on XCD c % 8 and that XCD's L2 keeps its
+    // eighth of the masses.  (The RMSD kernels' few, long chunks -- batch_chunks -- are slower here: 3.9 vs 3.1 us per 1e6-atom
+    // frame for the naive centre; this kernel's per-atom fp64 chains want many workgroups.)
+    uint32_t nch = chunks_for(sel);
+    if (nf > 1 && nch >= 8) nch &= ~7u;
     k_center_sums<<<dim3(nch, nf), dim3(GR_WG), 0, c->stream>>>(c->frames, c->frame_stride, first_slot, c->masses, sel, c->boxes_dev, c->state_dev, kind, weighted, c->cen_partials);
     k_center_finalize<<<dim3(nf), dim3(GR_WG), 0, c->stream>>>(c->cen_partials, nch, c->boxes_dev, first_slot, kind, weighted, mass_first, target, sel.n, c->state_dev);
     HIPCHK(c, hipGetLastError());
@@ -470,10 +490,14 @@ void gr_ctx_destroy(gr_ctx *c) {
     if (c->ps_rmsd) (void)hipFree(c->ps_rmsd);
     if (c->ps_sync) (void)hipFree(c->ps_sync);
     if (c->ps_trace) (void)hipFree(c->ps_trace);
-    if (c->xtc_host) (void)hipHostFree(c->xtc_host);
+    if (c->unpack_stream) { (void)hipStreamSynchronize(c->unpack_stream); (void)hipStreamDestroy(c->unpack_stream); }
+    for (int k = 0; k < 2; ++k) {
+        if (c->xtc_host[k]) (void)hipHostFree(c->xtc_host[k]);
+        if (c->xtc_dev[k]) (void)hipFree(c->xtc_dev[k]);
+        if (c->xtc_ev[k]) (void)hipEventDestroy(c->xtc_ev[k]);
+        if (c->xtc_unpacked[k]) (void)hipEventDestroy(c->xtc_unpacked[k]);
+    }
     if (c->wr_host) (void)hipHostFree(c->wr_host);
-    if (c->xtc_dev) (void)hipFree(c->xtc_dev);
-    if (c->xtc_ev) (void)hipEventDestroy(c->xtc_ev);
     if (c->ps_sync_host) (void)hipHostFree(c->ps_sync_host);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -499,7 +523,7 @@ uint32_t gr_n_slots(const gr_ctx *c) { return c ? c->n_slots : 0; }
 
 int gr_sync(gr_ctx *c) {
     if (!c) return GR_E_INVALID_ARG;
-    HIPCHK(c, hipStreamSynchronize(c->copy_stream));
+    HIPCHK(c, sync_ingest(c));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream2));
     return GR_OK;
@@ -608,7 +632,7 @@ int gr_frame_download(gr_ctx *c, uint32_t slot, float *xyz) {
 int gr_frame_set_box(gr_ctx *c, uint32_t slot, const float *box9) {
     int st = slot_check(c, slot); if (st) return st;
     (void)hipSetDevice(c->device);
-    HIPCHK(c, hipStreamSynchronize(c->copy_stream));
+    HIPCHK(c, sync_ingest(c));
     HIPCHK(c, hipStreamSynchronize(c->stream));   // boxes_host[slot] may still feed an earlier async copy
     return set_box(c, slot, box9);
 }
@@ -1598,6 +1622,8 @@ int gr_xtc_read_frames_device(const gr_xtc *x, uint64_t first_frame, uint32_t n_
         }
         return GR_OK;
     }
+    static const bool trace = getenv("GR_XTC_TRACE") != nullptr;   // host phase times to stderr
+    const auto t_call = std::chrono::steady_clock::now();
     // ---- layout of the batch's staging buffer: [streams (16-byte aligned, 16 zero bytes behind each)] [descs] [slots] [checkpoints]
     const uint32_t ncp = (n + GR_XTC_CP_ATOMS - 1) / GR_XTC_CP_ATOMS;
     std::vector<size_t> soff(n_frames);
@@ -1609,25 +1635,35 @@ int gr_xtc_read_frames_device(const gr_xtc *x, uint64_t first_frame, uint32_t n_
     const size_t off_desc = bytes;  bytes += (size_t)n_frames * sizeof(grx::FrameDesc);
     const size_t off_slot = bytes;  bytes += (((size_t)n_frames * sizeof(uint32_t)) + 15) & ~(size_t)15;
     const size_t off_cp = bytes;    bytes += (size_t)n_frames * ncp * sizeof(grx::Checkpoint);
-    if (c->xtc_ev) HIPCHK(c, hipEventSynchronize(c->xtc_ev));       // the previous batch has left the pinned buffer
-    else HIPCHK(c, hipEventCreateWithFlags(&c->xtc_ev, hipEventDisableTiming));
-    if (bytes > c->xtc_cap) {
-        HIPCHK(c, hipStreamSynchronize(c->copy_stream));
-        if (c->xtc_host) (void)hipHostFree(c->xtc_host);
-        if (c->xtc_dev) (void)hipFree(c->xtc_dev);
-        c->xtc_host = nullptr; c->xtc_dev = nullptr; c->xtc_cap = 0;
+    const uint32_t bank = c->xtc_bank; c->xtc_bank ^= 1u;
+    if (c->xtc_ev[bank]) HIPCHK(c, hipEventSynchronize(c->xtc_ev[bank]));       // the batch before the previous one has left this bank
+    else HIPCHK(c, hipEventCreateWithFlags(&c->xtc_ev[bank], hipEventDisableTiming));
+    if (bytes > c->xtc_host_cap[bank]) {
+        if (c->xtc_host[bank]) (void)hipHostFree(c->xtc_host[bank]);
+        c->xtc_host[bank] = nullptr; c->xtc_host_cap[bank] = 0;
         const size_t cap = bytes + bytes / 4;
-        HIPCHK(c, hipHostMalloc(&c->xtc_host, cap, hipHostMallocDefault));
-        HIPCHK(c, hipMalloc(&c->xtc_dev, cap));
-        c->xtc_cap = cap;
+        HIPCHK(c, hipHostMalloc(&c->xtc_host[bank], cap, hipHostMallocDefault));
+        c->xtc_host_cap[bank] = cap;
     }
-    unsigned char *H = c->xtc_host;
+    if (!c->unpack_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->unpack_stream, hipStreamNonBlocking));
+    if (!c->xtc_unpacked[bank]) HIPCHK(c, hipEventCreateWithFlags(&c->xtc_unpacked[bank], hipEventDisableTiming));
+    if (bytes > c->xtc_dev_cap[bank]) {
+        HIPCHK(c, hipStreamSynchronize(c->unpack_stream));        // nobody reads the old bank any more
+        if (c->xtc_dev[bank]) (void)hipFree(c->xtc_dev[bank]);
+        c->xtc_dev[bank] = nullptr; c->xtc_dev_cap[bank] = 0;
+        const size_t cap = bytes + bytes / 4;
+        HIPCHK(c, hipMalloc(&c->xtc_dev[bank], cap));
+        c->xtc_dev_cap[bank] = cap;
+    }
+    unsigned char *H = c->xtc_host[bank];
     grx::FrameDesc *descs = reinterpret_cast<grx::FrameDesc *>(H + off_desc);
     uint32_t *slots = reinterpret_cast<uint32_t *>(H + off_slot);
     grx::Checkpoint *cps = reinterpret_cast<grx::Checkpoint *>(H + off_cp);
     // ---- host: read + skim, one frame per worker at a time
     std::atomic<uint32_t> next(0);
     std::atomic<int> bad(grx::XTC_OK);
+    std::atomic<uint64_t> ns_read(0), ns_skim(0);
+    const auto t_begin = std::chrono::steady_clock::now();
     auto work = [&]() {
         std::vector<grx::Checkpoint> local;
         for (;;) {
@@ -1635,11 +1671,18 @@ int gr_xtc_read_frames_device(const gr_xtc *x, uint64_t first_frame, uint32_t n_
             if (k >= n_frames) return;
             const grx::FrameIndex &fi = x->f.frames[first_frame + k * frame_step];
             unsigned char *dst = H + soff[k];
+            const auto t0 = std::chrono::steady_clock::now();
             if (!grx::pread_all(x->f.fd, dst, (size_t)fi.nbytes, fi.data_offset)) { bad = grx::XTC_E_IO; return; }
             memset(dst + fi.nbytes, 0, (((size_t)fi.nbytes + 16 + 15) & ~(size_t)15) - (size_t)fi.nbytes);
             grx::FrameDesc d; memset(&d, 0, sizeof d);
             d.stream_off = soff[k]; d.cp_off = (uint64_t)k * ncp;
+            const auto t1 = std::chrono::steady_clock::now();
             const int r = grx::skim_frame(dst, fi, n, d, local);
+            if (trace) {
+                const auto t2 = std::chrono::steady_clock::now();
+                ns_read += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count();
+                ns_skim += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(t2 - t1).count();
+            }
             if (r != grx::XTC_OK || local.size() != ncp) { bad = r != grx::XTC_OK ? r : (int)grx::XTC_E_FORMAT; return; }
             memcpy(cps + (size_t)k * ncp, local.data(), ncp * sizeof(grx::Checkpoint));
             descs[k] = d; slots[k] = first_slot + k;
@@ -1650,27 +1693,48 @@ int gr_xtc_read_frames_device(const gr_xtc *x, uint64_t first_frame, uint32_t n_
     if (nt == 1) work();
     else { std::vector<std::thread> th; for (uint32_t t = 0; t < nt; ++t) th.emplace_back(work); for (auto &t : th) t.join(); }
     if (bad.load() != grx::XTC_OK) return fail(c, xtc_status(bad.load()), "corrupt or unreadable xtc frame");
-    // ---- device: behind the last kernels that still read these slots; boxes like gr_frame_upload
+    const auto t_host = std::chrono::steady_clock::now();
+    // ---- device.  copy stream: the bank's H2D, once the unpack kernel that last read the device bank is done.
+    // unpack stream: behind that copy and behind the last kernels that still read these slots -- the boxes (one copy from
+    // the pinned boxes_host range), the unpack kernel, then the slots' ready events.
+    unsigned char *D = c->xtc_dev[bank];
     for (uint32_t k = 0; k < n_frames; ++k) {
         const uint32_t slot = first_slot + k;
         if (!c->ev_ready[slot]) HIPCHK(c, hipEventCreateWithFlags(&c->ev_ready[slot], hipEventDisableTiming));
-        if (c->slot_gen[slot]) HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->ev_done_ring[c->slot_gen[slot] % 64], 0));
-        if (c->upload_pending[slot]) HIPCHK(c, hipEventSynchronize(c->ev_ready[slot]));
+        if (c->upload_pending[slot]) HIPCHK(c, hipEventSynchronize(c->ev_ready[slot]));   // boxes_host[slot] is about to be rewritten
     }
-    HIPCHK(c, hipMemcpyAsync(c->xtc_dev, H, bytes, hipMemcpyHostToDevice, c->copy_stream));
-    HIPCHK(c, hipEventRecord(c->xtc_ev, c->copy_stream));
-    k_xtc_unpack<<<dim3((ncp + 255) / 256, n_frames), dim3(256), 0, c->copy_stream>>>(
-        c->xtc_dev, reinterpret_cast<const grx::FrameDesc *>(c->xtc_dev + off_desc), reinterpret_cast<const grx::Checkpoint *>(c->xtc_dev + off_cp),
-        c->frames, c->frame_stride, reinterpret_cast<const uint32_t *>(c->xtc_dev + off_slot), n);
-    HIPCHK(c, hipGetLastError());
     for (uint32_t k = 0; k < n_frames; ++k) {
         const uint64_t fr = first_frame + k * frame_step;
         float box9[9];
         st = gr_xtc_frame_info(x, fr, steps ? steps + k : nullptr, times ? times + k : nullptr, box9, nullptr);
         if (st != GR_OK) return fail(c, st, "unsupported box in xtc frame", fr);
-        st = set_box(c, first_slot + k, box9, c->copy_stream); if (st) return st;
-        HIPCHK(c, hipEventRecord(c->ev_ready[first_slot + k], c->copy_stream));
+        box_fill(c, first_slot + k, box9);
+    }
+    HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->xtc_unpacked[bank], 0));
+    HIPCHK(c, hipMemcpyAsync(D, H, bytes, hipMemcpyHostToDevice, c->copy_stream));
+    HIPCHK(c, hipEventRecord(c->xtc_ev[bank], c->copy_stream));
+    hipStream_t U = c->unpack_stream;
+    HIPCHK(c, hipStreamWaitEvent(U, c->xtc_ev[bank], 0));
+    uint64_t waited = 0;
+    for (uint32_t k = 0; k < n_frames; ++k) {
+        const uint64_t gen = c->slot_gen[first_slot + k];
+        if (gen && gen != waited) { HIPCHK(c, hipStreamWaitEvent(U, c->ev_done_ring[gen % 64], 0)); waited = gen; }
+    }
+    HIPCHK(c, hipMemcpyAsync(c->boxes_dev + first_slot, c->boxes_host + first_slot, (size_t)n_frames * sizeof(GrBox), hipMemcpyHostToDevice, U));
+    k_xtc_unpack<<<dim3((ncp + 255) / 256, n_frames), dim3(256), 0, U>>>(
+        D, reinterpret_cast<const grx::FrameDesc *>(D + off_desc), reinterpret_cast<const grx::Checkpoint *>(D + off_cp),
+        c->frames, c->frame_stride, reinterpret_cast<const uint32_t *>(D + off_slot), n);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipEventRecord(c->xtc_unpacked[bank], U));
+    for (uint32_t k = 0; k < n_frames; ++k) {
+        HIPCHK(c, hipEventRecord(c->ev_ready[first_slot + k], U));
         c->upload_pending[first_slot + k] = 1;
+    }
+    if (trace) {
+        const auto t_end = std::chrono::steady_clock::now();
+        auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        fprintf(stderr, "[xtc] %u frames, %u threads: waits + buffers %.2f ms, read + skim %.2f ms (per frame, thread time: read %.3f, skim %.3f), enqueue %.2f ms\n",
+                n_frames, nt, ms(t_call, t_begin), ms(t_begin, t_host), ns_read.load() * 1e-6 / n_frames, ns_skim.load() * 1e-6 / n_frames, ms(t_host, t_end));
     }
     return GR_OK;
 }
@@ -1879,7 +1943,7 @@ int gr_profile_read(const gr_ctx *c, int kernel, double *ms_total, uint64_t *lau
 int gr_synth_reference(gr_ctx *c, uint32_t slot, const float *box9, float radius, uint64_t seed) {
     int st = slot_check(c, slot); if (st) return st;
     (void)hipSetDevice(c->device);
-    HIPCHK(c, hipStreamSynchronize(c->copy_stream));
+    HIPCHK(c, sync_ingest(c));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     st = set_box(c, slot, box9); if (st) return st;
     st = box_check(c, slot); if (st) return st;
@@ -1897,7 +1961,7 @@ int gr_synth_frames(gr_ctx *c, uint32_t ref_slot, uint32_t first_slot, uint32_t 
     (void)hipSetDevice(c->device);
     st = box_check(c, ref_slot); if (st) return st;
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->copy_stream));
+    HIPCHK(c, sync_ingest(c));
     for (uint32_t f = 0; f < n_frames; ++f) { st = set_box(c, first_slot + f, &c->box9_host[9 * (size_t)ref_slot]); if (st) return st; }
     for (uint32_t f0 = 0; f0 < n_frames; f0 += 1024) {
         const uint32_t nf = std::min<uint32_t>(1024, n_frames - f0);
@@ -1911,7 +1975,7 @@ int gr_synth_frames(gr_ctx *c, uint32_t ref_slot, uint32_t first_slot, uint32_t 
 int gr_synth_uniform(gr_ctx *c, uint32_t slot, const float *box9, uint64_t seed) {
     int st = slot_check(c, slot); if (st) return st;
     (void)hipSetDevice(c->device);
-    HIPCHK(c, hipStreamSynchronize(c->copy_stream));
+    HIPCHK(c, sync_ingest(c));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     st = set_box(c, slot, box9); if (st) return st;
     st = box_check(c, slot); if (st) return st;

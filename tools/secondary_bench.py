@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Secondary pipelines of SURVEY.md section 8(d) on resident frames: centres / COM, translate + wrap, centring.
+1e6 atoms, NF frames per call through the batch entry points; prints one JSON object with, per operation, us per frame,
+algorithmic GB/s (bytes per atom per frame from DESIGN.md section 5) and the fraction of the 8 TB/s HBM peak."""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import groan_rs_amd as G
+import oracle_lib as O
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+NF = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+REPS = 9
+PEAK = 8000.0
+out = {"n_atoms": n, "frames_per_call": NF}
+for bname, (l, a) in {"orthorhombic": ([24.0, 23.0, 22.0], [90.0, 90.0, 90.0]), "dodecahedron": ([24.18] * 3, [60.0, 60.0, 90.0])}.items():
+    box = O.box_from_lengths_angles(l, a)
+    masses = np.array([1.008, 12.011, 14.007, 15.999], np.float32)[np.arange(n) % 4]
+    s = G.System(n, masses=masses, n_slots=NF + 1)
+    s.synth_reference(NF, box, 0.2 * float(min(box[:3])), 1)
+    s.synth_frames(NF, 0, NF, 0, 0.05, 1)
+    s.group_create_from_ranges("tenth", [(0, n // 10 - 1)])
+
+    def timed(fn):
+        fn(); fn(); s.sync()
+        ts = []                     # wall clock around whole calls (each ends with its own read-back + synchronisation)
+        for _ in range(REPS):
+            t = time.perf_counter(); fn(); ts.append(time.perf_counter() - t)
+        return float(np.median(ts)) / NF * 1e6, float(np.max(ts)) / NF * 1e6     # us per frame: median, worst call
+
+    ops = {
+        "group_get_com_naive(all)  [16 B/atom]": (lambda: s.group_center_batch("all", G._lib.CENTER_NAIVE, 1, 0, NF), 16.0 * n),
+        "group_estimate_com(all)   [16 B/atom]": (lambda: s.group_estimate_com_batch("all", 0, NF), 16.0 * n),
+        "group_get_com(all)        [16 B/atom, 2 dependent passes]": (lambda: s.group_get_com_batch("all", 0, NF), 16.0 * n),
+        "group_get_center(all)     [12 B/atom, 2 dependent passes]": (lambda: s.group_get_center_batch("all", 0, NF), 12.0 * n),
+        "group_get_com(tenth)      [16 B/atom of the group]": (lambda: s.group_get_com_batch("tenth", 0, NF), 1.6 * n),
+        "atoms_translate           [24 B/atom]": (lambda: s.group_translate_batch(None, [0.3, -0.2, 0.1], 0, NF), 24.0 * n),
+        "atoms_wrap                [24 B/atom]": (lambda: s.group_wrap_batch(None, 0, NF), 24.0 * n),
+        "atoms_center(tenth)       [24 B/atom + 1.2 B/atom estimate]": (lambda: s.atoms_center_batch("tenth", 0, NF), 24.0 * n + 1.2 * n),
+        "atoms_center_mass(all)    [24 + 16 B/atom]": (lambda: s.atoms_center_batch("all", 0, NF, weighted=True), 40.0 * n),
+    }
+    res = {}
+    for name, (fn, nbytes) in ops.items():
+        us, worst = timed(fn)
+        gbs = nbytes / (us * 1e-6) / 1e9
+        res[name] = {"us_per_frame": round(us, 3), "frames_per_s": round(1e6 / us, 1), "algorithmic_GBps": round(gbs, 1), "frac_of_hbm_peak": round(gbs / PEAK, 3), "worst_call_us_per_frame": round(worst, 3)}
+    out[bname] = res
+    s.close()
+print(json.dumps(out, indent=1))
