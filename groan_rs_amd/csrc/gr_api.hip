@@ -1846,7 +1846,8 @@ int gr_xtc_write_frame(gr_xtc_writer *w, uint64_t n, const float *xyz, const flo
     if (!w || !w->fp || (!xyz && n) || n > 0x7fffffffull) return GR_E_INVALID_ARG;
     float m[9]; box9_rows(box9, m);
     std::vector<unsigned char> out; grx::EncodedFrame sc; std::vector<int> ints;
-    grx::serialise_frame(out, (uint32_t)n, (int32_t)step, time, m, xyz, precision, sc, ints);
+    // coordinate x precision beyond the format's 32-bit integers (or NaN in y / z): nothing is written
+    if (!grx::serialise_frame(out, (uint32_t)n, (int32_t)step, time, m, xyz, precision, sc, ints)) return GR_E_OUT_OF_RANGE;
     return fwrite(out.data(), 1, out.size(), w->fp) == out.size() ? GR_OK : GR_E_IO;
 }
 int gr_xtc_write_slots(gr_xtc_writer *w, gr_ctx *c, uint32_t first_slot, uint32_t n_frames, const char *group,
@@ -1885,6 +1886,7 @@ int gr_xtc_write_slots(gr_xtc_writer *w, gr_ctx *c, uint32_t first_slot, uint32_
     std::vector<std::vector<unsigned char>> frames_out(n_frames);
     std::atomic<uint32_t> next(0);
     std::atomic<int> bad(0);
+    std::atomic<unsigned> bad_frame(~0u);   // a frame whose coordinates the format cannot hold
     const int dev = c->device;
     auto work = [&]() {
         (void)hipSetDevice(dev);
@@ -1900,7 +1902,9 @@ int gr_xtc_write_slots(gr_xtc_writer *w, gr_ctx *c, uint32_t first_slot, uint32_
                 src = gathered.data();
             }
             float m[9]; box9_rows(c->box9_set[first_slot + k] ? &c->box9_host[9 * (size_t)(first_slot + k)] : nullptr, m);
-            grx::serialise_frame(frames_out[k], (uint32_t)n_out, (int32_t)(steps ? steps[k] : 0), times ? times[k] : 0.0f, m, src, precision, sc, ints);
+            if (!grx::serialise_frame(frames_out[k], (uint32_t)n_out, (int32_t)(steps ? steps[k] : 0), times ? times[k] : 0.0f, m, src, precision, sc, ints)) {
+                unsigned expect = ~0u; (void)bad_frame.compare_exchange_strong(expect, k);
+            }
         }
     };
     uint32_t nt = host_threads > 0 ? (uint32_t)host_threads : std::min<uint32_t>(n_frames, 8u);
@@ -1909,6 +1913,7 @@ int gr_xtc_write_slots(gr_xtc_writer *w, gr_ctx *c, uint32_t first_slot, uint32_
     else { std::vector<std::thread> th; for (uint32_t t = 0; t < nt; ++t) th.emplace_back(work); for (auto &t : th) t.join(); }
     for (auto x : ev) if (x) (void)hipEventDestroy(x);
     if (bad.load()) return fail(c, GR_E_HIP, "device-to-host copy failed while writing frames");
+    if (bad_frame.load() != ~0u) return fail(c, GR_E_OUT_OF_RANGE, "coordinates do not fit the xtc integers at this precision; nothing written", first_slot + bad_frame.load());
     for (uint32_t k = 0; k < n_frames; ++k)
         if (fwrite(frames_out[k].data(), 1, frames_out[k].size(), w->fp) != frames_out[k].size()) return fail(c, GR_E_IO, "short write");
     return GR_OK;

@@ -47,6 +47,9 @@ inline uint32_t be32(const unsigned char *p) { return ((uint32_t)p[0] << 24) | (
 inline float bef(const unsigned char *p) { uint32_t u = be32(p); float f; memcpy(&f, &u, 4); return f; }
 inline uint64_t be64(const unsigned char *p) { return ((uint64_t)be32(p) << 32) | be32(p + 4); }
 inline int bit_length(unsigned __int128 v) { int n = 0; while (v) { ++n; v >>= 1; } return n; }
+// two's-complement wrap-around sums: what the C decoder's `int` arithmetic does on a corrupt file, without the undefined behaviour
+inline int wadd(int a, int b) { return (int)((uint32_t)a + (uint32_t)b); }
+inline int wsub(int a, int b) { return (int)((uint32_t)a - (uint32_t)b); }
 
 struct FrameIndex {
     uint64_t offset;      // of the frame's magic number
@@ -164,17 +167,20 @@ inline int open_file(File &f, const char *path) {
 }
 
 // decode one frame into xyz[natoms][3]; scratch is grown as needed (one per calling thread)
+// zero bytes kept behind a bit stream: the position is checked once per group, and one group of a corrupt stream can pull
+// 96 + 6 + 8 * 72 bits (< 96 bytes) past the last valid position before that check sees it
+#define GR_XTC_PAD 128
 inline int decode_frame(const File &f, const FrameIndex &fi, float *xyz, std::vector<unsigned char> &scratch) {
     const uint32_t n = f.natoms;
-    scratch.resize((size_t)fi.nbytes + 16);
+    scratch.resize((size_t)fi.nbytes + GR_XTC_PAD);
     if (!pread_all(f.fd, scratch.data(), (size_t)fi.nbytes, fi.data_offset)) return XTC_E_IO;
-    memset(scratch.data() + fi.nbytes, 0, 16);
+    memset(scratch.data() + fi.nbytes, 0, GR_XTC_PAD);
     if (n <= 9) {
         for (uint32_t k = 0; k < 3 * n; ++k) xyz[k] = bef(scratch.data() + 4 * k);
         return XTC_OK;
     }
     uint32_t sizeint[3];
-    for (int k = 0; k < 3; ++k) sizeint[k] = (uint32_t)(fi.maxint[k] - fi.minint[k] + 1);
+    for (int k = 0; k < 3; ++k) sizeint[k] = (uint32_t)fi.maxint[k] - (uint32_t)fi.minint[k] + 1u;
     int bitsizeint[3] = { 0, 0, 0 }, bitsize;
     if ((sizeint[0] | sizeint[1] | sizeint[2]) > 0xffffffu) {
         for (int k = 0; k < 3; ++k) { int b = bit_length(sizeint[k]); bitsizeint[k] = b > 32 ? 32 : b; }
@@ -196,7 +202,7 @@ inline int decode_frame(const File &f, const FrameIndex &fi, float *xyz, std::ve
         int cur[3];
         if (bitsize == 0) { cur[0] = (int)bits.get(bitsizeint[0]); cur[1] = (int)bits.get(bitsizeint[1]); cur[2] = (int)bits.get(bitsizeint[2]); }
         else unpack3(bits, bitsize, sizeint, cur);
-        cur[0] += fi.minint[0]; cur[1] += fi.minint[1]; cur[2] += fi.minint[2];
+        cur[0] = wadd(cur[0], fi.minint[0]); cur[1] = wadd(cur[1], fi.minint[1]); cur[2] = wadd(cur[2], fi.minint[2]);
         ++i;
         int change = 0;
         if (bits.get(1)) {
@@ -211,7 +217,7 @@ inline int decode_frame(const File &f, const FrameIndex &fi, float *xyz, std::ve
             for (int k = 0; k < run; k += 3) {
                 int d[3];
                 unpack3(bits, smallidx, sizesmall, d);
-                int nxt[3] = { d[0] + prev[0] - smallnum, d[1] + prev[1] - smallnum, d[2] + prev[2] - smallnum };
+                int nxt[3] = { wsub(wadd(d[0], prev[0]), smallnum), wsub(wadd(d[1], prev[1]), smallnum), wsub(wadd(d[2], prev[2]), smallnum) };
                 ++i;
                 if (k == 0) {
                     // the first small atom is stored AFTER its successor (water: O H H -> H O H): emit it first
@@ -259,7 +265,7 @@ inline uint32_t peek_bits(const unsigned char *p, uint64_t bitpos, int n) {   //
 
 // Walk the groups of one frame (natoms > 9): fills the descriptor's decoding constants and the checkpoints.
 inline int skim_frame(const unsigned char *stream, const FrameIndex &fi, uint32_t n, FrameDesc &d, std::vector<Checkpoint> &cps) {
-    for (int k = 0; k < 3; ++k) { d.minint[k] = fi.minint[k]; d.sizeint[k] = (uint32_t)(fi.maxint[k] - fi.minint[k] + 1); }
+    for (int k = 0; k < 3; ++k) { d.minint[k] = fi.minint[k]; d.sizeint[k] = (uint32_t)fi.maxint[k] - (uint32_t)fi.minint[k] + 1u; }
     d.bitsizeint[0] = d.bitsizeint[1] = d.bitsizeint[2] = 0;
     int large_bits;
     if ((d.sizeint[0] | d.sizeint[1] | d.sizeint[2]) > 0xffffffu) {
@@ -283,6 +289,7 @@ inline int skim_frame(const unsigned char *stream, const FrameIndex &fi, uint32_
             while (next_cp <= i) { cps.push_back(Checkpoint{ (uint32_t)bitpos, i, (uint32_t)smallidx | ((uint32_t)run << 8) }); next_cp += GR_XTC_CP_ATOMS; }
         }
         bitpos += (uint64_t)large_bits;
+        if (bitpos + 6 > limit_bits) return XTC_E_FORMAT;       // the flag / run field below must lie inside the (padded) stream
         ++i;
         int change = 0;
         if (peek_bits(stream, bitpos, 1)) {
@@ -347,14 +354,18 @@ struct EncodedFrame {
     std::vector<unsigned char> bytes;   // the bit stream (not yet padded to 4 bytes)
 };
 
-inline int quantise(float x, float precision) {
+// false when the scaled value does not fit the format's integers (the C code prints "Internal overflow compressing
+// coordinates." and converts anyway -- undefined; here the frame is refused)
+inline bool quantise(float x, float precision, int &q) {
     const float prod = x * precision;
     const float lf = (float)((double)prod + (x >= 0.0f ? 0.5 : -0.5));
-    return (int)lf;
+    if (!(fabsf(lf) <= (float)(INT_MAX - 2))) return false;   // also NaN
+    q = (int)lf;
+    return true;
 }
 
 // xyz[n][3] (n > 9) -> header integers + bit stream; `ints` is scratch (3 n ints)
-inline void encode_coords(const float *xyz, uint32_t n, float precision, EncodedFrame &e, std::vector<int> &ints) {
+inline bool encode_coords(const float *xyz, uint32_t n, float precision, EncodedFrame &e, std::vector<int> &ints) {
     if (!(precision > 0.0f)) precision = 1000.0f;
     e.precision = precision;
     ints.resize(3 * (size_t)n);
@@ -366,7 +377,7 @@ inline void encode_coords(const float *xyz, uint32_t n, float precision, Encoded
         const bool missing = xyz[3 * (size_t)i] != xyz[3 * (size_t)i];   // None travels as NaN in x: written as the origin (xtc_io/mod.rs:296-301)
         for (int a = 0; a < 3; ++a) {
             const float x = missing ? 0.0f : xyz[3 * (size_t)i + a];
-            q[a] = quantise(x, precision);
+            if (!quantise(x, precision, q[a])) return false;
             if (q[a] < mn[a]) mn[a] = q[a];
             if (q[a] > mx[a]) mx[a] = q[a];
             ints[3 * (size_t)i + a] = q[a];
@@ -376,7 +387,10 @@ inline void encode_coords(const float *xyz, uint32_t n, float precision, Encoded
         old[0] = q[0]; old[1] = q[1]; old[2] = q[2];
     }
     uint32_t sizeint[3];
-    for (int a = 0; a < 3; ++a) { e.minint[a] = mn[a]; e.maxint[a] = mx[a]; sizeint[a] = (uint32_t)(mx[a] - mn[a] + 1); }
+    for (int a = 0; a < 3; ++a) {
+        if ((float)mx[a] - (float)mn[a] >= (float)(INT_MAX - 2)) return false;   // value - minint would not fit
+        e.minint[a] = mn[a]; e.maxint[a] = mx[a]; sizeint[a] = (uint32_t)mx[a] - (uint32_t)mn[a] + 1u;
+    }
     int bitsizeint[3] = { 0, 0, 0 }, bitsize;
     if ((sizeint[0] | sizeint[1] | sizeint[2]) > 0xffffffu) {
         for (int a = 0; a < 3; ++a) { int b = bit_length(sizeint[a]); bitsizeint[a] = b > 32 ? 32 : b; }
@@ -450,13 +464,14 @@ inline void encode_coords(const float *xyz, uint32_t n, float precision, Encoded
         }
     }
     bw.finish();
+    return true;
 }
 
 inline void put_be32(std::vector<unsigned char> &o, uint32_t v) { o.push_back((unsigned char)(v >> 24)); o.push_back((unsigned char)(v >> 16)); o.push_back((unsigned char)(v >> 8)); o.push_back((unsigned char)v); }
 inline void put_bef(std::vector<unsigned char> &o, float f) { uint32_t u; memcpy(&u, &f, 4); put_be32(o, u); }
 
 // one whole frame as it appears in the file (magic 1995): header, box (rows = box vectors), coordinates
-inline void serialise_frame(std::vector<unsigned char> &o, uint32_t natoms, int32_t step, float time, const float box_rows[9], const float *xyz,
+inline bool serialise_frame(std::vector<unsigned char> &o, uint32_t natoms, int32_t step, float time, const float box_rows[9], const float *xyz,
                             float precision, EncodedFrame &scratch, std::vector<int> &ints) {
     o.clear();
     put_be32(o, 1995u); put_be32(o, natoms); put_be32(o, (uint32_t)step); put_bef(o, time);
@@ -464,9 +479,9 @@ inline void serialise_frame(std::vector<unsigned char> &o, uint32_t natoms, int3
     put_be32(o, natoms);
     if (natoms <= 9) {
         for (uint32_t k = 0; k < 3 * natoms; ++k) put_bef(o, (xyz[3 * (k / 3)] != xyz[3 * (k / 3)]) ? 0.0f : xyz[k]);
-        return;
+        return true;
     }
-    encode_coords(xyz, natoms, precision, scratch, ints);
+    if (!encode_coords(xyz, natoms, precision, scratch, ints)) { o.clear(); return false; }
     put_bef(o, scratch.precision);
     for (int a = 0; a < 3; ++a) put_be32(o, (uint32_t)scratch.minint[a]);
     for (int a = 0; a < 3; ++a) put_be32(o, (uint32_t)scratch.maxint[a]);
@@ -474,6 +489,7 @@ inline void serialise_frame(std::vector<unsigned char> &o, uint32_t natoms, int3
     put_be32(o, (uint32_t)scratch.bytes.size());
     o.insert(o.end(), scratch.bytes.begin(), scratch.bytes.end());
     while (o.size() & 3u) o.push_back(0);
+    return true;
 }
 
 }  // namespace grx

@@ -79,3 +79,33 @@ def test_same_bytes_as_the_reference_writer(G, tmp_path, case):
 def test_errors(G, tmp_path):
     with pytest.raises(G.XtcError):
         G.XtcWriter(tmp_path / "no_such_dir" / "x.xtc")
+
+
+def test_coordinates_the_format_cannot_hold_are_refused(G, tmp_path):
+    """x * precision beyond the 32-bit integers of the format (xdrfile.c:1025-1030 prints "Internal overflow compressing
+    coordinates." and converts anyway -- undefined behaviour): the frame is refused and nothing reaches the file; a NaN in x
+    is the reference's missing position (written as the origin, xtc_io/mod.rs:296-301), a NaN in y or z is not a value"""
+    rng = np.random.default_rng(4)
+    pos = rng.uniform(0, 5, (40, 3)).astype(np.float32)
+    box = np.array([5, 5, 5, 0, 0, 0, 0, 0, 0], np.float32)
+    path = tmp_path / "refuse.xtc"
+    with G.XtcWriter(path) as w:
+        w.write_frame(pos, box, step=1)
+        for bad, prec in ((3e6, 1000.0), (-3e6, 1000.0), (np.inf, 1000.0), (3000.0, 1e6)):
+            p = pos.copy(); p[7, 1] = bad
+            with pytest.raises(G.XtcError) as e:
+                w.write_frame(p, box, step=2, precision=prec)
+            assert e.value.status == G._lib.GR_E_OUT_OF_RANGE if hasattr(G._lib, "GR_E_OUT_OF_RANGE") else e.value.status == 9
+        p = pos.copy(); p[3, 2] = np.nan
+        with pytest.raises(G.XtcError):
+            w.write_frame(p, box, step=3)
+        p = pos.copy(); p[3, 0] = np.nan                      # missing position: fine
+        w.write_frame(p, box, step=4)
+        wide = pos.copy(); wide[0, 0] = -1.2e6; wide[1, 0] = 1.2e6   # each value fits, their range does not
+        with pytest.raises(G.XtcError):
+            w.write_frame(wide, box, step=5)
+    x = G.XtcFile(path)
+    assert x.n_frames == 2                                     # the refused frames left no bytes behind
+    got = x.read_frame(1)[0]
+    assert np.all(got[3] == 0.0) and np.abs(got[4] - pos[4]).max() <= 0.00051
+    x.close()
