@@ -51,7 +51,8 @@ struct GrBox {
 
 // Closed forms of the reference's loops, branch-free.
 //   wrap:      `while w > L: w -= L; while w < 0: w += L` (vector3d.rs:398-417).  For t > 0 the result lies in
-//              (0, L] (the upper end stays closed: t == L is left alone), for t <= 0 in [0, L).
+//              (0, L] (the upper end stays closed: t == L is left alone), for t <= 0 in [0, L] -- L itself when a tiny
+//              negative t plus L rounds to L (tests/cpp/test_wrap.cpp walks these values against the loops).
 //              k = floor(t/L), and k - 1 when that lands a positive t exactly on 0.
 //   min_image: `while d > L/2: d -= L; while d < -L/2: d += L` (vector3d.rs:575-592): result in [-L/2, L/2].
 // k is first estimated with the reciprocal of L and then corrected by comparing the actual remainder, so the
@@ -62,7 +63,10 @@ GR_HD float gr_wrap_k(float t, float L, float iL) {
     float k = floorf(t * iL);
     float r = fmaf(-k, L, t);
     k += (r < 0.0f) ? -1.0f : 0.0f;
-    k += (r >= L) ? 1.0f : 0.0f;
+    k += (r > L) ? 1.0f : 0.0f;
+    // r == L: either t is an exact multiple of L (a negative one must come down to 0, a positive one stays on L), or a
+    // tiny negative t whose `w += L` ROUNDS to L -- the reference's loop then stops on L (the closed upper end)
+    if (r == L && t < 0.0f && fmaf(-(k + 1.0f), L, t) == 0.0f) k += 1.0f;
     r = fmaf(-k, L, t);
     k -= (r == 0.0f && t > 0.0f) ? 1.0f : 0.0f;
     return k;

@@ -1,0 +1,46 @@
+// Host check of the branch-free wrap / minimum-image closed forms (groan_rs_amd/csrc/gr_math.h) against the reference's loops
+// (Vector3D::wrap_coordinate src/structures/vector3d.rs:398-417, min_image :575-592), bit for bit, on the values where
+// rounding decides: tiny negatives (the loop's `w += L` rounds to exactly L and stays there -- the closed upper end),
+// exact multiples of L, neighbours of 0 / L / L/2, and random values within a few boxes.
+#include <cmath>
+#include <cstdio>
+#include <cstdint>
+#include <cstring>
+#include <random>
+#include <vector>
+#include "../../groan_rs_amd/csrc/gr_math.h"
+
+static float loop_wrap(float w, float L) { while (w > L) w -= L; while (w < 0.0f) w += L; return w; }
+static float loop_minimg(float d, float L) { const float h = L / 2.0f; while (d > h) d -= L; while (d < -h) d += L; return d; }
+static uint32_t bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+
+int main() {
+    std::mt19937_64 rng(7);
+    const float Ls[] = { 1.0f, 3.0f, 6.5f, 7.25f, 24.18f, 17.097843f, 0.37f, 100.0f };
+    long n = 0, bad = 0;
+    for (float L : Ls) {
+        std::vector<float> ts;
+        for (int m = -2; m <= 3; ++m) {                       // exact multiples and their neighbours
+            float t = (float)m * L;
+            ts.push_back(t);
+            float up = t, dn = t;
+            for (int k = 0; k < 4; ++k) { up = std::nextafterf(up, INFINITY); dn = std::nextafterf(dn, -INFINITY); ts.push_back(up); ts.push_back(dn); }
+        }
+        for (float e : { 1e-9f, 1e-8f, 3e-7f, 1e-6f, 1e-5f, 1e-12f, 1e-30f, 1e-45f }) { ts.push_back(-e); ts.push_back(e); ts.push_back(L - e); ts.push_back(L + e); ts.push_back(-L - e); ts.push_back(-L + e); }
+        std::uniform_real_distribution<float> u(-2.0f * L, 3.0f * L);
+        for (int k = 0; k < 200000; ++k) ts.push_back(u(rng));
+        for (float t : ts) {
+            // the closed forms promise bit-identity with the loops for |k| <= 1; beyond that the loops round once per turn
+            const float want = loop_wrap(t, L), got = gr_wrap_coordinate(t, L);
+            const bool one_turn = t >= -L && t <= 2.0f * L;
+            ++n;
+            if (one_turn ? bits(want) != bits(got) : std::fabs(want - got) > 4e-6f * L) { if (bad++ < 10) printf("wrap L=%g t=%.9g: loop %.9g closed %.9g\n", L, t, want, got); }
+            const float wm = loop_minimg(t, L), gm = fmaf(-gr_minimg_k(t, L, 1.0f / L, L / 2.0f), L, t);
+            const bool one = std::fabs(t) <= 1.5f * L;
+            ++n;
+            if (one ? bits(wm) != bits(gm) : std::fabs(wm - gm) > 4e-6f * L) { if (bad++ < 20) printf("min_image L=%g d=%.9g: loop %.9g closed %.9g\n", L, t, wm, gm); }
+        }
+    }
+    printf("%ld comparisons, %ld mismatches\n", n, bad);
+    return bad ? 1 : 0;
+}

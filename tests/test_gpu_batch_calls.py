@@ -97,3 +97,33 @@ def test_every_frame_is_judged_on_its_own(G):
     with pytest.raises(G.GroupError):
         s.group_get_com_batch("nope", 0, nf)
     s.close()
+
+
+def test_wrap_values_where_rounding_decides(G):
+    """atoms_wrap / atoms_translate against the reference's loops (vector3d.rs:398-417) bit for bit on tiny negatives (the loop's
+    `w += L` rounds to exactly L and stops there: the closed upper end), exact multiples of L and the neighbours of 0 and L"""
+    L = np.array([6.5, 7.25, 3.0], np.float32)
+    box = np.array([L[0], L[1], L[2], 0, 0, 0, 0, 0, 0], np.float32)
+    vals = []
+    for m in (-1, 0, 1, 2):
+        for k in range(-3, 4):
+            t = (np.float32(m) * L).astype(np.float32)
+            for _ in range(abs(k)):
+                t = np.nextafter(t, np.float32(np.inf if k > 0 else -np.inf)).astype(np.float32)
+            vals.append(t)
+    for e in (1e-9, 1e-8, 3e-7, 1e-12, 1e-30, 1e-45):
+        vals += [np.full(3, -e, np.float32), np.full(3, e, np.float32), (L - np.float32(e)).astype(np.float32), (L + np.float32(e)).astype(np.float32)]
+    pos = np.array(vals, np.float32)
+    n = pos.shape[0]
+    s = G.System(n, n_slots=1)
+    s.set_frame(pos, box)
+    s.atoms_wrap()
+    got = s.get_positions()
+    want = O.wrap_atoms(pos, np.arange(n), box)
+    assert np.array_equal(got.view(np.uint32) & 0x7fffffff, want.view(np.uint32) & 0x7fffffff), np.argwhere(got != want)[:5]   # (the sign of a zero is not compared)
+    s.set_frame(pos, box)
+    s.atoms_translate([1e-9, -1e-9, 0.0])
+    got = s.get_positions()
+    want = O.translate(pos, np.arange(n), [1e-9, -1e-9, 0.0], box)
+    assert np.array_equal(got.view(np.uint32) & 0x7fffffff, want.view(np.uint32) & 0x7fffffff)
+    s.close()

@@ -12,3 +12,13 @@ def test_polar_fast_path_agrees_with_kabsch_jacobi():
     p = subprocess.run([os.path.join(d, "test_rotation")], capture_output=True, text=True, timeout=300)
     print(p.stdout, p.stderr)
     assert p.returncode == 0 and "PASS" in p.stdout
+
+
+def test_wrap_and_min_image_closed_forms_equal_the_reference_loops():
+    """gr_math.h's branch-free wrap / min_image against the loops of src/structures/vector3d.rs:398-417,575-592, bit for bit
+    where rounding decides (tiny negatives land exactly on L, exact multiples, neighbours of 0 / L / L/2)"""
+    d = os.path.join(ROOT, "tests", "cpp")
+    subprocess.check_call(["make", "-C", d, "test_wrap"])
+    p = subprocess.run([os.path.join(d, "test_wrap")], capture_output=True, text=True, timeout=300)
+    print(p.stdout, p.stderr)
+    assert p.returncode == 0 and " 0 mismatches" in p.stdout
