@@ -58,6 +58,8 @@ struct gr_ctx {
     hipEvent_t ev_skew[3 * GR_MAX_BATCH] = {};   // skewed order: [3g] sums of group g done, [3g+1] finalize done, [3g+2] fit done
     uint32_t *fuse_cnt = nullptr;     // [2 * GR_MAX_BATCH] arrival counters of the fused finalize / close tails (self-resetting)
     int fuse = 1;                     // GR_FUSE=0: separate k_rmsd_finalize_lite / k_rmsd_close launches
+    uint64_t center_fallbacks = 0;    // frames the one-pass centre handed to the two-pass path (gr_center_fallbacks)
+    uint32_t com_onepass_min = 4096;  // GR_COM_ONEPASS_MIN: contiguous groups of at least this many atoms take the one-pass get_com / get_center (0 = never)
     int skew = 0;                     // GR_SKEW=1: small kernels on the second stream beside the next group's sums pass (measured slower)
     hipEvent_t ev_join = nullptr;           // "all fits done" (stream2 -> stream)
     int overlap = 0;   // GR_OVERLAP=1: +5 % frames/s at 256-frame calls (measured), but per-kernel durations then overlap
@@ -344,23 +346,58 @@ int frame_status(gr_ctx *c, const GrFrameState &st) {
 
 // launch one centre stage (sums + finalize) for `nf` frames starting at first_slot
 int center_stage(gr_ctx *c, uint32_t first_slot, uint32_t nf, const GrSel &sel, int kind, int weighted,
-                 int mass_first, int target) {
+                 int mass_first, int target, int only_status = 0) {
     // batches: a multiple of 8 chunks per frame, so that chunk c of every frame runs on XCD c % 8 and that XCD's L2 keeps its
     // eighth of the masses.  (The RMSD kernels' few, long chunks -- batch_chunks -- are slower here: 3.9 vs 3.1 us per 1e6-atom
     // frame for the naive centre; this kernel's per-atom fp64 chains want many workgroups.)
     uint32_t nch = chunks_for(sel);
     if (nf > 1 && nch >= 8) nch &= ~7u;
-    k_center_sums<<<dim3(nch, nf), dim3(GR_WG), 0, c->stream>>>(c->frames, c->frame_stride, first_slot, c->masses, sel, c->boxes_dev, c->state_dev, kind, weighted, c->cen_partials);
-    k_center_finalize<<<dim3(nf), dim3(GR_WG), 0, c->stream>>>(c->cen_partials, nch, c->boxes_dev, first_slot, kind, weighted, mass_first, target, sel.n, c->state_dev);
+    k_center_sums<<<dim3(nch, nf), dim3(GR_WG), 0, c->stream>>>(c->frames, c->frame_stride, first_slot, c->masses, sel, c->boxes_dev, c->state_dev, kind, weighted, c->cen_partials, only_status);
+    k_center_finalize<<<dim3(nf), dim3(GR_WG), 0, c->stream>>>(c->cen_partials, nch, c->boxes_dev, first_slot, kind, weighted, mass_first, target, sel.n, c->state_dev, only_status);
     HIPCHK(c, hipGetLastError());
     return GR_OK;
 }
 
 // get_center / get_com: unweighted Bai-Breen estimate, then the (weighted) unwrapped mean
-int pbc_center_stages(gr_ctx *c, uint32_t first_slot, uint32_t nf, const GrSel &sel, int weighted) {
-    int st = center_stage(c, first_slot, nf, sel, 1, 0, 0, 0);
+int pbc_center_stages(gr_ctx *c, uint32_t first_slot, uint32_t nf, const GrSel &sel, int weighted, int only_status = 0) {
+    int st = center_stage(c, first_slot, nf, sel, 1, 0, 0, 0, only_status);
     if (st != GR_OK) return st;
-    return center_stage(c, first_slot, nf, sel, 2, weighted, 0, 1);
+    return center_stage(c, first_slot, nf, sel, 2, weighted, 0, 1, only_status);
+}
+
+// get_center / get_com of a large contiguous group in ONE pass over the frame (the sums pass of the RMSD path without a
+// reference: images about the group's first atom, image proof, centre placed in the reference's periodic copy) instead of
+// estimate + unwrapped mean.  Frames whose proof fails come back GR_ST_FALLBACK in state_dev; center_redo_fallbacks reruns
+// those on the two-pass path.  The states must have been initialised (status 0 or the frame's host-side error).
+static bool center_onepass_ok(const gr_ctx *c, const GrSel &sel) {
+    return c->com_onepass_min != 0 && sel.contiguous && sel.n >= c->com_onepass_min && c->two_pass;
+}
+static int pbc_center_onepass(gr_ctx *c, uint32_t s0, uint32_t nb, const GrSel &sel, int weighted) {
+    GrPlanDev plan; memset(&plan, 0, sizeof plan);
+    plan.w_is_mass = weighted ? 1u : 0u;   // NOREF: "weighted"
+    plan.n = sel.n; plan.sw = 1.0;
+    const uint32_t nch = batch_chunks(c, sel, nb);
+    if (c->fuse) {
+        k_rmsd_accum<0, true, true><<<dim3(nch, nb), dim3(GR_WG), 0, c->stream>>>(c->frames, c->frame_stride, s0, c->masses, sel, c->boxes_dev, plan, c->state_dev, c->acc_partials, c->fuse_cnt, c->state_dev);
+    } else {
+        k_rmsd_accum<0, true, true><<<dim3(nch, nb), dim3(GR_WG), 0, c->stream>>>(c->frames, c->frame_stride, s0, c->masses, sel, c->boxes_dev, plan, c->state_dev, c->acc_partials);
+        k_rmsd_finalize_lite<true><<<dim3(nb), dim3(64), 0, c->stream>>>(c->acc_partials, nch, c->frames, c->frame_stride, s0, sel, c->boxes_dev, plan, c->state_dev);
+    }
+    HIPCHK(c, hipGetLastError());
+    return GR_OK;
+}
+// state_host[0..nb) has been fetched: when some frames are flagged GR_ST_FALLBACK the two dependent passes run over the
+// whole batch, masked to those frames (the other frames' workgroups leave at once), and the states are fetched again
+static int center_redo_fallbacks(gr_ctx *c, uint32_t s0, uint32_t nb, const GrSel &sel, int weighted, std::vector<GrFrameState> &res) {
+    uint32_t n_fb = 0;
+    for (uint32_t f = 0; f < nb; ++f) n_fb += c->state_host[f].status == GR_ST_FALLBACK;
+    if (n_fb) {
+        c->center_fallbacks += n_fb;
+        int st = pbc_center_stages(c, s0, nb, sel, weighted, GR_ST_FALLBACK); if (st) return st;
+        st = fetch_states(c, nb); if (st) return st;
+    }
+    res.assign(c->state_host, c->state_host + nb);
+    return GR_OK;
 }
 
 }  // namespace
@@ -444,6 +481,7 @@ gr_ctx *gr_ctx_create(int device, uint64_t n_atoms, uint32_t n_slots, int *statu
     ok = ok && hipHostMalloc(&c->bad_host, 4 * GR_MAX_BATCH * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess;
     ok = ok && hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess;
 
+    if (const char *e = getenv("GR_COM_ONEPASS_MIN")) { long v = atol(e); if (v >= 0) c->com_onepass_min = (uint32_t)std::min<long>(v, 0x7fffffffL); }
     if (const char *e = getenv("GR_FIT_SUB")) { int v = atoi(e); if (v >= 0 && v <= GR_MAX_BATCH) c->fit_sub = (uint32_t)v; }
     if (const char *e = getenv("GR_SUB_BATCH")) { int v = atoi(e); if (v >= 1 && v <= GR_MAX_BATCH) c->sub_batch = (uint32_t)v; }
     if (const char *e = getenv("GR_CHUNKS")) { int v = atoi(e); if (v >= 1 && v <= GR_MAX_CHUNKS) c->chunks = (uint32_t)v; }
@@ -668,10 +706,14 @@ int gr_group_center(gr_ctx *c, uint32_t slot, const char *group, int kind, int w
     st = state_reset(c, 1); if (st) return st;
     if (kind == GR_CENTER_NAIVE) st = center_stage(c, slot, 1, sel, 0, weighted, 0, 1);          // position first (:946-958)
     else if (kind == GR_CENTER_ESTIMATE) st = center_stage(c, slot, 1, sel, 1, weighted, 1, 1);  // mass first (:1324-1339)
-    else if (kind == GR_CENTER_PBC) st = pbc_center_stages(c, slot, 1, sel, weighted);
+    else if (kind == GR_CENTER_PBC) st = center_onepass_ok(c, sel) ? pbc_center_onepass(c, slot, 1, sel, weighted) : pbc_center_stages(c, slot, 1, sel, weighted);
     else return fail(c, GR_E_INVALID_ARG, "unknown centre kind");
     if (st) return st;
     st = fetch_states(c, 1); if (st) return st;
+    if (c->state_host[0].status == GR_ST_FALLBACK) {
+        std::vector<GrFrameState> res;
+        st = center_redo_fallbacks(c, slot, 1, sel, weighted, res); if (st) return st;
+    }
     st = frame_status(c, c->state_host[0]); if (st) return st;
     if (out) { out[0] = c->state_host[0].com[0]; out[1] = c->state_host[0].com[1]; out[2] = c->state_host[0].com[2]; }
     return GR_OK;
@@ -1063,16 +1105,18 @@ int gr_group_center_batch(gr_ctx *c, uint32_t first_slot, uint32_t n_frames, con
         HIPCHK(c, hipMemcpyAsync(c->state_dev, c->state_host, nb * sizeof(GrFrameState), hipMemcpyHostToDevice, c->stream));
         if (kind == GR_CENTER_NAIVE) st = center_stage(c, s0, nb, sel, 0, weighted, 0, 1);
         else if (kind == GR_CENTER_ESTIMATE) st = center_stage(c, s0, nb, sel, 1, weighted, 1, 1);
-        else st = pbc_center_stages(c, s0, nb, sel, weighted);
+        else st = center_onepass_ok(c, sel) ? pbc_center_onepass(c, s0, nb, sel, weighted) : pbc_center_stages(c, s0, nb, sel, weighted);
         if (st) return st;
         st = fetch_states(c, nb); if (st) return st;
+        std::vector<GrFrameState> res;
+        st = center_redo_fallbacks(c, s0, nb, sel, weighted, res); if (st) return st;   // (nothing to do unless the one-pass proof failed somewhere)
         for (uint32_t f = 0; f < nb; ++f) {
             int s = pre[f];
             if (s != GR_OK) c->err = msg[f];
-            else s = frame_status(c, c->state_host[f]);
+            else s = frame_status(c, res[f]);
             if (s != GR_OK && first_err == GR_OK) { first_err = s; first_msg = c->err; first_idx = c->err_index; }
             if (status_out) status_out[b0 + f] = s;
-            if (out) for (int k = 0; k < 3; ++k) out[3 * (size_t)(b0 + f) + k] = (s == GR_OK) ? c->state_host[f].com[k] : NAN;
+            if (out) for (int k = 0; k < 3; ++k) out[3 * (size_t)(b0 + f) + k] = (s == GR_OK) ? res[f].com[k] : NAN;
         }
     }
     if (first_err != GR_OK) { c->err = first_msg; c->err_index = first_idx; }
@@ -1203,6 +1247,8 @@ gr_rmsd_plan *gr_rmsd_plan_create(gr_ctx *ref, uint32_t ref_slot, gr_ctx *target
 
 uint32_t gr_rmsd_plan_last_fallbacks(const gr_rmsd_plan *p) { return p ? p->last_fallbacks : 0; }
 int gr_rmsd_plan_force_exact(gr_rmsd_plan *p, int on) { if (!p) return GR_E_INVALID_ARG; p->exact = on ? 1 : 0; return GR_OK; }
+int gr_ctx_set_center_onepass_min(gr_ctx *c, uint32_t min_atoms) { if (!c) return GR_E_INVALID_ARG; c->com_onepass_min = min_atoms; return GR_OK; }
+uint64_t gr_center_fallbacks(const gr_ctx *c) { return c ? c->center_fallbacks : 0; }
 int gr_ctx_set_persistent(gr_ctx *c, int mode) { if (!c || mode < 0 || mode > 2) return GR_E_INVALID_ARG; c->persist = mode; return GR_OK; }
 int gr_rmsd_plan_last_persistent(const gr_rmsd_plan *p) { return p && p->last_persist ? 1 : 0; }
 
@@ -1326,7 +1372,7 @@ static int segment_begin(gr_rmsd_plan *p, uint32_t s0, uint32_t nb, int fit) {
             const uint32_t f0 = g * sb, nf = group_nf(g), nch = batch_chunks(c, sel, nf);
             GrAccPartial *parts = c->acc_partials + (size_t)f0 * GR_MAX_CHUNKS;
             if (c->profile) EVREC(c, c->pev[6 * g + 2], true, on);
-            if (lite) k_rmsd_finalize_lite<<<dim3(nf), dim3(64), 0, on>>>(parts, nch, c->frames, c->frame_stride, s0 + f0, sel, c->boxes_dev, p->dev, c->state_dev + f0);
+            if (lite) k_rmsd_finalize_lite<false><<<dim3(nf), dim3(64), 0, on>>>(parts, nch, c->frames, c->frame_stride, s0 + f0, sel, c->boxes_dev, p->dev, c->state_dev + f0);
             else k_rmsd_finalize<0><<<dim3(nf), dim3(GR_WG), 0, on>>>(parts, nch, c->frames, c->frame_stride, s0 + f0, sel, c->boxes_dev, p->dev, c->state_dev + f0);
             if (c->profile) EVREC(c, c->pev[6 * g + 3], true, on);
             return GR_OK;

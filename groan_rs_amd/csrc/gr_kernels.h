@@ -263,12 +263,15 @@ struct GrCenPartial { double s[GR_CEN_K]; uint32_t bad_pos, bad_mass; };
 __global__ __launch_bounds__(GR_WG) void k_center_sums(
     const float *__restrict__ frames, size_t frame_stride, uint32_t first_slot,
     const float *__restrict__ masses, GrSel sel, const GrBox *__restrict__ boxes,
-    const GrFrameState *__restrict__ state, int kind, int weighted, GrCenPartial *__restrict__ partials) {
+    const GrFrameState *__restrict__ state, int kind, int weighted, GrCenPartial *__restrict__ partials, int only_status = 0) {
     __shared__ GrBox box;
     __shared__ double lds[(GR_WG / 64) * GR_CEN_K];
     __shared__ uint32_t ldsu[GR_WG / 64];
     __shared__ float4 tiles[(GR_WG / 64) * GR_TILE_F4];
     const uint32_t frame = blockIdx.y, chunk = blockIdx.x, nchunks = gridDim.x;
+    // only_status: a launch over a whole batch that works on the frames carrying this status only (the frames the one-pass
+    // centre handed back, GR_ST_FALLBACK); the workgroups of every other frame leave at once
+    if (only_status && state[frame].status != only_status) return;
     const float *xyz = frames + (size_t)(first_slot + frame) * frame_stride;
     gr_stage_box(&box, boxes + first_slot + frame);
     double acc[GR_CEN_K];
@@ -320,10 +323,11 @@ __global__ __launch_bounds__(GR_WG) void k_center_sums(
 __global__ __launch_bounds__(GR_WG) void k_center_finalize(
     const GrCenPartial *__restrict__ partials, uint32_t nchunks, const GrBox *__restrict__ boxes,
     uint32_t first_slot, int kind, int weighted, int mass_first, int target, uint32_t n_sel,
-    GrFrameState *__restrict__ state) {
+    GrFrameState *__restrict__ state, int only_status = 0) {
     __shared__ double lds[(GR_WG / 64) * GR_CEN_K];
     __shared__ uint32_t ldsu[GR_WG / 64];
     const uint32_t frame = blockIdx.x;
+    if (only_status && state[frame].status != only_status) return;
     double acc[GR_CEN_K];
 #pragma unroll
     for (int k = 0; k < GR_CEN_K; ++k) acc[k] = 0.0;
@@ -339,7 +343,7 @@ __global__ __launch_bounds__(GR_WG) void k_center_finalize(
     bad_mass = gr_block_min_u32(bad_mass, ldsu);
     if (threadIdx.x != 0) return;
     GrFrameState &st = state[frame];
-    if (st.status != 0) return;   // an earlier stage of this frame already failed
+    if (st.status != only_status) return;   // an earlier stage of this frame already failed
     const GrBox &b = boxes[first_slot + frame];
     // error precedence of the reference loops: estimate_com / get_com_naive test per atom
     // (mass first: iterators.rs:1324-1339; position first: :946-958); get_com runs the unweighted
@@ -372,6 +376,7 @@ __global__ __launch_bounds__(GR_WG) void k_center_finalize(
     else {
         st.com[0] = r[0]; st.com[1] = r[1]; st.com[2] = r[2];
         st.shift[0] = b.bcx - r[0]; st.shift[1] = b.bcy - r[1]; st.shift[2] = b.bcz - r[2];
+        if (only_status) st.status = 0;   // the frame's last stage: done
     }
 }
 
@@ -551,6 +556,7 @@ __device__ __forceinline__ void gr_unpack4(GrA4 &q, const float4 &a, const float
 #ifndef GR_ACC_MIN_WAVES
 #define GR_ACC_MIN_WAVES 1
 #endif
+template <bool NOREF = false>
 __device__ __forceinline__ void gr_finalize_frame_lite(const GrAccPartial *partials, uint32_t nchunks, uint32_t frame, const float *frames, size_t frame_stride,
                                                        uint32_t first_slot, const GrSel &sel, const GrBox *boxes, const GrPlanDev &plan, GrFrameState *state,
                                                        double *tot, float *ext, uint32_t lane);
@@ -562,7 +568,10 @@ template <typename T> __device__ __forceinline__ void gr_st_agent(T *p, T v) { _
 // closes the frame itself (gr_finalize_frame_lite) -- no separate finalize launch, no idle chip between the two passes.
 // Non-blocking: nobody waits; records are written with agent-scope stores and drained before the counter is bumped, the
 // closing wave invalidates its L2 view (acquire fence) before it reads them.
-template <int MODE, bool LITE = false>
+// NOREF (with MODE 0, LITE): the centre-of-mass use of this pass (group_get_com / group_get_center in ONE pass instead of
+// estimate + unwrapped mean): no reference coordinates are read (A stays zero), plan.w_is_mass = 0 counts every atom once,
+// and the closing step stops after the image proof and places the centre in the reference's periodic copy.
+template <int MODE, bool LITE = false, bool NOREF = false>
 __global__ __launch_bounds__(GR_WG, GR_ACC_MIN_WAVES) void k_rmsd_accum(
     const float *__restrict__ frames, size_t frame_stride, uint32_t first_slot,
     const float *__restrict__ masses, GrSel sel, const GrBox *__restrict__ boxes,
@@ -616,8 +625,9 @@ __global__ __launch_bounds__(GR_WG, GR_ACC_MIN_WAVES) void k_rmsd_accum(
                 a = f4[3 * (size_t)g]; b = f4[3 * (size_t)g + 1]; c = f4[3 * (size_t)g + 2];
             }
             const size_t pg = (size_t)(g - g0);
-            const float4 pa = p4[3 * pg], pb = p4[3 * pg + 1], pc = p4[3 * pg + 2];
-            const float4 mm = m4[g];
+            const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 pa = NOREF ? zero4 : p4[3 * pg], pb = NOREF ? zero4 : p4[3 * pg + 1], pc = NOREF ? zero4 : p4[3 * pg + 2];
+            const float4 mm = (NOREF && !wm) ? make_float4(1.f, 1.f, 1.f, 1.f) : m4[g];
             const float4 ww = (wm || LITE) ? mm : w4[pg];
             const uint32_t i = g << 2;
             GrA4 q;
@@ -689,7 +699,7 @@ __global__ __launch_bounds__(GR_WG, GR_ACC_MIN_WAVES) void k_rmsd_accum(
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                     double *tot = lds;                                        // wsum (same LDS) has been consumed by this wave
                     float *ext = reinterpret_cast<float *>(lds + 32);
-                    gr_finalize_frame_lite(partials, nchunks, frame, frames, frame_stride, first_slot, sel, boxes, plan, state_out, tot, ext, lane);
+                    gr_finalize_frame_lite<NOREF>(partials, nchunks, frame, frames, frame_stride, first_slot, sel, boxes, plan, state_out, tot, ext, lane);
                     if (lane == 0) fuse[frame] = 0u;
                 }
             }
@@ -725,7 +735,7 @@ __global__ __launch_bounds__(GR_WG, GR_ACC_MIN_WAVES) void k_rmsd_accum(
 // (wherever in its rigorously bounded region it is) and the COM; otherwise the frame is flagged GR_ST_FALLBACK
 // and redone by the multi-pass path.
 // Closing algebra of the single pass for one frame (one lane).  `st` receives centre / com / shift / R / rmsd / status.
-template <int MODE, bool LITE = false>
+template <int MODE, bool LITE = false, bool NOREF = false>
 __device__ inline void gr_finalize_math(const double *acc, const float mn[3], const float mx[3], const float fmn[3], const float fmx[3],
                                         uint32_t bad_pos, uint32_t bad_mass, const GrBox &b, const GrPlanDev &plan,
                                         const double g[3], uint32_t n_sel, GrFrameState &st) {
@@ -788,6 +798,24 @@ __device__ inline void gr_finalize_math(const double *acc, const float mn[3], co
             }
         }
         if (!ok) { st.status = GR_ST_FALLBACK; return; }
+        if (NOREF) {
+            // get_center / get_com (iterators.rs:1237-1266,1404-1438) unwrap the group about c' = the Bai-Breen estimate, which
+            // lies in the cell: the reference's copy of the group is the one whose mean fractional coordinate mu lies in
+            // [0, 1) -- c' is within eps of it.  With mu closer than that to a cell face the copy depends on where exactly
+            // c' fell: those frames take the two-pass path.
+            const double gfc = g[2] / (double)b.cz, guy = g[1] - gfc * (double)b.cy, gfb = guy / (double)b.by,
+                         gfa = (g[0] - gfb * (double)b.bx - gfc * (double)b.cx) / (double)b.ax;
+            const double gf[3] = { gfa, gfb, gfc };
+            double nl[3];
+            for (int a = 0; a < 3; ++a) {
+                const double m = gf[a] + mu[a], fl = floor(m), fr = m - fl, guard = eps[a] + 1.0e-4;
+                if (!(fr > guard && fr < 1.0 - guard)) { st.status = GR_ST_FALLBACK; return; }
+                nl[a] = -fl;
+            }
+            const double lat[3] = { nl[0] * b.ax + nl[1] * b.bx + nl[2] * b.cx, nl[1] * b.by + nl[2] * b.cy, nl[2] * b.cz };
+            for (int a = 0; a < 3; ++a) { st.center[a] = (float)(g[a] + ce[a] + lat[a]); st.com[a] = (float)(g[a] + cv[a] + lat[a]); }
+            return;
+        }
         st.center[0] = (float)(g[0] + ce[0]); st.center[1] = (float)(g[1] + ce[1]); st.center[2] = (float)(g[2] + ce[2]);
         const float com[3] = { (float)(g[0] + cv[0]), (float)(g[1] + cv[1]), (float)(g[2] + cv[2]) };
         st.com[0] = com[0]; st.com[1] = com[1]; st.com[2] = com[2];
@@ -857,6 +885,7 @@ __global__ __launch_bounds__(GR_WG) void k_rmsd_finalize(
 // The same for the two-pass sums records, ONE WAVE per frame and no barrier: lane c sums the records c, c + 64, ..., a
 // reduce-scatter leaves the 19 totals / 12 extents spread over the lanes, LDS hands them to lane 0.
 // (tot: 32 doubles, ext: 16 floats of LDS owned by the calling wave)
+template <bool NOREF>
 __device__ __forceinline__ void gr_finalize_frame_lite(const GrAccPartial *partials, uint32_t nchunks, uint32_t frame, const float *frames, size_t frame_stride,
                                                        uint32_t first_slot, const GrSel &sel, const GrBox *boxes, const GrPlanDev &plan, GrFrameState *state,
                                                        double *tot, float *ext, uint32_t lane) {
@@ -897,16 +926,17 @@ __device__ __forceinline__ void gr_finalize_frame_lite(const GrAccPartial *parti
     const float *xyz = frames + (size_t)(first_slot + frame) * frame_stride;
     const uint32_t i0 = sel.contiguous ? sel.start : sel.idx[0];
     const double g[3] = { xyz[3 * (size_t)i0], xyz[3 * (size_t)i0 + 1], xyz[3 * (size_t)i0 + 2] };
-    gr_finalize_math<0, true>(acc, mn, mx, fmn, fmx, bad_pos, bad_mass, boxes[first_slot + frame], plan, g, sel.n, st);
+    gr_finalize_math<0, true, NOREF>(acc, mn, mx, fmn, fmx, bad_pos, bad_mass, boxes[first_slot + frame], plan, g, sel.n, st);
 }
 
+template <bool NOREF = false>
 __global__ __launch_bounds__(64) void k_rmsd_finalize_lite(
     const GrAccPartial *__restrict__ partials, uint32_t nchunks,
     const float *__restrict__ frames, size_t frame_stride, uint32_t first_slot, GrSel sel,
     const GrBox *__restrict__ boxes, GrPlanDev plan, GrFrameState *__restrict__ state) {
     __shared__ double tot[32];
     __shared__ float ext[16];
-    gr_finalize_frame_lite(partials, nchunks, blockIdx.x, frames, frame_stride, first_slot, sel, boxes, plan, state, tot, ext, threadIdx.x);
+    gr_finalize_frame_lite<NOREF>(partials, nchunks, blockIdx.x, frames, frame_stride, first_slot, sel, boxes, plan, state, tot, ext, threadIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------ fit (all atoms)

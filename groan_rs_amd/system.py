@@ -251,6 +251,14 @@ class System:
         """RMSD-fit batches as one persistent LDS-resident kernel: 0 never, 1 where it pays, 2 whenever possible"""
         self._lib.gr_ctx_set_persistent(self._ctx, int(mode))
 
+    def set_center_onepass_min(self, min_atoms):
+        """get_center / get_com of contiguous groups of at least `min_atoms` atoms in one pass (0 = always two passes)"""
+        self._lib.gr_ctx_set_center_onepass_min(self._ctx, int(min_atoms))
+
+    def center_fallbacks(self):
+        """frames the one-pass centre handed to the two-pass path so far"""
+        return int(self._lib.gr_center_fallbacks(self._ctx))
+
     def set_strict_orthogonal(self, on=True):
         """reproduce the reference's SimBoxError::NotOrthogonal for non-orthogonal boxes"""
         self._strict_flag = bool(on)

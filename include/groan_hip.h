@@ -141,6 +141,14 @@ void gr_host_free(void *p);
  * iterators.rs:886-967,1152-1191,1237-1266,1314-1357,1404-1438.
  * Check order as in the reference: group exists -> non-empty -> box -> positions/masses. */
 int gr_group_center(gr_ctx *ctx, uint32_t slot, const char *group, int kind, int weighted, float out[3]);
+/* GR_CENTER_PBC (get_center / get_com) of a contiguous group of at least `min_atoms` atoms is computed in ONE pass over the
+ * frame instead of the reference's two dependent ones (Bai-Breen estimate, then the unwrapped mean): images about the
+ * group's first atom + a proof that they are the images the reference would unwrap to; frames where the proof fails
+ * (groups wider than half a box, a centre within ~1e-4 of a cell face) are recomputed with the two passes.
+ * min_atoms = 0 switches the one-pass path off; default 4096 (env GR_COM_ONEPASS_MIN).  gr_center_fallbacks counts the
+ * frames that were recomputed since the context was created. */
+int gr_ctx_set_center_onepass_min(gr_ctx *ctx, uint32_t min_atoms);
+uint64_t gr_center_fallbacks(const gr_ctx *ctx);
 
 /* ---------------------------------------------------------------- distances
  * System::group_distance analysis.rs:348-360; atoms_distance :459-471; group_all_distances :401-427
