@@ -260,6 +260,24 @@ __device__ __forceinline__ void gr_for_each_atom(const GrSel &sel, const float *
 #define GR_CEN_K 8
 struct GrCenPartial { double s[GR_CEN_K]; uint32_t bad_pos, bad_mass; };
 
+// sine and cosine of an f32 angle in [0, 2 pi] (any |theta| < ~1e3 works): q = nearest multiple of pi/2, Cody-Waite
+// reduction with pi/2 split in two f32 (q <= 4: q * hi is exact), |r| <= pi/4, Taylor polynomials to r^9 / r^10 (truncation
+// < 2e-9), then the quarter-turn symmetries.  Within ~1e-7 of the correctly rounded values, like libm's sincosf.
+__device__ __forceinline__ void gr_sincos_2pi(float theta, float &s, float &c) {
+    const float q = rintf(theta * 0.636619772367581343f);
+    float t = fmaf(-q, 1.57079637050628662109375f, theta);
+    t = fmaf(q, 4.37113900018624283e-8f, t);            // pi/2 = hi - 4.3711e-8
+    const float t2 = t * t;
+    float sp = fmaf(t2, 2.7557319e-6f, -1.9841270e-4f); sp = fmaf(sp, t2, 8.3333333e-3f); sp = fmaf(sp, t2, -1.6666667e-1f);
+    const float sn = fmaf(t * t2, sp, t);
+    float cp = fmaf(t2, -2.7557319e-7f, 2.4801587e-5f); cp = fmaf(cp, t2, -1.3888889e-3f); cp = fmaf(cp, t2, 4.1666667e-2f); cp = fmaf(cp, t2, -0.5f);
+    const float cs = fmaf(t2, cp, 1.0f);
+    const int qi = (int)q & 3;
+    const float a = (qi & 1) ? cs : sn, b = (qi & 1) ? sn : cs;
+    s = (qi & 2) ? -a : a;
+    c = ((qi + 1) & 2) ? -b : b;
+}
+
 __global__ __launch_bounds__(GR_WG) void k_center_sums(
     const float *__restrict__ frames, size_t frame_stride, uint32_t first_slot,
     const float *__restrict__ masses, GrSel sel, const GrBox *__restrict__ boxes,
@@ -296,8 +314,11 @@ __global__ __launch_bounds__(GR_WG) void k_center_sums(
                 const float ux = x - (uy / box.by) * box.bx - sc * box.cx;
                 x = ux; y = uy;
             }
+            // the reference's own f32 angle theta = wrap(x) * (2 pi / L) (auxiliary.rs:59-84), bit for bit -- for a group spread
+            // over the whole box the resultant is short and the estimate amplifies every 1e-7 in theta -- but its sine and
+            // cosine by quarter-turn reduction + two short polynomials instead of libm's sincosf (the pass was VALU-bound)
             float s0, c0, s1, c1, s2, c2;
-            sincosf(x * scx, &s0, &c0); sincosf(y * scy, &s1, &c1); sincosf(z * scz, &s2, &c2);
+            gr_sincos_2pi(x * scx, s0, c0); gr_sincos_2pi(y * scy, s1, c1); gr_sincos_2pi(z * scz, s2, c2);
             acc[0] += (double)(m * c0); acc[1] += (double)(m * c1); acc[2] += (double)(m * c2);
             acc[3] += (double)(m * s0); acc[4] += (double)(m * s1); acc[5] += (double)(m * s2);
             acc[6] += 1.0;
