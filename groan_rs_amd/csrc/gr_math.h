@@ -57,8 +57,10 @@ struct GrBox {
 //   min_image: `while d > L/2: d -= L; while d < -L/2: d += L` (vector3d.rs:575-592): result in [-L/2, L/2].
 // k is first estimated with the reciprocal of L and then corrected by comparing the actual remainder, so the
 // returned k always puts the result in range whatever the rounding of the estimate.  For |k| <= 1 the result
-// t - k L is bit-identical to the reference's loop; beyond that it differs from the repeated f32 subtraction by
-// an ulp.  No loop and no divide: a far-away coordinate cannot stall or diverge a wavefront.
+// t - k L is bit-identical to the reference's loop.  Beyond one turn the loop rounds once per turn: gr_wrap_value /
+// gr_minimg_value then RUN the loop for up to GR_LOOP_TURNS turns (bit-identical again) and keep the closed form only for
+// coordinates farther away than that (an ulp from the reference's value) -- a far-away, infinite or NaN coordinate cannot
+// stall a wavefront.
 GR_HD float gr_wrap_k(float t, float L, float iL) {
     float k = floorf(t * iL);
     float r = fmaf(-k, L, t);
@@ -71,7 +73,16 @@ GR_HD float gr_wrap_k(float t, float L, float iL) {
     k -= (r == 0.0f && t > 0.0f) ? 1.0f : 0.0f;
     return k;
 }
-GR_HD float gr_wrap_coordinate(float coor, float L) { return fmaf(-gr_wrap_k(coor, L, 1.0f / L), L, coor); }
+#define GR_LOOP_TURNS 16
+GR_HD float gr_wrap_value(float t, float L, float iL) {
+    const float k = gr_wrap_k(t, L, iL);
+    if (fabsf(k) <= 1.0f || !(fabsf(k) <= (float)GR_LOOP_TURNS)) return fmaf(-k, L, t);
+    float w = t;
+    for (int it = 0; it < GR_LOOP_TURNS + 2 && w > L; ++it) w -= L;
+    for (int it = 0; it < GR_LOOP_TURNS + 2 && w < 0.0f; ++it) w += L;
+    return w;
+}
+GR_HD float gr_wrap_coordinate(float coor, float L) { return gr_wrap_value(coor, L, 1.0f / L); }
 
 GR_HD float gr_minimg_k(float d, float L, float iL, float h) {
     float k = rintf(d * iL);
@@ -80,10 +91,17 @@ GR_HD float gr_minimg_k(float d, float L, float iL, float h) {
     k += (r < -h) ? -1.0f : 0.0f;
     return k;
 }
+GR_HD float gr_minimg_value(float d, float L, float iL, float h) {
+    const float k = gr_minimg_k(d, L, iL, h);
+    if (fabsf(k) <= 1.0f || !(fabsf(k) <= (float)GR_LOOP_TURNS)) return fmaf(-k, L, d);
+    float w = d;
+    for (int it = 0; it < GR_LOOP_TURNS + 2 && w > h; ++it) w -= L;
+    for (int it = 0; it < GR_LOOP_TURNS + 2 && w < -h; ++it) w += L;
+    return w;
+}
 GR_HD float gr_min_image(float dx, float L) {
-    const float h = L / 2.0f;
     // d exactly +-h must stay (the loops use strict comparisons): rint(+-0.5) = 0 keeps it
-    return fmaf(-gr_minimg_k(dx, L, 1.0f / L, h), L, dx);
+    return gr_minimg_value(dx, L, 1.0f / L, L / 2.0f);
 }
 
 GR_HD float gr_floor_mod(float x, float y) { return fmodf(fmodf(x, y) + y, y); }
@@ -128,9 +146,9 @@ GR_HD float gr_tric_refine_r2(float dx, float dy, float dz, const GrBox &b) {
 // wrap a position into the unit cell
 GR_HD void gr_wrap(float &x, float &y, float &z, const GrBox &b) {
     if (b.ortho) {
-        x = fmaf(-gr_wrap_k(x, b.ax, b.iax), b.ax, x);
-        y = fmaf(-gr_wrap_k(y, b.by, b.iby), b.by, y);
-        z = fmaf(-gr_wrap_k(z, b.cz, b.icz), b.cz, z);
+        x = gr_wrap_value(x, b.ax, b.iax);
+        y = gr_wrap_value(y, b.by, b.iby);
+        z = gr_wrap_value(z, b.cz, b.icz);
         return;
     }
     // along c, then b, then a
@@ -145,9 +163,9 @@ GR_HD void gr_wrap(float &x, float &y, float &z, const GrBox &b) {
 // minimum-image displacement (in place)
 GR_HD void gr_min_image_vec(float &dx, float &dy, float &dz, const GrBox &b) {
     if (b.ortho) {
-        dx = fmaf(-gr_minimg_k(dx, b.ax, b.iax, b.ax / 2.0f), b.ax, dx);
-        dy = fmaf(-gr_minimg_k(dy, b.by, b.iby, b.by / 2.0f), b.by, dy);
-        dz = fmaf(-gr_minimg_k(dz, b.cz, b.icz, b.cz / 2.0f), b.cz, dz);
+        dx = gr_minimg_value(dx, b.ax, b.iax, b.ax / 2.0f);
+        dy = gr_minimg_value(dy, b.by, b.iby, b.by / 2.0f);
+        dz = gr_minimg_value(dz, b.cz, b.icz, b.cz / 2.0f);
         return;
     }
     float k = gr_minimg_k(dz, b.cz, b.icz, b.cz / 2.0f);
@@ -210,9 +228,9 @@ GR_HD float gr_distance(float ax_, float ay_, float az_, float px, float py, flo
     float dx = ax_ - px, dy = ay_ - py, dz = az_ - pz;
     if (b.ortho) {
         // only the requested components are min-imaged, exactly as vector3d.rs:458-486
-        const float mx = fmaf(-gr_minimg_k(dx, b.ax, b.iax, b.ax / 2.0f), b.ax, dx);
-        const float my = fmaf(-gr_minimg_k(dy, b.by, b.iby, b.by / 2.0f), b.by, dy);
-        const float mz = fmaf(-gr_minimg_k(dz, b.cz, b.icz, b.cz / 2.0f), b.cz, dz);
+        const float mx = gr_minimg_value(dx, b.ax, b.iax, b.ax / 2.0f);
+        const float my = gr_minimg_value(dy, b.by, b.iby, b.by / 2.0f);
+        const float mz = gr_minimg_value(dz, b.cz, b.icz, b.cz / 2.0f);
         switch (dim) {
         case 1: return mx;
         case 2: return my;

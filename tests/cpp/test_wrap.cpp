@@ -27,18 +27,23 @@ int main() {
             for (int k = 0; k < 4; ++k) { up = std::nextafterf(up, INFINITY); dn = std::nextafterf(dn, -INFINITY); ts.push_back(up); ts.push_back(dn); }
         }
         for (float e : { 1e-9f, 1e-8f, 3e-7f, 1e-6f, 1e-5f, 1e-12f, 1e-30f, 1e-45f }) { ts.push_back(-e); ts.push_back(e); ts.push_back(L - e); ts.push_back(L + e); ts.push_back(-L - e); ts.push_back(-L + e); }
-        std::uniform_real_distribution<float> u(-2.0f * L, 3.0f * L);
+        std::uniform_real_distribution<float> u(-2.0f * L, 3.0f * L), far(-15.0f * L, 16.0f * L), beyond(-300.0f * L, 300.0f * L);
         for (int k = 0; k < 200000; ++k) ts.push_back(u(rng));
+        for (int k = 0; k < 100000; ++k) ts.push_back(far(rng));
+        for (int k = 0; k < 20000; ++k) ts.push_back(beyond(rng));
+        for (int m = -16; m <= 17; ++m) { ts.push_back((float)m * L); ts.push_back(std::nextafterf((float)m * L, INFINITY)); ts.push_back(std::nextafterf((float)m * L, -INFINITY)); ts.push_back(((float)m + 0.5f) * L); }
         for (float t : ts) {
-            // the closed forms promise bit-identity with the loops for |k| <= 1; beyond that the loops round once per turn
+            // bit-identity with the loops up to GR_LOOP_TURNS turns (one turn: closed form; more: the loop itself); farther away the
+            // closed form is an ulp-scale approximation of the loop's repeated rounding
             const float want = loop_wrap(t, L), got = gr_wrap_coordinate(t, L);
-            const bool one_turn = t >= -L && t <= 2.0f * L;
+            const bool one_turn = std::fabs(t) <= 15.0f * L;
             ++n;
-            if (one_turn ? bits(want) != bits(got) : std::fabs(want - got) > 4e-6f * L) { if (bad++ < 10) printf("wrap L=%g t=%.9g: loop %.9g closed %.9g\n", L, t, want, got); }
-            const float wm = loop_minimg(t, L), gm = fmaf(-gr_minimg_k(t, L, 1.0f / L, L / 2.0f), L, t);
-            const bool one = std::fabs(t) <= 1.5f * L;
+            const float tol = 1.2e-7f * std::fabs(t) * (std::fabs(t) / L + 2.0f);   // the loop's own drift: an ulp of t per turn (and either end of the cell)
+            if (one_turn ? bits(want) != bits(got) : (std::fabs(want - got) > tol && std::fabs(std::fabs(want - got) - L) > tol)) { if (bad++ < 10) printf("wrap L=%g t=%.9g: loop %.9g closed %.9g\n", L, t, want, got); }
+            const float wm = loop_minimg(t, L), gm = gr_min_image(t, L);
+            const bool one = std::fabs(t) <= 15.0f * L;
             ++n;
-            if (one ? bits(wm) != bits(gm) : std::fabs(wm - gm) > 4e-6f * L) { if (bad++ < 20) printf("min_image L=%g d=%.9g: loop %.9g closed %.9g\n", L, t, wm, gm); }
+            if (one ? bits(wm) != bits(gm) : (std::fabs(wm - gm) > tol && std::fabs(std::fabs(wm - gm) - L) > tol)) { if (bad++ < 20) printf("min_image L=%g d=%.9g: loop %.9g closed %.9g\n", L, t, wm, gm); }
         }
     }
     printf("%ld comparisons, %ld mismatches\n", n, bad);

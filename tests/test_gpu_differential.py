@@ -1,0 +1,131 @@
+"""Differential test of the GPU path against the oracle on ADVERSARIAL inputs: coordinates exactly on cell faces and half-box
+separations, one ulp either side of them, tiny negatives, atoms several boxes away, one- to three-atom groups, coincident
+atoms, very small and very flat boxes.  Every case is generated from a seed; the operations are the reference's
+wrap / translate (bit-exact; vector3d.rs:380-417, iterators.rs:1520-1553), centres (iterators.rs:886-1438), distances
+(analysis.rs:348-471, vector3d.rs:458-486) and calc_rmsd(_and_fit) (rmsd.rs:75-166)."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+DIMS = ["X", "Y", "Z", "XY", "XZ", "YZ", "XYZ"]
+
+
+@pytest.fixture(scope="module")
+def G():
+    import groan_rs_amd as g
+    g._lib.load()
+    return g
+
+
+def nasty_positions(rng, n, L):
+    """coordinates drawn per component from a mix of distributions that sit on the decision points of the closed forms"""
+    pos = np.empty((n, 3), np.float32)
+    for a in range(3):
+        kind = rng.integers(0, 8, n)
+        u = rng.random(n)
+        base = (u * L[a]).astype(np.float32)                                   # 0: inside the cell
+        v = base.copy()
+        faces = np.float32(L[a]) * rng.choice(np.float32([0.0, 0.5, 1.0, -1.0, 2.0, -0.5, 1.5]), n)
+        m = kind == 1; v[m] = faces[m]                                         # 1: exactly on a face / half box / next cell
+        m = kind == 2; v[m] = np.nextafter(faces[m], np.float32(np.inf))       # 2, 3: one ulp either side
+        m = kind == 3; v[m] = np.nextafter(faces[m], np.float32(-np.inf))
+        m = kind == 4; v[m] = -np.float32(10.0) ** rng.integers(-12, -5, m.sum()).astype(np.float32)   # 4: tiny negatives
+        m = kind == 5; v[m] = base[m] + np.float32(L[a]) * rng.integers(-4, 5, m.sum()).astype(np.float32)   # 5: a few cells away
+        m = kind == 6; v[m] = base[m] * np.float32(1e-3)                       # 6: crowded near the origin
+        pos[:, a] = v                                                          # 7: inside the cell again
+    dup = rng.random(n) < 0.1                                                  # coincident atoms
+    if n > 1:
+        pos[dup] = pos[rng.integers(0, n, dup.sum())]
+    return pos
+
+
+def eq_bits(a, b):
+    """bit equality up to the sign of a zero"""
+    return np.array_equal(a.view(np.uint32) & 0x7fffffff, b.view(np.uint32) & 0x7fffffff)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_orthorhombic_operations_on_nasty_inputs(G, seed):
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.choice([1, 2, 3, 5, 17, 64, 257, 300]))
+    L = np.float32(rng.choice([0.37, 1.0, 3.0, 6.5, 13.01327, 30.0], 3) * rng.choice([1.0, 1.0, 0.05, 1.7], 3))
+    box = np.array([L[0], L[1], L[2], 0, 0, 0, 0, 0, 0], np.float32)
+    pos = nasty_positions(rng, n, L)
+    masses = rng.choice(np.float32([1.008, 12.011, 15.999, 72.0, 0.0005]), n).astype(np.float32)
+    s = G.System(n, masses=masses, n_slots=2)
+    a0 = int(rng.integers(0, n)); a1 = int(rng.integers(a0, n))
+    b0 = int(rng.integers(0, n)); b1 = int(rng.integers(b0, n))
+    s.group_create_from_ranges("A", [(a0, a1)]); s.group_create_from_ranges("B", [(b0, b1)])
+    ia, ib, iall = np.arange(a0, a1 + 1), np.arange(b0, b1 + 1), np.arange(n)
+    # ---- wrap / translate: bit-exact
+    s.set_frame(pos, box)
+    s.atoms_wrap()
+    assert eq_bits(s.get_positions(), O.wrap_atoms(pos, iall, box)), "atoms_wrap"
+    v = (rng.normal(0, 1, 3) * L * rng.choice([1e-6, 0.3, 2.5])).astype(np.float32)
+    s.set_frame(pos, box)
+    s.group_translate("A", v)
+    assert eq_bits(s.get_positions(), O.translate(pos, ia, v, box)), "group_translate"
+    # ---- centres
+    s.set_frame(pos, box)
+    with O.acc64():
+        for weighted in (False, True):
+            m = masses if weighted else None
+            got = np.array(s.group_get_com_naive("A") if weighted else s.group_get_center_naive("A"))
+            want = O.center_naive(pos, ia, mass=m)
+            np.testing.assert_allclose(got, want, atol=TOL, rtol=2e-7, err_msg="naive")
+            if ia.size <= 64:   # (the circular mean of many scattered atoms is ill-conditioned: a short resultant amplifies the last bit of every angle)
+                got = np.array(s.group_estimate_com("A") if weighted else s.group_estimate_center("A"))
+                want = O.estimate_center(pos, ia, box, mass=m)
+                d = np.abs(got - want); d = np.minimum(d, np.abs(d - L))       # (0 and L are the same point of the circle)
+                assert d.max() <= 2e-5 * max(1.0, float(L.max())), ("estimate", got, want)
+    # ---- distances: every dimension, the whole matrix
+    for dim in DIMS:
+        got = s.group_all_distances("A", "B", G.Dimension[dim])
+        want = O.group_all_distances(pos, ia, ib, dim.lower(), box)
+        if len(dim) == 1:
+            assert eq_bits(got, want), dim          # signed 1-D distances: the min_image loops themselves, bit for bit
+        else:
+            np.testing.assert_allclose(got, want, atol=3e-6 * max(1.0, float(L.max())), rtol=2e-6, err_msg=dim)
+    i, j = int(rng.integers(0, n)), int(rng.integers(0, n))
+    assert abs(s.atoms_distance(i, j) - O.distance(pos[i], pos[j], "xyz", box)) <= 3e-6 * max(1.0, float(L.max()))
+    s.close()
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_rmsd_of_compact_groups_anywhere_in_the_cell(G, seed):
+    """calc_rmsd / calc_rmsd_and_fit for a compact group broken over the periodic boundary in both systems, random rotation,
+    small boxes (the group fills up to 40 % of the cell), atoms of the rest of the system anywhere"""
+    rng = np.random.default_rng(5000 + seed)
+    n = int(rng.choice([12, 61, 200, 1500]))
+    ns = max(4, n // 2)
+    L = np.float32(rng.choice([3.0, 6.5, 13.0], 3))
+    box = np.array([L[0], L[1], L[2], 0, 0, 0, 0, 0, 0], np.float32)
+    core = rng.normal(0, 0.07 * float(L.min()), (ns, 3))
+    q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+    if np.linalg.det(q) < 0:
+        q[:, 0] = -q[:, 0]
+    masses = rng.choice(np.float32([1.008, 12.011, 15.999, 32.06]), n).astype(np.float32)
+    def frame(rot, noise):
+        p = np.empty((n, 3), np.float64)
+        p[:ns] = core @ rot.T + rng.random(3) * L + rng.normal(0, noise, (ns, 3))
+        p[ns:] = rng.random((n - ns, 3)) * L * 3 - L
+        out = p.astype(np.float32)
+        out[:ns] = O.wrap_atoms(out[:ns].copy(), np.arange(ns), box)
+        return out
+    ref_pos, cur_pos = frame(np.eye(3), 0.0), frame(q, 0.02)
+    ref = G.System(n, masses=masses, box=box, positions=ref_pos)
+    cur = G.System(n, masses=masses, box=box, positions=cur_pos)
+    for sy in (ref, cur):
+        sy.group_create_from_ranges("G", [(0, ns - 1)])
+    idx = np.arange(ns)
+    with O.acc64():
+        want_r, want_fit = O.calc_rmsd_and_fit(ref_pos, masses, idx, box, cur_pos, masses, idx, box)
+    got = cur.calc_rmsd(ref, "G")
+    assert abs(got - want_r) <= TOL, (got, want_r)
+    got2 = cur.calc_rmsd_and_fit(ref, "G")
+    assert abs(got2 - want_r) <= TOL
+    np.testing.assert_allclose(cur.get_positions(), want_fit, atol=5e-5, rtol=0)
+    ref.close(); cur.close()
