@@ -22,7 +22,8 @@ struct GrShapeSet { int n, naive; GrShapeDev s[GR_MAX_SHAPES]; };
 
 GR_HD float gr_box_len(const GrBox &b, int dim) { return dim == 1 ? b.ax : (dim == 2 ? b.by : b.cz); }
 
-// vector3d.rs:522-533
+// vector3d.rs:522-533 -- compared with a radius: the reference's own arithmetic (no FMA contraction, correctly rounded
+// square root), an atom ON the surface must fall on the reference's side
 GR_HD float gr_distance_naive(float ax_, float ay_, float az_, float px, float py, float pz, int dim) {
     const float dx = ax_ - px, dy = ay_ - py, dz = az_ - pz;
     switch (dim) {
@@ -30,15 +31,20 @@ GR_HD float gr_distance_naive(float ax_, float ay_, float az_, float px, float p
     case 1: return dx;
     case 2: return dy;
     case 3: return dz;
-    case 4: return gr_mag3(dx, dy, 0.0f);
-    case 5: return gr_mag3(dx, 0.0f, dz);
-    case 6: return gr_mag3(0.0f, dy, dz);
-    default: return gr_mag3(dx, dy, dz);
+    case 4: return gr_mag3_exact(dx, dy, 0.0f);
+    case 5: return gr_mag3_exact(dx, 0.0f, dz);
+    case 6: return gr_mag3_exact(0.0f, dy, dz);
+    default: return gr_mag3_exact(dx, dy, dz);
     }
 }
 
 // TriangularPrism::sign (shape.rs:408-428)
-GR_HD float gr_prism_sign(float u1, float v1, float u2, float v2, float u3, float v3) { return (u1 - u3) * (v2 - v3) - (u2 - u3) * (v1 - v3); }
+// every product and the difference rounded on its own, as the reference computes them: a point on a face must get the same sign
+GR_HD float gr_prism_sign(float u1, float v1, float u2, float v2, float u3, float v3) {
+#pragma clang fp contract(off)
+    const float a = (u1 - u3) * (v2 - v3), b = (u2 - u3) * (v1 - v3);
+    return a - b;
+}
 
 template <int NC = GR_MAX_CAND>
 GR_HD bool gr_shape_inside_pbc(const GrShapeDev &s, float x, float y, float z, const GrBox &box) {

@@ -129,3 +129,112 @@ def test_rmsd_of_compact_groups_anywhere_in_the_cell(G, seed):
     assert abs(got2 - want_r) <= TOL
     np.testing.assert_allclose(cur.get_positions(), want_fit, atol=5e-5, rtol=0)
     ref.close(); cur.close()
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_geometry_selection_and_cutoff_pairs_with_atoms_on_the_boundaries(G, seed):
+    """Shape::inside (src/structures/shape.rs:110-505) and the cell-grid pair search (cellgrid.rs:301-409) decide membership by
+    comparing a distance with a threshold: atoms are placed EXACTLY on sphere / cylinder radii, box faces of the rectangular
+    shape, prism faces and at the cut-off distance (and one ulp either side); the index lists must be identical"""
+    rng = np.random.default_rng(9000 + seed)
+    n = 400
+    L = np.float32(rng.choice([4.0, 6.5, 9.0], 3))
+    box = np.array([L[0], L[1], L[2], 0, 0, 0, 0, 0, 0], np.float32)
+    pos = (rng.random((n, 3)) * L).astype(np.float32)
+    centre = (rng.random(3) * L).astype(np.float32)
+    radius = np.float32(rng.choice([0.75, 1.3, 2.0]))
+    for k in range(0, 120):                                       # on / next to the sphere and cylinder radius, through the boundary
+        d = rng.normal(size=3); d /= np.linalg.norm(d)
+        r = radius if k % 3 == 0 else np.nextafter(radius, np.float32(np.inf if k % 3 == 1 else -np.inf))
+        if k % 2:
+            d[1] = 0.0; d /= np.linalg.norm(d)                     # in the plane of a Y cylinder
+        pos[k] = centre + np.float32(r) * d.astype(np.float32)
+    size = np.float32([1.5, 2.25, 1.0])
+    for k in range(120, 180):                                     # faces of the rectangular shape (origin corner + size)
+        a = k % 3
+        p = centre + (rng.random(3) * size).astype(np.float32)
+        p[a] = centre[a] + (size[a] if k % 2 else np.float32(0.0))
+        if k % 5 == 0:
+            p[a] = np.nextafter(p[a], np.float32(np.inf))
+        pos[k] = p
+    b1, b2, b3 = centre, centre + np.float32([2.0, 0.5, 0.0]), centre + np.float32([0.5, 2.0, 0.0])
+    for k in range(180, 240):                                     # on the slanted faces of the prism (sign of a cross product ~ 0)
+        e0, e1 = ((b1, b2), (b2, b3), (b3, b1))[k % 3]
+        p = (e0 + np.float32(rng.random()) * (e1 - e0)).astype(np.float32)
+        p[2] = centre[2] + np.float32(rng.random() * 1.5)
+        pos[k] = p
+    pos = O.wrap_atoms(pos, np.arange(n), box)
+    s = G.System(n, n_slots=1)
+    s.set_frame(pos, box)
+    s.group_create_from_ranges("src", [(0, n - 1)])
+    idx = np.arange(n)
+    specs = [{"kind": "sphere", "position": centre.tolist(), "radius": float(radius)},
+             {"kind": "cylinder", "position": centre.tolist(), "radius": float(radius), "height": 2.5, "orientation": "Y"},
+             {"kind": "rectangular", "position": centre.tolist(), "size": size.tolist()},
+             {"kind": "prism", "base1": centre.tolist(), "base2": (centre + np.float32([2.0, 0.5, 0.0])).tolist(), "base3": (centre + np.float32([0.5, 2.0, 0.0])).tolist(), "height": 1.5}]
+    def build(sp):
+        k = sp["kind"]
+        if k == "sphere": return G.Sphere(sp["position"], sp["radius"])
+        if k == "rectangular": return G.Rectangular(sp["position"], *sp["size"])
+        if k == "cylinder": return G.Cylinder(sp["position"], sp["radius"], sp["height"], G.Dimension[sp["orientation"]])
+        return G.TriangularPrism(sp["base1"], sp["base2"], sp["base3"], sp["height"])
+    for sp in specs:
+        for naive in ((False,) if sp["kind"] == "prism" else (False, True)):    # (the reference has no NaiveShape for the prism)
+            s.group_create_from_geometries("sel", "src", [build(sp)], naive=naive)
+            got = np.array(list(s.group_container("sel")), np.uint64)
+            want = O.group_from_geometries(pos, idx, box, [sp], naive=naive)
+            assert np.array_equal(got, want), (sp["kind"], naive, np.setxor1d(got, want))
+    # pairs at exactly the cut-off: atom k + 200 sits at distance `cut` (or an ulp off) from atom k
+    cut = np.float32(0.4)
+    for k in range(40):
+        d = rng.normal(size=3); d /= np.linalg.norm(d)
+        r = cut if k % 3 == 0 else np.nextafter(cut, np.float32(np.inf if k % 3 == 1 else -np.inf))
+        pos[200 + k] = pos[k] + np.float32(r) * d.astype(np.float32)
+    pos = O.wrap_atoms(pos, np.arange(n), box)
+    s.set_frame(pos, box)
+    s.group_create_from_ranges("g1", [(0, 199)]); s.group_create_from_ranges("g2", [(150, n - 1)])
+    gi, gj, gd = s.group_pairs_within("g1", "g2", float(cut))
+    wi, wj, wd = O.pairs_within(pos, np.arange(0, 200), np.arange(150, n), box, float(cut))
+    assert np.array_equal(gi.astype(np.uint64), wi) and np.array_equal(gj.astype(np.uint64), wj), (gi.size, wi.size)
+    s.close()
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_triclinic_operations_on_nasty_inputs(G, seed):
+    """the triclinic extension (parity unpinned: the reference refuses such boxes) against the oracle's restatement of the
+    same definitions: wrapped positions must be the same point of the lattice, centres and distances agree to 1e-5 nm"""
+    rng = np.random.default_rng(7000 + seed)
+    n = int(rng.choice([3, 17, 64, 200]))
+    angles = [[60.0, 60.0, 90.0], [70.53, 109.47, 70.53], [75.0, 80.0, 70.0], [90.0, 90.0, 60.0]][seed % 4]
+    l0 = float(rng.choice([3.0, 6.5, 12.0]))
+    box = O.box_from_lengths_angles([l0, l0, l0] if seed % 4 < 2 else [l0, 0.9 * l0, 0.8 * l0], angles)
+    boxm = np.array([[box[0], 0, 0], [box[5], box[1], 0], [box[7], box[8], box[2]]], np.float64)
+    frac = rng.random((n, 3))
+    kind = rng.integers(0, 5, (n, 3))
+    frac = np.where(kind == 1, rng.choice([0.0, 0.5, 1.0], (n, 3)), frac)          # on faces / half way
+    frac = np.where(kind == 2, frac + rng.integers(-3, 4, (n, 3)), frac)           # a few cells away
+    frac = np.where(kind == 3, -10.0 ** rng.integers(-9, -5, (n, 3)), frac)        # tiny negatives
+    pos = (frac @ boxm).astype(np.float32)
+    masses = rng.choice(np.float32([1.008, 12.011, 15.999]), n).astype(np.float32)
+    s = G.System(n, masses=masses, n_slots=1)
+    s.group_create_from_ranges("A", [(0, n // 2)]); s.group_create_from_ranges("B", [(n // 3, n - 1)])
+    ia, ib, iall = np.arange(0, n // 2 + 1), np.arange(n // 3, n), np.arange(n)
+    scale = max(1.0, l0)
+    s.set_frame(pos, box)
+    s.atoms_wrap()
+    got, want = s.get_positions(), O.wrap_atoms(pos, iall, box)
+    for i in range(n):                                                             # the same lattice point (a face atom may sit on either face)
+        assert O.distance(got[i], want[i], "xyz", box) <= 2e-5 * scale, (i, got[i], want[i])
+    s.set_frame(pos, box)
+    for dim in ("XYZ", "X", "YZ"):
+        g = s.group_all_distances("A", "B", G.Dimension[dim])
+        w = O.group_all_distances(pos, ia, ib, dim.lower(), box)
+        if dim == "XYZ":
+            np.testing.assert_allclose(g, w, atol=1e-5 * scale, rtol=2e-6)
+        else:   # components of the minimum image: where two images tie (half-box separations) either is a minimum image
+            bad = np.abs(g - w) > 1e-5 * scale
+            assert bad.mean() <= 0.2, (dim, bad.mean())
+    with O.acc64():
+        got = np.array(s.group_get_com_naive("A"))
+        np.testing.assert_allclose(got, O.center_naive(pos, ia, mass=masses), atol=TOL * scale, rtol=2e-7)
+    s.close()
