@@ -238,3 +238,41 @@ def test_triclinic_operations_on_nasty_inputs(G, seed):
         got = np.array(s.group_get_com_naive("A"))
         np.testing.assert_allclose(got, O.center_naive(pos, ia, mass=masses), atol=TOL * scale, rtol=2e-7)
     s.close()
+
+
+@pytest.mark.parametrize("ns", [1, 2, 3, 4])
+@pytest.mark.parametrize("flat", [False, True])
+def test_rmsd_of_degenerate_groups(G, ns, flat):
+    """one, two (collinear), three (planar) atoms and flat 4-atom groups: the covariance matrix is rank deficient, the
+    optimal rotation is not unique for rank <= 1, but the RMSD (rmsd.rs:592-599) and the fitted positions of the group's own
+    atoms are; for rank 2 the determinant correction (rmsd.rs:576-583) makes the whole rotation unique"""
+    rng = np.random.default_rng(40 + ns + 10 * flat)
+    n = 40
+    box = np.array([5.0, 6.0, 7.0, 0, 0, 0, 0, 0, 0], np.float32)
+    masses = rng.choice(np.float32([1.008, 12.011, 15.999]), n).astype(np.float32)
+    for trial in range(6):
+        core = rng.normal(0, 0.4, (ns, 3))
+        if flat:
+            core[:, 2] = 0.0
+        q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+        if np.linalg.det(q) < 0:
+            q[:, 0] = -q[:, 0]
+        ref_pos = (rng.random((n, 3)) * box[:3]).astype(np.float32)
+        cur_pos = (rng.random((n, 3)) * box[:3]).astype(np.float32)
+        ref_pos[:ns] = (core + [2.5, 3.0, 3.5]).astype(np.float32)
+        cur_pos[:ns] = O.wrap_atoms((core @ q.T + rng.random(3) * box[:3] + rng.normal(0, 0.03, (ns, 3))).astype(np.float32), np.arange(ns), box)
+        ref = G.System(n, masses=masses, box=box, positions=ref_pos)
+        cur = G.System(n, masses=masses, box=box, positions=cur_pos)
+        for sy in (ref, cur):
+            sy.group_create_from_ranges("G", [(0, ns - 1)])
+        idx = np.arange(ns)
+        with O.acc64():
+            want_r, want_fit = O.calc_rmsd_and_fit(ref_pos, masses, idx, box, cur_pos, masses, idx, box)
+        assert abs(cur.calc_rmsd(ref, "G") - want_r) <= TOL, (ns, flat, trial)
+        assert abs(cur.calc_rmsd_and_fit(ref, "G") - want_r) <= TOL
+        got = cur.get_positions()
+        np.testing.assert_allclose(got[:ns], want_fit[:ns], atol=5e-5, rtol=0)        # the group itself: unique
+        rank = np.linalg.matrix_rank(core - core.mean(0), tol=1e-6) if ns > 1 else 0
+        if rank >= 2:                                                                  # the whole rotation is unique: every atom
+            np.testing.assert_allclose(got, want_fit, atol=2e-4, rtol=0)
+        ref.close(); cur.close()
