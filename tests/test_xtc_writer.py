@@ -12,7 +12,7 @@ import zlib
 import numpy as np
 import pytest
 
-from test_xtc_decoder import GOLD, REF_SO, water_like, write_with_ref
+from test_xtc_decoder import GOLD, REF_SO, read_with_ref, water_like, write_with_ref
 
 
 @pytest.fixture(scope="module")
@@ -108,4 +108,43 @@ def test_coordinates_the_format_cannot_hold_are_refused(G, tmp_path):
     assert x.n_frames == 2                                     # the refused frames left no bytes behind
     got = x.read_frame(1)[0]
     assert np.all(got[3] == 0.0) and np.abs(got[4] - pos[4]).max() <= 0.00051
+    x.close()
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_random_systems_encode_to_the_reference_writers_bytes(G, tmp_path, seed):
+    """randomised byte-for-byte comparison with the reference's writer (oracle/_ref = the reference's vendored xdrfile compiled
+    where it lies): atom counts around the format's thresholds, coincident and collinear atoms (zero minimum step), identical
+    frames, runs of every length, molecules of 2-9 atoms, coordinates on the quantisation half-steps, mixed magnitudes,
+    several precisions"""
+    if not os.path.exists(REF_SO):
+        pytest.skip("oracle/_ref not built (reference tree absent)")
+    rng = np.random.default_rng(31000 + seed)
+    n = int(rng.choice([10, 11, 12, 13, 27, 100, 333, 1000, 2501]))
+    prec = float(rng.choice([1000.0, 100.0, 10.0, 10000.0, 500.0]))
+    span = float(rng.choice([0.5, 3.0, 12.0, 80.0, 900.0]))
+    mol = int(rng.integers(1, 10))
+    frames = []
+    for f in range(3):
+        base = rng.uniform(-span if seed % 3 == 0 else 0.0, span, ((n + mol - 1) // mol, 3))
+        x = np.repeat(base, mol, axis=0)[:n] + rng.normal(0, float(rng.choice([0.0, 0.002, 0.05, 0.3])), (n, 3))
+        kind = rng.integers(0, 6, n)
+        x[kind == 1] = x[0]                                                   # coincident atoms
+        x[kind == 2] = np.round(x[kind == 2] * prec) / prec + 0.5 / prec      # on the rounding half-steps
+        x[kind == 3, 1:] = x[0, 1:]                                           # collinear along x
+        if seed % 4 == 1 and f == 2:
+            x = frames[-1].astype(np.float64)                                 # an identical frame
+        frames.append(x.astype(np.float32))
+    boxm = np.array([[span, 0, 0], [0, span, 0], [0, 0, span]], np.float32)
+    ref_path, our_path = tmp_path / "ref.xtc", tmp_path / "ours.xtc"
+    write_with_ref(ref_path, frames, boxm, prec)
+    with G.XtcWriter(our_path) as w:
+        for i, fr in enumerate(frames):
+            w.write_frame(fr, rows_to_box9(boxm), step=i * 10, time=i * 0.5, precision=prec)
+    a, b = open(our_path, "rb").read(), open(ref_path, "rb").read()
+    assert len(a) == len(b) and a == b, (seed, n, prec, span, mol, len(a), len(b), next((k for k in range(min(len(a), len(b))) if a[k] != b[k]), None))
+    x = G.XtcFile(our_path)                                                  # and our decoder reads it back like the reference's
+    want = read_with_ref(ref_path, n)
+    for i in range(3):
+        assert np.array_equal(x.read_frame(i)[0], want[i])
     x.close()
