@@ -78,3 +78,24 @@ def test_decoded_slots_feed_the_kernels(G, short_traj, example):
         t.set_frame(pos, box)
         assert np.array_equal(t.group_get_center("Protein"), got[f])
     s.close(); t.close(); x.close()
+
+
+@pytest.mark.parametrize("seed", range(20))
+def test_random_systems_unpack_like_the_host_decoder(G, tmp_path, seed):
+    """randomised frames (atom counts around the 32-atom checkpoint spacing and the format's thresholds, molecules of 1-9
+    atoms = runs of every length, coincident atoms, several precisions and magnitudes) written with the library's encoder
+    (byte-identical to the reference's writer, tests/test_xtc_writer.py): device unpack == host decode, bit for bit"""
+    rng = np.random.default_rng(52000 + seed)
+    n = int(rng.choice([10, 31, 32, 33, 63, 64, 65, 100, 1000, 4097, 20011]))
+    prec = float(rng.choice([1000.0, 100.0, 10000.0]))
+    span = float(rng.choice([0.5, 3.0, 12.0, 80.0, 3000.0]))
+    mol = int(rng.integers(1, 10))
+    path = tmp_path / "rand.xtc"
+    with G.XtcWriter(path) as w:
+        for f in range(5):
+            base = rng.uniform(-span if seed % 3 == 0 else 0.0, span, ((n + mol - 1) // mol, 3))
+            x = np.repeat(base, mol, axis=0)[:n] + rng.normal(0, float(rng.choice([0.0, 0.002, 0.05, 0.3])), (n, 3))
+            x[rng.integers(0, 6, n) == 1] = x[0]
+            w.write_frame(x.astype(np.float32), [span, span, span, 0, 0, 0, 0, 0, 0], step=f, time=0.1 * f, precision=prec)
+    check_file(G, path)
+    check_file(G, path, batch=2, host_threads=2)
