@@ -1929,18 +1929,22 @@ int gr_xtc_write_slots(gr_xtc_writer *w, gr_ctx *c, uint32_t first_slot, uint32_
             if (e != hipSuccess) { for (auto x : ev) if (x) (void)hipEventDestroy(x); c->err = hipGetErrorString(e); return GR_E_HIP; }
         }
     }
+    // encoders take frames in order; the calling thread writes frame k as soon as it is encoded, while later frames are still
+    // being encoded (a frame the format cannot hold stops the output there: the frames before it are in the file, exactly as
+    // a loop of write_frame calls would leave it)
     std::vector<std::vector<unsigned char>> frames_out(n_frames);
+    std::vector<std::atomic<int>> done(n_frames);           // 0 pending, 1 encoded, 2 refused, 3 copy failed
+    for (auto &d : done) d.store(0);
     std::atomic<uint32_t> next(0);
-    std::atomic<int> bad(0);
-    std::atomic<unsigned> bad_frame(~0u);   // a frame whose coordinates the format cannot hold
+    std::atomic<int> stop(0);
     const int dev = c->device;
     auto work = [&]() {
         (void)hipSetDevice(dev);
         grx::EncodedFrame sc; std::vector<int> ints; std::vector<float> gathered;
         for (;;) {
             const uint32_t k = next.fetch_add(1);
-            if (k >= n_frames) return;
-            if (hipEventSynchronize(ev[k]) != hipSuccess) { bad = 1; return; }
+            if (k >= n_frames || stop.load()) return;
+            if (hipEventSynchronize(ev[k]) != hipSuccess) { done[k].store(3); return; }
             const float *src = host + (size_t)k * c->n * 3;
             if (g) {
                 gathered.resize(3 * (size_t)n_out);
@@ -1948,20 +1952,29 @@ int gr_xtc_write_slots(gr_xtc_writer *w, gr_ctx *c, uint32_t first_slot, uint32_
                 src = gathered.data();
             }
             float m[9]; box9_rows(c->box9_set[first_slot + k] ? &c->box9_host[9 * (size_t)(first_slot + k)] : nullptr, m);
-            if (!grx::serialise_frame(frames_out[k], (uint32_t)n_out, (int32_t)(steps ? steps[k] : 0), times ? times[k] : 0.0f, m, src, precision, sc, ints)) {
-                unsigned expect = ~0u; (void)bad_frame.compare_exchange_strong(expect, k);
-            }
+            const bool ok = grx::serialise_frame(frames_out[k], (uint32_t)n_out, (int32_t)(steps ? steps[k] : 0), times ? times[k] : 0.0f, m, src, precision, sc, ints);
+            done[k].store(ok ? 1 : 2);
         }
     };
-    uint32_t nt = host_threads > 0 ? (uint32_t)host_threads : std::min<uint32_t>(n_frames, 8u);
+    uint32_t nt = host_threads > 0 ? (uint32_t)host_threads : std::min<uint32_t>(n_frames, 16u);
     nt = std::max<uint32_t>(1u, std::min<uint32_t>(nt, n_frames));
-    if (nt == 1) work();
-    else { std::vector<std::thread> th; for (uint32_t t = 0; t < nt; ++t) th.emplace_back(work); for (auto &t : th) t.join(); }
+    std::vector<std::thread> th;
+    for (uint32_t t = 0; t < nt; ++t) th.emplace_back(work);
+    int result = GR_OK; uint32_t failed_at = 0;
+    for (uint32_t k = 0; k < n_frames && result == GR_OK; ++k) {
+        int d;
+        while ((d = done[k].load()) == 0) std::this_thread::sleep_for(std::chrono::microseconds(50));
+        if (d == 1) {
+            if (fwrite(frames_out[k].data(), 1, frames_out[k].size(), w->fp) != frames_out[k].size()) { result = GR_E_IO; failed_at = k; }
+            std::vector<unsigned char>().swap(frames_out[k]);
+        } else { result = d == 2 ? GR_E_OUT_OF_RANGE : GR_E_HIP; failed_at = k; }
+    }
+    stop.store(1);
+    for (auto &t : th) t.join();
     for (auto x : ev) if (x) (void)hipEventDestroy(x);
-    if (bad.load()) return fail(c, GR_E_HIP, "device-to-host copy failed while writing frames");
-    if (bad_frame.load() != ~0u) return fail(c, GR_E_OUT_OF_RANGE, "coordinates do not fit the xtc integers at this precision; nothing written", first_slot + bad_frame.load());
-    for (uint32_t k = 0; k < n_frames; ++k)
-        if (fwrite(frames_out[k].data(), 1, frames_out[k].size(), w->fp) != frames_out[k].size()) return fail(c, GR_E_IO, "short write");
+    if (result == GR_E_HIP) return fail(c, GR_E_HIP, "device-to-host copy failed while writing frames");
+    if (result == GR_E_OUT_OF_RANGE) return fail(c, GR_E_OUT_OF_RANGE, "coordinates do not fit the xtc integers at this precision; the frames before this slot were written", first_slot + failed_at);
+    if (result == GR_E_IO) return fail(c, GR_E_IO, "short write");
     return GR_OK;
 }
 

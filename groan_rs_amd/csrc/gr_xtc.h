@@ -332,21 +332,39 @@ inline int skim_frame(const unsigned char *stream, const FrameIndex &fi, uint32_
 //   * ... signalled by one flag bit + 5 bits (run length * 3 + change + 1) only when run length or index change.
 // MSB-first bit writer
 struct BitWriter {
-    std::vector<unsigned char> &out; unsigned char *p; uint64_t acc = 0; int nacc = 0;
-    // `o` must already be sized for the worst case (encode_coords: 16 bytes per atom); finish() trims it
+    std::vector<unsigned char> &out; unsigned char *p; uint64_t acc = 0; int nacc = 0;   // nacc < 32 pending bits at the bottom of acc
+    // `o` must already be sized for the worst case (encode_coords: 16 bytes per atom + slack); finish() trims it
     explicit BitWriter(std::vector<unsigned char> &o) : out(o), p(o.data()) {}
     inline void put(int nbits, uint32_t v) {   // 0 <= nbits <= 32, v < 2^nbits
-        if (nbits == 0) return;
         acc = (acc << nbits) | (uint64_t)v; nacc += nbits;
-        while (nacc >= 8) { *p++ = (unsigned char)(acc >> (nacc - 8)); nacc -= 8; }
-        acc &= (nacc == 0) ? 0ull : ((1ull << nacc) - 1ull);
+        if (nacc >= 32) {                      // four bytes at a time, most significant first
+            const uint32_t w = __builtin_bswap32((uint32_t)(acc >> (nacc - 32)));
+            memcpy(p, &w, 4); p += 4; nacc -= 32;
+            acc &= (1ull << nacc) - 1ull;
+        }
     }
-    // a packed integer of `nbits` bits: its bytes go out least significant first, the last (partial) chunk holds the top bits
+    // a packed integer of `nbits` bits: its bytes go out least significant first, the last (partial) chunk holds the top bits.
+    // m whole bytes b0 b1 .. in stream order are the byte-swapped low m bytes of v, written as at most two fields
+    inline void put_packed64(int nbits, uint64_t v) {   // nbits <= 64
+        const int m = nbits >> 3, rest = nbits & 7;
+        if (m > 0) {
+            const uint64_t sw = __builtin_bswap64(v) >> (64 - 8 * m);   // b0 is now the most significant of the m bytes
+            if (m > 4) { put(8 * (m - 4), (uint32_t)(sw >> 32)); put(32, (uint32_t)sw); }
+            else put(8 * m, (uint32_t)sw);
+        }
+        if (rest) put(rest, (uint32_t)((m < 8 ? v >> (8 * m) : 0ull) & ((1u << rest) - 1u)));
+    }
     inline void put_packed(int nbits, unsigned __int128 v) {
-        while (nbits >= 8) { put(8, (uint32_t)(v & 0xff)); v >>= 8; nbits -= 8; }
-        if (nbits > 0) put(nbits, (uint32_t)(v & ((1u << nbits) - 1u)));
+        if (nbits <= 64) { put_packed64(nbits, (uint64_t)v); return; }
+        put_packed64(64, (uint64_t)v);
+        put_packed64(nbits - 64, (uint64_t)(v >> 64));
     }
-    inline void finish() { if (nacc > 0) { *p++ = (unsigned char)(acc << (8 - nacc)); nacc = 0; acc = 0; } out.resize((size_t)(p - out.data())); }
+    inline void finish() {
+        while (nacc >= 8) { *p++ = (unsigned char)(acc >> (nacc - 8)); nacc -= 8; }
+        if (nacc > 0) { *p++ = (unsigned char)((acc << (8 - nacc)) & 0xff); nacc = 0; }
+        acc = 0;
+        out.resize((size_t)(p - out.data()));
+    }
 };
 
 struct EncodedFrame {
@@ -425,6 +443,8 @@ inline bool encode_coords(const float *xyz, uint32_t n, float precision, Encoded
         }
         if (bitsize == 0) {
             for (int a = 0; a < 3; ++a) bw.put(bitsizeint[a], (uint32_t)(cur[a] - mn[a]));
+        } else if (bitsize <= 64) {
+            bw.put_packed64(bitsize, ((uint64_t)(uint32_t)(cur[0] - mn[0]) * sizeint[1] + (uint32_t)(cur[1] - mn[1])) * sizeint[2] + (uint32_t)(cur[2] - mn[2]));
         } else {
             const unsigned __int128 v = ((unsigned __int128)(uint32_t)(cur[0] - mn[0]) * sizeint[1] + (uint32_t)(cur[1] - mn[1])) * sizeint[2] + (uint32_t)(cur[2] - mn[2]);
             bw.put_packed(bitsize, v);
@@ -453,8 +473,8 @@ inline bool encode_coords(const float *xyz, uint32_t n, float precision, Encoded
             bw.put(1, 0u);
         }
         for (int k = 0; k < run; k += 3) {
-            const unsigned __int128 v = ((unsigned __int128)small[k] * sizesmall + small[k + 1]) * sizesmall + small[k + 2];
-            bw.put_packed(smallidx, v);
+            if (smallidx <= 64) bw.put_packed64(smallidx, ((uint64_t)small[k] * sizesmall + small[k + 1]) * sizesmall + small[k + 2]);
+            else bw.put_packed(smallidx, ((unsigned __int128)small[k] * sizesmall + small[k + 1]) * sizesmall + small[k + 2]);
         }
         if (is_smaller != 0) {
             smallidx += is_smaller;

@@ -273,9 +273,10 @@ int gr_atoms_center_batch(gr_ctx *ctx, uint32_t first_slot, uint32_t n_frames, c
  * byte the stream the reference writes for the same coordinates (the reference's golden fitted trajectories are files).
  * Atoms without a position are written as the origin, a frame without box as a zero matrix (xdrfile.rs:188-200).
  * gr_xtc_write_slots streams device frames out: D2H of slot k+1 overlaps the encoding of slot k (`host_threads` encoders,
- * 0 = up to 8), frames are written in slot order; `group` = NULL writes every atom, else the group's atoms in its order
+ * 0 = up to 16), frames are written in slot order; `group` = NULL writes every atom, else the group's atoms in its order
  * (xtc_group_writer_init).  A coordinate whose value x precision does not fit the format's 32-bit integers (or a NaN in
- * y / z) makes the call fail with GR_E_OUT_OF_RANGE and nothing is written -- the reference's C writer prints "Internal
+ * y / z) makes the call fail with GR_E_OUT_OF_RANGE and that frame is not written (gr_xtc_write_slots stops there: the frames
+ * before it are in the file, as after a loop of write_frame calls) -- the reference's C writer prints "Internal
  * overflow compressing coordinates." and converts anyway (undefined behaviour, external/xdrfile/xdrfile.c:1025-1030). */
 typedef struct gr_xtc_writer gr_xtc_writer;
 gr_xtc_writer *gr_xtc_writer_open(const char *path, int *status);

@@ -78,3 +78,29 @@ def test_decode_fit_write_matches_the_reference_fit_golden(G, tmp_path, example,
                 w.write_frame(fr, b9, step=i * 10, time=i * 0.5, precision=prec)
         assert open(refp, "rb").read() == open(ours, "rb").read()
     x.close(); y.close(); z.close(); ref.close(); cur.close()
+
+
+def test_a_frame_the_format_cannot_hold_stops_the_output_there(tmp_path):
+    """write_slots over four slots, the third holds a coordinate whose quantum does not fit 32 bits: GR_E_OUT_OF_RANGE, and the
+    file holds the two frames before it -- what a loop of write_frame calls would leave (the reference's C writer prints
+    "Internal overflow compressing coordinates." and converts anyway: undefined behaviour, xdrfile.c:1025-1030)"""
+    import groan_rs_amd as G
+    rng = np.random.default_rng(8)
+    n = 500
+    box = np.array([5, 5, 5, 0, 0, 0, 0, 0, 0], np.float32)
+    s = G.System(n, n_slots=4)
+    frames = [rng.uniform(0, 5, (n, 3)).astype(np.float32) for _ in range(4)]
+    frames[2][77, 1] = 3.0e6
+    for f in range(4):
+        s.set_frame(frames[f], box, slot=f)
+    path = tmp_path / "stop.xtc"
+    with G.XtcWriter(path) as w:
+        with pytest.raises(G.XtcError) as e:
+            w.write_slots(s, 0, 4, host_threads=3)
+        assert e.value.status == 9                                      # GR_E_OUT_OF_RANGE
+        w.write_slots(s, 3, 1)                                          # the writer is still usable
+    x = G.XtcFile(path)
+    assert x.n_frames == 3
+    for k, f in enumerate((0, 1, 3)):
+        assert np.abs(x.read_frame(k)[0] - frames[f]).max() <= 0.00051
+    x.close(); s.close()

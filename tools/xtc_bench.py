@@ -85,6 +85,16 @@ def main():
             s.atoms_center_batch("Solute", (k % 2) * B, B, G.Dimension.XYZ, weighted=True)
         s.sync()
         out["device_unpack_com_center_batch_%d_frames_per_s" % B] = round(NF / (time.perf_counter() - t0), 1)
+    # and out again: D2H + the library's encoder (fitted-trajectory output), T encoder threads, 32 frames per call
+    x.read_frames_device(s, 0, 32, first_slot=0, host_threads=T); s.sync()
+    wpath = os.path.join(tmp, "rewritten.xtc")
+    with G.XtcWriter(wpath) as w:
+        w.write_slots(s, 0, 32, precision=1000.0, host_threads=T)
+        t0 = time.perf_counter()
+        for _ in range(4):
+            w.write_slots(s, 0, 32, precision=1000.0, host_threads=T)
+        out["write_slots_frames_per_s"] = round(4 * 32 / (time.perf_counter() - t0), 1)
+    os.remove(wpath)
     print(json.dumps(out, indent=1))
     x.close(); s.close(); os.remove(path)
 
