@@ -276,3 +276,49 @@ def test_rmsd_of_degenerate_groups(G, ns, flat):
         if rank >= 2:                                                                  # the whole rotation is unique: every atom
             np.testing.assert_allclose(got, want_fit, atol=2e-4, rtol=0)
         ref.close(); cur.close()
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 63, 64, 65, 255, 256, 257, 1023, 1024, 1025, 4099])
+def test_sizes_around_the_tile_boundaries(G, n):
+    """systems and selections whose sizes straddle the 4-atom lane groups, the 64-lane wavefront and the 256-atom tile: batched
+    RMSD-fit (two-pass and closed-form paths), centres, wrap -- against the oracle, every atom of the ragged tail included"""
+    rng = np.random.default_rng(600 + n)
+    box = O.box_from_lengths_angles([6.0, 6.0, 6.0], [60.0, 60.0, 90.0]) if n % 2 else np.array([6.0, 5.5, 5.0, 0, 0, 0, 0, 0, 0], np.float32)
+    boxm = np.array([[box[0], 0, 0], [box[5], box[1], 0], [box[7], box[8], box[2]]], np.float64)
+    masses = rng.choice(np.float32([1.008, 12.011, 15.999]), n).astype(np.float32)
+    core = rng.normal(0, 0.35, (n, 3))
+    nf = 3
+    ref_pos = (core + np.array([0.5, 0.5, 0.5]) @ boxm).astype(np.float32)
+    cur = G.System(n, masses=masses, n_slots=nf)
+    ref = G.System(n, masses=masses, box=box, positions=ref_pos)
+    sel = (0, n - 1) if n < 8 else (1, n - 2)                  # interior selection: the first and last lane groups are partial
+    idx = np.arange(sel[0], sel[1] + 1)
+    for sy in (ref, cur):
+        sy.group_create_from_ranges("S", [sel])
+    frames = []
+    for f in range(nf):
+        q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+        if np.linalg.det(q) < 0:
+            q[:, 0] = -q[:, 0]
+        x = (core @ q.T + rng.random(3) @ boxm + rng.normal(0, 0.02, (n, 3))).astype(np.float32)
+        x = O.wrap_atoms(x, np.arange(n), box)
+        frames.append(x); cur.set_frame(x, box, slot=f)
+    with O.acc64():
+        want = [O.calc_rmsd_and_fit(ref_pos, masses, idx, box, frames[f], masses, idx, box) for f in range(nf)]
+        coms = [O.get_center(frames[f], idx, box, mass=masses) for f in range(nf)]
+    got_com, st = cur.group_get_com_batch("S", 0, nf)
+    assert (st == 0).all()
+    for f in range(nf):
+        assert np.abs(got_com[f] - coms[f]).max() <= TOL
+    plan = G.RMSDPlan(ref, cur, "S")
+    r, st = plan.rmsd(0, nf)                                    # closed-form single pass
+    assert (st == 0).all() and np.abs(r - [w[0] for w in want]).max() <= TOL
+    r, st = plan.rmsd_fit(0, nf)                                # two-pass
+    assert (st == 0).all() and np.abs(r - [w[0] for w in want]).max() <= TOL
+    rank = np.linalg.matrix_rank(core[idx] - core[idx].mean(0), tol=1e-6) if idx.size > 1 else 0
+    for f in range(nf):
+        got = cur.get_positions(f)
+        np.testing.assert_allclose(got[idx], want[f][1][idx], atol=5e-5, rtol=0)
+        if rank >= 2:
+            np.testing.assert_allclose(got, want[f][1], atol=2e-4, rtol=0)
+    plan.close(); ref.close(); cur.close()
