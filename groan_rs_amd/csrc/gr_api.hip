@@ -25,6 +25,7 @@
 #include <set>
 #include <thread>
 #include <atomic>
+#include <system_error>
 #include <chrono>
 
 #define GR_MAX_BATCH 1024    // frames per batched call segment (workspace is sized for this; 82 MB of partial records)
@@ -1737,7 +1738,14 @@ int gr_xtc_read_frames_device(const gr_xtc *x, uint64_t first_frame, uint32_t n_
     uint32_t nt = host_threads > 0 ? (uint32_t)host_threads : std::min<uint32_t>(n_frames, 16u);
     nt = std::max<uint32_t>(1u, std::min<uint32_t>(nt, n_frames));
     if (nt == 1) work();
-    else { std::vector<std::thread> th; for (uint32_t t = 0; t < nt; ++t) th.emplace_back(work); for (auto &t : th) t.join(); }
+    else {
+        // (a thread that cannot be started must not unwind through the C ABI: the frames it would have taken are picked up by
+        // the workers that did start, or by this thread)
+        std::vector<std::thread> th;
+        for (uint32_t t = 0; t < nt; ++t) { try { th.emplace_back(work); } catch (const std::system_error &) { break; } }
+        if (th.empty()) work();
+        for (auto &t : th) t.join();
+    }
     if (bad.load() != grx::XTC_OK) return fail(c, xtc_status(bad.load()), "corrupt or unreadable xtc frame");
     const auto t_host = std::chrono::steady_clock::now();
     // ---- device.  copy stream: the bank's H2D, once the unpack kernel that last read the device bank is done.
@@ -1959,7 +1967,8 @@ int gr_xtc_write_slots(gr_xtc_writer *w, gr_ctx *c, uint32_t first_slot, uint32_
     uint32_t nt = host_threads > 0 ? (uint32_t)host_threads : std::min<uint32_t>(n_frames, 16u);
     nt = std::max<uint32_t>(1u, std::min<uint32_t>(nt, n_frames));
     std::vector<std::thread> th;
-    for (uint32_t t = 0; t < nt; ++t) th.emplace_back(work);
+    for (uint32_t t = 0; t < nt; ++t) { try { th.emplace_back(work); } catch (const std::system_error &) { break; } }
+    if (th.empty()) work();   // no worker could be started: encode here, then write
     int result = GR_OK; uint32_t failed_at = 0;
     for (uint32_t k = 0; k < n_frames && result == GR_OK; ++k) {
         int d;

@@ -978,11 +978,7 @@ __global__ __launch_bounds__(GR_WG) void k_fit(
     __shared__ GrBox box;
     __shared__ double lds[GR_WG / 64];
     __shared__ uint32_t last_flag;
-#if defined(GR_FIT_REVERSE) && GR_FIT_REVERSE
-    const uint32_t frame = gridDim.y - 1 - blockIdx.y;
-#else
-    const uint32_t frame = blockIdx.y;
-#endif
+    const uint32_t frame = blockIdx.y;   // (last-read-first order over the group's frames: 1.5 % slower, the Infinity Cache keeps nothing of the sums pass)
     const GrFrameState &st = state[frame];
     if (st.status != 0) return;   // analysis failed -> frame left unmodified (rmsd.rs:91)
     float *xyz = frames + (size_t)(first_slot + frame) * frame_stride;
