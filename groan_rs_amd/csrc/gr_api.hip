@@ -403,11 +403,15 @@ static int center_redo_fallbacks(gr_ctx *c, uint32_t s0, uint32_t nb, const GrSe
 
 }  // namespace
 
+// Nothing may unwind through the C ABI: every multi-line entry point below is a function-try-block.  What can throw in here
+// is memory exhaustion in the host containers (std::bad_alloc) and std::system_error from the worker threads.
+static int gr_abi_guard() { return GR_E_HIP; }
+
 extern "C" {
 
 const char *gr_version(void) { return "groan_hip 0.1.0 (gfx950)"; }
 
-const char *gr_status_string(int s) {
+const char *gr_status_string(int s) try {
     switch (s) {
     case GR_OK: return "ok";
     case GR_E_NO_BOX: return "simulation box does not exist";
@@ -429,16 +433,16 @@ const char *gr_status_string(int s) {
     case GR_E_INVALID_NAME: return "invalid group name";
     default: return "unknown status";
     }
-}
+} catch (...) { return nullptr; }
 
-int gr_device_count(int *count) {
+int gr_device_count(int *count) try {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) { if (count) *count = 0; return GR_E_NO_DEVICE; }
     if (count) *count = n;
     return n > 0 ? GR_OK : GR_E_NO_DEVICE;
-}
+} catch (...) { return gr_abi_guard(); }
 
-gr_ctx *gr_ctx_create(int device, uint64_t n_atoms, uint32_t n_slots, int *status) {
+gr_ctx *gr_ctx_create(int device, uint64_t n_atoms, uint32_t n_slots, int *status) try {
     int dummy; if (!status) status = &dummy;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) { *status = GR_E_NO_DEVICE; return nullptr; }
@@ -503,9 +507,9 @@ gr_ctx *gr_ctx_create(int device, uint64_t n_atoms, uint32_t n_slots, int *statu
     install_group(c, "all", all);
     *status = GR_OK;
     return c;
-}
+} catch (...) { return nullptr; }
 
-void gr_ctx_destroy(gr_ctx *c) {
+void gr_ctx_destroy(gr_ctx *c) try {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
@@ -551,7 +555,7 @@ void gr_ctx_destroy(gr_ctx *c) {
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
-}
+} catch (...) { }
 
 const char *gr_last_error(const gr_ctx *c) { return c ? c->err.c_str() : "null context"; }
 uint64_t gr_last_error_index(const gr_ctx *c) { return c ? c->err_index : 0; }
@@ -560,86 +564,86 @@ int gr_ctx_set_strict_orthogonal(gr_ctx *c, int on) { if (!c) return GR_E_INVALI
 uint64_t gr_n_atoms(const gr_ctx *c) { return c ? c->n : 0; }
 uint32_t gr_n_slots(const gr_ctx *c) { return c ? c->n_slots : 0; }
 
-int gr_sync(gr_ctx *c) {
+int gr_sync(gr_ctx *c) try {
     if (!c) return GR_E_INVALID_ARG;
     HIPCHK(c, sync_ingest(c));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream2));
     return GR_OK;
-}
+} catch (...) { return gr_abi_guard(); }
 
-int gr_set_masses(gr_ctx *c, const float *masses, uint64_t n) {
+int gr_set_masses(gr_ctx *c, const float *masses, uint64_t n) try {
     if (!c || !masses || n != c->n) return c ? fail(c, GR_E_INVALID_ARG, "masses: size mismatch") : GR_E_INVALID_ARG;
     c->masses_host.assign(masses, masses + n);
     HIPCHK(c, hipMemcpyAsync(c->masses, masses, n * sizeof(float), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return GR_OK;
-}
+} catch (...) { return gr_abi_guard(); }
 
 /* ------------------------------------------------------------ containers */
-size_t gr_container_from_indices(const uint64_t *indices, size_t n, uint64_t n_atoms, uint64_t *os, uint64_t *oe) {
+size_t gr_container_from_indices(const uint64_t *indices, size_t n, uint64_t n_atoms, uint64_t *os, uint64_t *oe) try {
     return grc::store(grc::from_indices(std::vector<uint64_t>(indices, indices + n), n_atoms), os, oe);
-}
-size_t gr_container_from_ranges(const uint64_t *s, const uint64_t *e, size_t n, uint64_t n_atoms, uint64_t *os, uint64_t *oe) {
+} catch (...) { return 0; }
+size_t gr_container_from_ranges(const uint64_t *s, const uint64_t *e, size_t n, uint64_t n_atoms, uint64_t *os, uint64_t *oe) try {
     return grc::store(grc::from_ranges(s, e, n, n_atoms), os, oe);
-}
+} catch (...) { return 0; }
 size_t gr_container_union(const uint64_t *s1, const uint64_t *e1, size_t n1, const uint64_t *s2, const uint64_t *e2, size_t n2,
-                          uint64_t *os, uint64_t *oe) {
+                          uint64_t *os, uint64_t *oe) try {
     return grc::store(grc::set_union(grc::make(s1, e1, n1), grc::make(s2, e2, n2)), os, oe);
-}
+} catch (...) { return 0; }
 size_t gr_container_intersection(const uint64_t *s1, const uint64_t *e1, size_t n1, const uint64_t *s2, const uint64_t *e2, size_t n2,
-                                 uint64_t *os, uint64_t *oe) {
+                                 uint64_t *os, uint64_t *oe) try {
     return grc::store(grc::set_intersection(grc::make(s1, e1, n1), grc::make(s2, e2, n2)), os, oe);
-}
+} catch (...) { return 0; }
 uint64_t gr_container_n_atoms(const uint64_t *s, const uint64_t *e, size_t n) { return grc::n_atoms(grc::make(s, e, n)); }
-size_t gr_container_expand(const uint64_t *s, const uint64_t *e, size_t n, uint64_t *out) {
+size_t gr_container_expand(const uint64_t *s, const uint64_t *e, size_t n, uint64_t *out) try {
     std::vector<uint64_t> v = grc::expand(grc::make(s, e, n));
     for (size_t k = 0; k < v.size(); ++k) out[k] = v[k];
     return v.size();
-}
+} catch (...) { return 0; }
 int gr_container_isin(const uint64_t *s, const uint64_t *e, size_t n, uint64_t index) { return grc::isin(grc::make(s, e, n), index) ? 1 : 0; }
 
 /* ------------------------------------------------------------ groups */
-int gr_group_create_from_ranges(gr_ctx *c, const char *name, const uint64_t *s, const uint64_t *e, size_t n) {
+int gr_group_create_from_ranges(gr_ctx *c, const char *name, const uint64_t *s, const uint64_t *e, size_t n) try {
     if (!c) return GR_E_INVALID_ARG;
     (void)hipSetDevice(c->device);
     return install_group(c, name, grc::from_ranges(s, e, n, c->n));
-}
-int gr_group_create_from_indices(gr_ctx *c, const char *name, const uint64_t *indices, size_t n) {
+} catch (...) { return gr_abi_guard(); }
+int gr_group_create_from_indices(gr_ctx *c, const char *name, const uint64_t *indices, size_t n) try {
     if (!c) return GR_E_INVALID_ARG;
     (void)hipSetDevice(c->device);
     return install_group(c, name, grc::from_indices(std::vector<uint64_t>(indices, indices + n), c->n));
-}
-int gr_group_remove(gr_ctx *c, const char *name) {
+} catch (...) { return gr_abi_guard(); }
+int gr_group_remove(gr_ctx *c, const char *name) try {
     if (!c || !name) return GR_E_INVALID_ARG;
     auto it = c->groups.find(name);
     if (it == c->groups.end()) return fail(c, GR_E_GROUP_NOT_FOUND, name);
     if (it->second.idx_dev) (void)hipFree(it->second.idx_dev);
     c->groups.erase(it);
     return GR_OK;
-}
+} catch (...) { return gr_abi_guard(); }
 int gr_group_exists(const gr_ctx *c, const char *name) { return (c && find_group(c, name)) ? 1 : 0; }
-int gr_group_n_atoms(const gr_ctx *c, const char *name, uint64_t *n) {
+int gr_group_n_atoms(const gr_ctx *c, const char *name, uint64_t *n) try {
     const Group *g = c ? find_group(c, name) : nullptr;
     if (!g) return GR_E_GROUP_NOT_FOUND;
     if (n) *n = g->n;
     return GR_OK;
-}
-int gr_group_n_blocks(const gr_ctx *c, const char *name, size_t *nb) {
+} catch (...) { return gr_abi_guard(); }
+int gr_group_n_blocks(const gr_ctx *c, const char *name, size_t *nb) try {
     const Group *g = c ? find_group(c, name) : nullptr;
     if (!g) return GR_E_GROUP_NOT_FOUND;
     if (nb) *nb = g->blocks.size();
     return GR_OK;
-}
-int gr_group_blocks(const gr_ctx *c, const char *name, uint64_t *os, uint64_t *oe) {
+} catch (...) { return gr_abi_guard(); }
+int gr_group_blocks(const gr_ctx *c, const char *name, uint64_t *os, uint64_t *oe) try {
     const Group *g = c ? find_group(c, name) : nullptr;
     if (!g) return GR_E_GROUP_NOT_FOUND;
     grc::store(g->blocks, os, oe);
     return GR_OK;
-}
+} catch (...) { return gr_abi_guard(); }
 
 /* ------------------------------------------------------------ frames */
-int gr_frame_upload(gr_ctx *c, uint32_t slot, const float *xyz, const float *box9) {
+int gr_frame_upload(gr_ctx *c, uint32_t slot, const float *xyz, const float *box9) try {
     int st = slot_check(c, slot); if (st) return st;
     if (!xyz) return fail(c, GR_E_INVALID_ARG, "xyz is NULL");
     (void)hipSetDevice(c->device);
@@ -653,13 +657,13 @@ int gr_frame_upload(gr_ctx *c, uint32_t slot, const float *xyz, const float *box
     HIPCHK(c, hipEventRecord(c->ev_ready[slot], c->copy_stream));
     c->upload_pending[slot] = 1;
     return GR_OK;
-}
-int gr_frame_upload_wait(gr_ctx *c, uint32_t slot) {
+} catch (...) { return gr_abi_guard(); }
+int gr_frame_upload_wait(gr_ctx *c, uint32_t slot) try {
     int st = slot_check(c, slot); if (st) return st;
     if (c->ev_ready[slot]) HIPCHK(c, hipEventSynchronize(c->ev_ready[slot]));
     return GR_OK;
-}
-int gr_frame_download(gr_ctx *c, uint32_t slot, float *xyz) {
+} catch (...) { return gr_abi_guard(); }
+int gr_frame_download(gr_ctx *c, uint32_t slot, float *xyz) try {
     int st = slot_check(c, slot); if (st) return st;
     if (!xyz) return fail(c, GR_E_INVALID_ARG, "xyz is NULL");
     (void)hipSetDevice(c->device);
@@ -667,21 +671,21 @@ int gr_frame_download(gr_ctx *c, uint32_t slot, float *xyz) {
     HIPCHK(c, hipMemcpyAsync(xyz, c->frames + (size_t)slot * c->frame_stride, c->n * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return GR_OK;
-}
-int gr_frame_set_box(gr_ctx *c, uint32_t slot, const float *box9) {
+} catch (...) { return gr_abi_guard(); }
+int gr_frame_set_box(gr_ctx *c, uint32_t slot, const float *box9) try {
     int st = slot_check(c, slot); if (st) return st;
     (void)hipSetDevice(c->device);
     HIPCHK(c, sync_ingest(c));
     HIPCHK(c, hipStreamSynchronize(c->stream));   // boxes_host[slot] may still feed an earlier async copy
     return set_box(c, slot, box9);
-}
-int gr_frame_get_box(const gr_ctx *c, uint32_t slot, float box9[9]) {
+} catch (...) { return gr_abi_guard(); }
+int gr_frame_get_box(const gr_ctx *c, uint32_t slot, float box9[9]) try {
     if (!c || slot >= c->n_slots) return GR_E_INVALID_ARG;
     if (!c->box9_set[slot]) return GR_E_NO_BOX;
     memcpy(box9, &c->box9_host[9 * (size_t)slot], 9 * sizeof(float));
     return GR_OK;
-}
-int gr_frame_copy(gr_ctx *c, uint32_t dst, uint32_t src) {
+} catch (...) { return gr_abi_guard(); }
+int gr_frame_copy(gr_ctx *c, uint32_t dst, uint32_t src) try {
     int st = slot_check(c, dst); if (st) return st;
     st = slot_check(c, src); if (st) return st;
     (void)hipSetDevice(c->device);
@@ -690,12 +694,12 @@ int gr_frame_copy(gr_ctx *c, uint32_t dst, uint32_t src) {
                              c->frame_stride * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return set_box(c, dst, c->box9_set[src] ? &c->box9_host[9 * (size_t)src] : nullptr);
-}
+} catch (...) { return gr_abi_guard(); }
 void *gr_host_alloc(size_t bytes) { void *p = nullptr; return hipHostMalloc(&p, bytes, hipHostMallocDefault) == hipSuccess ? p : nullptr; }
 void gr_host_free(void *p) { if (p) (void)hipHostFree(p); }
 
 /* ------------------------------------------------------------ centres */
-int gr_group_center(gr_ctx *c, uint32_t slot, const char *group, int kind, int weighted, float out[3]) {
+int gr_group_center(gr_ctx *c, uint32_t slot, const char *group, int kind, int weighted, float out[3]) try {
     int st = slot_check(c, slot); if (st) return st;
     (void)hipSetDevice(c->device);
     const Group *g = find_group(c, group);
@@ -718,10 +722,10 @@ int gr_group_center(gr_ctx *c, uint32_t slot, const char *group, int kind, int w
     st = frame_status(c, c->state_host[0]); if (st) return st;
     if (out) { out[0] = c->state_host[0].com[0]; out[1] = c->state_host[0].com[1]; out[2] = c->state_host[0].com[2]; }
     return GR_OK;
-}
+} catch (...) { return gr_abi_guard(); }
 
 /* ------------------------------------------------------------ distances */
-int gr_group_distance(gr_ctx *c, uint32_t slot, const char *g1, const char *g2, int dim, float *out) {
+int gr_group_distance(gr_ctx *c, uint32_t slot, const char *g1, const char *g2, int dim, float *out) try {
     float c1[3], c2[3];
     int st = gr_group_center(c, slot, g1, GR_CENTER_PBC, 0, c1); if (st) return st;   // analysis.rs:354-355
     st = gr_group_center(c, slot, g2, GR_CENTER_PBC, 0, c2); if (st) return st;
@@ -729,7 +733,7 @@ int gr_group_distance(gr_ctx *c, uint32_t slot, const char *g1, const char *g2, 
     if (dim < 0 || dim > 7) return fail(c, GR_E_INVALID_ARG, "bad dimension");
     if (out) *out = gr_distance(c1[0], c1[1], c1[2], c2[0], c2[1], c2[2], dim, c->boxes_host[slot]);
     return GR_OK;
-}
+} catch (...) { return gr_abi_guard(); }
 
 static void batch_prechecks(gr_ctx *c, uint32_t s0, uint32_t nb, bool need_box, std::vector<int> &pre, std::vector<std::string> &msg);
 // pair distances of `nb` consecutive slots in one launch; matrices `out_stride` floats apart; -> bad_host[4 f + 0 / 1]
@@ -775,7 +779,7 @@ static int pairdist_reserve(gr_ctx *c, size_t need) {
 }
 
 int gr_group_all_distances_batch_device(gr_ctx *c, uint32_t first_slot, uint32_t n_frames, const char *g1, const char *g2, int dim,
-                                        float **out_dev, uint64_t *n1, uint64_t *n2, int *status_out) {
+                                        float **out_dev, uint64_t *n1, uint64_t *n2, int *status_out) try {
     int st = slot_check(c, first_slot, n_frames); if (st) return st;
     (void)hipSetDevice(c->device);
     const Group *a = find_group(c, g1); if (!a) return fail(c, GR_E_GROUP_NOT_FOUND, g1 ? g1 : "(null)");
@@ -803,10 +807,10 @@ int gr_group_all_distances_batch_device(gr_ctx *c, uint32_t first_slot, uint32_t
     if (n2) *n2 = b->n;
     if (first_err != GR_OK) { c->err = first_msg; c->err_index = first_idx; }
     return first_err;
-}
+} catch (...) { return gr_abi_guard(); }
 
 int gr_group_all_distances_device(gr_ctx *c, uint32_t slot, const char *g1, const char *g2, int dim,
-                                  float **out_dev, uint64_t *n1, uint64_t *n2) {
+                                  float **out_dev, uint64_t *n1, uint64_t *n2) try {
     int st = slot_check(c, slot); if (st) return st;
     (void)hipSetDevice(c->device);
     const Group *a = find_group(c, g1); if (!a) return fail(c, GR_E_GROUP_NOT_FOUND, g1 ? g1 : "(null)");
@@ -819,18 +823,18 @@ int gr_group_all_distances_device(gr_ctx *c, uint32_t slot, const char *g1, cons
     if (n1) *n1 = a->n;
     if (n2) *n2 = b->n;
     return GR_OK;
-}
+} catch (...) { return gr_abi_guard(); }
 
-int gr_device_read(gr_ctx *c, const void *dev, void *host, size_t bytes) {
+int gr_device_read(gr_ctx *c, const void *dev, void *host, size_t bytes) try {
     if (!c) return GR_E_INVALID_ARG;
     if (!dev || !host) return fail(c, GR_E_INVALID_ARG, "NULL pointer");
     (void)hipSetDevice(c->device);
     HIPCHK(c, hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return GR_OK;
-}
+} catch (...) { return gr_abi_guard(); }
 
-int gr_group_all_distances(gr_ctx *c, uint32_t slot, const char *g1, const char *g2, int dim, float *out_host, size_t cap) {
+int gr_group_all_distances(gr_ctx *c, uint32_t slot, const char *g1, const char *g2, int dim, float *out_host, size_t cap) try {
     float *dev = nullptr; uint64_t n1 = 0, n2 = 0;
     int st = gr_group_all_distances_device(c, slot, g1, g2, dim, &dev, &n1, &n2); if (st) return st;
     if ((size_t)(n1 * n2) > cap || !out_host) return fail(c, GR_E_INVALID_ARG, "output buffer too small");
@@ -839,9 +843,9 @@ int gr_group_all_distances(gr_ctx *c, uint32_t slot, const char *g1, const char 
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
     return GR_OK;
-}
+} catch (...) { return gr_abi_guard(); }
 
-int gr_atoms_distance(gr_ctx *c, uint32_t slot, uint64_t i1, uint64_t i2, int dim, float *out) {
+int gr_atoms_distance(gr_ctx *c, uint32_t slot, uint64_t i1, uint64_t i2, int dim, float *out) try {
     int st = slot_check(c, slot); if (st) return st;
     (void)hipSetDevice(c->device);
     if (i1 >= c->n) return fail(c, GR_E_OUT_OF_RANGE, "atom index out of range", i1);   // analysis.rs:465-466
@@ -855,7 +859,7 @@ int gr_atoms_distance(gr_ctx *c, uint32_t slot, uint64_t i1, uint64_t i2, int di
     HIPCHK(c, hipMemcpy(&v, c->pd_out, sizeof(float), hipMemcpyDeviceToHost));
     if (out) *out = v;
     return GR_OK;
-}
+} catch (...) { return gr_abi_guard(); }
 
 /* ------------------------------------------------------------ geometry selection */
 static bool name_is_valid(const char *name) {   // auxiliary.rs:37-51
@@ -867,22 +871,22 @@ static bool name_is_valid(const char *name) {   // auxiliary.rs:37-51
     }
     return !blank;
 }
-int gr_shape_sphere(gr_shape *s, const float pos[3], float radius) {
+int gr_shape_sphere(gr_shape *s, const float pos[3], float radius) try {
     if (!s || !pos) return GR_E_INVALID_ARG;
     memset(s, 0, sizeof *s); s->kind = GR_SHAPE_SPHERE; memcpy(s->position, pos, 12); s->size[0] = radius; return GR_OK;
-}
-int gr_shape_rectangular(gr_shape *s, const float pos[3], float x, float y, float z) {
+} catch (...) { return gr_abi_guard(); }
+int gr_shape_rectangular(gr_shape *s, const float pos[3], float x, float y, float z) try {
     if (!s || !pos) return GR_E_INVALID_ARG;
     memset(s, 0, sizeof *s); s->kind = GR_SHAPE_RECTANGULAR; memcpy(s->position, pos, 12); s->size[0] = x; s->size[1] = y; s->size[2] = z; return GR_OK;
-}
-int gr_shape_cylinder(gr_shape *s, const float pos[3], float radius, float height, int orientation) {
+} catch (...) { return gr_abi_guard(); }
+int gr_shape_cylinder(gr_shape *s, const float pos[3], float radius, float height, int orientation) try {
     if (!s || !pos || orientation < GR_DIM_X || orientation > GR_DIM_Z) return GR_E_INVALID_ARG;
     memset(s, 0, sizeof *s); s->kind = GR_SHAPE_CYLINDER; memcpy(s->position, pos, 12); s->size[0] = radius; s->size[1] = height;
     s->orientation = orientation;
     s->plane = orientation == GR_DIM_X ? GR_DIM_YZ : (orientation == GR_DIM_Y ? GR_DIM_XZ : GR_DIM_XY);
     return GR_OK;
-}
-int gr_shape_triangular_prism(gr_shape *s, const float b1[3], const float b2[3], const float b3[3], float height) {
+} catch (...) { return gr_abi_guard(); }
+int gr_shape_triangular_prism(gr_shape *s, const float b1[3], const float b2[3], const float b3[3], float height) try {
     if (!s || !b1 || !b2 || !b3) return GR_E_INVALID_ARG;
     static const int orient[3] = { GR_DIM_X, GR_DIM_Y, GR_DIM_Z }, plane[3] = { GR_DIM_YZ, GR_DIM_XZ, GR_DIM_XY };
     int found = -1;
@@ -893,7 +897,7 @@ int gr_shape_triangular_prism(gr_shape *s, const float b1[3], const float b2[3],
     memcpy(s->position, b1, 12); memcpy(s->base2, b2, 12); memcpy(s->base3, b3, 12); s->size[0] = height;
     s->orientation = orient[found]; s->plane = plane[found];
     return GR_OK;
-}
+} catch (...) { return gr_abi_guard(); }
 static bool shape_to_dev(const gr_shape &h, int naive, GrShapeDev *d) {
     if (h.kind < GR_SHAPE_SPHERE || h.kind > GR_SHAPE_TRIANGULAR_PRISM) return false;
     if (naive && h.kind == GR_SHAPE_TRIANGULAR_PRISM) return false;                 // no NaiveShape for the prism (shape.rs:466-505)
@@ -904,7 +908,7 @@ static bool shape_to_dev(const gr_shape &h, int naive, GrShapeDev *d) {
     d->orientation = h.orientation; d->plane = h.plane;
     return true;
 }
-int gr_shape_inside(const gr_shape *s, const float point[3], const float box9[9], int naive, int *inside) {
+int gr_shape_inside(const gr_shape *s, const float point[3], const float box9[9], int naive, int *inside) try {
     if (!s || !point || !inside || (!naive && !box9)) return GR_E_INVALID_ARG;
     GrShapeDev d;
     if (!shape_to_dev(*s, naive, &d)) return GR_E_INVALID_ARG;
@@ -914,8 +918,8 @@ int gr_shape_inside(const gr_shape *s, const float point[3], const float box9[9]
     if (!b.ortho) return GR_E_NOT_ORTHOGONAL;
     *inside = gr_shape_inside_pbc(d, point[0], point[1], point[2], b) ? 1 : 0;
     return GR_OK;
-}
-int gr_group_create_from_geometries(gr_ctx *c, uint32_t slot, const char *name, const char *source, const gr_shape *shapes, size_t ns, int naive) {
+} catch (...) { return gr_abi_guard(); }
+int gr_group_create_from_geometries(gr_ctx *c, uint32_t slot, const char *name, const char *source, const gr_shape *shapes, size_t ns, int naive) try {
     int st = slot_check(c, slot); if (st) return st;
     (void)hipSetDevice(c->device);
     if (!name_is_valid(name)) return fail(c, GR_E_INVALID_NAME, name ? name : "(null)");                 // groups.rs:100-102
@@ -950,7 +954,7 @@ int gr_group_create_from_geometries(gr_ctx *c, uint32_t slot, const char *name, 
                 if ((mask[j >> 6] >> (j & 63)) & 1ull) picked.push_back(a);
     }
     return install_group(c, name, grc::from_indices(picked, c->n));
-}
+} catch (...) { return gr_abi_guard(); }
 
 /* ------------------------------------------------------------ translate / wrap / centre */
 static int translate_impl(gr_ctx *c, uint32_t slot, const char *group, const float *v, int use_state, int dim_mask) {
@@ -971,19 +975,19 @@ static int translate_impl(gr_ctx *c, uint32_t slot, const char *group, const flo
     return GR_OK;
 }
 
-int gr_group_translate(gr_ctx *c, uint32_t slot, const char *group, const float v[3]) {
+int gr_group_translate(gr_ctx *c, uint32_t slot, const char *group, const float v[3]) try {
     int st = slot_check(c, slot); if (st) return st;
     if (!v) return fail(c, GR_E_INVALID_ARG, "vector is NULL");
     (void)hipSetDevice(c->device);
     return translate_impl(c, slot, group, v, 0, 7);
-}
-int gr_group_wrap(gr_ctx *c, uint32_t slot, const char *group) {
+} catch (...) { return gr_abi_guard(); }
+int gr_group_wrap(gr_ctx *c, uint32_t slot, const char *group) try {
     int st = slot_check(c, slot); if (st) return st;
     (void)hipSetDevice(c->device);
     const float z[3] = { 0.f, 0.f, 0.f };
     return translate_impl(c, slot, group, z, 0, 7);
-}
-int gr_atoms_center(gr_ctx *c, uint32_t slot, const char *ref_group, int dim, int weighted) {
+} catch (...) { return gr_abi_guard(); }
+int gr_atoms_center(gr_ctx *c, uint32_t slot, const char *ref_group, int dim, int weighted) try {
     int st = slot_check(c, slot); if (st) return st;
     (void)hipSetDevice(c->device);
     const Group *g = find_group(c, ref_group);
@@ -998,11 +1002,11 @@ int gr_atoms_center(gr_ctx *c, uint32_t slot, const char *ref_group, int dim, in
     st = fetch_states(c, 1); if (st) return st;
     st = frame_status(c, c->state_host[0]); if (st) return st;
     return translate_impl(c, slot, "all", nullptr, 1, mask[dim]);
-}
+} catch (...) { return gr_abi_guard(); }
 
 /* ------------------------------------------------------------ cut-off pair search */
 int gr_group_pairs_within(gr_ctx *c, uint32_t slot, const char *g1, const char *g2, float cutoff, uint64_t max_pairs,
-                          uint32_t *i_out, uint32_t *j_out, float *d_out, uint64_t *n_pairs) {
+                          uint32_t *i_out, uint32_t *j_out, float *d_out, uint64_t *n_pairs) try {
     int st = slot_check(c, slot); if (st) return st;
     (void)hipSetDevice(c->device);
     const Group *a = find_group(c, g1); if (!a) return fail(c, GR_E_GROUP_NOT_FOUND, g1 ? g1 : "(null)");
@@ -1075,7 +1079,7 @@ int gr_group_pairs_within(gr_ctx *c, uint32_t slot, const char *g1, const char *
     }
     cleanup();
     return GR_OK;
-}
+} catch (...) { return gr_abi_guard(); }
 
 /* ------------------------------------------------------------ the same per-frame calls over a batch of slots */
 // host checks of one batch in the reference's order; pre[f] = GR_OK or the frame's error (messages kept for the first)
@@ -1088,7 +1092,7 @@ static void batch_prechecks(gr_ctx *c, uint32_t s0, uint32_t nb, bool need_box, 
         if (s != GR_OK) msg[f] = c->err;
     }
 }
-int gr_group_center_batch(gr_ctx *c, uint32_t first_slot, uint32_t n_frames, const char *group, int kind, int weighted, float *out, int *status_out) {
+int gr_group_center_batch(gr_ctx *c, uint32_t first_slot, uint32_t n_frames, const char *group, int kind, int weighted, float *out, int *status_out) try {
     int st = slot_check(c, first_slot, n_frames); if (st) return st;
     (void)hipSetDevice(c->device);
     const Group *g = find_group(c, group);
@@ -1122,7 +1126,7 @@ int gr_group_center_batch(gr_ctx *c, uint32_t first_slot, uint32_t n_frames, con
     }
     if (first_err != GR_OK) { c->err = first_msg; c->err_index = first_idx; }
     return first_err;
-}
+} catch (...) { return gr_abi_guard(); }
 // translate / wrap / centre a batch of frames: pre[] carries the host checks, frames that failed are left untouched
 static int translate_batch(gr_ctx *c, uint32_t s0, uint32_t nb, const Group *g, const float *v, int mode, int dim_mask,
                            const std::vector<int> &pre, const std::vector<std::string> &msg, int *status_out, int &first_err, std::string &first_msg, uint64_t &first_idx) {
@@ -1176,32 +1180,32 @@ static int translate_batch_api(gr_ctx *c, uint32_t first_slot, uint32_t n_frames
     if (first_err != GR_OK) { c->err = first_msg; c->err_index = first_idx; }
     return first_err;
 }
-int gr_group_translate_batch(gr_ctx *c, uint32_t first_slot, uint32_t n_frames, const char *group, const float v[3], int *status_out) {
+int gr_group_translate_batch(gr_ctx *c, uint32_t first_slot, uint32_t n_frames, const char *group, const float v[3], int *status_out) try {
     if (!c) return GR_E_INVALID_ARG;
     if (!v) return fail(c, GR_E_INVALID_ARG, "vector is NULL");
     return translate_batch_api(c, first_slot, n_frames, group, v, nullptr, 7, 0, status_out);
-}
-int gr_group_wrap_batch(gr_ctx *c, uint32_t first_slot, uint32_t n_frames, const char *group, int *status_out) {
+} catch (...) { return gr_abi_guard(); }
+int gr_group_wrap_batch(gr_ctx *c, uint32_t first_slot, uint32_t n_frames, const char *group, int *status_out) try {
     if (!c) return GR_E_INVALID_ARG;
     const float z[3] = { 0.f, 0.f, 0.f };
     return translate_batch_api(c, first_slot, n_frames, group, z, nullptr, 7, 0, status_out);
-}
-int gr_atoms_center_batch(gr_ctx *c, uint32_t first_slot, uint32_t n_frames, const char *ref_group, int dim, int weighted, int *status_out) {
+} catch (...) { return gr_abi_guard(); }
+int gr_atoms_center_batch(gr_ctx *c, uint32_t first_slot, uint32_t n_frames, const char *ref_group, int dim, int weighted, int *status_out) try {
     if (!c) return GR_E_INVALID_ARG;
     if (!ref_group) return fail(c, GR_E_GROUP_NOT_FOUND, "(null)");
     return translate_batch_api(c, first_slot, n_frames, "all", nullptr, ref_group, dim, weighted, status_out);
-}
+} catch (...) { return gr_abi_guard(); }
 
 /* ------------------------------------------------------------ RMSD */
-void gr_rmsd_plan_destroy(gr_rmsd_plan *p) {
+void gr_rmsd_plan_destroy(gr_rmsd_plan *p) try {
     if (!p) return;
     if (p->target) (void)hipSetDevice(p->target->device);
     if (p->p_dev) (void)hipFree(p->p_dev);
     if (p->w_dev) (void)hipFree(p->w_dev);
     delete p;
-}
+} catch (...) { }
 
-gr_rmsd_plan *gr_rmsd_plan_create(gr_ctx *ref, uint32_t ref_slot, gr_ctx *target, const char *group, int *status) {
+gr_rmsd_plan *gr_rmsd_plan_create(gr_ctx *ref, uint32_t ref_slot, gr_ctx *target, const char *group, int *status) try {
     int dummy; if (!status) status = &dummy;
     if (!ref || !target || !group || ref_slot >= ref->n_slots) { *status = GR_E_INVALID_ARG; return nullptr; }
     if (ref->device != target->device) { *status = fail(ref, GR_E_INVALID_ARG, "reference and target live on different devices"); return nullptr; }
@@ -1244,7 +1248,7 @@ gr_rmsd_plan *gr_rmsd_plan_create(gr_ctx *ref, uint32_t ref_slot, gr_ctx *target
     for (uint64_t i : grc::expand(g->blocks)) p->w_host.push_back(ref->masses_host[i]);
     *status = GR_OK;
     return p;
-}
+} catch (...) { return nullptr; }
 
 uint32_t gr_rmsd_plan_last_fallbacks(const gr_rmsd_plan *p) { return p ? p->last_fallbacks : 0; }
 int gr_rmsd_plan_force_exact(gr_rmsd_plan *p, int on) { if (!p) return GR_E_INVALID_ARG; p->exact = on ? 1 : 0; return GR_OK; }
@@ -1559,7 +1563,7 @@ static int rmsd_batch_impl(gr_rmsd_plan *p, uint32_t first_slot, uint32_t n_fram
     return first_err;
 }
 
-int gr_rmsd_batch_begin(gr_rmsd_plan *p, uint32_t first_slot, uint32_t n, int fit) {
+int gr_rmsd_batch_begin(gr_rmsd_plan *p, uint32_t first_slot, uint32_t n, int fit) try {
     if (!p || !p->target) return GR_E_INVALID_ARG;
     gr_ctx *c = p->target;
     int st = slot_check(c, first_slot, n); if (st) return st;
@@ -1570,19 +1574,19 @@ int gr_rmsd_batch_begin(gr_rmsd_plan *p, uint32_t first_slot, uint32_t n, int fi
     st = segment_begin(p, first_slot, n, fit ? 1 : 0);
     if (st) p->pend.active = false;
     return st;
-}
-int gr_rmsd_batch_end(gr_rmsd_plan *p, float *rmsd_out, int *status_out, float *R_out) {
+} catch (...) { return gr_abi_guard(); }
+int gr_rmsd_batch_end(gr_rmsd_plan *p, float *rmsd_out, int *status_out, float *R_out) try {
     if (!p || !p->target) return GR_E_INVALID_ARG;
     (void)hipSetDevice(p->target->device);
     return segment_end(p, rmsd_out, status_out, R_out);
-}
+} catch (...) { return gr_abi_guard(); }
 
-int gr_rmsd_batch(gr_rmsd_plan *p, uint32_t first_slot, uint32_t n, float *rmsd_out, int *status_out, float *R_out) {
+int gr_rmsd_batch(gr_rmsd_plan *p, uint32_t first_slot, uint32_t n, float *rmsd_out, int *status_out, float *R_out) try {
     return rmsd_batch_impl(p, first_slot, n, rmsd_out, status_out, R_out, 0);
-}
-int gr_rmsd_fit_batch(gr_rmsd_plan *p, uint32_t first_slot, uint32_t n, float *rmsd_out, int *status_out) {
+} catch (...) { return gr_abi_guard(); }
+int gr_rmsd_fit_batch(gr_rmsd_plan *p, uint32_t first_slot, uint32_t n, float *rmsd_out, int *status_out) try {
     return rmsd_batch_impl(p, first_slot, n, rmsd_out, status_out, nullptr, 1);
-}
+} catch (...) { return gr_abi_guard(); }
 
 static int calc_rmsd_impl(gr_ctx *c, uint32_t slot, gr_ctx *ref, uint32_t ref_slot, const char *group, float *rmsd, float *R, int fit) {
     if (!c || !ref) return GR_E_INVALID_ARG;
@@ -1600,19 +1604,19 @@ static int calc_rmsd_impl(gr_ctx *c, uint32_t slot, gr_ctx *ref, uint32_t ref_sl
     if (R) memcpy(R, Rm, sizeof(Rm));
     return GR_OK;
 }
-int gr_calc_rmsd(gr_ctx *c, uint32_t slot, gr_ctx *ref, uint32_t ref_slot, const char *group, float *rmsd, float *R) {
+int gr_calc_rmsd(gr_ctx *c, uint32_t slot, gr_ctx *ref, uint32_t ref_slot, const char *group, float *rmsd, float *R) try {
     return calc_rmsd_impl(c, slot, ref, ref_slot, group, rmsd, R, 0);
-}
-int gr_calc_rmsd_and_fit(gr_ctx *c, uint32_t slot, gr_ctx *ref, uint32_t ref_slot, const char *group, float *rmsd) {
+} catch (...) { return gr_abi_guard(); }
+int gr_calc_rmsd_and_fit(gr_ctx *c, uint32_t slot, gr_ctx *ref, uint32_t ref_slot, const char *group, float *rmsd) try {
     return calc_rmsd_impl(c, slot, ref, ref_slot, group, rmsd, nullptr, 1);
-}
+} catch (...) { return gr_abi_guard(); }
 
 /* ------------------------------------------------------------ xtc reader (host; NEXT-1 of SURVEY.md section 8f) */
 struct gr_xtc { grx::File f; };
 
 static int xtc_status(int s) { return s == grx::XTC_OK ? GR_OK : (s == grx::XTC_E_IO ? GR_E_IO : (s == grx::XTC_E_BOX ? GR_E_UNSUPPORTED_BOX : GR_E_FORMAT)); }
 
-gr_xtc *gr_xtc_open(const char *path, int *status) {
+gr_xtc *gr_xtc_open(const char *path, int *status) try {
     int dummy; if (!status) status = &dummy;
     if (!path) { *status = GR_E_INVALID_ARG; return nullptr; }
     gr_xtc *x = new gr_xtc();
@@ -1620,7 +1624,7 @@ gr_xtc *gr_xtc_open(const char *path, int *status) {
     if (s != grx::XTC_OK) { *status = xtc_status(s); if (x->f.fd >= 0) ::close(x->f.fd); delete x; return nullptr; }
     *status = GR_OK;
     return x;
-}
+} catch (...) { return nullptr; }
 void gr_xtc_close(gr_xtc *x) { if (!x) return; if (x->f.fd >= 0) ::close(x->f.fd); delete x; }
 uint64_t gr_xtc_n_atoms(const gr_xtc *x) { return x ? x->f.natoms : 0; }
 uint64_t gr_xtc_n_frames(const gr_xtc *x) { return x ? x->f.frames.size() : 0; }
@@ -1632,7 +1636,7 @@ static int xtc_box9(const float m[9], float box9[9]) {
     return GR_OK;
 }
 
-int gr_xtc_frame_info(const gr_xtc *x, uint64_t frame, uint64_t *step, float *time, float box9[9], float *precision) {
+int gr_xtc_frame_info(const gr_xtc *x, uint64_t frame, uint64_t *step, float *time, float box9[9], float *precision) try {
     if (!x) return GR_E_INVALID_ARG;
     if (frame >= x->f.frames.size()) return GR_E_OUT_OF_RANGE;
     const grx::FrameIndex &fi = x->f.frames[frame];
@@ -1640,18 +1644,18 @@ int gr_xtc_frame_info(const gr_xtc *x, uint64_t frame, uint64_t *step, float *ti
     if (time) *time = fi.time;
     if (precision) *precision = fi.precision;
     return box9 ? xtc_box9(fi.box, box9) : GR_OK;
-}
+} catch (...) { return gr_abi_guard(); }
 
-int gr_xtc_read_frame(const gr_xtc *x, uint64_t frame, float *xyz, float box9[9], uint64_t *step, float *time, float *precision) {
+int gr_xtc_read_frame(const gr_xtc *x, uint64_t frame, float *xyz, float box9[9], uint64_t *step, float *time, float *precision) try {
     if (!x || !xyz) return GR_E_INVALID_ARG;
     int st = gr_xtc_frame_info(x, frame, step, time, box9, precision);
     if (st != GR_OK) return st;
     static thread_local std::vector<unsigned char> scratch;   // one bit-stream buffer per decoding thread
     return xtc_status(grx::decode_frame(x->f, x->f.frames[frame], xyz, scratch));
-}
+} catch (...) { return gr_abi_guard(); }
 
 int gr_xtc_read_frames_device(const gr_xtc *x, uint64_t first_frame, uint32_t n_frames, uint64_t frame_step, gr_ctx *c,
-                              uint32_t first_slot, int host_threads, uint64_t *steps, float *times) {
+                              uint32_t first_slot, int host_threads, uint64_t *steps, float *times) try {
     if (!x || !c) return GR_E_INVALID_ARG;
     int st = slot_check(c, first_slot, n_frames); if (st) return st;
     if (frame_step == 0) frame_step = 1;
@@ -1791,7 +1795,7 @@ int gr_xtc_read_frames_device(const gr_xtc *x, uint64_t first_frame, uint32_t n_
                 n_frames, nt, ms(t_call, t_begin), ms(t_begin, t_host), ns_read.load() * 1e-6 / n_frames, ns_skim.load() * 1e-6 / n_frames, ms(t_host, t_end));
     }
     return GR_OK;
-}
+} catch (...) { return gr_abi_guard(); }
 
 /* ------------------------------------------------------------ text front end */
 struct gr_structure { grt::Structure s; };
@@ -1801,7 +1805,7 @@ static int parse_result(int rc, const std::string &d, int *code, char *detail, s
     if (detail && cap) { const size_t n = std::min(cap - 1, d.size()); memcpy(detail, d.data(), n); detail[n] = 0; }
     return rc == grt::P_OK ? GR_OK : (rc == grt::P_FILE_NOT_FOUND ? GR_E_IO : GR_E_FORMAT);
 }
-int gr_gro_read(const char *path, gr_structure **out, int *code, char *detail, size_t cap) {
+int gr_gro_read(const char *path, gr_structure **out, int *code, char *detail, size_t cap) try {
     if (!path || !out) return GR_E_INVALID_ARG;
     *out = nullptr;
     gr_structure *s = new gr_structure();
@@ -1810,27 +1814,27 @@ int gr_gro_read(const char *path, gr_structure **out, int *code, char *detail, s
     if (rc != grt::P_OK) { delete s; return parse_result(rc, d, code, detail, cap); }
     *out = s;
     return parse_result(rc, d, code, detail, cap);
-}
+} catch (...) { return gr_abi_guard(); }
 void gr_structure_free(gr_structure *s) { delete s; }
 uint64_t gr_structure_n_atoms(const gr_structure *s) { return s ? s->s.atoms.size() : 0; }
 const char *gr_structure_title(const gr_structure *s) { return s ? s->s.title.c_str() : ""; }
-int gr_structure_box(const gr_structure *s, float box9[9]) {
+int gr_structure_box(const gr_structure *s, float box9[9]) try {
     if (!s || !box9) return GR_E_INVALID_ARG;
     if (!s->s.has_box) return GR_E_NO_BOX;
     memcpy(box9, s->s.box9, 9 * sizeof(float));
     return GR_OK;
-}
-int gr_structure_positions(const gr_structure *s, float *xyz) {
+} catch (...) { return gr_abi_guard(); }
+int gr_structure_positions(const gr_structure *s, float *xyz) try {
     if (!s || !xyz) return GR_E_INVALID_ARG;
     for (size_t i = 0; i < s->s.atoms.size(); ++i) memcpy(xyz + 3 * i, s->s.atoms[i].pos, 12);
     return GR_OK;
-}
-int gr_structure_velocities(const gr_structure *s, float *vel) {
+} catch (...) { return gr_abi_guard(); }
+int gr_structure_velocities(const gr_structure *s, float *vel) try {
     if (!s || !vel) return GR_E_INVALID_ARG;
     for (size_t i = 0; i < s->s.atoms.size(); ++i) memcpy(vel + 3 * i, s->s.atoms[i].vel, 12);
     return GR_OK;
-}
-int gr_structure_atom(const gr_structure *s, uint64_t i, uint64_t *resid, uint64_t *atomid, char resname[8], char atomname[8]) {
+} catch (...) { return gr_abi_guard(); }
+int gr_structure_atom(const gr_structure *s, uint64_t i, uint64_t *resid, uint64_t *atomid, char resname[8], char atomname[8]) try {
     if (!s) return GR_E_INVALID_ARG;
     if (i >= s->s.atoms.size()) return GR_E_OUT_OF_RANGE;
     const grt::Atom &a = s->s.atoms[i];
@@ -1839,8 +1843,8 @@ int gr_structure_atom(const gr_structure *s, uint64_t i, uint64_t *resid, uint64
     if (resname) { strncpy(resname, a.resname.c_str(), 7); resname[7] = 0; }
     if (atomname) { strncpy(atomname, a.atomname.c_str(), 7); atomname[7] = 0; }
     return GR_OK;
-}
-int gr_ndx_read(const char *path, uint64_t n_atoms, gr_ndx **out, int *code, char *detail, size_t cap) {
+} catch (...) { return gr_abi_guard(); }
+int gr_ndx_read(const char *path, uint64_t n_atoms, gr_ndx **out, int *code, char *detail, size_t cap) try {
     if (!path || !out) return GR_E_INVALID_ARG;
     *out = nullptr;
     gr_ndx *x = new gr_ndx();
@@ -1849,17 +1853,17 @@ int gr_ndx_read(const char *path, uint64_t n_atoms, gr_ndx **out, int *code, cha
     if (rc != grt::P_OK) { delete x; return parse_result(rc, d, code, detail, cap); }
     *out = x;
     return parse_result(rc, d, code, detail, cap);
-}
+} catch (...) { return gr_abi_guard(); }
 void gr_ndx_free(gr_ndx *x) { delete x; }
 size_t gr_ndx_n_groups(const gr_ndx *x) { return x ? x->g.size() : 0; }
 const char *gr_ndx_group_name(const gr_ndx *x, size_t g) { return (x && g < x->g.size()) ? x->g[g].name.c_str() : ""; }
 size_t gr_ndx_group_size(const gr_ndx *x, size_t g) { return (x && g < x->g.size()) ? x->g[g].indices.size() : 0; }
-int gr_ndx_group_indices(const gr_ndx *x, size_t g, uint64_t *out) {
+int gr_ndx_group_indices(const gr_ndx *x, size_t g, uint64_t *out) try {
     if (!x || g >= x->g.size() || !out) return GR_E_INVALID_ARG;
     memcpy(out, x->g[g].indices.data(), x->g[g].indices.size() * sizeof(uint64_t));
     return GR_OK;
-}
-int gr_ndx_install(const gr_ndx *x, gr_ctx *c, size_t *n_invalid, size_t *n_dup) {
+} catch (...) { return gr_abi_guard(); }
+int gr_ndx_install(const gr_ndx *x, gr_ctx *c, size_t *n_invalid, size_t *n_dup) try {
     if (!x || !c) return GR_E_INVALID_ARG;
     (void)hipSetDevice(c->device);
     std::set<std::string> invalid, dup;
@@ -1872,40 +1876,40 @@ int gr_ndx_install(const gr_ndx *x, gr_ctx *c, size_t *n_invalid, size_t *n_dup)
     if (n_invalid) *n_invalid = invalid.size();
     if (n_dup) *n_dup = dup.size();
     return GR_OK;
-}
+} catch (...) { return gr_abi_guard(); }
 
 /* ------------------------------------------------------------ xtc writer */
 struct gr_xtc_writer { FILE *fp = nullptr; };
 
-gr_xtc_writer *gr_xtc_writer_open(const char *path, int *status) {
+gr_xtc_writer *gr_xtc_writer_open(const char *path, int *status) try {
     int dummy; if (!status) status = &dummy;
     if (!path) { *status = GR_E_INVALID_ARG; return nullptr; }
     FILE *fp = fopen(path, "wb");
     if (!fp) { *status = GR_E_IO; return nullptr; }
     gr_xtc_writer *w = new gr_xtc_writer(); w->fp = fp; *status = GR_OK;
     return w;
-}
-int gr_xtc_writer_close(gr_xtc_writer *w) {
+} catch (...) { return nullptr; }
+int gr_xtc_writer_close(gr_xtc_writer *w) try {
     if (!w) return GR_E_INVALID_ARG;
     const int rc = w->fp ? fclose(w->fp) : 0;
     delete w;
     return rc == 0 ? GR_OK : GR_E_IO;
-}
+} catch (...) { return gr_abi_guard(); }
 // gro-order box9 -> rows = box vectors (simbox2matrix, xdrfile.rs:188-200); NULL -> zero matrix
 static void box9_rows(const float *b, float m[9]) {
     if (!b) { memset(m, 0, 9 * sizeof(float)); return; }
     m[0] = b[0]; m[1] = b[3]; m[2] = b[4]; m[3] = b[5]; m[4] = b[1]; m[5] = b[6]; m[6] = b[7]; m[7] = b[8]; m[8] = b[2];
 }
-int gr_xtc_write_frame(gr_xtc_writer *w, uint64_t n, const float *xyz, const float box9[9], int64_t step, float time, float precision) {
+int gr_xtc_write_frame(gr_xtc_writer *w, uint64_t n, const float *xyz, const float box9[9], int64_t step, float time, float precision) try {
     if (!w || !w->fp || (!xyz && n) || n > 0x7fffffffull) return GR_E_INVALID_ARG;
     float m[9]; box9_rows(box9, m);
     std::vector<unsigned char> out; grx::EncodedFrame sc; std::vector<int> ints;
     // coordinate x precision beyond the format's 32-bit integers (or NaN in y / z): nothing is written
     if (!grx::serialise_frame(out, (uint32_t)n, (int32_t)step, time, m, xyz, precision, sc, ints)) return GR_E_OUT_OF_RANGE;
     return fwrite(out.data(), 1, out.size(), w->fp) == out.size() ? GR_OK : GR_E_IO;
-}
+} catch (...) { return gr_abi_guard(); }
 int gr_xtc_write_slots(gr_xtc_writer *w, gr_ctx *c, uint32_t first_slot, uint32_t n_frames, const char *group,
-                       const int64_t *steps, const float *times, float precision, int host_threads) {
+                       const int64_t *steps, const float *times, float precision, int host_threads) try {
     if (!w || !w->fp || !c) return GR_E_INVALID_ARG;
     int st = slot_check(c, first_slot, n_frames); if (st) return st;
     (void)hipSetDevice(c->device);
@@ -1985,11 +1989,11 @@ int gr_xtc_write_slots(gr_xtc_writer *w, gr_ctx *c, uint32_t first_slot, uint32_
     if (result == GR_E_OUT_OF_RANGE) return fail(c, GR_E_OUT_OF_RANGE, "coordinates do not fit the xtc integers at this precision; the frames before this slot were written", first_slot + failed_at);
     if (result == GR_E_IO) return fail(c, GR_E_IO, "short write");
     return GR_OK;
-}
+} catch (...) { return gr_abi_guard(); }
 
 /* ------------------------------------------------------------ measurement / synthetic data */
 int gr_timer_start(gr_ctx *c) { if (!c) return GR_E_INVALID_ARG; HIPCHK(c, hipEventRecord(c->ev0, c->stream)); return GR_OK; }
-int gr_timer_stop(gr_ctx *c, float *ms) {
+int gr_timer_stop(gr_ctx *c, float *ms) try {
     if (!c) return GR_E_INVALID_ARG;
     HIPCHK(c, hipEventRecord(c->ev1, c->stream));
     HIPCHK(c, hipEventSynchronize(c->ev1));
@@ -1997,23 +2001,23 @@ int gr_timer_stop(gr_ctx *c, float *ms) {
     HIPCHK(c, hipEventElapsedTime(&t, c->ev0, c->ev1));
     if (ms) *ms = t;
     return GR_OK;
-}
+} catch (...) { return gr_abi_guard(); }
 
-int gr_profile_enable(gr_ctx *c, int on) {
+int gr_profile_enable(gr_ctx *c, int on) try {
     if (!c) return GR_E_INVALID_ARG;
     c->profile = on ? 1 : 0;
     for (int k = 0; k < 4; ++k) { c->prof_ms[k] = 0; c->prof_launches[k] = 0; c->prof_frames[k] = 0; }
     return GR_OK;
-}
-int gr_profile_read(const gr_ctx *c, int kernel, double *ms_total, uint64_t *launches, uint64_t *frames) {
+} catch (...) { return gr_abi_guard(); }
+int gr_profile_read(const gr_ctx *c, int kernel, double *ms_total, uint64_t *launches, uint64_t *frames) try {
     if (!c || kernel < 0 || kernel > 3) return GR_E_INVALID_ARG;
     if (ms_total) *ms_total = c->prof_ms[kernel];
     if (launches) *launches = c->prof_launches[kernel];
     if (frames) *frames = c->prof_frames[kernel];
     return GR_OK;
-}
+} catch (...) { return gr_abi_guard(); }
 
-int gr_synth_reference(gr_ctx *c, uint32_t slot, const float *box9, float radius, uint64_t seed) {
+int gr_synth_reference(gr_ctx *c, uint32_t slot, const float *box9, float radius, uint64_t seed) try {
     int st = slot_check(c, slot); if (st) return st;
     (void)hipSetDevice(c->device);
     HIPCHK(c, sync_ingest(c));
@@ -2024,10 +2028,10 @@ int gr_synth_reference(gr_ctx *c, uint32_t slot, const float *box9, float radius
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return GR_OK;
-}
+} catch (...) { return gr_abi_guard(); }
 
 int gr_synth_frames(gr_ctx *c, uint32_t ref_slot, uint32_t first_slot, uint32_t n_frames, uint64_t first_frame_index,
-                    uint64_t frame_index_stride, float sigma, uint64_t seed) {
+                    uint64_t frame_index_stride, float sigma, uint64_t seed) try {
     int st = slot_check(c, ref_slot); if (st) return st;
     st = slot_check(c, first_slot, n_frames); if (st) return st;
     if (ref_slot >= first_slot && ref_slot < first_slot + n_frames) return fail(c, GR_E_INVALID_ARG, "reference slot inside the output range");
@@ -2043,9 +2047,9 @@ int gr_synth_frames(gr_ctx *c, uint32_t ref_slot, uint32_t first_slot, uint32_t 
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return GR_OK;
-}
+} catch (...) { return gr_abi_guard(); }
 
-int gr_synth_uniform(gr_ctx *c, uint32_t slot, const float *box9, uint64_t seed) {
+int gr_synth_uniform(gr_ctx *c, uint32_t slot, const float *box9, uint64_t seed) try {
     int st = slot_check(c, slot); if (st) return st;
     (void)hipSetDevice(c->device);
     HIPCHK(c, sync_ingest(c));
@@ -2056,6 +2060,6 @@ int gr_synth_uniform(gr_ctx *c, uint32_t slot, const float *box9, uint64_t seed)
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return GR_OK;
-}
+} catch (...) { return gr_abi_guard(); }
 
 }  // extern "C"
