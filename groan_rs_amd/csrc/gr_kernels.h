@@ -307,7 +307,9 @@ __global__ __launch_bounds__(GR_WG) void k_center_sums(
         if (kind == 0) {
             acc[0] += (double)(x * m); acc[1] += (double)(y * m); acc[2] += (double)(z * m); acc[3] += (double)m;
         } else if (kind == 1) {
-            gr_wrap(x, y, z, box);
+            // position.wrap(simbox): an atom inside the cell is left as it is (every stage's k is 0: the reference's loops do
+            // not turn), so the closed form (~25 VALU slots per axis) only runs for the lanes that need it
+            if (!(x >= 0.0f && x <= box.ax && y >= 0.0f && y <= box.by && z >= 0.0f && z <= box.cz)) gr_wrap(x, y, z, box);
             if (!box.ortho) {   // fractional ("u") coordinates, scaled by the box diagonal
                 const float sc = z / box.cz;
                 const float uy = y - sc * box.cy;
