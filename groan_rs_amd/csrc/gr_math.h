@@ -104,7 +104,19 @@ GR_HD float gr_min_image(float dx, float L) {
     return gr_minimg_value(dx, L, 1.0f / L, L / 2.0f);
 }
 
-GR_HD float gr_floor_mod(float x, float y) { return fmodf(fmodf(x, y) + y, y); }
+// auxiliary floor_mod = ((x % y) + y) % y.  For |x| < 2y both remainders are a conditional, exact subtraction (fmodf of a
+// value in [y, 2y) is value - y), so the result is the same bits as the two fmodf calls at a fraction of their cost; anything
+// farther away takes the library calls.  (tests/cpp/test_wrap.cpp compares the two bit for bit.)
+GR_HD float gr_floor_mod_ref(float x, float y) { return fmodf(fmodf(x, y) + y, y); }
+GR_HD float gr_floor_mod(float x, float y) {
+    if (!(fabsf(x) < 2.0f * y)) return gr_floor_mod_ref(x, y);
+    float s = x;
+    if (x >= y) s = x - y; else if (x <= -y) s = x + y;   // x % y (sign of x, exact)
+    float u = s + y;                                       // rounds once, like the reference's addition
+    if (u >= y) u -= y;                                    // (...) % y: exact
+    if (u >= y) u -= y;                                    // s + y rounded up to 2y
+    return u;
+}
 
 // A vector shorter than r_ws (half the shortest lattice vector) is its own unique minimum image
 // (|d + t| >= |t| - |d| > |d| for every lattice vector t), so the table is searched only beyond it.

@@ -40,6 +40,8 @@ int main() {
             ++n;
             const float tol = 1.2e-7f * std::fabs(t) * (std::fabs(t) / L + 2.0f);   // the loop's own drift: an ulp of t per turn (and either end of the cell)
             if (one_turn ? bits(want) != bits(got) : (std::fabs(want - got) > tol && std::fabs(std::fabs(want - got) - L) > tol)) { if (bad++ < 10) printf("wrap L=%g t=%.9g: loop %.9g closed %.9g\n", L, t, want, got); }
+            ++n;   // floor_mod (vector_to, vector3d.rs:561-569): conditional subtractions == the two fmodf calls, bit for bit
+            if (bits(gr_floor_mod(t, L)) != bits(gr_floor_mod_ref(t, L)) && !(gr_floor_mod(t, L) == 0.0f && gr_floor_mod_ref(t, L) == 0.0f)) { if (bad++ < 30) printf("floor_mod L=%g t=%.9g: %.9g vs %.9g\n", L, t, gr_floor_mod(t, L), gr_floor_mod_ref(t, L)); }
             const float wm = loop_minimg(t, L), gm = gr_min_image(t, L);
             const bool one = std::fabs(t) <= 15.0f * L;
             ++n;
