@@ -322,3 +322,33 @@ def test_sizes_around_the_tile_boundaries(G, n):
         if rank >= 2:
             np.testing.assert_allclose(got, want[f][1], atol=2e-4, rtol=0)
     plan.close(); ref.close(); cur.close()
+
+
+def test_results_are_bitwise_reproducible(G):
+    """no atomics on floating-point data anywhere: partial sums are combined in a fixed order, so the same frames give the same
+    bits on every run -- RMSD, rotation, fitted coordinates, centres (large enough for every multi-workgroup reduction)"""
+    rng = np.random.default_rng(77)
+    n, nf = 300_000, 12
+    box = O.box_from_lengths_angles([12.0, 12.0, 12.0], [60.0, 60.0, 90.0])
+    masses = rng.choice(np.float32([1.008, 12.011, 15.999]), n).astype(np.float32)
+    cur = G.System(n, masses=masses, n_slots=nf + 1)
+    cur.synth_reference(nf, box, 0.2 * float(min(box[:3])), 3)
+    ref = None
+    runs = []
+    for rep in range(3):
+        cur.synth_frames(nf, 0, nf, 0, 0.05, 3)
+        if ref is None:
+            ref = G.System(n, masses=masses, box=box, positions=cur.get_positions(nf))
+        plan = G.RMSDPlan(ref, cur, "all")
+        com, _ = cur.group_get_com_batch("all", 0, nf)
+        r0, _ = plan.rmsd(0, nf)
+        r1, _ = plan.rmsd_fit(0, nf)
+        runs.append((com.copy(), r0.copy(), r1.copy(), [cur.get_positions(f) for f in (0, nf - 1)]))
+        plan.close()
+    for rep in (1, 2):
+        assert np.array_equal(runs[0][0].view(np.uint32), runs[rep][0].view(np.uint32))
+        assert np.array_equal(runs[0][1].view(np.uint32), runs[rep][1].view(np.uint32))
+        assert np.array_equal(runs[0][2].view(np.uint32), runs[rep][2].view(np.uint32))
+        for a, b in zip(runs[0][3], runs[rep][3]):
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    ref.close(); cur.close()
