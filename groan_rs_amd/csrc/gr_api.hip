@@ -59,7 +59,7 @@ struct gr_ctx {
     hipEvent_t ev_skew[3 * GR_MAX_BATCH] = {};   // skewed order: [3g] sums of group g done, [3g+1] finalize done, [3g+2] fit done
     uint32_t *fuse_cnt = nullptr;     // [2 * GR_MAX_BATCH] arrival counters of the fused finalize / close tails (self-resetting)
     int fuse = 1;                     // GR_FUSE=0: separate k_rmsd_finalize_lite / k_rmsd_close launches
-    uint64_t center_fallbacks = 0;    // frames the one-pass centre handed to the two-pass path (gr_center_fallbacks)
+    uint64_t center_fallbacks = 0;    // frames the one-pass centre handed to the estimate pass (copy selection) or to both passes (gr_center_fallbacks)
     uint32_t com_onepass_min = 4096;  // GR_COM_ONEPASS_MIN: contiguous groups of at least this many atoms take the one-pass get_com / get_center (0 = never)
     int skew = 0;                     // GR_SKEW=1: small kernels on the second stream beside the next group's sums pass (measured slower)
     hipEvent_t ev_join = nullptr;           // "all fits done" (stream2 -> stream)
@@ -390,11 +390,14 @@ static int pbc_center_onepass(gr_ctx *c, uint32_t s0, uint32_t nb, const GrSel &
 // state_host[0..nb) has been fetched: when some frames are flagged GR_ST_FALLBACK the two dependent passes run over the
 // whole batch, masked to those frames (the other frames' workgroups leave at once), and the states are fetched again
 static int center_redo_fallbacks(gr_ctx *c, uint32_t s0, uint32_t nb, const GrSel &sel, int weighted, std::vector<GrFrameState> &res) {
-    uint32_t n_fb = 0;
-    for (uint32_t f = 0; f < nb; ++f) n_fb += c->state_host[f].status == GR_ST_FALLBACK;
-    if (n_fb) {
-        c->center_fallbacks += n_fb;
-        int st = pbc_center_stages(c, s0, nb, sel, weighted, GR_ST_FALLBACK); if (st) return st;
+    uint32_t n_fb = 0, n_amb = 0;
+    for (uint32_t f = 0; f < nb; ++f) { n_fb += c->state_host[f].status == GR_ST_FALLBACK; n_amb += c->state_host[f].status == GR_ST_AMBIG; }
+    if (n_fb || n_amb) {
+        c->center_fallbacks += n_fb + n_amb;
+        int st = GR_OK;
+        // images proven, centre near a cell face: only the (unweighted) estimate is needed, it selects the periodic copy
+        if (n_amb) { st = center_stage(c, s0, nb, sel, 1, 0, 0, 0, GR_ST_AMBIG); if (st) return st; }
+        if (n_fb) { st = pbc_center_stages(c, s0, nb, sel, weighted, GR_ST_FALLBACK); if (st) return st; }
         st = fetch_states(c, nb); if (st) return st;
     }
     res.assign(c->state_host, c->state_host + nb);
@@ -715,7 +718,7 @@ int gr_group_center(gr_ctx *c, uint32_t slot, const char *group, int kind, int w
     else return fail(c, GR_E_INVALID_ARG, "unknown centre kind");
     if (st) return st;
     st = fetch_states(c, 1); if (st) return st;
-    if (c->state_host[0].status == GR_ST_FALLBACK) {
+    if (c->state_host[0].status == GR_ST_FALLBACK || c->state_host[0].status == GR_ST_AMBIG) {
         std::vector<GrFrameState> res;
         st = center_redo_fallbacks(c, slot, 1, sel, weighted, res); if (st) return st;
     }

@@ -28,6 +28,7 @@
 #define GR_WG 256
 #define GR_NOIDX 0xFFFFFFFFu
 #define GR_ST_FALLBACK 100 /* internal: frame must be redone on the multi-pass exact path */
+#define GR_ST_AMBIG 101    /* internal (one-pass centre): images proven, but the periodic copy needs the Bai-Breen estimate itself */
 
 struct GrSel {
     uint32_t n;            // atoms in the selection
@@ -390,6 +391,16 @@ __global__ __launch_bounds__(GR_WG) void k_center_finalize(
         else {
             const float s_c = t[2] / b.cz, s_b = t[1] / b.by;
             r[2] = t[2]; r[1] = t[1] + s_c * b.cy; r[0] = t[0] + s_b * b.bx + s_c * b.cx;
+        }
+        if (only_status == GR_ST_AMBIG) {
+            // the one-pass centre left its centre / com in SOME periodic copy: the reference's copy is the one about c' (= r),
+            // i.e. the copy whose centre is the minimum image of the stored one as seen from c' (they are within eps of each other)
+            float vx, vy, vz;
+            gr_vector_to(r[0], r[1], r[2], st.center[0], st.center[1], st.center[2], b, vx, vy, vz);
+            const double lat[3] = { (double)r[0] + vx - st.center[0], (double)r[1] + vy - st.center[1], (double)r[2] + vz - st.center[2] };
+            for (int a = 0; a < 3; ++a) { st.center[a] = (float)((double)st.center[a] + lat[a]); st.com[a] = (float)((double)st.com[a] + lat[a]); }
+            st.status = 0;
+            return;
         }
     } else {
         const double div = weighted ? acc[3] : (double)n_sel;
@@ -830,10 +841,16 @@ __device__ inline void gr_finalize_math(const double *acc, const float mn[3], co
                          gfa = (g[0] - gfb * (double)b.bx - gfc * (double)b.cx) / (double)b.ax;
             const double gf[3] = { gfa, gfb, gfc };
             double nl[3];
+            bool face = false;
             for (int a = 0; a < 3; ++a) {
                 const double m = gf[a] + mu[a], fl = floor(m), fr = m - fl, guard = eps[a] + 1.0e-4;
-                if (!(fr > guard && fr < 1.0 - guard)) { st.status = GR_ST_FALLBACK; return; }
+                if (!(fr > guard && fr < 1.0 - guard)) face = true;
                 nl[a] = -fl;
+            }
+            if (face) {   // some copy of (centre, com): the masked estimate pass places it (k_center_finalize, GR_ST_AMBIG)
+                for (int a = 0; a < 3; ++a) { st.center[a] = (float)(g[a] + ce[a]); st.com[a] = (float)(g[a] + cv[a]); }
+                st.status = GR_ST_AMBIG;
+                return;
             }
             const double lat[3] = { nl[0] * b.ax + nl[1] * b.bx + nl[2] * b.cx, nl[1] * b.by + nl[2] * b.cy, nl[2] * b.cz };
             for (int a = 0; a < 3; ++a) { st.center[a] = (float)(g[a] + ce[a] + lat[a]); st.com[a] = (float)(g[a] + cv[a] + lat[a]); }

@@ -143,10 +143,11 @@ void gr_host_free(void *p);
 int gr_group_center(gr_ctx *ctx, uint32_t slot, const char *group, int kind, int weighted, float out[3]);
 /* GR_CENTER_PBC (get_center / get_com) of a contiguous group of at least `min_atoms` atoms is computed in ONE pass over the
  * frame instead of the reference's two dependent ones (Bai-Breen estimate, then the unwrapped mean): images about the
- * group's first atom + a proof that they are the images the reference would unwrap to; frames where the proof fails
- * (groups wider than half a box, a centre within ~1e-4 of a cell face) are recomputed with the two passes.
+ * group's first atom + a proof that they are the images the reference would unwrap to.  Frames whose centre lies within the
+ * proof's bound of a cell face additionally run the estimate pass (it selects the periodic copy the result lies in), frames
+ * where the proof fails (groups wider than half a box) both passes -- one masked launch over the batch either way.
  * min_atoms = 0 switches the one-pass path off; default 4096 (env GR_COM_ONEPASS_MIN).  gr_center_fallbacks counts the
- * frames that were recomputed since the context was created. */
+ * frames that needed those extra passes since the context was created. */
 int gr_ctx_set_center_onepass_min(gr_ctx *ctx, uint32_t min_atoms);
 uint64_t gr_center_fallbacks(const gr_ctx *ctx);
 
