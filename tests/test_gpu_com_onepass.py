@@ -120,3 +120,27 @@ def test_errors_in_reference_order_and_batches(G):
     assert e.value.variant == "InvalidMass" and e.value.detail == 150
     assert np.abs(np.array(s2.group_get_center("G")) - O.get_center(frames[0], idx, box)).max() <= 1e-4   # unweighted: no masses needed (f32 oracle sums)
     s.close(); s2.close()
+
+
+@pytest.mark.parametrize("bname", list(BOXES))
+def test_centre_on_a_cell_face_takes_the_copy_the_estimate_selects(G, bname):
+    """the group's centre within the proof's bound of one, two or three cell faces: the images are proven, the periodic copy is
+    not -- the masked estimate pass selects it (GR_ST_AMBIG); the answer must be the reference's, whichever side c' falls"""
+    box = O.box_from_lengths_angles(*BOXES[bname])
+    rng = np.random.default_rng(31)
+    n = 20_000
+    masses = np.array([1.008, 12.011, 15.999], np.float32)[np.arange(n) % 3]
+    s = G.System(n, masses=masses, n_slots=1)
+    s.group_create_from_ranges("G", [(0, n - 1)])
+    idx = np.arange(n)
+    for cf in ([1.0 - 1e-5, 0.5, 0.5], [1e-5, 1.0 - 2e-5, 0.5], [3e-6, 1.0 - 3e-6, 1e-6], [0.0, 0.0, 0.0], [0.5, 0.99999, 0.00001]):
+        pos = O.wrap_atoms(cluster(rng, n, box, cf, 0.25), idx, box)
+        fb0 = s.center_fallbacks()
+        s.set_frame(pos, box)
+        for weighted in (True, False):
+            got = np.array(s.group_get_com("G") if weighted else s.group_get_center("G"))
+            with O.acc64():
+                want = O.get_center(pos, idx, box, mass=masses if weighted else None)
+            assert np.abs(got - want).max() <= 2e-5, (bname, cf, weighted, got, want)
+        assert s.center_fallbacks() == fb0 + 2
+    s.close()
