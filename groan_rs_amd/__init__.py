@@ -12,6 +12,7 @@ from .traj import (FrameAnalyze, FrameConvert, FrameConvertAnalyze, RMSDConverte
                    TrajAnalysisError, TrajConverter, TrajConverterAnalyzer, TrajReader)
 from .xtc import XtcError, XtcFile, XtcWriter
 from .textio import ParseGroError, ParseNdxError, Structure, read_ndx_groups, system_from_gro, system_read_ndx
+from .select import SelectError, parse_query, select
 from .shapes import Cylinder, Rectangular, Shape, Sphere, TriangularPrism
 from .parallel import ParallelTrajData, gather_per_frame, interleave, shard_frames, traj_iter_map_reduce
 

@@ -47,6 +47,8 @@ SIGNATURES = {
     "gr_group_create_from_indices": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t]),
     "gr_group_remove": (C.c_int, [C.c_void_p, C.c_char_p]),
     "gr_group_exists": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "gr_group_count": (C.c_uint64, [C.c_void_p]),
+    "gr_group_name": (C.c_int, [C.c_void_p, C.c_uint64, C.c_char_p, C.c_size_t]),
     "gr_group_n_atoms": (C.c_int, [C.c_void_p, C.c_char_p, c_u64p]),
     "gr_group_n_blocks": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_size_t)]),
     "gr_group_blocks": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p]),

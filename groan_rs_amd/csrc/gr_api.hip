@@ -626,6 +626,16 @@ int gr_group_remove(gr_ctx *c, const char *name) try {
     return GR_OK;
 } catch (...) { return gr_abi_guard(); }
 int gr_group_exists(const gr_ctx *c, const char *name) { return (c && find_group(c, name)) ? 1 : 0; }
+uint64_t gr_group_count(const gr_ctx *c) { return c ? (uint64_t)c->groups.size() : 0; }
+int gr_group_name(const gr_ctx *c, uint64_t i, char *name, size_t cap) try {   // groups in name order (Groups::names_iter)
+    if (!c || !name || cap == 0) return GR_E_INVALID_ARG;
+    if (i >= c->groups.size()) return GR_E_OUT_OF_RANGE;
+    auto it = c->groups.begin();
+    std::advance(it, (long)i);
+    const size_t n = std::min(cap - 1, it->first.size());
+    memcpy(name, it->first.data(), n); name[n] = 0;
+    return GR_OK;
+} catch (...) { return gr_abi_guard(); }
 int gr_group_n_atoms(const gr_ctx *c, const char *name, uint64_t *n) try {
     const Group *g = c ? find_group(c, name) : nullptr;
     if (!g) return GR_E_GROUP_NOT_FOUND;

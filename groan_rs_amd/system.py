@@ -307,6 +307,19 @@ class System:
     def group_exists(self, name):
         return bool(self._lib.gr_group_exists(self._ctx, name.encode()))
 
+    def group_names(self):
+        out, buf = [], C.create_string_buffer(256)
+        for i in range(int(self._lib.gr_group_count(self._ctx))):
+            if self._lib.gr_group_name(self._ctx, i, buf, 256) == OK:
+                out.append(buf.value.decode(errors="replace"))
+        return out
+
+    def group_create(self, name, query, structure):
+        """System::group_create (groups.rs:36-92): a group from a selection-language query (groan_rs_amd/select.py) over the
+        names / numbers of `structure` (textio.Structure); -> True when an existing group was overwritten"""
+        from .select import group_create as _group_create   # (the package re-exports the FUNCTION `select` under the module's name)
+        return _group_create(self, name, query, structure)
+
     def group_get_n_atoms(self, name):
         n = C.c_uint64(0)
         st = self._lib.gr_group_n_atoms(self._ctx, name.encode(), C.byref(n))

@@ -114,6 +114,9 @@ int gr_group_create_from_ranges(gr_ctx *ctx, const char *name, const uint64_t *s
 int gr_group_create_from_indices(gr_ctx *ctx, const char *name, const uint64_t *indices, size_t n);
 int gr_group_remove(gr_ctx *ctx, const char *name);
 int gr_group_exists(const gr_ctx *ctx, const char *name);
+/* the context's groups, for front ends that match group names (the selection language's `group r'...'`): */
+uint64_t gr_group_count(const gr_ctx *ctx);
+int gr_group_name(const gr_ctx *ctx, uint64_t i, char *name, size_t capacity);
 int gr_group_n_atoms(const gr_ctx *ctx, const char *name, uint64_t *n);            /* group_get_n_atoms */
 int gr_group_n_blocks(const gr_ctx *ctx, const char *name, size_t *n_blocks);
 int gr_group_blocks(const gr_ctx *ctx, const char *name, uint64_t *out_start, uint64_t *out_end);

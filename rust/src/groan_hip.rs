@@ -42,6 +42,8 @@ extern "C" {
     pub fn gr_group_all_distances(ctx: *mut gr_ctx, slot: u32, g1: *const c_char, g2: *const c_char, dim: c_int, out: *mut c_float, cap: usize) -> c_int;
     pub fn gr_group_all_distances_batch_device(ctx: *mut gr_ctx, first_slot: u32, n_frames: u32, g1: *const c_char, g2: *const c_char, dim: c_int,
                                                out_dev: *mut *mut c_float, n1: *mut u64, n2: *mut u64, status_out: *mut c_int) -> c_int;
+    pub fn gr_group_count(ctx: *const gr_ctx) -> u64;
+    pub fn gr_group_name(ctx: *const gr_ctx, i: u64, name: *mut c_char, capacity: usize) -> c_int;
     pub fn gr_ctx_set_center_onepass_min(ctx: *mut gr_ctx, min_atoms: u32) -> c_int;
     pub fn gr_center_fallbacks(ctx: *const gr_ctx) -> u64;
     pub fn gr_device_read(ctx: *mut gr_ctx, dev: *const c_void, host: *mut c_void, bytes: usize) -> c_int;

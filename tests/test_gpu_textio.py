@@ -74,3 +74,28 @@ def test_analysis_straight_from_files(G):
     np.testing.assert_allclose(s.group_estimate_center("Backbone"), O.estimate_center(st.positions, idx, st.box9), atol=1e-5, rtol=0)
     np.testing.assert_allclose(s.group_get_center("all"), O.get_center(st.positions, np.arange(st.n_atoms), st.box9), atol=1e-5, rtol=0)
     s.close()
+
+
+def test_group_create_from_a_selection_query(G):
+    """System::group_create (groups.rs:36-92) on the device mirror: query -> indices (groan_rs_amd/select.py) -> device group;
+    existing groups can be referenced, an overwritten group answers True (the reference's AlreadyExistsWarning)"""
+    s = fresh(G)
+    st = G.Structure(f("example_novelocities.gro"))
+    G.system_read_ndx(s, f("index_small.ndx"))
+    assert s.group_create("Sel", "serial 1 to 10 or resid 3", st) is False
+    want = np.union1d(st.indices_where(serial=(1, 10)), st.indices_where(resid=3))
+    assert np.array_equal(np.array(list(s.group_container("Sel")), np.uint64), want) and want.size >= 10
+    assert s.group_create("Sel", "Protein and not Sel", st) is True                    # references the OLD Sel, then replaces it
+    assert s.group_get_n_atoms("Sel") == 50 - want.size
+    names = sorted(set(st.atomname))[:2]
+    s.group_create("ByName", "name %s %s and System" % tuple(names), st)
+    assert np.array_equal(np.array(list(s.group_container("ByName")), np.uint64), st.indices_where(name=names))
+    assert "Sel" in s.group_names() and "ByName" in s.group_names() and "all" in s.group_names()
+    np.testing.assert_allclose(s.group_get_center_naive("ByName"), st.positions[st.indices_where(name=names).astype(int)].mean(0), atol=1e-5)
+    with pytest.raises(G.SelectError) as e:
+        s.group_create("Bad", "resname", st)
+    assert e.value.variant == "EmptyArgument" and not s.group_exists("Bad")
+    with pytest.raises(G.SelectError) as e:
+        s.group_create("Bad", "NoSuchGroup", st)
+    assert e.value.variant == "GroupNotFound"
+    s.close()
