@@ -353,7 +353,10 @@ int center_stage(gr_ctx *c, uint32_t first_slot, uint32_t nf, const GrSel &sel, 
     // frame for the naive centre; this kernel's per-atom fp64 chains want many workgroups.)
     uint32_t nch = chunks_for(sel);
     if (nf > 1 && nch >= 8) nch &= ~7u;
-    k_center_sums<<<dim3(nch, nf), dim3(GR_WG), 0, c->stream>>>(c->frames, c->frame_stride, first_slot, c->masses, sel, c->boxes_dev, c->state_dev, kind, weighted, c->cen_partials, only_status);
+    const dim3 grid(nch, nf), wg(GR_WG);
+    if (kind == 0) k_center_sums<0><<<grid, wg, 0, c->stream>>>(c->frames, c->frame_stride, first_slot, c->masses, sel, c->boxes_dev, c->state_dev, weighted, c->cen_partials, only_status);
+    else if (kind == 1) k_center_sums<1><<<grid, wg, 0, c->stream>>>(c->frames, c->frame_stride, first_slot, c->masses, sel, c->boxes_dev, c->state_dev, weighted, c->cen_partials, only_status);
+    else k_center_sums<2><<<grid, wg, 0, c->stream>>>(c->frames, c->frame_stride, first_slot, c->masses, sel, c->boxes_dev, c->state_dev, weighted, c->cen_partials, only_status);
     k_center_finalize<<<dim3(nf), dim3(GR_WG), 0, c->stream>>>(c->cen_partials, nch, c->boxes_dev, first_slot, kind, weighted, mass_first, target, sel.n, c->state_dev, only_status);
     HIPCHK(c, hipGetLastError());
     return GR_OK;
