@@ -67,6 +67,13 @@ SIGNATURES = {
     "gr_group_all_distances_device": (C.c_int, [C.c_void_p, C.c_uint32, C.c_char_p, C.c_char_p, C.c_int, C.POINTER(C.c_void_p), c_u64p, c_u64p]),
     "gr_group_all_distances_batch_device": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_char_p, C.c_char_p, C.c_int, C.POINTER(C.c_void_p), c_u64p, c_u64p, C.c_void_p]),
     "gr_device_read": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "gr_trr_open": (C.c_void_p, [C.c_char_p, C.POINTER(C.c_int)]),
+    "gr_trr_close": (None, [C.c_void_p]),
+    "gr_trr_n_atoms": (C.c_uint64, [C.c_void_p]),
+    "gr_trr_n_frames": (C.c_uint64, [C.c_void_p]),
+    "gr_trr_frame_info": (C.c_int, [C.c_void_p, C.c_uint64, c_u64p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "gr_trr_read_frame": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, c_u64p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "gr_trr_read_frames_device": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
     "gr_group_translate": (C.c_int, [C.c_void_p, C.c_uint32, C.c_char_p, C.c_void_p]),
     "gr_group_wrap": (C.c_int, [C.c_void_p, C.c_uint32, C.c_char_p]),
     "gr_atoms_center": (C.c_int, [C.c_void_p, C.c_uint32, C.c_char_p, C.c_int, C.c_int]),

@@ -20,6 +20,7 @@
 #include "gr_persist.h"
 #include "gr_shape.h"
 #include "gr_xtc_dev.h"
+#include "gr_trr.h"
 #include "gr_cellgrid.h"
 #include "gr_textio.h"
 #include <set>
@@ -1809,6 +1810,146 @@ int gr_xtc_read_frames_device(const gr_xtc *x, uint64_t first_frame, uint32_t n_
         auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
         fprintf(stderr, "[xtc] %u frames, %u threads: waits + buffers %.2f ms, read + skim %.2f ms (per frame, thread time: read %.3f, skim %.3f), enqueue %.2f ms\n",
                 n_frames, nt, ms(t_call, t_begin), ms(t_begin, t_host), ns_read.load() * 1e-6 / n_frames, ns_skim.load() * 1e-6 / n_frames, ms(t_host, t_end));
+    }
+    return GR_OK;
+} catch (...) { return gr_abi_guard(); }
+
+/* ------------------------------------------------------------ trr reader */
+struct gr_trr { grtr::File f; };
+static int trr_status(int s) { return s == grtr::TRR_OK ? GR_OK : (s == grtr::TRR_E_IO ? GR_E_IO : GR_E_FORMAT); }
+
+gr_trr *gr_trr_open(const char *path, int *status) try {
+    int dummy; if (!status) status = &dummy;
+    if (!path) { *status = GR_E_INVALID_ARG; return nullptr; }
+    gr_trr *t = new gr_trr();
+    const int s = grtr::open_file(t->f, path);
+    if (s != grtr::TRR_OK) { *status = trr_status(s); if (t->f.fd >= 0) ::close(t->f.fd); delete t; return nullptr; }
+    *status = GR_OK;
+    return t;
+} catch (...) { return nullptr; }
+void gr_trr_close(gr_trr *t) { if (!t) return; if (t->f.fd >= 0) ::close(t->f.fd); delete t; }
+uint64_t gr_trr_n_atoms(const gr_trr *t) { return t ? t->f.natoms : 0; }
+uint64_t gr_trr_n_frames(const gr_trr *t) { return t ? t->f.frames.size() : 0; }
+
+int gr_trr_frame_info(const gr_trr *t, uint64_t frame, uint64_t *step, float *time, float *lambda, float box9[9], int *sections, int *double_precision) try {
+    if (!t) return GR_E_INVALID_ARG;
+    if (frame >= t->f.frames.size()) return GR_E_OUT_OF_RANGE;
+    const grtr::FrameIndex &fi = t->f.frames[frame];
+    if (step) *step = (uint64_t)(uint32_t)fi.step;
+    if (time) *time = fi.time;
+    if (lambda) *lambda = fi.lambda;
+    if (sections) *sections = (fi.x_off ? 1 : 0) | (fi.v_off ? 2 : 0) | (fi.f_off ? 4 : 0) | (fi.has_box ? 8 : 0);
+    if (double_precision) *double_precision = fi.real_size == 8;
+    return box9 ? xtc_box9(fi.box, box9) : GR_OK;
+} catch (...) { return gr_abi_guard(); }
+
+int gr_trr_read_frame(const gr_trr *t, uint64_t frame, float *xyz, float *velocities, float *forces, float box9[9], uint64_t *step, float *time, float *lambda) try {
+    if (!t) return GR_E_INVALID_ARG;
+    int st = gr_trr_frame_info(t, frame, step, time, lambda, box9, nullptr, nullptr);
+    if (st != GR_OK) return st;
+    static thread_local std::vector<unsigned char> scratch;
+    const grtr::FrameIndex &fi = t->f.frames[frame];
+    st = trr_status(grtr::read_section(t->f, fi, fi.x_off, xyz, scratch)); if (st) return st;
+    st = trr_status(grtr::read_section(t->f, fi, fi.v_off, velocities, scratch)); if (st) return st;
+    return trr_status(grtr::read_section(t->f, fi, fi.f_off, forces, scratch));
+} catch (...) { return gr_abi_guard(); }
+
+// raw big-endian position sections of a batch of frames -> frame slots (f32); an all-zero position is "no position"
+// (TrrFrameData::update_system, trr_io.rs:108-112) and travels as NaN in x like everywhere else in this library
+__global__ __launch_bounds__(256) void k_trr_unpack(const unsigned char *__restrict__ raw, const uint64_t *__restrict__ sec_off, const uint32_t *__restrict__ real_size,
+                                                    float *__restrict__ frames, size_t frame_stride, const uint32_t *__restrict__ slots, uint32_t n_atoms) {
+    const uint32_t k = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_atoms) return;
+    float *dst = frames + (size_t)slots[k] * frame_stride + 3 * (size_t)i;
+    const uint64_t so = sec_off[k];
+    float v[3] = { 0.f, 0.f, 0.f };
+    if (so != ~0ull) {
+        const unsigned char *src = raw + so;
+        if (real_size[k] == 4) {
+            for (int a = 0; a < 3; ++a) { const uint32_t u = __builtin_bswap32(reinterpret_cast<const uint32_t *>(src)[3 * (size_t)i + a]); v[a] = __uint_as_float(u); }
+        } else {
+            for (int a = 0; a < 3; ++a) { const uint64_t u = __builtin_bswap64(reinterpret_cast<const uint64_t *>(src)[3 * (size_t)i + a]); v[a] = (float)__longlong_as_double((long long)u); }
+        }
+    }
+    if (v[0] == 0.0f && v[1] == 0.0f && v[2] == 0.0f) v[0] = __uint_as_float(0x7fc00000u);
+    dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2];
+}
+
+int gr_trr_read_frames_device(const gr_trr *t, uint64_t first_frame, uint32_t n_frames, uint64_t frame_step, gr_ctx *c, uint32_t first_slot,
+                              uint64_t *steps, float *times) try {
+    if (!t || !c) return GR_E_INVALID_ARG;
+    int st = slot_check(c, first_slot, n_frames); if (st) return st;
+    if (frame_step == 0) frame_step = 1;
+    if (n_frames == 0) return GR_OK;
+    if (first_frame + (uint64_t)(n_frames - 1) * frame_step >= t->f.frames.size()) return fail(c, GR_E_OUT_OF_RANGE, "trr frame out of range", first_frame);
+    if (t->f.natoms != c->n) return fail(c, GR_E_INVALID_ARG, "the trajectory's atom count differs from the context's");
+    (void)hipSetDevice(c->device);
+    // staging: [raw sections, 16-byte aligned] [section offsets u64] [real sizes u32] [slots u32]; the xtc banks are reused
+    const size_t n3 = (size_t)t->f.natoms * 3;
+    std::vector<size_t> soff(n_frames);
+    size_t bytes = 0;
+    for (uint32_t k = 0; k < n_frames; ++k) {
+        const grtr::FrameIndex &fi = t->f.frames[first_frame + k * frame_step];
+        soff[k] = bytes; bytes += ((fi.x_off ? n3 * fi.real_size : 0) + 15) & ~(size_t)15;
+    }
+    const size_t off_sec = bytes;  bytes += (size_t)n_frames * sizeof(uint64_t);
+    const size_t off_rs = bytes;   bytes += (((size_t)n_frames * sizeof(uint32_t)) + 15) & ~(size_t)15;
+    const size_t off_slot = bytes; bytes += (((size_t)n_frames * sizeof(uint32_t)) + 15) & ~(size_t)15;
+    const uint32_t bank = c->xtc_bank; c->xtc_bank ^= 1u;
+    if (c->xtc_ev[bank]) HIPCHK(c, hipEventSynchronize(c->xtc_ev[bank]));
+    else HIPCHK(c, hipEventCreateWithFlags(&c->xtc_ev[bank], hipEventDisableTiming));
+    if (bytes > c->xtc_host_cap[bank]) {
+        if (c->xtc_host[bank]) (void)hipHostFree(c->xtc_host[bank]);
+        c->xtc_host[bank] = nullptr; c->xtc_host_cap[bank] = 0;
+        HIPCHK(c, hipHostMalloc(&c->xtc_host[bank], bytes + bytes / 4, hipHostMallocDefault));
+        c->xtc_host_cap[bank] = bytes + bytes / 4;
+    }
+    if (!c->unpack_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->unpack_stream, hipStreamNonBlocking));
+    if (!c->xtc_unpacked[bank]) HIPCHK(c, hipEventCreateWithFlags(&c->xtc_unpacked[bank], hipEventDisableTiming));
+    if (bytes > c->xtc_dev_cap[bank]) {
+        HIPCHK(c, hipStreamSynchronize(c->unpack_stream));
+        if (c->xtc_dev[bank]) (void)hipFree(c->xtc_dev[bank]);
+        c->xtc_dev[bank] = nullptr; c->xtc_dev_cap[bank] = 0;
+        HIPCHK(c, hipMalloc(&c->xtc_dev[bank], bytes + bytes / 4));
+        c->xtc_dev_cap[bank] = bytes + bytes / 4;
+    }
+    unsigned char *H = c->xtc_host[bank], *D = c->xtc_dev[bank];
+    uint64_t *sec = reinterpret_cast<uint64_t *>(H + off_sec);
+    uint32_t *rsz = reinterpret_cast<uint32_t *>(H + off_rs), *slots = reinterpret_cast<uint32_t *>(H + off_slot);
+    for (uint32_t k = 0; k < n_frames; ++k) {
+        const uint64_t fr = first_frame + k * frame_step;
+        const grtr::FrameIndex &fi = t->f.frames[fr];
+        const uint32_t slot = first_slot + k;
+        if (fi.x_off) {
+            if (!grtr::pread_all(t->f.fd, H + soff[k], n3 * fi.real_size, fi.x_off)) return fail(c, GR_E_IO, "short read in trr frame", fr);
+            sec[k] = soff[k];
+        } else sec[k] = ~0ull;
+        rsz[k] = fi.real_size; slots[k] = slot;
+        if (!c->ev_ready[slot]) HIPCHK(c, hipEventCreateWithFlags(&c->ev_ready[slot], hipEventDisableTiming));
+        if (c->upload_pending[slot]) HIPCHK(c, hipEventSynchronize(c->ev_ready[slot]));
+        float box9[9];
+        st = gr_trr_frame_info(t, fr, steps ? steps + k : nullptr, times ? times + k : nullptr, nullptr, box9, nullptr, nullptr);
+        if (st != GR_OK) return fail(c, st, "unsupported box in trr frame", fr);
+        box_fill(c, slot, fi.has_box ? box9 : nullptr);
+    }
+    HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->xtc_unpacked[bank], 0));
+    HIPCHK(c, hipMemcpyAsync(D, H, bytes, hipMemcpyHostToDevice, c->copy_stream));
+    HIPCHK(c, hipEventRecord(c->xtc_ev[bank], c->copy_stream));
+    hipStream_t U = c->unpack_stream;
+    HIPCHK(c, hipStreamWaitEvent(U, c->xtc_ev[bank], 0));
+    uint64_t waited = 0;
+    for (uint32_t k = 0; k < n_frames; ++k) {
+        const uint64_t gen = c->slot_gen[first_slot + k];
+        if (gen && gen != waited) { HIPCHK(c, hipStreamWaitEvent(U, c->ev_done_ring[gen % 64], 0)); waited = gen; }
+    }
+    HIPCHK(c, hipMemcpyAsync(c->boxes_dev + first_slot, c->boxes_host + first_slot, (size_t)n_frames * sizeof(GrBox), hipMemcpyHostToDevice, U));
+    k_trr_unpack<<<dim3((t->f.natoms + 255) / 256, n_frames), dim3(256), 0, U>>>(D, reinterpret_cast<const uint64_t *>(D + off_sec), reinterpret_cast<const uint32_t *>(D + off_rs),
+                                                                                  c->frames, c->frame_stride, reinterpret_cast<const uint32_t *>(D + off_slot), t->f.natoms);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipEventRecord(c->xtc_unpacked[bank], U));
+    for (uint32_t k = 0; k < n_frames; ++k) {
+        HIPCHK(c, hipEventRecord(c->ev_ready[first_slot + k], U));
+        c->upload_pending[first_slot + k] = 1;
     }
     return GR_OK;
 } catch (...) { return gr_abi_guard(); }

@@ -272,6 +272,24 @@ int gr_group_translate_batch(gr_ctx *ctx, uint32_t first_slot, uint32_t n_frames
 int gr_group_wrap_batch(gr_ctx *ctx, uint32_t first_slot, uint32_t n_frames, const char *group, int *status_out);
 int gr_atoms_center_batch(gr_ctx *ctx, uint32_t first_slot, uint32_t n_frames, const char *ref_group, int dim, int weighted, int *status_out);
 
+/* ---------------------------------------------------------------- trr reader
+ * TrrReader / TrrFrameData (src/io/trr_io.rs:30-135 over the vendored xdrfile's read_trr): an own reader of the GROMACS trr
+ * format.  gr_trr_open indexes the file (frames are random-access, reads are thread-safe).  A frame carries any of positions /
+ * velocities / forces / box, in single or double precision; *sections = 1 positions | 2 velocities | 4 forces | 8 box.
+ * gr_trr_read_frame converts to f32 into the caller's buffers (any may be NULL); a section the frame does not carry reads as
+ * zeros, which the reference turns into "no position / velocity / force" (trr_io.rs:101-126).  gr_trr_read_frames_device
+ * copies the raw big-endian position sections of a batch of frames to the GPU and converts them there, straight into the
+ * slots (asynchronous like gr_frame_upload; all-zero positions become the NaN marker of a missing position). */
+typedef struct gr_trr gr_trr;
+gr_trr *gr_trr_open(const char *path, int *status);
+void gr_trr_close(gr_trr *trr);
+uint64_t gr_trr_n_atoms(const gr_trr *trr);
+uint64_t gr_trr_n_frames(const gr_trr *trr);
+int gr_trr_frame_info(const gr_trr *trr, uint64_t frame, uint64_t *step, float *time, float *lambda, float box9[9], int *sections, int *double_precision);
+int gr_trr_read_frame(const gr_trr *trr, uint64_t frame, float *xyz, float *velocities, float *forces, float box9[9], uint64_t *step, float *time, float *lambda);
+int gr_trr_read_frames_device(const gr_trr *trr, uint64_t first_frame, uint32_t n_frames, uint64_t frame_step, gr_ctx *ctx, uint32_t first_slot,
+                              uint64_t *steps, float *times);
+
 /* ---------------------------------------------------------------- xtc writer (host side; the step after calc_rmsd_and_fit)
  * XtcWriter::new / write_frame (src/io/xtc_io/mod.rs:256-331 over xdrfile's write_xtc): the library's own encoder, byte for
  * byte the stream the reference writes for the same coordinates (the reference's golden fitted trajectories are files).

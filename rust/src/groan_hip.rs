@@ -42,6 +42,13 @@ extern "C" {
     pub fn gr_group_all_distances(ctx: *mut gr_ctx, slot: u32, g1: *const c_char, g2: *const c_char, dim: c_int, out: *mut c_float, cap: usize) -> c_int;
     pub fn gr_group_all_distances_batch_device(ctx: *mut gr_ctx, first_slot: u32, n_frames: u32, g1: *const c_char, g2: *const c_char, dim: c_int,
                                                out_dev: *mut *mut c_float, n1: *mut u64, n2: *mut u64, status_out: *mut c_int) -> c_int;
+    pub fn gr_trr_open(path: *const c_char, status: *mut c_int) -> *mut gr_trr;
+    pub fn gr_trr_close(trr: *mut gr_trr);
+    pub fn gr_trr_n_atoms(trr: *const gr_trr) -> u64;
+    pub fn gr_trr_n_frames(trr: *const gr_trr) -> u64;
+    pub fn gr_trr_frame_info(trr: *const gr_trr, frame: u64, step: *mut u64, time: *mut c_float, lambda: *mut c_float, box9: *mut c_float, sections: *mut c_int, double_precision: *mut c_int) -> c_int;
+    pub fn gr_trr_read_frame(trr: *const gr_trr, frame: u64, xyz: *mut c_float, vel: *mut c_float, force: *mut c_float, box9: *mut c_float, step: *mut u64, time: *mut c_float, lambda: *mut c_float) -> c_int;
+    pub fn gr_trr_read_frames_device(trr: *const gr_trr, first_frame: u64, n_frames: u32, frame_step: u64, ctx: *mut gr_ctx, first_slot: u32, steps: *mut u64, times: *mut c_float) -> c_int;
     pub fn gr_group_count(ctx: *const gr_ctx) -> u64;
     pub fn gr_group_name(ctx: *const gr_ctx, i: u64, name: *mut c_char, capacity: usize) -> c_int;
     pub fn gr_ctx_set_center_onepass_min(ctx: *mut gr_ctx, min_atoms: u32) -> c_int;
@@ -69,6 +76,7 @@ extern "C" {
 }
 
 #[repr(C)] pub struct gr_xtc { _private: [u8; 0] }
+#[repr(C)] pub struct gr_trr { _private: [u8; 0] }
 /// `gr_shape` of include/groan_hip.h: filled by the `gr_shape_*` constructors from the fields of
 /// `Sphere` / `Rectangular` / `Cylinder` / `TriangularPrism` (src/structures/shape.rs:17-68).
 #[repr(C)] #[derive(Clone, Copy, Default)]

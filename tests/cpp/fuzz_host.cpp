@@ -14,6 +14,7 @@
 #include <vector>
 #include "../../groan_rs_amd/csrc/gr_xtc.h"
 #include "../../groan_rs_amd/csrc/gr_textio.h"
+#include "../../groan_rs_amd/csrc/gr_trr.h"
 
 static std::vector<unsigned char> slurp(const char *path) {
     std::vector<unsigned char> v;
@@ -64,13 +65,33 @@ static void run_xtc(const std::string &path, Tally &t) {
     if (all) t.ok++; else t.rejected++;
 }
 
+// open + read every section of every frame of a (possibly corrupt) trr file
+static void run_trr(const std::string &path, Tally &t) {
+    grtr::File f;
+    const int st = grtr::open_file(f, path.c_str());
+    if (st != grtr::TRR_OK) { if (f.fd >= 0) close(f.fd); t.rejected++; return; }
+    if (f.natoms > (1u << 22)) { close(f.fd); t.rejected++; return; }
+    std::vector<float> x(3 * (size_t)f.natoms + 3);
+    std::vector<unsigned char> scratch;
+    bool all = true;
+    for (const grtr::FrameIndex &fi : f.frames)
+        for (uint64_t off : { fi.x_off, fi.v_off, fi.f_off })
+            if (grtr::read_section(f, fi, off, x.data(), scratch) != grtr::TRR_OK) all = false;
+    close(f.fd);
+    if (all) t.ok++; else t.rejected++;
+}
+
 int main(int argc, char **argv) {
     if (argc < 4) { fprintf(stderr, "usage: fuzz_host <iterations> <seed> <xtc...> -- <gro/ndx...>\n"); return 2; }
     const int iters = atoi(argv[1]);
     std::mt19937_64 rng((uint64_t)atoll(argv[2]));
-    std::vector<std::string> xtcs, texts;
+    std::vector<std::string> xtcs, texts, trrs;
     bool second = false;
-    for (int k = 3; k < argc; ++k) { if (!strcmp(argv[k], "--")) { second = true; continue; } (second ? texts : xtcs).push_back(argv[k]); }
+    for (int k = 3; k < argc; ++k) {
+        if (!strcmp(argv[k], "--")) { second = true; continue; }
+        const std::string a = argv[k];
+        if (a.size() > 4 && a.substr(a.size() - 4) == ".trr") trrs.push_back(a); else (second ? texts : xtcs).push_back(a);
+    }
     const char *tmpdir = getenv("TMPDIR") ? getenv("TMPDIR") : "/tmp";
     const std::string tmp = std::string(tmpdir) + "/fuzz_host_" + std::to_string((long)getpid());
     auto rnd = [&](uint64_t n) { return n ? rng() % n : 0; };
@@ -93,6 +114,25 @@ int main(int argc, char **argv) {
             }
             spit(tmp + ".xtc", m);
             run_xtc(tmp + ".xtc", tx);
+        }
+    }
+    // ---- trr: pristine files read; mutants (same mutators) never crash
+    Tally tr;
+    for (const std::string &p : trrs) {
+        const std::vector<unsigned char> orig = slurp(p.c_str());
+        { Tally t0; run_trr(p, t0); if (t0.ok != 1) { fprintf(stderr, "pristine %s rejected\n", p.c_str()); return 1; } }
+        for (int it = 0; it < iters; ++it) {
+            std::vector<unsigned char> m = orig;
+            switch (rnd(5)) {
+            case 0: m.resize(rnd(m.size() + 1)); break;
+            case 1: for (int k = 0, n = 1 + (int)rnd(8); k < n && !m.empty(); ++k) m[rnd(m.size())] ^= (unsigned char)(1u << rnd(8)); break;
+            case 2: if (m.size() >= 96) { size_t o = 4 * rnd(24); static const uint32_t evil[] = { 0u, 0xffffffffu, 0x7fffffffu, 0x80000000u, 1u, 12u, 0x01000000u };
+                        uint32_t v = evil[rnd(7)]; unsigned char b[4] = { (unsigned char)(v >> 24), (unsigned char)(v >> 16), (unsigned char)(v >> 8), (unsigned char)v }; memcpy(&m[o], b, 4); } break;
+            case 3: for (int k = 0, n = 1 + (int)rnd(4); k < n && m.size() >= 4; ++k) { size_t o = rnd(m.size() - 3); uint32_t v = (uint32_t)rng(); memcpy(&m[o], &v, 4); } break;
+            default: { size_t o = rnd(m.size() + 1), n = rnd(4096); m.insert(m.begin() + (long)o, n, (unsigned char)rnd(256)); } break;
+            }
+            spit(tmp + ".trr", m);
+            run_trr(tmp + ".trr", tr);
         }
     }
     // ---- encoder: hostile coordinates (NaN, infinities, 1e30, denormals) round-trip or are rejected, never crash
@@ -132,8 +172,9 @@ int main(int argc, char **argv) {
             else { grt::Structure s; const int r = grt::read_gro((tmp + ".gro").c_str(), s, detail); (r == grt::P_OK ? tt.ok : tt.rejected)++; }
         }
     }
+    remove((tmp + ".trr").c_str());
     remove((tmp + ".xtc").c_str()); remove((tmp + ".gro").c_str()); remove((tmp + ".ndx").c_str());
-    printf("xtc mutants: %ld decoded, %ld rejected; hostile encodes that decode: %ld of %d; text mutants: %ld parsed, %ld rejected\n",
-           tx.ok, tx.rejected, enc, iters, tt.ok, tt.rejected);
+    printf("xtc mutants: %ld decoded, %ld rejected; hostile encodes that decode: %ld of %d; text mutants: %ld parsed, %ld rejected; trr mutants: %ld read, %ld rejected\n",
+           tx.ok, tx.rejected, enc, iters, tt.ok, tt.rejected, tr.ok, tr.rejected);
     return 0;
 }

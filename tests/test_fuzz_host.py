@@ -21,9 +21,9 @@ def fuzz_bin():
 
 @pytest.mark.parametrize("seed", [1, 20260424])
 def test_mutated_inputs_never_crash(fuzz_bin, seed, tmp_path):
-    xtcs = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "*.xtc")))
+    xtcs = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "*.xtc"))) + sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "*.trr")))
     texts = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "textio", "*.gro")) + glob.glob(os.path.join(ROOT, "tests", "golden", "textio", "*.ndx")))
-    assert len(xtcs) >= 4 and len(texts) >= 10
+    assert len(xtcs) >= 9 and len(texts) >= 10
     env = dict(os.environ, TMPDIR=str(tmp_path), ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
     r = subprocess.run([fuzz_bin, "250", str(seed)] + xtcs + ["--"] + texts, capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
@@ -32,3 +32,4 @@ def test_mutated_inputs_never_crash(fuzz_bin, seed, tmp_path):
     words = r.stdout.replace(";", " ").replace(",", " ").split()
     decoded, rejected = int(words[2]), int(words[4])
     assert decoded > 50 and rejected > 50, r.stdout
+    assert "trr mutants:" in r.stdout and int(words[words.index("trr") + 2]) > 20 and int(words[words.index("trr") + 4]) > 50, r.stdout
