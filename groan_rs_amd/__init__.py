@@ -11,7 +11,7 @@ from .system import (AtomContainer, AtomError, DeviceError, Dimension, GroanErro
 from .traj import (FrameAnalyze, FrameConvert, FrameConvertAnalyze, RMSDConverterAnalyzer, TrajAnalyzer,
                    TrajAnalysisError, TrajConverter, TrajConverterAnalyzer, TrajReader)
 from .xtc import XtcError, XtcFile, XtcWriter
-from .trr import TrrFile
+from .trr import TrrFile, TrrWriter
 from .textio import ParseGroError, ParseNdxError, Structure, read_ndx_groups, system_from_gro, system_read_ndx
 from .select import SelectError, parse_query, select
 from .shapes import Cylinder, Rectangular, Shape, Sphere, TriangularPrism

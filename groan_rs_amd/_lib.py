@@ -73,6 +73,9 @@ SIGNATURES = {
     "gr_trr_n_frames": (C.c_uint64, [C.c_void_p]),
     "gr_trr_frame_info": (C.c_int, [C.c_void_p, C.c_uint64, c_u64p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "gr_trr_read_frame": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, c_u64p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "gr_trr_writer_open": (C.c_void_p, [C.c_char_p, C.POINTER(C.c_int)]),
+    "gr_trr_writer_close": (C.c_int, [C.c_void_p]),
+    "gr_trr_write_frame": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float]),
     "gr_trr_read_frames_device": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
     "gr_group_translate": (C.c_int, [C.c_void_p, C.c_uint32, C.c_char_p, C.c_void_p]),
     "gr_group_wrap": (C.c_int, [C.c_void_p, C.c_uint32, C.c_char_p]),

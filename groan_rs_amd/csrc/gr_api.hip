@@ -1814,7 +1814,8 @@ int gr_xtc_read_frames_device(const gr_xtc *x, uint64_t first_frame, uint32_t n_
     return GR_OK;
 } catch (...) { return gr_abi_guard(); }
 
-/* ------------------------------------------------------------ trr reader */
+static void box9_rows(const float *b, float m[9]);
+/* ------------------------------------------------------------ trr reader / writer */
 struct gr_trr { grtr::File f; };
 static int trr_status(int s) { return s == grtr::TRR_OK ? GR_OK : (s == grtr::TRR_E_IO ? GR_E_IO : GR_E_FORMAT); }
 
@@ -1852,6 +1853,26 @@ int gr_trr_read_frame(const gr_trr *t, uint64_t frame, float *xyz, float *veloci
     st = trr_status(grtr::read_section(t->f, fi, fi.x_off, xyz, scratch)); if (st) return st;
     st = trr_status(grtr::read_section(t->f, fi, fi.v_off, velocities, scratch)); if (st) return st;
     return trr_status(grtr::read_section(t->f, fi, fi.f_off, forces, scratch));
+} catch (...) { return gr_abi_guard(); }
+
+struct gr_trr_writer { FILE *fp = nullptr; };
+gr_trr_writer *gr_trr_writer_open(const char *path, int *status) try {
+    int dummy; if (!status) status = &dummy;
+    if (!path) { *status = GR_E_INVALID_ARG; return nullptr; }
+    FILE *fp = fopen(path, "wb");
+    if (!fp) { *status = GR_E_IO; return nullptr; }
+    gr_trr_writer *w = new gr_trr_writer(); w->fp = fp;
+    *status = GR_OK;
+    return w;
+} catch (...) { return nullptr; }
+int gr_trr_writer_close(gr_trr_writer *w) { if (!w) return GR_E_INVALID_ARG; const int r = w->fp ? fclose(w->fp) : 0; delete w; return r == 0 ? GR_OK : GR_E_IO; }
+int gr_trr_write_frame(gr_trr_writer *w, uint64_t n, const float *xyz, const float *velocities, const float *forces, const float box9[9],
+                       int64_t step, float time, float lambda) try {
+    if (!w || !w->fp || n > 0x0fffffffull) return GR_E_INVALID_ARG;
+    float m[9]; box9_rows(box9, m);
+    std::vector<unsigned char> out;
+    grtr::serialise_frame(out, (uint32_t)n, (int32_t)step, time, lambda, m, xyz, velocities, forces);
+    return fwrite(out.data(), 1, out.size(), w->fp) == out.size() ? GR_OK : GR_E_IO;
 } catch (...) { return gr_abi_guard(); }
 
 // raw big-endian position sections of a batch of frames -> frame slots (f32); an all-zero position is "no position"

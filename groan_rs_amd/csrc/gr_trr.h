@@ -126,4 +126,27 @@ inline int read_section(const File &f, const FrameIndex &fi, uint64_t sec_off, f
     return TRR_OK;
 }
 
+// ---- writer: what the reference's TrrWriter produces through xdrfile's write_trr (src/io/trr_io.rs:441-520,
+// xdrfile_trr.c do_trn / do_trnheader / do_htrn): single precision, box + positions + velocities + forces sections (a NULL
+// array omits its section), nre = 0, no virial / pressure.  A position without value (NaN in x) is written as zeros.
+inline void put_be32(std::vector<unsigned char> &o, uint32_t v) { o.push_back((unsigned char)(v >> 24)); o.push_back((unsigned char)(v >> 16)); o.push_back((unsigned char)(v >> 8)); o.push_back((unsigned char)v); }
+inline void put_bef(std::vector<unsigned char> &o, float f) { uint32_t u; memcpy(&u, &f, 4); put_be32(o, u); }
+inline void serialise_frame(std::vector<unsigned char> &o, uint32_t natoms, int32_t step, float time, float lambda, const float *box_rows,
+                            const float *x, const float *v, const float *f) {
+    o.clear();
+    o.reserve(96 + 36 + (size_t)natoms * 36);
+    put_be32(o, 1993u); put_be32(o, 13u); put_be32(o, 12u);
+    o.insert(o.end(), (const unsigned char *)"GMX_trn_file", (const unsigned char *)"GMX_trn_file" + 12);
+    const uint32_t n12 = natoms * 12u;
+    put_be32(o, 0); put_be32(o, 0); put_be32(o, box_rows ? 36u : 0u); put_be32(o, 0); put_be32(o, 0); put_be32(o, 0); put_be32(o, 0);   // ir e box vir pres top sym
+    put_be32(o, x ? n12 : 0u); put_be32(o, v ? n12 : 0u); put_be32(o, f ? n12 : 0u);
+    put_be32(o, natoms); put_be32(o, (uint32_t)step); put_be32(o, 0u);
+    put_bef(o, time); put_bef(o, lambda);
+    if (box_rows) for (int k = 0; k < 9; ++k) put_bef(o, box_rows[k]);
+    const size_t n3 = (size_t)natoms * 3;
+    if (x) for (size_t k = 0; k < n3; ++k) put_bef(o, (x[3 * (k / 3)] != x[3 * (k / 3)]) ? 0.0f : x[k]);
+    if (v) for (size_t k = 0; k < n3; ++k) put_bef(o, v[k]);
+    if (f) for (size_t k = 0; k < n3; ++k) put_bef(o, f[k]);
+}
+
 }  // namespace grtr

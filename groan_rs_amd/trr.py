@@ -72,3 +72,38 @@ class TrrFile:
             if zero.any():
                 x[zero, 0] = np.nan
             yield x, box, s, t
+
+
+class TrrWriter:
+    """TrrWriter (src/io/trr_io.rs:441-520): single-precision frames with box, positions, velocities and forces -- like the
+    reference, every frame carries all three arrays, zeros where the system has none; byte-compatible with its writer."""
+
+    def __init__(self, path):
+        self._lib = _lib.load()
+        st = C.c_int(0)
+        self._w = self._lib.gr_trr_writer_open(str(path).encode(), C.byref(st))
+        if not self._w:
+            raise XtcError(st.value, "cannot create %s" % path)
+
+    def write_frame(self, positions, box9, step=0, time=0.0, lambda_=0.0, velocities=None, forces=None):
+        x = np.ascontiguousarray(positions, np.float32)
+        v = np.zeros_like(x) if velocities is None else np.ascontiguousarray(velocities, np.float32)
+        f = np.zeros_like(x) if forces is None else np.ascontiguousarray(forces, np.float32)
+        b = None if box9 is None else np.ascontiguousarray(box9, np.float32)
+        p = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
+        st = self._lib.gr_trr_write_frame(self._w, x.shape[0], p(x), p(v), p(f), p(b), int(step), C.c_float(time), C.c_float(lambda_))
+        if st != _lib.OK:
+            raise XtcError(st, "write_frame")
+
+    def close(self):
+        if getattr(self, "_w", None):
+            st = self._lib.gr_trr_writer_close(self._w)
+            self._w = None
+            if st != _lib.OK:
+                raise XtcError(st, "close")
+
+    def __enter__(self): return self
+    def __exit__(self, *a): self.close()
+    def __del__(self):
+        try: self.close()
+        except Exception: pass

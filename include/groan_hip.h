@@ -289,6 +289,14 @@ int gr_trr_frame_info(const gr_trr *trr, uint64_t frame, uint64_t *step, float *
 int gr_trr_read_frame(const gr_trr *trr, uint64_t frame, float *xyz, float *velocities, float *forces, float box9[9], uint64_t *step, float *time, float *lambda);
 int gr_trr_read_frames_device(const gr_trr *trr, uint64_t first_frame, uint32_t n_frames, uint64_t frame_step, gr_ctx *ctx, uint32_t first_slot,
                               uint64_t *steps, float *times);
+/* TrrWriter (src/io/trr_io.rs:441-520 over xdrfile's write_trr): single precision, box + the sections whose array is not
+ * NULL (the reference always writes positions, velocities and forces, zeros where an atom has none), byte for byte the
+ * reference writer's frames.  A position without value (NaN in x) is written as zeros; box9 NULL writes a zero matrix. */
+typedef struct gr_trr_writer gr_trr_writer;
+gr_trr_writer *gr_trr_writer_open(const char *path, int *status);
+int gr_trr_writer_close(gr_trr_writer *w);
+int gr_trr_write_frame(gr_trr_writer *w, uint64_t n_atoms, const float *xyz, const float *velocities, const float *forces, const float box9[9],
+                       int64_t step, float time, float lambda);
 
 /* ---------------------------------------------------------------- xtc writer (host side; the step after calc_rmsd_and_fit)
  * XtcWriter::new / write_frame (src/io/xtc_io/mod.rs:256-331 over xdrfile's write_xtc): the library's own encoder, byte for

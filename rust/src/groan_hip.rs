@@ -48,6 +48,9 @@ extern "C" {
     pub fn gr_trr_n_frames(trr: *const gr_trr) -> u64;
     pub fn gr_trr_frame_info(trr: *const gr_trr, frame: u64, step: *mut u64, time: *mut c_float, lambda: *mut c_float, box9: *mut c_float, sections: *mut c_int, double_precision: *mut c_int) -> c_int;
     pub fn gr_trr_read_frame(trr: *const gr_trr, frame: u64, xyz: *mut c_float, vel: *mut c_float, force: *mut c_float, box9: *mut c_float, step: *mut u64, time: *mut c_float, lambda: *mut c_float) -> c_int;
+    pub fn gr_trr_writer_open(path: *const c_char, status: *mut c_int) -> *mut gr_trr_writer;
+    pub fn gr_trr_writer_close(w: *mut gr_trr_writer) -> c_int;
+    pub fn gr_trr_write_frame(w: *mut gr_trr_writer, n_atoms: u64, xyz: *const c_float, vel: *const c_float, force: *const c_float, box9: *const c_float, step: i64, time: c_float, lambda: c_float) -> c_int;
     pub fn gr_trr_read_frames_device(trr: *const gr_trr, first_frame: u64, n_frames: u32, frame_step: u64, ctx: *mut gr_ctx, first_slot: u32, steps: *mut u64, times: *mut c_float) -> c_int;
     pub fn gr_group_count(ctx: *const gr_ctx) -> u64;
     pub fn gr_group_name(ctx: *const gr_ctx, i: u64, name: *mut c_char, capacity: usize) -> c_int;
@@ -77,6 +80,7 @@ extern "C" {
 
 #[repr(C)] pub struct gr_xtc { _private: [u8; 0] }
 #[repr(C)] pub struct gr_trr { _private: [u8; 0] }
+#[repr(C)] pub struct gr_trr_writer { _private: [u8; 0] }
 /// `gr_shape` of include/groan_hip.h: filled by the `gr_shape_*` constructors from the fields of
 /// `Sphere` / `Rectangular` / `Cylinder` / `TriangularPrism` (src/structures/shape.rs:17-68).
 #[repr(C)] #[derive(Clone, Copy, Default)]
