@@ -14,6 +14,8 @@
 //   FrameAnalyze / FrameConvert / FrameConvertAnalyze    abstract classes with the same single method
 //   TrajAnalyzer / TrajConverter / TrajConverterAnalyzer for_each_frame_* adapters over any frame source
 //   RMSDConverterAnalyzer                                 groan::RMSDConverterAnalyzer (cached plan)
+//   XtcReader / TrrReader (+ with_range / with_step)      groan::XtcReader / TrrReader::frames(start, end, step) as frame sources
+//   XtcWriter                                             groan::XtcWriter (host frames and device slots)
 //   ParallelTrajData + traj_iter_map_reduce              groan::traj_iter_map_reduce (one worker thread per GPU,
 //                                                         frames round-robin, shared error flag, reduce())
 //   Result<T, GroupError|AtomError|RMSDError>             exceptions carrying the variant + payload
@@ -22,7 +24,9 @@
 #include <atomic>
 #include <cmath>
 #include <cstdint>
+#include <algorithm>
 #include <functional>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <thread>
@@ -308,6 +312,110 @@ void for_each_frame_convert_analyze(System &system, Source &&next_frame, FrameCo
     Frame f;
     while (next_frame(f)) { system.set_frame(f.xyz, f.box); sink(f, ca.convert_analyze(system)); }
 }
+
+// ---- XtcReader / TrrReader as frame sources (src/io/xtc_io/mod.rs, src/io/trr_io.rs; `with_range` / `with_step` of
+// traj_read.rs:609-697 are the `start, end, step` of frames()), XtcWriter (xtc_io/mod.rs:256-331)
+class XtcReader {
+  public:
+    explicit XtcReader(const std::string &path) {
+        int st = 0;
+        x_ = gr_xtc_open(path.c_str(), &st);
+        if (!x_) throw Error("ReadTrajError", st == GR_E_IO ? "FileNotFound" : "NotXtc", st);
+        xyz_.resize(3 * (size_t)n_atoms());
+    }
+    ~XtcReader() { if (x_) gr_xtc_close(x_); }
+    XtcReader(const XtcReader &) = delete;
+    XtcReader &operator=(const XtcReader &) = delete;
+    uint64_t n_atoms() const { return gr_xtc_n_atoms(x_); }
+    uint64_t n_frames() const { return gr_xtc_n_frames(x_); }
+    const gr_xtc *raw() const { return x_; }
+    // frame i decoded into this reader's buffer (valid until the next read)
+    Frame read(uint64_t i) {
+        float b[9]; uint64_t step = 0; float time = 0, prec = 0;
+        const int st = gr_xtc_read_frame(x_, i, xyz_.data(), b, &step, &time, &prec);
+        if (st != GR_OK) throw Error("ReadTrajError", "FrameNotFound", st, i);
+        for (int k = 0; k < 9; ++k) box_[k] = b[k];
+        return Frame{xyz_.data(), &box_, step, time};
+    }
+    // a Source for for_each_frame_*: frames start, start + step, ... < end
+    std::function<bool(Frame &)> frames(uint64_t start = 0, uint64_t end = UINT64_MAX, uint64_t step = 1) {
+        auto next = std::make_shared<uint64_t>(start);
+        return [this, next, end, step](Frame &out) {
+            if (*next >= std::min<uint64_t>(end, n_frames())) return false;
+            out = read(*next); *next += step;
+            return true;
+        };
+    }
+    // a batch of frames unpacked on the GPU straight into the system's slots (compressed bytes over PCIe)
+    void read_frames_device(System &system, uint64_t first_frame, uint32_t n, uint32_t first_slot = 0, uint64_t frame_step = 1, int host_threads = 0) {
+        const int st = gr_xtc_read_frames_device(x_, first_frame, n, frame_step, system.raw(), first_slot, host_threads, nullptr, nullptr);
+        if (st != GR_OK) throw Error("ReadTrajError", "FrameNotFound", st, first_frame);
+    }
+  private:
+    gr_xtc *x_ = nullptr;
+    std::vector<float> xyz_;
+    Box9 box_{};
+};
+
+class TrrReader {
+  public:
+    explicit TrrReader(const std::string &path) {
+        int st = 0;
+        t_ = gr_trr_open(path.c_str(), &st);
+        if (!t_) throw Error("ReadTrajError", st == GR_E_IO ? "FileNotFound" : "NotTrr", st);
+        xyz_.resize(3 * (size_t)n_atoms());
+    }
+    ~TrrReader() { if (t_) gr_trr_close(t_); }
+    TrrReader(const TrrReader &) = delete;
+    TrrReader &operator=(const TrrReader &) = delete;
+    uint64_t n_atoms() const { return gr_trr_n_atoms(t_); }
+    uint64_t n_frames() const { return gr_trr_n_frames(t_); }
+    // positions of frame i (an all-zero position = the reference's "no position": NaN in x, trr_io.rs:108-112)
+    Frame read(uint64_t i) {
+        float b[9]; uint64_t step = 0; float time = 0, lambda = 0;
+        const int st = gr_trr_read_frame(t_, i, xyz_.data(), nullptr, nullptr, b, &step, &time, &lambda);
+        if (st != GR_OK) throw Error("ReadTrajError", "FrameNotFound", st, i);
+        for (size_t a = 0; a < xyz_.size(); a += 3) if (xyz_[a] == 0.0f && xyz_[a + 1] == 0.0f && xyz_[a + 2] == 0.0f) xyz_[a] = NAN;
+        for (int k = 0; k < 9; ++k) box_[k] = b[k];
+        return Frame{xyz_.data(), &box_, step, time};
+    }
+    std::function<bool(Frame &)> frames(uint64_t start = 0, uint64_t end = UINT64_MAX, uint64_t step = 1) {
+        auto next = std::make_shared<uint64_t>(start);
+        return [this, next, end, step](Frame &out) {
+            if (*next >= std::min<uint64_t>(end, n_frames())) return false;
+            out = read(*next); *next += step;
+            return true;
+        };
+    }
+  private:
+    gr_trr *t_ = nullptr;
+    std::vector<float> xyz_;
+    Box9 box_{};
+};
+
+class XtcWriter {
+  public:
+    explicit XtcWriter(const std::string &path) {
+        int st = 0;
+        w_ = gr_xtc_writer_open(path.c_str(), &st);
+        if (!w_) throw Error("WriteTrajError", "CouldNotCreate", st);
+    }
+    ~XtcWriter() { if (w_) gr_xtc_writer_close(w_); }
+    XtcWriter(const XtcWriter &) = delete;
+    XtcWriter &operator=(const XtcWriter &) = delete;
+    void write_frame(const float *xyz, uint64_t n_atoms, const Box9 *box, int64_t step, float time, float precision = 1000.0f) {
+        const int st = gr_xtc_write_frame(w_, n_atoms, xyz, box ? box->data() : nullptr, step, time, precision);
+        if (st != GR_OK) throw Error("WriteTrajError", "CouldNotWrite", st);
+    }
+    // device frames (e.g. after calc_rmsd_and_fit on a batch of slots), all atoms or a group
+    void write_slots(System &system, uint32_t first_slot, uint32_t n_frames, const char *group = nullptr, float precision = 1000.0f, int host_threads = 0) {
+        const int st = gr_xtc_write_slots(w_, system.raw(), first_slot, n_frames, group, nullptr, nullptr, precision, host_threads);
+        if (st == GR_E_GROUP_NOT_FOUND) throw Error("WriteTrajError", "GroupNotFound", st);
+        if (st != GR_OK) throw Error("WriteTrajError", "CouldNotWrite", st);
+    }
+  private:
+    gr_xtc_writer *w_ = nullptr;
+};
 
 // ---- ParallelTrajData + traj_iter_map_reduce (src/system/parallel.rs:31-49,208-481)
 // One worker thread per device; worker n takes frames n, n+T, ... (parallel.rs:424-448); a shared AtomicBool

@@ -145,6 +145,40 @@ int main(int argc, char **argv) {
         auto bad_body = [&](System &s, RmsdData &) { std::lock_guard<std::mutex> lock(ref_mutex); s.calc_rmsd(reference, "Nonexistent"); };
         try { traj_iter_map_reduce<RmsdData>({0, 0}, 11, make_system, read_frame, bad_body, RmsdData{}); CHECK(false); } catch (const std::runtime_error &) {}
     }
+    // ---- XtcReader as a frame source + RMSDConverterAnalyzer + XtcWriter: `system.xtc_iter(f)?.convert_and_analyze(..)` and
+    // traj_write_frame on the reference's 50-atom triclinic trajectory (argv[2]); decode(encode(decode)) is a fixed point
+    if (argc >= 3) {
+        XtcReader xr(std::string(argv[2]) + "/triclinic_trajectory.xtc");
+        CHECK(xr.n_atoms() == 50 && xr.n_frames() == 11);
+        System sys50(50, 0, 4);
+        std::vector<float> m50(50, 1.0f);
+        sys50.set_masses(m50);
+        std::vector<uint64_t> steps;
+        std::vector<std::vector<float>> decoded;
+        {
+            XtcWriter xw(std::string(argv[1]) + "/rewritten.xtc");
+            auto src = xr.frames();
+            Frame f;
+            while (src(f)) {
+                steps.push_back(f.step);
+                decoded.emplace_back(f.xyz, f.xyz + 150);
+                xw.write_frame(f.xyz, 50, f.box, (int64_t)f.step, f.time, 100.0f);
+            }
+        }
+        CHECK(steps.size() == 11 && steps[0] == 0 && steps[1] == 5000 && steps[10] == 50000);   // xtc_io/mod.rs tests
+        XtcReader again(std::string(argv[1]) + "/rewritten.xtc");
+        CHECK(again.n_frames() == 11);
+        for (uint64_t i = 0; i < 11; ++i) { Frame f = again.read(i); for (int k = 0; k < 150; ++k) CHECK(f.xyz[k] == decoded[i][k]); }
+        auto strided = xr.frames(1, 8, 3);   // with_range + with_step: frames 1, 4, 7
+        Frame f; int cnt = 0; uint64_t want[3] = {5000, 20000, 35000};
+        while (strided(f)) { CHECK(cnt < 3 && f.step == want[cnt]); ++cnt; }
+        CHECK(cnt == 3);
+        xr.read_frames_device(sys50, 0, 4);
+        for (uint32_t k = 0; k < 4; ++k) { std::vector<float> got = sys50.get_positions(k); for (int j = 0; j < 150; ++j) CHECK(got[j] == decoded[k][j]); }
+        TrrReader tr(std::string(argv[2]) + "/triclinic_trajectory.trr");
+        CHECK(tr.n_atoms() == 50 && tr.n_frames() == 13);
+        try { XtcReader bad(std::string(argv[2]) + "/no_such_file.xtc"); CHECK(false); } catch (const Error &e) { CHECK(e.variant == "FileNotFound"); }
+    }
     printf(failures ? "test_host: %d FAILED\n" : "test_host: all passed\n", failures);
     return failures ? 1 : 0;
 }

@@ -22,7 +22,7 @@ def test_cpp_host_mirror(tmp_path, example, short_traj):
     m.astype("<f4").tofile(tmp_path / "masses.f32")
     env = dict(os.environ)
     env["LD_LIBRARY_PATH"] = os.path.join(ROOT, "groan_rs_amd") + ":/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
-    p = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, env=env, timeout=300)
+    p = subprocess.run([exe, str(tmp_path), os.path.join(ROOT, "tests", "golden")], capture_output=True, text=True, env=env, timeout=300)
     print(p.stdout, p.stderr)
     assert p.returncode == 0, p.stdout + p.stderr
     assert "all passed" in p.stdout
