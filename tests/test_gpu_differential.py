@@ -352,3 +352,45 @@ def test_results_are_bitwise_reproducible(G):
         for a, b in zip(runs[0][3], runs[rep][3]):
             assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
     ref.close(); cur.close()
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_centring_and_group_distance_on_nasty_inputs(G, seed):
+    """atoms_center / atoms_center_mass in every Dimension (utility.rs:109-185: Bai-Breen estimate of the reference group, masked
+    shift, translate + wrap of every atom) and group_distance (analysis.rs:348-360: distance between two get_center results) on
+    the adversarial coordinate mix; the reference group is compact (a scattered group's circular mean is ill-conditioned)"""
+    rng = np.random.default_rng(3000 + seed)
+    n = int(rng.choice([8, 40, 150, 300]))
+    L = np.float32(rng.choice([1.0, 3.0, 6.5, 13.0], 3))
+    box = np.array([L[0], L[1], L[2], 0, 0, 0, 0, 0, 0], np.float32)
+    pos = nasty_positions(rng, n, L)
+    nref = max(3, n // 4)
+    centre = (rng.random(3) * L).astype(np.float32)
+    pos[:nref] = O.wrap_atoms((centre + rng.normal(0, 0.05 * float(L.min()), (nref, 3))).astype(np.float32), np.arange(nref), box)
+    pos[nref:2 * nref] = O.wrap_atoms((centre * np.float32(0.37) + rng.normal(0, 0.04 * float(L.min()), (min(nref, n - nref), 3))[: max(0, min(nref, n - nref))]).astype(np.float32), np.arange(max(0, min(nref, n - nref))), box) if n >= 2 * nref else pos[nref:2 * nref]
+    masses = rng.choice(np.float32([1.008, 12.011, 15.999, 72.0]), n).astype(np.float32)
+    s = G.System(n, masses=masses, n_slots=1)
+    s.group_create_from_ranges("R", [(0, nref - 1)])
+    if n >= 2 * nref:
+        s.group_create_from_ranges("Q", [(nref, 2 * nref - 1)])
+    iref = np.arange(nref)
+    tol = 3e-5 * max(1.0, float(L.max()))
+    for dim in DIMS:
+        for weighted in (False, True):
+            s.set_frame(pos, box)
+            (s.atoms_center_mass if weighted else s.atoms_center)("R", G.Dimension[dim])
+            got = s.get_positions()
+            with O.acc64():
+                want = O.atoms_center(pos, iref, dim.lower(), box, mass=masses if weighted else None)
+            d = np.abs(got - want); d = np.minimum(d, np.abs(d - L))        # an atom may land on either face of the cell
+            assert d.max() <= tol, (dim, weighted, float(d.max()))
+    if n >= 2 * nref:
+        s.set_frame(pos, box)
+        iq = np.arange(nref, 2 * nref)
+        with O.acc64():
+            c1, c2 = O.get_center(pos, iref, box), O.get_center(pos, iq, box)
+        for dim in DIMS:
+            want = O.distance(c1, c2, dim.lower(), box)
+            got = s.group_distance("R", "Q", G.Dimension[dim])
+            assert min(abs(got - want), abs(abs(got - want) - float(L[{"X": 0, "Y": 1, "Z": 2}.get(dim, 0)]))) <= tol, (dim, got, want)
+    s.close()
