@@ -54,7 +54,7 @@ def main():
     for f in range(nf):
         print("%6d %10.6f" % (f, rmsd[f]))
     print("# %d frames x %d atoms in %.3f s = %.1f frames/s (decode on device, fit on device, encode on %s host threads)"
-          % (nf, n, dt, nf / dt, a.threads or "up to 8"), file=sys.stderr)
+          % (nf, n, dt, nf / dt, a.threads or "up to 16"), file=sys.stderr)
 
 
 if __name__ == "__main__":
