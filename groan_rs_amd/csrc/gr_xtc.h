@@ -67,41 +67,60 @@ struct File {
     std::string error;
 };
 
-// MSB-first bit reader over a byte buffer (the buffer carries 8 bytes of zero padding behind the stream)
+// MSB-first bit reader over a byte buffer (the buffer carries GR_XTC_PAD bytes of zero padding behind the stream); the
+// window is refilled four bytes at a time
 struct Bits {
     const unsigned char *p; size_t pos = 0;   // next byte to pull
-    uint64_t win = 0; int have = 0;           // `have` valid bits at the bottom of win
+    uint64_t win = 0; int have = 0;           // `have` (< 32 between calls) valid bits at the bottom of win
     explicit Bits(const unsigned char *buf) : p(buf) {}
     inline uint32_t get(int n) {              // 0 <= n <= 32
         if (n == 0) return 0;
-        while (have < n) { win = (win << 8) | p[pos++]; have += 8; }
+        if (have < n) { win = (win << 32) | (uint64_t)be32(p + pos); pos += 4; have += 32; }
         have -= n;
         return (uint32_t)((win >> have) & ((n == 32) ? 0xFFFFFFFFull : ((1ull << n) - 1)));
     }
     // the integer that packs three mixed-radix digits: bytes in read order are its little-endian bytes, the trailing
-    // partial byte is the most significant
-    inline unsigned __int128 get_packed(int nbits) {
-        unsigned __int128 v = 0;
-        int shift = 0;
-        while (nbits > 8) { v |= (unsigned __int128)get(8) << shift; shift += 8; nbits -= 8; }
-        if (nbits > 0) v |= (unsigned __int128)get(nbits) << shift;
+    // partial byte is the most significant.  The m whole bytes are read as one big-endian field and byte-swapped.
+    inline uint64_t get_packed64(int nbits) {  // nbits <= 64
+        const int m = nbits >> 3, rest = nbits & 7;
+        uint64_t v = 0;
+        if (m > 0) {
+            uint64_t be = 0;
+            if (m > 4) { be = (uint64_t)get(8 * (m - 4)) << 32; be |= get(32); } else be = get(8 * m);
+            v = __builtin_bswap64(be << (64 - 8 * m));
+        }
+        if (rest) v |= (uint64_t)get(rest) << (8 * m);     // (m <= 7 here)
         return v;
     }
-    inline uint64_t get_packed64(int nbits) {  // nbits <= 64
-        uint64_t v = 0;
-        int shift = 0;
-        while (nbits > 8) { v |= (uint64_t)get(8) << shift; shift += 8; nbits -= 8; }
-        if (nbits > 0) v |= (uint64_t)get(nbits) << shift;
-        return v;
+    inline unsigned __int128 get_packed(int nbits) {
+        if (nbits <= 64) return get_packed64(nbits);
+        const uint64_t lo = get_packed64(64);
+        return (unsigned __int128)lo | ((unsigned __int128)get_packed64(nbits - 64) << 64);
     }
 };
 
-inline void unpack3(Bits &b, int nbits, const uint32_t sz[3], int out[3]) {
+// quotient and remainder by a divisor known in advance: below 2^52 the product with the stored reciprocal is within one of
+// the true quotient (the numerator converts exactly, the reciprocal is correctly rounded), one compare fixes it -- a third of
+// the latency of the 64-bit division; above that the division itself
+inline uint64_t divrem(uint64_t v, uint32_t d, double inv, uint32_t &rem) {
+    if (v < (1ull << 52)) {
+        uint64_t q = (uint64_t)((double)v * inv);
+        int64_t r = (int64_t)(v - q * d);
+        if (r < 0) { --q; r += d; } else if (r >= (int64_t)d) { ++q; r -= d; }
+        rem = (uint32_t)r;
+        return q;
+    }
+    const uint64_t q = v / d; rem = (uint32_t)(v - q * d);
+    return q;
+}
+// inv[0] = 1 / sz[1], inv[1] = 1 / sz[2]
+inline void unpack3(Bits &b, int nbits, const uint32_t sz[3], const double inv[2], int out[3]) {
     if (nbits <= 64) {
-        uint64_t v = b.get_packed64(nbits);
-        const uint64_t q2 = v / sz[2]; out[2] = (int)(v - q2 * sz[2]);
-        const uint64_t q1 = q2 / sz[1]; out[1] = (int)(q2 - q1 * sz[1]);
-        out[0] = (int)(uint32_t)q1;
+        const uint64_t v = b.get_packed64(nbits);
+        uint32_t r2, r1;
+        const uint64_t q2 = divrem(v, sz[2], inv[1], r2);
+        const uint64_t q1 = divrem(q2, sz[1], inv[0], r1);
+        out[2] = (int)r2; out[1] = (int)r1; out[0] = (int)(uint32_t)q1;
     } else {
         unsigned __int128 v = b.get_packed(nbits);
         const unsigned __int128 q2 = v / sz[2]; out[2] = (int)(uint64_t)(v - q2 * sz[2]);
@@ -192,6 +211,9 @@ inline int decode_frame(const File &f, const FrameIndex &fi, float *xyz, std::ve
     int smaller = kMagic[smallidx - 1 > kFirstIdx ? smallidx - 1 : kFirstIdx] / 2;
     int smallnum = kMagic[smallidx] / 2;
     uint32_t sizesmall[3] = { (uint32_t)kMagic[smallidx], (uint32_t)kMagic[smallidx], (uint32_t)kMagic[smallidx] };
+    if (sizeint[0] == 0 || sizeint[1] == 0 || sizeint[2] == 0) return XTC_E_FORMAT;   // maxint - minint + 1 wrapped: a corrupt header
+    const double inv_large[2] = { 1.0 / (double)sizeint[1], 1.0 / (double)sizeint[2] };
+    double inv_small[2] = { 1.0 / (double)sizesmall[1], 1.0 / (double)sizesmall[2] };
     const float inv_precision = (float)(1.0 / (double)fi.precision);
     Bits bits(scratch.data());
     const size_t limit = (size_t)fi.nbytes + 8;
@@ -201,7 +223,7 @@ inline int decode_frame(const File &f, const FrameIndex &fi, float *xyz, std::ve
     while (i < n) {
         int cur[3];
         if (bitsize == 0) { cur[0] = (int)bits.get(bitsizeint[0]); cur[1] = (int)bits.get(bitsizeint[1]); cur[2] = (int)bits.get(bitsizeint[2]); }
-        else unpack3(bits, bitsize, sizeint, cur);
+        else unpack3(bits, bitsize, sizeint, inv_large, cur);
         cur[0] = wadd(cur[0], fi.minint[0]); cur[1] = wadd(cur[1], fi.minint[1]); cur[2] = wadd(cur[2], fi.minint[2]);
         ++i;
         int change = 0;
@@ -216,7 +238,7 @@ inline int decode_frame(const File &f, const FrameIndex &fi, float *xyz, std::ve
             int prev[3] = { cur[0], cur[1], cur[2] };
             for (int k = 0; k < run; k += 3) {
                 int d[3];
-                unpack3(bits, smallidx, sizesmall, d);
+                unpack3(bits, smallidx, sizesmall, inv_small, d);
                 int nxt[3] = { wsub(wadd(d[0], prev[0]), smallnum), wsub(wadd(d[1], prev[1]), smallnum), wsub(wadd(d[2], prev[2]), smallnum) };
                 ++i;
                 if (k == 0) {
@@ -237,7 +259,7 @@ inline int decode_frame(const File &f, const FrameIndex &fi, float *xyz, std::ve
         if (smallidx < kFirstIdx || smallidx >= kLastIdx) return XTC_E_FORMAT;
         if (change < 0) { smallnum = smaller; smaller = smallidx > kFirstIdx ? kMagic[smallidx - 1] / 2 : 0; }
         else if (change > 0) { smaller = smallnum; smallnum = kMagic[smallidx] / 2; }
-        sizesmall[0] = sizesmall[1] = sizesmall[2] = (uint32_t)kMagic[smallidx];
+        if (change != 0) { sizesmall[0] = sizesmall[1] = sizesmall[2] = (uint32_t)kMagic[smallidx]; inv_small[0] = inv_small[1] = 1.0 / (double)sizesmall[1]; }
     }
     return XTC_OK;
 }
@@ -266,6 +288,7 @@ inline uint32_t peek_bits(const unsigned char *p, uint64_t bitpos, int n) {   //
 // Walk the groups of one frame (natoms > 9): fills the descriptor's decoding constants and the checkpoints.
 inline int skim_frame(const unsigned char *stream, const FrameIndex &fi, uint32_t n, FrameDesc &d, std::vector<Checkpoint> &cps) {
     for (int k = 0; k < 3; ++k) { d.minint[k] = fi.minint[k]; d.sizeint[k] = (uint32_t)fi.maxint[k] - (uint32_t)fi.minint[k] + 1u; }
+    if (d.sizeint[0] == 0 || d.sizeint[1] == 0 || d.sizeint[2] == 0) return XTC_E_FORMAT;   // corrupt header (the decoder refuses it too)
     d.bitsizeint[0] = d.bitsizeint[1] = d.bitsizeint[2] = 0;
     int large_bits;
     if ((d.sizeint[0] | d.sizeint[1] | d.sizeint[2]) > 0xffffffu) {
