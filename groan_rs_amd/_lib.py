@@ -43,6 +43,7 @@ SIGNATURES = {
     "gr_container_n_atoms": (C.c_uint64, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "gr_container_expand": (C.c_size_t, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "gr_container_isin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64]),
+    "gr_container_validate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64, c_u64p]),
     "gr_group_create_from_ranges": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "gr_group_create_from_indices": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t]),
     "gr_group_remove": (C.c_int, [C.c_void_p, C.c_char_p]),

@@ -126,6 +126,8 @@ struct gr_ctx {
     float *wr_host = nullptr; size_t wr_cap = 0;   // pinned landing buffer of gr_xtc_write_slots (grow-only)
     std::string ps_trace_path;
     int strict = 0;
+    gr_rmsd_plan *in_flight = nullptr;   // the plan whose gr_rmsd_batch_begin has not been ended yet (shared workspace: one at a time)
+    uint64_t epoch = 1;                  // bumped whenever masses or groups change: plans re-resolve what they cached
     std::string err;
     uint64_t err_index = 0;
     uint64_t counts[2] = { 0, 0 };
@@ -139,6 +141,9 @@ struct Pending {   // a segment between gr_rmsd_batch_begin and gr_rmsd_batch_en
     std::vector<uint32_t> fit_launch_frames;   // profiling: frames of every k_fit launch of the segment, in pev_fit order
     std::vector<uint64_t> pre_idx;
     std::vector<std::string> pre_msg;
+    GrSel sel = {};        // the group as it was at begin (the context refuses group / mass changes while a batch is in flight)
+    uint64_t group_n = 0;
+    bool has_group = false;
 };
 
 struct gr_rmsd_plan {
@@ -152,6 +157,7 @@ struct gr_rmsd_plan {
     int exact = 0;
     uint32_t last_fallbacks = 0;
     bool resolved = false, last_persist = false;
+    uint64_t resolved_epoch = 0;   // context epoch at which w_is_mass was decided
 };
 
 namespace {
@@ -234,10 +240,17 @@ uint32_t fit_grid(const gr_ctx *c, uint32_t nf) {
     return (uint32_t)(gx < 1 ? 1 : gx);
 }
 
-int install_group(gr_ctx *c, const char *name, std::vector<grc::Block> blocks) {
-    if (!name) return fail(c, GR_E_INVALID_ARG, "group name is NULL");
-    const bool existed = c->groups.count(name) != 0;
-    if (existed && c->groups[name].idx_dev) { (void)hipFree(c->groups[name].idx_dev); }
+// a batch begun with gr_rmsd_batch_begin is still in flight on this context: only uploads may run beside it
+int busy_check(gr_ctx *c) {
+    if (c && c->in_flight) return fail(c, GR_E_INVALID_ARG, "a batch begun with gr_rmsd_batch_begin is in flight on this context: only gr_frame_upload / gr_frame_upload_wait / gr_host_* / gr_*_read_frames_device may run before gr_rmsd_batch_end");
+    return GR_OK;
+}
+
+// expand a block list into the device-side selection (nothing for a contiguous list)
+int group_build(gr_ctx *c, std::vector<grc::Block> blocks, Group *out) {
+    uint64_t bad = 0;
+    // no kernel bounds-checks a selection: a block outside [0, n) never becomes a group (the reference panics on first use)
+    if (!grc::valid_for(blocks, c->n, &bad)) return fail(c, GR_E_OUT_OF_RANGE, "atom index out of range", bad);
     Group g;
     g.blocks = std::move(blocks);
     g.n = grc::n_atoms(g.blocks);
@@ -247,9 +260,24 @@ int install_group(gr_ctx *c, const char *name, std::vector<grc::Block> blocks) {
         std::vector<uint64_t> e = grc::expand(g.blocks);
         std::vector<uint32_t> e32(e.begin(), e.end());
         HIPCHK(c, hipMalloc(&g.idx_dev, e32.size() * sizeof(uint32_t)));
-        HIPCHK(c, hipMemcpy(g.idx_dev, e32.data(), e32.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        if (hipMemcpy(g.idx_dev, e32.data(), e32.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) {
+            (void)hipFree(g.idx_dev);
+            return fail(c, GR_E_HIP, "copy of the selection's index list failed");
+        }
     }
+    *out = g;
+    return GR_OK;
+}
+
+int install_group(gr_ctx *c, const char *name, std::vector<grc::Block> blocks) {
+    if (!name) return fail(c, GR_E_INVALID_ARG, "group name is NULL");
+    int st = busy_check(c); if (st) return st;
+    Group g;
+    st = group_build(c, std::move(blocks), &g); if (st) return st;   // on failure the context is unchanged (no group created, none lost)
+    const bool existed = c->groups.count(name) != 0;
+    if (existed && c->groups[name].idx_dev) { (void)hipStreamSynchronize(c->stream); (void)hipFree(c->groups[name].idx_dev); }
     c->groups[name] = g;
+    c->epoch++;
     return existed ? GR_E_GROUP_EXISTS : GR_OK;
 }
 
@@ -268,10 +296,11 @@ int box_check(gr_ctx *c, uint32_t slot) {
     return GR_OK;
 }
 
-int slot_check(gr_ctx *c, uint32_t slot, uint32_t n = 1) {
+// ingest = the call only feeds slots (uploads on the copy stream): allowed beside a batch in flight; everything else is refused
+int slot_check(gr_ctx *c, uint32_t slot, uint32_t n = 1, bool ingest = false) {
     if (!c) return GR_E_INVALID_ARG;
     if ((uint64_t)slot + n > c->n_slots || n == 0) return fail(c, GR_E_INVALID_ARG, "slot out of range");
-    return GR_OK;
+    return ingest ? GR_OK : busy_check(c);
 }
 
 // Every API call that reads or writes frame slots on the compute stream brackets itself with a SlotUse:
@@ -581,7 +610,9 @@ int gr_sync(gr_ctx *c) try {
 
 int gr_set_masses(gr_ctx *c, const float *masses, uint64_t n) try {
     if (!c || !masses || n != c->n) return c ? fail(c, GR_E_INVALID_ARG, "masses: size mismatch") : GR_E_INVALID_ARG;
+    { int st = busy_check(c); if (st) return st; }
     c->masses_host.assign(masses, masses + n);
+    c->epoch++;
     HIPCHK(c, hipMemcpyAsync(c->masses, masses, n * sizeof(float), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return GR_OK;
@@ -609,6 +640,10 @@ size_t gr_container_expand(const uint64_t *s, const uint64_t *e, size_t n, uint6
     return v.size();
 } catch (...) { return 0; }
 int gr_container_isin(const uint64_t *s, const uint64_t *e, size_t n, uint64_t index) { return grc::isin(grc::make(s, e, n), index) ? 1 : 0; }
+int gr_container_validate(const uint64_t *s, const uint64_t *e, size_t n, uint64_t n_atoms, uint64_t *bad_index) try {
+    if (n && (!s || !e)) return GR_E_INVALID_ARG;
+    return grc::valid_for(grc::make(s, e, n), n_atoms, bad_index) ? GR_OK : GR_E_OUT_OF_RANGE;
+} catch (...) { return gr_abi_guard(); }
 
 /* ------------------------------------------------------------ groups */
 int gr_group_create_from_ranges(gr_ctx *c, const char *name, const uint64_t *s, const uint64_t *e, size_t n) try {
@@ -623,10 +658,12 @@ int gr_group_create_from_indices(gr_ctx *c, const char *name, const uint64_t *in
 } catch (...) { return gr_abi_guard(); }
 int gr_group_remove(gr_ctx *c, const char *name) try {
     if (!c || !name) return GR_E_INVALID_ARG;
+    { int st = busy_check(c); if (st) return st; }
     auto it = c->groups.find(name);
     if (it == c->groups.end()) return fail(c, GR_E_GROUP_NOT_FOUND, name);
-    if (it->second.idx_dev) (void)hipFree(it->second.idx_dev);
+    if (it->second.idx_dev) { (void)hipSetDevice(c->device); (void)hipStreamSynchronize(c->stream); (void)hipFree(it->second.idx_dev); }
     c->groups.erase(it);
+    c->epoch++;
     return GR_OK;
 } catch (...) { return gr_abi_guard(); }
 int gr_group_exists(const gr_ctx *c, const char *name) { return (c && find_group(c, name)) ? 1 : 0; }
@@ -661,14 +698,17 @@ int gr_group_blocks(const gr_ctx *c, const char *name, uint64_t *os, uint64_t *o
 
 /* ------------------------------------------------------------ frames */
 int gr_frame_upload(gr_ctx *c, uint32_t slot, const float *xyz, const float *box9) try {
-    int st = slot_check(c, slot); if (st) return st;
+    int st = slot_check(c, slot, 1, true); if (st) return st;
     if (!xyz) return fail(c, GR_E_INVALID_ARG, "xyz is NULL");
     (void)hipSetDevice(c->device);
-    if (!c->ev_ready[slot]) HIPCHK(c, hipEventCreateWithFlags(&c->ev_ready[slot], hipEventDisableTiming));
+    // boxes_host[slot] is the pinned SOURCE of the slot's previous box copy, which sits on the copy stream behind that
+    // upload's 12 MB frame copy: it may only be rewritten once that copy has run -- whether or not a compute call has
+    // meanwhile consumed the "upload pending" flag (upload -> batch_begin -> upload again into the same slot)
+    if (c->ev_ready[slot]) HIPCHK(c, hipEventSynchronize(c->ev_ready[slot]));
+    else HIPCHK(c, hipEventCreateWithFlags(&c->ev_ready[slot], hipEventDisableTiming));
     // the slot may still be read by kernels issued earlier: order the copy behind the last compute call that used it
     // (events of one stream complete in order, so a recycled ring entry only makes the wait conservative)
     if (c->slot_gen[slot]) HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->ev_done_ring[c->slot_gen[slot] % 64], 0));
-    if (c->upload_pending[slot]) HIPCHK(c, hipEventSynchronize(c->ev_ready[slot]));   // boxes_host[slot] is about to be rewritten
     HIPCHK(c, hipMemcpyAsync(c->frames + (size_t)slot * c->frame_stride, xyz, c->n * 3 * sizeof(float), hipMemcpyHostToDevice, c->copy_stream));
     st = set_box(c, slot, box9, c->copy_stream); if (st) return st;
     HIPCHK(c, hipEventRecord(c->ev_ready[slot], c->copy_stream));
@@ -676,7 +716,7 @@ int gr_frame_upload(gr_ctx *c, uint32_t slot, const float *xyz, const float *box
     return GR_OK;
 } catch (...) { return gr_abi_guard(); }
 int gr_frame_upload_wait(gr_ctx *c, uint32_t slot) try {
-    int st = slot_check(c, slot); if (st) return st;
+    int st = slot_check(c, slot, 1, true); if (st) return st;
     if (c->ev_ready[slot]) HIPCHK(c, hipEventSynchronize(c->ev_ready[slot]));
     return GR_OK;
 } catch (...) { return gr_abi_guard(); }
@@ -710,6 +750,7 @@ int gr_frame_copy(gr_ctx *c, uint32_t dst, uint32_t src) try {
     HIPCHK(c, hipMemcpyAsync(c->frames + (size_t)dst * c->frame_stride, c->frames + (size_t)src * c->frame_stride,
                              c->frame_stride * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, sync_ingest(c));                    // boxes_host[dst] may still feed an earlier upload's box copy
     return set_box(c, dst, c->box9_set[src] ? &c->box9_host[9 * (size_t)src] : nullptr);
 } catch (...) { return gr_abi_guard(); }
 void *gr_host_alloc(size_t bytes) { void *p = nullptr; return hipHostMalloc(&p, bytes, hipHostMallocDefault) == hipSuccess ? p : nullptr; }
@@ -1217,6 +1258,7 @@ int gr_atoms_center_batch(gr_ctx *c, uint32_t first_slot, uint32_t n_frames, con
 void gr_rmsd_plan_destroy(gr_rmsd_plan *p) try {
     if (!p) return;
     if (p->target) (void)hipSetDevice(p->target->device);
+    if (p->target && p->target->in_flight == p) { (void)hipStreamSynchronize(p->target->stream); p->target->in_flight = nullptr; }
     if (p->p_dev) (void)hipFree(p->p_dev);
     if (p->w_dev) (void)hipFree(p->w_dev);
     delete p;
@@ -1227,8 +1269,10 @@ gr_rmsd_plan *gr_rmsd_plan_create(gr_ctx *ref, uint32_t ref_slot, gr_ctx *target
     if (!ref || !target || !group || ref_slot >= ref->n_slots) { *status = GR_E_INVALID_ARG; return nullptr; }
     if (ref->device != target->device) { *status = fail(ref, GR_E_INVALID_ARG, "reference and target live on different devices"); return nullptr; }
     (void)hipSetDevice(ref->device);
+    int st = busy_check(ref);
+    if (st) { *status = st; return nullptr; }
     // extract_data_from_system(reference): box first (rmsd.rs:430), then group_get_com (:433)
-    int st = box_check(ref, ref_slot);
+    st = box_check(ref, ref_slot);
     if (st) { *status = st; return nullptr; }
     const Group *g = find_group(ref, group);
     if (!g) { *status = fail(ref, GR_E_GROUP_NOT_FOUND, group); return nullptr; }
@@ -1312,7 +1356,9 @@ static int segment_begin(gr_rmsd_plan *p, uint32_t s0, uint32_t nb, int fit) {
     }
     if (!q.any_ok) return GR_OK;
     const GrSel sel = make_sel(*g);
-    if (!p->resolved) {   // weights identical to the target's masses of the group -> one load serves both
+    q.sel = sel; q.group_n = g->n; q.has_group = true;
+    if (!p->resolved || p->resolved_epoch != c->epoch) {   // weights identical to the target's masses of the group -> one load serves both
+        p->resolved_epoch = c->epoch;
         bool same = (g->n == p->n_ref);
         if (same) { size_t k = 0; for (uint64_t i : grc::expand(g->blocks)) { const float a = c->masses_host[i], b = p->w_host[k++]; if (!(a == b)) { same = false; break; } } }
         p->dev.w_is_mass = same ? 1u : 0u; p->resolved = true;
@@ -1495,8 +1541,8 @@ static int segment_end(gr_rmsd_plan *p, float *rmsd_out, int *status_out, float 
             if (R_out) for (int k = 0; k < 9; ++k) R_out[9 * (size_t)f + k] = NAN;
         }
     } else {
-        const Group *g = find_group(c, p->group.c_str());
-        const GrSel sel = make_sel(*g);
+        if (!q.has_group) return fail(c, GR_E_INVALID_ARG, "batch state lost");
+        const GrSel sel = q.sel;
         HIPCHK(c, hipStreamSynchronize(c->stream));
         if (q.persist) {
             if (c->ps_trace) {
@@ -1546,7 +1592,7 @@ static int segment_end(gr_rmsd_plan *p, float *rmsd_out, int *status_out, float 
             int s = res[f].status;
             if (q.pre[f] != GR_OK) { s = q.pre[f]; c->err = q.pre_msg[f]; c->err_index = q.pre_idx[f]; }
             else if (s == GR_OK && !q.consistent) {
-                c->counts[0] = p->n_ref; c->counts[1] = g->n;
+                c->counts[0] = p->n_ref; c->counts[1] = q.group_n;
                 s = fail(c, GR_E_INCONSISTENT_GROUP, p->group);
             } else if (s != GR_OK) {
                 s = frame_status(c, res[f]);
@@ -1589,12 +1635,13 @@ int gr_rmsd_batch_begin(gr_rmsd_plan *p, uint32_t first_slot, uint32_t n, int fi
     (void)hipSetDevice(c->device);
     p->last_fallbacks = 0;
     st = segment_begin(p, first_slot, n, fit ? 1 : 0);
-    if (st) p->pend.active = false;
+    if (st) p->pend.active = false; else c->in_flight = p;
     return st;
 } catch (...) { return gr_abi_guard(); }
 int gr_rmsd_batch_end(gr_rmsd_plan *p, float *rmsd_out, int *status_out, float *R_out) try {
     if (!p || !p->target) return GR_E_INVALID_ARG;
     (void)hipSetDevice(p->target->device);
+    if (p->target->in_flight == p) p->target->in_flight = nullptr;
     return segment_end(p, rmsd_out, status_out, R_out);
 } catch (...) { return gr_abi_guard(); }
 
@@ -1674,7 +1721,7 @@ int gr_xtc_read_frame(const gr_xtc *x, uint64_t frame, float *xyz, float box9[9]
 int gr_xtc_read_frames_device(const gr_xtc *x, uint64_t first_frame, uint32_t n_frames, uint64_t frame_step, gr_ctx *c,
                               uint32_t first_slot, int host_threads, uint64_t *steps, float *times) try {
     if (!x || !c) return GR_E_INVALID_ARG;
-    int st = slot_check(c, first_slot, n_frames); if (st) return st;
+    int st = slot_check(c, first_slot, n_frames, true); if (st) return st;
     if (frame_step == 0) frame_step = 1;
     if (first_frame + (uint64_t)(n_frames - 1) * frame_step >= x->f.frames.size()) return fail(c, GR_E_OUT_OF_RANGE, "xtc frame out of range", first_frame);
     if (x->f.natoms != c->n) return fail(c, GR_E_INVALID_ARG, "the trajectory's atom count differs from the context's");
@@ -1775,8 +1822,9 @@ int gr_xtc_read_frames_device(const gr_xtc *x, uint64_t first_frame, uint32_t n_
     unsigned char *D = c->xtc_dev[bank];
     for (uint32_t k = 0; k < n_frames; ++k) {
         const uint32_t slot = first_slot + k;
-        if (!c->ev_ready[slot]) HIPCHK(c, hipEventCreateWithFlags(&c->ev_ready[slot], hipEventDisableTiming));
-        if (c->upload_pending[slot]) HIPCHK(c, hipEventSynchronize(c->ev_ready[slot]));   // boxes_host[slot] is about to be rewritten
+        // boxes_host[slot] is about to be rewritten: the slot's previous box copy must have left it (see gr_frame_upload)
+        if (c->ev_ready[slot]) HIPCHK(c, hipEventSynchronize(c->ev_ready[slot]));
+        else HIPCHK(c, hipEventCreateWithFlags(&c->ev_ready[slot], hipEventDisableTiming));
     }
     for (uint32_t k = 0; k < n_frames; ++k) {
         const uint64_t fr = first_frame + k * frame_step;
@@ -1899,7 +1947,7 @@ __global__ __launch_bounds__(256) void k_trr_unpack(const unsigned char *__restr
 int gr_trr_read_frames_device(const gr_trr *t, uint64_t first_frame, uint32_t n_frames, uint64_t frame_step, gr_ctx *c, uint32_t first_slot,
                               uint64_t *steps, float *times) try {
     if (!t || !c) return GR_E_INVALID_ARG;
-    int st = slot_check(c, first_slot, n_frames); if (st) return st;
+    int st = slot_check(c, first_slot, n_frames, true); if (st) return st;
     if (frame_step == 0) frame_step = 1;
     if (n_frames == 0) return GR_OK;
     if (first_frame + (uint64_t)(n_frames - 1) * frame_step >= t->f.frames.size()) return fail(c, GR_E_OUT_OF_RANGE, "trr frame out of range", first_frame);
@@ -1946,8 +1994,8 @@ int gr_trr_read_frames_device(const gr_trr *t, uint64_t first_frame, uint32_t n_
             sec[k] = soff[k];
         } else sec[k] = ~0ull;
         rsz[k] = fi.real_size; slots[k] = slot;
-        if (!c->ev_ready[slot]) HIPCHK(c, hipEventCreateWithFlags(&c->ev_ready[slot], hipEventDisableTiming));
-        if (c->upload_pending[slot]) HIPCHK(c, hipEventSynchronize(c->ev_ready[slot]));
+        if (c->ev_ready[slot]) HIPCHK(c, hipEventSynchronize(c->ev_ready[slot]));
+        else HIPCHK(c, hipEventCreateWithFlags(&c->ev_ready[slot], hipEventDisableTiming));
         float box9[9];
         st = gr_trr_frame_info(t, fr, steps ? steps + k : nullptr, times ? times + k : nullptr, nullptr, box9, nullptr, nullptr);
         if (st != GR_OK) return fail(c, st, "unsupported box in trr frame", fr);

@@ -107,6 +107,19 @@ inline std::vector<Block> set_intersection(const std::vector<Block> &a, const st
     return from_indices(keep, mx + 1);
 }
 
+// A block list a device kernel may index with: every block ordered and inside [0, n_atoms).  from_indices keeps the
+// reference's quirk of never range-checking the smallest index (container.rs:66; the reference then panics on the first
+// access), so `[n_atoms]` yields the block (n, n) and `[n, n + 1]` the block (n, n - 1): such lists must never reach a kernel.
+inline bool valid_for(const std::vector<Block> &b, uint64_t n_atoms, uint64_t *bad_index) {
+    for (const Block &x : b) {
+        if (x.first > x.second || x.second >= n_atoms) {
+            if (bad_index) *bad_index = x.first >= n_atoms ? x.first : x.second;
+            return false;
+        }
+    }
+    return true;
+}
+
 inline std::vector<Block> make(const uint64_t *s, const uint64_t *e, size_t n) {
     std::vector<Block> b(n);
     for (size_t k = 0; k < n; ++k) b[k] = Block(s[k], e[k]);

@@ -175,6 +175,10 @@ inline int open_file(File &f, const char *path) {
             fi.nbytes = (magic == 2023) ? be64(h + 32) : (uint64_t)be32(h + 32);
             p += hl;
             fi.data_offset = p;
+            // the byte count comes from the file (64 bits wide for magic 2023): it must fit what is left of the file BEFORE it
+            // is rounded up or added to anything -- 2^64 - 1 would round to 0, pass the size test below and later size the
+            // decoder's scratch buffer by wrap-around.  2^29 is the decoder's own limit (bit positions are 32-bit).
+            if (p > f.size || fi.nbytes > f.size - p || fi.nbytes >= (1ull << 29)) { f.error = "frame byte count exceeds the file"; return XTC_E_FORMAT; }
             p += (fi.nbytes + 3) & ~(uint64_t)3;
             if (fi.smallidx < kFirstIdx || fi.smallidx >= kLastIdx) { f.error = "small-range index out of the table"; return XTC_E_FORMAT; }
         }

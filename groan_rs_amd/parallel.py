@@ -60,16 +60,39 @@ def gather_per_frame(local_values, n_total, dist=None, device=None):
     return interleave([o.cpu().numpy() for o in outs], n_total)
 
 
+class AbortedByOtherRank(RuntimeError):
+    """Raised on the ranks that stopped because ANOTHER rank's body failed: the call as a whole failed
+    (the reference returns the failing worker's Err for the whole traj_iter_map_reduce, parallel.rs:288-321),
+    so no rank may hand its partial Data on as a success."""
+
+
+def _flag_any(dist, world, device, raised):
+    """all_reduce(MAX) of the shared error flag (the AtomicBool of parallel.rs:28,230).  The tensor lives where the
+    backend can reduce it: on `device` for nccl / RCCL (CPU tensors have no nccl backend), on the CPU for gloo."""
+    if dist is None or not dist.is_initialized() or world <= 1:
+        return raised
+    import torch
+    dev = device
+    if dev is None and dist.get_backend() == "nccl":
+        dev = torch.device("cuda", torch.cuda.current_device())
+    flag = torch.tensor([1 if raised else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+    return bool(int(flag.item()))
+
+
 def traj_iter_map_reduce(make_system, frames_of, n_frames, body, init_data, rank=0, world=1, dist=None,
-                         start=0, step=1, error_flag_freq=10):
+                         start=0, step=1, error_flag_freq=10, device=None):
     """System::traj_iter_map_reduce for one worker.
 
     make_system(rank) -> System clone living on this worker's GPU (parallel.rs:236)
     frames_of(indices) -> iterable of frames (positions, box[, step, time]) for those frame indices
     body(system, data) -> None or raises; data = copy of init_data, initialised with the worker id
+    device: torch device of the flag tensor (required form for backend nccl: the rank's GPU; None = CPU / current GPU)
     Returns the rank-local Data; callers reduce with ParallelTrajData.reduce after gathering.
     An error on any worker stops the others at their next check, every ERROR_FLAG_FREQ frames
-    (parallel.rs:28,453-475): with torch.distributed the flag is a 1-int all_reduce(MAX).
+    (parallel.rs:28,453-475): with torch.distributed the flag is a 1-int all_reduce(MAX); one more reduction after
+    the last frame shares an error raised after the last periodic check.  The failing rank re-raises its error, every
+    other rank raises AbortedByOtherRank: like the reference's Err for the whole call, nobody returns partial data.
     """
     import copy
     data = copy.deepcopy(init_data)
@@ -81,14 +104,11 @@ def traj_iter_map_reduce(make_system, frames_of, n_frames, body, init_data, rank
     n_rounds = (len(shard_frames(n_frames, 0, world, start, step)) + error_flag_freq - 1) // error_flag_freq
     it = iter(frames_of(mine))
     done = False
+    aborted = False
+    n_done = 0
     for _round in range(n_rounds):
-        if dist is not None and dist.is_initialized() and world > 1:
-            import torch
-            flag = torch.tensor([1 if err is not None else 0], dtype=torch.int32)
-            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-            if int(flag.item()):
-                break
-        elif err is not None:
+        if _flag_any(dist, world, device, err is not None):
+            aborted = True
             break
         for _ in range(error_flag_freq):
             if done or err is not None:
@@ -101,8 +121,13 @@ def traj_iter_map_reduce(make_system, frames_of, n_frames, body, init_data, rank
             try:
                 system.set_frame(fr[0], fr[1], slot=0, step=fr[2] if len(fr) > 2 else None, time=fr[3] if len(fr) > 3 else None)
                 body(system, data)
+                n_done += 1
             except Exception as e:   # first error wins (parallel.rs:468-471)
                 err = e
+    if not aborted:                  # the final check: an error of the last round is shared, too
+        aborted = _flag_any(dist, world, device, err is not None)
     if err is not None:
         raise err
+    if aborted:
+        raise AbortedByOtherRank("another rank's frame body failed; this rank stopped after %d of its %d frames" % (n_done, len(mine)))
     return data

@@ -105,10 +105,16 @@ size_t gr_container_intersection(const uint64_t *s1, const uint64_t *e1, size_t 
 uint64_t gr_container_n_atoms(const uint64_t *s, const uint64_t *e, size_t n);     /* container.rs:161-165 */
 size_t gr_container_expand(const uint64_t *s, const uint64_t *e, size_t n, uint64_t *out); /* :381-411 */
 int gr_container_isin(const uint64_t *s, const uint64_t *e, size_t n, uint64_t index);     /* :241-258 */
+/* May this block list index a system of n_atoms atoms?  GR_OK, or GR_E_OUT_OF_RANGE with *bad_index = the offending index.
+ * AtomContainer::from_indices never range-checks its smallest index (container.rs:66): from_indices([n], n) is the block
+ * (n, n) and the reference panics on the first access through it.  Every entry point that takes a selection (groups,
+ * gr_sel_*) applies this check and creates / computes nothing when it fails -- no kernel bounds-checks a selection. */
+int gr_container_validate(const uint64_t *s, const uint64_t *e, size_t n, uint64_t n_atoms, uint64_t *bad_index);
 
 /* ---------------------------------------------------------------- groups (src/system/groups.rs)
  * System::group_create_from_ranges / _from_indices.  "all" exists from creation (System::new).
- * Creating an existing name overwrites it and returns GR_E_GROUP_EXISTS (the reference's warning). */
+ * Creating an existing name overwrites it and returns GR_E_GROUP_EXISTS (the reference's warning).
+ * A block outside [0, n_atoms) (see gr_container_validate) is GR_E_OUT_OF_RANGE + gr_last_error_index; no group is created. */
 int gr_group_create_from_ranges(gr_ctx *ctx, const char *name, const uint64_t *start,
                                 const uint64_t *end_inclusive, size_t n_ranges);
 int gr_group_create_from_indices(gr_ctx *ctx, const char *name, const uint64_t *indices, size_t n);

@@ -116,6 +116,29 @@ int main(int argc, char **argv) {
             run_xtc(tmp + ".xtc", tx);
         }
     }
+    // ---- crafted magic-2023 frames: that variant carries a 64-bit byte count, taken from the file.  The first frame of every
+    // pristine file is rewritten as magic 2023 with byte counts that wrap when rounded up to 4, when added to the file
+    // offset, or when they size a buffer (2^64 - 1 ... ) -- all must be refused at open; the honest count must still decode.
+    long crafted_ok = 0, crafted_rej = 0;
+    for (const std::string &p : xtcs) {
+        const std::vector<unsigned char> orig = slurp(p.c_str());
+        if (orig.size() < 96 || grx::be32(orig.data() + 4) <= 9) continue;
+        const uint32_t honest = grx::be32(orig.data() + 88);
+        const uint64_t evil[] = { (uint64_t)honest, ~0ull, ~0ull - 1, ~0ull - 2, ~0ull - 3, ~0ull - 127, 1ull << 63, (1ull << 63) - 1, 1ull << 32, (1ull << 32) | honest,
+                                  (uint64_t)orig.size(), (uint64_t)orig.size() + 4, ~0ull - (uint64_t)orig.size(), 0ull - 96ull, 0ull - 92ull, (1ull << 29), (1ull << 29) - 1 };
+        for (uint64_t nb : evil) {
+            std::vector<unsigned char> m = orig;
+            m[0] = 0; m[1] = 0; m[2] = 0x07; m[3] = 0xE7;                       // magic 2023
+            unsigned char b[8]; for (int k = 0; k < 8; ++k) b[k] = (unsigned char)(nb >> (56 - 8 * k));
+            m.insert(m.begin() + 88, 4, (unsigned char)0);
+            memcpy(&m[88], b, 8);
+            spit(tmp + ".xtc", m);
+            Tally t; run_xtc(tmp + ".xtc", t);
+            if (nb == honest) { if (t.ok != 1) { fprintf(stderr, "honest magic-2023 frame rejected (%s)\n", p.c_str()); return 1; } crafted_ok++; }
+            else { if (t.ok != 0) { fprintf(stderr, "a frame with byte count %llu was accepted (%s)\n", (unsigned long long)nb, p.c_str()); return 1; } crafted_rej++; }
+        }
+    }
+    printf("crafted 2023 frames: %ld decoded, %ld refused\n", crafted_ok, crafted_rej);
     // ---- trr: pristine files read; mutants (same mutators) never crash
     Tally tr;
     for (const std::string &p : trrs) {

@@ -29,7 +29,11 @@ def test_mutated_inputs_never_crash(fuzz_bin, seed, tmp_path):
     assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
     assert "xtc mutants:" in r.stdout
     # the mutators must exercise both outcomes, or the run proves nothing
-    words = r.stdout.replace(";", " ").replace(",", " ").split()
+    lines = r.stdout.splitlines()
+    crafted = [ln for ln in lines if ln.startswith("crafted 2023 frames:")]
+    # magic-2023 byte counts that wrap (2^64 - 1 ...) are refused at open; the honest count still decodes
+    assert crafted and int(crafted[0].split()[3]) >= 3 and int(crafted[0].split()[5]) >= 40, r.stdout
+    words = [ln for ln in lines if ln.startswith("xtc mutants:")][0].replace(";", " ").replace(",", " ").split()
     decoded, rejected = int(words[2]), int(words[4])
     assert decoded > 50 and rejected > 50, r.stdout
     assert "trr mutants:" in r.stdout and int(words[words.index("trr") + 2]) > 20 and int(words[words.index("trr") + 4]) > 50, r.stdout

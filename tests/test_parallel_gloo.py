@@ -8,7 +8,7 @@ import socket
 import numpy as np
 import pytest
 
-from groan_rs_amd.parallel import ParallelTrajData, gather_per_frame, interleave, shard_frames, traj_iter_map_reduce
+from groan_rs_amd.parallel import AbortedByOtherRank, ParallelTrajData, gather_per_frame, interleave, shard_frames, traj_iter_map_reduce
 
 
 def test_shard_frames_covers_exactly_like_the_reference():
@@ -75,6 +75,8 @@ def _worker(rank, world, port, n_frames, fail_at, q):
         err = None
         try:
             data = traj_iter_map_reduce(lambda r: _FakeSystem(), frames_of, n_frames, body, _Data(), rank, world, dist)
+        except AbortedByOtherRank as e:
+            err, data = "aborted: " + str(e), None
         except RuntimeError as e:
             err, data = str(e), None
         # final gather of a per-frame scalar (what the RMSD bench gathers over RCCL)
@@ -90,7 +92,7 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("fail_at", [None, 35])
+@pytest.mark.parametrize("fail_at", [None, 35, 100])
 def test_world_size_2_gloo(fail_at):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
@@ -112,7 +114,11 @@ def test_world_size_2_gloo(fail_at):
         assert merged.seen == list(range(n_frames))           # multiset of visited frames == serial
         assert [d[0] for _, d, _, _ in res] == [0, 1]         # initialize(thread_id)
     else:
+        # the call fails on EVERY rank (the reference returns Err for the whole map-reduce, parallel.rs:288-321): the rank whose
+        # body failed re-raises its error, the other one raises AbortedByOtherRank -- nobody returns partial data as success.
+        # fail_at = 100 is the LAST frame (rank 0's last round): only the final flag reduction after the loop can share it.
         errs = [err for _, _, err, _ in res]
-        assert sum(e is not None for e in errs) == 1 and "frame 35" in [e for e in errs if e][0]
-        other = [d for _, d, err, _ in res if err is None][0]
-        assert len(other[1]) < len(shard_frames(n_frames, 0, world))   # the healthy worker stopped early at a flag check
+        assert all(e is not None for e in errs), errs
+        assert sum(("frame %d" % fail_at) in e for e in errs) == 1
+        assert sum(e.startswith("aborted: ") for e in errs) == 1
+        assert all(d is None for _, d, _, _ in res)
