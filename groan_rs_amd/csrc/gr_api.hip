@@ -127,6 +127,7 @@ struct gr_ctx {
     std::string ps_trace_path;
     int strict = 0;
     gr_rmsd_plan *in_flight = nullptr;   // the plan whose gr_rmsd_batch_begin has not been ended yet (shared workspace: one at a time)
+    uint32_t in_flight_s0 = 0, in_flight_n = 0;   // its slots
     uint64_t epoch = 1;                  // bumped whenever masses or groups change: plans re-resolve what they cached
     std::string err;
     uint64_t err_index = 0;
@@ -296,11 +297,16 @@ int box_check(gr_ctx *c, uint32_t slot) {
     return GR_OK;
 }
 
-// ingest = the call only feeds slots (uploads on the copy stream): allowed beside a batch in flight; everything else is refused
+// ingest = the call only feeds slots (uploads on the copy stream): allowed beside a batch in flight -- into OTHER slots (the
+// batch's own frames may still be needed by gr_rmsd_batch_end, which redoes frames whose image proof failed); everything
+// else is refused while a batch is in flight
 int slot_check(gr_ctx *c, uint32_t slot, uint32_t n = 1, bool ingest = false) {
     if (!c) return GR_E_INVALID_ARG;
     if ((uint64_t)slot + n > c->n_slots || n == 0) return fail(c, GR_E_INVALID_ARG, "slot out of range");
-    return ingest ? GR_OK : busy_check(c);
+    if (!ingest) return busy_check(c);
+    if (c->in_flight && slot < c->in_flight_s0 + c->in_flight_n && c->in_flight_s0 < slot + n)
+        return fail(c, GR_E_INVALID_ARG, "upload into a slot of the batch in flight: call gr_rmsd_batch_end first (or use the other half of the double buffer)");
+    return GR_OK;
 }
 
 // Every API call that reads or writes frame slots on the compute stream brackets itself with a SlotUse:
@@ -1635,7 +1641,7 @@ int gr_rmsd_batch_begin(gr_rmsd_plan *p, uint32_t first_slot, uint32_t n, int fi
     (void)hipSetDevice(c->device);
     p->last_fallbacks = 0;
     st = segment_begin(p, first_slot, n, fit ? 1 : 0);
-    if (st) p->pend.active = false; else c->in_flight = p;
+    if (st) p->pend.active = false; else { c->in_flight = p; c->in_flight_s0 = first_slot; c->in_flight_n = n; }
     return st;
 } catch (...) { return gr_abi_guard(); }
 int gr_rmsd_batch_end(gr_rmsd_plan *p, float *rmsd_out, int *status_out, float *R_out) try {

@@ -214,6 +214,7 @@ class System:
         if st in (E_NO_BOX, E_NOT_ORTHOGONAL, E_ZERO_BOX): raise GroupError("InvalidSimBox", _simbox(st), st)
         if st == E_NO_POSITION: raise GroupError("InvalidPosition", idx, st)
         if st == E_NO_MASS: raise GroupError("InvalidMass", idx, st)
+        if st == E_OUT_OF_RANGE: raise AtomError("OutOfRange", idx, st)   # a selection outside the system (the reference panics on first use)
         raise DeviceError(self._lib.gr_status_string(st).decode(), msg, st)
 
     def _raise_atom(self, status):

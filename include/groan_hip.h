@@ -213,8 +213,11 @@ int gr_rmsd_fit_batch(gr_rmsd_plan *plan, uint32_t first_slot, uint32_t n_frames
                       float *rmsd_out, int *status_out);
 /* The same in two halves, for pipelines that keep the GPU busy while the host decodes / uploads the next frames:
  * begin issues every launch for `n_frames` (<= 1024) consecutive slots and returns without waiting; end waits and
- * delivers the results.  One batch in flight per plan; between the two calls the context may be used for
- * gr_frame_upload / gr_frame_upload_wait / gr_host_* only (uploads run on the copy stream beside the kernels). */
+ * delivers the results.  One batch in flight per CONTEXT; between the two calls the context accepts gr_frame_upload /
+ * gr_frame_upload_wait / gr_xtc_read_frames_device / gr_trr_read_frames_device into slots OUTSIDE the batch and gr_host_*
+ * only (uploads run on the copy stream beside the kernels) -- every other call, and an upload into one of the batch's own
+ * slots (gr_rmsd_batch_end may still need those frames: it redoes the ones whose image proof failed), returns
+ * GR_E_INVALID_ARG and changes nothing. */
 int gr_rmsd_batch_begin(gr_rmsd_plan *plan, uint32_t first_slot, uint32_t n_frames, int fit);
 int gr_rmsd_batch_end(gr_rmsd_plan *plan, float *rmsd_out, int *status_out, float *R_out);
 /* number of frames of the last batch that left the single-pass path for the multi-pass exact path */

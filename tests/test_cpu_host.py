@@ -107,3 +107,25 @@ def test_dimension_mirror(G):
     assert [d.is_x() for d in D] == [False, True, False, False, True, True, False, True]
     assert [d.is_y() for d in D] == [False, False, True, False, True, False, True, True]
     assert [d.is_z() for d in D] == [False, False, False, True, False, True, True, True]
+
+
+def test_container_validate_refuses_what_from_indices_lets_through(G):
+    """AtomContainer::from_indices never range-checks its smallest index (container.rs:66): [n] -> block (n, n),
+    [n, n + 1] -> block (n, n - 1).  The reference panics on the first access through such a container; here no kernel
+    bounds-checks a selection, so gr_container_validate (applied by every entry point that takes a selection) must refuse them."""
+    lib = G._lib.load()
+    n = 100
+
+    def validate(indices):
+        c = G.AtomContainer.from_indices(indices, n)
+        s = np.array([b[0] for b in c.blocks], np.uint64); e = np.array([b[1] for b in c.blocks], np.uint64)
+        bad = C.c_uint64(0)
+        st = lib.gr_container_validate(s.ctypes.data_as(C.c_void_p), e.ctypes.data_as(C.c_void_p), len(c.blocks), n, C.byref(bad))
+        return c.blocks, st, bad.value
+
+    assert validate([105]) == ([(105, 105)], G._lib.E_OUT_OF_RANGE, 105)            # the quirk itself is kept bit-exact ...
+    assert validate([100, 101]) == ([(100, 99)], G._lib.E_OUT_OF_RANGE, 100)        # ... and caught before any kernel sees it
+    assert validate([100])[1:] == (G._lib.E_OUT_OF_RANGE, 100)                       # a 1-based last-atom index
+    assert validate([256 + 3])[1:] == (G._lib.E_OUT_OF_RANGE, 259)                   # beyond the padded slot as well
+    assert validate([5, 6, 7, 250])[1] == G._lib.OK                                  # out-of-range tail: clamped by the reference's scan
+    assert validate([0, 99])[1] == G._lib.OK and validate([])[1] == G._lib.OK
