@@ -6,7 +6,9 @@ Workload (BASELINE.json metric): 1e6 atoms in a rhombic-do
 the box centre; frame f = R_f (x0 - c) + c + t_f + noise(0.05 nm), wrapped into the cell (so the blob is
 broken across the periodic boundaries); masses {1.008,12.011,14.007,15.999}[i mod 4]; group = all atoms.
 One "step" = gr_rmsd_fit_batch over `--frames-per-step` frames (RMSD + in-place fit of every atom).
-Every frame of warmup + timed steps is a distinct HBM-resident buffer (no reuse inside a run while it fits).
+Every frame of warmup + timed steps is a DISTINCT, freshly generated PBC-broken frame in its own HBM-resident buffer:
+frames-per-step is sized so that (steps + warmup) x frames-per-step fits the pool (768 frames per step = 230 GB for the
+driver's --steps 20 --warmup 5), and `config.reused_frames` (0 unless the caller forces more work than 288 GB hold) says so.
 
   python bench.py                      # 1 GPU
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N   # one rank per GPU
@@ -18,12 +20,17 @@ processes `--frames-per-step` frames per step.
 
 Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel, measured with HIP events on the
 library's own stream during the timed region (gr_profile_*); `cpu_baseline` times the CPU oracle's restatement
-of the reference path (oracle/, kind "port") on a bounded sample of the same frames, rank 0 at N=1 only.
+of the reference path (oracle/, kind "port") on a bounded sample of the same frames, rank 0 at N=1 only -- in a fresh
+CHILD process that never touches the GPU (`bench.py --cpu-baseline-child`), so nothing on the CPU side can take the GPU
+number down with it; nproc, CPU model and both thread counts (all visible cores, and 16 = one GPU's share of the node) are
+reported as BASELINE.md section 3 promises.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -40,14 +47,19 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--atoms", type=int, default=1_000_000)
-    ap.add_argument("--frames-per-step", type=int, default=1024)
-    ap.add_argument("--max-pool-gb", type=float, default=160.0)
-    ap.add_argument("--cpu-frames-per-thread", type=int, default=2)
-    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = min(host cores visible, 16): "
-                    "16 is one GPU's share of the host cores on the GPU box)")
+    ap.add_argument("--frames-per-step", type=int, default=0, help="0 = the largest multiple of 256 (<= 1024) for which every frame "
+                    "of warmup + timed steps is a distinct buffer inside --max-pool-gb")
+    ap.add_argument("--max-pool-gb", type=float, default=240.0, help="HBM for the frame pool (288 GB per MI355X)")
+    ap.add_argument("--cpu-frames-per-thread", type=int, default=4)
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline's main figure (0 = all host cores visible "
+                    "to this process); a second figure at 16 threads (one GPU's share of the node) is always reported")
+    ap.add_argument("--cpu-max-frames", type=int, default=256, help="upper bound on the CPU sample (frames)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-child", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--with-torch", action="store_true", help="import torch first even at N=1 (coexistence check)")
     args = ap.parse_args()
+    if args.cpu_baseline_child:
+        return cpu_baseline_child(args.cpu_baseline_child)
 
     # stdout carries exactly ONE JSON line: everything else any library prints there (RCCL prints a version banner on
     # init) is sent to stderr by pointing fd 1 at fd 2 until the result is written to the saved descriptor
@@ -82,27 +94,26 @@ def main():
     import numpy as np
     import groan_rs_amd as G
 
+    from groan_rs_amd import workload as WL
+
     G._lib.load()
     n = args.atoms
-    B = args.frames_per_step
     K, W = args.steps, args.warmup
-    frame_bytes = ((n + 3) // 4 * 4) * 12
+    frame_bytes = ((n + 255) // 256 * 256) * 12
+    max_frames = int(args.max_pool_gb * 1e9 // frame_bytes)
+    B = args.frames_per_step
+    if B <= 0:
+        # every frame of the run distinct: B <= max_frames / (K + W), in whole 256-frame launch groups where possible
+        B = min(1024, max(1, max_frames // max(K + W, 1)))
+        B = B // 256 * 256 if B >= 256 else (B // 64 * 64 if B >= 64 else B)
+        B = max(B, 1)
     want = (K + W) * B
-    pool = max(B, min(want, int(args.max_pool_gb * 1e9 // frame_bytes) // B * B))
-    d = 24.18
-    box = np.zeros(9, np.float32)
+    pool = max(B, min(want, max_frames // B * B))
+    reused = max(0, want - pool)      # frames of the run that are a second visit to a buffer (already fitted): 0 by construction
     # rhombic dodecahedron, SimBox::from_lengths_angles([d,d,d],[60,60,90]) (simbox.rs:96-123, :300-314)
-    import math
-    a, b_, g_ = [np.float32(x) * np.float32(math.pi) / np.float32(180.0) for x in (60.0, 60.0, 90.0)]
-    f32 = np.float32
-    box[0] = d
-    box[5] = f32(d) * f32(math.cos(g_)); box[1] = f32(d) * f32(math.sin(g_))
-    box[7] = f32(d) * f32(math.cos(b_))
-    box[8] = f32(d) * (f32(math.cos(a)) - f32(math.cos(b_)) * f32(math.cos(g_))) / f32(math.sin(g_))
-    box[2] = f32(math.sqrt(f32(d) * f32(d) - box[7] * box[7] - box[8] * box[8]))
-    height = float(min(box[0], box[1], box[2]))
-    radius = 0.2 * height
-    masses = np.array([1.008, 12.011, 14.007, 15.999], np.float32)[np.arange(n) % 4]
+    box = WL.c4_box(24.18)
+    radius = WL.blob_radius(box)
+    masses = WL.masses_cycle(n)
 
     dev = local_rank
     cur = G.System(n, masses=masses, n_slots=pool + 1, device=dev)      # slot `pool` holds the reference blob
@@ -124,6 +135,7 @@ def main():
             torch.cuda.synchronize()
 
     rmsd_all = np.zeros((K, B), np.float32)
+    step_ms = []
     step_slot = lambda s: ((s * B) % pool)
     # ---- warmup (untimed); profiling already on so the first use of the profiling events is not timed
     cur.profile_enable(True)
@@ -135,10 +147,12 @@ def main():
     cur.profile_enable(True)
     cur.timer_start()
     t0 = time.perf_counter()
+    t_prev = t0
     for s in range(K):
-        r, st = plan.rmsd_fit(step_slot(W + s), B)
+        r, st = plan.rmsd_fit(step_slot(W + s), B)       # synchronous: returns with the step's results on the host
         rmsd_all[s] = r
         fallbacks += plan.last_fallbacks()
+        t_now = time.perf_counter(); step_ms.append(round(1e3 * (t_now - t_prev), 4)); t_prev = t_now
     gathered = None
     if dist is not None:
         # final gather of the per-frame RMSDs (K*B floats per rank) over RCCL, restored to global frame order
@@ -149,11 +163,18 @@ def main():
     prof = cur.profile_read()
     cur.profile_enable(False)
     elapsed = t1 - t0
+    per_rank_fps = [K * B / elapsed]
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=tdev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        mine = torch.tensor([elapsed], dtype=torch.float64, device=tdev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)                     # per-rank times: a straggler shows in per_rank_frames_per_s
+        per_rank_fps = [K * B / float(t.item()) for t in every]
+        elapsed = max(float(t.item()) for t in every)    # MAX over ranks
     assert np.isfinite(rmsd_all).all()
+    if gathered is not None:
+        # every rank's frames arrived, in global frame order: frame g sits at g, and this rank's own are where they belong
+        assert gathered.shape[0] == world * K * B, (gathered.shape, world, K, B)
+        assert np.array_equal(gathered[rank::world], rmsd_all.reshape(-1)) and np.isfinite(gathered).all()
     total_frames = K * B * world
     value = total_frames / elapsed
 
@@ -194,52 +215,54 @@ def main():
         "config": {"workload": "synthetic %d-atom rhombic-dodecahedral (triclinic) frames resident in HBM, Kabsch RMSD-fit of all atoms "
                                "(BASELINE configs[3] shard per GPU)" % n,
                    "n_atoms": n, "frames_per_step": B, "frames_per_gpu": K * B, "selection": "all atoms", "box9": [float(x) for x in box],
-                   "pool_frames": pool, "parallelism": "frames round-robin over %d GPU(s), final RCCL gather" % world,
-                   "fallback_frames": fallbacks, "synth_seconds": round(t_gen, 2)},
+                   "pool_frames": pool, "reused_frames": reused, "parallelism": "frames round-robin over %d GPU(s), final RCCL gather" % world,
+                   "fallback_frames": fallbacks, "synth_seconds": round(t_gen, 2), "step_ms": step_ms,
+                   "per_rank_frames_per_s": [round(v, 1) for v in per_rank_fps]},
         "roofline": roofline,
         "kernels": kernels,
         "path": {"algorithmic_GBs": round(path_gbs, 1), "frac_of_peak": round(path_gbs / HBM_PEAK_GBS, 4), "gpu_ms_timed_region": round(gpu_ms, 3),
                  "bytes_per_frame": 40.0 * n},
     }
 
-    # ---- CPU baseline: the oracle's restatement of the reference path on a bounded sample (rank 0, N=1 only)
+    # ---- CPU baseline: the oracle's restatement of the reference path on a bounded sample of the SAME frames (rank 0, N=1 only),
+    # timed in a child process that never touches the GPU; a failure there is reported, never fatal for the GPU number
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        tmpdir = None
         try:
-            import oracle_lib as O
-            cores = args.cpu_threads or min(len(os.sched_getaffinity(0)), 16)
-            nf = max(cores * args.cpu_frames_per_thread, 2)
-            nf = min(nf, pool)
-            # fresh frames: regenerate the first nf frames (the timed region fitted them in place)
+            visible = len(os.sched_getaffinity(0))
+            t_main = args.cpu_threads or visible
+            nf = min(max(t_main, 16) * args.cpu_frames_per_thread, args.cpu_max_frames, pool)
+            # fresh frames: regenerate the first nf frames (the timed region fitted them in place), copy them out, then run
+            # the GPU on them for the parity figures
             cur.synth_frames(pool, 0, nf, rank, 0.05, SEED, frame_index_stride=world)
-            sample = np.stack([cur.get_positions(f) for f in range(nf)])
-            ref_pos = ref.get_positions(0)
+            tmpdir = tempfile.mkdtemp(prefix="groan_cpu_baseline_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+            sample = np.lib.format.open_memmap(os.path.join(tmpdir, "frames.npy"), mode="w+", dtype=np.float32, shape=(nf, n, 3))
+            for f in range(nf):
+                sample[f] = cur.get_positions(f)
+            sample.flush(); del sample
+            np.save(os.path.join(tmpdir, "ref.npy"), ref.get_positions(0))
+            np.save(os.path.join(tmpdir, "masses.npy"), masses)
+            np.save(os.path.join(tmpdir, "box.npy"), box)
             gpu_r, gpu_st = plan.rmsd_fit(0, nf)
-            gpu_fit0 = cur.get_positions(0)
-            soa = sample.copy()
-            sec_f, r_f = O.baseline_rmsd_fit(sample, ref_pos, masses, box, cores, 0)
-            sec_s, r_s = O.baseline_rmsd_fit(soa, ref_pos, masses, box, cores, 1)
-            sec_1, _ = O.baseline_rmsd_fit(soa[:1].copy(), ref_pos, masses, box, 1, 0)   # one thread, one (already fitted) frame
-            # parity at full size: the reference's sequential f32 sums lose ~1e-2 nm over 1e6 terms, so the GPU (fp64
-            # sums) is compared with the same CPU restatement summing in double; the f32 figure is reported beside it
-            cur.synth_frames(pool, 0, 2, rank, 0.05, SEED, frame_index_stride=world)
-            chk = np.stack([cur.get_positions(f) for f in range(2)])
-            O.set_accumulate_f64(True)
-            _, r_64 = O.baseline_rmsd_fit(chk, ref_pos, masses, box, 2, 1)
-            O.set_accumulate_f64(False)
-            out["cpu_baseline"] = {
-                "value": round(nf / sec_f, 2), "unit": "frames/s", "cores": cores, "kind": "port",
-                "sample": "%d of the benchmark's own frames (%d per thread), reference-faithful 232-byte AoS layout, f32, frames round-robin over %d threads" % (nf, args.cpu_frames_per_thread, cores),
-                "soa_value": round(nf / sec_s, 2), "single_thread_value": round(1.0 / sec_1, 3),
-                "gpu_vs_cpu": round(value / (nf / sec_f), 1),
-                "parity_max_abs_rmsd_diff_vs_cpu_f64sums": float(np.abs(gpu_r[:2] - r_64).max()),
-                "parity_max_abs_fit_diff_vs_cpu_f64sums_frame0": float(np.abs(gpu_fit0 - chk[0]).max()),
-                "reference_f32_sum_error_rmsd": float(np.abs(r_f[:2] - r_64).max()),
-            }
-        except Exception as e:   # the baseline is reported, never required for the GPU number
+            np.save(os.path.join(tmpdir, "gpu_rmsd.npy"), gpu_r)
+            np.save(os.path.join(tmpdir, "gpu_fit0.npy"), cur.get_positions(0))
+            with open(os.path.join(tmpdir, "job.json"), "w") as fh:
+                json.dump({"threads_main": t_main, "frames_per_thread": args.cpu_frames_per_thread, "gpu_value": value}, fh)
+            child = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", tmpdir],
+                                   stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+            line = [ln for ln in child.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]
+            if child.returncode != 0 or not line:
+                raise RuntimeError("child rc=%d: %s" % (child.returncode, child.stderr.decode(errors="replace")[-400:]))
+            out["cpu_baseline"] = json.loads(line[-1])
+        except Exception as e:
             out["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
+        finally:
+            if tmpdir:
+                import shutil
+                shutil.rmtree(tmpdir, ignore_errors=True)
     if rank == 0:
         if gathered is not None:
-            out["config"]["gathered_frames"] = int(gathered.shape[0])
+            out["config"]["gathered_frames"] = int(gathered.shape[0])      # == n_gpus * steps * frames_per_step (asserted above)
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     plan.close(); ref.close(); cur.close()
@@ -247,5 +270,69 @@ def main():
         dist.destroy_process_group()
 
 
+def cpu_baseline_child(tmpdir):
+    """The CPU leg (kind "port": oracle/groan_oracle.c, the restatement of the reference path pinned by its known answers).
+    Runs in its own process, loads no GPU library.  Sample frames come from the parent through files in `tmpdir`."""
+    import numpy as np
+    import oracle_lib as O
+    job = json.load(open(os.path.join(tmpdir, "job.json")))
+    # BASELINE.md section 3 asks for -O3 -march=native: built HERE, on the host that runs it (the shipped liboracle.so is a
+    # portable build, so that a test process can never die of an illegal instruction on a different CPU)
+    build = "portable -O3 (oracle/liboracle.so)"
+    try:
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "native"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=120)
+        O.use_library(os.path.join(ROOT, "oracle", "liboracle_native.so"))
+        build = "-O3 -march=native, built on this host (oracle/liboracle_native.so)"
+    except Exception:
+        pass
+    frames = np.load(os.path.join(tmpdir, "frames.npy"), mmap_mode="r")
+    ref_pos, masses, box = (np.load(os.path.join(tmpdir, k + ".npy")) for k in ("ref", "masses", "box"))
+    gpu_r, gpu_fit0 = np.load(os.path.join(tmpdir, "gpu_rmsd.npy")), np.load(os.path.join(tmpdir, "gpu_fit0.npy"))
+    nf_all, fpt = frames.shape[0], int(job["frames_per_thread"])
+    visible = len(os.sched_getaffinity(0))
+    model = ""
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                model = ln.split(":", 1)[1].strip(); break
+    except OSError:
+        pass
+    cargo = subprocess.run("cargo --version", shell=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout.decode().strip()
+
+    def run(threads, layout):
+        nf = min(nf_all, max(threads * fpt, 1))
+        buf = np.array(frames[:nf])                     # private copy: fitted in place
+        sec, r = O.baseline_rmsd_fit(buf, ref_pos, masses, box, threads, layout)
+        return nf / sec, nf, r, buf
+
+    t_main = int(job["threads_main"])
+    fps_main, nf_main, r_f, _ = run(t_main, 0)          # reference-faithful 232-byte AoS records, frames round-robin over threads
+    fps_soa, _, _, _ = run(t_main, 1)
+    fps_16, nf_16, _, _ = run(16, 0) if t_main != 16 else (fps_main, nf_main, None, None)
+    fps_1, _, _, _ = run(1, 0) if fpt <= 4 else (None, 0, None, None)
+    # parity at full size: the reference's sequential f32 sums lose ~1e-2 nm over 1e6 terms, so the GPU (fp64 sums) is compared
+    # with the same CPU restatement summing in double; the literal f32 figure is reported beside it
+    O.set_accumulate_f64(True)
+    chk = np.array(frames[:2])
+    _, r_64 = O.baseline_rmsd_fit(chk, ref_pos, masses, box, 2, 1)
+    O.set_accumulate_f64(False)
+    out = {
+        "value": round(fps_main, 2), "unit": "frames/s", "cores": t_main, "kind": "port",
+        "sample": "%d of the benchmark's own frames (%d per thread), reference-faithful 232-byte AoS layout, f32, frames round-robin over %d threads "
+                  "(src/system/parallel.rs:424-448), decode excluded" % (nf_main, fpt, t_main),
+        "nproc": os.cpu_count(), "cores_visible": visible, "cpu_model": model, "build": build,
+        "value_16_threads": round(fps_16, 2), "sample_16_threads": "%d frames" % nf_16,
+        "soa_value": round(fps_soa, 2), "single_thread_value": None if fps_1 is None else round(fps_1, 3),
+        "gpu_vs_cpu": round(float(job["gpu_value"]) / fps_main, 1),
+        "rust_toolchain_on_this_host": cargo or "absent (cargo --version fails): the reference itself cannot be built here",
+        "process": "child process without any GPU library",
+        "parity_max_abs_rmsd_diff_vs_cpu_f64sums": float(np.abs(gpu_r[:2] - r_64).max()),
+        "parity_max_abs_fit_diff_vs_cpu_f64sums_frame0": float(np.abs(gpu_fit0 - chk[0]).max()),
+        "reference_f32_sum_error_rmsd": float(np.abs(r_f[:2] - r_64).max()),
+    }
+    sys.stdout.write(json.dumps(out) + "\n")
+    return 0
+
+
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

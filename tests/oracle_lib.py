@@ -18,12 +18,21 @@ OK, E_NO_BOX, E_NOT_ORTHOGONAL, E_ZERO_BOX, E_EMPTY_GROUP, E_INCONSISTENT_GROUP,
 DIM = {"none": 0, "x": 1, "y": 2, "z": 3, "xy": 4, "xz": 5, "yz": 6, "xyz": 7}
 
 
+_PATH = None
+
+
+def use_library(path):
+    """load another build of the same oracle (bench.py's CPU-baseline child: the -march=native variant built on that host)"""
+    global _LIB, _PATH
+    _LIB, _PATH = None, path
+
+
 def lib():
     global _LIB
     if _LIB is None:
-        path = os.path.join(ROOT, "oracle", "liboracle.so")
+        path = _PATH or os.path.join(ROOT, "oracle", "liboracle.so")
         src = os.path.join(ROOT, "oracle", "groan_oracle.c")
-        if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
+        if _PATH is None and (not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src)):
             subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "liboracle.so"],
                                   stdout=subprocess.DEVNULL)
         L = C.CDLL(path)
