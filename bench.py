@@ -229,8 +229,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         tmpdir = None
         try:
-            visible = len(os.sched_getaffinity(0))
-            t_main = args.cpu_threads or visible
+            t_main = args.cpu_threads or usable_cores()
             nf = min(max(t_main, 16) * args.cpu_frames_per_thread, args.cpu_max_frames, pool)
             # fresh frames: regenerate the first nf frames (the timed region fitted them in place), copy them out, then run
             # the GPU on them for the parity figures
@@ -268,6 +267,24 @@ def main():
     plan.close(); ref.close(); cur.close()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def usable_cores():
+    """host cores this process can actually run on: the affinity mask, capped by the cgroup CPU quota (a GPU box hands each
+    GPU's job a share of the node: 256 hardware threads may be visible while the quota is 16 cores' worth of time)"""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, int(-(-int(quota) // int(period)))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and p > 0:
+                n = max(1, min(n, -(-q // p)))
+        except (OSError, ValueError):
+            pass
+    return n
 
 
 def cpu_baseline_child(tmpdir):
@@ -316,14 +333,18 @@ def cpu_baseline_child(tmpdir):
     chk = np.array(frames[:2])
     _, r_64 = O.baseline_rmsd_fit(chk, ref_pos, masses, box, 2, 1)
     O.set_accumulate_f64(False)
+    # the headline CPU figure is the BETTER of the two thread counts (a container may expose 256 hardware threads and schedule
+    # 16 cores' worth of them: oversubscribed threads then make "all cores" the slower configuration); both are reported
+    best_fps, best_t, best_nf = (fps_main, t_main, nf_main) if fps_main >= fps_16 else (fps_16, 16, nf_16)
     out = {
-        "value": round(fps_main, 2), "unit": "frames/s", "cores": t_main, "kind": "port",
+        "value": round(best_fps, 2), "unit": "frames/s", "cores": best_t, "kind": "port",
         "sample": "%d of the benchmark's own frames (%d per thread), reference-faithful 232-byte AoS layout, f32, frames round-robin over %d threads "
-                  "(src/system/parallel.rs:424-448), decode excluded" % (nf_main, fpt, t_main),
-        "nproc": os.cpu_count(), "cores_visible": visible, "cpu_model": model, "build": build,
+                  "(src/system/parallel.rs:424-448), decode excluded" % (best_nf, fpt, best_t),
+        "value_all_cores": round(fps_main, 2), "threads_all_cores": t_main,
+        "nproc": os.cpu_count(), "cores_visible": visible, "cores_usable_cgroup_quota": usable_cores(), "cpu_model": model, "build": build,
         "value_16_threads": round(fps_16, 2), "sample_16_threads": "%d frames" % nf_16,
         "soa_value": round(fps_soa, 2), "single_thread_value": None if fps_1 is None else round(fps_1, 3),
-        "gpu_vs_cpu": round(float(job["gpu_value"]) / fps_main, 1),
+        "gpu_vs_cpu": round(float(job["gpu_value"]) / best_fps, 1),
         "rust_toolchain_on_this_host": cargo or "absent (cargo --version fails): the reference itself cannot be built here",
         "process": "child process without any GPU library",
         "parity_max_abs_rmsd_diff_vs_cpu_f64sums": float(np.abs(gpu_r[:2] - r_64).max()),
