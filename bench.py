@@ -55,6 +55,8 @@ def main():
                     "to this process); a second figure at 16 threads (one GPU's share of the node) is always reported")
     ap.add_argument("--cpu-max-frames", type=int, default=256, help="upper bound on the CPU sample (frames)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE", help="gr_ctx_set_tuning (sub_batch, chunks, fit_wgs, fuse, "
+                    "two_pass): launch-geometry sweeps; the defaults are the measured optimum")
     ap.add_argument("--cpu-baseline-child", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--with-torch", action="store_true", help="import torch first even at N=1 (coexistence check)")
     args = ap.parse_args()
@@ -117,6 +119,8 @@ def main():
 
     dev = local_rank
     cur = G.System(n, masses=masses, n_slots=pool + 1, device=dev)      # slot `pool` holds the reference blob
+    if args.tune:
+        cur.set_tuning(**{kv.split("=")[0]: int(kv.split("=")[1]) for kv in args.tune})
     cur.synth_reference(pool, box, radius, SEED)
     ref = G.System(n, masses=masses, n_slots=1, device=dev)
     ref.set_frame(cur.get_positions(pool), box)
@@ -179,9 +183,9 @@ def main():
     value = total_frames / elapsed
 
     # ---- roofline of the dominant kernel (HIP events on the library's stream, timed region)
-    # algorithmic bytes per frame: the persistent kernel is the whole path (read x, p, m once + write x = 40 B/atom)
-    alg_bytes = {"k_rmsd_accum": 28.0 * n, "k_rmsd_finalize": 0.0, "k_fit": 24.0 * n, "k_rmsd_fit_persist": 40.0 * n}
-    dom = max(("k_rmsd_accum", "k_fit", "k_rmsd_fit_persist"), key=lambda k: prof[k][0] if k in prof else -1.0)
+    # algorithmic bytes per frame: sums pass 28 B/atom (cur 12 + ref 12 + mass 4), fit pass 24 B/atom (12 r + 12 w)
+    alg_bytes = {"k_sums_pk": 28.0 * n, "k_rmsd_finalize": 0.0, "k_fit_pk": 24.0 * n}
+    dom = max(("k_sums_pk", "k_fit_pk"), key=lambda k: prof[k][0] if k in prof else -1.0)
     ms_total, launches, frames = prof[dom]
     avg_ms = ms_total / max(launches, 1)
     bytes_per_launch = alg_bytes[dom] * (frames / max(launches, 1))

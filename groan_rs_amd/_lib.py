@@ -91,7 +91,7 @@ SIGNATURES = {
     "gr_rmsd_batch_end": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gr_rmsd_plan_last_fallbacks": (C.c_uint32, [C.c_void_p]),
     "gr_rmsd_plan_force_exact": (C.c_int, [C.c_void_p, C.c_int]),
-    "gr_ctx_set_persistent": (C.c_int, [C.c_void_p, C.c_int]),
+    "gr_ctx_set_tuning": (C.c_int, [C.c_void_p, C.c_int, C.c_int64]),
     "gr_ctx_set_center_onepass_min": (C.c_int, [C.c_void_p, C.c_uint32]),
     "gr_center_fallbacks": (C.c_uint64, [C.c_void_p]),
     "gr_gro_read": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_char_p, C.c_size_t]),
@@ -125,7 +125,6 @@ SIGNATURES = {
     "gr_shape_triangular_prism": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float]),
     "gr_shape_inside": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
     "gr_group_create_from_geometries": (C.c_int, [C.c_void_p, C.c_uint32, C.c_char_p, C.c_char_p, C.c_void_p, C.c_size_t, C.c_int]),
-    "gr_rmsd_plan_last_persistent": (C.c_int, [C.c_void_p]),
     "gr_xtc_open": (C.c_void_p, [C.c_char_p, c_i32p]),
     "gr_xtc_close": (None, [C.c_void_p]),
     "gr_xtc_n_atoms": (C.c_uint64, [C.c_void_p]),
@@ -159,6 +158,8 @@ def load():
             "`make -C groan_rs_amd/csrc`); the HIP extension is required, there is no CPU fallback")
     lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
     for name, (res, args) in SIGNATURES.items():
+        if os.environ.get("GR_LIB_PATH") and not hasattr(lib, name):
+            continue              # A/B builds of older sources (tools/ab_bench.sh) may lack newer entry points
         fn = getattr(lib, name)   # AttributeError if a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args

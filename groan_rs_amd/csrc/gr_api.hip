@@ -16,8 +16,8 @@
 #include "../../include/groan_hip.h"
 #include "gr_container.h"
 #include "gr_kernels.h"
+#include "gr_hot.h"
 #include "gr_xtc.h"
-#include "gr_persist.h"
 #include "gr_shape.h"
 #include "gr_xtc_dev.h"
 #include "gr_trr.h"
@@ -47,7 +47,6 @@ struct Group {
 struct gr_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipStream_t stream2 = nullptr;    // second queue: k_fit of group k runs beside k_rmsd_accum of group k+1
     // H2D double buffering: uploads run on their own stream; per-slot "upload done" events gate the compute
     // stream, and a ring of "compute done" events gates the next upload into a slot that kernels still read
     hipStream_t copy_stream = nullptr;
@@ -56,19 +55,16 @@ struct gr_ctx {
     hipEvent_t ev_done_ring[64] = {};
     uint64_t done_gen = 0;
     std::vector<uint64_t> slot_gen;         // per slot: generation of the last compute call that touched it
-    hipEvent_t ev_grp[GR_MAX_BATCH] = {};   // "finalize of group k done" (stream -> stream2)
-    hipEvent_t ev_skew[3 * GR_MAX_BATCH] = {};   // skewed order: [3g] sums of group g done, [3g+1] finalize done, [3g+2] fit done
     uint32_t *fuse_cnt = nullptr;     // [2 * GR_MAX_BATCH] arrival counters of the fused finalize / close tails (self-resetting)
-    int fuse = 1;                     // GR_FUSE=0: separate k_rmsd_finalize_lite / k_rmsd_close launches
+    int fuse = 1;                     // GR_TUNE_FUSE 0: separate k_rmsd_finalize_lite launch instead of the sums kernel's closing tail
     uint64_t center_fallbacks = 0;    // frames the one-pass centre handed to the estimate pass (copy selection) or to both passes (gr_center_fallbacks)
-    uint32_t com_onepass_min = 4096;  // GR_COM_ONEPASS_MIN: contiguous groups of at least this many atoms take the one-pass get_com / get_center (0 = never)
-    int skew = 0;                     // GR_SKEW=1: small kernels on the second stream beside the next group's sums pass (measured slower)
-    hipEvent_t ev_join = nullptr;           // "all fits done" (stream2 -> stream)
-    int overlap = 0;   // GR_OVERLAP=1: +5 % frames/s at 256-frame calls (measured), but per-kernel durations then overlap
+    uint32_t com_onepass_min = 4096;  // contiguous groups of at least this many atoms take the one-pass get_com / get_center (0 = never)
     uint64_t n = 0, n_pad = 0;
     uint32_t n_slots = 0;
     size_t frame_stride = 0;          // floats per slot
-    float *frames = nullptr;          // [n_slots][n_pad][3]
+    float *frames = nullptr;          // [n_slots] pair-tiled slots of n_pad atoms (gr_layout.h)
+    float *aos_up = nullptr;          // [n_pad][3] packed records: landing buffer of gr_frame_upload on the copy stream (-> k_tile)
+    float *aos_dl = nullptr;          // [n_pad][3] packed records: k_untile's output on the compute stream (-> D2H)
     float *masses = nullptr;          // [n_pad]
     std::vector<float> masses_host;   // copy kept for plan bookkeeping (weights == masses test)
     GrBox *boxes_dev = nullptr;       // [n_slots]
@@ -82,7 +78,7 @@ struct gr_ctx {
     GrAccPartial *acc_partials = nullptr;
     double *fit_partials = nullptr;   // [frames of a segment][fit workgroups per frame]: sum w |R q - p|^2 of k_fit<true>
     size_t fit_partials_cap = 0;
-    int two_pass = 1;                 // GR_TWO_PASS=0: RMSD-fit keeps the closed-form single-pass rmsd (k_rmsd_accum<0,false>)
+    int two_pass = 1;                 // GR_TUNE_TWO_PASS 0: RMSD-fit keeps the closed-form single-pass rmsd (k_rmsd_accum<0>)
     GrFrameState *state_dev = nullptr;
     GrFrameState *state_host = nullptr;   // pinned
     uint32_t *bad_dev = nullptr;          // [4 * GR_MAX_BATCH]: per frame, first atom without position (rows / columns)
@@ -91,11 +87,7 @@ struct gr_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // per-kernel HIP-event profile of the batched RMSD path (gr_profile_*): 0 accumulate, 1 finalize, 2 fit
     hipEvent_t pev[6 * GR_MAX_BATCH] = {};   // per group: begin / end of the sums, finalize and fit kernels
-    hipEvent_t pev_fit[2 * GR_MAX_BATCH] = {};   // begin / end of every k_fit launch when a group's fit is split (fit_sub)
-    uint32_t fit_sub = 0;       // frames per k_fit launch inside a group (GR_FIT_SUB); 0 = the whole group in one launch.
-                                // Measured at 1e6 atoms, 1024 frames per call, groups of 256: 0 -> 148.9 k frames/s, 128 -> 149.7 k,
-                                // 64 -> 148.8 k, 32 -> 144.4 k: no gain from decoupling the two passes' launch lengths.
-    // launch geometry of the batched RMSD path (env GR_SUB_BATCH / GR_CHUNKS / GR_FIT_WGS override)
+    // launch geometry of the batched RMSD path (gr_ctx_set_tuning)
     uint32_t sub_batch = 256;   // frames per sums->fit group.  The group's frames (12 MB each) leave the L2 / Infinity Cache
                                 // between the two passes at any size worth launching, so the size only trades launch
                                 // boundaries (6-11 us each) against the sums pass's chunk count per frame.  Measured at 1e6
@@ -104,17 +96,10 @@ struct gr_ctx {
     uint32_t chunks = 0;        // workgroups per frame in the reductions (0 = auto)
     uint32_t fit_wgs = 0;       // workgroups per frame in k_fit (0 = auto)
     int profile = 0;
-    double prof_ms[4] = { 0, 0, 0, 0 };        // 3 = k_rmsd_fit_persist
+    double prof_ms[4] = { 0, 0, 0, 0 };
     uint64_t prof_launches[4] = { 0, 0, 0, 0 };
     uint64_t prof_frames[4] = { 0, 0, 0, 0 };
-    // persistent RMSD-fit kernel (gr_persist.h)
-    int persist = 0;                  // GR_PERSIST=1 / gr_ctx_set_persistent: persistent kernel for large fit batches
     uint32_t n_cus = 0;
-    double *ps_partials = nullptr;    // [GR_MAX_BATCH][n_cus][GR_PS_REC]
-    double *ps_rmsd = nullptr;        // [GR_MAX_BATCH][n_cus * GR_PS_WAVES]
-    uint32_t *ps_sync = nullptr;      // [2 + 2 * GR_MAX_BATCH]
-    uint32_t *ps_sync_host = nullptr; // pinned [2]
-    unsigned long long *ps_trace = nullptr;   // GR_PS_TRACE=<file>: time stamps of the last persistent launch, dumped to <file>
     // device-side xtc unpacking (gr_xtc_read_frames_device): grow-only staging, pinned host mirror + device copy
     // two pinned staging banks used in turn: the host reads + skims batch k + 1 while the H2D copy of batch k drains the other
     // and two device banks: the H2D copy of batch k + 1 (copy stream) runs beside k_xtc_unpack of batch k (unpack stream)
@@ -124,7 +109,6 @@ struct gr_ctx {
     hipStream_t unpack_stream = nullptr;
     uint32_t xtc_bank = 0;
     float *wr_host = nullptr; size_t wr_cap = 0;   // pinned landing buffer of gr_xtc_write_slots (grow-only)
-    std::string ps_trace_path;
     int strict = 0;
     gr_rmsd_plan *in_flight = nullptr;   // the plan whose gr_rmsd_batch_begin has not been ended yet (shared workspace: one at a time)
     uint32_t in_flight_s0 = 0, in_flight_n = 0;   // its slots
@@ -135,11 +119,10 @@ struct gr_ctx {
 };
 
 struct Pending {   // a segment between gr_rmsd_batch_begin and gr_rmsd_batch_end
-    bool active = false, any_ok = false, consistent = true, prof_two = false, persist = false, fused = false;
+    bool active = false, any_ok = false, consistent = true, fused = false;
     uint32_t s0 = 0, nb = 0, n_prof_groups = 0;
     int fit = 0;
     std::vector<int> pre;
-    std::vector<uint32_t> fit_launch_frames;   // profiling: frames of every k_fit launch of the segment, in pev_fit order
     std::vector<uint64_t> pre_idx;
     std::vector<std::string> pre_msg;
     GrSel sel = {};        // the group as it was at begin (the context refuses group / mass changes while a batch is in flight)
@@ -157,7 +140,7 @@ struct gr_rmsd_plan {
     GrPlanDev dev = {};
     int exact = 0;
     uint32_t last_fallbacks = 0;
-    bool resolved = false, last_persist = false;
+    bool resolved = false;
     uint64_t resolved_epoch = 0;   // context epoch at which w_is_mass was decided
 };
 
@@ -211,21 +194,6 @@ uint32_t batch_chunks(const gr_ctx *c, const GrSel &s, uint32_t nf) {
     // of 8 rotate the mapping and run ~25 % slower)
     if (ch >= 8) ch &= ~(uint64_t)7;
     return (uint32_t)ch;
-}
-
-// Can the persistent kernel take this batch?  Contiguous selection, one tile per wave (<= 16 tiles per workgroup), a ring
-// of 3 (else 2) frame slices per workgroup inside the 160 KiB of LDS.  persist == 1 asks for it only where it pays (at
-// least 8 tiles per workgroup); persist == 2 takes it whenever it is possible (tests).
-bool persist_plan(const gr_ctx *c, const GrSel &s, uint32_t nf, uint32_t *T, uint32_t *D) {
-    if (!c->persist || !s.contiguous || c->n_cus == 0 || (c->n_cus % 32u) != 0 || nf < 2) return false;
-    const uint32_t ntiles = (uint32_t)((c->n + 255) >> 8);
-    if (ntiles < c->n_cus) return false;                       // small systems: the batched three-kernel path
-    const uint32_t ncomp = c->n_cus - 1;                        // one workgroup finalizes, the others stream
-    const uint32_t t = (ntiles + ncomp - 1) / ncomp;
-    if (t > GR_PS_WAVES || (c->persist == 1 && t < 8)) return false;
-    for (uint32_t d = 3; d >= 2; --d)
-        if (GrPersistLds(t, d).total <= 160u * 1024u) { *T = t; *D = d; return true; }
-    return false;
 }
 
 // Workgroups per frame of k_fit: one 256-atom tile per wave (measured at 1e6 atoms x 64 frames: 3.8 us/frame with 976
@@ -354,6 +322,25 @@ int set_box(gr_ctx *c, uint32_t slot, const float *box9, hipStream_t on = nullpt
     return GR_OK;
 }
 
+// packed-record staging buffers (the C ABI speaks rvec[n], the slots are pair-tiled): allocated on first use, pad atoms zero
+int ensure_staging(gr_ctx *c, float **buf) {
+    if (*buf) return GR_OK;
+    HIPCHK(c, hipMalloc(buf, c->frame_stride * sizeof(float)));
+    // (hipMemset on device memory may return before it has run, and the context's streams are non-blocking: clear on the
+    // context's stream and wait, so the clear can never land on top of the first frame that passes through the buffer)
+    HIPCHK(c, hipMemsetAsync(*buf, 0, c->frame_stride * sizeof(float), c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return GR_OK;
+}
+// slot -> packed records in aos_dl, on the compute stream (the caller copies aos_dl out on the same stream)
+int untile_slot(gr_ctx *c, uint32_t slot) {
+    int st = ensure_staging(c, &c->aos_dl); if (st) return st;
+    const uint32_t ng = (uint32_t)(c->n_pad >> 2);
+    k_untile<<<dim3((ng + 255) / 256), dim3(256), 0, c->stream>>>(c->frames + (size_t)slot * c->frame_stride, c->aos_dl, ng);
+    HIPCHK(c, hipGetLastError());
+    return GR_OK;
+}
+
 // events of the batched paths are created when first needed
 int ensure_event(gr_ctx *c, hipEvent_t *ev, bool timing) {
     if (*ev) return GR_OK;
@@ -418,9 +405,9 @@ static int pbc_center_onepass(gr_ctx *c, uint32_t s0, uint32_t nb, const GrSel &
     plan.n = sel.n; plan.sw = 1.0;
     const uint32_t nch = batch_chunks(c, sel, nb);
     if (c->fuse) {
-        k_rmsd_accum<0, true, true><<<dim3(nch, nb), dim3(GR_WG), 0, c->stream>>>(c->frames, c->frame_stride, s0, c->masses, sel, c->boxes_dev, plan, c->state_dev, c->acc_partials, c->fuse_cnt, c->state_dev);
+        k_sums_pk<true><<<dim3(nch, nb), dim3(GR_WG), 0, c->stream>>>(c->frames, c->frame_stride, s0, c->masses, sel, c->boxes_dev, plan, c->acc_partials, c->fuse_cnt, c->state_dev);
     } else {
-        k_rmsd_accum<0, true, true><<<dim3(nch, nb), dim3(GR_WG), 0, c->stream>>>(c->frames, c->frame_stride, s0, c->masses, sel, c->boxes_dev, plan, c->state_dev, c->acc_partials);
+        k_sums_pk<true><<<dim3(nch, nb), dim3(GR_WG), 0, c->stream>>>(c->frames, c->frame_stride, s0, c->masses, sel, c->boxes_dev, plan, c->acc_partials, nullptr, nullptr);
         k_rmsd_finalize_lite<true><<<dim3(nb), dim3(64), 0, c->stream>>>(c->acc_partials, nch, c->frames, c->frame_stride, s0, sel, c->boxes_dev, plan, c->state_dev);
     }
     HIPCHK(c, hipGetLastError());
@@ -495,27 +482,13 @@ gr_ctx *gr_ctx_create(int device, uint64_t n_atoms, uint32_t n_slots, int *statu
     c->frame_stride = (size_t)c->n_pad * 3;
     bool ok = true;
     ok = ok && hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
-    {   // the second queue carries the small latency-critical kernels of the skewed order: highest priority
-        int lo = 0, hi = 0;
-        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-        ok = ok && hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, hi) == hipSuccess;
-    }
     ok = ok && hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) == hipSuccess;
     for (int k = 0; k < 64; ++k) ok = ok && hipEventCreateWithFlags(&c->ev_done_ring[k], hipEventDisableTiming) == hipSuccess;
     c->ev_ready.assign(n_slots, nullptr); c->upload_pending.assign(n_slots, 0); c->slot_gen.assign(n_slots, 0);
-    // ev_grp / ev_skew / pev are created on first use (ensure_event): thousands of events per context otherwise
-    ok = ok && hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) == hipSuccess;
-    if (const char *e = getenv("GR_OVERLAP")) c->overlap = atoi(e) ? 1 : 0;
-    if (const char *e = getenv("GR_PERSIST")) { const int v = atoi(e); c->persist = v < 0 ? 0 : (v > 2 ? 2 : v); }
-    if (const char *e = getenv("GR_TWO_PASS")) c->two_pass = atoi(e) ? 1 : 0;
-    if (const char *e = getenv("GR_SKEW")) c->skew = atoi(e) ? 1 : 0;
-    if (const char *e = getenv("GR_FUSE")) c->fuse = atoi(e) ? 1 : 0;
+    // pev (profiling events) are created on first use (ensure_event): thousands of events per context otherwise
     ok = ok && hipMalloc(&c->fuse_cnt, 2 * GR_MAX_BATCH * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipMemset(c->fuse_cnt, 0, 2 * GR_MAX_BATCH * sizeof(uint32_t)) == hipSuccess;
-    if (const char *e = getenv("GR_PS_TRACE")) c->ps_trace_path = e;
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cus = (uint32_t)prop.multiProcessorCount; }
-    ok = ok && hipMalloc(&c->ps_sync, (2 + 2 * GR_MAX_BATCH) * sizeof(uint32_t)) == hipSuccess;
-    ok = ok && hipHostMalloc(&c->ps_sync_host, 2 * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess;
     ok = ok && hipMalloc(&c->frames, (size_t)n_slots * c->frame_stride * sizeof(float)) == hipSuccess;
     ok = ok && hipMalloc(&c->masses, c->n_pad * sizeof(float)) == hipSuccess;
     ok = ok && hipMalloc(&c->boxes_dev, n_slots * sizeof(GrBox)) == hipSuccess;
@@ -528,11 +501,6 @@ gr_ctx *gr_ctx_create(int device, uint64_t n_atoms, uint32_t n_slots, int *statu
     ok = ok && hipHostMalloc(&c->bad_host, 4 * GR_MAX_BATCH * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess;
     ok = ok && hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess;
 
-    if (const char *e = getenv("GR_COM_ONEPASS_MIN")) { long v = atol(e); if (v >= 0) c->com_onepass_min = (uint32_t)std::min<long>(v, 0x7fffffffL); }
-    if (const char *e = getenv("GR_FIT_SUB")) { int v = atoi(e); if (v >= 0 && v <= GR_MAX_BATCH) c->fit_sub = (uint32_t)v; }
-    if (const char *e = getenv("GR_SUB_BATCH")) { int v = atoi(e); if (v >= 1 && v <= GR_MAX_BATCH) c->sub_batch = (uint32_t)v; }
-    if (const char *e = getenv("GR_CHUNKS")) { int v = atoi(e); if (v >= 1 && v <= GR_MAX_CHUNKS) c->chunks = (uint32_t)v; }
-    if (const char *e = getenv("GR_FIT_WGS")) { int v = atoi(e); if (v >= 1 && v <= 65535) c->fit_wgs = (uint32_t)v; }
     if (!ok) { *status = GR_E_HIP; gr_ctx_destroy(c); return nullptr; }
     // masses undefined (None) until gr_set_masses; padding and frames zero
     std::vector<float> nanv(c->n_pad, NAN);
@@ -547,6 +515,7 @@ gr_ctx *gr_ctx_create(int device, uint64_t n_atoms, uint32_t n_slots, int *statu
     // System::new creates the group "all" (src/system/mod.rs)
     std::vector<grc::Block> all(1, grc::Block(0, n_atoms - 1));
     install_group(c, "all", all);
+    (void)hipDeviceSynchronize();   // the clears above run on the null stream; the context's own streams do not wait for it
     *status = GR_OK;
     return c;
 } catch (...) { return nullptr; }
@@ -556,9 +525,10 @@ void gr_ctx_destroy(gr_ctx *c) try {
     (void)hipSetDevice(c->device);
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    if (c->stream2) (void)hipStreamSynchronize(c->stream2);
     for (auto &kv : c->groups) if (kv.second.idx_dev) (void)hipFree(kv.second.idx_dev);
     if (c->frames) (void)hipFree(c->frames);
+    if (c->aos_up) (void)hipFree(c->aos_up);
+    if (c->aos_dl) (void)hipFree(c->aos_dl);
     if (c->masses) (void)hipFree(c->masses);
     if (c->boxes_dev) (void)hipFree(c->boxes_dev);
     if (c->boxes_host) (void)hipHostFree(c->boxes_host);
@@ -571,10 +541,6 @@ void gr_ctx_destroy(gr_ctx *c) try {
     if (c->bad_dev) (void)hipFree(c->bad_dev);
     if (c->bad_host) (void)hipHostFree(c->bad_host);
     if (c->pd_out) (void)hipFree(c->pd_out);
-    if (c->ps_partials) (void)hipFree(c->ps_partials);
-    if (c->ps_rmsd) (void)hipFree(c->ps_rmsd);
-    if (c->ps_sync) (void)hipFree(c->ps_sync);
-    if (c->ps_trace) (void)hipFree(c->ps_trace);
     if (c->unpack_stream) { (void)hipStreamSynchronize(c->unpack_stream); (void)hipStreamDestroy(c->unpack_stream); }
     for (int k = 0; k < 2; ++k) {
         if (c->xtc_host[k]) (void)hipHostFree(c->xtc_host[k]);
@@ -583,18 +549,12 @@ void gr_ctx_destroy(gr_ctx *c) try {
         if (c->xtc_unpacked[k]) (void)hipEventDestroy(c->xtc_unpacked[k]);
     }
     if (c->wr_host) (void)hipHostFree(c->wr_host);
-    if (c->ps_sync_host) (void)hipHostFree(c->ps_sync_host);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     for (int k = 0; k < 6 * GR_MAX_BATCH; ++k) if (c->pev[k]) (void)hipEventDestroy(c->pev[k]);
-    for (int k = 0; k < 2 * GR_MAX_BATCH; ++k) if (c->pev_fit[k]) (void)hipEventDestroy(c->pev_fit[k]);
-    for (int k = 0; k < 3 * GR_MAX_BATCH; ++k) if (c->ev_skew[k]) (void)hipEventDestroy(c->ev_skew[k]);
-    for (int k = 0; k < GR_MAX_BATCH; ++k) if (c->ev_grp[k]) (void)hipEventDestroy(c->ev_grp[k]);
-    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     for (hipEvent_t e : c->ev_ready) if (e) (void)hipEventDestroy(e);
     for (int k = 0; k < 64; ++k) if (c->ev_done_ring[k]) (void)hipEventDestroy(c->ev_done_ring[k]);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
-    if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 } catch (...) { }
@@ -610,7 +570,6 @@ int gr_sync(gr_ctx *c) try {
     if (!c) return GR_E_INVALID_ARG;
     HIPCHK(c, sync_ingest(c));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream2));
     return GR_OK;
 } catch (...) { return gr_abi_guard(); }
 
@@ -715,7 +674,14 @@ int gr_frame_upload(gr_ctx *c, uint32_t slot, const float *xyz, const float *box
     // the slot may still be read by kernels issued earlier: order the copy behind the last compute call that used it
     // (events of one stream complete in order, so a recycled ring entry only makes the wait conservative)
     if (c->slot_gen[slot]) HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->ev_done_ring[c->slot_gen[slot] % 64], 0));
-    HIPCHK(c, hipMemcpyAsync(c->frames + (size_t)slot * c->frame_stride, xyz, c->n * 3 * sizeof(float), hipMemcpyHostToDevice, c->copy_stream));
+    // packed rvec[n] -> landing buffer -> pair-tiled slot, all on the copy stream (stream order keeps the one landing buffer safe)
+    st = ensure_staging(c, &c->aos_up); if (st) return st;
+    HIPCHK(c, hipMemcpyAsync(c->aos_up, xyz, c->n * 3 * sizeof(float), hipMemcpyHostToDevice, c->copy_stream));
+    {
+        const uint32_t ng = (uint32_t)(c->n_pad >> 2);
+        k_tile<<<dim3((ng + 255) / 256), dim3(256), 0, c->copy_stream>>>(c->aos_up, c->frames + (size_t)slot * c->frame_stride, ng);
+        HIPCHK(c, hipGetLastError());
+    }
     st = set_box(c, slot, box9, c->copy_stream); if (st) return st;
     HIPCHK(c, hipEventRecord(c->ev_ready[slot], c->copy_stream));
     c->upload_pending[slot] = 1;
@@ -731,7 +697,8 @@ int gr_frame_download(gr_ctx *c, uint32_t slot, float *xyz) try {
     if (!xyz) return fail(c, GR_E_INVALID_ARG, "xyz is NULL");
     (void)hipSetDevice(c->device);
     SlotUse use(c, slot);
-    HIPCHK(c, hipMemcpyAsync(xyz, c->frames + (size_t)slot * c->frame_stride, c->n * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    st = untile_slot(c, slot); if (st) return st;
+    HIPCHK(c, hipMemcpyAsync(xyz, c->aos_dl, c->n * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return GR_OK;
 } catch (...) { return gr_abi_guard(); }
@@ -1321,8 +1288,19 @@ uint32_t gr_rmsd_plan_last_fallbacks(const gr_rmsd_plan *p) { return p ? p->last
 int gr_rmsd_plan_force_exact(gr_rmsd_plan *p, int on) { if (!p) return GR_E_INVALID_ARG; p->exact = on ? 1 : 0; return GR_OK; }
 int gr_ctx_set_center_onepass_min(gr_ctx *c, uint32_t min_atoms) { if (!c) return GR_E_INVALID_ARG; c->com_onepass_min = min_atoms; return GR_OK; }
 uint64_t gr_center_fallbacks(const gr_ctx *c) { return c ? c->center_fallbacks : 0; }
-int gr_ctx_set_persistent(gr_ctx *c, int mode) { if (!c || mode < 0 || mode > 2) return GR_E_INVALID_ARG; c->persist = mode; return GR_OK; }
-int gr_rmsd_plan_last_persistent(const gr_rmsd_plan *p) { return p && p->last_persist ? 1 : 0; }
+int gr_ctx_set_tuning(gr_ctx *c, int key, int64_t value) try {
+    if (!c) return GR_E_INVALID_ARG;
+    { int st = busy_check(c); if (st) return st; }
+    switch (key) {
+    case GR_TUNE_SUB_BATCH: if (value < 1 || value > GR_MAX_BATCH) break; c->sub_batch = (uint32_t)value; return GR_OK;
+    case GR_TUNE_CHUNKS: if (value < 0 || value > GR_MAX_CHUNKS) break; c->chunks = (uint32_t)value; return GR_OK;
+    case GR_TUNE_FIT_WGS: if (value < 0 || value > 65535) break; c->fit_wgs = (uint32_t)value; return GR_OK;
+    case GR_TUNE_FUSE: c->fuse = value ? 1 : 0; return GR_OK;
+    case GR_TUNE_TWO_PASS: c->two_pass = value ? 1 : 0; return GR_OK;
+    default: break;
+    }
+    return fail(c, GR_E_INVALID_ARG, "unknown tuning key or value out of range");
+} catch (...) { return gr_abi_guard(); }
 
 // multi-pass exact path for `nf` frames starting at first_slot; states [0, nf) must be reset by the caller
 static int rmsd_exact(gr_rmsd_plan *p, gr_ctx *c, const GrSel &sel, uint32_t first_slot, uint32_t nf, int fit) {
@@ -1332,7 +1310,7 @@ static int rmsd_exact(gr_rmsd_plan *p, gr_ctx *c, const GrSel &sel, uint32_t fir
     k_rmsd_finalize<1><<<dim3(nf), dim3(GR_WG), 0, c->stream>>>(c->acc_partials, nch, c->frames, c->frame_stride, first_slot, sel, c->boxes_dev, p->dev, c->state_dev);
     if (fit) {
         const uint32_t gx = (uint32_t)std::min<uint64_t>(((c->n >> 2) + GR_WG * 4 - 1) / (GR_WG * 4) + 1, 1024);
-        k_fit<false><<<dim3(gx, nf), dim3(GR_WG), 0, c->stream>>>(c->frames, c->frame_stride, first_slot, (uint32_t)c->n, c->boxes_dev, p->dev, c->state_dev, c->masses, sel, nullptr);
+        k_fit_pk<false><<<dim3(gx, nf), dim3(GR_WG), 0, c->stream>>>(c->frames, c->frame_stride, first_slot, (uint32_t)c->n, c->boxes_dev, p->dev, c->state_dev, c->masses, sel, nullptr);
     }
     HIPCHK(c, hipGetLastError());
     return GR_OK;
@@ -1346,7 +1324,6 @@ static int segment_begin(gr_rmsd_plan *p, uint32_t s0, uint32_t nb, int fit) {
     gr_ctx *c = p->target;
     Pending &q = p->pend;
     q = Pending();
-    if (fit) p->last_persist = false;
     q.s0 = s0; q.nb = nb; q.fit = fit; q.active = true;
     SlotUse use(c, s0, nb);
     const Group *g = find_group(c, p->group.c_str());
@@ -1373,48 +1350,22 @@ static int segment_begin(gr_rmsd_plan *p, uint32_t s0, uint32_t nb, int fit) {
     HIPCHK(c, hipMemcpyAsync(c->state_dev, c->state_host, nb * sizeof(GrFrameState), hipMemcpyHostToDevice, c->stream));
     q.consistent = (g->n == p->n_ref);
     int st;
-    uint32_t ps_T = 0, ps_D = 0;
     if (!q.consistent) {
         // positions and masses of the target are still checked first (extract_data_from_system runs to
         // completion before number_of_positions_consistent, rmsd.rs:206-214)
         st = pbc_center_stages(c, s0, nb, sel, 1); if (st) return st;
     } else if (p->exact) {
         st = rmsd_exact(p, c, sel, s0, nb, fit); if (st) return st;
-    } else if (fit && persist_plan(c, sel, nb, &ps_T, &ps_D)) {
-        // persistent pipelined kernel: every frame is read from HBM once (its slices wait in LDS for the rotation)
-        if (!c->ps_partials) HIPCHK(c, hipMalloc(&c->ps_partials, (size_t)GR_MAX_BATCH * c->n_cus * GR_PS_REC * sizeof(double)));
-        if (!c->ps_rmsd) HIPCHK(c, hipMalloc(&c->ps_rmsd, (size_t)GR_MAX_BATCH * c->n_cus * GR_PS_WAVES * sizeof(double)));
-        HIPCHK(c, hipMemsetAsync(c->ps_rmsd, 0, (size_t)nb * c->n_cus * GR_PS_WAVES * sizeof(double), c->stream));
-        HIPCHK(c, hipMemsetAsync(c->ps_sync, 0, (2 + 2 * (size_t)nb) * sizeof(uint32_t), c->stream));
-        GrPersistArgs a;
-        a.frames = c->frames; a.frame_stride = c->frame_stride; a.first_slot = s0; a.n_frames = nb; a.n_atoms = (uint32_t)c->n;
-        a.masses = c->masses; a.sel = sel; a.boxes = c->boxes_dev; a.plan = p->dev; a.state = c->state_dev;
-        a.partials = c->ps_partials; a.rmsd_partials = c->ps_rmsd; a.sync = c->ps_sync; a.tiles_per_wg = ps_T; a.depth = ps_D;
-        a.trace = nullptr;
-        if (!c->ps_trace_path.empty()) {
-            const size_t tb = (size_t)GR_MAX_BATCH * c->n_cus * GR_PS_TRACE_N * sizeof(unsigned long long);
-            if (!c->ps_trace) HIPCHK(c, hipMalloc(&c->ps_trace, tb));
-            HIPCHK(c, hipMemsetAsync(c->ps_trace, 0, tb, c->stream));
-            a.trace = c->ps_trace;
-        }
-        const size_t lds = GrPersistLds(ps_T, ps_D).total;
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rmsd_fit_persist), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        if (c->profile) EVREC(c, c->pev[0], true, c->stream);
-        k_rmsd_fit_persist<<<dim3(c->n_cus), dim3(GR_PS_THREADS), lds, c->stream>>>(a);
-        if (c->profile) EVREC(c, c->pev[1], true, c->stream);
-        HIPCHK(c, hipGetLastError());
-        k_rmsd_close<<<dim3(nb), dim3(64), 0, c->stream>>>(c->ps_rmsd, c->n_cus * GR_PS_WAVES, p->dev.sw, c->state_dev);
-        HIPCHK(c, hipMemcpyAsync(c->ps_sync_host, c->ps_sync, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-        q.persist = true; p->last_persist = true;
     } else {
-        // groups of sub_batch frames: accumulate -> finalize -> fit back to back on the stream, no host
-        // round trip in between; one state fetch for the whole segment afterwards
+        // groups of sub_batch frames: sums (closing its frames on its own tail) -> fit -> rmsd close back to back on the stream,
+        // no host round trip in between; one state fetch for the whole segment afterwards.  (Orders that put the fit of group g
+        // beside the sums of group g + 1 on a second stream, or the small kernels on a high-priority stream, were measured
+        // slower in round 1 and are gone: DESIGN.md "Batching".)
         const uint32_t sb = c->sub_batch;
-        uint32_t ng = 0;
-        const bool two = fit && c->overlap && nb > sb;
         // RMSD-fit of a contiguous selection: the sums pass only steers R and the centre, the fit pass evaluates
-        // sum w |R q - p|^2 on the way (k_fit<true>) and k_rmsd_close turns it into the rmsd
+        // sum w |R q - p|^2 on the way (k_fit_pk<true>) and k_rmsd_close turns it into the rmsd
         const bool lite = fit && sel.contiguous && c->two_pass;
+        const uint32_t n_groups = (nb + sb - 1) / sb;
         if (lite) {
             size_t need = 0;
             for (uint32_t f0 = 0; f0 < nb; f0 += sb) need = std::max(need, (size_t)nb * fit_grid(c, std::min<uint32_t>(sb, nb - f0)));
@@ -1425,106 +1376,35 @@ static int segment_begin(gr_rmsd_plan *p, uint32_t s0, uint32_t nb, int fit) {
                 c->fit_partials_cap = need;
             }
         }
-        const uint32_t n_groups = (nb + sb - 1) / sb;
-        q.fit_launch_frames.clear();
         const bool fused = lite && c->fuse;   // the finalize rides on the tail of the sums kernel
         q.fused = fused;
-        // The kernels of one group, each bracketed by its own pair of profiling events on the stream it runs on
-        auto group_nf = [&](uint32_t g) { return std::min<uint32_t>(sb, nb - g * sb); };
-        auto launch_sums = [&](uint32_t g, hipStream_t on) -> int {
-            const uint32_t f0 = g * sb, nf = group_nf(g), nch = batch_chunks(c, sel, nf);
+        hipStream_t S = c->stream;
+        for (uint32_t g = 0; g < n_groups; ++g) {
+            const uint32_t f0 = g * sb, nf = std::min<uint32_t>(sb, nb - f0), nch = batch_chunks(c, sel, nf), gx = fit_grid(c, nf);
             GrAccPartial *parts = c->acc_partials + (size_t)f0 * GR_MAX_CHUNKS;
-            if (c->profile) EVREC(c, c->pev[6 * g], true, on);
-            if (lite) k_rmsd_accum<0, true><<<dim3(nch, nf), dim3(GR_WG), 0, on>>>(c->frames, c->frame_stride, s0 + f0, c->masses, sel, c->boxes_dev, p->dev, c->state_dev + f0, parts,
-                                                                                  fused ? c->fuse_cnt + f0 : nullptr, c->state_dev + f0);
-            else k_rmsd_accum<0><<<dim3(nch, nf), dim3(GR_WG), 0, on>>>(c->frames, c->frame_stride, s0 + f0, c->masses, sel, c->boxes_dev, p->dev, c->state_dev + f0, parts);
-            if (c->profile) EVREC(c, c->pev[6 * g + 1], true, on);
-            return GR_OK;
-        };
-        auto launch_finalize = [&](uint32_t g, hipStream_t on) -> int {
-            if (fused) return GR_OK;   // the sums kernel's last workgroup per frame has closed it
-            const uint32_t f0 = g * sb, nf = group_nf(g), nch = batch_chunks(c, sel, nf);
-            GrAccPartial *parts = c->acc_partials + (size_t)f0 * GR_MAX_CHUNKS;
-            if (c->profile) EVREC(c, c->pev[6 * g + 2], true, on);
-            if (lite) k_rmsd_finalize_lite<false><<<dim3(nf), dim3(64), 0, on>>>(parts, nch, c->frames, c->frame_stride, s0 + f0, sel, c->boxes_dev, p->dev, c->state_dev + f0);
-            else k_rmsd_finalize<0><<<dim3(nf), dim3(GR_WG), 0, on>>>(parts, nch, c->frames, c->frame_stride, s0 + f0, sel, c->boxes_dev, p->dev, c->state_dev + f0);
-            if (c->profile) EVREC(c, c->pev[6 * g + 3], true, on);
-            return GR_OK;
-        };
-        auto launch_fit = [&](uint32_t g, hipStream_t on) -> int {
-            const uint32_t g0 = g * sb, gn = group_nf(g), gx = fit_grid(c, gn);
-            const uint32_t step = (c->fit_sub && c->fit_sub < gn) ? c->fit_sub : gn;   // the sums pass likes long groups, the fit pass short ones
-            for (uint32_t h0 = 0; h0 < gn; h0 += step) {
-                const uint32_t f0 = g0 + h0, nf = std::min<uint32_t>(step, gn - h0);
-                const uint32_t e = 2 * (uint32_t)q.fit_launch_frames.size();
-                if (c->profile) EVREC(c, c->pev_fit[e], true, on);
-                if (lite) k_fit<true><<<dim3(gx, nf), dim3(GR_WG), 0, on>>>(c->frames, c->frame_stride, s0 + f0, (uint32_t)c->n, c->boxes_dev, p->dev, c->state_dev + f0, c->masses, sel, c->fit_partials + (size_t)f0 * gx,
-                                                                            nullptr, c->state_dev + f0);   // (a fused close makes every one of the 62 k workgroups drain its stores: 3x slower)
-                else k_fit<false><<<dim3(gx, nf), dim3(GR_WG), 0, on>>>(c->frames, c->frame_stride, s0 + f0, (uint32_t)c->n, c->boxes_dev, p->dev, c->state_dev + f0, c->masses, sel, nullptr);
-                if (c->profile) { EVREC(c, c->pev_fit[e + 1], true, on); q.fit_launch_frames.push_back(nf); }
+            // each kernel is bracketed by its own pair of profiling events (gr_profile_*)
+            if (c->profile) EVREC(c, c->pev[6 * g], true, S);
+            if (lite) k_sums_pk<false><<<dim3(nch, nf), dim3(GR_WG), 0, S>>>(c->frames, c->frame_stride, s0 + f0, c->masses, sel, c->boxes_dev, p->dev, parts,
+                                                                             fused ? c->fuse_cnt + f0 : nullptr, c->state_dev + f0);
+            else k_rmsd_accum<0><<<dim3(nch, nf), dim3(GR_WG), 0, S>>>(c->frames, c->frame_stride, s0 + f0, c->masses, sel, c->boxes_dev, p->dev, c->state_dev + f0, parts);
+            if (c->profile) EVREC(c, c->pev[6 * g + 1], true, S);
+            if (!fused) {
+                if (c->profile) EVREC(c, c->pev[6 * g + 2], true, S);
+                if (lite) k_rmsd_finalize_lite<false><<<dim3(nf), dim3(64), 0, S>>>(parts, nch, c->frames, c->frame_stride, s0 + f0, sel, c->boxes_dev, p->dev, c->state_dev + f0);
+                else k_rmsd_finalize<0><<<dim3(nf), dim3(GR_WG), 0, S>>>(parts, nch, c->frames, c->frame_stride, s0 + f0, sel, c->boxes_dev, p->dev, c->state_dev + f0);
+                if (c->profile) EVREC(c, c->pev[6 * g + 3], true, S);
             }
-            return GR_OK;
-        };
-        auto launch_close = [&](uint32_t g, hipStream_t on) -> int {
-            if (!lite) return GR_OK;
-            const uint32_t f0 = g * sb, nf = group_nf(g), gx = fit_grid(c, nf);
-            k_rmsd_close<<<dim3(nf), dim3(64), 0, on>>>(c->fit_partials + (size_t)f0 * gx, gx, p->dev.sw, c->state_dev + f0);
-            return GR_OK;
-        };
-        hipStream_t S = c->stream, B = c->stream2;
-        if (fit && !two && c->skew && n_groups > 1) {
-            // Skewed order (GR_SKEW=1, off by default).  The two small kernels of a group (finalize: one workgroup per
-            // frame, ~17 us; close: one wave per frame) leave the chip idle when they sit between the big ones on one
-            // stream.  Here they run on the second stream BESIDE the next group's sums pass, and the fit of group g follows
-            // the sums of group g + 1.  Measured: the finalize kernel then starves behind the sums pass's workgroups
-            // (17 -> 100-200 us per launch, even on a high-priority stream) and delays the fit: 130 k vs 134 k frames/s.
-            //   S: sums(0) sums(1) fit(0) sums(2) fit(1) ...            B: fin(0) fin(1) close(0) fin(2) close(1) ...
-            for (uint32_t g = 0; g < n_groups; ++g) {
-                st = launch_sums(g, S); if (st) return st;
-                EVREC(c, c->ev_skew[3 * g], false, S);
-                HIPCHK(c, hipStreamWaitEvent(B, c->ev_skew[3 * g], 0));
-                st = launch_finalize(g, B); if (st) return st;
-                EVREC(c, c->ev_skew[3 * g + 1], false, B);
-                if (g > 0) {
-                    HIPCHK(c, hipStreamWaitEvent(S, c->ev_skew[3 * (g - 1) + 1], 0));
-                    st = launch_fit(g - 1, S); if (st) return st;
-                    EVREC(c, c->ev_skew[3 * (g - 1) + 2], false, S);
-                    HIPCHK(c, hipStreamWaitEvent(B, c->ev_skew[3 * (g - 1) + 2], 0));
-                    st = launch_close(g - 1, B); if (st) return st;
-                }
-            }
-            const uint32_t g = n_groups - 1;
-            HIPCHK(c, hipStreamWaitEvent(S, c->ev_skew[3 * g + 1], 0));
-            st = launch_fit(g, S); if (st) return st;
-            EVREC(c, c->ev_skew[3 * g + 2], false, S);
-            HIPCHK(c, hipStreamWaitEvent(B, c->ev_skew[3 * g + 2], 0));
-            st = launch_close(g, B); if (st) return st;
-            HIPCHK(c, hipEventRecord(c->ev_join, B));
-            HIPCHK(c, hipStreamWaitEvent(S, c->ev_join, 0));
-        } else {
-            for (uint32_t g = 0; g < n_groups; ++g) {
-                st = launch_sums(g, S); if (st) return st;
-                st = launch_finalize(g, S); if (st) return st;
-                if (fit) {
-                    hipStream_t fs = S;
-                    if (two) {   // GR_OVERLAP=1: the whole fit of group g beside the sums of group g + 1
-                        EVREC(c, c->ev_grp[g], false, S);
-                        HIPCHK(c, hipStreamWaitEvent(B, c->ev_grp[g], 0));
-                        fs = B;
-                    }
-                    st = launch_fit(g, fs); if (st) return st;
-                    st = launch_close(g, fs); if (st) return st;
-                }
-            }
-            if (two) {   // join: the state fetch (and the caller) must see every fit finished
-                HIPCHK(c, hipEventRecord(c->ev_join, B));
-                HIPCHK(c, hipStreamWaitEvent(S, c->ev_join, 0));
+            if (fit) {
+                if (c->profile) EVREC(c, c->pev[6 * g + 4], true, S);
+                // (closing the rmsd on the tail of this kernel makes every one of its 62 k workgroups drain its stores: 3x slower)
+                if (lite) k_fit_pk<true><<<dim3(gx, nf), dim3(GR_WG), 0, S>>>(c->frames, c->frame_stride, s0 + f0, (uint32_t)c->n, c->boxes_dev, p->dev, c->state_dev + f0, c->masses, sel, c->fit_partials + (size_t)f0 * gx);
+                else k_fit_pk<false><<<dim3(gx, nf), dim3(GR_WG), 0, S>>>(c->frames, c->frame_stride, s0 + f0, (uint32_t)c->n, c->boxes_dev, p->dev, c->state_dev + f0, c->masses, sel, nullptr);
+                if (c->profile) EVREC(c, c->pev[6 * g + 5], true, S);
+                if (lite) k_rmsd_close<<<dim3(nf), dim3(64), 0, S>>>(c->fit_partials + (size_t)f0 * gx, gx, p->dev.sw, c->state_dev + f0);
             }
         }
-        ng = n_groups;
-        q.prof_two = two;
         HIPCHK(c, hipGetLastError());
-        if (c->profile) q.n_prof_groups = ng;
+        if (c->profile) q.n_prof_groups = n_groups;
     }
     HIPCHK(c, hipMemcpyAsync(c->state_host, c->state_dev, nb * sizeof(GrFrameState), hipMemcpyDeviceToHost, c->stream));
     return GR_OK;
@@ -1550,39 +1430,15 @@ static int segment_end(gr_rmsd_plan *p, float *rmsd_out, int *status_out, float 
         if (!q.has_group) return fail(c, GR_E_INVALID_ARG, "batch state lost");
         const GrSel sel = q.sel;
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        if (q.persist) {
-            if (c->ps_trace) {
-                const size_t cnt = (size_t)nb * c->n_cus * GR_PS_TRACE_N;
-                std::vector<unsigned long long> h(cnt);
-                HIPCHK(c, hipMemcpy(h.data(), c->ps_trace, cnt * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-                if (FILE *fp = fopen(c->ps_trace_path.c_str(), "wb")) {
-                    const unsigned long long hdr[4] = { nb, c->n_cus, GR_PS_TRACE_N, 0 };
-                    fwrite(hdr, sizeof(hdr), 1, fp); fwrite(h.data(), sizeof(unsigned long long), cnt, fp); fclose(fp);
-                }
-            }
-            if (c->ps_sync_host[1] != 0) return fail(c, GR_E_HIP, "persistent RMSD-fit kernel timed out waiting for its workgroups (GPU shared with another process?); set GR_PERSIST=0");
-            if (c->profile) {
-                float ms = 0.f;
-                HIPCHK(c, hipEventElapsedTime(&ms, c->pev[0], c->pev[1]));
-                c->prof_ms[3] += ms; c->prof_launches[3] += 1; c->prof_frames[3] += nb;
-            }
-        }
         for (uint32_t gi = 0; gi < q.n_prof_groups; ++gi) {   // the stream is idle here: read this segment's event pairs
-            const int nk = 2;
             const uint32_t nf = std::min<uint32_t>(c->sub_batch, nb - gi * c->sub_batch);
-            for (int k = 0; k < nk; ++k) {
-                if (k == 1 && q.fused) continue;   // no finalize launch: the sums kernel closed the frames
+            for (int k = 0; k < 3; ++k) {     // 0 sums, 1 finalize (separate launch only when not fused), 2 fit
+                if ((k == 1 && q.fused) || (k == 2 && !fit)) continue;
                 float ms = 0.f;
                 HIPCHK(c, hipEventElapsedTime(&ms, c->pev[6 * gi + 2 * k], c->pev[6 * gi + 2 * k + 1]));
                 c->prof_ms[k] += ms; c->prof_launches[k] += 1; c->prof_frames[k] += nf;
             }
         }
-        for (size_t h = 0; h < q.fit_launch_frames.size(); ++h) {
-            float ms = 0.f;
-            HIPCHK(c, hipEventElapsedTime(&ms, c->pev_fit[2 * h], c->pev_fit[2 * h + 1]));
-            c->prof_ms[2] += ms; c->prof_launches[2] += 1; c->prof_frames[2] += q.fit_launch_frames[h];
-        }
-        q.fit_launch_frames.clear();
         std::vector<GrFrameState> res(c->state_host, c->state_host + nb);
         // frames whose single-pass image proof failed are redone on the exact path, one by one
         for (uint32_t f = 0; f < nb; ++f) {
@@ -1935,7 +1791,6 @@ __global__ __launch_bounds__(256) void k_trr_unpack(const unsigned char *__restr
                                                     float *__restrict__ frames, size_t frame_stride, const uint32_t *__restrict__ slots, uint32_t n_atoms) {
     const uint32_t k = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_atoms) return;
-    float *dst = frames + (size_t)slots[k] * frame_stride + 3 * (size_t)i;
     const uint64_t so = sec_off[k];
     float v[3] = { 0.f, 0.f, 0.f };
     if (so != ~0ull) {
@@ -1947,7 +1802,7 @@ __global__ __launch_bounds__(256) void k_trr_unpack(const unsigned char *__restr
         }
     }
     if (v[0] == 0.0f && v[1] == 0.0f && v[2] == 0.0f) v[0] = __uint_as_float(0x7fc00000u);
-    dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2];
+    gr_pos_store(frames + (size_t)slots[k] * frame_stride, i, v[0], v[1], v[2]);
 }
 
 int gr_trr_read_frames_device(const gr_trr *t, uint64_t first_frame, uint32_t n_frames, uint64_t frame_step, gr_ctx *c, uint32_t first_slot,
@@ -2167,7 +2022,9 @@ int gr_xtc_write_slots(gr_xtc_writer *w, gr_ctx *c, uint32_t first_slot, uint32_
     {
         SlotUse use(c, first_slot, n_frames);
         for (uint32_t k = 0; k < n_frames; ++k) {
-            hipError_t e = hipMemcpyAsync(host + (size_t)k * c->n * 3, c->frames + (size_t)(first_slot + k) * c->frame_stride, fb, hipMemcpyDeviceToHost, c->stream);
+            // slot -> packed records (k_untile) -> pinned host, in stream order: the one staging buffer is rewritten only after its copy
+            hipError_t e = untile_slot(c, first_slot + k) == GR_OK ? hipSuccess : hipErrorUnknown;
+            if (e == hipSuccess) e = hipMemcpyAsync(host + (size_t)k * c->n * 3, c->aos_dl, fb, hipMemcpyDeviceToHost, c->stream);
             if (e == hipSuccess) e = hipEventCreateWithFlags(&ev[k], hipEventDisableTiming);
             if (e == hipSuccess) e = hipEventRecord(ev[k], c->stream);
             if (e != hipSuccess) { for (auto x : ev) if (x) (void)hipEventDestroy(x); c->err = hipGetErrorString(e); return GR_E_HIP; }
@@ -2242,7 +2099,7 @@ int gr_profile_enable(gr_ctx *c, int on) try {
     return GR_OK;
 } catch (...) { return gr_abi_guard(); }
 int gr_profile_read(const gr_ctx *c, int kernel, double *ms_total, uint64_t *launches, uint64_t *frames) try {
-    if (!c || kernel < 0 || kernel > 3) return GR_E_INVALID_ARG;
+    if (!c || kernel < 0 || kernel > 2) return GR_E_INVALID_ARG;
     if (ms_total) *ms_total = c->prof_ms[kernel];
     if (launches) *launches = c->prof_launches[kernel];
     if (frames) *frames = c->prof_frames[kernel];

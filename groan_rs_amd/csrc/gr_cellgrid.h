@@ -58,7 +58,8 @@ __global__ __launch_bounds__(256) void k_cg_assign(const float *__restrict__ xyz
     const uint32_t k = blockIdx.x * 256u + threadIdx.x;
     if (k >= sel.n) return;
     const uint32_t a = sel.contiguous ? sel.start + k : sel.idx[k];
-    const float x = xyz[3 * (size_t)a], y = xyz[3 * (size_t)a + 1], z = xyz[3 * (size_t)a + 2];
+    float x, y, z;
+    gr_pos_load(xyz, a, x, y, z);
     uint32_t c[3] = { 0, 0, 0 };
     if (x != x) atomicMin(bad, k);                              // ordinal of the first atom without position (group order)
     else gr_cg_cell_of(x, y, z, box, g, c);
@@ -84,7 +85,8 @@ __global__ __launch_bounds__(256) void k_cg_pairs(const float *__restrict__ xyz,
     const uint32_t k = blockIdx.x * 256u + threadIdx.x;
     if (k >= s1.n) return;
     const uint32_t i = s1.contiguous ? s1.start + k : s1.idx[k];
-    const float x = xyz[3 * (size_t)i], y = xyz[3 * (size_t)i + 1], z = xyz[3 * (size_t)i + 2];
+    float x, y, z;
+    gr_pos_load(xyz, i, x, y, z);
     if (x != x) { if (!WRITE) { atomicMin(bad + 1, k); counts[k] = 0; } return; }
     uint32_t c[3];
     gr_cg_cell_of(x, y, z, box, g, c);
@@ -103,7 +105,8 @@ __global__ __launch_bounds__(256) void k_cg_pairs(const float *__restrict__ xyz,
                 for (uint32_t q = starts[cell]; q < starts[cell + 1]; ++q) {
                     const uint32_t j = sorted_atoms[q];
                     if (j == i) continue;                                                     // hbonds.rs:250
-                    const float jx = xyz[3 * (size_t)j], jy = xyz[3 * (size_t)j + 1], jz = xyz[3 * (size_t)j + 2];
+                    float jx, jy, jz;
+                    gr_pos_load(xyz, j, jx, jy, jz);
                     const float d = gr_distance<4, true>(jx, jy, jz, x, y, z, 7, box);              // acceptor.distance(donor), :261
                     if (d > cutoff) continue;                                                 // :262-264
                     if (WRITE && base + n < cap) { out_i[base + n] = i; out_j[base + n] = j; out_d[base + n] = d; }

@@ -1,0 +1,331 @@
+// gr_hot.h -- the two kernels of the RMSD-fit hot path (contiguous selection):
+//
+//   k_sums_pk<NOREF>   pass 1 over the group: sum m, sum m v, A = sum p v^T (rmsd.rs:567-570), fractional moments + extents for
+//                      the image proof; the workgroup that completes a frame closes it (rotation, shift)
+//   k_fit_pk<RMSD>     pass 2 over all atoms: z = R (wrap(x + shift) - box centre) + reference COM and, for the group,
+//                      sum w |R q - p|^2 (rmsd.rs:508-528,592-599)
+//
+// Round 1 measured both passes co-limited by VALU issue (65 and 94 VALU instructions per atom, rocprofv3 SQ_INSTS_VALU) and
+// by the access pattern of the packed xyz records.  Here
+//   * slots and plans are pair-tiled (gr_layout.h): a lane's 4 atoms arrive as three fully coalesced 16-byte loads -- one
+//     element per lane and instruction, the shape that streams fastest on this chip -- and every register pair a lane receives
+//     is (coordinate of atom a, same coordinate of atom a + 1): no LDS, no transposes, no register shuffles;
+//   * every add / multiply / fma of the per-atom arithmetic is one v_pk_*_f32 for two atoms (gfx950 issues packed f32 at
+//     full rate); only rint / floor and the min / max chains stay scalar, and those take two atoms per v_min3 / v_max3;
+//   * the box is read through a uniform pointer: scalar loads, every box constant is an SGPR operand (no LDS staging, no barrier);
+//   * the fit's wrap is the one-turn closed form k = floor(t / L) per axis (c, then b, then a) with ONE wave-wide check that
+//     every result lies in (0, L]; a wave with an atom on a face, more than one cell away, or without position redoes its
+//     atoms with the general wrap (gr_wrap: bit-identical to the reference's loops) -- ~11 instead of ~66 instructions per atom;
+//   * interior trips carry no per-atom validity tests (a NaN poisons the sums, the closing step sends the frame to the
+//     multi-pass path, which names the atom); the two ragged ends of the selection are masked instead of branched on.
+// Reference arithmetic kept: rmsd.rs:562-599 (unweighted covariance, mass-weighted final sum), vector3d.rs:380-417 (wrap).
+#pragma once
+#include "gr_kernels.h"
+
+__device__ __forceinline__ gr_v2f gr_v2p(float lo, float hi) { gr_v2f r = { lo, hi }; return r; }
+__device__ __forceinline__ gr_v2f gr_v2_rint(gr_v2f a) { gr_v2f r = { rintf(a.x), rintf(a.y) }; return r; }
+__device__ __forceinline__ gr_v2f gr_v2_floor(gr_v2f a) { gr_v2f r = { floorf(a.x), floorf(a.y) }; return r; }
+__device__ __forceinline__ float gr_max3f(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+
+// box constants of one frame as wave-uniform values (SGPRs)
+struct GrBoxU {
+    float ax, by, cz, bx, cx, cy, bcx, bcy, bcz, iax, iby, icz, rws2;
+    bool tric;
+};
+__device__ __forceinline__ GrBoxU gr_box_uniform(const GrBox *__restrict__ b) {
+    GrBoxU u;
+    u.ax = b->ax; u.by = b->by; u.cz = b->cz; u.bx = b->bx; u.cx = b->cx; u.cy = b->cy;
+    u.bcx = b->bcx; u.bcy = b->bcy; u.bcz = b->bcz; u.iax = b->iax; u.iby = b->iby; u.icz = b->icz;
+    u.rws2 = b->r_ws * b->r_ws; u.tric = !b->ortho;
+    return u;
+}
+
+// the three rows of a 4-atom group (gr_layout.h) are pairs of atoms per coordinate already
+struct GrP4 { gr_v2f x01, y01, z01, x23, y23, z23; };
+__device__ __forceinline__ GrP4 gr_pairs_rows(const float4 &r0, const float4 &r1, const float4 &r2) {
+    GrP4 p;
+    p.x01 = gr_v2p(r0.x, r0.y); p.y01 = gr_v2p(r0.z, r0.w); p.z01 = gr_v2p(r1.x, r1.y);
+    p.x23 = gr_v2p(r1.z, r1.w); p.y23 = gr_v2p(r2.x, r2.y); p.z23 = gr_v2p(r2.z, r2.w);
+    return p;
+}
+__device__ __forceinline__ void gr_rows_pairs(const GrP4 &p, float4 &r0, float4 &r1, float4 &r2) {
+    r0 = make_float4(p.x01.x, p.x01.y, p.y01.x, p.y01.y); r1 = make_float4(p.z01.x, p.z01.y, p.x23.x, p.x23.y);
+    r2 = make_float4(p.y23.x, p.y23.y, p.z23.x, p.z23.y);
+}
+
+// ------------------------------------------------------------------------------------------ pass 1: sums
+// per-lane accumulators: every sum as a pair (even atoms, odd atoms), folded once after the loop
+struct GrSumsPk {
+    gr_v2f m, mx, my, mz;                 // sum m, sum m v
+    gr_v2f a[9];                          // A = sum p v^T (unweighted, rmsd.rs:567-570)
+    gr_v2f f1a, f1b, f1c, f2a, f2b, f2c;  // first / second moments of the fractional coordinates of v
+    float mn[3], mx3[3], fmn[3], fmx[3];  // Cartesian and fractional extents of v
+};
+
+// two atoms: v = image of (x - g) nearest to g, then every sum.  `p*` = reference coordinates (NOREF: unused), m = masses.
+template <bool NOREF>
+__device__ __forceinline__ void gr_sums_pair(GrSumsPk &S, gr_v2f x, gr_v2f y, gr_v2f z, gr_v2f px, gr_v2f py, gr_v2f pz, gr_v2f m,
+                                             const GrBoxU &B, const GrBox *__restrict__ boxp, float gx, float gy, float gz) {
+    gr_v2f vx = x - gr_v2(gx), vy = y - gr_v2(gy), vz = z - gr_v2(gz);
+    // closed-form brick reduction along c, b, a (gr_image_about)
+    gr_v2f k = gr_v2_rint(vz * gr_v2(B.icz));
+    vx = gr_v2_fma(-k, gr_v2(B.cx), vx); vy = gr_v2_fma(-k, gr_v2(B.cy), vy); vz = gr_v2_fma(-k, gr_v2(B.cz), vz);
+    k = gr_v2_rint(vy * gr_v2(B.iby));
+    vx = gr_v2_fma(-k, gr_v2(B.bx), vx); vy = gr_v2_fma(-k, gr_v2(B.by), vy);
+    k = gr_v2_rint(vx * gr_v2(B.iax));
+    vx = gr_v2_fma(-k, gr_v2(B.ax), vx);
+    if (B.tric) {
+        // already THE minimum image whenever |v| < r_ws; otherwise search the image table (rare: wave-uniform branch)
+        const gr_v2f r2 = gr_v2_fma(vx, vx, gr_v2_fma(vy, vy, vz * vz));
+        if (__builtin_amdgcn_ballot_w64(!(gr_fmaxf(r2.x, r2.y) < B.rws2)) != 0ull) {
+            if (!(r2.x < B.rws2)) { float a = vx.x, b = vy.x, c = vz.x; gr_tric_refine(a, b, c, *boxp); vx.x = a; vy.x = b; vz.x = c; }
+            if (!(r2.y < B.rws2)) { float a = vx.y, b = vy.y, c = vz.y; gr_tric_refine(a, b, c, *boxp); vx.y = a; vy.y = b; vz.y = c; }
+        }
+    }
+    // fractional coordinates of v: moments + extents feed the image proof (gr_finalize_math)
+    const gr_v2f fc = vz * gr_v2(B.icz);
+    const gr_v2f fb = gr_v2_fma(-fc, gr_v2(B.cy), vy) * gr_v2(B.iby);
+    const gr_v2f fa = gr_v2_fma(-fc, gr_v2(B.cx), gr_v2_fma(-fb, gr_v2(B.bx), vx)) * gr_v2(B.iax);
+    S.f1a += fa; S.f1b += fb; S.f1c += fc;
+    S.f2a = gr_v2_fma(fa, fa, S.f2a); S.f2b = gr_v2_fma(fb, fb, S.f2b); S.f2c = gr_v2_fma(fc, fc, S.f2c);
+    S.fmn[0] = gr_min3f(S.fmn[0], fa.x, fa.y); S.fmn[1] = gr_min3f(S.fmn[1], fb.x, fb.y); S.fmn[2] = gr_min3f(S.fmn[2], fc.x, fc.y);
+    S.fmx[0] = gr_max3f(S.fmx[0], fa.x, fa.y); S.fmx[1] = gr_max3f(S.fmx[1], fb.x, fb.y); S.fmx[2] = gr_max3f(S.fmx[2], fc.x, fc.y);
+    S.mn[0] = gr_min3f(S.mn[0], vx.x, vx.y); S.mn[1] = gr_min3f(S.mn[1], vy.x, vy.y); S.mn[2] = gr_min3f(S.mn[2], vz.x, vz.y);
+    S.mx3[0] = gr_max3f(S.mx3[0], vx.x, vx.y); S.mx3[1] = gr_max3f(S.mx3[1], vy.x, vy.y); S.mx3[2] = gr_max3f(S.mx3[2], vz.x, vz.y);
+    S.m += m;
+    S.mx = gr_v2_fma(m, vx, S.mx); S.my = gr_v2_fma(m, vy, S.my); S.mz = gr_v2_fma(m, vz, S.mz);
+    if (!NOREF) {
+        S.a[0] = gr_v2_fma(px, vx, S.a[0]); S.a[1] = gr_v2_fma(px, vy, S.a[1]); S.a[2] = gr_v2_fma(px, vz, S.a[2]);
+        S.a[3] = gr_v2_fma(py, vx, S.a[3]); S.a[4] = gr_v2_fma(py, vy, S.a[4]); S.a[5] = gr_v2_fma(py, vz, S.a[5]);
+        S.a[6] = gr_v2_fma(pz, vx, S.a[6]); S.a[7] = gr_v2_fma(pz, vy, S.a[7]); S.a[8] = gr_v2_fma(pz, vz, S.a[8]);
+    }
+}
+
+// Same contract as k_rmsd_accum<0, true, NOREF> for a CONTIGUOUS selection (the caller checks): partial record per workgroup
+// in `partials`, optional fused closing of the frame through `fuse` / `state_out` (see k_rmsd_accum).
+template <bool NOREF = false>
+__global__ __launch_bounds__(GR_WG) void k_sums_pk(
+    const float *__restrict__ frames, size_t frame_stride, uint32_t first_slot,
+    const float *__restrict__ masses, GrSel sel, const GrBox *__restrict__ boxes,
+    GrPlanDev plan, GrAccPartial *partials, uint32_t *fuse, GrFrameState *state_out) {
+    __shared__ double lds[(GR_WG / 64) * GR_ACC_K];
+    const uint32_t frame = blockIdx.y, chunk = blockIdx.x, nchunks = gridDim.x;
+    const float *xyz = frames + (size_t)(first_slot + frame) * frame_stride;
+    const GrBox *boxp = boxes + first_slot + frame;
+    const GrBoxU B = gr_box_uniform(boxp);
+    const bool wm = plan.w_is_mass != 0;     // NOREF: "weighted"
+    float gx, gy, gz;                         // provisional centre: the first atom of the selection
+    gr_pos_load(xyz, sel.start, gx, gy, gz);
+    GrSumsPk S;
+    S.m = S.mx = S.my = S.mz = gr_v2(0.0f);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) S.a[k] = gr_v2(0.0f);
+    S.f1a = S.f1b = S.f1c = S.f2a = S.f2b = S.f2c = gr_v2(0.0f);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { S.mn[a] = S.fmn[a] = 3.0e38f; S.mx3[a] = S.fmx[a] = -3.0e38f; }
+
+    const uint32_t first = sel.start, last = sel.start + sel.n;
+    const uint32_t g0 = sel.g0 << 6, g1 = (last + 3u) >> 2;      // float4 groups [g0, g1): g0 = first group of the first tile
+    const float4 *f4 = reinterpret_cast<const float4 *>(xyz);
+    const float4 *p4 = reinterpret_cast<const float4 *>(plan.p);
+    const float4 *m4 = reinterpret_cast<const float4 *>(masses);
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // software pipeline of depth one: the rows of trip k + 1 are requested before the arithmetic of trip k and waited for after
+    // it (measured at 1e6 atoms, 256 frames per launch: 1.7 us per frame with the prefetch, 2.3 without -- with ~40 VALU
+    // instructions per atom the loop no longer hides its own load latency behind issue slots at 4 waves per SIMD)
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f), one4 = make_float4(1.f, 1.f, 1.f, 1.f);
+    float4 r0 = zero4, r1 = zero4, r2 = zero4, q0 = zero4, q1 = zero4, q2 = zero4, mm = one4;
+    auto request = [&](uint32_t gg, float4 &a0, float4 &a1, float4 &a2, float4 &b0, float4 &b1, float4 &b2, float4 &m) {
+        gr_rows_load<true>(f4, gg, a0, a1, a2);
+        if (!NOREF) gr_rows_load(p4, (size_t)(gg - g0), b0, b1, b2);
+        if (!(NOREF && !wm)) m = m4[gg];
+    };
+    uint32_t g = g0 + chunk * GR_WG + threadIdx.x;
+    if (g < g1) request(g, r0, r1, r2, q0, q1, q2, mm);
+    while (g < g1) {
+        const uint32_t gn = g + nchunks * GR_WG;
+        float4 n0 = zero4, n1 = zero4, n2 = zero4, nq0 = zero4, nq1 = zero4, nq2 = zero4, nm = one4;
+        if (gn < g1) request(gn, n0, n1, n2, nq0, nq1, nq2, nm);
+        GrP4 q = gr_pairs_rows(r0, r1, r2), p;
+        if (!NOREF) p = gr_pairs_rows(q0, q1, q2); else p.x01 = p.y01 = p.z01 = p.x23 = p.y23 = p.z23 = gr_v2(0.0f);
+        const uint32_t i = g << 2;
+        if (!(i >= first && i + 3 < last)) {
+            // a ragged end of the selection: atoms outside it become copies of the first atom with zero mass and zero
+            // reference coordinates -- v = 0 adds nothing to any sum and lies inside every extent (the first atom's own v is 0)
+            if (!(i >= first && i < last)) { q.x01.x = gx; q.y01.x = gy; q.z01.x = gz; mm.x = 0.f; p.x01.x = p.y01.x = p.z01.x = 0.f; }
+            if (!(i + 1 >= first && i + 1 < last)) { q.x01.y = gx; q.y01.y = gy; q.z01.y = gz; mm.y = 0.f; p.x01.y = p.y01.y = p.z01.y = 0.f; }
+            if (!(i + 2 >= first && i + 2 < last)) { q.x23.x = gx; q.y23.x = gy; q.z23.x = gz; mm.z = 0.f; p.x23.x = p.y23.x = p.z23.x = 0.f; }
+            if (!(i + 3 >= first && i + 3 < last)) { q.x23.y = gx; q.y23.y = gy; q.z23.y = gz; mm.w = 0.f; p.x23.y = p.y23.y = p.z23.y = 0.f; }
+        }
+        gr_sums_pair<NOREF>(S, q.x01, q.y01, q.z01, p.x01, p.y01, p.z01, gr_v2p(mm.x, mm.y), B, boxp, gx, gy, gz);
+        gr_sums_pair<NOREF>(S, q.x23, q.y23, q.z23, p.x23, p.y23, p.z23, gr_v2p(mm.z, mm.w), B, boxp, gx, gy, gz);
+        g = gn;
+        r0 = n0; r1 = n1; r2 = n2; q0 = nq0; q1 = nq1; q2 = nq2; mm = nm;
+    }
+    // epilogue (as k_rmsd_accum's LITE epilogue): every wave reduce-scatters its 19 sums and 12 extents, the four waves
+    // meet in LDS once, and 33 lanes of wave 0 write the record
+    float s32[32], e32[32];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) { s32[k] = 0.0f; e32[k] = -3.0e38f; }
+    s32[0] = S.m.x + S.m.y; s32[1] = S.mx.x + S.mx.y; s32[2] = S.my.x + S.my.y; s32[3] = S.mz.x + S.mz.y;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) s32[4 + k] = S.a[k].x + S.a[k].y;
+    s32[13] = S.f1a.x + S.f1a.y; s32[14] = S.f1b.x + S.f1b.y; s32[15] = S.f1c.x + S.f1c.y;
+    s32[16] = S.f2a.x + S.f2a.y; s32[17] = S.f2b.x + S.f2b.y; s32[18] = S.f2c.x + S.f2c.y;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { e32[k] = -S.mn[k]; e32[3 + k] = S.mx3[k]; e32[6 + k] = -S.fmn[k]; e32[9 + k] = S.fmx[k]; }
+    const float tot = gr_wave_sum_scatter32(s32, lane);
+    const float emax = gr_wave_max_scatter16(e32, lane);
+    float *wsum = reinterpret_cast<float *>(lds);            // [4 waves][32 sums | 16 maxima]
+    if ((lane & 1u) == 0) wsum[wave * 48 + (lane >> 1)] = tot;
+    if ((lane & 3u) == 0) wsum[wave * 48 + 32 + (lane >> 2)] = emax;
+    __syncthreads();
+    if (wave != 0) return;
+    GrAccPartial &o = partials[(size_t)frame * nchunks + chunk];
+    if (lane < 19) {
+        const double v = (double)wsum[lane] + (double)wsum[48 + lane] + (double)wsum[96 + lane] + (double)wsum[144 + lane];
+        gr_st_agent(&o.s[lane < 13 ? lane : 13 + lane], v);           // sums 13..18 are the moments: record slots 26..31
+    } else if (lane < 32) {
+        gr_st_agent(&o.s[lane - 6], 0.0);                             // slots 13..25 are not used by the two-pass sums
+    } else if (lane < 44) {
+        const uint32_t q = lane - 32;
+        const float m = gr_fmaxf(gr_fmaxf(wsum[32 + q], wsum[48 + 32 + q]), gr_fmaxf(wsum[96 + 32 + q], wsum[144 + 32 + q]));
+        if (q < 3) gr_st_agent(&o.vmin[q], -m); else if (q < 6) gr_st_agent(&o.vmax[q - 3], m); else if (q < 9) gr_st_agent(&o.fmin[q - 6], -m); else gr_st_agent(&o.fmax[q - 9], m);
+    } else if (lane == 44) {
+        gr_st_agent(&o.bad_pos, GR_NOIDX);      // no per-atom tests here: a missing position / mass shows up as a NaN sum
+        gr_st_agent(&o.bad_mass, GR_NOIDX);
+    }
+    if (fuse) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // every lane's record stores have left
+        uint32_t old = 0;
+        if (lane == 0) old = __hip_atomic_fetch_add(fuse + frame, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__builtin_amdgcn_readfirstlane(old) == nchunks - 1) {     // this frame's records are complete: close it
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            double *totd = lds;                                       // wsum (same LDS) has been consumed by this wave
+            float *ext = reinterpret_cast<float *>(lds + 32);
+            gr_finalize_frame_lite<NOREF>(partials, nchunks, frame, frames, frame_stride, first_slot, sel, boxes, plan, state_out, totd, ext, lane);
+            if (lane == 0) fuse[frame] = 0u;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ pass 2: fit
+// one-turn wrap of two atoms along c, b, a: k = floor(t / L) per stage; `lo` / `hi` collect the smallest and largest
+// result per axis so that ONE test per tile decides whether every result landed in (0, L]
+__device__ __forceinline__ void gr_wrap_pair_fast(gr_v2f &x, gr_v2f &y, gr_v2f &z, const GrBoxU &B) {
+    gr_v2f k = gr_v2_floor(z * gr_v2(B.icz));
+    x = gr_v2_fma(-k, gr_v2(B.cx), x); y = gr_v2_fma(-k, gr_v2(B.cy), y); z = gr_v2_fma(-k, gr_v2(B.cz), z);
+    k = gr_v2_floor(y * gr_v2(B.iby));
+    x = gr_v2_fma(-k, gr_v2(B.bx), x); y = gr_v2_fma(-k, gr_v2(B.by), y);
+    k = gr_v2_floor(x * gr_v2(B.iax));
+    x = gr_v2_fma(-k, gr_v2(B.ax), x);
+}
+
+// A wave owns ONE group row set per trip and, at the default grid (one 256-atom tile per wave), one trip: whatever a wave
+// waits for in sequence is exposed, so the tile and -- for the rmsd -- the reference coordinates and weights of the tile are
+// requested first (they depend on the kernel arguments only), then the frame state and the box (dependent scalar loads).
+template <bool RMSD>
+__global__ __launch_bounds__(GR_WG) void k_fit_pk(
+    float *__restrict__ frames, size_t frame_stride, uint32_t first_slot, uint32_t n_atoms,
+    const GrBox *__restrict__ boxes, GrPlanDev plan, const GrFrameState *__restrict__ state,
+    const float *__restrict__ masses, GrSel sel, double *fit_partials) {
+    __shared__ double lds[GR_WG / 64];
+    const uint32_t frame = blockIdx.y;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float *xyz = frames + (size_t)(first_slot + frame) * frame_stride;
+    float4 *f4 = reinterpret_cast<float4 *>(xyz);
+    const float4 *p4 = reinterpret_cast<const float4 *>(plan.p);
+    const float4 *w4 = plan.w_is_mass ? reinterpret_cast<const float4 *>(masses) : reinterpret_cast<const float4 *>(plan.w);
+    const uint32_t first = sel.start, last = sel.start + sel.n, g0 = sel.g0 << 6;
+    const uint32_t wofs = plan.w_is_mass ? 0u : g0;        // masses are indexed by atom group, plan.w by selection group
+    const uint32_t ngroups = ((n_atoms + 255u) >> 8) << 6;   // the slot is padded to whole tiles; pad atoms are transformed too (harmless)
+    const uint32_t gstep = gridDim.x * GR_WG;
+    uint32_t g = blockIdx.x * GR_WG + threadIdx.x;
+    if (g >= ngroups && !RMSD) return;
+    float4 r0, r1, r2, pa, pb, pc, ww;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    r0 = r1 = r2 = pa = pb = pc = ww = zero4;
+    bool in_sel = false;
+    auto request = [&](uint32_t gg) {
+        gr_rows_load<true>(f4, gg, r0, r1, r2);   // non-temporal loads AND stores measured best (4.28 us/frame; plain loads 4.6, plain stores 4.5)
+        if (RMSD) {
+            const uint32_t i = gg << 2;
+            in_sel = (i + 3 >= first) && (i < last);
+            if (in_sel) { gr_rows_load(p4, (size_t)(gg - g0), pa, pb, pc); ww = w4[gg - wofs]; }
+        }
+    };
+    if (g < ngroups) request(g);
+    const GrFrameState &st = state[frame];
+    const GrBox *boxp = boxes + first_slot + frame;
+    const GrBoxU B = gr_box_uniform(boxp);
+    const float sx = st.shift[0], sy = st.shift[1], sz = st.shift[2];
+    const float r00 = st.R[0], r10 = st.R[1], r20 = st.R[2], r01 = st.R[3], r11 = st.R[4], r21 = st.R[5], r02 = st.R[6], r12 = st.R[7], r22 = st.R[8];
+    const float cx = plan.ref_com[0], cy = plan.ref_com[1], cz = plan.ref_com[2];
+    if (st.status != 0) return;   // analysis failed -> frame left unmodified (rmsd.rs:91)
+    double rs = 0.0;
+    while (g < ngroups) {
+        GrP4 q = gr_pairs_rows(r0, r1, r2);
+        q.x01 += gr_v2(sx); q.y01 += gr_v2(sy); q.z01 += gr_v2(sz); q.x23 += gr_v2(sx); q.y23 += gr_v2(sy); q.z23 += gr_v2(sz);
+        gr_wrap_pair_fast(q.x01, q.y01, q.z01, B);
+        gr_wrap_pair_fast(q.x23, q.y23, q.z23, B);
+        {
+            // every wrapped coordinate in (0, L]?  (NaN fails; an atom exactly on a face, or whose k came out one off by the
+            // rounding of t * (1/L), fails too) -- otherwise the wave redoes its atoms with the general wrap
+            const float xl = gr_fminf(gr_min3f(q.x01.x, q.x01.y, q.x23.x), q.x23.y), xh = gr_fmaxf(gr_max3f(q.x01.x, q.x01.y, q.x23.x), q.x23.y);
+            const float yl = gr_fminf(gr_min3f(q.y01.x, q.y01.y, q.y23.x), q.y23.y), yh = gr_fmaxf(gr_max3f(q.y01.x, q.y01.y, q.y23.x), q.y23.y);
+            const float zl = gr_fminf(gr_min3f(q.z01.x, q.z01.y, q.z23.x), q.z23.y), zh = gr_fmaxf(gr_max3f(q.z01.x, q.z01.y, q.z23.x), q.z23.y);
+            const bool ok = (xl > 0.0f) & (xh <= B.ax) & (yl > 0.0f) & (yh <= B.by) & (zl > 0.0f) & (zh <= B.cz);
+            if (__builtin_amdgcn_ballot_w64(!ok) != 0ull) {
+                float x[4], y[4], z[4];
+                gr_rows_unpack(r0, r1, r2, x, y, z);
+                float x0 = x[0] + sx, y0 = y[0] + sy, z0 = z[0] + sz, x1 = x[1] + sx, y1 = y[1] + sy, z1 = z[1] + sz;
+                float x2 = x[2] + sx, y2 = y[2] + sy, z2 = z[2] + sz, x3 = x[3] + sx, y3 = y[3] + sy, z3 = z[3] + sz;
+                gr_wrap(x0, y0, z0, *boxp); gr_wrap(x1, y1, z1, *boxp); gr_wrap(x2, y2, z2, *boxp); gr_wrap(x3, y3, z3, *boxp);
+                q.x01 = gr_v2p(x0, x1); q.x23 = gr_v2p(x2, x3); q.y01 = gr_v2p(y0, y1); q.y23 = gr_v2p(y2, y3); q.z01 = gr_v2p(z0, z1); q.z23 = gr_v2p(z2, z3);
+            }
+        }
+        // q = wrap(x + shift) - box centre; R q
+        q.x01 -= gr_v2(B.bcx); q.y01 -= gr_v2(B.bcy); q.z01 -= gr_v2(B.bcz); q.x23 -= gr_v2(B.bcx); q.y23 -= gr_v2(B.bcy); q.z23 -= gr_v2(B.bcz);
+        GrP4 n;
+        n.x01 = gr_v2_fma(gr_v2(r02), q.z01, gr_v2_fma(gr_v2(r01), q.y01, gr_v2(r00) * q.x01));
+        n.y01 = gr_v2_fma(gr_v2(r12), q.z01, gr_v2_fma(gr_v2(r11), q.y01, gr_v2(r10) * q.x01));
+        n.z01 = gr_v2_fma(gr_v2(r22), q.z01, gr_v2_fma(gr_v2(r21), q.y01, gr_v2(r20) * q.x01));
+        n.x23 = gr_v2_fma(gr_v2(r02), q.z23, gr_v2_fma(gr_v2(r01), q.y23, gr_v2(r00) * q.x23));
+        n.y23 = gr_v2_fma(gr_v2(r12), q.z23, gr_v2_fma(gr_v2(r11), q.y23, gr_v2(r10) * q.x23));
+        n.z23 = gr_v2_fma(gr_v2(r22), q.z23, gr_v2_fma(gr_v2(r21), q.y23, gr_v2(r20) * q.x23));
+        if (RMSD && in_sel) {
+            const uint32_t i = g << 2;
+            const GrP4 p = gr_pairs_rows(pa, pb, pc);
+            if (!(i >= first && i + 3 < last)) {   // ragged end: atoms outside the selection weigh nothing
+                if (!(i >= first && i < last)) ww.x = 0.f;
+                if (!(i + 1 >= first && i + 1 < last)) ww.y = 0.f;
+                if (!(i + 2 >= first && i + 2 < last)) ww.z = 0.f;
+                if (!(i + 3 >= first && i + 3 < last)) ww.w = 0.f;
+            }
+            // sum w |R q - p|^2 (rmsd.rs:592-599): two atoms per packed operation, 4-atom f32 partial -> fp64 per lane
+            gr_v2f dx = n.x01 - p.x01, dy = n.y01 - p.y01, dz = n.z01 - p.z01;
+            gr_v2f part = gr_v2p(ww.x, ww.y) * gr_v2_fma(dx, dx, gr_v2_fma(dy, dy, dz * dz));
+            dx = n.x23 - p.x23; dy = n.y23 - p.y23; dz = n.z23 - p.z23;
+            part = gr_v2_fma(gr_v2p(ww.z, ww.w), gr_v2_fma(dx, dx, gr_v2_fma(dy, dy, dz * dz)), part);
+            rs += (double)(part.x + part.y);
+        }
+        n.x01 += gr_v2(cx); n.y01 += gr_v2(cy); n.z01 += gr_v2(cz); n.x23 += gr_v2(cx); n.y23 += gr_v2(cy); n.z23 += gr_v2(cz);
+        float4 o0, o1, o2;
+        gr_rows_pairs(n, o0, o1, o2);
+        gr_rows_store<true>(f4, g, o0, o1, o2);
+        g += gstep;
+        if (g < ngroups) request(g);
+    }
+    if (RMSD) {
+        rs = gr_wave_sum(rs);
+        if (lane == 0) lds[wave] = rs;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double tot = 0.0;
+#pragma unroll
+            for (int k = 0; k < GR_WG / 64; ++k) tot += lds[k];
+            fit_partials[(size_t)frame * gridDim.x + blockIdx.x] = tot;
+        }
+    }
+}
+

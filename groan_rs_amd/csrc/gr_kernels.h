@@ -2,20 +2,25 @@
 // HBM-bound vector math (no MFMA: nothing here is a dense contraction).
 //
 // Data layout in HBM
-//   frame slot : float xyz[n_pad][3]  (packed 12-byte records exactly as the xtc decoders deliver
-//                them; n_pad = n_atoms rounded up to 256 = one wavefront tile)
+//   frame slot : "pair-tiled" structure of arrays.  Atoms are taken in tiles of 256 (n_pad = n_atoms rounded up to 256); lane L
+//                of a wave owns atoms 4L .. 4L+3 of a tile, and the tile is three ROWS of 64 float4 -- lane L's float4 of
+//                row r sits at float4 index tile * 192 + r * 64 + L:
+//                    row 0 = (x0, x1, y0, y1)     row 1 = (z0, z1, x2, x3)     row 2 = (y2, y3, z2, z3)
+//                A wave moves a tile as three fully coalesced 1-KiB loads / stores (one 16-byte element per lane and
+//                instruction: the access shape that streams fastest on this chip), every 128-byte line is touched by exactly
+//                one instruction, and each register pair a lane receives is (coordinate of atom a, same coordinate of atom
+//                a + 1) -- the operand form of the packed-f32 instructions (v_pk_fma_f32 ...) the hot kernels are written in.
+//                The C ABI still takes and returns the packed rvec[n] records the xtc / trr decoders deliver
+//                (molly_xtc.rs:294-307): k_tile / k_untile convert on the way in and out (one extra 24 B/atom pass on the copy
+//                stream, hidden behind the 50 GB/s PCIe copy); the device-side xtc / trr unpackers write the layout directly.
+//                Round 1 kept the packed records in HBM: lanes striding 48 B made every line pass the L1 three times (the
+//                sums pass ran at 4.9 TB/s however few instructions it issued), and the LDS transpose that repairs the access
+//                pattern costs more than it saves (measured round 2: 2.3 vs 1.7 us per 1e6-atom frame).
 //   masses     : float m[n_pad]       (separate array; NaN = no mass)
-//   selection  : one contiguous block  -> {start, n}            (tile path, 4 atoms / lane / trip)
+//   selection  : one contiguous block  -> {start, n}            (row path, 4 atoms / lane / trip)
 //                anything else         -> uint32 idx[n] in HBM  (gather path, 1 atom / lane / trip)
-//   plan       : float p[s_pad][3] (reference coordinates minus the reference box centre, stored so
-//                that the 256-atom tiles of p line up with the tiles of the frame), float w[s_pad]
-//
-// Tile path: a wavefront moves 256 atoms = 3 KiB as three fully contiguous 1-KiB wave loads/stores
-// (16 B per lane) and transposes through its own LDS tile so that lane L ends up with atoms 4L..4L+3.
-// Measured on MI355X for a streaming read-modify-write of 64 x 1e6 atoms (tools/layout_bench.hip):
-//   lanes striding 48 B over packed records 4.7-4.9 TB/s | three planes x[] y[] z[] 5.5-5.6 TB/s |
-//   packed records + LDS transpose 5.8-5.9 TB/s  -> packed xyz stays the HBM layout (no transpose at
-//   ingest either), and the LDS tile is how it is read.
+//   plan       : reference coordinates minus the reference box centre in the same pair-tiled layout, indexed by
+//                ordinal + offset so that the plan's tiles line up with the frame's; float w[s_pad]
 //
 // Reductions: per-lane fp64 accumulators -> wave __shfl_down tree -> LDS across the 4 waves of a
 // workgroup -> one partial record per workgroup in HBM -> a one-workgroup finalize kernel sums the
@@ -23,6 +28,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "gr_math.h"
+#include "gr_layout.h"
 #include "gr_rotation.h"
 
 #define GR_WG 256
@@ -90,6 +96,13 @@ __device__ __forceinline__ void gr_block_sum(double (&v)[K], double *lds /* [GR_
     __syncthreads();
 }
 
+__device__ __forceinline__ void gr_wave_sync() {
+    // LDS operations of one wavefront execute in order; this only stops the compiler from moving
+    // LDS accesses across the point where lanes exchange data
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 __device__ __forceinline__ double gr_wave_sum(double x) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
@@ -166,91 +179,6 @@ __device__ __forceinline__ float gr_wave_max_scatter16(float (&a)[32], const uin
     gr_rs_step<8, 32, true>(a, lane); gr_rs_step<4, 16, true>(a, lane); gr_rs_step<2, 8, true>(a, lane); gr_rs_step<1, 4, true>(a, lane);
     const float m = gr_fmaxf(a[0], __shfl_xor(a[0], 2, 64));
     return gr_fmaxf(m, __shfl_xor(m, 1, 64));
-}
-
-// ------------------------------------------------------------------------------------------ wave tiles
-#define GR_TILE_ATOMS 256
-#define GR_TILE_F4 192
-__device__ __forceinline__ void gr_wave_sync() {
-    // LDS operations of one wavefront execute in order; this only stops the compiler from moving
-    // LDS accesses across the point where lanes exchange data
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-// src = first float4 of a 256-atom tile in HBM; on return lane L holds atoms 4L..4L+3 of the tile:
-// (a.x a.y a.z) (a.w b.x b.y) (b.z b.w c.x) (c.y c.z c.w)
-// Frame data is streamed (each byte is touched once per pass): the non-temporal hint keeps it from pushing the
-// reference coordinates / masses, which every frame re-reads, out of the 4 MiB L2 of the XCD (GR_STREAM_NT=0 to compare).
-#ifndef GR_STREAM_NT_LD
-#define GR_STREAM_NT_LD 1
-#endif
-#ifndef GR_STREAM_NT_ST
-#define GR_STREAM_NT_ST 1
-#endif
-typedef float gr_f4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ float4 gr_stream_load(const float4 *p) {
-#if GR_STREAM_NT_LD
-    const gr_f4 v = __builtin_nontemporal_load(reinterpret_cast<const gr_f4 *>(p));
-    return make_float4(v.x, v.y, v.z, v.w);
-#else
-    return *p;
-#endif
-}
-__device__ __forceinline__ void gr_stream_store(float4 *p, const float4 &v) {
-#if GR_STREAM_NT_ST
-    gr_f4 t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
-    __builtin_nontemporal_store(t, reinterpret_cast<gr_f4 *>(p));
-#else
-    *p = v;
-#endif
-}
-template <bool NT = true>
-__device__ __forceinline__ void gr_tile_load(const float4 *__restrict__ src, float4 *tile, uint32_t lane, float4 &a, float4 &b, float4 &c) {
-    const float4 r0 = NT ? gr_stream_load(src + lane) : src[lane], r1 = NT ? gr_stream_load(src + lane + 64) : src[lane + 64],
-                 r2 = NT ? gr_stream_load(src + lane + 128) : src[lane + 128];
-    tile[lane] = r0; tile[lane + 64] = r1; tile[lane + 128] = r2;
-    gr_wave_sync();
-    a = tile[3 * lane]; b = tile[3 * lane + 1]; c = tile[3 * lane + 2];
-    gr_wave_sync();
-}
-__device__ __forceinline__ void gr_tile_store(float4 *__restrict__ dst, float4 *tile, uint32_t lane, const float4 &a, const float4 &b, const float4 &c) {
-    tile[3 * lane] = a; tile[3 * lane + 1] = b; tile[3 * lane + 2] = c;
-    gr_wave_sync();
-    const float4 r0 = tile[lane], r1 = tile[lane + 64], r2 = tile[lane + 128];
-    gr_stream_store(dst + lane, r0); gr_stream_store(dst + lane + 64, r1); gr_stream_store(dst + lane + 128, r2);
-    gr_wave_sync();
-}
-
-// ------------------------------------------------------------------------------------------ atom streams
-// Calls f(atom_index, ordinal, x, y, z) for every atom of the selection handled by this workgroup.
-// Workgroup `chunk` of `nchunks` takes an interleaved share (grid-stride) so consecutive lanes
-// always touch consecutive memory.
-template <typename F>
-__device__ __forceinline__ void gr_for_each_atom(const GrSel &sel, const float *__restrict__ xyz,
-                                                 uint32_t chunk, uint32_t nchunks, float4 *tiles, F f) {
-    if (sel.contiguous) {
-        const uint32_t first = sel.start, last = sel.start + sel.n;   // [first, last)
-        const uint32_t t0 = first >> 8, t1 = (last + 255u) >> 8;      // tiles [t0, t1)
-        const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        float4 *tile = tiles + wave * GR_TILE_F4;
-        const float4 *f4 = reinterpret_cast<const float4 *>(xyz);
-        for (uint32_t t = t0 + chunk * (GR_WG / 64) + wave; t < t1; t += nchunks * (GR_WG / 64)) {
-            float4 a, b, c;
-            gr_tile_load(f4 + (size_t)t * GR_TILE_F4, tile, lane, a, b, c);
-            const uint32_t i = (t << 8) + (lane << 2);
-            if (i >= first && i < last) f(i, i - first, a.x, a.y, a.z);
-            if (i + 1 >= first && i + 1 < last) f(i + 1, i + 1 - first, a.w, b.x, b.y);
-            if (i + 2 >= first && i + 2 < last) f(i + 2, i + 2 - first, b.z, b.w, c.x);
-            if (i + 3 >= first && i + 3 < last) f(i + 3, i + 3 - first, c.y, c.z, c.w);
-        }
-    } else {
-        for (uint32_t j = chunk * GR_WG + threadIdx.x; j < sel.n; j += nchunks * GR_WG) {
-            const uint32_t i = sel.idx[j];
-            const float *p = xyz + 3 * (size_t)i;
-            f(i, j, p[0], p[1], p[2]);
-        }
-    }
 }
 
 // ------------------------------------------------------------------------------------------ centres
@@ -333,17 +261,19 @@ __global__ __launch_bounds__(GR_WG) void k_center_sums(
         }
     };
     if (sel.contiguous) {
-        // read-only stream: a lane's 4 atoms are three direct 16-byte loads (+ one of masses); their terms form 4-atom f32
-        // partials that go into the lane's fp64 accumulators (naive centre 3.2 -> 2.1 us per 1e6-atom frame against the
-        // coalesced loads + LDS transpose + per-atom fp64 adds this kernel used before)
+        // read-only stream: a lane's 4 atoms are its three row loads (coalesced: consecutive lanes, consecutive 16 bytes) + one of
+        // masses; their terms form 4-atom f32 partials that go into the lane's fp64 accumulators
         const float4 *f4 = reinterpret_cast<const float4 *>(xyz);
         const float4 *m4 = reinterpret_cast<const float4 *>(masses);
         const uint32_t first = sel.start, last = sel.start + sel.n;
         const uint32_t g0 = first >> 2, g1 = (last + 3u) >> 2;
         for (uint32_t g = g0 + chunk * GR_WG + threadIdx.x; g < g1; g += nchunks * GR_WG) {
-            const float4 a = f4[3 * (size_t)g], b = f4[3 * (size_t)g + 1], c = f4[3 * (size_t)g + 2];
+            float4 r0, r1, r2;
+            gr_rows_load(f4, g, r0, r1, r2);
             const float4 mm = weighted ? m4[g] : make_float4(1.f, 1.f, 1.f, 1.f);
-            const float x[4] = { a.x, a.w, b.z, c.y }, y[4] = { a.y, b.x, b.w, c.z }, z[4] = { a.z, b.y, c.x, c.w }, m[4] = { mm.x, mm.y, mm.z, mm.w };
+            float x[4], y[4], z[4];
+            gr_rows_unpack(r0, r1, r2, x, y, z);
+            const float m[4] = { mm.x, mm.y, mm.z, mm.w };
             const uint32_t i = g << 2;
             float p[7] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
 #pragma unroll
@@ -354,9 +284,10 @@ __global__ __launch_bounds__(GR_WG) void k_center_sums(
     } else {
         for (uint32_t j = chunk * GR_WG + threadIdx.x; j < sel.n; j += nchunks * GR_WG) {
             const uint32_t i = sel.idx[j];
-            const float *r = xyz + 3 * (size_t)i;
+            float rx, ry, rz;
+            gr_pos_load(xyz, i, rx, ry, rz);
             float p[7] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
-            atom(i, r[0], r[1], r[2], weighted ? masses[i] : 1.0f, p);
+            atom(i, rx, ry, rz, weighted ? masses[i] : 1.0f, p);
 #pragma unroll
             for (int k = 0; k < (KIND == 1 ? 7 : 4); ++k) acc[k] += (double)p[k];
         }
@@ -462,13 +393,12 @@ __global__ void k_state_reset(GrFrameState *state, uint32_t n) {
 #define GR_ACC_K 32
 struct GrAccPartial { double s[GR_ACC_K]; float vmin[3], vmax[3], fmin[3], fmax[3]; uint32_t bad_pos, bad_mass; };
 
-// ---- per-lane state and per-atom arithmetic of the single pass (shared by k_rmsd_accum and the persistent kernel)
+// ---- per-lane state and per-atom arithmetic of the closed-form single pass
 struct GrA4 { float x[4], y[4], z[4], m[4], px[4], py[4], pz[4], w[4]; uint32_t i[4]; bool ok[4]; };   // four atoms of one lane
 
 struct GrLaneAcc {
     double acc[GR_ACC_K];
     float fsum[6];                       // first / second moments of the fractional coordinates
-    float facc[13];                      // LITE: sum m, sum m v, A as f32 lane sums, moved to acc after the loop
     float mn[3], mx[3], fmn[3], fmx[3];  // Cartesian and fractional extent of v
     uint32_t bad_pos, bad_mass;
     __device__ __forceinline__ void reset() {
@@ -477,15 +407,8 @@ struct GrLaneAcc {
 #pragma unroll
         for (int k = 0; k < 6; ++k) fsum[k] = 0.0f;
 #pragma unroll
-        for (int k = 0; k < 13; ++k) facc[k] = 0.0f;
-#pragma unroll
         for (int a = 0; a < 3; ++a) { mn[a] = fmn[a] = 3.0e38f; mx[a] = fmx[a] = -3.0e38f; }
         bad_pos = bad_mass = GR_NOIDX;
-    }
-    // LITE: move the f32 lane sums into their fp64 slots (once, after the loop)
-    __device__ __forceinline__ void fold() {
-#pragma unroll
-        for (int k = 0; k < 13; ++k) { acc[k] += (double)facc[k]; facc[k] = 0.0f; }
     }
     // fold the f32 moment sums into their fp64 slots (call once, before the cross-lane reduction)
     __device__ __forceinline__ void close(bool w_is_mass) {
@@ -503,10 +426,8 @@ struct GrFrameConst {   // wave-uniform per-frame constants
 };
 
 // v = the image of (x - g) nearest to the provisional centre g, and its fractional coordinates (single pass, MODE 0)
-// (`box` supplies the cell, `cand_box` the minimum-image table: the same object, except where the caller keeps the
-// cell in registers and leaves the rarely needed table in memory)
 __device__ __forceinline__ void gr_image_about(float &vx, float &vy, float &vz, float &f_a, float &f_b, float &f_c,
-                                               float x, float y, float z, const GrBox &box, const GrBox &cand_box, const GrFrameConst &fc) {
+                                               float x, float y, float z, const GrBox &box, const GrFrameConst &fc) {
     // closed-form brick reduction along c, b, a ...
     vx = x - fc.gx; vy = y - fc.gy; vz = z - fc.gz;
     const float kc = rintf(vz * fc.icz);
@@ -516,7 +437,7 @@ __device__ __forceinline__ void gr_image_about(float &vx, float &vy, float &vz, 
     const float ka = rintf(vx * fc.iax);
     vx = fmaf(-ka, box.ax, vx);
     // ... which is already THE minimum image whenever |v| < r_ws; otherwise search the table
-    if (fc.tric && vx * vx + vy * vy + vz * vz >= fc.rws2) gr_tric_refine(vx, vy, vz, cand_box);
+    if (fc.tric && vx * vx + vy * vy + vz * vz >= fc.rws2) gr_tric_refine(vx, vy, vz, box);
     // fractional coordinates of v: first and second moments feed the image proof (see gr_finalize_math)
     f_c = vz * fc.icz;
     const float uy = fmaf(-f_c, box.cy, vy);
@@ -534,12 +455,11 @@ __device__ __forceinline__ void gr_image_about(float &vx, float &vy, float &vz, 
 // tests.  Interior groups skip them: a NaN position or mass then simply poisons the fp64 sums, which the finalize step
 // detects and answers by sending the frame to the multi-pass path, whose kernels report the first atom without
 // position / mass in the reference's order.
-// LITE (RMSD-fit of a contiguous selection): the fit pass evaluates sum w |R q - p|^2 directly once R is known
-// (k_fit<true>), exactly the reference's own final loop (rmsd.rs:592-599), so this pass only needs what steers the
-// rotation and the centre -- sum m, sum m v, A -- and all of it tolerates 4-atom f32 partials: no per-atom fp64 at all.
-template <int MODE, bool LITE = false>
+// (RMSD-fit of a contiguous selection does not come through here: its sums pass is k_sums_pk of gr_hot.h, and the fit pass
+// evaluates sum w |R q - p|^2 directly.)
+template <int MODE>
 __device__ __forceinline__ void gr_flush4(GrLaneAcc &L, const GrA4 &a, const bool checked, const GrBox &box, const GrFrameConst &fc) {
-    float part[9], pm[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+    float part[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) part[k] = 0.0f;
 #pragma unroll
@@ -553,7 +473,7 @@ __device__ __forceinline__ void gr_flush4(GrLaneAcc &L, const GrA4 &a, const boo
         float vx, vy, vz;
         if (MODE == 0) {
             float f_a, f_b, f_c;
-            gr_image_about(vx, vy, vz, f_a, f_b, f_c, a.x[q], a.y[q], a.z[q], box, box, fc);
+            gr_image_about(vx, vy, vz, f_a, f_b, f_c, a.x[q], a.y[q], a.z[q], box, fc);
             L.fsum[0] += f_a; L.fsum[1] += f_b; L.fsum[2] += f_c;
             L.fsum[3] = fmaf(f_a, f_a, L.fsum[3]); L.fsum[4] = fmaf(f_b, f_b, L.fsum[4]); L.fsum[5] = fmaf(f_c, f_c, L.fsum[5]);
             L.fmn[0] = gr_fminf(L.fmn[0], f_a); L.fmn[1] = gr_fminf(L.fmn[1], f_b); L.fmn[2] = gr_fminf(L.fmn[2], f_c);
@@ -569,10 +489,6 @@ __device__ __forceinline__ void gr_flush4(GrLaneAcc &L, const GrA4 &a, const boo
         part[0] = fmaf(px, vx, part[0]); part[1] = fmaf(px, vy, part[1]); part[2] = fmaf(px, vz, part[2]);
         part[3] = fmaf(py, vx, part[3]); part[4] = fmaf(py, vy, part[4]); part[5] = fmaf(py, vz, part[5]);
         part[6] = fmaf(pz, vx, part[6]); part[7] = fmaf(pz, vy, part[7]); part[8] = fmaf(pz, vz, part[8]);
-        if (LITE) {
-            pm[0] += m; pm[1] = fmaf(m, vx, pm[1]); pm[2] = fmaf(m, vy, pm[2]); pm[3] = fmaf(m, vz, pm[3]);
-            continue;
-        }
         const double dvx = vx, dvy = vy, dvz = vz, dm = m, dw = a.w[q];
         const double wpx = dw * (double)px, wpy = dw * (double)py, wpz = dw * (double)pz;
         double *acc = L.acc;
@@ -584,41 +500,10 @@ __device__ __forceinline__ void gr_flush4(GrLaneAcc &L, const GrA4 &a, const boo
         acc[22] = fma(dw, fma(dvx, dvx, fma(dvy, dvy, dvz * dvz)), acc[22]);
         if (!fc.wm) { acc[23] = fma(dw, dvx, acc[23]); acc[24] = fma(dw, dvy, acc[24]); acc[25] = fma(dw, dvz, acc[25]); }
     }
-    if (LITE) {
-        // f32 lane sums: a lane sees n / (256 * chunks) atoms (~160 at 1e6 atoms, <= ~1500 at 1e8): ~1e-6 relative per
-        // lane, independent over 1e4..1e5 lanes, so the frame sums keep ~1e-8; the rmsd no longer comes from these sums
 #pragma unroll
-        for (int k = 0; k < 4; ++k) L.facc[k] += pm[k];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) L.facc[4 + k] += part[k];
-    } else {
-#pragma unroll
-        for (int k = 0; k < 9; ++k) L.acc[4 + k] += (double)part[k];
-    }
+    for (int k = 0; k < 9; ++k) L.acc[4 + k] += (double)part[k];
 }
 
-// unpack the three float4 of positions / reference coordinates + masses / weights of one lane into four atoms
-__device__ __forceinline__ void gr_unpack4(GrA4 &q, const float4 &a, const float4 &b, const float4 &c, const float4 &pa, const float4 &pb,
-                                           const float4 &pc, const float4 &mm, const float4 &ww, uint32_t i, uint32_t first, uint32_t last) {
-    q.x[0] = a.x; q.y[0] = a.y; q.z[0] = a.z; q.x[1] = a.w; q.y[1] = b.x; q.z[1] = b.y;
-    q.x[2] = b.z; q.y[2] = b.w; q.z[2] = c.x; q.x[3] = c.y; q.y[3] = c.z; q.z[3] = c.w;
-    q.px[0] = pa.x; q.py[0] = pa.y; q.pz[0] = pa.z; q.px[1] = pa.w; q.py[1] = pb.x; q.pz[1] = pb.y;
-    q.px[2] = pb.z; q.py[2] = pb.w; q.pz[2] = pc.x; q.px[3] = pc.y; q.py[3] = pc.z; q.pz[3] = pc.w;
-    q.m[0] = mm.x; q.m[1] = mm.y; q.m[2] = mm.z; q.m[3] = mm.w;
-    q.w[0] = ww.x; q.w[1] = ww.y; q.w[2] = ww.z; q.w[3] = ww.w;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { q.i[k] = i + k; q.ok[k] = (i + k >= first) && (i + k < last); }
-}
-
-#ifndef GR_ACC_TILE
-#define GR_ACC_TILE 0
-#endif
-#ifndef GR_ACC_TILE_NT
-#define GR_ACC_TILE_NT false
-#endif
-#ifndef GR_ACC_MIN_WAVES
-#define GR_ACC_MIN_WAVES 1
-#endif
 template <bool NOREF = false>
 __device__ __forceinline__ void gr_finalize_frame_lite(const GrAccPartial *partials, uint32_t nchunks, uint32_t frame, const float *frames, size_t frame_stride,
                                                        uint32_t first_slot, const GrSel &sel, const GrBox *boxes, const GrPlanDev &plan, GrFrameState *state,
@@ -627,33 +512,24 @@ __device__ __forceinline__ void gr_finalize_frame_lite(const GrAccPartial *parti
 // agent-scope (sc1, write-through) stores for records another workgroup of the same launch will read
 template <typename T> __device__ __forceinline__ void gr_st_agent(T *p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-// `fuse` (LITE only): per-frame arrival counters, zero between launches.  The workgroup that completes a frame's records
-// closes the frame itself (gr_finalize_frame_lite) -- no separate finalize launch, no idle chip between the two passes.
-// Non-blocking: nobody waits; records are written with agent-scope stores and drained before the counter is bumped, the
-// closing wave invalidates its L2 view (acquire fence) before it reads them.
-// NOREF (with MODE 0, LITE): the centre-of-mass use of this pass (group_get_com / group_get_center in ONE pass instead of
-// estimate + unwrapped mean): no reference coordinates are read (A stays zero), plan.w_is_mass = 0 counts every atom once,
-// and the closing step stops after the image proof and places the centre in the reference's periodic copy.
-template <int MODE, bool LITE = false, bool NOREF = false>
-__global__ __launch_bounds__(GR_WG, GR_ACC_MIN_WAVES) void k_rmsd_accum(
+// The closed-form single pass (MODE 0: RMSD without fit, and non-contiguous selections) and the literal multi-pass sums
+// (MODE 1: q = wrap(x + shift) - box centre with the shift of the frame's state, the exact path).
+template <int MODE>
+__global__ __launch_bounds__(GR_WG) void k_rmsd_accum(
     const float *__restrict__ frames, size_t frame_stride, uint32_t first_slot,
     const float *__restrict__ masses, GrSel sel, const GrBox *__restrict__ boxes,
-    GrPlanDev plan, const GrFrameState *state, GrAccPartial *partials, uint32_t *fuse = nullptr, GrFrameState *state_out = nullptr) {
+    GrPlanDev plan, const GrFrameState *state, GrAccPartial *partials) {
     __shared__ GrBox box;
     __shared__ double lds[(GR_WG / 64) * GR_ACC_K];
     __shared__ uint32_t ldsu[GR_WG / 64];
     __shared__ float ldsf[GR_WG / 64];
-    __shared__ float4 acc_tiles[GR_ACC_TILE ? (GR_WG / 64) * GR_TILE_F4 : 1];
     const uint32_t frame = blockIdx.y, chunk = blockIdx.x, nchunks = gridDim.x;
     const float *xyz = frames + (size_t)(first_slot + frame) * frame_stride;
     gr_stage_box(&box, boxes + first_slot + frame);
     GrLaneAcc L;
     L.reset();
     GrFrameConst fc;
-    {
-        const uint32_t i0 = sel.contiguous ? sel.start : sel.idx[0];
-        fc.gx = xyz[3 * (size_t)i0]; fc.gy = xyz[3 * (size_t)i0 + 1]; fc.gz = xyz[3 * (size_t)i0 + 2];
-    }
+    gr_pos_load(xyz, sel.contiguous ? sel.start : sel.idx[0], fc.gx, fc.gy, fc.gz);
     fc.sx = fc.sy = fc.sz = 0.f;
     if (MODE == 1) { fc.sx = state[frame].shift[0]; fc.sy = state[frame].shift[1]; fc.sz = state[frame].shift[2]; }
     fc.iax = box.iax; fc.iby = box.iby; fc.icz = box.icz;
@@ -663,39 +539,30 @@ __global__ __launch_bounds__(GR_WG, GR_ACC_MIN_WAVES) void k_rmsd_accum(
     const bool wm = fc.wm;
 
     if (sel.contiguous) {
-        // 4 atoms per lane per trip: 3 float4 of positions, 3 float4 of reference coordinates, 1 float4 of masses
-        // (+1 of weights when they differ from the masses).  Read-only streams: lanes striding 48 B over the packed
-        // records re-touch each line from L1/L2 at no measurable cost (unlike the read-modify-write of k_fit, which
-        // goes through the LDS tile); the direct loads keep 7 independent 16-B loads per lane in flight.
+        // 4 atoms per lane per trip: 3 rows of positions, 3 rows of reference coordinates, 1 float4 of masses
+        // (+1 of weights when they differ from the masses), all coalesced
         const uint32_t first = sel.start, last = sel.start + sel.n;
         const uint32_t g0 = sel.g0 << 6, g1 = (last + 3u) >> 2;      // float4 groups [g0, g1): g0 = first group of the first tile
         const float4 *f4 = reinterpret_cast<const float4 *>(xyz);
         const float4 *p4 = reinterpret_cast<const float4 *>(plan.p);
         const float4 *m4 = reinterpret_cast<const float4 *>(masses);
         const float4 *w4 = reinterpret_cast<const float4 *>(plan.w);
-        // (requesting the NEXT trip's positions before this trip's arithmetic was measured 6 % slower: the loop is bound
-        // by VALU issue, not by bytes in flight)
-        for (uint32_t g = g0 + chunk * GR_WG + threadIdx.x; g - (threadIdx.x & 63u) < g1; g += nchunks * GR_WG) {
-            float4 a, b, c;
-            if (GR_ACC_TILE) {
-                // compile-time experiment (-DGR_ACC_TILE=1): a wave's 64 groups are one 256-atom tile, so the positions could
-                // come in as three coalesced 1-KiB loads + an LDS transpose like the read-modify-write kernels.  Measured
-                // SLOWER here (3.1 vs 2.8 us/frame): this loop is not bound by the load pattern, and the transpose costs issue slots.
-                gr_tile_load<GR_ACC_TILE_NT>(f4 + 3 * (size_t)(g - (threadIdx.x & 63u)), acc_tiles + (threadIdx.x >> 6) * GR_TILE_F4, threadIdx.x & 63u, a, b, c);
-                if (g >= g1) continue;
-            } else {
-                if (g >= g1) continue;
-                a = f4[3 * (size_t)g]; b = f4[3 * (size_t)g + 1]; c = f4[3 * (size_t)g + 2];
-            }
+        for (uint32_t g = g0 + chunk * GR_WG + threadIdx.x; g < g1; g += nchunks * GR_WG) {
+            float4 r0, r1, r2, q0, q1, q2;
+            gr_rows_load(f4, g, r0, r1, r2);
             const size_t pg = (size_t)(g - g0);
-            const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            const float4 pa = NOREF ? zero4 : p4[3 * pg], pb = NOREF ? zero4 : p4[3 * pg + 1], pc = NOREF ? zero4 : p4[3 * pg + 2];
-            const float4 mm = (NOREF && !wm) ? make_float4(1.f, 1.f, 1.f, 1.f) : m4[g];
-            const float4 ww = (wm || LITE) ? mm : w4[pg];
+            gr_rows_load(p4, pg, q0, q1, q2);
+            const float4 mm = m4[g];
+            const float4 ww = wm ? mm : w4[pg];
             const uint32_t i = g << 2;
             GrA4 q;
-            gr_unpack4(q, a, b, c, pa, pb, pc, mm, ww, i, first, last);
-            if (MODE == 0 && i >= first && i + 3 < last) gr_flush4<MODE, LITE>(L, q, false, box, fc); else gr_flush4<MODE, LITE>(L, q, true, box, fc);
+            gr_rows_unpack(r0, r1, r2, q.x, q.y, q.z);
+            gr_rows_unpack(q0, q1, q2, q.px, q.py, q.pz);
+            q.m[0] = mm.x; q.m[1] = mm.y; q.m[2] = mm.z; q.m[3] = mm.w;
+            q.w[0] = ww.x; q.w[1] = ww.y; q.w[2] = ww.z; q.w[3] = ww.w;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { q.i[k] = i + k; q.ok[k] = (i + k >= first) && (i + k < last); }
+            if (MODE == 0 && i >= first && i + 3 < last) gr_flush4<MODE>(L, q, false, box, fc); else gr_flush4<MODE>(L, q, true, box, fc);
         }
     } else {
         const uint32_t n4 = (sel.n + 3u) >> 2;
@@ -707,67 +574,12 @@ __global__ __launch_bounds__(GR_WG, GR_ACC_MIN_WAVES) void k_rmsd_accum(
                 t.ok[q] = j < sel.n;
                 const uint32_t jj = t.ok[q] ? j : 0u;
                 const uint32_t i = sel.idx[jj];
-                const float *r = xyz + 3 * (size_t)i;
-                t.i[q] = i; t.x[q] = r[0]; t.y[q] = r[1]; t.z[q] = r[2]; t.m[q] = masses[i];
-                t.px[q] = plan.p[3 * (size_t)jj]; t.py[q] = plan.p[3 * (size_t)jj + 1]; t.pz[q] = plan.p[3 * (size_t)jj + 2];
+                t.i[q] = i; gr_pos_load(xyz, i, t.x[q], t.y[q], t.z[q]); t.m[q] = masses[i];
+                gr_pos_load(plan.p, jj, t.px[q], t.py[q], t.pz[q]);
                 t.w[q] = wm ? t.m[q] : plan.w[jj];
             }
             if (MODE == 0 && j4 * 4 + 3 < sel.n) gr_flush4<MODE>(L, t, false, box, fc); else gr_flush4<MODE>(L, t, true, box, fc);
         }
-    }
-    if (LITE) {
-        // Cheap epilogue: every live lane sum is f32, so each wave reduce-scatters its 19 sums and 12 extents (49
-        // exchanges instead of 31 x 6), the four waves meet in LDS once, and 33 lanes of wave 0 write the record.
-        const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        float s32[32], e32[32];
-#pragma unroll
-        for (int k = 0; k < 32; ++k) { s32[k] = 0.0f; e32[k] = -3.0e38f; }
-#pragma unroll
-        for (int k = 0; k < 13; ++k) s32[k] = L.facc[k];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) s32[13 + k] = L.fsum[k];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { e32[k] = -L.mn[k]; e32[3 + k] = L.mx[k]; e32[6 + k] = -L.fmn[k]; e32[9 + k] = L.fmx[k]; }
-        const float tot = gr_wave_sum_scatter32(s32, lane);
-        const float emax = gr_wave_max_scatter16(e32, lane);
-        uint32_t bp = L.bad_pos, bm = L.bad_mass;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) { bp = min(bp, (uint32_t)__shfl_xor((int)bp, off, 64)); bm = min(bm, (uint32_t)__shfl_xor((int)bm, off, 64)); }
-        float *wsum = reinterpret_cast<float *>(lds);            // [4 waves][32 sums | 16 maxima | 2 indices]
-        if ((lane & 1u) == 0) wsum[wave * 50 + (lane >> 1)] = tot;
-        if ((lane & 3u) == 0) wsum[wave * 50 + 32 + (lane >> 2)] = emax;
-        if (lane == 0) { reinterpret_cast<uint32_t *>(wsum)[wave * 50 + 48] = bp; reinterpret_cast<uint32_t *>(wsum)[wave * 50 + 49] = bm; }
-        __syncthreads();
-        if (wave == 0) {
-            GrAccPartial &o = partials[(size_t)frame * nchunks + chunk];
-            if (lane < 19) {
-                const double v = (double)wsum[lane] + (double)wsum[50 + lane] + (double)wsum[100 + lane] + (double)wsum[150 + lane];
-                gr_st_agent(&o.s[lane < 13 ? lane : 13 + lane], v);           // sums 13..18 are the moments: record slots 26..31
-            } else if (lane < 32) {
-                gr_st_agent(&o.s[lane - 6], 0.0);                             // slots 13..25 are not used by the two-pass sums
-            } else if (lane < 44) {
-                const uint32_t q = lane - 32;
-                const float m = gr_fmaxf(gr_fmaxf(wsum[32 + q], wsum[50 + 32 + q]), gr_fmaxf(wsum[100 + 32 + q], wsum[150 + 32 + q]));
-                if (q < 3) gr_st_agent(&o.vmin[q], -m); else if (q < 6) gr_st_agent(&o.vmax[q - 3], m); else if (q < 9) gr_st_agent(&o.fmin[q - 6], -m); else gr_st_agent(&o.fmax[q - 9], m);
-            } else if (lane == 44) {
-                const uint32_t *u = reinterpret_cast<const uint32_t *>(wsum);
-                gr_st_agent(&o.bad_pos, min(min(u[48], u[98]), min(u[148], u[198])));
-                gr_st_agent(&o.bad_mass, min(min(u[49], u[99]), min(u[149], u[199])));
-            }
-            if (fuse) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // every lane's record stores have left
-                uint32_t old = 0;
-                if (lane == 0) old = __hip_atomic_fetch_add(fuse + frame, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (__builtin_amdgcn_readfirstlane(old) == nchunks - 1) {     // this frame's records are complete: close it
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                    double *tot = lds;                                        // wsum (same LDS) has been consumed by this wave
-                    float *ext = reinterpret_cast<float *>(lds + 32);
-                    gr_finalize_frame_lite<NOREF>(partials, nchunks, frame, frames, frame_stride, first_slot, sel, boxes, plan, state_out, tot, ext, lane);
-                    if (lane == 0) fuse[frame] = 0u;
-                }
-            }
-        }
-        return;
     }
     L.close(wm);
     gr_block_sum<GR_ACC_K>(L.acc, lds);
@@ -853,9 +665,15 @@ __device__ inline void gr_finalize_math(const double *acc, const float mn[3], co
                 }
             } else {
                 double r2 = 0;
+                const double L[3] = { b.ax, b.by, b.cz };
                 for (int a = 0; a < 3; ++a) {
                     const double far = fmax(fabs((double)mx[a] - cen[t][a]), fabs((double)mn[a] - cen[t][a]));
                     r2 += far * far;
+                    // about the COM the reference's q is wrap(x + shift) - box centre (rmsd.rs:479-492), and the triclinic wrap
+                    // maps into the BRICK 0..ax, 0..by, 0..cz about the box centre: a group that fits the Wigner-Seitz sphere
+                    // but sticks out of the brick (cz / 2 < r_ws in a rhombic dodecahedron) is broken by that wrap -- the
+                    // images chosen here are then not the path's q, and the frame must take the literal path
+                    if (!NOREF && t == 1 && !(far < 0.5 * L[a] - margin)) ok = false;
                 }
                 if (!(sqrt(r2) + (t == 0 ? slack_tric : 0.0) < (double)b.r_ws - margin)) ok = false;
             }
@@ -910,7 +728,7 @@ __device__ inline void gr_finalize_math(const double *acc, const float mn[3], co
     for (int a = 0; a < 3; ++a) for (int c = 0; c < 3; ++c) st.R[3 * c + a] = (float)R[a][c];   // column-major
 }
 
-template <int MODE, bool LITE = false>
+template <int MODE>
 __global__ __launch_bounds__(GR_WG) void k_rmsd_finalize(
     const GrAccPartial *__restrict__ partials, uint32_t nchunks,
     const float *__restrict__ frames, size_t frame_stride, uint32_t first_slot, GrSel sel,
@@ -946,9 +764,10 @@ __global__ __launch_bounds__(GR_WG) void k_rmsd_finalize(
     GrFrameState &st = state[frame];
     if (st.status != 0) return;
     const float *xyz = frames + (size_t)(first_slot + frame) * frame_stride;
-    const uint32_t i0 = sel.contiguous ? sel.start : sel.idx[0];
-    const double g[3] = { xyz[3 * (size_t)i0], xyz[3 * (size_t)i0 + 1], xyz[3 * (size_t)i0 + 2] };
-    gr_finalize_math<MODE, LITE>(acc, mn, mx, fmn, fmx, bad_pos, bad_mass, boxes[first_slot + frame], plan, g, sel.n, st);
+    float g0x, g0y, g0z;
+    gr_pos_load(xyz, sel.contiguous ? sel.start : sel.idx[0], g0x, g0y, g0z);
+    const double g[3] = { g0x, g0y, g0z };
+    gr_finalize_math<MODE>(acc, mn, mx, fmn, fmx, bad_pos, bad_mass, boxes[first_slot + frame], plan, g, sel.n, st);
 }
 
 // The same for the two-pass sums records, ONE WAVE per frame and no barrier: lane c sums the records c, c + 64, ..., a
@@ -993,8 +812,9 @@ __device__ __forceinline__ void gr_finalize_frame_lite(const GrAccPartial *parti
     const float mn[3] = { -ext[0], -ext[1], -ext[2] }, mx[3] = { ext[3], ext[4], ext[5] };
     const float fmn[3] = { -ext[6], -ext[7], -ext[8] }, fmx[3] = { ext[9], ext[10], ext[11] };
     const float *xyz = frames + (size_t)(first_slot + frame) * frame_stride;
-    const uint32_t i0 = sel.contiguous ? sel.start : sel.idx[0];
-    const double g[3] = { xyz[3 * (size_t)i0], xyz[3 * (size_t)i0 + 1], xyz[3 * (size_t)i0 + 2] };
+    float g0x, g0y, g0z;
+    gr_pos_load(xyz, sel.contiguous ? sel.start : sel.idx[0], g0x, g0y, g0z);
+    const double g[3] = { g0x, g0y, g0z };
     gr_finalize_math<0, true, NOREF>(acc, mn, mx, fmn, fmx, bad_pos, bad_mass, boxes[first_slot + frame], plan, g, sel.n, st);
 }
 
@@ -1006,120 +826,6 @@ __global__ __launch_bounds__(64) void k_rmsd_finalize_lite(
     __shared__ double tot[32];
     __shared__ float ext[16];
     gr_finalize_frame_lite<NOREF>(partials, nchunks, blockIdx.x, frames, frame_stride, first_slot, sel, boxes, plan, state, tot, ext, threadIdx.x);
-}
-
-// ------------------------------------------------------------------------------------------ fit (all atoms)
-// fit_structure (rmsd.rs:508-528, atom.rs:498-528,894-903), one streaming read-modify-write pass:
-//   z = R (wrap(x + shift) - box_centre) + reference_group_com
-// RMSD = true (contiguous selection) also evaluates the reference's final loop while the atoms are in registers:
-//   sum_i w_i |R q_i - p_i|^2   (rmsd.rs:592-599; |R^T p - q| = |p - R q|), q_i = wrap(x_i + shift) - box_centre
-// as 4-atom f32 partials -> fp64 per lane -> one fp64 partial per workgroup in fit_partials[frame][blockIdx.x];
-// k_rmsd_close sums them in a fixed order.  d = R q - p is a difference of O(nm) numbers with ~1e-7 relative rounding,
-// so a rigid copy of the reference gives rmsd ~ 1e-6 nm instead of the cancellation-limited closed form.
-// `fuse` (RMSD only): per-frame arrival counters, zero between launches; the workgroup that delivers a frame's last partial
-// sums them in a fixed order and writes the rmsd (what k_rmsd_close does otherwise).
-template <bool RMSD>
-__global__ __launch_bounds__(GR_WG) void k_fit(
-    float *__restrict__ frames, size_t frame_stride, uint32_t first_slot, uint32_t n_atoms,
-    const GrBox *__restrict__ boxes, GrPlanDev plan, const GrFrameState *state,
-    const float *__restrict__ masses, GrSel sel, double *fit_partials, uint32_t *fuse = nullptr, GrFrameState *state_out = nullptr) {
-    __shared__ GrBox box;
-    __shared__ double lds[GR_WG / 64];
-    __shared__ uint32_t last_flag;
-    const uint32_t frame = blockIdx.y;   // (last-read-first order over the group's frames: 1.5 % slower, the Infinity Cache keeps nothing of the sums pass)
-    const GrFrameState &st = state[frame];
-    if (st.status != 0) return;   // analysis failed -> frame left unmodified (rmsd.rs:91)
-    float *xyz = frames + (size_t)(first_slot + frame) * frame_stride;
-    gr_stage_box(&box, boxes + first_slot + frame);
-    const float sx = st.shift[0], sy = st.shift[1], sz = st.shift[2];
-    const float r00 = st.R[0], r10 = st.R[1], r20 = st.R[2], r01 = st.R[3], r11 = st.R[4], r21 = st.R[5], r02 = st.R[6], r12 = st.R[7], r22 = st.R[8];
-    const float cx = plan.ref_com[0], cy = plan.ref_com[1], cz = plan.ref_com[2];
-    // x,y,z <- R q (q = wrap(x + shift) - box centre); the caller adds the reference COM.
-    // (A one-turn wrap -- k from two compares, ~7 instead of ~25 VALU slots per axis, general form only for waves that
-    // need it -- changes nothing here: 3.94 us/frame either way.  The kernel waits on HBM, not on its 88 VALU slots per atom.)
-    auto rot = [&](float &x, float &y, float &z) {
-        x += sx; y += sy; z += sz;
-        gr_wrap(x, y, z, box);
-        x -= box.bcx; y -= box.bcy; z -= box.bcz;
-        const float nx = r00 * x + r01 * y + r02 * z;
-        const float ny = r10 * x + r11 * y + r12 * z;
-        const float nz = r20 * x + r21 * y + r22 * z;
-        x = nx; y = ny; z = nz;
-    };
-    __shared__ float4 tiles[(GR_WG / 64) * GR_TILE_F4];
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float4 *tile = tiles + wave * GR_TILE_F4;
-    float4 *f4 = reinterpret_cast<float4 *>(xyz);
-    const float4 *p4 = reinterpret_cast<const float4 *>(plan.p);
-    const float4 *w4 = plan.w_is_mass ? reinterpret_cast<const float4 *>(masses) : reinterpret_cast<const float4 *>(plan.w);
-    const uint32_t first = sel.start, last = sel.start + sel.n, g0 = sel.g0 << 6;
-    const uint32_t wofs = plan.w_is_mass ? 0u : g0;        // masses are indexed by atom group, plan.w by selection group
-    double rs = 0.0;
-    const uint32_t ntiles = (n_atoms + 255u) >> 8;   // the slot is padded to whole tiles; pad atoms are transformed too (harmless)
-    for (uint32_t t = blockIdx.x * (GR_WG / 64) + wave; t < ntiles; t += gridDim.x * (GR_WG / 64)) {
-        float4 a, b, c;
-        gr_tile_load(f4 + (size_t)t * GR_TILE_F4, tile, lane, a, b, c);
-        rot(a.x, a.y, a.z); rot(a.w, b.x, b.y); rot(b.z, b.w, c.x); rot(c.y, c.z, c.w);
-        if (RMSD) {
-            const uint32_t g = (t << 6) + lane, i = g << 2;
-            if (i + 3 >= first && i < last) {
-                const size_t pg = (size_t)(g - g0);
-                const float4 pa = p4[3 * pg], pb = p4[3 * pg + 1], pc = p4[3 * pg + 2];
-                const float4 ww = w4[g - wofs];
-                auto d2 = [](float x, float y, float z, float px, float py, float pz) { const float dx = x - px, dy = y - py, dz = z - pz; return fmaf(dx, dx, fmaf(dy, dy, dz * dz)); };
-                float part = 0.0f;
-                if (i >= first && i + 3 < last) {
-                    part = ww.x * d2(a.x, a.y, a.z, pa.x, pa.y, pa.z);
-                    part = fmaf(ww.y, d2(a.w, b.x, b.y, pa.w, pb.x, pb.y), part);
-                    part = fmaf(ww.z, d2(b.z, b.w, c.x, pb.z, pb.w, pc.x), part);
-                    part = fmaf(ww.w, d2(c.y, c.z, c.w, pc.y, pc.z, pc.w), part);
-                } else {
-                    if (i >= first && i < last) part = ww.x * d2(a.x, a.y, a.z, pa.x, pa.y, pa.z);
-                    if (i + 1 >= first && i + 1 < last) part = fmaf(ww.y, d2(a.w, b.x, b.y, pa.w, pb.x, pb.y), part);
-                    if (i + 2 >= first && i + 2 < last) part = fmaf(ww.z, d2(b.z, b.w, c.x, pb.z, pb.w, pc.x), part);
-                    if (i + 3 >= first && i + 3 < last) part = fmaf(ww.w, d2(c.y, c.z, c.w, pc.y, pc.z, pc.w), part);
-                }
-                rs += (double)part;
-            }
-        }
-        a.x += cx; a.y += cy; a.z += cz; a.w += cx; b.x += cy; b.y += cz; b.z += cx; b.w += cy; c.x += cz; c.y += cx; c.z += cy; c.w += cz;
-        gr_tile_store(f4 + (size_t)t * GR_TILE_F4, tile, lane, a, b, c);
-    }
-    if (RMSD) {
-        rs = gr_wave_sum(rs);
-        if (lane == 0) lds[wave] = rs;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            double tot = 0.0;
-#pragma unroll
-            for (int k = 0; k < GR_WG / 64; ++k) tot += lds[k];
-            gr_st_agent(&fit_partials[(size_t)frame * gridDim.x + blockIdx.x], tot);
-            if (fuse) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                last_flag = (__hip_atomic_fetch_add(fuse + frame, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) ? 1u : 0u;
-            }
-        }
-        if (fuse) {
-            __syncthreads();
-            if (last_flag) {   // workgroup-uniform
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                const double *p = fit_partials + (size_t)frame * gridDim.x;
-                double s = 0.0;
-                for (uint32_t k = threadIdx.x; k < gridDim.x; k += GR_WG) s += p[k];
-                s = gr_wave_sum(s);
-                __syncthreads();
-                if (lane == 0) lds[wave] = s;
-                __syncthreads();
-                if (threadIdx.x == 0) {
-                    double tot = 0.0;
-#pragma unroll
-                    for (int k = 0; k < GR_WG / 64; ++k) tot += lds[k];
-                    state_out[frame].rmsd = (float)sqrt(fmax(tot, 0.0) / plan.sw);
-                    fuse[frame] = 0u;
-                }
-            }
-        }
-    }
 }
 
 // rmsd = sqrt(sum of the fit pass's workgroup partials / sum w)  (rmsd.rs:599); one wave per frame, fixed summation order
@@ -1145,24 +851,27 @@ __global__ __launch_bounds__(GR_WG) void k_plan_extract(
     GrCenPartial *__restrict__ partials) {
     __shared__ GrBox box;
     __shared__ double lds[(GR_WG / 64) * GR_CEN_K];
-    __shared__ float4 tiles[(GR_WG / 64) * GR_TILE_F4];
     gr_stage_box(&box, boxp);
     const float sx = state->shift[0], sy = state->shift[1], sz = state->shift[2];
     double acc[GR_CEN_K];
 #pragma unroll
     for (int k = 0; k < GR_CEN_K; ++k) acc[k] = 0.0;
-    gr_for_each_atom(sel, xyz, blockIdx.x, gridDim.x, tiles, [&](uint32_t i, uint32_t j, float x, float y, float z) {
+    // once per plan: one atom per lane and trip, component loads / stores through the layout's index function
+    for (uint32_t j = blockIdx.x * GR_WG + threadIdx.x; j < sel.n; j += gridDim.x * GR_WG) {
+        const uint32_t i = sel.contiguous ? sel.start + j : sel.idx[j];
+        float x, y, z;
+        gr_pos_load(xyz, i, x, y, z);
         x += sx; y += sy; z += sz;
         gr_wrap(x, y, z, box);
         x -= box.bcx; y -= box.bcy; z -= box.bcz;
         const float w = masses[i];
         const size_t jj = (size_t)j + pofs;
-        p_out[3 * jj] = x; p_out[3 * jj + 1] = y; p_out[3 * jj + 2] = z; w_out[jj] = w;
+        gr_pos_store(p_out, jj, x, y, z); w_out[jj] = w;
         const double dx = x, dy = y, dz = z, dw = w;
         acc[0] += dx; acc[1] += dy; acc[2] += dz;
         acc[3] += dw * dx; acc[4] += dw * dy; acc[5] += dw * dz;
         acc[6] += dw * (dx * dx + dy * dy + dz * dz); acc[7] += dw;
-    });
+    }
     gr_block_sum<GR_CEN_K>(acc, lds);
     if (threadIdx.x == 0) {
         GrCenPartial &o = partials[blockIdx.x];
@@ -1182,7 +891,6 @@ __global__ __launch_bounds__(GR_WG) void k_translate_wrap(
     int use_state_shift, int dim_mask, float tx, float ty, float tz, uint32_t *__restrict__ bad_out) {
     __shared__ GrBox box;
     __shared__ uint32_t ldsu[GR_WG / 64];
-    __shared__ float4 tiles[(GR_WG / 64) * GR_TILE_F4];
     xyz += (size_t)blockIdx.y * frame_stride; boxp += blockIdx.y; state += blockIdx.y; bad_out += 4 * blockIdx.y;
     gr_stage_box(&box, boxp);
     if (use_state_shift == 2 && state->status != 0) return;
@@ -1199,28 +907,29 @@ __global__ __launch_bounds__(GR_WG) void k_translate_wrap(
         gr_wrap(x, y, z, box);
     };
     if (sel.contiguous) {
+        // read-modify-write of the selection's 4-atom groups: three coalesced row loads, three coalesced row stores per lane
+        // (atoms of a ragged first / last group that lie outside the selection are written back unchanged)
         const uint32_t first = sel.start, last = sel.start + sel.n;
-        const uint32_t t0 = first >> 8, t1 = (last + 255u) >> 8;
-        const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        float4 *tile = tiles + wave * GR_TILE_F4;
+        const uint32_t g0 = first >> 2, g1 = (last + 3u) >> 2;
         float4 *f4 = reinterpret_cast<float4 *>(xyz);
-        for (uint32_t t = t0 + blockIdx.x * (GR_WG / 64) + wave; t < t1; t += gridDim.x * (GR_WG / 64)) {
-            float4 a, b, c;
-            gr_tile_load(f4 + (size_t)t * GR_TILE_F4, tile, lane, a, b, c);
-            const uint32_t i = (t << 8) + (lane << 2);
-            if (i >= first && i < last) tf(i, a.x, a.y, a.z);
-            if (i + 1 >= first && i + 1 < last) tf(i + 1, a.w, b.x, b.y);
-            if (i + 2 >= first && i + 2 < last) tf(i + 2, b.z, b.w, c.x);
-            if (i + 3 >= first && i + 3 < last) tf(i + 3, c.y, c.z, c.w);
-            gr_tile_store(f4 + (size_t)t * GR_TILE_F4, tile, lane, a, b, c);
+        for (uint32_t g = g0 + blockIdx.x * GR_WG + threadIdx.x; g < g1; g += gridDim.x * GR_WG) {
+            float4 r0, r1, r2;
+            gr_rows_load<true>(f4, g, r0, r1, r2);
+            float x[4], y[4], z[4];
+            gr_rows_unpack(r0, r1, r2, x, y, z);
+            const uint32_t i = g << 2;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (i + k >= first && i + k < last) tf(i + k, x[k], y[k], z[k]);
+            gr_rows_pack(x, y, z, r0, r1, r2);
+            gr_rows_store<true>(f4, g, r0, r1, r2);
         }
     } else {
         for (uint32_t j = blockIdx.x * GR_WG + threadIdx.x; j < sel.n; j += gridDim.x * GR_WG) {
             const uint32_t i = sel.idx[j];
-            float *p = xyz + 3 * (size_t)i;
-            float x = p[0], y = p[1], z = p[2];
+            float x, y, z;
+            gr_pos_load(xyz, i, x, y, z);
             tf(i, x, y, z);
-            p[0] = x; p[1] = y; p[2] = z;
+            gr_pos_store(xyz, i, x, y, z);
         }
     }
     bad = gr_block_min_u32(bad, ldsu);
@@ -1322,18 +1031,18 @@ __global__ __launch_bounds__(GR_WG) void k_pairdist(
         float x = 0.f, y = 0.f, z = 0.f;
         if (i < s1.n) {
             const uint32_t a = s1.contiguous ? s1.start + i : s1.idx[i];
-            x = xyz[3 * (size_t)a]; y = xyz[3 * (size_t)a + 1]; z = xyz[3 * (size_t)a + 2];
+            gr_pos_load(xyz, a, x, y, z);
             if (x != x) bad = min(bad, a);
             far |= !(x >= lx && x <= ux && y >= ly && y <= uy && z >= lz && z <= uz);
         }
         ti[threadIdx.x][0] = x; ti[threadIdx.x][1] = y; ti[threadIdx.x][2] = z; ti[threadIdx.x][3] = 0.f;
     }
     float jx[4], jy[4], jz[4];
-    if (s2.contiguous && j0 + 3 < s2.n && ((s2.start + j0) & 3u) == 0u && (frame_stride & 3u) == 0u) {
-        // the lane's 4 atoms are 48 consecutive, 16-byte aligned bytes: three 16-byte loads instead of twelve 4-byte ones
-        const float4 *q = reinterpret_cast<const float4 *>(xyz + 3 * (size_t)(s2.start + j0));
-        const float4 a = q[0], b = q[1], c = q[2];
-        jx[0] = a.x; jy[0] = a.y; jz[0] = a.z; jx[1] = a.w; jy[1] = b.x; jz[1] = b.y; jx[2] = b.z; jy[2] = b.w; jz[2] = c.x; jx[3] = c.y; jy[3] = c.z; jz[3] = c.w;
+    if (s2.contiguous && j0 + 3 < s2.n && ((s2.start + j0) & 3u) == 0u) {
+        // the lane's 4 atoms are one group of the slot: its three (coalesced) row loads instead of twelve 4-byte ones
+        float4 r0, r1, r2;
+        gr_rows_load(reinterpret_cast<const float4 *>(xyz), (size_t)((s2.start + j0) >> 2), r0, r1, r2);
+        gr_rows_unpack(r0, r1, r2, jx, jy, jz);
 #pragma unroll
         for (int k = 0; k < 4; ++k) if (jx[k] != jx[k]) badj = min(badj, s2.start + j0 + k);
     } else {
@@ -1343,7 +1052,7 @@ __global__ __launch_bounds__(GR_WG) void k_pairdist(
             jx[k] = jy[k] = jz[k] = 0.f;
             if (j < s2.n) {
                 const uint32_t a = s2.contiguous ? s2.start + j : s2.idx[j];
-                jx[k] = xyz[3 * (size_t)a]; jy[k] = xyz[3 * (size_t)a + 1]; jz[k] = xyz[3 * (size_t)a + 2];
+                gr_pos_load(xyz, a, jx[k], jy[k], jz[k]);
                 if (jx[k] != jx[k]) badj = min(badj, a);
             }
         }
@@ -1434,7 +1143,7 @@ __global__ void k_synth_reference(float *xyz, uint32_t n, const GrBox *boxp, flo
         if (x * x + y * y + z * z <= 1.0f) break;
         if (t == 15) { x *= 0.5f; y *= 0.5f; z *= 0.5f; }
     }
-    xyz[3 * (size_t)i] = b.bcx + radius * x; xyz[3 * (size_t)i + 1] = b.bcy + radius * y; xyz[3 * (size_t)i + 2] = b.bcz + radius * z;
+    gr_pos_store(xyz, i, b.bcx + radius * x, b.bcy + radius * y, b.bcz + radius * z);
 }
 
 // frame f = R_f (x0 - c) + c + t_f + noise, wrapped into the cell
@@ -1457,7 +1166,9 @@ __global__ void k_synth_frames(const float *ref, float *frames, size_t frame_str
     // translation anywhere in the cell (fractional)
     const float fa = gr_u01(seed, fi, 4, 2), fb = gr_u01(seed, fi, 5, 2), fc = gr_u01(seed, fi, 6, 2);
     const float tx = fa * b.ax + fb * b.bx + fc * b.cx, ty = fb * b.by + fc * b.cy, tz = fc * b.cz;
-    const float x0 = ref[3 * (size_t)i] - b.bcx, y0 = ref[3 * (size_t)i + 1] - b.bcy, z0 = ref[3 * (size_t)i + 2] - b.bcz;
+    float x0, y0, z0;
+    gr_pos_load(ref, i, x0, y0, z0);
+    x0 -= b.bcx; y0 -= b.bcy; z0 -= b.bcz;
     // noise: sum of 4 uniforms (variance 1/3) scaled to sigma
     float nz[3];
     for (int a = 0; a < 3; ++a) {
@@ -1468,8 +1179,8 @@ __global__ void k_synth_frames(const float *ref, float *frames, size_t frame_str
     float y = R[1][0] * x0 + R[1][1] * y0 + R[1][2] * z0 + b.bcy + ty + nz[1];
     float z = R[2][0] * x0 + R[2][1] * y0 + R[2][2] * z0 + b.bcz + tz + nz[2];
     gr_wrap(x, y, z, b);
-    float *o = frames + (size_t)(first_slot + f) * frame_stride + 3 * (size_t)i;
-    o[0] = x; o[1] = y; o[2] = z;
+    gr_pos_store(frames + (size_t)(first_slot + f) * frame_stride, i, x, y, z);
+
 }
 
 __global__ void k_synth_uniform(float *xyz, uint32_t n, const GrBox *boxp, uint64_t seed) {
@@ -1477,5 +1188,5 @@ __global__ void k_synth_uniform(float *xyz, uint32_t n, const GrBox *boxp, uint6
     if (i >= n) return;
     const GrBox &b = *boxp;
     const float fa = gr_u01(seed, i, 0, 7), fb = gr_u01(seed, i, 1, 7), fc = gr_u01(seed, i, 2, 7);
-    xyz[3 * (size_t)i] = fa * b.ax + fb * b.bx + fc * b.cx; xyz[3 * (size_t)i + 1] = fb * b.by + fc * b.cy; xyz[3 * (size_t)i + 2] = fc * b.cz;
+    gr_pos_store(xyz, i, fa * b.ax + fb * b.bx + fc * b.cx, fb * b.by + fc * b.cy, fc * b.cz);
 }

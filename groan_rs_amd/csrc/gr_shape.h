@@ -7,6 +7,9 @@
 // src/system/groups.rs:104-110).
 #pragma once
 #include "gr_math.h"
+#if defined(__HIPCC__)
+#include "gr_layout.h"
+#endif
 
 enum { GR_SH_SPHERE = 1, GR_SH_RECTANGULAR = 2, GR_SH_CYLINDER = 3, GR_SH_PRISM = 4 };
 #define GR_MAX_SHAPES 8
@@ -104,7 +107,8 @@ __global__ __launch_bounds__(256) void k_shape_mask(const float *__restrict__ xy
     bool in = false;
     if (j < sel.n) {
         const uint32_t a = sel.contiguous ? sel.start + j : sel.idx[j];
-        const float x = xyz[3 * (size_t)a], y = xyz[3 * (size_t)a + 1], z = xyz[3 * (size_t)a + 2];
+        float x, y, z;
+        gr_pos_load(xyz, a, x, y, z);
         in = (x == x);
         for (int q = 0; q < shapes.n && in; ++q)
             in = shapes.naive ? gr_shape_inside_naive(shapes.s[q], x, y, z) : gr_shape_inside_pbc(shapes.s[q], x, y, z, box);

@@ -12,6 +12,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "gr_xtc.h"
+#include "gr_layout.h"
 
 __constant__ int gr_xtc_magic[73] = {
     0, 0, 0, 0, 0, 0, 0, 0, 0, 8, 10, 12, 16, 20, 25, 32, 40, 50, 64, 80, 101, 128, 161, 203, 256, 322, 406, 512, 645, 812, 1024, 1290, 1625,
@@ -82,7 +83,8 @@ __global__ __launch_bounds__(256) void k_xtc_unpack(const unsigned char *__restr
     bits.init(streams + d.stream_off, cp.bitpos);
     int smallidx = (int)(cp.state & 0xFFu), run = (int)((cp.state >> 8) & 0xFFu);
     const float inv = d.inv_precision;
-    float *out = frames + (size_t)slots[blockIdx.y] * frame_stride + 3 * (size_t)cp.atom;
+    float *slot = frames + (size_t)slots[blockIdx.y] * frame_stride;
+    uint32_t o = cp.atom;          // next atom to be written (the slot is pair-tiled: gr_pos_store)
     uint32_t i = cp.atom;
     while (i < end_atom) {
         int cur[3];
@@ -107,18 +109,18 @@ __global__ __launch_bounds__(256) void k_xtc_unpack(const unsigned char *__restr
                 const int nxt[3] = { dl[0] + prev[0] - smallnum, dl[1] + prev[1] - smallnum, dl[2] + prev[2] - smallnum };
                 ++i;
                 if (k == 0) {   // the first small atom is stored AFTER its successor: emit it first
-                    out[0] = nxt[0] * inv; out[1] = nxt[1] * inv; out[2] = nxt[2] * inv;
-                    out[3] = prev[0] * inv; out[4] = prev[1] * inv; out[5] = prev[2] * inv;
-                    out += 6;
+                    gr_pos_store(slot, o, nxt[0] * inv, nxt[1] * inv, nxt[2] * inv);
+                    gr_pos_store(slot, o + 1, prev[0] * inv, prev[1] * inv, prev[2] * inv);
+                    o += 2;
                 } else {
-                    out[0] = nxt[0] * inv; out[1] = nxt[1] * inv; out[2] = nxt[2] * inv;
-                    out += 3;
+                    gr_pos_store(slot, o, nxt[0] * inv, nxt[1] * inv, nxt[2] * inv);
+                    o += 1;
                 }
                 prev[0] = nxt[0]; prev[1] = nxt[1]; prev[2] = nxt[2];
             }
         } else {
-            out[0] = cur[0] * inv; out[1] = cur[1] * inv; out[2] = cur[2] * inv;
-            out += 3;
+            gr_pos_store(slot, o, cur[0] * inv, cur[1] * inv, cur[2] * inv);
+            o += 1;
         }
         smallidx += change;
     }

@@ -248,9 +248,14 @@ class System:
         if st != OK:
             raise DeviceError("set_masses", self._err(st)[1], st)
 
-    def set_persistent(self, mode=1):
-        """RMSD-fit batches as one persistent LDS-resident kernel: 0 never, 1 where it pays, 2 whenever possible"""
-        self._lib.gr_ctx_set_persistent(self._ctx, int(mode))
+    TUNE = {"sub_batch": 1, "chunks": 2, "fit_wgs": 3, "fuse": 4, "two_pass": 5}
+
+    def set_tuning(self, **kw):
+        """gr_ctx_set_tuning: launch geometry / path selection of the batched RMSD calls (measurement only; same results)"""
+        for k, v in kw.items():
+            st = self._lib.gr_ctx_set_tuning(self._ctx, self.TUNE[k], int(v))
+            if st != OK:
+                raise DeviceError("set_tuning", self._err(st)[1], st)
 
     def set_center_onepass_min(self, min_atoms):
         """get_center / get_com of contiguous groups of at least `min_atoms` atoms in one pass (0 = always two passes)"""
@@ -586,7 +591,7 @@ class System:
     def profile_read(self):
         """-> {kernel: (ms_total, launches, frames)} for the batched RMSD path"""
         out = {}
-        for k, name in enumerate(("k_rmsd_accum", "k_rmsd_finalize", "k_fit", "k_rmsd_fit_persist")):
+        for k, name in enumerate(("k_sums_pk", "k_rmsd_finalize", "k_fit_pk")):
             ms = C.c_double(0); n = C.c_uint64(0); f = C.c_uint64(0)
             self._lib.gr_profile_read(self._ctx, k, C.byref(ms), C.byref(n), C.byref(f))
             out[name] = (ms.value, int(n.value), int(f.value))
@@ -642,10 +647,6 @@ class RMSDPlan:
 
     def last_fallbacks(self):
         return int(self._lib.gr_rmsd_plan_last_fallbacks(self._plan))
-
-    def last_persistent(self):
-        """True when the last fit batch ran as the persistent LDS-resident kernel"""
-        return bool(self._lib.gr_rmsd_plan_last_persistent(self._plan))
 
     def rmsd(self, first_slot=0, n_frames=1, return_rotation=False, raise_on_error=True):
         r = np.zeros(n_frames, np.float32); s = np.zeros(n_frames, np.int32); R = np.zeros((n_frames, 9), np.float32)

@@ -155,7 +155,7 @@ int gr_group_center(gr_ctx *ctx, uint32_t slot, const char *group, int kind, int
  * group's first atom + a proof that they are the images the reference would unwrap to.  Frames whose centre lies within the
  * proof's bound of a cell face additionally run the estimate pass (it selects the periodic copy the result lies in), frames
  * where the proof fails (groups wider than half a box) both passes -- one masked launch over the batch either way.
- * min_atoms = 0 switches the one-pass path off; default 4096 (env GR_COM_ONEPASS_MIN).  gr_center_fallbacks counts the
+ * min_atoms = 0 switches the one-pass path off; default 4096.  gr_center_fallbacks counts the
  * frames that needed those extra passes since the context was created. */
 int gr_ctx_set_center_onepass_min(gr_ctx *ctx, uint32_t min_atoms);
 uint64_t gr_center_fallbacks(const gr_ctx *ctx);
@@ -224,12 +224,16 @@ int gr_rmsd_batch_end(gr_rmsd_plan *plan, float *rmsd_out, int *status_out, floa
 uint32_t gr_rmsd_plan_last_fallbacks(const gr_rmsd_plan *plan);
 /* force the multi-pass exact path (parity testing of both paths) */
 int gr_rmsd_plan_force_exact(gr_rmsd_plan *plan, int on);
-/* RMSD-fit batches can run as ONE persistent kernel that keeps each frame in LDS between the sums and the transform
- * (DESIGN.md): mode 0 = never (accumulate -> finalize -> fit kernels), 1 = where it pays (contiguous selection, at least
- * 8 x 256 atoms per compute unit), 2 = whenever it is possible (testing).  Also: environment GR_PERSIST=0/1/2.
- * gr_rmsd_plan_last_persistent: 1 when the last fit batch of the plan took the persistent kernel. */
-int gr_ctx_set_persistent(gr_ctx *ctx, int mode);
-int gr_rmsd_plan_last_persistent(const gr_rmsd_plan *plan);
+/* Launch geometry and path selection of the batched RMSD calls.  Nothing in the library reads the environment for these:
+ * results of a call depend on its arguments and on what the caller set here, never on the caller's environment.
+ *   GR_TUNE_SUB_BATCH  frames per sums -> fit launch group (1 .. 1024, default 256)
+ *   GR_TUNE_CHUNKS     workgroups per frame of the reduction kernels (0 = automatic)
+ *   GR_TUNE_FIT_WGS    workgroups per frame of the fit kernel (0 = automatic: one 256-atom tile per wave)
+ *   GR_TUNE_FUSE       1 (default): the sums kernel's last workgroup per frame closes the frame; 0: separate finalize launch
+ *   GR_TUNE_TWO_PASS   1 (default): RMSD-fit = sums pass + fit pass that evaluates the rmsd; 0: closed-form single-pass rmsd
+ * Every setting gives the same results within the parity tolerance (tests/test_gpu_tuning.py); they exist for measurement. */
+enum { GR_TUNE_SUB_BATCH = 1, GR_TUNE_CHUNKS = 2, GR_TUNE_FIT_WGS = 3, GR_TUNE_FUSE = 4, GR_TUNE_TWO_PASS = 5 };
+int gr_ctx_set_tuning(gr_ctx *ctx, int key, int64_t value);
 
 /* ---------------------------------------------------------------- text front end: gro structures, ndx index groups (host side)
  * read_gro (src/io/gro_io/structure.rs:120-231, gro_io/mod.rs:21-72) and Groups::from_ndx (src/io/ndx_io.rs:104-230): what is
@@ -379,7 +383,7 @@ int gr_xtc_read_frames_device(const gr_xtc *xtc, uint64_t first_frame, uint32_t 
 int gr_timer_start(gr_ctx *ctx);
 int gr_timer_stop(gr_ctx *ctx, float *milliseconds);
 /* Per-kernel HIP-event profile of the batched RMSD path, recorded on the context's stream around
- * each launch while enabled: kernel 0 = k_rmsd_accum, 1 = k_rmsd_finalize, 2 = k_fit, 3 = k_rmsd_fit_persist.  Enabling resets
+ * each launch while enabled: kernel 0 = sums pass (k_sums_pk / k_rmsd_accum), 1 = k_rmsd_finalize (separate launch only), 2 = fit pass (k_fit_pk).  Enabling resets
  * the counters.  ms_total / launches = average launch duration; frames = frames those launches covered. */
 int gr_profile_enable(gr_ctx *ctx, int on);
 int gr_profile_read(const gr_ctx *ctx, int kernel, double *ms_total, uint64_t *launches, uint64_t *frames);

@@ -145,7 +145,7 @@ def test_full_size_properties_1e6_atoms(G):
     plan.force_exact(False)
     assert np.abs(r0 - r_exact).max() <= 2e-6                      # single-pass == multi-pass at full size
     rf, _ = plan.rmsd_fit(0, nf)
-    assert np.abs(rf - r0).max() <= 2e-6   # (persistent kernel: same arithmetic, another summation tree)
+    assert np.abs(rf - r0).max() <= 2e-6   # the fit pass's direct sum vs the closed form of the rmsd-only pass
     # idempotence: a fitted frame is already optimally superposed -> same RMSD, identity rotation
     r1, _, R1 = plan.rmsd(0, nf, return_rotation=True)
     assert np.abs(r1 - r0).max() <= TOL
