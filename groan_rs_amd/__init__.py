@@ -6,7 +6,7 @@ the tests and the benchmark; importing it does not load the library (so CPU-only
 it), but every operation does and fails loudly when the library is missing.
 """
 from . import _lib
-from .system import (AtomContainer, AtomError, DeviceError, Dimension, GroanError, GroupError, RMSDError,
+from .system import (AtomContainer, AtomError, AtomIterator, DeviceError, Dimension, GroanError, GroupError, RMSDError,
                      RMSDPlan, SimBoxError, System, pinned_array, pinned_free)
 from .traj import (FrameAnalyze, FrameConvert, FrameConvertAnalyze, RMSDConverterAnalyzer, TrajAnalyzer,
                    TrajAnalysisError, TrajConverter, TrajConverterAnalyzer, TrajReader)
@@ -18,7 +18,7 @@ from .shapes import Cylinder, Rectangular, Shape, Sphere, TriangularPrism
 from .parallel import ParallelTrajData, gather_per_frame, interleave, shard_frames, traj_iter_map_reduce
 
 __all__ = [
-    "AtomContainer", "AtomError", "DeviceError", "Dimension", "GroanError", "GroupError", "RMSDError", "RMSDPlan",
+    "AtomContainer", "AtomError", "AtomIterator", "DeviceError", "Dimension", "GroanError", "GroupError", "RMSDError", "RMSDPlan",
     "SimBoxError", "System", "pinned_array", "pinned_free", "FrameAnalyze", "FrameConvert", "FrameConvertAnalyze", "RMSDConverterAnalyzer",
     "TrajAnalyzer", "TrajAnalysisError", "TrajConverter", "TrajConverterAnalyzer", "TrajReader",
     "XtcError", "XtcFile", "XtcWriter", "ParseGroError", "ParseNdxError", "Structure", "read_ndx_groups", "system_from_gro", "system_read_ndx", "Cylinder", "Rectangular", "Shape", "Sphere", "TriangularPrism", "ParallelTrajData", "gather_per_frame", "interleave", "shard_frames", "traj_iter_map_reduce",

@@ -62,6 +62,12 @@ SIGNATURES = {
     "gr_host_alloc": (C.c_void_p, [C.c_size_t]),
     "gr_host_free": (None, [C.c_void_p]),
     "gr_group_center": (C.c_int, [C.c_void_p, C.c_uint32, C.c_char_p, C.c_int, C.c_int, C.c_void_p]),
+    "gr_sel_center": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p]),
+    "gr_sel_translate": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "gr_sel_wrap": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "gr_sel_all_distances": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t]),
+    "gr_sel_filter_geometry": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t,
+                                         C.POINTER(C.c_size_t), c_u64p]),
     "gr_group_distance": (C.c_int, [C.c_void_p, C.c_uint32, C.c_char_p, C.c_char_p, C.c_int, c_f32p]),
     "gr_atoms_distance": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64, C.c_int, c_f32p]),
     "gr_group_all_distances": (C.c_int, [C.c_void_p, C.c_uint32, C.c_char_p, C.c_char_p, C.c_int, C.c_void_p, C.c_size_t]),

@@ -730,20 +730,16 @@ void *gr_host_alloc(size_t bytes) { void *p = nullptr; return hipHostMalloc(&p, 
 void gr_host_free(void *p) { if (p) (void)hipHostFree(p); }
 
 /* ------------------------------------------------------------ centres */
-int gr_group_center(gr_ctx *c, uint32_t slot, const char *group, int kind, int weighted, float out[3]) try {
-    int st = slot_check(c, slot); if (st) return st;
-    (void)hipSetDevice(c->device);
-    const Group *g = find_group(c, group);
-    if (!g) return fail(c, GR_E_GROUP_NOT_FOUND, group ? group : "(null)");
-    if (g->n == 0) return fail(c, GR_E_EMPTY_GROUP, group);               // analysis.rs:52-55
-    if (kind != GR_CENTER_NAIVE) { st = box_check(c, slot); if (st) return st; }
+// centre of one selection of one frame: the device work shared by the named-group calls (System::group_get_center ...,
+// analysis.rs:52-320) and the anonymous-selection calls (the iterator-level AtomIteratorWithBox::get_center ..., iterators.rs:886-1438)
+static int center_core(gr_ctx *c, uint32_t slot, const Group &g, int kind, int weighted, float out[3]) {
+    int st;
     SlotUse use(c, slot);
-    const GrSel sel = make_sel(*g);
+    const GrSel sel = make_sel(g);
     st = state_reset(c, 1); if (st) return st;
     if (kind == GR_CENTER_NAIVE) st = center_stage(c, slot, 1, sel, 0, weighted, 0, 1);          // position first (:946-958)
     else if (kind == GR_CENTER_ESTIMATE) st = center_stage(c, slot, 1, sel, 1, weighted, 1, 1);  // mass first (:1324-1339)
-    else if (kind == GR_CENTER_PBC) st = center_onepass_ok(c, sel) ? pbc_center_onepass(c, slot, 1, sel, weighted) : pbc_center_stages(c, slot, 1, sel, weighted);
-    else return fail(c, GR_E_INVALID_ARG, "unknown centre kind");
+    else st = center_onepass_ok(c, sel) ? pbc_center_onepass(c, slot, 1, sel, weighted) : pbc_center_stages(c, slot, 1, sel, weighted);
     if (st) return st;
     st = fetch_states(c, 1); if (st) return st;
     if (c->state_host[0].status == GR_ST_FALLBACK || c->state_host[0].status == GR_ST_AMBIG) {
@@ -753,6 +749,17 @@ int gr_group_center(gr_ctx *c, uint32_t slot, const char *group, int kind, int w
     st = frame_status(c, c->state_host[0]); if (st) return st;
     if (out) { out[0] = c->state_host[0].com[0]; out[1] = c->state_host[0].com[1]; out[2] = c->state_host[0].com[2]; }
     return GR_OK;
+}
+
+int gr_group_center(gr_ctx *c, uint32_t slot, const char *group, int kind, int weighted, float out[3]) try {
+    int st = slot_check(c, slot); if (st) return st;
+    (void)hipSetDevice(c->device);
+    const Group *g = find_group(c, group);
+    if (!g) return fail(c, GR_E_GROUP_NOT_FOUND, group ? group : "(null)");
+    if (g->n == 0) return fail(c, GR_E_EMPTY_GROUP, group);               // analysis.rs:52-55
+    if (kind != GR_CENTER_NAIVE && kind != GR_CENTER_ESTIMATE && kind != GR_CENTER_PBC) return fail(c, GR_E_INVALID_ARG, "unknown centre kind");
+    if (kind != GR_CENTER_NAIVE) { st = box_check(c, slot); if (st) return st; }
+    return center_core(c, slot, *g, kind, weighted, out);
 } catch (...) { return gr_abi_guard(); }
 
 /* ------------------------------------------------------------ distances */
@@ -946,54 +953,61 @@ int gr_shape_inside(const gr_shape *s, const float point[3], const float box9[9]
     if (naive) { *inside = gr_shape_inside_naive(d, point[0], point[1], point[2]) ? 1 : 0; return GR_OK; }
     GrBox b;
     if (!gr_box_setup(box9, &b)) return GR_E_ZERO_BOX;
-    if (!b.ortho) return GR_E_NOT_ORTHOGONAL;
-    *inside = gr_shape_inside_pbc(d, point[0], point[1], point[2], b) ? 1 : 0;
+    *inside = gr_shape_inside_pbc(d, point[0], point[1], point[2], b) ? 1 : 0;   // (non-orthogonal boxes: the image-enumeration extension, gr_shape.h)
     return GR_OK;
 } catch (...) { return gr_abi_guard(); }
+// atoms of `g` (in its iteration order) that have a position and lie inside every shape -> `picked`
+static int geometry_filter(gr_ctx *c, uint32_t slot, const Group &g, const gr_shape *shapes, size_t ns, int naive, std::vector<uint64_t> &picked) {
+    if (ns > GR_MAX_SHAPES || (ns && !shapes)) return fail(c, GR_E_INVALID_ARG, "too many shapes");
+    GrShapeSet set; set.n = (int)ns; set.naive = naive ? 1 : 0;
+    for (size_t q = 0; q < ns; ++q) if (!shape_to_dev(shapes[q], naive, &set.s[q])) return fail(c, GR_E_INVALID_ARG, "invalid shape");
+    picked.clear();
+    if (!g.n) return GR_OK;
+    const GrSel sel = make_sel(g);
+    const size_t words = ((size_t)g.n + 63) / 64;
+    unsigned long long *mask_dev = nullptr;
+    HIPCHK(c, hipMalloc(&mask_dev, words * sizeof(unsigned long long)));
+    {
+        SlotUse use(c, slot);
+        k_shape_mask<<<dim3((unsigned)((g.n + 255) / 256)), dim3(256), 0, c->stream>>>(c->frames + (size_t)slot * c->frame_stride, sel, c->boxes_host[slot], set, mask_dev);
+    }
+    std::vector<unsigned long long> mask(words);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(mask.data(), mask_dev, words * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(mask_dev);
+    if (e != hipSuccess) { c->err = std::string("geometry selection: ") + hipGetErrorString(e); return GR_E_HIP; }
+    // ordinal -> atom index in the source group's iteration order (AtomContainer::iter, container.rs:381-411)
+    size_t j = 0;
+    for (const auto &blk : g.blocks)
+        for (uint64_t a = blk.first; a <= blk.second; ++a, ++j)
+            if ((mask[j >> 6] >> (j & 63)) & 1ull) picked.push_back(a);
+    return GR_OK;
+}
+// the box gate of Shape::inside with PBC (groups.rs:104-110 / the iterator's get_simbox_unwrap): a usable box; in strict mode orthogonal
+static int geometry_box_check(gr_ctx *c, uint32_t slot) {
+    if (c->box_status[slot] == GR_E_NO_BOX) return fail(c, GR_E_NO_BOX, "simulation box does not exist");   // :104-106
+    if (c->box_status[slot] != GR_OK) return fail(c, c->box_status[slot], "invalid simulation box");
+    if (c->strict && !c->boxes_host[slot].ortho) return fail(c, GR_E_NOT_ORTHOGONAL, "simulation box is not orthogonal"); // :108-110
+    return GR_OK;
+}
 int gr_group_create_from_geometries(gr_ctx *c, uint32_t slot, const char *name, const char *source, const gr_shape *shapes, size_t ns, int naive) try {
     int st = slot_check(c, slot); if (st) return st;
     (void)hipSetDevice(c->device);
     if (!name_is_valid(name)) return fail(c, GR_E_INVALID_NAME, name ? name : "(null)");                 // groups.rs:100-102
-    if (c->box_status[slot] == GR_E_NO_BOX) return fail(c, GR_E_NO_BOX, "simulation box does not exist");   // :104-106
-    if (c->box_status[slot] != GR_OK) return fail(c, c->box_status[slot], "invalid simulation box");
-    if (!c->boxes_host[slot].ortho) return fail(c, GR_E_NOT_ORTHOGONAL, "simulation box is not orthogonal"); // :108-110
+    st = geometry_box_check(c, slot); if (st) return st;
     const Group *g = find_group(c, source);
     if (!g) return fail(c, GR_E_GROUP_NOT_FOUND, source ? source : "(null)");                               // InvalidQuery(GroupNotFound)
-    if (ns > GR_MAX_SHAPES || (ns && !shapes)) return fail(c, GR_E_INVALID_ARG, "too many shapes");
-    GrShapeSet set; set.n = (int)ns; set.naive = naive ? 1 : 0;
-    for (size_t q = 0; q < ns; ++q) if (!shape_to_dev(shapes[q], naive, &set.s[q])) return fail(c, GR_E_INVALID_ARG, "invalid shape");
     std::vector<uint64_t> picked;
-    if (g->n) {
-        const GrSel sel = make_sel(*g);
-        const size_t words = ((size_t)g->n + 63) / 64;
-        unsigned long long *mask_dev = nullptr;
-        HIPCHK(c, hipMalloc(&mask_dev, words * sizeof(unsigned long long)));
-        {
-            SlotUse use(c, slot);
-            k_shape_mask<<<dim3((unsigned)((g->n + 255) / 256)), dim3(256), 0, c->stream>>>(c->frames + (size_t)slot * c->frame_stride, sel, c->boxes_host[slot], set, mask_dev);
-        }
-        std::vector<unsigned long long> mask(words);
-        hipError_t e = hipGetLastError();
-        if (e == hipSuccess) e = hipMemcpyAsync(mask.data(), mask_dev, words * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        (void)hipFree(mask_dev);
-        if (e != hipSuccess) { c->err = std::string("geometry selection: ") + hipGetErrorString(e); return GR_E_HIP; }
-        // ordinal -> atom index in the source group's iteration order (AtomContainer::iter, container.rs:381-411)
-        size_t j = 0;
-        for (const auto &blk : g->blocks)
-            for (uint64_t a = blk.first; a <= blk.second; ++a, ++j)
-                if ((mask[j >> 6] >> (j & 63)) & 1ull) picked.push_back(a);
-    }
+    st = geometry_filter(c, slot, *g, shapes, ns, naive, picked); if (st) return st;
     return install_group(c, name, grc::from_indices(picked, c->n));
 } catch (...) { return gr_abi_guard(); }
 
 /* ------------------------------------------------------------ translate / wrap / centre */
-static int translate_impl(gr_ctx *c, uint32_t slot, const char *group, const float *v, int use_state, int dim_mask) {
-    const Group *g = find_group(c, group ? group : "all");
-    if (!g) return fail(c, GR_E_GROUP_NOT_FOUND, group);
+static int translate_core(gr_ctx *c, uint32_t slot, const Group &g, const float *v, int use_state, int dim_mask) {
     int st = box_check(c, slot); if (st) return st;
-    if (g->n == 0) return GR_OK;
-    const GrSel sel = make_sel(*g);
+    if (g.n == 0) return GR_OK;
+    const GrSel sel = make_sel(g);
     SlotUse use(c, slot);
     HIPCHK(c, hipMemsetAsync(c->bad_dev, 0xFF, 4 * sizeof(uint32_t), c->stream));
     const uint64_t units = sel.contiguous ? ((uint64_t)sel.n + 3) / 4 + 128 : sel.n;
@@ -1004,6 +1018,11 @@ static int translate_impl(gr_ctx *c, uint32_t slot, const char *group, const flo
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->bad_host[0] != GR_NOIDX) return fail(c, GR_E_NO_POSITION, "atom has no position", c->bad_host[0]);
     return GR_OK;
+}
+static int translate_impl(gr_ctx *c, uint32_t slot, const char *group, const float *v, int use_state, int dim_mask) {
+    const Group *g = find_group(c, group ? group : "all");
+    if (!g) return fail(c, GR_E_GROUP_NOT_FOUND, group);
+    return translate_core(c, slot, *g, v, use_state, dim_mask);
 }
 
 int gr_group_translate(gr_ctx *c, uint32_t slot, const char *group, const float v[3]) try {
@@ -1035,6 +1054,78 @@ int gr_atoms_center(gr_ctx *c, uint32_t slot, const char *ref_group, int dim, in
     return translate_impl(c, slot, "all", nullptr, 1, mask[dim]);
 } catch (...) { return gr_abi_guard(); }
 
+/* ------------------------------------------------------------ anonymous selections (the iterator-level surface) */
+// a selection handed over as AtomContainer blocks (container.rs:23-31) instead of a group name: validated, expanded for the
+// device when it is not one block, used for one call, released
+struct TempSel {
+    gr_ctx *c; Group g; bool ok = false;
+    TempSel(gr_ctx *ctx, const uint64_t *s, const uint64_t *e, size_t n, int *st) : c(ctx) {
+        if (n && (!s || !e)) { *st = fail(c, GR_E_INVALID_ARG, "selection blocks are NULL"); return; }
+        *st = group_build(c, grc::make(s, e, n), &g);
+        ok = *st == GR_OK;
+    }
+    ~TempSel() { if (ok && g.idx_dev) { (void)hipStreamSynchronize(c->stream); (void)hipFree(g.idx_dev); } }
+};
+
+int gr_sel_center(gr_ctx *c, uint32_t slot, const uint64_t *start, const uint64_t *end, size_t n_blocks, int kind, int weighted, float out[3]) try {
+    int st = slot_check(c, slot); if (st) return st;
+    (void)hipSetDevice(c->device);
+    if (kind != GR_CENTER_NAIVE && kind != GR_CENTER_ESTIMATE && kind != GR_CENTER_PBC) return fail(c, GR_E_INVALID_ARG, "unknown centre kind");
+    if (kind != GR_CENTER_NAIVE) { st = box_check(c, slot); if (st) return st; }      // simbox_check first (iterators.rs:1153,1238,1315,1405)
+    TempSel sel(c, start, end, n_blocks, &st); if (st) return st;
+    if (sel.g.n == 0) { if (out) out[0] = out[1] = out[2] = NAN; return GR_OK; }      // an empty iterator yields NaN, not an error (:1186-1188)
+    return center_core(c, slot, sel.g, kind, weighted, out);
+} catch (...) { return gr_abi_guard(); }
+
+int gr_sel_translate(gr_ctx *c, uint32_t slot, const uint64_t *start, const uint64_t *end, size_t n_blocks, const float v[3]) try {
+    int st = slot_check(c, slot); if (st) return st;
+    if (!v) return fail(c, GR_E_INVALID_ARG, "vector is NULL");
+    (void)hipSetDevice(c->device);
+    st = box_check(c, slot); if (st) return st;                                          // :1521-1522
+    TempSel sel(c, start, end, n_blocks, &st); if (st) return st;
+    return translate_core(c, slot, sel.g, v, 0, 7);
+} catch (...) { return gr_abi_guard(); }
+
+int gr_sel_wrap(gr_ctx *c, uint32_t slot, const uint64_t *start, const uint64_t *end, size_t n_blocks) try {
+    const float z[3] = { 0.f, 0.f, 0.f };
+    return gr_sel_translate(c, slot, start, end, n_blocks, z);                           // :1548-1553
+} catch (...) { return gr_abi_guard(); }
+
+int gr_sel_all_distances(gr_ctx *c, uint32_t slot, const uint64_t *s1, const uint64_t *e1, size_t n1, const uint64_t *s2, const uint64_t *e2, size_t n2,
+                         int dim, float *out_host, size_t cap) try {
+    int st = slot_check(c, slot); if (st) return st;
+    (void)hipSetDevice(c->device);
+    st = box_check(c, slot); if (st) return st;
+    if (dim < 0 || dim > 7) return fail(c, GR_E_INVALID_ARG, "bad dimension");
+    TempSel a(c, s1, e1, n1, &st); if (st) return st;
+    TempSel b(c, s2, e2, n2, &st); if (st) return st;
+    const size_t total = (size_t)a.g.n * b.g.n;
+    if (total > cap || (total && !out_host)) return fail(c, GR_E_INVALID_ARG, "output buffer too small");
+    st = pairdist_reserve(c, total); if (st) return st;
+    st = pairdist_run(c, slot, make_sel(a.g), make_sel(b.g), dim, c->pd_out); if (st) return st;
+    if (total) {
+        HIPCHK(c, hipMemcpyAsync(out_host, c->pd_out, total * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    return GR_OK;
+} catch (...) { return gr_abi_guard(); }
+
+int gr_sel_filter_geometry(gr_ctx *c, uint32_t slot, const uint64_t *start, const uint64_t *end, size_t n_blocks, const gr_shape *shapes, size_t n_shapes, int naive,
+                           uint64_t *out_start, uint64_t *out_end, size_t cap_blocks, size_t *n_out_blocks, uint64_t *n_out_atoms) try {
+    int st = slot_check(c, slot); if (st) return st;
+    (void)hipSetDevice(c->device);
+    if (!naive) { st = geometry_box_check(c, slot); if (st) return st; }                 // filter_geometry panics without a box (:1098); an error here
+    TempSel sel(c, start, end, n_blocks, &st); if (st) return st;
+    std::vector<uint64_t> picked;
+    st = geometry_filter(c, slot, sel.g, shapes, n_shapes, naive, picked); if (st) return st;
+    const std::vector<grc::Block> blocks = grc::from_indices(picked, c->n);
+    if (n_out_blocks) *n_out_blocks = blocks.size();
+    if (n_out_atoms) *n_out_atoms = picked.size();
+    if (blocks.size() > cap_blocks) return (out_start || out_end) ? fail(c, GR_E_INVALID_ARG, "block buffers too small") : GR_OK;   // NULL buffers: count only
+    if (out_start && out_end) grc::store(blocks, out_start, out_end);
+    return GR_OK;
+} catch (...) { return gr_abi_guard(); }
+
 /* ------------------------------------------------------------ cut-off pair search */
 int gr_group_pairs_within(gr_ctx *c, uint32_t slot, const char *g1, const char *g2, float cutoff, uint64_t max_pairs,
                           uint32_t *i_out, uint32_t *j_out, float *d_out, uint64_t *n_pairs) try {
@@ -1045,7 +1136,7 @@ int gr_group_pairs_within(gr_ctx *c, uint32_t slot, const char *g1, const char *
     if (!(cutoff > 0.0f)) return fail(c, GR_E_INVALID_ARG, "cell size (cut-off) must be positive");              // cellgrid.rs:323-325
     if (c->box_status[slot] == GR_E_NO_BOX) return fail(c, GR_E_NO_BOX, "simulation box does not exist");            // check_box :411-430
     if (c->box_status[slot] != GR_OK) return fail(c, c->box_status[slot], "invalid simulation box");
-    if (!c->boxes_host[slot].ortho) return fail(c, GR_E_NOT_ORTHOGONAL, "simulation box is not orthogonal");
+    if (c->strict && !c->boxes_host[slot].ortho) return fail(c, GR_E_NOT_ORTHOGONAL, "simulation box is not orthogonal");   // the reference's gate (cellgrid.rs:423)
     if (n_pairs) *n_pairs = 0;
     if (a->n == 0 || b->n == 0) return GR_OK;
     const GrBox &box = c->boxes_host[slot];

@@ -5,7 +5,7 @@
 // no cell visited twice) as its consumer uses it (src/system/hbonds.rs:248-265: every candidate from the neighbouring cells,
 // self pairs skipped, kept when distance <= max_distance).  The grid only prunes: the result is the set of pairs
 // {(i, j): i in g1, j in g2, i != j, distance(x_j, x_i) <= cutoff}, reported by i then j -- the reference leaves the visiting
-// order undefined.  Orthogonal boxes only, like the reference.
+// order undefined.  Orthogonal boxes as in the reference; triclinic boxes through a grid in fractional coordinates (below).
 //
 // Device pipeline (all on the context's stream):
 //   k_cg_assign   group-2 atoms -> cell id                                        (12 B/atom read)
@@ -19,24 +19,38 @@
 #include "gr_kernels.h"
 
 struct GrCellGrid {
-    uint32_t nc[3];          // cells per axis
-    float inv_cell[3];       // 1 / cell length
+    uint32_t nc[3];          // cells per axis (orthorhombic: along x, y, z; triclinic: along the box vectors a, b, c)
+    float inv_cell[3];       // orthorhombic: 1 / cell length; triclinic: cells per unit of the fractional coordinate (= nc)
     uint32_t ncells;
+    int tric;
 };
 
-// cells per axis for a cut-off: the cell is at least (1 + 1e-5) x cutoff long so that rounding at a cell border can never
-// put two atoms within the cut-off two cells apart (the reference bins with the bare cut-off; the pruned set is the same)
+// cells per axis for a cut-off: the cell is at least (1 + 1e-5) x cutoff thick so that rounding at a cell border can never
+// put two atoms within the cut-off two cells apart (the reference bins with the bare cut-off; the pruned set is the same).
+// Triclinic boxes (extension; the reference's CellGrid needs an orthogonal box, cellgrid.rs:411-430): the grid lives in
+// FRACTIONAL coordinates -- nc_a slabs between lattice planes parallel to (b, c), and so on -- and a slab's thickness is the
+// cell's perpendicular height over nc: h_a = V / |b x c|, h_b = V / |c x a|, h_c = V / |a x b| = cz.  Two atoms whose
+// minimum-image distance is within the cut-off then sit in the same or in periodically adjacent slabs along every axis, so
+// the 27-cell walk of the orthorhombic grid finds them.
 static inline GrCellGrid gr_cellgrid_make(const GrBox &b, float cutoff) {
     GrCellGrid g;
-    const float L[3] = { b.ax, b.by, b.cz };
     const float cs = cutoff * 1.00001f;
     g.ncells = 1;
+    g.tric = b.ortho ? 0 : 1;
+    double h[3] = { b.ax, b.by, b.cz };
+    if (g.tric) {
+        const double ax = b.ax, bx = b.bx, by = b.by, cx = b.cx, cy = b.cy, cz = b.cz, V = ax * by * cz;
+        const double bc[3] = { by * cz, -bx * cz, bx * cy - by * cx };          // b x c
+        h[0] = V / sqrt(bc[0] * bc[0] + bc[1] * bc[1] + bc[2] * bc[2]);
+        h[1] = V / (ax * sqrt(cz * cz + cy * cy));                              // |c x a| = ax sqrt(cy^2 + cz^2)
+        h[2] = cz;
+    }
     for (int a = 0; a < 3; ++a) {
-        float n = floorf(L[a] / cs);
+        float n = floorf((float)h[a] / cs);
         if (!(n >= 1.0f)) n = 1.0f;
         if (n > 1024.0f) n = 1024.0f;    // bounded table: more cells than this only make the lists shorter than one atom
         g.nc[a] = (uint32_t)n;
-        g.inv_cell[a] = (float)g.nc[a] / L[a];
+        g.inv_cell[a] = g.tric ? (float)g.nc[a] : (float)g.nc[a] / (float)h[a];
         g.ncells *= g.nc[a];
     }
     return g;
@@ -44,7 +58,11 @@ static inline GrCellGrid gr_cellgrid_make(const GrBox &b, float cutoff) {
 
 __device__ __forceinline__ void gr_cg_cell_of(float x, float y, float z, const GrBox &box, const GrCellGrid &g, uint32_t (&c)[3]) {
     gr_wrap(x, y, z, box);                                       // pos.wrap(simbox), cellgrid.rs:463
-    const float p[3] = { x, y, z };
+    float p[3] = { x, y, z };
+    if (g.tric) {   // fractional coordinates of the wrapped position, taken modulo 1 (the brick is not the parallelepiped)
+        const float fc = z / box.cz, fb = (y - fc * box.cy) / box.by, fa = (x - fb * box.bx - fc * box.cx) / box.ax;
+        p[0] = fa - floorf(fa); p[1] = fb - floorf(fb); p[2] = fc - floorf(fc);
+    }
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         int k = (int)floorf(p[a] * g.inv_cell[a]);

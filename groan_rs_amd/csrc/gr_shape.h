@@ -4,7 +4,7 @@
 // (src/structures/group.rs:119-175: an atom without a position is inside nothing; with several shapes it must be inside
 // all of them).  The predicates are compositions of gr_distance (1-D distances are signed), so their truth values are
 // the reference's wherever gr_distance is bit-compatible (orthorhombic boxes, which is all the reference accepts here:
-// src/system/groups.rs:104-110).
+// src/system/groups.rs:104-110).  Non-orthogonal boxes: gr_shape_inside_tric below.
 #pragma once
 #include "gr_math.h"
 #if defined(__HIPCC__)
@@ -49,8 +49,63 @@ GR_HD float gr_prism_sign(float u1, float v1, float u2, float v2, float u3, floa
     return a - b;
 }
 
+// Non-orthogonal boxes (an extension: the reference needs an orthogonal box here, groups.rs:108-110).  Definition: a point is
+// inside a shape under periodic boundary conditions iff SOME lattice image of the point lies inside the shape taken as a plain
+// (non-periodic) body anchored at its position -- which is what the orthorhombic arithmetic of the reference computes for its
+// boxes, where "some image" can be found per axis (`if d < 0 { d += L }`).  In a triclinic cell the lattice vectors couple the
+// axes, so the images are enumerated: the difference to the anchor is reduced into the brick about it (k = rint(d / L) along
+// c, b, a) and the 125 images i a + j b + k c, |i|,|j|,|k| <= 2, around it are tested (the shapes are smaller than the cell).
+// The boundary conventions are the PBC variants' (Rectangular and Cylinder closed, the prism's height half-open).  Every
+// operation is rounded on its own, in this order, on the device and in the oracle alike.
+GR_HD bool gr_shape_free_inside(const GrShapeDev &s, float ex, float ey, float ez) {
+#pragma clang fp contract(off)
+    switch (s.kind) {
+    case GR_SH_RECTANGULAR:
+        return ex >= 0.0f && ex <= s.a && ey >= 0.0f && ey <= s.b && ez >= 0.0f && ez <= s.c;
+    case GR_SH_CYLINDER: {
+        const float along = s.orientation == 1 ? ex : (s.orientation == 2 ? ey : ez);
+        if (!(along >= 0.0f && along <= s.b)) return false;
+        const float planar = s.orientation == 1 ? gr_mag3_exact(0.0f, ey, ez) : (s.orientation == 2 ? gr_mag3_exact(ex, 0.0f, ez) : gr_mag3_exact(ex, ey, 0.0f));
+        return planar <= s.a;
+    }
+    case GR_SH_PRISM: {
+        const float along = s.orientation == 1 ? ex : (s.orientation == 2 ? ey : ez);
+        if (!(along >= 0.0f && along < s.a)) return false;
+        const float x = s.px + ex, y = s.py + ey, z = s.pz + ez;      // the image itself, for the base triangle's signs
+        float pu, pv, u1, v1, u2, v2, u3, v3;
+        if (s.plane == 4) { pu = x; pv = y; u1 = s.px; v1 = s.py; u2 = s.b2x; v2 = s.b2y; u3 = s.b3x; v3 = s.b3y; }
+        else if (s.plane == 5) { pu = x; pv = z; u1 = s.px; v1 = s.pz; u2 = s.b2x; v2 = s.b2z; u3 = s.b3x; v3 = s.b3z; }
+        else { pu = y; pv = z; u1 = s.py; v1 = s.pz; u2 = s.b2y; v2 = s.b2z; u3 = s.b3y; v3 = s.b3z; }
+        const float d1 = gr_prism_sign(pu, pv, u1, v1, u2, v2), d2 = gr_prism_sign(pu, pv, u2, v2, u3, v3), d3 = gr_prism_sign(pu, pv, u3, v3, u1, v1);
+        const bool has_neg = (d1 < 0.0f) || (d2 < 0.0f) || (d3 < 0.0f), has_pos = (d1 > 0.0f) || (d2 > 0.0f) || (d3 > 0.0f);
+        return !(has_neg && has_pos);
+    }
+    }
+    return false;
+}
+GR_HD bool gr_shape_inside_tric(const GrShapeDev &s, float x, float y, float z, const GrBox &b) {
+#pragma clang fp contract(off)
+    float dx = x - s.px, dy = y - s.py, dz = z - s.pz;
+    float k = rintf(dz / b.cz);
+    dx = dx - k * b.cx; dy = dy - k * b.cy; dz = dz - k * b.cz;
+    k = rintf(dy / b.by);
+    dx = dx - k * b.bx; dy = dy - k * b.by;
+    k = rintf(dx / b.ax);
+    dx = dx - k * b.ax;
+    for (int kc = -2; kc <= 2; ++kc)
+        for (int kb = -2; kb <= 2; ++kb)
+            for (int ka = -2; ka <= 2; ++ka) {
+                const float tx = ((float)ka * b.ax + (float)kb * b.bx) + (float)kc * b.cx;
+                const float ty = (float)kb * b.by + (float)kc * b.cy;
+                const float tz = (float)kc * b.cz;
+                if (gr_shape_free_inside(s, dx + tx, dy + ty, dz + tz)) return true;
+            }
+    return false;
+}
+
 template <int NC = GR_MAX_CAND>
 GR_HD bool gr_shape_inside_pbc(const GrShapeDev &s, float x, float y, float z, const GrBox &box) {
+    if (!box.ortho && s.kind != GR_SH_SPHERE) return gr_shape_inside_tric(s, x, y, z, box);   // (the sphere is the minimum-image distance either way)
     switch (s.kind) {
     case GR_SH_SPHERE:   // :114-116
         return gr_distance<NC, true>(x, y, z, s.px, s.py, s.pz, 7, box) < s.a;

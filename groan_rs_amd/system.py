@@ -166,6 +166,101 @@ class AtomContainer:
 
 
 # ----------------------------------------------------------------------------- System
+class AtomIterator:
+    """Iterator-level surface of the reference: AtomIterator / MutAtomIterator / FilterAtomIterator / Union / Intersection
+    (src/structures/iterators.rs:28-46,350-402,1053-1604) -- an AtomContainer + the system (and slot) whose box and atoms it
+    walks.  Obtained from System.group_iter / atoms_iter / selection_iter / container_iter (src/system/iterating.rs:43-140).
+    Every method is ONE call into the C ABI's anonymous-selection entry points (gr_sel_*): the kernels take the blocks directly.
+
+    Error behaviour is the iterator traits', not System's: box first (AtomError::InvalidSimBox), then the first atom without
+    position / mass; an EMPTY iterator is not an error, its centre is (NaN, NaN, NaN) (iterators.rs:1186-1188)."""
+
+    def __init__(self, system, container, slot=0):
+        self.system, self.container, self.slot = system, container, slot
+
+    def _se(self):
+        b = np.asarray(self.container.blocks, dtype=np.uint64).reshape(-1, 2)
+        return np.ascontiguousarray(b[:, 0]), np.ascontiguousarray(b[:, 1]), b.shape[0]
+
+    def __iter__(self):
+        return iter(self.container)
+
+    def __len__(self):
+        return self.container.get_n_atoms()
+
+    def get_n_atoms(self):
+        return self.container.get_n_atoms()
+
+    def _center(self, kind, weighted):
+        s, e, n = self._se()
+        out = np.zeros(3, np.float32)
+        st = self.system._lib.gr_sel_center(self.system._ctx, self.slot, _ptr(s), _ptr(e), n, kind, weighted, _ptr(out))
+        if st != OK:
+            self.system._raise_atom(st)
+        return out
+
+    def get_center_naive(self): return self._center(_lib.CENTER_NAIVE, 0)       # iterators.rs:886-903
+    def get_com_naive(self): return self._center(_lib.CENTER_NAIVE, 1)          # :946-967
+    def estimate_center(self): return self._center(_lib.CENTER_ESTIMATE, 0)     # :1152-1191
+    def get_center(self): return self._center(_lib.CENTER_PBC, 0)               # :1237-1266
+    def estimate_com(self): return self._center(_lib.CENTER_ESTIMATE, 1)        # :1314-1357
+    def get_com(self): return self._center(_lib.CENTER_PBC, 1)                  # :1404-1438
+
+    def _filter(self, geometries, naive):
+        from .shapes import pack
+        arr, ns = pack(geometries if isinstance(geometries, (list, tuple)) else [geometries])
+        s, e, n = self._se()
+        nb, na = C.c_size_t(0), C.c_uint64(0)
+        cap = max(self.get_n_atoms(), 1)
+        os_, oe = np.zeros(cap, np.uint64), np.zeros(cap, np.uint64)
+        st = self.system._lib.gr_sel_filter_geometry(self.system._ctx, self.slot, _ptr(s), _ptr(e), n, arr, ns, int(naive), _ptr(os_), _ptr(oe), cap,
+                                                     C.byref(nb), C.byref(na))
+        if st != OK:
+            self.system._raise_atom(st)
+        return AtomIterator(self.system, AtomContainer(list(zip(os_[:nb.value].tolist(), oe[:nb.value].tolist()))), self.slot)
+
+    def filter_geometry(self, geometry):
+        """AtomIteratorWithBox::filter_geometry (:1094-1105): atoms inside the shape, PBC-aware; the reference panics without a box"""
+        return self._filter(geometry, False)
+
+    def filter_geometry_naive(self, geometry):
+        """ImmutableAtomIterable::filter_geometry_naive (:994-1004)"""
+        return self._filter(geometry, True)
+
+    def translate(self, vector):
+        """MutAtomIteratorWithBox::translate (:1520-1524)"""
+        s, e, n = self._se()
+        v = np.ascontiguousarray(vector, dtype=np.float32)
+        st = self.system._lib.gr_sel_translate(self.system._ctx, self.slot, _ptr(s), _ptr(e), n, _ptr(v))
+        if st != OK:
+            self.system._raise_atom(st)
+
+    def wrap(self):
+        """MutAtomIteratorWithBox::wrap (:1548-1553)"""
+        s, e, n = self._se()
+        st = self.system._lib.gr_sel_wrap(self.system._ctx, self.slot, _ptr(s), _ptr(e), n)
+        if st != OK:
+            self.system._raise_atom(st)
+
+    def union(self, other):
+        """OrderedAtomIterator::union (:1572-1591): every atom once, in index order"""
+        return AtomIterator(self.system, AtomContainer.union(self.container, other.container), self.slot)
+
+    def intersection(self, other):
+        """OrderedAtomIterator::intersection (:1593-1604)"""
+        return AtomIterator(self.system, AtomContainer.intersection(self.container, other.container), self.slot)
+
+    def all_distances(self, other, dim=None):
+        """the double loop of System::group_all_distances (analysis.rs:414-424) over two iterators -> [n1, n2] float32"""
+        s1, e1, n1 = self._se(); s2, e2, n2 = other._se()
+        out = np.zeros((self.get_n_atoms(), other.get_n_atoms()), np.float32)
+        st = self.system._lib.gr_sel_all_distances(self.system._ctx, self.slot, _ptr(s1), _ptr(e1), n1, _ptr(s2), _ptr(e2), n2,
+                                                   int(Dimension.XYZ if dim is None else dim), _ptr(out), out.size)
+        if st != OK:
+            self.system._raise_atom(st)
+        return out
+
+
 class System:
     """Device mirror of groan_rs `System` (src/system/mod.rs:38-73): atoms' masses, named groups,
     `n_slots` resident frames (positions + box).  Slot 0 is "the current frame"."""
@@ -335,6 +430,26 @@ class System:
 
     def group_isempty(self, name):
         return self.group_get_n_atoms(name) == 0
+
+    # -- iterators (src/system/iterating.rs:43-140)
+    def group_iter(self, name, slot=0):
+        """System::group_iter / group_iter_mut: GroupError::NotFound for an unknown group"""
+        return AtomIterator(self, self.group_container(name), slot)
+
+    def atoms_iter(self, slot=0):
+        """System::atoms_iter / atoms_iter_mut"""
+        return AtomIterator(self, AtomContainer([(0, self.n_atoms - 1)]), slot)
+
+    def container_iter(self, container, slot=0):
+        return AtomIterator(self, container, slot)
+
+    def selection_iter(self, query, structure, slot=0):
+        """System::selection_iter / selection_iter_mut (iterating.rs:124-140): the atoms a selection-language query picks"""
+        import importlib
+        sel = importlib.import_module(".select", __package__)    # (the package re-exports the FUNCTION `select` under the module's name)
+        groups = {g: np.array(list(self.group_container(g)), np.int64) for g in self.group_names()}
+        idx = sel.select(structure, query, groups)
+        return AtomIterator(self, AtomContainer.from_indices([int(i) for i in idx], self.n_atoms), slot)
 
     def group_container(self, name):
         nb = C.c_size_t(0)

@@ -188,6 +188,30 @@ int gr_group_translate(gr_ctx *ctx, uint32_t slot, const char *group, const floa
 int gr_group_wrap(gr_ctx *ctx, uint32_t slot, const char *group);
 int gr_atoms_center(gr_ctx *ctx, uint32_t slot, const char *reference_group, int dim, int weighted);
 
+/* ---------------------------------------------------------------- anonymous selections: the iterator-level surface
+ * The reference's atom iterators carry an AtomContainer (inclusive index blocks, container.rs:23-31) and a box, no name
+ * (System::group_iter / atoms_iter / selection_iter, src/system/iterating.rs:43-140; unions and intersections of containers,
+ * iterators.rs:1563-1604).  These entry points take the blocks directly -- (start[], end_inclusive[], n_blocks), exactly the
+ * AtomBlock layout -- and compute what the iterator traits compute, with THEIR error behaviour, which differs from the
+ * System-level calls in one place: an EMPTY selection is not an error, its centre is (NaN, NaN, NaN)
+ * (iterators.rs:1186-1188,1259-1261).  Blocks are validated like groups (gr_container_validate: GR_E_OUT_OF_RANGE).
+ *   gr_sel_center          AtomIterable::get_center_naive / get_com_naive (:886-967), AtomIteratorWithBox::estimate_center /
+ *                          get_center / estimate_com / get_com (:1152-1438); kind / weighted as gr_group_center
+ *   gr_sel_translate/wrap  MutAtomIteratorWithBox::translate / wrap (:1520-1553)
+ *   gr_sel_all_distances   the double loop of group_all_distances (analysis.rs:414-424) over two iterators, row-major n1 x n2
+ *   gr_sel_filter_geometry AtomIteratorWithBox::filter_geometry / ImmutableAtomIterable::filter_geometry_naive (:994-1004,
+ *                          1094-1105): the atoms of the selection that have a position and lie inside every shape, returned as
+ *                          the blocks of a new container (*n_out_blocks of them, *n_out_atoms atoms; pass NULL buffers to count) */
+int gr_sel_center(gr_ctx *ctx, uint32_t slot, const uint64_t *start, const uint64_t *end_inclusive, size_t n_blocks, int kind, int weighted, float out[3]);
+int gr_sel_translate(gr_ctx *ctx, uint32_t slot, const uint64_t *start, const uint64_t *end_inclusive, size_t n_blocks, const float v[3]);
+int gr_sel_wrap(gr_ctx *ctx, uint32_t slot, const uint64_t *start, const uint64_t *end_inclusive, size_t n_blocks);
+int gr_sel_all_distances(gr_ctx *ctx, uint32_t slot, const uint64_t *start1, const uint64_t *end1, size_t n_blocks1,
+                         const uint64_t *start2, const uint64_t *end2, size_t n_blocks2, int dim, float *out_host, size_t out_capacity_floats);
+struct gr_shape;
+int gr_sel_filter_geometry(gr_ctx *ctx, uint32_t slot, const uint64_t *start, const uint64_t *end_inclusive, size_t n_blocks,
+                           const struct gr_shape *shapes, size_t n_shapes, int naive,
+                           uint64_t *out_start, uint64_t *out_end, size_t capacity_blocks, size_t *n_out_blocks, uint64_t *n_out_atoms);
+
 /* ---------------------------------------------------------------- RMSD / RMSD-fit
  * gr_calc_rmsd / gr_calc_rmsd_and_fit = System::calc_rmsd / calc_rmsd_and_fit (rmsd.rs:75-166):
  * reference and current frame are two (context, slot) pairs on the same device (they may be the same
@@ -267,7 +291,9 @@ int gr_ndx_install(const gr_ndx *x, gr_ctx *ctx, size_t *n_invalid_names, size_t
  * as src/system/hbonds.rs:248-265 uses them): all pairs (i in group1, j in group2, i != j) with distance(x_j, x_i) <= cutoff,
  * ordered by i then j (the reference leaves the order undefined).  The grid (cells of at least `cutoff`, periodic 27-cell
  * neighbourhood) is built on the device; it replaces the S1 x S2 distance matrix when only near pairs are wanted.
- * Needs an orthogonal box (GR_E_NO_BOX / GR_E_NOT_ORTHOGONAL), cutoff > 0 (GR_E_INVALID_ARG, the reference's
+ * Needs a box (GR_E_NO_BOX); non-orthogonal boxes -- which the reference's CellGrid rejects (cellgrid.rs:411-430), and so does
+ * this call in strict-orthogonal mode (GR_E_NOT_ORTHOGONAL) -- are binned in fractional coordinates with the triclinic
+ * minimum-image distance as the filter; cutoff > 0 (GR_E_INVALID_ARG, the reference's
  * CellGridError::InvalidCellSize), positions for every atom of both groups (GR_E_NO_POSITION + index: group2 is checked
  * first, as the grid is built before it is queried).  *n_pairs receives the number of pairs found; at most max_pairs are
  * written -- when *n_pairs > max_pairs call again with larger buffers (the buffers may be NULL to just count). */
@@ -332,8 +358,9 @@ int gr_xtc_write_slots(gr_xtc_writer *w, gr_ctx *ctx, uint32_t first_slot, uint3
  * Shape::inside of Sphere / Rectangular / Cylinder / TriangularPrism (src/structures/shape.rs:110-185,252-276,431-461),
  * the PBC-free NaiveShape variants (:466-505), and System::group_create_from_geometry / _geometries
  * (src/system/groups.rs:94-188 over Group::apply_geometries, src/structures/group.rs:119-175): the new group holds, in
- * the source group's order, the atoms that have a position and lie inside EVERY shape.  Like the reference this needs an
- * orthogonal box (GR_E_NO_BOX / GR_E_NOT_ORTHOGONAL); the name must be valid (GR_E_INVALID_NAME: empty, or one of
+ * the source group's order, the atoms that have a position and lie inside EVERY shape.  Needs a box (GR_E_NO_BOX); the reference
+ * also needs it orthogonal (groups.rs:108-110: GR_E_NOT_ORTHOGONAL in strict-orthogonal mode) -- otherwise a non-orthogonal box
+ * takes the image-enumeration extension (some lattice image of the atom lies inside the shape); the name must be valid (GR_E_INVALID_NAME: empty, or one of
  * '"&|!@()<>= , auxiliary.rs:37-51); an existing group is replaced and GR_E_GROUP_EXISTS returned (the reference's
  * AlreadyExistsWarning).  The predicate runs on the device (one ballot bit per atom), the blocks are built on the host. */
 enum { GR_SHAPE_SPHERE = 1, GR_SHAPE_RECTANGULAR = 2, GR_SHAPE_CYLINDER = 3, GR_SHAPE_TRIANGULAR_PRISM = 4 };

@@ -121,6 +121,10 @@ class System {
     System(System &&o) noexcept : ctx_(o.ctx_), n_(o.n_), device_(o.device_) { o.ctx_ = nullptr; }
 
     gr_ctx *raw() const { return ctx_; }
+    // System::atoms_iter / group_iter (src/system/iterating.rs:43,108); defined below AtomIterator
+    class AtomIterator atoms_iter(uint32_t slot = 0);
+    class AtomIterator group_iter(const std::string &name, uint32_t slot = 0);
+    friend class AtomIterator;
     uint64_t get_n_atoms() const { return n_; }
     int device() const { return device_; }
     void set_masses(const std::vector<float> &m) { check_plain(gr_set_masses(ctx_, m.data(), m.size())); }
@@ -257,6 +261,7 @@ class System {
         switch (st) {
         case GR_E_OUT_OF_RANGE: throw Error("AtomError", "OutOfRange", st, idx);
         case GR_E_NO_POSITION: throw Error("AtomError", "InvalidPosition", st, idx);
+        case GR_E_NO_MASS: throw Error("AtomError", "InvalidMass", st, idx);
         case GR_E_NO_BOX: case GR_E_NOT_ORTHOGONAL: case GR_E_ZERO_BOX: throw Error("AtomError", "InvalidSimBox(" + simbox_variant(st) + ")", st);
         default: throw Error("DeviceError", std::string(gr_status_string(st)) + ": " + gr_last_error(ctx_), st);
         }
@@ -265,6 +270,66 @@ class System {
     uint64_t n_;
     int device_;
 };
+
+// ---- atom iterators (src/structures/iterators.rs:28-46,350-402,1053-1604; src/system/iterating.rs:43-140)
+// An AtomContainer + the System (and slot) it walks.  Each method is one gr_sel_* call: the kernels take the container's
+// blocks directly.  Error behaviour is the iterator traits': box first, then the first atom without position / mass; an EMPTY
+// iterator is not an error -- its centre is (NaN, NaN, NaN) (iterators.rs:1186-1188).
+class AtomIterator {
+  public:
+    AtomIterator(System &system, AtomContainer container, uint32_t slot = 0) : sys_(&system), c_(std::move(container)), slot_(slot) {}
+    const AtomContainer &container() const { return c_; }
+    uint64_t get_n_atoms() const { return c_.get_n_atoms(); }
+    Vector3D get_center_naive() const { return center(GR_CENTER_NAIVE, 0); }
+    Vector3D get_com_naive() const { return center(GR_CENTER_NAIVE, 1); }
+    Vector3D estimate_center() const { return center(GR_CENTER_ESTIMATE, 0); }
+    Vector3D get_center() const { return center(GR_CENTER_PBC, 0); }
+    Vector3D estimate_com() const { return center(GR_CENTER_ESTIMATE, 1); }
+    Vector3D get_com() const { return center(GR_CENTER_PBC, 1); }
+    AtomIterator filter_geometry(const Shape &shape) const { return filter(shape, false); }          // :1094-1105
+    AtomIterator filter_geometry_naive(const Shape &shape) const { return filter(shape, true); }     // :994-1004
+    void translate(const Vector3D &v) { auto se = split(); int st = gr_sel_translate(sys_->raw(), slot_, se.first.data(), se.second.data(), c_.blocks.size(), v.data()); if (st) sys_->atom_error(st); }
+    void wrap() { auto se = split(); int st = gr_sel_wrap(sys_->raw(), slot_, se.first.data(), se.second.data(), c_.blocks.size()); if (st) sys_->atom_error(st); }
+    AtomIterator set_union(const AtomIterator &o) const { return AtomIterator(*sys_, AtomContainer::set_union(c_, o.c_), slot_); }   // OrderedAtomIterator::union :1572
+    std::vector<float> all_distances(const AtomIterator &o, Dimension dim) const {
+        auto a = split(); auto b = o.split();
+        std::vector<float> out((size_t)get_n_atoms() * o.get_n_atoms());
+        int st = gr_sel_all_distances(sys_->raw(), slot_, a.first.data(), a.second.data(), c_.blocks.size(), b.first.data(), b.second.data(), o.c_.blocks.size(), (int)dim, out.data(), out.size());
+        if (st) sys_->atom_error(st);
+        return out;
+    }
+  private:
+    std::pair<std::vector<uint64_t>, std::vector<uint64_t>> split() const {
+        std::vector<uint64_t> s(c_.blocks.size() + 1), e(c_.blocks.size() + 1);
+        for (size_t i = 0; i < c_.blocks.size(); ++i) { s[i] = c_.blocks[i].first; e[i] = c_.blocks[i].second; }
+        return {s, e};
+    }
+    Vector3D center(int kind, int weighted) const {
+        auto se = split(); Vector3D out{};
+        int st = gr_sel_center(sys_->raw(), slot_, se.first.data(), se.second.data(), c_.blocks.size(), kind, weighted, out.data());
+        if (st) sys_->atom_error(st);
+        return out;
+    }
+    AtomIterator filter(const Shape &shape, bool naive) const {
+        auto se = split();
+        const size_t cap = (size_t)get_n_atoms() + 1;
+        std::vector<uint64_t> os(cap), oe(cap); size_t nb = 0; uint64_t na = 0;
+        int st = gr_sel_filter_geometry(sys_->raw(), slot_, se.first.data(), se.second.data(), c_.blocks.size(), &shape.c, 1, naive ? 1 : 0, os.data(), oe.data(), cap, &nb, &na);
+        if (st) sys_->atom_error(st);
+        AtomContainer out; for (size_t i = 0; i < nb; ++i) out.blocks.emplace_back(os[i], oe[i]);
+        return AtomIterator(*sys_, out, slot_);
+    }
+    System *sys_; AtomContainer c_; uint32_t slot_;
+};
+inline AtomIterator System::atoms_iter(uint32_t slot) { AtomContainer c; c.blocks.emplace_back(0, n_ - 1); return AtomIterator(*this, c, slot); }
+inline AtomIterator System::group_iter(const std::string &name, uint32_t slot) {
+    size_t nb = 0;
+    if (gr_group_n_blocks(ctx_, name.c_str(), &nb) != GR_OK) throw Error("GroupError", "NotFound", GR_E_GROUP_NOT_FOUND);
+    std::vector<uint64_t> s(nb + 1), e(nb + 1);
+    gr_group_blocks(ctx_, name.c_str(), s.data(), e.data());
+    AtomContainer c; for (size_t i = 0; i < nb; ++i) c.blocks.emplace_back(s[i], e[i]);
+    return AtomIterator(*this, c, slot);
+}
 
 // ---- plug-in traits (src/structures/traj_convert.rs:30-36,76-83,125-132)
 template <typename R> struct FrameAnalyze { virtual ~FrameAnalyze() = default; virtual R analyze(const System &system) = 0; };

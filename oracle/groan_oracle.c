@@ -946,7 +946,58 @@ static float prism_sign(const float p1[3], const float p2[3], const float p3[3],
 
 static float box_len(const float *b, int dim) { return dim == GO_DIM_X ? V1X(b) : (dim == GO_DIM_Y ? V2Y(b) : V3Z(b)); }
 
+/* Non-orthogonal boxes (extension, same definition as groan_rs_amd/csrc/gr_shape.h: SOME lattice image of the point lies inside
+ * the shape taken as a plain body anchored at its position; images = 125 around the brick-reduced difference).  Operation by
+ * operation the device code's arithmetic (this file is built with -ffp-contract=off). */
+static int shape_free_inside(const go_shape *s, float ex, float ey, float ez) {
+    switch (s->kind) {
+    case GO_SHAPE_RECTANGULAR:
+        return ex >= 0.0f && ex <= s->size[0] && ey >= 0.0f && ey <= s->size[1] && ez >= 0.0f && ez <= s->size[2];
+    case GO_SHAPE_CYLINDER: {
+        const float along = s->orientation == GO_DIM_X ? ex : (s->orientation == GO_DIM_Y ? ey : ez);
+        if (!(along >= 0.0f && along <= s->size[1])) return 0;
+        float u, v;
+        if (s->orientation == GO_DIM_X) { u = ey; v = ez; } else if (s->orientation == GO_DIM_Y) { u = ex; v = ez; } else { u = ex; v = ey; }
+        const float uu = u * u, vv = v * v;
+        /* gr_mag3_exact(x, y, z) = sqrt((xx + yy) + zz) with one of the three terms an exact 0 */
+        const float sum = s->orientation == GO_DIM_X ? ((0.0f + uu) + vv) : (s->orientation == GO_DIM_Y ? ((uu + 0.0f) + vv) : ((uu + vv) + 0.0f));
+        return sqrtf(sum) <= s->size[0];
+    }
+    case GO_SHAPE_TRIANGULAR_PRISM: {
+        const float along = s->orientation == GO_DIM_X ? ex : (s->orientation == GO_DIM_Y ? ey : ez);
+        if (!(along >= 0.0f && along < s->size[0])) return 0;
+        const float img[3] = { s->position[0] + ex, s->position[1] + ey, s->position[2] + ez };
+        float d1 = prism_sign(img, s->position, s->base2, s->plane);
+        float d2 = prism_sign(img, s->base2, s->base3, s->plane);
+        float d3 = prism_sign(img, s->base3, s->position, s->plane);
+        int has_neg = (d1 < 0.0f) || (d2 < 0.0f) || (d3 < 0.0f);
+        int has_pos = (d1 > 0.0f) || (d2 > 0.0f) || (d3 > 0.0f);
+        return !(has_neg && has_pos);
+    }
+    }
+    return 0;
+}
+static int shape_inside_tric(const go_shape *s, const float pt[3], const float *b) {
+    float dx = pt[0] - s->position[0], dy = pt[1] - s->position[1], dz = pt[2] - s->position[2];
+    float k = rintf(dz / V3Z(b));
+    dx = dx - k * V3X(b); dy = dy - k * V3Y(b); dz = dz - k * V3Z(b);
+    k = rintf(dy / V2Y(b));
+    dx = dx - k * V2X(b); dy = dy - k * V2Y(b);
+    k = rintf(dx / V1X(b));
+    dx = dx - k * V1X(b);
+    for (int kc = -2; kc <= 2; ++kc)
+        for (int kb = -2; kb <= 2; ++kb)
+            for (int ka = -2; ka <= 2; ++ka) {
+                const float tx = ((float)ka * V1X(b) + (float)kb * V2X(b)) + (float)kc * V3X(b);
+                const float ty = (float)kb * V2Y(b) + (float)kc * V3Y(b);
+                const float tz = (float)kc * V3Z(b);
+                if (shape_free_inside(s, dx + tx, dy + ty, dz + tz)) return 1;
+            }
+    return 0;
+}
+
 int go_shape_inside(const go_shape *s, const float pt[3], const float *b) {
+    if ((V2X(b) != 0.0f || V3X(b) != 0.0f || V3Y(b) != 0.0f) && s->kind != GO_SHAPE_SPHERE) return shape_inside_tric(s, pt, b);
     switch (s->kind) {
     case GO_SHAPE_SPHERE: /* :114-116 */
         return go_distance(pt, s->position, GO_DIM_XYZ, b) < s->size[0];

@@ -64,6 +64,15 @@ extern "C" {
     pub fn gr_rmsd_plan_destroy(plan: *mut gr_rmsd_plan);
     pub fn gr_rmsd_batch(plan: *mut gr_rmsd_plan, first_slot: u32, n: u32, rmsd: *mut c_float, status: *mut c_int, rot: *mut c_float) -> c_int;
     pub fn gr_rmsd_fit_batch(plan: *mut gr_rmsd_plan, first_slot: u32, n: u32, rmsd: *mut c_float, status: *mut c_int) -> c_int;
+    // anonymous selections = the iterator-level surface (src/structures/iterators.rs:886-1554): AtomContainer blocks in, no group name
+    pub fn gr_sel_center(ctx: *mut gr_ctx, slot: u32, start: *const u64, end: *const u64, n_blocks: usize, kind: c_int, weighted: c_int, out: *mut c_float) -> c_int;
+    pub fn gr_sel_translate(ctx: *mut gr_ctx, slot: u32, start: *const u64, end: *const u64, n_blocks: usize, v: *const c_float) -> c_int;
+    pub fn gr_sel_wrap(ctx: *mut gr_ctx, slot: u32, start: *const u64, end: *const u64, n_blocks: usize) -> c_int;
+    pub fn gr_sel_all_distances(ctx: *mut gr_ctx, slot: u32, s1: *const u64, e1: *const u64, n1: usize, s2: *const u64, e2: *const u64, n2: usize,
+                                dim: c_int, out: *mut c_float, cap: usize) -> c_int;
+    pub fn gr_sel_filter_geometry(ctx: *mut gr_ctx, slot: u32, start: *const u64, end: *const u64, n_blocks: usize, shapes: *const gr_shape, n_shapes: usize,
+                                  naive: c_int, out_start: *mut u64, out_end: *mut u64, cap_blocks: usize, n_out_blocks: *mut usize, n_out_atoms: *mut u64) -> c_int;
+    pub fn gr_frame_upload_wait(ctx: *mut gr_ctx, slot: u32) -> c_int;
     // geometry selection (src/structures/shape.rs, src/system/groups.rs:94-188)
     pub fn gr_shape_sphere(s: *mut gr_shape, position: *const c_float, radius: c_float) -> c_int;
     pub fn gr_shape_rectangular(s: *mut gr_shape, position: *const c_float, x: c_float, y: c_float, z: c_float) -> c_int;
@@ -155,6 +164,100 @@ impl HipSystem {
         match unsafe { gr_group_distance(self.ctx, slot, a.as_ptr(), b.as_ptr(), dim as c_int, &mut out) } {
             GR_OK => Ok(out),
             s => Err(self.group_error(s, g1)),
+        }
+    }
+}
+
+/// The iterator-level surface on the device: what `AtomIterable` / `AtomIteratorWithBox` / `MutAtomIteratorWithBox`
+/// (src/structures/iterators.rs:842-1554) compute for an `AtomContainer`, as ONE call each into the anonymous-selection entry
+/// points -- no named group is created.  Obtain one from `HipSystem::iter_container` with the container of
+/// `system.group_iter(..)`, `atoms_iter()`, a union / intersection (`container.rs:268-291`) ...
+/// Error behaviour is the iterator traits': box first (`AtomError::InvalidSimBox`), then the first atom without position /
+/// mass; an empty container yields `Vector3D(NaN, NaN, NaN)`, not an error (iterators.rs:1186-1188).
+pub struct HipAtomIterator<'a> { sys: &'a HipSystem, slot: u32, start: Vec<u64>, end: Vec<u64> }
+
+impl HipSystem {
+    pub fn iter_container(&self, slot: u32, container: &AtomContainer) -> HipAtomIterator<'_> {
+        let (start, end): (Vec<u64>, Vec<u64>) = container.blocks().map(|(a, b)| (a as u64, b as u64)).unzip();
+        HipAtomIterator { sys: self, slot, start, end }
+    }
+    fn atom_error(&self, status: c_int) -> AtomError {
+        let idx = unsafe { gr_last_error_index(self.ctx) } as usize;
+        match status {
+            GR_E_NO_POSITION => AtomError::InvalidPosition(PositionError::NoPosition(idx)),
+            GR_E_NO_MASS => AtomError::InvalidMass(MassError::NoMass(idx)),
+            9 /* GR_E_OUT_OF_RANGE */ => AtomError::OutOfRange(idx),
+            s => AtomError::InvalidSimBox(simbox_err(s)),
+        }
+    }
+}
+
+impl<'a> HipAtomIterator<'a> {
+    fn center(&self, kind: c_int, weighted: c_int) -> Result<Vector3D, AtomError> {
+        let mut out = [0f32; 3];
+        match unsafe { gr_sel_center(self.sys.ctx, self.slot, self.start.as_ptr(), self.end.as_ptr(), self.start.len(), kind, weighted, out.as_mut_ptr()) } {
+            GR_OK => Ok(Vector3D::new(out[0], out[1], out[2])),
+            s => Err(self.sys.atom_error(s)),
+        }
+    }
+    pub fn get_center_naive(&self) -> Result<Vector3D, AtomError> { self.center(0, 0) }   // iterators.rs:886-903
+    pub fn get_com_naive(&self) -> Result<Vector3D, AtomError> { self.center(0, 1) }      // :946-967
+    pub fn estimate_center(&self) -> Result<Vector3D, AtomError> { self.center(1, 0) }    // :1152-1191
+    pub fn estimate_com(&self) -> Result<Vector3D, AtomError> { self.center(1, 1) }       // :1314-1357
+    pub fn get_center(&self) -> Result<Vector3D, AtomError> { self.center(2, 0) }         // :1237-1266
+    pub fn get_com(&self) -> Result<Vector3D, AtomError> { self.center(2, 1) }            // :1404-1438
+    /// `MutAtomIteratorWithBox::translate` (:1520-1524)
+    pub fn translate(&self, v: &Vector3D) -> Result<(), AtomError> {
+        let a = [v.x, v.y, v.z];
+        match unsafe { gr_sel_translate(self.sys.ctx, self.slot, self.start.as_ptr(), self.end.as_ptr(), self.start.len(), a.as_ptr()) } { GR_OK => Ok(()), s => Err(self.sys.atom_error(s)) }
+    }
+    /// `MutAtomIteratorWithBox::wrap` (:1548-1553)
+    pub fn wrap(&self) -> Result<(), AtomError> {
+        match unsafe { gr_sel_wrap(self.sys.ctx, self.slot, self.start.as_ptr(), self.end.as_ptr(), self.start.len()) } { GR_OK => Ok(()), s => Err(self.sys.atom_error(s)) }
+    }
+    /// `AtomIteratorWithBox::filter_geometry` / `filter_geometry_naive` (:994-1004,1094-1105): the blocks of the filtered container
+    pub fn filter_geometry(&self, shape: &gr_shape, naive: bool) -> Result<Vec<(usize, usize)>, AtomError> {
+        let cap = self.start.iter().zip(&self.end).map(|(a, b)| (b - a + 1) as usize).sum::<usize>().max(1);
+        let (mut os, mut oe) = (vec![0u64; cap], vec![0u64; cap]);
+        let (mut nb, mut na) = (0usize, 0u64);
+        match unsafe { gr_sel_filter_geometry(self.sys.ctx, self.slot, self.start.as_ptr(), self.end.as_ptr(), self.start.len(), shape, 1, naive as c_int,
+                                              os.as_mut_ptr(), oe.as_mut_ptr(), cap, &mut nb, &mut na) } {
+            GR_OK => Ok(os[..nb].iter().zip(&oe[..nb]).map(|(a, b)| (*a as usize, *b as usize)).collect()),
+            s => Err(self.sys.atom_error(s)),
+        }
+    }
+}
+
+/// Batched form of `HipRmsd` for trajectory loops that can look ahead: `push` stages a frame into the next free slot (one
+/// copy out of the `System`, one asynchronous upload), `flush` runs ONE `gr_rmsd_batch` over everything staged -- the
+/// library's batched path (256-frame launch groups) instead of one launch + synchronisation per frame.
+pub struct HipRmsdBatch { inner: HipRmsd, staged: u32, capacity: u32, pinned: Vec<Vec<[f32; 3]>> }
+impl HipRmsdBatch {
+    pub fn new(reference: &System, target: &System, group: &str, device: i32, capacity: u32) -> Result<Self, RMSDError> {
+        let mut inner = HipRmsd::new(reference, target, group, device)?;
+        inner.target = HipSystem::new(target, device, capacity).ok_or_else(|| RMSDError::NonexistentGroup(group.to_owned()))?;
+        let cname = CString::new(group).unwrap();
+        let mut st = 0;
+        unsafe { gr_rmsd_plan_destroy(inner.plan) };
+        inner.plan = unsafe { gr_rmsd_plan_create(inner._reference.ctx, 0, inner.target.ctx, cname.as_ptr(), &mut st) };
+        if inner.plan.is_null() { return Err(rmsd_error(&inner._reference, st, group)); }
+        Ok(HipRmsdBatch { inner, staged: 0, capacity, pinned: (0..capacity).map(|_| Vec::new()).collect() })
+    }
+    pub fn is_full(&self) -> bool { self.staged == self.capacity }
+    pub fn push(&mut self, system: &System) {
+        let buf = &mut self.pinned[self.staged as usize];
+        buf.clear();
+        buf.extend(system.atoms_iter().map(|a| a.get_position().map_or([f32::NAN; 3], |p| [p.x, p.y, p.z])));
+        self.inner.target.upload(self.staged, buf, system.get_box());
+        self.staged += 1;
+    }
+    pub fn flush(&mut self) -> Result<Vec<f32>, RMSDError> {
+        let n = self.staged;
+        self.staged = 0;
+        let (mut r, mut st) = (vec![0f32; n as usize], vec![0 as c_int; n as usize]);
+        match unsafe { gr_rmsd_batch(self.inner.plan, 0, n, r.as_mut_ptr(), st.as_mut_ptr(), std::ptr::null_mut()) } {
+            GR_OK => Ok(r),
+            s => Err(rmsd_error(&self.inner.target, s, &self.inner.group)),
         }
     }
 }

@@ -120,6 +120,30 @@ int main(int argc, char **argv) {
         system.group_create_from_ranges("Protein", {{0, 59}});
         try { system.calc_rmsd(reference, "Protein"); CHECK(false); } catch (const Error &e) { CHECK(e.variant == "InconsistentGroup" && e.counts[0] == 61 && e.counts[1] == 60); }
     }
+    // ---- atom iterators (iterators.rs:1053-1554, iterating.rs:43,108): anonymous selections through gr_sel_*
+    {
+        System s(n, 0, 1);
+        s.set_masses(masses);
+        Box9 bx; for (int k = 0; k < 9; ++k) bx[k] = boxes[k];
+        s.set_frame(frames.data(), &bx);
+        s.group_create_from_ranges("Protein", {{0, 60}});
+        AtomIterator it = s.group_iter("Protein");
+        CHECK(it.get_n_atoms() == 61);
+        Vector3D a = it.get_com(), b = s.group_get_com("Protein");
+        for (int k = 0; k < 3; ++k) CHECK(a[k] == b[k]);                                   // the same kernels, the same bits
+        AtomContainer none;
+        Vector3D e = AtomIterator(s, none).get_center();
+        CHECK(std::isnan(e[0]) && std::isnan(e[1]) && std::isnan(e[2]));                   // an empty iterator is NaN, not an error (:1186-1188)
+        AtomIterator near = s.atoms_iter().filter_geometry(Shape::sphere(b, 1.0f));
+        CHECK(near.get_n_atoms() > 0 && near.get_n_atoms() < n);
+        std::vector<float> before = s.get_positions();
+        it.translate({1.0f, 0.0f, 0.0f});
+        std::vector<float> after = s.get_positions();
+        CHECK(after[3 * 100] == before[3 * 100]);                                          // atom 100 is not in the iterator
+        CHECK(after[0] != before[0]);
+        AtomContainer out; out.blocks.emplace_back(n - 1, n + 3);
+        try { AtomIterator(s, out).get_center_naive(); CHECK(false); } catch (const Error &err) { CHECK(err.variant == "OutOfRange"); }
+    }
     // ---- traj_iter_map_reduce (parallel.rs:208-481): two workers (both on device 0), frames round-robin
     {
         auto make_system = [&](int device) {

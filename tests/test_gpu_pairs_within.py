@@ -76,11 +76,55 @@ def test_errors(G, example):
         s.group_pairs_within("A", "B", 0.5)
     assert e.value.variant == "InvalidPosition" and e.value.detail == 700
     s.set_frame(pos, np.array([13.0, 13.0, 11.0, 0, 0, 1.0, 0, 0, 0], np.float32))
+    s.set_strict_orthogonal(True)                                           # the reference's gate (cellgrid.rs:423)
     with pytest.raises(G.GroupError) as e:
         s.group_pairs_within("A", "B", 0.5)
     assert e.value.variant == "InvalidSimBox" and e.value.detail.variant == "NotOrthogonal"
+    s.set_strict_orthogonal(False)
     s.reset_box()
     with pytest.raises(G.GroupError) as e:
         s.group_pairs_within("A", "B", 0.5)
     assert e.value.detail.variant == "DoesNotExist"
+    s.close()
+
+
+@pytest.mark.parametrize("lengths,angles,cutoff", [([7.0, 6.5, 6.0], [75.0, 80.0, 70.0], 0.45), ([6.0, 6.0, 6.0], [60.0, 60.0, 90.0], 0.6),
+                                                   ([6.0, 6.0, 6.0], [70.53, 109.47, 70.53], 1.3), ([6.5, 7.5, 6.0], [100.0, 95.0, 110.0], 2.4)])
+def test_pairs_within_in_non_orthogonal_boxes(G, lengths, angles, cutoff):
+    """NEXT-2, triclinic cell lists (the reference's CellGrid is orthogonal-only, cellgrid.rs:423): the
+    grid lives in fractional coordinates with slabs at least one cut-off thick, the filter is the triclinic minimum-image
+    distance.  Pairs identical to the oracle's brute force over all pairs (a pair whose distance is within 2e-6 nm of the
+    cut-off may fall on either side: the two sides round the minimum image differently), distances within 2e-6 nm, and the
+    distances themselves checked against an fp64 search over 5 x 5 x 5 lattice images.  Cut-offs from many cells per axis
+    down to fewer than three (no cell visited twice)."""
+    from groan_rs_amd import workload as W
+    box = W.box_from_lengths_angles(lengths, angles)
+    L = np.array([[box[0], 0, 0], [box[5], box[1], 0], [box[7], box[8], box[2]]], np.float64)
+    rng = np.random.default_rng(int(cutoff * 100))
+    n = 6000
+    pos = (rng.uniform(-0.4, 1.4, (n, 3)) @ L).astype(np.float32)             # in and around the cell
+    s = G.System(n, box=box, positions=pos)
+    i1 = np.arange(0, 1500); i2 = np.unique(np.concatenate([np.arange(1000, n, 2), np.arange(3000, 3200)]))
+    s.group_create_from_ranges("A", [(0, 1499)]); s.group_create_from_indices("B", i2.tolist())
+    gi, gj, gd = s.group_pairs_within("A", "B", cutoff)
+    oi, oj, od = O.pairs_within(pos, i1, i2, box, cutoff)
+    got = {(int(a), int(b)): float(d) for a, b, d in zip(gi, gj, gd)}
+    want = {(int(a), int(b)): float(d) for a, b, d in zip(oi, oj, od)}
+    assert len(want) > 1000
+    for key in set(got) ^ set(want):                                          # only borderline pairs may differ
+        d = got.get(key, want.get(key))
+        assert abs(d - cutoff) <= 2e-6, (key, d)
+    common = sorted(set(got) & set(want))
+    assert max(abs(got[k] - want[k]) for k in common) <= 2e-6
+    images = np.array([(i, j, k) for i in range(-2, 3) for j in range(-2, 3) for k in range(-2, 3)], np.float64) @ L
+    for a, b in common[:: max(1, len(common) // 300)]:
+        d = pos[b].astype(np.float64) - pos[a].astype(np.float64)
+        assert abs(np.sqrt(((d[None, :] + images) ** 2).sum(1).min()) - got[(a, b)]) <= 1e-5
+    # completeness against the true geometry: every pair closer than the cut-off minus the f32 slack is reported
+    sub1, sub2 = i1[:200], i2[:800]
+    d = pos[sub2][None, :, :].astype(np.float64) - pos[sub1][:, None, :].astype(np.float64)
+    dmin = np.sqrt(((d[:, :, None, :] + images[None, None, :, :]) ** 2).sum(3).min(2))
+    for x, y in zip(*np.nonzero(dmin < cutoff - 1e-5)):
+        if sub1[x] != sub2[y]:
+            assert (int(sub1[x]), int(sub2[y])) in got
     s.close()

@@ -84,9 +84,11 @@ def test_errors_follow_the_reference_order(G, ex, example):
         ex.group_create_from_geometry("P", "W", G.TriangularPrism([8, 8, 8], [15, 12, 8], [9.5, 7.3, 8], 5.4), naive=True)
     tric = np.array([13.0, 13.0, 11.0, 0, 0, 1.0, 0, 0, 0], np.float32)
     ex.set_box(tric)
+    ex.set_strict_orthogonal(True)            # the reference's gate; without it a non-orthogonal box takes the extension
     with pytest.raises(G.GroupError) as e:                                            # groups.rs:108-110
         ex.group_create_from_geometry("S", "Membrane", cyl)
     assert e.value.variant == "InvalidSimBox" and e.value.detail.variant == "NotOrthogonal"
+    ex.set_strict_orthogonal(False)
     ex.reset_box()
     with pytest.raises(G.GroupError) as e:                                            # :1694-1704
         ex.group_create_from_geometry("S", "Membrane", cyl)
@@ -126,4 +128,63 @@ def test_random_shapes_on_synthetic_systems(G, seed):
             want = O.group_from_geometries(pos, idx, box, specs, naive=naive)
             got = members(s, "picked")
             assert np.array_equal(got, want), (trial, src, specs, got.size, want.size)
+    s.close()
+
+
+TRIC_CELLS = {"triclinic_75_80_70": ([7.0, 6.5, 6.0], [75.0, 80.0, 70.0]), "dodecahedron": ([6.0, 6.0, 6.0], [60.0, 60.0, 90.0]),
+              "octahedron": ([6.0, 6.0, 6.0], [70.53, 109.47, 70.53]), "skewed_negative": ([6.5, 7.5, 6.0], [100.0, 95.0, 110.0])}
+
+
+@pytest.mark.parametrize("cell", sorted(TRIC_CELLS))
+def test_shapes_in_non_orthogonal_boxes(G, cell):
+    """NEXT-2 as SURVEY section 8(f) words it (triclinic too): group_create_from_geometries / filter_geometry in triclinic,
+    dodecahedral and octahedral cells.  The reference needs an orthogonal box here, so this is the library's extension
+    (some lattice image of the atom lies inside the shape): index lists identical to the oracle's restatement of that
+    definition, and -- independently of both -- equal to an fp64 search over 7 x 7 x 7 lattice images for every atom that is
+    not within 2e-5 nm of a shape's surface."""
+    from groan_rs_amd import workload as W
+    lengths, angles = TRIC_CELLS[cell]
+    box = W.box_from_lengths_angles(lengths, angles)
+    L = np.array([[box[0], 0, 0], [box[5], box[1], 0], [box[7], box[8], box[2]]], np.float64)
+    rng = np.random.default_rng(len(cell) * 7 + 5)
+    n = 30000
+    pos = (rng.uniform(-0.3, 1.3, (n, 3)) @ L).astype(np.float32)            # in and around the cell
+    s = G.System(n, box=box, positions=pos)
+    s.group_create_from_indices("Odd", list(range(1, n, 2)))
+    specs = [dict(kind="sphere", position=[1.0, 5.5, 0.4], radius=1.7),
+             dict(kind="rectangular", position=[5.5, 0.5, 4.8], size=[2.5, 1.5, 2.0]),
+             dict(kind="cylinder", position=[0.3, 0.2, 5.0], radius=1.4, height=2.5, orientation="Z"),
+             dict(kind="cylinder", position=[6.0, 3.0, 1.0], radius=1.1, height=3.0, orientation="X"),
+             dict(kind="prism", base1=[1.0, 1.0, 5.0], base2=[3.5, 1.5, 5.0], base3=[2.0, 3.5, 5.0], height=2.2)]
+    shapes = [G.Sphere(specs[0]["position"], 1.7), G.Rectangular(specs[1]["position"], 2.5, 1.5, 2.0),
+              G.Cylinder(specs[2]["position"], 1.4, 2.5, G.Dimension.Z), G.Cylinder(specs[3]["position"], 1.1, 3.0, G.Dimension.X),
+              G.TriangularPrism(specs[4]["base1"], specs[4]["base2"], specs[4]["base3"], 2.2)]
+    images = np.array([(i, j, k) for i in range(-3, 4) for j in range(-3, 4) for k in range(-3, 4)], np.float64) @ L
+    for spec, shape in zip(specs, shapes):
+        for src, idx in (("all", np.arange(n)), ("Odd", np.arange(1, n, 2))):
+            s.group_create_from_geometry("Sel", src, shape)
+            got = members(s, "Sel")
+            want = O.group_from_geometries(pos, idx, box, [spec])
+            assert np.array_equal(got, want) and 0 < got.size < idx.size, (cell, spec["kind"], got.size, want.size)
+            it = s.group_iter(src).filter_geometry(shape)                       # the iterator-level entry point: the same atoms
+            assert list(it) == [int(i) for i in want]
+        if spec["kind"] == "prism":
+            continue
+        anchor = np.asarray(spec["position"], np.float64)
+        inside = np.zeros(n, bool); near = np.zeros(n, bool)
+        for a0 in range(0, n, 2000):
+            e = pos[a0:a0 + 2000, None, :].astype(np.float64) - anchor + images[None, :, :]
+            # vectorised per shape kind
+            if spec["kind"] == "sphere":
+                r = np.linalg.norm(e, axis=2); ins = r < spec["radius"]; dist = np.abs(r - spec["radius"])
+            elif spec["kind"] == "rectangular":
+                m = np.minimum(e, np.asarray(spec["size"]) - e).min(axis=2); ins = m >= 0; dist = np.abs(m)
+            else:
+                ax = "xyz".index(spec["orientation"].lower())
+                along = e[:, :, ax]; planar = np.linalg.norm(np.delete(e, ax, axis=2), axis=2)
+                m = np.minimum(np.minimum(along, spec["height"] - along), spec["radius"] - planar); ins = m >= 0; dist = np.abs(m)
+            inside[a0:a0 + 2000] = ins.any(axis=1); near[a0:a0 + 2000] = (dist.min(axis=1) < 2e-5)
+        s.group_create_from_geometry("Sel", "all", shape)
+        got = np.zeros(n, bool); got[members(s, "Sel")] = True
+        assert np.array_equal(got[~near], inside[~near]), (cell, spec["kind"], int((got[~near] != inside[~near]).sum()))
     s.close()
