@@ -15,11 +15,11 @@ from .trr import TrrFile, TrrWriter
 from .textio import ParseGroError, ParseNdxError, Structure, read_ndx_groups, system_from_gro, system_read_ndx
 from .select import SelectError, parse_query, select
 from .shapes import Cylinder, Rectangular, Shape, Sphere, TriangularPrism
-from .parallel import ParallelTrajData, gather_per_frame, interleave, shard_frames, traj_iter_map_reduce
+from .parallel import AbortedByOtherRank, Comm, ParallelTrajData, Pool, gather_per_frame, interleave, shard_frames, traj_iter_map_reduce
 
 __all__ = [
     "AtomContainer", "AtomError", "AtomIterator", "DeviceError", "Dimension", "GroanError", "GroupError", "RMSDError", "RMSDPlan",
     "SimBoxError", "System", "pinned_array", "pinned_free", "FrameAnalyze", "FrameConvert", "FrameConvertAnalyze", "RMSDConverterAnalyzer",
     "TrajAnalyzer", "TrajAnalysisError", "TrajConverter", "TrajConverterAnalyzer", "TrajReader",
-    "XtcError", "XtcFile", "XtcWriter", "ParseGroError", "ParseNdxError", "Structure", "read_ndx_groups", "system_from_gro", "system_read_ndx", "Cylinder", "Rectangular", "Shape", "Sphere", "TriangularPrism", "ParallelTrajData", "gather_per_frame", "interleave", "shard_frames", "traj_iter_map_reduce",
+    "XtcError", "XtcFile", "XtcWriter", "ParseGroError", "ParseNdxError", "Structure", "read_ndx_groups", "system_from_gro", "system_read_ndx", "Cylinder", "Rectangular", "Shape", "Sphere", "TriangularPrism", "AbortedByOtherRank", "Comm", "Pool", "ParallelTrajData", "gather_per_frame", "interleave", "shard_frames", "traj_iter_map_reduce",
 ]

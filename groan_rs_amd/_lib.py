@@ -137,6 +137,20 @@ SIGNATURES = {
     "gr_xtc_n_frames": (C.c_uint64, [C.c_void_p]),
     "gr_xtc_frame_info": (C.c_int, [C.c_void_p, C.c_uint64, c_u64p, c_f32p, C.c_void_p, c_f32p]),
     "gr_xtc_read_frame": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, c_u64p, c_f32p, c_f32p]),
+    "gr_pool_create": (C.c_void_p, [C.POINTER(C.c_int), C.c_int, C.c_uint64, C.c_uint32, c_i32p]),
+    "gr_pool_destroy": (None, [C.c_void_p]),
+    "gr_pool_size": (C.c_int, [C.c_void_p]),
+    "gr_pool_ctx": (C.c_void_p, [C.c_void_p, C.c_int]),
+    "gr_pool_last_error": (C.c_char_p, [C.c_void_p]),
+    "gr_pool_map": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, c_u64p, c_u64p]),
+    "gr_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "gr_comm_create": (C.c_void_p, [C.c_int, C.c_int, C.c_int, C.c_void_p, c_i32p]),
+    "gr_comm_destroy": (None, [C.c_void_p]),
+    "gr_comm_last_error": (C.c_char_p, [C.c_void_p]),
+    "gr_comm_library": (C.c_char_p, []),
+    "gr_comm_gather_per_frame": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_size_t, C.c_void_p]),
+    "gr_comm_any_error": (C.c_int, [C.c_void_p, C.c_int, c_i32p]),
+    "gr_shard_deinterleave": (None, [C.c_void_p, C.c_int, C.c_uint64, C.c_size_t, C.c_void_p]),
     "gr_timer_start": (C.c_int, [C.c_void_p]),
     "gr_timer_stop": (C.c_int, [C.c_void_p, c_f32p]),
     "gr_synth_reference": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_float, C.c_uint64]),

@@ -23,6 +23,7 @@
 #include "gr_trr.h"
 #include "gr_cellgrid.h"
 #include "gr_textio.h"
+#include "gr_pool.h"
 #include <set>
 #include <thread>
 #include <atomic>
@@ -2170,6 +2171,151 @@ int gr_xtc_write_slots(gr_xtc_writer *w, gr_ctx *c, uint32_t first_slot, uint32_
     if (result == GR_E_IO) return fail(c, GR_E_IO, "short write");
     return GR_OK;
 } catch (...) { return gr_abi_guard(); }
+
+/* ------------------------------------------------------------ frame-sharded map-reduce: in-process pool */
+gr_pool *gr_pool_create(const int *devices, int n_workers, uint64_t n_atoms, uint32_t n_slots, int *status) try {
+    int dummy; if (!status) status = &dummy;
+    if (!devices || n_workers <= 0 || n_workers > 1024) { *status = GR_E_INVALID_ARG; return nullptr; }
+    gr_pool *p = new gr_pool();
+    for (int w = 0; w < n_workers; ++w) {
+        int st = GR_OK;
+        gr_ctx *c = gr_ctx_create(devices[w], n_atoms, n_slots, &st);     // System::clone per worker (parallel.rs:236)
+        if (!c) { *status = st; gr_pool_destroy(p); return nullptr; }
+        p->ctx.push_back(c); p->device.push_back(devices[w]);
+    }
+    *status = GR_OK;
+    return p;
+} catch (...) { return nullptr; }
+void gr_pool_destroy(gr_pool *p) try {
+    if (!p) return;
+    for (gr_ctx *c : p->ctx) gr_ctx_destroy(c);
+    delete p;
+} catch (...) { }
+int gr_pool_size(const gr_pool *p) { return p ? (int)p->ctx.size() : 0; }
+gr_ctx *gr_pool_ctx(gr_pool *p, int worker) { return (p && worker >= 0 && worker < (int)p->ctx.size()) ? p->ctx[worker] : nullptr; }
+const char *gr_pool_last_error(const gr_pool *p) { return p ? p->err.c_str() : "null pool"; }
+
+int gr_pool_map(gr_pool *p, uint64_t n_frames, gr_pool_body body, void *user, size_t width, float *results, uint64_t *frames_done, uint64_t *error_frame) try {
+    if (!p || !body || (width && !results)) return GR_E_INVALID_ARG;
+    const uint64_t T = p->ctx.size();
+    std::atomic<int> flag(0);                 // the shared AtomicBool of parallel.rs:230
+    std::atomic<int> first_status(GR_OK);
+    std::atomic<uint64_t> first_frame(0), done(0);
+    auto worker = [&](uint64_t w) {
+        (void)hipSetDevice(p->device[w]);
+        uint64_t k = 0;
+        for (uint64_t f = w; f < n_frames; f += T, ++k) {                // frames w, w + T, ... (parallel.rs:424-448)
+            if (k % GR_POOL_ERROR_FLAG_FREQ == 0 && flag.load()) return;  // polled every 10 frames (:453-459)
+            int st;
+            try { st = body(p->ctx[w], (int)w, f, user, width ? results + f * width : nullptr); } catch (...) { st = GR_E_HIP; }
+            if (st != GR_OK) {                                            // the first error wins (:468-471)
+                int expect = 0;
+                if (flag.compare_exchange_strong(expect, 1)) { first_status = st; first_frame = f; }
+                return;
+            }
+            done.fetch_add(1);
+        }
+    };
+    std::vector<std::thread> th;
+    for (uint64_t w = 1; w < T; ++w) { try { th.emplace_back(worker, w); } catch (const std::system_error &) { flag = 1; first_status = GR_E_HIP; break; } }
+    worker(0);
+    for (auto &t : th) t.join();
+    if (frames_done) *frames_done = done.load();
+    if (flag.load()) {
+        if (error_frame) *error_frame = first_frame.load();
+        p->err = "frame body failed at frame " + std::to_string(first_frame.load());
+        return first_status.load();                                       // Err for the whole call (:288-321)
+    }
+    return GR_OK;
+} catch (...) { return gr_abi_guard(); }
+
+/* ------------------------------------------------------------ frame-sharded map-reduce: one process per GPU, RCCL over xGMI */
+int gr_comm_unique_id(void *id128) try {
+    if (!id128) return GR_E_INVALID_ARG;
+    grn::Api &a = grn::api();
+    if (!a.ok) return GR_E_NO_DEVICE;
+    grn::unique_id id;
+    if (a.GetUniqueId(&id) != grn::Success) return GR_E_HIP;
+    memcpy(id128, &id, sizeof id);
+    return GR_OK;
+} catch (...) { return gr_abi_guard(); }
+
+gr_comm *gr_comm_create(int device, int rank, int world, const void *id128, int *status) try {
+    int dummy; if (!status) status = &dummy;
+    if (!id128 || world < 1 || rank < 0 || rank >= world) { *status = GR_E_INVALID_ARG; return nullptr; }
+    grn::Api &a = grn::api();
+    if (!a.ok) { *status = GR_E_NO_DEVICE; return nullptr; }
+    if (hipSetDevice(device) != hipSuccess) { *status = GR_E_NO_DEVICE; return nullptr; }
+    gr_comm *c = new gr_comm();
+    c->device = device; c->rank = rank; c->world = world;
+    grn::unique_id id; memcpy(&id, id128, sizeof id);
+    bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess && hipMalloc(&c->flag, 2 * sizeof(int)) == hipSuccess;
+    if (ok) ok = a.CommInitRank(&c->comm, world, id, rank) == grn::Success;
+    if (!ok) { *status = GR_E_HIP; gr_comm_destroy(c); return nullptr; }
+    *status = GR_OK;
+    return c;
+} catch (...) { return nullptr; }
+
+void gr_comm_destroy(gr_comm *c) try {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->comm) (void)grn::api().CommDestroy(c->comm);
+    if (c->send) (void)hipFree(c->send);
+    if (c->recv) (void)hipFree(c->recv);
+    if (c->flag) (void)hipFree(c->flag);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+} catch (...) { }
+const char *gr_comm_last_error(const gr_comm *c) { return c ? c->err.c_str() : "null communicator"; }
+const char *gr_comm_library(void) { return grn::api().source.c_str(); }
+
+#define COMMCHK(c, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { (c)->err = std::string(#call) + ": " + hipGetErrorString(e_); return GR_E_HIP; } } while (0)
+int gr_comm_gather_per_frame(gr_comm *c, const float *local, uint64_t n_total, size_t width, float *out) try {
+    if (!c || !out || width == 0) return GR_E_INVALID_ARG;
+    (void)hipSetDevice(c->device);
+    const uint64_t G = (uint64_t)c->world, per = (n_total + G - 1) / G;                        // ceil(F / G) rows from every rank
+    const uint64_t mine = n_total > (uint64_t)c->rank ? (n_total - c->rank + G - 1) / G : 0;  // frames rank, rank + G, ...
+    if (mine && !local) return GR_E_INVALID_ARG;
+    const size_t row = per * width;
+    if (row > c->cap) {
+        if (c->send) (void)hipFree(c->send);
+        if (c->recv) (void)hipFree(c->recv);
+        c->send = c->recv = nullptr; c->cap = 0;
+        COMMCHK(c, hipMalloc(&c->send, (row ? row : 1) * sizeof(float)));
+        COMMCHK(c, hipMalloc(&c->recv, (row ? row : 1) * G * sizeof(float)));
+        c->cap = row;
+    }
+    if (row == 0) return GR_OK;
+    COMMCHK(c, hipMemsetAsync(c->send, 0, row * sizeof(float), c->stream));
+    if (mine) COMMCHK(c, hipMemcpyAsync(c->send, local, mine * width * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    const int rc = grn::api().AllGather(c->send, c->recv, row, grn::Float32, c->comm, c->stream);      // the run's one collective
+    if (rc != grn::Success) { c->err = std::string("ncclAllGather: ") + (grn::api().GetErrorString ? grn::api().GetErrorString(rc) : "failed"); return GR_E_HIP; }
+    std::vector<float> all(row * G);
+    COMMCHK(c, hipMemcpyAsync(all.data(), c->recv, all.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    COMMCHK(c, hipStreamSynchronize(c->stream));
+    gr_deinterleave(all.data(), c->world, per, width, n_total, out);
+    return GR_OK;
+} catch (...) { return gr_abi_guard(); }
+
+int gr_comm_any_error(gr_comm *c, int local_flag, int *any) try {
+    if (!c || !any) return GR_E_INVALID_ARG;
+    (void)hipSetDevice(c->device);
+    const int v = local_flag ? 1 : 0;
+    COMMCHK(c, hipMemcpyAsync(c->flag, &v, sizeof(int), hipMemcpyHostToDevice, c->stream));
+    const int rc = grn::api().AllReduce(c->flag, c->flag + 1, 1, grn::Int32, grn::Max, c->comm, c->stream);
+    if (rc != grn::Success) { c->err = "ncclAllReduce failed"; return GR_E_HIP; }
+    int r = 0;
+    COMMCHK(c, hipMemcpyAsync(&r, c->flag + 1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    COMMCHK(c, hipStreamSynchronize(c->stream));
+    *any = r;
+    return GR_OK;
+} catch (...) { return gr_abi_guard(); }
+
+void gr_shard_deinterleave(const float *gathered, int world, uint64_t n_total, size_t width, float *out) try {
+    if (!gathered || !out || world < 1) return;
+    gr_deinterleave(gathered, world, (n_total + (uint64_t)world - 1) / (uint64_t)world, width, n_total, out);
+} catch (...) { }
 
 /* ------------------------------------------------------------ measurement / synthetic data */
 int gr_timer_start(gr_ctx *c) { if (!c) return GR_E_INVALID_ARG; HIPCHK(c, hipEventRecord(c->ev0, c->stream)); return GR_OK; }

@@ -7,6 +7,8 @@ The reference clones the System per worker thread and gives worker n the frames 
 (torch.distributed rank; backend nccl = RCCL over xGMI on the GPU box, gloo in the CPU tests); frames are
 independent, so the only exchange is the final gather of the per-rank results -- no data-path collective.
 """
+import ctypes as C
+
 import numpy as np
 
 
@@ -131,3 +133,107 @@ def traj_iter_map_reduce(make_system, frames_of, n_frames, body, init_data, rank
     if aborted:
         raise AbortedByOtherRank("another rank's frame body failed; this rank stopped after %d of its %d frames" % (n_done, len(mine)))
     return data
+
+
+# ------------------------------------------------------------------------------------------------ behind the C ABI
+class Pool:
+    """gr_pool_*: the in-process form -- one worker thread + one device context per entry of `devices` (the per-thread System
+    clones of parallel.rs:236), frames round-robin, shared error flag, per-frame results in frame order.
+
+        pool = Pool([0, 0], n_atoms)                       # two workers on GPU 0 (or [0, 1, 2, 3]: one per GPU)
+        for s in pool.systems: s.set_masses(m); s.group_create_from_ranges("Protein", [(0, 60)])
+        results = pool.map(n_frames, body, width=3)        # body(system, worker, frame, out_row) -> None (raise on error)
+    """
+    BODY = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_uint64, C.c_void_p, C.POINTER(C.c_float))
+
+    def __init__(self, devices, n_atoms, n_slots=1):
+        from . import _lib
+        from .system import DeviceError, System
+        self._lib = _lib.load()
+        dev = (C.c_int * len(devices))(*[int(d) for d in devices])
+        st = C.c_int(0)
+        self._pool = self._lib.gr_pool_create(dev, len(devices), int(n_atoms), int(n_slots), C.byref(st))
+        if not self._pool:
+            raise DeviceError("PoolCreation", self._lib.gr_status_string(st.value).decode(), st.value)
+        self.systems = [System._borrow(self._lib.gr_pool_ctx(self._pool, w), n_atoms, n_slots, devices[w], name="worker %d" % w)
+                        for w in range(len(devices))]
+        self.last_error = None
+
+    def close(self):
+        if getattr(self, "_pool", None):
+            for s in self.systems:
+                s.close()
+            self._lib.gr_pool_destroy(self._pool)
+            self._pool = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def map(self, n_frames, body, width):
+        """-> float32 [n_frames, width]; raises the first failing frame's exception (the call as a whole fails, parallel.rs:288-321)"""
+        out = np.full((n_frames, max(width, 1)), np.nan, np.float32)
+        errors = {}
+
+        def trampoline(ctx, worker, frame, user, result):
+            try:
+                row = np.ctypeslib.as_array(result, shape=(max(width, 1),))
+                body(self.systems[worker], worker, int(frame), row)
+                return 0
+            except Exception as e:   # the body's error: reported through the status, re-raised by map()
+                errors[int(frame)] = e
+                return getattr(e, "status", None) or 10
+        cb = self.BODY(trampoline)
+        done, bad = C.c_uint64(0), C.c_uint64(0)
+        st = self._lib.gr_pool_map(self._pool, int(n_frames), cb, None, int(width), out.ctypes.data_as(C.c_void_p), C.byref(done), C.byref(bad))
+        self.frames_done = int(done.value)
+        if st != 0:
+            self.last_error = (int(bad.value), errors.get(int(bad.value)))
+            raise errors.get(int(bad.value)) or RuntimeError("gr_pool_map failed at frame %d (status %d)" % (bad.value, st))
+        return out
+
+
+class Comm:
+    """gr_comm_*: the multi-process form -- an RCCL communicator (ncclCommInitRank) for the final gather of per-frame results
+    over xGMI and the shared error flag.  `unique_id()` on rank 0, hand the 128 bytes round, `Comm(device, rank, world, id)`."""
+
+    @staticmethod
+    def unique_id():
+        from . import _lib
+        buf = C.create_string_buffer(128)
+        st = _lib.load().gr_comm_unique_id(buf)
+        if st != 0:
+            raise RuntimeError("gr_comm_unique_id: status %d (RCCL: %s)" % (st, _lib.load().gr_comm_library().decode()))
+        return buf.raw
+
+    def __init__(self, device, rank, world, unique_id):
+        from . import _lib
+        self._lib = _lib.load()
+        st = C.c_int(0)
+        self.rank, self.world = int(rank), int(world)
+        self._comm = self._lib.gr_comm_create(int(device), self.rank, self.world, C.create_string_buffer(bytes(unique_id), 128), C.byref(st))
+        if not self._comm:
+            raise RuntimeError("gr_comm_create: status %d (RCCL: %s)" % (st.value, self._lib.gr_comm_library().decode()))
+
+    def close(self):
+        if getattr(self, "_comm", None):
+            self._lib.gr_comm_destroy(self._comm)
+            self._comm = None
+
+    def gather_per_frame(self, local_values, n_total):
+        local = np.ascontiguousarray(local_values, dtype=np.float32)
+        width = int(np.prod(local.shape[1:])) if local.ndim > 1 else 1
+        out = np.zeros((n_total,) + tuple(local.shape[1:]), np.float32)
+        st = self._lib.gr_comm_gather_per_frame(self._comm, local.ctypes.data_as(C.c_void_p), int(n_total), width, out.ctypes.data_as(C.c_void_p))
+        if st != 0:
+            raise RuntimeError("gr_comm_gather_per_frame: %s" % self._lib.gr_comm_last_error(self._comm).decode())
+        return out
+
+    def any_error(self, flag):
+        r = C.c_int(0)
+        st = self._lib.gr_comm_any_error(self._comm, int(bool(flag)), C.byref(r))
+        if st != 0:
+            raise RuntimeError("gr_comm_any_error: %s" % self._lib.gr_comm_last_error(self._comm).decode())
+        return bool(r.value)

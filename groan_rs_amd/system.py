@@ -281,12 +281,24 @@ class System:
         elif box is not None:
             self.set_box(box)
 
+    @classmethod
+    def _borrow(cls, ctx, n_atoms, n_slots, device, name="System"):
+        """a System over a context somebody else owns (the workers of a gr_pool): close() releases the plans, not the context"""
+        self = cls.__new__(cls)
+        self._lib = _lib.load()
+        self._ctx, self._owned = ctx, False
+        self.name, self.n_atoms, self.n_slots, self.device = name, int(n_atoms), int(n_slots), int(device)
+        self.simulation_step, self.simulation_time = 0, 0.0
+        self._plans = []
+        return self
+
     # -- lifetime
     def close(self):
         if getattr(self, "_ctx", None):
             for p in self._plans:
                 p.close()
-            self._lib.gr_ctx_destroy(self._ctx)
+            if getattr(self, "_owned", True):
+                self._lib.gr_ctx_destroy(self._ctx)
             self._ctx = None
 
     def __del__(self):

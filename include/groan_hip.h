@@ -405,6 +405,46 @@ int gr_xtc_read_frame(const gr_xtc *xtc, uint64_t frame, float *xyz, float box9[
 int gr_xtc_read_frames_device(const gr_xtc *xtc, uint64_t first_frame, uint32_t n_frames, uint64_t frame_step, gr_ctx *ctx,
                               uint32_t first_slot, int host_threads, uint64_t *steps, float *times);
 
+/* ---------------------------------------------------------------- frame-sharded map-reduce over several GPUs
+ * System::traj_iter_map_reduce (src/system/parallel.rs:208-481): frames are independent units; worker w of T takes frames
+ * w, w + T, ... (parallel.rs:424-448); every worker owns a clone of the System; a shared error flag, polled every 10 frames,
+ * stops the others when one fails (parallel.rs:28,453-475) and the call as a whole fails (:288-321); the per-worker results
+ * are merged at the end (ParallelTrajData::reduce, :31-49).  Bulk frame data never crosses GPUs: no data-path collective.
+ *
+ * In-process form (one host process, several GPUs or several workers per GPU): gr_pool_create makes one context per entry of
+ * `devices` (System::clone per worker) -- set masses / groups / plans on them through gr_pool_ctx.  gr_pool_map runs `body`
+ * for frames 0 .. n_frames - 1 on the workers' own threads (worker w: frames w, w + T, ...); the body loads its frame into its
+ * context (gr_frame_upload, gr_xtc_read_frames_device ...: the xtc / trr handles are thread-safe), analyses it and writes
+ * `width` floats to `result`, which IS the frame's row of `results` -- the order is restored by construction, the gather is
+ * host memory.  A non-zero return is the frame's error: the first one wins, becomes the return value of gr_pool_map
+ * (*error_frame = its frame), and the other workers stop at their next flag check; *frames_done counts completed frames. */
+typedef struct gr_pool gr_pool;
+typedef int (*gr_pool_body)(gr_ctx *ctx, int worker, uint64_t frame, void *user, float *result);
+gr_pool *gr_pool_create(const int *devices, int n_workers, uint64_t n_atoms, uint32_t n_slots, int *status);
+void gr_pool_destroy(gr_pool *pool);
+int gr_pool_size(const gr_pool *pool);
+gr_ctx *gr_pool_ctx(gr_pool *pool, int worker);
+const char *gr_pool_last_error(const gr_pool *pool);
+int gr_pool_map(gr_pool *pool, uint64_t n_frames, gr_pool_body body, void *user, size_t width, float *results,
+                uint64_t *frames_done, uint64_t *error_frame);
+/* Multi-process form (one process per GPU, e.g. under torchrun / mpirun): an RCCL communicator over xGMI for the two exchanges
+ * the path has -- the final gather of the per-frame results and the shared error flag.  Rank 0 calls gr_comm_unique_id and
+ * hands the 128 bytes to every rank by whatever the launcher offers (a file, MPI_Bcast, torch.distributed ...); every rank
+ * then calls gr_comm_create (collective).  gr_comm_gather_per_frame: `local` holds this rank's frames rank, rank + G, ...
+ * ([n_local][width], host memory); every rank receives all n_total rows in frame order (out[f] = shard[f mod G][f div G]): ONE
+ * ncclAllGather of ceil(n_total / G) x width floats per rank.  gr_comm_any_error: 1-int ncclAllReduce(MAX) of the flag.
+ * RCCL is resolved at run time (gr_comm_library says from where); without it these calls return GR_E_NO_DEVICE. */
+typedef struct gr_comm gr_comm;
+int gr_comm_unique_id(void *id128);
+gr_comm *gr_comm_create(int device, int rank, int world, const void *id128, int *status);
+void gr_comm_destroy(gr_comm *comm);
+const char *gr_comm_last_error(const gr_comm *comm);
+const char *gr_comm_library(void);
+int gr_comm_gather_per_frame(gr_comm *comm, const float *local, uint64_t n_total, size_t width, float *out);
+int gr_comm_any_error(gr_comm *comm, int local_flag, int *any);
+/* the host half of the gather on its own (no device, no RCCL): `gathered` = G shards of ceil(n_total / G) rows -> frame order */
+void gr_shard_deinterleave(const float *gathered, int world, uint64_t n_total, size_t width, float *out);
+
 /* ---------------------------------------------------------------- measurement / synthetic data
  * HIP-event timing on the context's stream (the stream the kernels are launched on). */
 int gr_timer_start(gr_ctx *ctx);

@@ -122,3 +122,21 @@ def test_world_size_2_gloo(fail_at):
         assert sum(("frame %d" % fail_at) in e for e in errs) == 1
         assert sum(e.startswith("aborted: ") for e in errs) == 1
         assert all(d is None for _, d, _, _ in res)
+
+
+def test_abi_deinterleave_matches_the_python_gather():
+    """gr_shard_deinterleave (the host half of gr_comm_gather_per_frame; no device, no RCCL) == interleave()"""
+    import ctypes as C
+    from groan_rs_amd import _lib
+    lib = _lib.load()
+    for world in (1, 2, 3, 8):
+        for n in (1, 7, 64, 1001):
+            for width in (1, 4):
+                full = (np.arange(n * width, dtype=np.float32) * 0.5).reshape(n, width)
+                per = (n + world - 1) // world
+                shards = np.zeros((world, per, width), np.float32)
+                for r in range(world):
+                    loc = full[r::world]; shards[r, : loc.shape[0]] = loc
+                out = np.zeros((n, width), np.float32)
+                lib.gr_shard_deinterleave(shards.ctypes.data_as(C.c_void_p), world, n, width, out.ctypes.data_as(C.c_void_p))
+                assert np.array_equal(out, full) and np.array_equal(out, interleave([s for s in shards], n))
