@@ -57,6 +57,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE", help="gr_ctx_set_tuning (sub_batch, chunks, fit_wgs, fuse, "
                     "two_pass): launch-geometry sweeps; the defaults are the measured optimum")
+    ap.add_argument("--gather", choices=["torch", "abi"], default="torch", help="final gather of the per-frame RMSDs at N > 1: torch.distributed "
+                    "all_gather (backend nccl = RCCL; the launch contract's own channel) or the library's C-ABI communicator (gr_comm_*: "
+                    "ncclCommInitRank + ncclAllGather; the unique id travels through torch.distributed)")
     ap.add_argument("--cpu-baseline-child", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--with-torch", action="store_true", help="import torch first even at N=1 (coexistence check)")
     args = ap.parse_args()
@@ -97,6 +100,11 @@ def main():
     import groan_rs_amd as G
 
     from groan_rs_amd import workload as WL
+    abi_comm = None
+    if dist is not None and world > 1 and args.gather == "abi":
+        ids = [G.Comm.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        abi_comm = G.Comm(local_rank, rank, world, ids[0])
 
     G._lib.load()
     n = args.atoms
@@ -160,7 +168,10 @@ def main():
     gathered = None
     if dist is not None:
         # final gather of the per-frame RMSDs (K*B floats per rank) over RCCL, restored to global frame order
-        gathered = G.gather_per_frame(rmsd_all.reshape(-1), K * B * world, dist=dist, device=tdev)
+        if abi_comm is not None:
+            gathered = abi_comm.gather_per_frame(rmsd_all.reshape(-1), K * B * world)
+        else:
+            gathered = G.gather_per_frame(rmsd_all.reshape(-1), K * B * world, dist=dist, device=tdev)
     gpu_ms = cur.timer_stop()
     barrier()
     t1 = time.perf_counter()
@@ -219,7 +230,7 @@ def main():
         "config": {"workload": "synthetic %d-atom rhombic-dodecahedral (triclinic) frames resident in HBM, Kabsch RMSD-fit of all atoms "
                                "(BASELINE configs[3] shard per GPU)" % n,
                    "n_atoms": n, "frames_per_step": B, "frames_per_gpu": K * B, "selection": "all atoms", "box9": [float(x) for x in box],
-                   "pool_frames": pool, "reused_frames": reused, "parallelism": "frames round-robin over %d GPU(s), final RCCL gather" % world,
+                   "pool_frames": pool, "reused_frames": reused, "parallelism": "frames round-robin over %d GPU(s), final RCCL gather (%s)" % (world, "gr_comm_gather_per_frame" if abi_comm is not None else "torch.distributed all_gather"),
                    "fallback_frames": fallbacks, "synth_seconds": round(t_gen, 2), "step_ms": step_ms,
                    "per_rank_frames_per_s": [round(v, 1) for v in per_rank_fps]},
         "roofline": roofline,
