@@ -125,6 +125,8 @@ SIGNATURES = {
     "gr_xtc_write_frame": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float]),
     "gr_xtc_write_slots": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_char_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int]),
     "gr_xtc_read_frames_device": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]),
+    "gr_xtc_read_frame_prefix": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, c_u64p, c_f32p, c_f32p, c_u64p]),
+    "gr_xtc_read_frames_device_group": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_void_p, C.c_uint32, C.c_char_p, C.c_int, C.c_void_p, C.c_void_p]),
     "gr_shape_sphere": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float]),
     "gr_shape_rectangular": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float]),
     "gr_shape_cylinder": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int]),

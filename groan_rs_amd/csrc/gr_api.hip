@@ -41,6 +41,7 @@ struct Group {
     bool contiguous = true;
     uint32_t start = 0;
     uint32_t *idx_dev = nullptr;
+    uint32_t *mask_dev = nullptr;     // one bit per atom of the system (group-limited trajectory reads), built on first use
 };
 
 }  // namespace
@@ -216,6 +217,17 @@ int busy_check(gr_ctx *c) {
     return GR_OK;
 }
 
+// device memory of a group that is being replaced / removed (kernels that read it may still be running)
+void group_release(gr_ctx *c, Group &g) {
+    if (!g.idx_dev && !g.mask_dev) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    if (c->unpack_stream) (void)hipStreamSynchronize(c->unpack_stream);
+    if (g.idx_dev) (void)hipFree(g.idx_dev);
+    if (g.mask_dev) (void)hipFree(g.mask_dev);
+    g.idx_dev = nullptr; g.mask_dev = nullptr;
+}
+
 // expand a block list into the device-side selection (nothing for a contiguous list)
 int group_build(gr_ctx *c, std::vector<grc::Block> blocks, Group *out) {
     uint64_t bad = 0;
@@ -245,7 +257,7 @@ int install_group(gr_ctx *c, const char *name, std::vector<grc::Block> blocks) {
     Group g;
     st = group_build(c, std::move(blocks), &g); if (st) return st;   // on failure the context is unchanged (no group created, none lost)
     const bool existed = c->groups.count(name) != 0;
-    if (existed && c->groups[name].idx_dev) { (void)hipStreamSynchronize(c->stream); (void)hipFree(c->groups[name].idx_dev); }
+    if (existed) group_release(c, c->groups[name]);
     c->groups[name] = g;
     c->epoch++;
     return existed ? GR_E_GROUP_EXISTS : GR_OK;
@@ -526,7 +538,7 @@ void gr_ctx_destroy(gr_ctx *c) try {
     (void)hipSetDevice(c->device);
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    for (auto &kv : c->groups) if (kv.second.idx_dev) (void)hipFree(kv.second.idx_dev);
+    for (auto &kv : c->groups) { if (kv.second.idx_dev) (void)hipFree(kv.second.idx_dev); if (kv.second.mask_dev) (void)hipFree(kv.second.mask_dev); }
     if (c->frames) (void)hipFree(c->frames);
     if (c->aos_up) (void)hipFree(c->aos_up);
     if (c->aos_dl) (void)hipFree(c->aos_dl);
@@ -627,7 +639,7 @@ int gr_group_remove(gr_ctx *c, const char *name) try {
     { int st = busy_check(c); if (st) return st; }
     auto it = c->groups.find(name);
     if (it == c->groups.end()) return fail(c, GR_E_GROUP_NOT_FOUND, name);
-    if (it->second.idx_dev) { (void)hipSetDevice(c->device); (void)hipStreamSynchronize(c->stream); (void)hipFree(it->second.idx_dev); }
+    group_release(c, it->second);
     c->groups.erase(it);
     c->epoch++;
     return GR_OK;
@@ -1672,8 +1684,11 @@ int gr_xtc_read_frame(const gr_xtc *x, uint64_t frame, float *xyz, float box9[9]
     return xtc_status(grx::decode_frame(x->f, x->f.frames[frame], xyz, scratch));
 } catch (...) { return gr_abi_guard(); }
 
-int gr_xtc_read_frames_device(const gr_xtc *x, uint64_t first_frame, uint32_t n_frames, uint64_t frame_step, gr_ctx *c,
-                              uint32_t first_slot, int host_threads, uint64_t *steps, float *times) try {
+// frames of an xtc file -> frame slots, unpacked on the device.  group == nullptr: every atom (XtcReader); else only the atoms of
+// the group change (GroupXtcReader, molly_xtc.rs:440-470,585-587): the host reads + skims the bit stream only up to the group's
+// last atom, only that prefix crosses PCIe, and the unpack kernel writes the group's atoms only.
+static int xtc_read_frames_device_impl(const gr_xtc *x, uint64_t first_frame, uint32_t n_frames, uint64_t frame_step, gr_ctx *c,
+                                       uint32_t first_slot, const char *group, int host_threads, uint64_t *steps, float *times) {
     if (!x || !c) return GR_E_INVALID_ARG;
     int st = slot_check(c, first_slot, n_frames, true); if (st) return st;
     if (frame_step == 0) frame_step = 1;
@@ -1681,29 +1696,50 @@ int gr_xtc_read_frames_device(const gr_xtc *x, uint64_t first_frame, uint32_t n_
     if (x->f.natoms != c->n) return fail(c, GR_E_INVALID_ARG, "the trajectory's atom count differs from the context's");
     (void)hipSetDevice(c->device);
     const uint32_t n = x->f.natoms;
+    Group *g = nullptr;
+    uint32_t n_stop = n;
+    if (group) {
+        auto it = c->groups.find(group);
+        if (it == c->groups.end()) return fail(c, GR_E_GROUP_NOT_FOUND, group);            // ReadTrajError::GroupNotFound
+        g = &it->second;
+        n_stop = g->blocks.empty() ? 0u : (uint32_t)(g->blocks.back().second + 1);       // everything up to the group's last atom
+        if (!g->mask_dev && g->n) {
+            std::vector<uint32_t> bits(((size_t)c->n_pad + 31) / 32, 0u);
+            for (const auto &b : g->blocks) for (uint64_t a = b.first; a <= b.second; ++a) bits[a >> 5] |= 1u << (a & 31u);
+            HIPCHK(c, hipMalloc(&g->mask_dev, bits.size() * sizeof(uint32_t)));
+            HIPCHK(c, hipMemcpy(g->mask_dev, bits.data(), bits.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        }
+    }
     if (n <= 9) {   // uncompressed frames: nothing to unpack
-        std::vector<float> xyz(3 * (size_t)n);
+        std::vector<float> xyz(3 * (size_t)n), old(3 * (size_t)n);
         for (uint32_t k = 0; k < n_frames; ++k) {
             float box9[9];
             st = gr_xtc_read_frame(x, first_frame + k * frame_step, xyz.data(), box9, steps ? steps + k : nullptr, times ? times + k : nullptr, nullptr); if (st) return st;
+            if (g) {   // keep the atoms outside the group
+                st = gr_frame_download(c, first_slot + k, old.data()); if (st) return st;
+                for (uint32_t a = 0; a < n; ++a) if (!grc::isin(g->blocks, a)) memcpy(&xyz[3 * a], &old[3 * a], 12);
+            }
             st = gr_frame_upload(c, first_slot + k, xyz.data(), box9); if (st) return st;
             st = gr_frame_upload_wait(c, first_slot + k); if (st) return st;
         }
         return GR_OK;
     }
-    static const bool trace = getenv("GR_XTC_TRACE") != nullptr;   // host phase times to stderr
+    static const bool trace = getenv("GR_XTC_TRACE") != nullptr;   // host phase times to stderr (tracing only: no effect on results)
     const auto t_call = std::chrono::steady_clock::now();
     // ---- layout of the batch's staging buffer: [streams (16-byte aligned, 16 zero bytes behind each)] [descs] [slots] [checkpoints]
-    const uint32_t ncp = (n + GR_XTC_CP_ATOMS - 1) / GR_XTC_CP_ATOMS;
-    std::vector<size_t> soff(n_frames);
+    const uint32_t ncp = (n_stop + GR_XTC_CP_ATOMS - 1) / GR_XTC_CP_ATOMS;
+    std::vector<size_t> soff(n_frames), sread(n_frames);
     size_t bytes = 0;
     for (uint32_t k = 0; k < n_frames; ++k) {
         const grx::FrameIndex &fi = x->f.frames[first_frame + k * frame_step];
         soff[k] = bytes; bytes += ((size_t)fi.nbytes + 16 + 15) & ~(size_t)15;
+        // a partial read starts with the share of the stream the group's prefix should need (mean bits per atom + 30 %)
+        sread[k] = n_stop >= n ? (size_t)fi.nbytes : std::min<size_t>((size_t)fi.nbytes, (size_t)((double)fi.nbytes * ((double)n_stop / (double)n) * 1.3) + 256);
     }
+    const size_t stream_bytes = bytes;
     const size_t off_desc = bytes;  bytes += (size_t)n_frames * sizeof(grx::FrameDesc);
     const size_t off_slot = bytes;  bytes += (((size_t)n_frames * sizeof(uint32_t)) + 15) & ~(size_t)15;
-    const size_t off_cp = bytes;    bytes += (size_t)n_frames * ncp * sizeof(grx::Checkpoint);
+    const size_t off_cp = bytes;    bytes += (size_t)n_frames * (ncp ? ncp : 1) * sizeof(grx::Checkpoint);
     const uint32_t bank = c->xtc_bank; c->xtc_bank ^= 1u;
     if (c->xtc_ev[bank]) HIPCHK(c, hipEventSynchronize(c->xtc_ev[bank]));       // the batch before the previous one has left this bank
     else HIPCHK(c, hipEventCreateWithFlags(&c->xtc_ev[bank], hipEventDisableTiming));
@@ -1728,37 +1764,53 @@ int gr_xtc_read_frames_device(const gr_xtc *x, uint64_t first_frame, uint32_t n_
     grx::FrameDesc *descs = reinterpret_cast<grx::FrameDesc *>(H + off_desc);
     uint32_t *slots = reinterpret_cast<uint32_t *>(H + off_slot);
     grx::Checkpoint *cps = reinterpret_cast<grx::Checkpoint *>(H + off_cp);
-    // ---- host: read + skim, one frame per worker at a time
+    // ---- host: read + skim, TWO frames per worker at a time (their walks are interleaved: skim_pair)
     std::atomic<uint32_t> next(0);
     std::atomic<int> bad(grx::XTC_OK);
     std::atomic<uint64_t> ns_read(0), ns_skim(0);
     const auto t_begin = std::chrono::steady_clock::now();
     auto work = [&]() {
-        std::vector<grx::Checkpoint> local;
+        std::vector<grx::Checkpoint> local[2];
         for (;;) {
-            const uint32_t k = next.fetch_add(1);
-            if (k >= n_frames) return;
-            const grx::FrameIndex &fi = x->f.frames[first_frame + k * frame_step];
-            unsigned char *dst = H + soff[k];
+            const uint32_t k0 = next.fetch_add(2);
+            if (k0 >= n_frames) return;
+            const uint32_t nk = std::min<uint32_t>(2u, n_frames - k0);
+            grx::Skim sk[2]; grx::FrameDesc d[2];
             const auto t0 = std::chrono::steady_clock::now();
-            if (!grx::pread_all(x->f.fd, dst, (size_t)fi.nbytes, fi.data_offset)) { bad = grx::XTC_E_IO; return; }
-            memset(dst + fi.nbytes, 0, (((size_t)fi.nbytes + 16 + 15) & ~(size_t)15) - (size_t)fi.nbytes);
-            grx::FrameDesc d; memset(&d, 0, sizeof d);
-            d.stream_off = soff[k]; d.cp_off = (uint64_t)k * ncp;
+            for (uint32_t q = 0; q < nk; ++q) {
+                const uint32_t k = k0 + q;
+                const grx::FrameIndex &fi = x->f.frames[first_frame + k * frame_step];
+                unsigned char *dst = H + soff[k];
+                if (!grx::pread_all(x->f.fd, dst, sread[k], fi.data_offset)) { bad = grx::XTC_E_IO; return; }
+                memset(dst + sread[k], 0, (((size_t)fi.nbytes + 16 + 15) & ~(size_t)15) - sread[k]);
+                memset(&d[q], 0, sizeof d[q]);
+                d[q].stream_off = soff[k]; d[q].cp_off = (uint64_t)k * ncp;
+                if (sk[q].begin(dst, fi, n, d[q], local[q], n_stop) && sread[k] < (size_t)fi.nbytes) sk[q].have_bits = (uint64_t)sread[k] * 8;
+            }
             const auto t1 = std::chrono::steady_clock::now();
-            const int r = grx::skim_frame(dst, fi, n, d, local);
+            if (nk == 2) grx::skim_pair(sk[0], sk[1]); else grx::skim_run(sk[0]);
+            for (uint32_t q = 0; q < nk; ++q) {
+                const uint32_t k = k0 + q;
+                const grx::FrameIndex &fi = x->f.frames[first_frame + k * frame_step];
+                int r = sk[q].finish();
+                if (r == grx::XTC_E_RANGE) {   // the estimate of the prefix was too short: read the whole stream, walk again
+                    unsigned char *dst = H + soff[k];
+                    if (!grx::pread_all(x->f.fd, dst, (size_t)fi.nbytes, fi.data_offset)) { bad = grx::XTC_E_IO; return; }
+                    r = grx::skim_frame(dst, fi, n, d[q], local[q], n_stop);
+                }
+                if (r != grx::XTC_OK || local[q].size() != ncp) { bad = r != grx::XTC_OK ? r : (int)grx::XTC_E_FORMAT; return; }
+                if (ncp) memcpy(cps + (size_t)k * ncp, local[q].data(), ncp * sizeof(grx::Checkpoint));
+                descs[k] = d[q]; slots[k] = first_slot + k;
+            }
             if (trace) {
                 const auto t2 = std::chrono::steady_clock::now();
                 ns_read += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count();
                 ns_skim += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(t2 - t1).count();
             }
-            if (r != grx::XTC_OK || local.size() != ncp) { bad = r != grx::XTC_OK ? r : (int)grx::XTC_E_FORMAT; return; }
-            memcpy(cps + (size_t)k * ncp, local.data(), ncp * sizeof(grx::Checkpoint));
-            descs[k] = d; slots[k] = first_slot + k;
         }
     };
-    uint32_t nt = host_threads > 0 ? (uint32_t)host_threads : std::min<uint32_t>(n_frames, 16u);
-    nt = std::max<uint32_t>(1u, std::min<uint32_t>(nt, n_frames));
+    uint32_t nt = host_threads > 0 ? (uint32_t)host_threads : std::min<uint32_t>((n_frames + 1) / 2, 16u);
+    nt = std::max<uint32_t>(1u, std::min<uint32_t>(nt, (n_frames + 1) / 2));
     if (nt == 1) work();
     else {
         // (a thread that cannot be started must not unwind through the C ABI: the frames it would have taken are picked up by
@@ -1788,7 +1840,14 @@ int gr_xtc_read_frames_device(const gr_xtc *x, uint64_t first_frame, uint32_t n_
         box_fill(c, first_slot + k, box9);
     }
     HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->xtc_unpacked[bank], 0));
-    HIPCHK(c, hipMemcpyAsync(D, H, bytes, hipMemcpyHostToDevice, c->copy_stream));
+    if (n_stop >= n) {
+        HIPCHK(c, hipMemcpyAsync(D, H, bytes, hipMemcpyHostToDevice, c->copy_stream));
+    } else {
+        // partial read: only the stream prefixes the skim said the group needs cross PCIe, then the tables
+        for (uint32_t k = 0; k < n_frames; ++k)
+            if (descs[k].nbytes) HIPCHK(c, hipMemcpyAsync(D + soff[k], H + soff[k], ((size_t)descs[k].nbytes + 16 + 15) & ~(size_t)15, hipMemcpyHostToDevice, c->copy_stream));
+        HIPCHK(c, hipMemcpyAsync(D + stream_bytes, H + stream_bytes, bytes - stream_bytes, hipMemcpyHostToDevice, c->copy_stream));
+    }
     HIPCHK(c, hipEventRecord(c->xtc_ev[bank], c->copy_stream));
     hipStream_t U = c->unpack_stream;
     HIPCHK(c, hipStreamWaitEvent(U, c->xtc_ev[bank], 0));
@@ -1798,10 +1857,12 @@ int gr_xtc_read_frames_device(const gr_xtc *x, uint64_t first_frame, uint32_t n_
         if (gen && gen != waited) { HIPCHK(c, hipStreamWaitEvent(U, c->ev_done_ring[gen % 64], 0)); waited = gen; }
     }
     HIPCHK(c, hipMemcpyAsync(c->boxes_dev + first_slot, c->boxes_host + first_slot, (size_t)n_frames * sizeof(GrBox), hipMemcpyHostToDevice, U));
-    k_xtc_unpack<<<dim3((ncp + 255) / 256, n_frames), dim3(256), 0, U>>>(
-        D, reinterpret_cast<const grx::FrameDesc *>(D + off_desc), reinterpret_cast<const grx::Checkpoint *>(D + off_cp),
-        c->frames, c->frame_stride, reinterpret_cast<const uint32_t *>(D + off_slot), n);
-    HIPCHK(c, hipGetLastError());
+    if (ncp) {
+        k_xtc_unpack<<<dim3((ncp + 255) / 256, n_frames), dim3(256), 0, U>>>(
+            D, reinterpret_cast<const grx::FrameDesc *>(D + off_desc), reinterpret_cast<const grx::Checkpoint *>(D + off_cp),
+            c->frames, c->frame_stride, reinterpret_cast<const uint32_t *>(D + off_slot), n, g ? g->mask_dev : nullptr);
+        HIPCHK(c, hipGetLastError());
+    }
     HIPCHK(c, hipEventRecord(c->xtc_unpacked[bank], U));
     for (uint32_t k = 0; k < n_frames; ++k) {
         HIPCHK(c, hipEventRecord(c->ev_ready[first_slot + k], U));
@@ -1814,6 +1875,30 @@ int gr_xtc_read_frames_device(const gr_xtc *x, uint64_t first_frame, uint32_t n_
                 n_frames, nt, ms(t_call, t_begin), ms(t_begin, t_host), ns_read.load() * 1e-6 / n_frames, ns_skim.load() * 1e-6 / n_frames, ms(t_host, t_end));
     }
     return GR_OK;
+}
+
+int gr_xtc_read_frames_device(const gr_xtc *x, uint64_t first_frame, uint32_t n_frames, uint64_t frame_step, gr_ctx *c,
+                              uint32_t first_slot, int host_threads, uint64_t *steps, float *times) try {
+    return xtc_read_frames_device_impl(x, first_frame, n_frames, frame_step, c, first_slot, nullptr, host_threads, steps, times);
+} catch (...) { return gr_abi_guard(); }
+
+int gr_xtc_read_frames_device_group(const gr_xtc *x, uint64_t first_frame, uint32_t n_frames, uint64_t frame_step, gr_ctx *c,
+                                    uint32_t first_slot, const char *group, int host_threads, uint64_t *steps, float *times) try {
+    if (!group) return c ? fail(c, GR_E_GROUP_NOT_FOUND, "(null)") : GR_E_INVALID_ARG;
+    return xtc_read_frames_device_impl(x, first_frame, n_frames, frame_step, c, first_slot, group, host_threads, steps, times);
+} catch (...) { return gr_abi_guard(); }
+
+int gr_xtc_read_frame_prefix(const gr_xtc *x, uint64_t frame, uint64_t n_prefix, float *xyz, float box9[9], uint64_t *step, float *time, float *precision,
+                             uint64_t *stream_bytes_read) try {
+    if (!x || (!xyz && n_prefix)) return GR_E_INVALID_ARG;
+    int st = gr_xtc_frame_info(x, frame, step, time, box9, precision);
+    if (st != GR_OK) return st;
+    static thread_local std::vector<unsigned char> scratch;
+    size_t got = 0;
+    const uint32_t want = (uint32_t)std::min<uint64_t>(n_prefix, x->f.natoms);
+    st = xtc_status(grx::decode_frame_prefix(x->f, x->f.frames[frame], want, xyz, scratch, &got));
+    if (stream_bytes_read) *stream_bytes_read = got;
+    return st;
 } catch (...) { return gr_abi_guard(); }
 
 static void box9_rows(const float *b, float m[9]);

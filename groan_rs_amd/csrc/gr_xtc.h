@@ -193,13 +193,22 @@ inline int open_file(File &f, const char *path) {
 // zero bytes kept behind a bit stream: the position is checked once per group, and one group of a corrupt stream can pull
 // 96 + 6 + 8 * 72 bits (< 96 bytes) past the last valid position before that check sees it
 #define GR_XTC_PAD 128
-inline int decode_frame(const File &f, const FrameIndex &fi, float *xyz, std::vector<unsigned char> &scratch) {
+// n_want < natoms = PARTIAL decode (the reference's GroupXtcReader through the molly crate, molly_xtc.rs:475-560: "all positions
+// up to the end of the group must be loaded" and nothing behind it): the bit stream is walked only until atom n_want - 1 has
+// been produced and only `have` bytes of it are in `scratch` (the caller reads a prefix and retries with more when the walk
+// runs off its end: XTC_E_RANGE).  xyz receives n_want atoms; groups that straddle n_want are decoded into `spill`.
+inline int decode_frame(const File &f, const FrameIndex &fi, float *xyz, std::vector<unsigned char> &scratch, uint32_t n_want = 0xFFFFFFFFu, size_t have = (size_t)-1) {
     const uint32_t n = f.natoms;
-    scratch.resize((size_t)fi.nbytes + GR_XTC_PAD);
-    if (!pread_all(f.fd, scratch.data(), (size_t)fi.nbytes, fi.data_offset)) return XTC_E_IO;
-    memset(scratch.data() + fi.nbytes, 0, GR_XTC_PAD);
+    const bool partial = n_want < n;
+    if (!partial) {
+        n_want = n;
+        have = (size_t)fi.nbytes;
+        scratch.resize((size_t)fi.nbytes + GR_XTC_PAD);
+        if (!pread_all(f.fd, scratch.data(), (size_t)fi.nbytes, fi.data_offset)) return XTC_E_IO;
+        memset(scratch.data() + fi.nbytes, 0, GR_XTC_PAD);
+    }
     if (n <= 9) {
-        for (uint32_t k = 0; k < 3 * n; ++k) xyz[k] = bef(scratch.data() + 4 * k);
+        for (uint32_t k = 0; k < 3 * n_want; ++k) xyz[k] = bef(scratch.data() + 4 * k);
         return XTC_OK;
     }
     uint32_t sizeint[3];
@@ -221,10 +230,14 @@ inline int decode_frame(const File &f, const FrameIndex &fi, float *xyz, std::ve
     const float inv_precision = (float)(1.0 / (double)fi.precision);
     Bits bits(scratch.data());
     const size_t limit = (size_t)fi.nbytes + 8;
+    // partial decode: atoms land in a buffer that also takes the tail of a group straddling n_want (a group holds <= 9 atoms)
+    std::vector<float> part;
     float *out = xyz;
+    if (partial) { part.resize(3 * ((size_t)n_want + 10)); out = part.data(); }
+    const float *out0 = out;
     int run = 0;
     uint32_t i = 0;
-    while (i < n) {
+    while (i < n_want) {
         int cur[3];
         if (bitsize == 0) { cur[0] = (int)bits.get(bitsizeint[0]); cur[1] = (int)bits.get(bitsizeint[1]); cur[2] = (int)bits.get(bitsizeint[2]); }
         else unpack3(bits, bitsize, sizeint, inv_large, cur);
@@ -259,13 +272,33 @@ inline int decode_frame(const File &f, const FrameIndex &fi, float *xyz, std::ve
             *out++ = cur[0] * inv_precision; *out++ = cur[1] * inv_precision; *out++ = cur[2] * inv_precision;
         }
         if (bits.pos > limit) return XTC_E_FORMAT;
+        // (the window pulls 4 bytes at a time: what counts is the bits CONSUMED, not the bytes pulled)
+        if (partial && (uint64_t)bits.pos * 8 - (uint64_t)bits.have > (uint64_t)have * 8) return XTC_E_RANGE;      // walked off the prefix that was read: the caller reads more
         smallidx += change;
         if (smallidx < kFirstIdx || smallidx >= kLastIdx) return XTC_E_FORMAT;
         if (change < 0) { smallnum = smaller; smaller = smallidx > kFirstIdx ? kMagic[smallidx - 1] / 2 : 0; }
         else if (change > 0) { smaller = smallnum; smallnum = kMagic[smallidx] / 2; }
         if (change != 0) { sizesmall[0] = sizesmall[1] = sizesmall[2] = (uint32_t)kMagic[smallidx]; inv_small[0] = inv_small[1] = 1.0 / (double)sizesmall[1]; }
     }
+    if (partial) memcpy(xyz, out0, 3 * (size_t)n_want * sizeof(float));
     return XTC_OK;
+}
+
+// decode the first n_want atoms of a frame, reading only as much of its bit stream as the walk needs (estimate from the
+// frame's mean bits per atom, doubled on a miss)
+inline int decode_frame_prefix(const File &f, const FrameIndex &fi, uint32_t n_want, float *xyz, std::vector<unsigned char> &scratch, size_t *bytes_read = nullptr) {
+    if (n_want >= f.natoms || f.natoms <= 9) { if (bytes_read) *bytes_read = (size_t)fi.nbytes; return decode_frame(f, fi, xyz, scratch); }
+    if (n_want == 0) { if (bytes_read) *bytes_read = 0; return XTC_OK; }
+    size_t want = (size_t)((double)fi.nbytes * ((double)n_want / (double)f.natoms) * 1.3) + 256;
+    for (;;) {
+        if (want > (size_t)fi.nbytes) want = (size_t)fi.nbytes;
+        scratch.resize(want + GR_XTC_PAD);
+        if (!pread_all(f.fd, scratch.data(), want, fi.data_offset)) return XTC_E_IO;
+        memset(scratch.data() + want, 0, GR_XTC_PAD);
+        const int r = decode_frame(f, fi, xyz, scratch, n_want, want);
+        if (r != XTC_E_RANGE || want == (size_t)fi.nbytes) { if (bytes_read) *bytes_read = want; return r == XTC_E_RANGE ? (int)XTC_E_FORMAT : r; }
+        want *= 2;
+    }
 }
 
 
@@ -281,7 +314,7 @@ struct FrameDesc {                                      // one per frame of a ba
     int32_t minint[3]; uint32_t sizeint[3];
     int32_t bitsize, bitsizeint[3];
     float inv_precision;
-    uint32_t pad;
+    uint32_t n_end;            // atoms [0, n_end) are covered by the checkpoints (n_atoms for a full skim)
 };
 
 inline uint32_t peek_bits(const unsigned char *p, uint64_t bitpos, int n) {   // n <= 32; p is padded by >= 8 bytes
@@ -290,61 +323,101 @@ inline uint32_t peek_bits(const unsigned char *p, uint64_t bitpos, int n) {   //
 }
 
 // Walk the groups of one frame (natoms > 9): fills the descriptor's decoding constants and the checkpoints.
-inline int skim_frame(const unsigned char *stream, const FrameIndex &fi, uint32_t n, FrameDesc &d, std::vector<Checkpoint> &cps) {
-    for (int k = 0; k < 3; ++k) { d.minint[k] = fi.minint[k]; d.sizeint[k] = (uint32_t)fi.maxint[k] - (uint32_t)fi.minint[k] + 1u; }
-    if (d.sizeint[0] == 0 || d.sizeint[1] == 0 || d.sizeint[2] == 0) return XTC_E_FORMAT;   // corrupt header (the decoder refuses it too)
-    d.bitsizeint[0] = d.bitsizeint[1] = d.bitsizeint[2] = 0;
-    int large_bits;
-    if ((d.sizeint[0] | d.sizeint[1] | d.sizeint[2]) > 0xffffffu) {
-        for (int k = 0; k < 3; ++k) { int b = bit_length(d.sizeint[k]); d.bitsizeint[k] = b > 32 ? 32 : b; }
-        d.bitsize = 0;
-        large_bits = d.bitsizeint[0] + d.bitsizeint[1] + d.bitsizeint[2];
-    } else {
-        d.bitsize = bit_length((unsigned __int128)d.sizeint[0] * d.sizeint[1] * d.sizeint[2]);
-        large_bits = d.bitsize;
-    }
-    d.inv_precision = (float)(1.0 / (double)fi.precision);
-    d.nbytes = (uint32_t)fi.nbytes;
-    if (fi.nbytes >= (1ull << 29)) return XTC_E_FORMAT;        // bit positions are 32-bit
-    const uint64_t limit_bits = (fi.nbytes + 8) * 8;
-    cps.clear();
-    int smallidx = fi.smallidx, run = 0;
-    uint64_t bitpos = 0;
-    uint32_t i = 0, next_cp = 0;
-    while (i < n) {
-        if (i >= next_cp) {
-            while (next_cp <= i) { cps.push_back(Checkpoint{ (uint32_t)bitpos, i, (uint32_t)smallidx | ((uint32_t)run << 8) }); next_cp += GR_XTC_CP_ATOMS; }
-        }
-        bitpos += (uint64_t)large_bits;
-        if (bitpos + 6 > limit_bits) return XTC_E_FORMAT;       // the flag / run field below must lie inside the (padded) stream
-        ++i;
-        int change = 0;
-        if (peek_bits(stream, bitpos, 1)) {
-            run = (int)peek_bits(stream, bitpos + 1, 5);
-            bitpos += 6;
-            change = run % 3;
-            run -= change;
-            change -= 1;
+// The walk of one frame's skim.  Where the next group starts depends on the flag / run bits of this one: one dependent load per
+// group, ~170 k groups per 5e5-atom water frame.  The walk keeps its whole state in locals (GR_SKIM_STEP) so that TWO frames
+// can be walked in lockstep by one thread (skim_pair): two independent dependency chains in flight instead of one.
+// n_stop < n: PARTIAL skim (GroupXtcReader, molly_xtc.rs:475-560): stop at the first group that starts at or behind atom n_stop;
+// the checkpoints then cover atoms [0, n_end) and d.nbytes is the length of the stream prefix they need.  have_bits: the
+// prefix of the stream that is in memory -- walking past it is XTC_E_RANGE (the caller reads more and walks again).
+struct Skim {
+    const unsigned char *stream = nullptr; const FrameIndex *fi = nullptr; FrameDesc *d = nullptr; std::vector<Checkpoint> *cps = nullptr;
+    uint32_t n = 0, n_stop = 0, i = 0, next_cp = 0; int smallidx = 0, run = 0, large_bits = 0; uint64_t bitpos = 0, limit_bits = 0, have_bits = ~0ull;
+    int status = XTC_OK; bool done = false;
+    bool begin(const unsigned char *s, const FrameIndex &f, uint32_t n_atoms, FrameDesc &desc, std::vector<Checkpoint> &c, uint32_t stop) {
+        stream = s; fi = &f; d = &desc; cps = &c; n = n_atoms; n_stop = stop < n_atoms ? stop : n_atoms;
+        for (int k = 0; k < 3; ++k) { desc.minint[k] = f.minint[k]; desc.sizeint[k] = (uint32_t)f.maxint[k] - (uint32_t)f.minint[k] + 1u; }
+        if (desc.sizeint[0] == 0 || desc.sizeint[1] == 0 || desc.sizeint[2] == 0) { status = XTC_E_FORMAT; done = true; return false; }
+        desc.bitsizeint[0] = desc.bitsizeint[1] = desc.bitsizeint[2] = 0;
+        if ((desc.sizeint[0] | desc.sizeint[1] | desc.sizeint[2]) > 0xffffffu) {
+            for (int k = 0; k < 3; ++k) { int b = bit_length(desc.sizeint[k]); desc.bitsizeint[k] = b > 32 ? 32 : b; }
+            desc.bitsize = 0;
+            large_bits = desc.bitsizeint[0] + desc.bitsizeint[1] + desc.bitsizeint[2];
         } else {
-            bitpos += 1;
+            desc.bitsize = bit_length((unsigned __int128)desc.sizeint[0] * desc.sizeint[1] * desc.sizeint[2]);
+            large_bits = desc.bitsize;
         }
-        if (run > 0) {
-            if ((uint64_t)i + (uint64_t)(run / 3) > n) return XTC_E_FORMAT;
-            bitpos += (uint64_t)(run / 3) * (uint64_t)smallidx;
-            i += (uint32_t)(run / 3);
-        }
-        if (bitpos > limit_bits) return XTC_E_FORMAT;
-        smallidx += change;
-        if (smallidx < kFirstIdx || smallidx >= kLastIdx) return XTC_E_FORMAT;
+        desc.inv_precision = (float)(1.0 / (double)f.precision);
+        desc.nbytes = (uint32_t)f.nbytes;
+        if (f.nbytes >= (1ull << 29)) { status = XTC_E_FORMAT; done = true; return false; }
+        limit_bits = (f.nbytes + 8) * 8;
+        c.clear();
+        c.reserve((size_t)(n_stop + GR_XTC_CP_ATOMS - 1) / GR_XTC_CP_ATOMS + 2);
+        smallidx = f.smallidx;
+        return true;
     }
-    // one checkpoint per started window of 32 atoms, whether or not a group starts inside it (it always does: a group
-    // holds at most 9 atoms); pad so that the count is exactly ceil(n / 32)
-    const uint32_t want = (n + GR_XTC_CP_ATOMS - 1) / GR_XTC_CP_ATOMS;
-    while (cps.size() < want) cps.push_back(Checkpoint{ (uint32_t)bitpos, n, (uint32_t)smallidx });
-    d.n_cp = (uint32_t)cps.size();
-    return XTC_OK;
+    int finish() {
+        if (status != XTC_OK) return status;
+        // one checkpoint per started window of 32 atoms of [0, n_stop) (a group holds at most 9 atoms, so every window has a
+        // group starting in it); pad so that the count is exactly ceil(n_stop / 32)
+        const uint32_t want = (n_stop + GR_XTC_CP_ATOMS - 1) / GR_XTC_CP_ATOMS;
+        while (cps->size() < want) cps->push_back(Checkpoint{ (uint32_t)bitpos, i, (uint32_t)smallidx });
+        cps->resize(want);
+        d->n_cp = want;
+        d->n_end = i < n ? i : n;                  // first atom NOT covered by the checkpoints' segments (partial: >= n_stop)
+        if (n_stop < n) d->nbytes = (uint32_t)std::min<uint64_t>((bitpos + 7) / 8 + 16, fi->nbytes);
+        return XTC_OK;
+    }
+};
+
+// one group of the walk on LOCAL state: X = suffix of the locals (i, next_cp, bitpos, run, smallidx, status, done ...)
+#define GR_SKIM_LOCALS(X, S) \
+    const unsigned char *stream##X = (S).stream; uint32_t i##X = (S).i, next_cp##X = (S).next_cp; const uint32_t n##X = (S).n, n_stop##X = (S).n_stop; \
+    int smallidx##X = (S).smallidx, run##X = (S).run; const int large##X = (S).large_bits; uint64_t bitpos##X = (S).bitpos; \
+    const uint64_t limit##X = (S).limit_bits, have##X = (S).have_bits; int status##X = (S).status; bool done##X = (S).done; std::vector<Checkpoint> &cps##X = *(S).cps;
+#define GR_SKIM_STORE(X, S) (S).i = i##X; (S).next_cp = next_cp##X; (S).smallidx = smallidx##X; (S).run = run##X; (S).bitpos = bitpos##X; (S).status = status##X; (S).done = true;
+#define GR_SKIM_STEP(X) do { \
+    if (i##X >= n_stop##X) { done##X = true; break; } \
+    if (i##X >= next_cp##X) { while (next_cp##X <= i##X) { cps##X.push_back(Checkpoint{ (uint32_t)bitpos##X, i##X, (uint32_t)smallidx##X | ((uint32_t)run##X << 8) }); next_cp##X += GR_XTC_CP_ATOMS; } } \
+    bitpos##X += (uint64_t)large##X; \
+    if (bitpos##X + 6 > limit##X) { status##X = XTC_E_FORMAT; done##X = true; break; }       /* the flag / run field below must lie inside the (padded) stream */ \
+    ++i##X; \
+    int change_ = 0; \
+    const uint32_t six_ = peek_bits(stream##X, bitpos##X, 6); \
+    if (six_ & 32u) { run##X = (int)(six_ & 31u); bitpos##X += 6; change_ = run##X % 3; run##X -= change_; change_ -= 1; } else bitpos##X += 1; \
+    if (run##X > 0) { \
+        if ((uint64_t)i##X + (uint64_t)(run##X / 3) > n##X) { status##X = XTC_E_FORMAT; done##X = true; break; } \
+        bitpos##X += (uint64_t)(run##X / 3) * (uint64_t)smallidx##X; i##X += (uint32_t)(run##X / 3); \
+    } \
+    if (bitpos##X > limit##X) { status##X = XTC_E_FORMAT; done##X = true; break; } \
+    if (bitpos##X > have##X) { status##X = XTC_E_RANGE; done##X = true; break; }           /* partial read: the walk left the prefix that is in memory */ \
+    smallidx##X += change_; \
+    if (smallidx##X < kFirstIdx || smallidx##X >= kLastIdx) { status##X = XTC_E_FORMAT; done##X = true; break; } \
+} while (0)
+
+inline void skim_run(Skim &a) {
+    if (a.done) return;
+    GR_SKIM_LOCALS(A, a)
+    while (!doneA) GR_SKIM_STEP(A);
+    GR_SKIM_STORE(A, a)
+}
+// two frames in lockstep, then whichever is longer on its own
+inline void skim_pair(Skim &a, Skim &b) {
+    if (a.done || b.done) { skim_run(a); skim_run(b); return; }
+    GR_SKIM_LOCALS(A, a)
+    GR_SKIM_LOCALS(B, b)
+    while (!doneA && !doneB) { GR_SKIM_STEP(A); GR_SKIM_STEP(B); }
+    while (!doneA) GR_SKIM_STEP(A);
+    while (!doneB) GR_SKIM_STEP(B);
+    GR_SKIM_STORE(A, a)
+    GR_SKIM_STORE(B, b)
 }
 
+inline int skim_frame(const unsigned char *stream, const FrameIndex &fi, uint32_t n, FrameDesc &d, std::vector<Checkpoint> &cps, uint32_t n_stop = 0xFFFFFFFFu,
+                      uint64_t have_bytes = ~0ull) {
+    Skim s;
+    if (s.begin(stream, fi, n, d, cps, n_stop)) { if (have_bytes != ~0ull) s.have_bits = have_bytes * 8; skim_run(s); }
+    return s.finish();
+}
 
 // ================================================================================================ writer
 // The encoder of the same format (what the reference's XtcWriter produces through xdrfile's write_xtc,

@@ -72,12 +72,15 @@ __device__ __forceinline__ void gr_xtc_unpack3(GrBitsDev &b, int nbits, uint32_t
 // one lane = one checkpoint segment (~32 atoms) of one frame; grid (ceil(max n_cp / 256), frames)
 __global__ __launch_bounds__(256) void k_xtc_unpack(const unsigned char *__restrict__ streams, const grx::FrameDesc *__restrict__ descs,
                                                      const grx::Checkpoint *__restrict__ cps, float *__restrict__ frames, size_t frame_stride,
-                                                     const uint32_t *__restrict__ slots, uint32_t n_atoms) {
+                                                     const uint32_t *__restrict__ slots, uint32_t n_atoms, const uint32_t *__restrict__ mask) {
     const grx::FrameDesc &d = descs[blockIdx.y];
     const uint32_t m = blockIdx.x * 256u + threadIdx.x;
     if (m >= d.n_cp) return;
     const grx::Checkpoint cp = cps[d.cp_off + m];
-    const uint32_t end_atom = (m + 1 < d.n_cp) ? cps[d.cp_off + m + 1].atom : n_atoms;
+    // (a partial skim -- the reference's GroupXtcReader -- covers atoms [0, d.n_end) only; `mask` = one bit per atom: positions of
+    // atoms outside the group are decoded on the way but NOT written: "all other atoms are left unchanged", molly_xtc.rs:585-587)
+    const uint32_t end_atom = (m + 1 < d.n_cp) ? cps[d.cp_off + m + 1].atom : d.n_end;
+    (void)n_atoms;
     if (cp.atom >= end_atom) return;
     GrBitsDev bits;
     bits.init(streams + d.stream_off, cp.bitpos);
@@ -85,6 +88,7 @@ __global__ __launch_bounds__(256) void k_xtc_unpack(const unsigned char *__restr
     const float inv = d.inv_precision;
     float *slot = frames + (size_t)slots[blockIdx.y] * frame_stride;
     uint32_t o = cp.atom;          // next atom to be written (the slot is pair-tiled: gr_pos_store)
+    auto put = [&](uint32_t a, float x, float y, float z) { if (!mask || ((mask[a >> 5] >> (a & 31u)) & 1u)) gr_pos_store(slot, a, x, y, z); };
     uint32_t i = cp.atom;
     while (i < end_atom) {
         int cur[3];
@@ -109,17 +113,17 @@ __global__ __launch_bounds__(256) void k_xtc_unpack(const unsigned char *__restr
                 const int nxt[3] = { dl[0] + prev[0] - smallnum, dl[1] + prev[1] - smallnum, dl[2] + prev[2] - smallnum };
                 ++i;
                 if (k == 0) {   // the first small atom is stored AFTER its successor: emit it first
-                    gr_pos_store(slot, o, nxt[0] * inv, nxt[1] * inv, nxt[2] * inv);
-                    gr_pos_store(slot, o + 1, prev[0] * inv, prev[1] * inv, prev[2] * inv);
+                    put(o, nxt[0] * inv, nxt[1] * inv, nxt[2] * inv);
+                    put(o + 1, prev[0] * inv, prev[1] * inv, prev[2] * inv);
                     o += 2;
                 } else {
-                    gr_pos_store(slot, o, nxt[0] * inv, nxt[1] * inv, nxt[2] * inv);
+                    put(o, nxt[0] * inv, nxt[1] * inv, nxt[2] * inv);
                     o += 1;
                 }
                 prev[0] = nxt[0]; prev[1] = nxt[1]; prev[2] = nxt[2];
             }
         } else {
-            gr_pos_store(slot, o, cur[0] * inv, cur[1] * inv, cur[2] * inv);
+            put(o, cur[0] * inv, cur[1] * inv, cur[2] * inv);
             o += 1;
         }
         smallidx += change;

@@ -58,15 +58,30 @@ class XtcFile:
             raise XtcError(st, "read_frame(%d)" % i)
         return out, box, int(step.value), float(time.value), float(prec.value)
 
-    def read_frames_device(self, system, first_frame, n_frames, first_slot=0, frame_step=1, host_threads=0):
-        """frames first_frame, first_frame + frame_step, ... -> slots first_slot.. of `system`, unpacked on the GPU
-        (gr_xtc_read_frames_device): only the compressed stream crosses PCIe.  Asynchronous like upload_async.
-        -> (steps uint64[n], times float32[n])"""
+    def read_frame_prefix(self, i, n_prefix):
+        """gr_xtc_read_frame_prefix: the first n_prefix atoms of frame i (what a GroupXtcReader needs for a group whose last atom
+        is n_prefix - 1, molly_xtc.rs:475-560) -> (positions [n_prefix, 3], box9, step, time, precision, stream_bytes_read)"""
+        n_prefix = int(min(n_prefix, self.n_atoms))
+        xyz = np.zeros((max(n_prefix, 1), 3), np.float32); box = np.zeros(9, np.float32)
+        step = C.c_uint64(0); time = C.c_float(0); prec = C.c_float(0); got = C.c_uint64(0)
+        st = self._lib.gr_xtc_read_frame_prefix(self._x, int(i), n_prefix, xyz.ctypes.data_as(C.c_void_p), box.ctypes.data_as(C.c_void_p),
+                                                C.byref(step), C.byref(time), C.byref(prec), C.byref(got))
+        if st != 0:
+            raise XtcError(st, "frame %d" % i)
+        return xyz[:n_prefix], box, int(step.value), float(time.value), float(prec.value), int(got.value)
+
+    def read_frames_device(self, system, first_frame, n_frames, first_slot=0, frame_step=1, host_threads=0, group=None):
+        """frames first_frame, first_frame + frame_step, ... unpacked ON THE DEVICE into slots first_slot ... (asynchronous);
+        group = name: only that group's atoms change (GroupXtcReader / System::group_xtc_iter) -> (steps, times)"""
         steps = np.zeros(n_frames, np.uint64); times = np.zeros(n_frames, np.float32)
-        st = self._lib.gr_xtc_read_frames_device(self._x, first_frame, n_frames, frame_step, system._ctx, first_slot, host_threads,
-                                                 steps.ctypes.data_as(C.c_void_p), times.ctypes.data_as(C.c_void_p))
-        if st != _lib.OK:
-            raise XtcError(st, "read_frames_device(%d, %d): %s" % (first_frame, n_frames, self._lib.gr_last_error(system._ctx).decode(errors="replace")))
+        if group is None:
+            st = self._lib.gr_xtc_read_frames_device(self._x, int(first_frame), int(n_frames), int(frame_step), system._ctx, int(first_slot), int(host_threads),
+                                                     steps.ctypes.data_as(C.c_void_p), times.ctypes.data_as(C.c_void_p))
+        else:
+            st = self._lib.gr_xtc_read_frames_device_group(self._x, int(first_frame), int(n_frames), int(frame_step), system._ctx, int(first_slot), group.encode(),
+                                                           int(host_threads), steps.ctypes.data_as(C.c_void_p), times.ctypes.data_as(C.c_void_p))
+        if st != 0:
+            raise XtcError(st, system._lib.gr_last_error(system._ctx).decode(errors="replace"))
         return steps, times
 
     def frames(self, start=0, stop=None, step=1):

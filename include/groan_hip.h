@@ -445,6 +445,20 @@ int gr_comm_any_error(gr_comm *comm, int local_flag, int *any);
 /* the host half of the gather on its own (no device, no RCCL): `gathered` = G shards of ceil(n_total / G) rows -> frame order */
 void gr_shard_deinterleave(const float *gathered, int world, uint64_t n_total, size_t width, float *out);
 
+/* Partial-frame reading = GroupXtcReader / System::group_xtc_iter (src/io/xtc_io/molly_xtc.rs:475-620 over the molly crate):
+ * only the atoms of a group change, "all other atoms are left unchanged", the frame's box / step / time are set as usual.  The
+ * bit stream is sequential, so everything UP TO the group's last atom is walked -- and nothing behind it: for a group near the
+ * start of the structure (a peptide in front of its membrane and water) that is a small fraction of the frame.
+ *   gr_xtc_read_frame_prefix        host decode of the first n_prefix atoms (= last atom of the group + 1) into xyz[n_prefix][3];
+ *                                   reads only the needed prefix of the frame's stream (*stream_bytes_read, may be NULL)
+ *   gr_xtc_read_frames_device_group like gr_xtc_read_frames_device, but the host reads + skims only up to the group's last atom,
+ *                                   only that prefix crosses PCIe, and the unpack kernel writes the group's atoms only
+ * Both are bit-identical to the full decode on the atoms they deliver. */
+int gr_xtc_read_frame_prefix(const gr_xtc *xtc, uint64_t frame, uint64_t n_prefix, float *xyz, float box9[9], uint64_t *step, float *time, float *precision,
+                             uint64_t *stream_bytes_read);
+int gr_xtc_read_frames_device_group(const gr_xtc *xtc, uint64_t first_frame, uint32_t n_frames, uint64_t frame_step, gr_ctx *ctx,
+                                    uint32_t first_slot, const char *group, int host_threads, uint64_t *steps, float *times);
+
 /* ---------------------------------------------------------------- measurement / synthetic data
  * HIP-event timing on the context's stream (the stream the kernels are launched on). */
 int gr_timer_start(gr_ctx *ctx);

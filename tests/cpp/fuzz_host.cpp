@@ -52,6 +52,16 @@ static void run_xtc(const std::string &path, Tally &t) {
             if (grx::pread_all(f.fd, scratch.data(), (size_t)fi.nbytes, fi.data_offset)) {
                 memset(scratch.data() + fi.nbytes, 0, 16);
                 grx::FrameDesc d; memset(&d, 0, sizeof d);
+                {   // partial walks (GroupXtcReader): any stop atom, any prefix length of the stream -- an error code or a valid table, never a crash
+                    std::vector<grx::Checkpoint> pc; grx::FrameDesc pd; memset(&pd, 0, sizeof pd);
+                    const uint32_t stop = (uint32_t)((fi.nbytes * 2654435761ull + fi.step) % (f.natoms + 1));
+                    const uint64_t have = fi.nbytes ? (fi.nbytes * 40503ull + 7) % (fi.nbytes + 1) : 0;
+                    const int ps = grx::skim_frame(scratch.data(), fi, f.natoms, pd, pc, stop, have);
+                    if (ps == grx::XTC_OK && (pc.size() != (stop + GR_XTC_CP_ATOMS - 1) / GR_XTC_CP_ATOMS || pd.n_end > f.natoms || pd.nbytes > fi.nbytes)) { fprintf(stderr, "partial skim table\n"); abort(); }
+                    std::vector<float> part(3 * (size_t)stop + 3);
+                    std::vector<unsigned char> sc2;
+                    (void)grx::decode_frame_prefix(f, fi, stop, part.data(), sc2);
+                }
                 const int s = grx::skim_frame(scratch.data(), fi, f.natoms, d, cps);
                 // whatever the decoder accepts the skimmer must accept, with one checkpoint per 32 atoms inside the stream
                 if (r == grx::XTC_OK && s == grx::XTC_OK) {

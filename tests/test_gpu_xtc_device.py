@@ -99,3 +99,47 @@ def test_random_systems_unpack_like_the_host_decoder(G, tmp_path, seed):
             w.write_frame(x.astype(np.float32), [span, span, span, 0, 0, 0, 0, 0, 0], step=f, time=0.1 * f, precision=prec)
     check_file(G, path)
     check_file(G, path, batch=2, host_threads=2)
+
+
+def test_group_limited_device_read(G, tmp_path):
+    """GroupXtcReader on the device path (gr_xtc_read_frames_device_group): BASELINE configs[1]'s shape -- 363 peptide atoms in
+    front of a 32 817-atom system -- and a scattered group.  The group's atoms are bit for bit the full decode's, every other
+    atom of the slot is left as it was ("all other atoms are left unchanged", molly_xtc.rs:585-587), box / step / time are set."""
+    rng = np.random.default_rng(11)
+    n, nf = 32817, 6
+    frames = [water_like(rng, n, 7.0) for _ in range(nf)]
+    path = tmp_path / "aa_shaped.xtc"
+    box = [6.44, 6.76, 7.26, 0, 0, 0, 0, 0, 0]
+    with G.XtcWriter(path) as w:
+        for k, fr in enumerate(frames):
+            w.write_frame(fr, box, step=100 * k, time=0.5 * k, precision=1000.0)
+    x = G.XtcFile(path)
+    s = G.System(n, n_slots=nf)
+    s.group_create_from_ranges("Peptide", [(0, 362)])
+    s.group_create_from_indices("Scattered", list(range(5, 20000, 7)) + list(range(100, 140)))
+    s.group_create_from_indices("Empty", [])
+    sentinel = np.full((n, 3), -7.25, np.float32)
+    for group, members in (("Peptide", np.arange(363)), ("Scattered", np.unique(np.concatenate([np.arange(5, 20000, 7), np.arange(100, 140)]))), ("Empty", np.arange(0))):
+        for f in range(nf):
+            s.set_frame(sentinel, [1, 1, 1, 0, 0, 0, 0, 0, 0], slot=f)
+        steps, times = x.read_frames_device(s, 0, nf, group=group, host_threads=3)
+        inside = np.zeros(n, bool); inside[members] = True
+        for f in range(nf):
+            full, fbox, step, time, _ = x.read_frame(f)
+            got = s.get_positions(f)
+            assert np.array_equal(got[inside].view(np.uint32), full[inside].view(np.uint32)), (group, f)
+            assert (got[~inside] == -7.25).all(), (group, f)
+            assert np.array_equal(s.get_box(f), fbox) and steps[f] == step and times[f] == np.float32(time)
+    with pytest.raises(G.XtcError):
+        x.read_frames_device(s, 0, nf, group="NoSuchGroup")
+    # and the consumer: RMSD of the peptide to the first frame from group-limited reads == from full reads
+    m = np.ones(n, np.float32)
+    s.set_masses(m)
+    ref = G.System(n, masses=m, box=box, positions=x.read_frame(0)[0]); ref.group_create_from_ranges("Peptide", [(0, 362)])
+    plan = G.RMSDPlan(ref, s, "Peptide")
+    x.read_frames_device(s, 0, nf, group="Peptide")
+    r_group, _ = plan.rmsd(0, nf)
+    x.read_frames_device(s, 0, nf)
+    r_full, _ = plan.rmsd(0, nf)
+    assert np.array_equal(r_group, r_full)
+    plan.close(); ref.close(); s.close(); x.close()

@@ -166,3 +166,44 @@ def test_threaded_decode_is_consistent(G):
     for a, b in zip(serial, out):
         assert np.array_equal(a, b)
     x.close()
+
+
+@pytest.mark.parametrize("name", ["short_trajectory.xtc", "triclinic_trajectory.xtc", "octahedron_trajectory.xtc"])
+def test_prefix_decode_is_the_full_decodes_prefix(G, name):
+    """Partial-frame reading (GroupXtcReader, molly_xtc.rs:475-560): the first n atoms decoded on their own are bit for bit the
+    first n atoms of the full decode, for prefixes that end inside runs, on run boundaries, at 0 and at the whole frame -- and a
+    short prefix reads only the head of the frame's bit stream."""
+    x = G.XtcFile(os.path.join(GOLD, name))
+    n = x.n_atoms
+    for f in (0, x.n_frames - 1):
+        full, box, step, time, prec = x.read_frame(f)
+        for k in sorted({0, 1, 2, 3, 7, 8, 9, 10, 31, 32, 33, 61, 363, n // 3, n - 1, n, n + 5} & set(range(0, n + 6))):
+            part, pbox, pstep, ptime, pprec, got = x.read_frame_prefix(f, k)
+            kk = min(k, n)
+            assert part.shape == (kk, 3) and np.array_equal(part.view(np.uint32), full[:kk].view(np.uint32)), (name, f, k)
+            assert np.array_equal(pbox, box) and (pstep, ptime, pprec) == (step, time, prec)
+        if n > 5000:
+            _, _, _, _, _, got_small = x.read_frame_prefix(f, 61)
+            _, _, _, _, _, got_all = x.read_frame_prefix(f, n)
+            assert got_small < got_all / 20                       # 61 of 16844 atoms: a few hundred bytes instead of ~60 kB
+    x.close()
+
+
+def test_prefix_decode_on_every_format_branch(G, tmp_path):
+    """the same on synthetic systems written with the library's encoder (water runs, wide ranges, high precision): random prefixes"""
+    rng = np.random.default_rng(77)
+    for case, (frames, prec) in {"water": ([water_like(rng, 30000, 20.0) for _ in range(2)], 1000.0),
+                                 "gas": ([rng.uniform(-50, 50, (5000, 3)).astype(np.float32) for _ in range(2)], 1000.0),
+                                 "wide": ([np.concatenate([rng.uniform(0, 10, (4000, 3)), [[20000.0, 3.0, 4.0]]]).astype(np.float32)], 1000.0),
+                                 "fine": ([water_like(rng, 3000, 6.0)], 100000.0)}.items():
+        path = tmp_path / (case + ".xtc")
+        with G.XtcWriter(path) as w:
+            for k, fr in enumerate(frames):
+                w.write_frame(fr, [30, 30, 25, 0, 0, 0, 0, 10, 10], step=k, time=float(k), precision=prec)
+        x = G.XtcFile(path)
+        for f in range(x.n_frames):
+            full = x.read_frame(f)[0]
+            for k in [int(v) for v in rng.integers(0, x.n_atoms + 1, 12)] + [363]:
+                part = x.read_frame_prefix(f, k)[0]
+                assert np.array_equal(part.view(np.uint32), full[:min(k, x.n_atoms)].view(np.uint32)), (case, f, k)
+        x.close()

@@ -85,6 +85,17 @@ def main():
             s.atoms_center_batch("Solute", (k % 2) * B, B, G.Dimension.XYZ, weighted=True)
         s.sync()
         out["device_unpack_com_center_batch_%d_frames_per_s" % B] = round(NF / (time.perf_counter() - t0), 1)
+    # group-limited reads (GroupXtcReader): only the 30 000 solute atoms at the head of the 5e5-atom frame are walked, copied, unpacked
+    B = 64
+    for w in range(2):
+        x.read_frames_device(s, 0, B, first_slot=w * B, host_threads=T, group="Solute")
+    s.sync()
+    t0 = time.perf_counter()
+    for k, f0 in enumerate(range(0, NF, B)):
+        x.read_frames_device(s, f0, B, first_slot=(k % 2) * B, host_threads=T, group="Solute")
+    for k in range(2 * B):
+        s.upload_wait(k)
+    out["device_unpack_group_30k_of_%dk_batch_64_frames_per_s" % (n // 1000)] = round(NF / (time.perf_counter() - t0), 1)
     # and out again: D2H + the library's encoder (fitted-trajectory output), T encoder threads, 32 frames per call
     x.read_frames_device(s, 0, 32, first_slot=0, host_threads=T); s.sync()
     wpath = os.path.join(tmp, "rewritten.xtc")
