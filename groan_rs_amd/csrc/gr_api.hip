@@ -1764,44 +1764,34 @@ static int xtc_read_frames_device_impl(const gr_xtc *x, uint64_t first_frame, ui
     grx::FrameDesc *descs = reinterpret_cast<grx::FrameDesc *>(H + off_desc);
     uint32_t *slots = reinterpret_cast<uint32_t *>(H + off_slot);
     grx::Checkpoint *cps = reinterpret_cast<grx::Checkpoint *>(H + off_cp);
-    // ---- host: read + skim, TWO frames per worker at a time (their walks are interleaved: skim_pair)
+    // ---- host: read + skim, one frame per worker at a time (walking two frames interleaved in one thread was measured:
+    // slower per frame on the EPYC hosts -- the walk is bound by its instruction count, not by the latency of its loads)
     std::atomic<uint32_t> next(0);
     std::atomic<int> bad(grx::XTC_OK);
     std::atomic<uint64_t> ns_read(0), ns_skim(0);
     const auto t_begin = std::chrono::steady_clock::now();
     auto work = [&]() {
-        std::vector<grx::Checkpoint> local[2];
+        std::vector<grx::Checkpoint> local;
         for (;;) {
-            const uint32_t k0 = next.fetch_add(2);
-            if (k0 >= n_frames) return;
-            const uint32_t nk = std::min<uint32_t>(2u, n_frames - k0);
-            grx::Skim sk[2]; grx::FrameDesc d[2];
+            const uint32_t k = next.fetch_add(1);
+            if (k >= n_frames) return;
+            const grx::FrameIndex &fi = x->f.frames[first_frame + k * frame_step];
+            unsigned char *dst = H + soff[k];
             const auto t0 = std::chrono::steady_clock::now();
-            for (uint32_t q = 0; q < nk; ++q) {
-                const uint32_t k = k0 + q;
-                const grx::FrameIndex &fi = x->f.frames[first_frame + k * frame_step];
-                unsigned char *dst = H + soff[k];
-                if (!grx::pread_all(x->f.fd, dst, sread[k], fi.data_offset)) { bad = grx::XTC_E_IO; return; }
-                memset(dst + sread[k], 0, (((size_t)fi.nbytes + 16 + 15) & ~(size_t)15) - sread[k]);
-                memset(&d[q], 0, sizeof d[q]);
-                d[q].stream_off = soff[k]; d[q].cp_off = (uint64_t)k * ncp;
-                if (sk[q].begin(dst, fi, n, d[q], local[q], n_stop) && sread[k] < (size_t)fi.nbytes) sk[q].have_bits = (uint64_t)sread[k] * 8;
-            }
+            if (!grx::pread_all(x->f.fd, dst, sread[k], fi.data_offset)) { bad = grx::XTC_E_IO; return; }
+            memset(dst + sread[k], 0, (((size_t)fi.nbytes + 16 + 15) & ~(size_t)15) - sread[k]);
+            grx::FrameDesc d;
+            memset(&d, 0, sizeof d);
+            d.stream_off = soff[k]; d.cp_off = (uint64_t)k * ncp;
             const auto t1 = std::chrono::steady_clock::now();
-            if (nk == 2) grx::skim_pair(sk[0], sk[1]); else grx::skim_run(sk[0]);
-            for (uint32_t q = 0; q < nk; ++q) {
-                const uint32_t k = k0 + q;
-                const grx::FrameIndex &fi = x->f.frames[first_frame + k * frame_step];
-                int r = sk[q].finish();
-                if (r == grx::XTC_E_RANGE) {   // the estimate of the prefix was too short: read the whole stream, walk again
-                    unsigned char *dst = H + soff[k];
-                    if (!grx::pread_all(x->f.fd, dst, (size_t)fi.nbytes, fi.data_offset)) { bad = grx::XTC_E_IO; return; }
-                    r = grx::skim_frame(dst, fi, n, d[q], local[q], n_stop);
-                }
-                if (r != grx::XTC_OK || local[q].size() != ncp) { bad = r != grx::XTC_OK ? r : (int)grx::XTC_E_FORMAT; return; }
-                if (ncp) memcpy(cps + (size_t)k * ncp, local[q].data(), ncp * sizeof(grx::Checkpoint));
-                descs[k] = d[q]; slots[k] = first_slot + k;
+            int r = grx::skim_frame(dst, fi, n, d, local, n_stop, sread[k] < (size_t)fi.nbytes ? (uint64_t)sread[k] : ~0ull);
+            if (r == grx::XTC_E_RANGE) {   // the estimate of the prefix was too short: read the whole stream, walk again
+                if (!grx::pread_all(x->f.fd, dst, (size_t)fi.nbytes, fi.data_offset)) { bad = grx::XTC_E_IO; return; }
+                r = grx::skim_frame(dst, fi, n, d, local, n_stop);
             }
+            if (r != grx::XTC_OK || local.size() != ncp) { bad = r != grx::XTC_OK ? r : (int)grx::XTC_E_FORMAT; return; }
+            if (ncp) memcpy(cps + (size_t)k * ncp, local.data(), ncp * sizeof(grx::Checkpoint));
+            descs[k] = d; slots[k] = first_slot + k;
             if (trace) {
                 const auto t2 = std::chrono::steady_clock::now();
                 ns_read += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count();
@@ -1809,8 +1799,8 @@ static int xtc_read_frames_device_impl(const gr_xtc *x, uint64_t first_frame, ui
             }
         }
     };
-    uint32_t nt = host_threads > 0 ? (uint32_t)host_threads : std::min<uint32_t>((n_frames + 1) / 2, 16u);
-    nt = std::max<uint32_t>(1u, std::min<uint32_t>(nt, (n_frames + 1) / 2));
+    uint32_t nt = host_threads > 0 ? (uint32_t)host_threads : std::min<uint32_t>(n_frames, 16u);
+    nt = std::max<uint32_t>(1u, std::min<uint32_t>(nt, n_frames));
     if (nt == 1) work();
     else {
         // (a thread that cannot be started must not unwind through the C ABI: the frames it would have taken are picked up by

@@ -323,100 +323,85 @@ inline uint32_t peek_bits(const unsigned char *p, uint64_t bitpos, int n) {   //
 }
 
 // Walk the groups of one frame (natoms > 9): fills the descriptor's decoding constants and the checkpoints.
-// The walk of one frame's skim.  Where the next group starts depends on the flag / run bits of this one: one dependent load per
-// group, ~170 k groups per 5e5-atom water frame.  The walk keeps its whole state in locals (GR_SKIM_STEP) so that TWO frames
-// can be walked in lockstep by one thread (skim_pair): two independent dependency chains in flight instead of one.
+// Where the next group starts depends on the flag / run bits of this one: one dependent load per group, ~170 k groups per
+// 5e5-atom water frame.  (Walking two frames in lockstep in one thread -- two dependency chains in flight -- and a
+// branch-free flag / run selection were both measured slower: the branches predict well, and speculation past them is what
+// hides the load latency.)
 // n_stop < n: PARTIAL skim (GroupXtcReader, molly_xtc.rs:475-560): stop at the first group that starts at or behind atom n_stop;
-// the checkpoints then cover atoms [0, n_end) and d.nbytes is the length of the stream prefix they need.  have_bits: the
+// the checkpoints then cover atoms [0, n_end) and d.nbytes is the length of the stream prefix they need.  have_bytes: the
 // prefix of the stream that is in memory -- walking past it is XTC_E_RANGE (the caller reads more and walks again).
-struct Skim {
-    const unsigned char *stream = nullptr; const FrameIndex *fi = nullptr; FrameDesc *d = nullptr; std::vector<Checkpoint> *cps = nullptr;
-    uint32_t n = 0, n_stop = 0, i = 0, next_cp = 0; int smallidx = 0, run = 0, large_bits = 0; uint64_t bitpos = 0, limit_bits = 0, have_bits = ~0ull;
-    int status = XTC_OK; bool done = false;
-    bool begin(const unsigned char *s, const FrameIndex &f, uint32_t n_atoms, FrameDesc &desc, std::vector<Checkpoint> &c, uint32_t stop) {
-        stream = s; fi = &f; d = &desc; cps = &c; n = n_atoms; n_stop = stop < n_atoms ? stop : n_atoms;
-        for (int k = 0; k < 3; ++k) { desc.minint[k] = f.minint[k]; desc.sizeint[k] = (uint32_t)f.maxint[k] - (uint32_t)f.minint[k] + 1u; }
-        if (desc.sizeint[0] == 0 || desc.sizeint[1] == 0 || desc.sizeint[2] == 0) { status = XTC_E_FORMAT; done = true; return false; }
-        desc.bitsizeint[0] = desc.bitsizeint[1] = desc.bitsizeint[2] = 0;
-        if ((desc.sizeint[0] | desc.sizeint[1] | desc.sizeint[2]) > 0xffffffu) {
-            for (int k = 0; k < 3; ++k) { int b = bit_length(desc.sizeint[k]); desc.bitsizeint[k] = b > 32 ? 32 : b; }
-            desc.bitsize = 0;
-            large_bits = desc.bitsizeint[0] + desc.bitsizeint[1] + desc.bitsizeint[2];
-        } else {
-            desc.bitsize = bit_length((unsigned __int128)desc.sizeint[0] * desc.sizeint[1] * desc.sizeint[2]);
-            large_bits = desc.bitsize;
-        }
-        desc.inv_precision = (float)(1.0 / (double)f.precision);
-        desc.nbytes = (uint32_t)f.nbytes;
-        if (f.nbytes >= (1ull << 29)) { status = XTC_E_FORMAT; done = true; return false; }
-        limit_bits = (f.nbytes + 8) * 8;
-        c.clear();
-        c.reserve((size_t)(n_stop + GR_XTC_CP_ATOMS - 1) / GR_XTC_CP_ATOMS + 2);
-        smallidx = f.smallidx;
-        return true;
-    }
-    int finish() {
-        if (status != XTC_OK) return status;
-        // one checkpoint per started window of 32 atoms of [0, n_stop) (a group holds at most 9 atoms, so every window has a
-        // group starting in it); pad so that the count is exactly ceil(n_stop / 32)
-        const uint32_t want = (n_stop + GR_XTC_CP_ATOMS - 1) / GR_XTC_CP_ATOMS;
-        while (cps->size() < want) cps->push_back(Checkpoint{ (uint32_t)bitpos, i, (uint32_t)smallidx });
-        cps->resize(want);
-        d->n_cp = want;
-        d->n_end = i < n ? i : n;                  // first atom NOT covered by the checkpoints' segments (partial: >= n_stop)
-        if (n_stop < n) d->nbytes = (uint32_t)std::min<uint64_t>((bitpos + 7) / 8 + 16, fi->nbytes);
-        return XTC_OK;
-    }
-};
-
-// one group of the walk on LOCAL state: X = suffix of the locals (i, next_cp, bitpos, run, smallidx, status, done ...)
-#define GR_SKIM_LOCALS(X, S) \
-    const unsigned char *stream##X = (S).stream; uint32_t i##X = (S).i, next_cp##X = (S).next_cp; const uint32_t n##X = (S).n, n_stop##X = (S).n_stop; \
-    int smallidx##X = (S).smallidx, run##X = (S).run; const int large##X = (S).large_bits; uint64_t bitpos##X = (S).bitpos; \
-    const uint64_t limit##X = (S).limit_bits, have##X = (S).have_bits; int status##X = (S).status; bool done##X = (S).done; std::vector<Checkpoint> &cps##X = *(S).cps;
-#define GR_SKIM_STORE(X, S) (S).i = i##X; (S).next_cp = next_cp##X; (S).smallidx = smallidx##X; (S).run = run##X; (S).bitpos = bitpos##X; (S).status = status##X; (S).done = true;
-#define GR_SKIM_STEP(X) do { \
-    if (i##X >= n_stop##X) { done##X = true; break; } \
-    if (i##X >= next_cp##X) { while (next_cp##X <= i##X) { cps##X.push_back(Checkpoint{ (uint32_t)bitpos##X, i##X, (uint32_t)smallidx##X | ((uint32_t)run##X << 8) }); next_cp##X += GR_XTC_CP_ATOMS; } } \
-    bitpos##X += (uint64_t)large##X; \
-    if (bitpos##X + 6 > limit##X) { status##X = XTC_E_FORMAT; done##X = true; break; }       /* the flag / run field below must lie inside the (padded) stream */ \
-    ++i##X; \
-    int change_ = 0; \
-    const uint32_t six_ = peek_bits(stream##X, bitpos##X, 6); \
-    if (six_ & 32u) { run##X = (int)(six_ & 31u); bitpos##X += 6; change_ = run##X % 3; run##X -= change_; change_ -= 1; } else bitpos##X += 1; \
-    if (run##X > 0) { \
-        if ((uint64_t)i##X + (uint64_t)(run##X / 3) > n##X) { status##X = XTC_E_FORMAT; done##X = true; break; } \
-        bitpos##X += (uint64_t)(run##X / 3) * (uint64_t)smallidx##X; i##X += (uint32_t)(run##X / 3); \
-    } \
-    if (bitpos##X > limit##X) { status##X = XTC_E_FORMAT; done##X = true; break; } \
-    if (bitpos##X > have##X) { status##X = XTC_E_RANGE; done##X = true; break; }           /* partial read: the walk left the prefix that is in memory */ \
-    smallidx##X += change_; \
-    if (smallidx##X < kFirstIdx || smallidx##X >= kLastIdx) { status##X = XTC_E_FORMAT; done##X = true; break; } \
-} while (0)
-
-inline void skim_run(Skim &a) {
-    if (a.done) return;
-    GR_SKIM_LOCALS(A, a)
-    while (!doneA) GR_SKIM_STEP(A);
-    GR_SKIM_STORE(A, a)
-}
-// two frames in lockstep, then whichever is longer on its own
-inline void skim_pair(Skim &a, Skim &b) {
-    if (a.done || b.done) { skim_run(a); skim_run(b); return; }
-    GR_SKIM_LOCALS(A, a)
-    GR_SKIM_LOCALS(B, b)
-    while (!doneA && !doneB) { GR_SKIM_STEP(A); GR_SKIM_STEP(B); }
-    while (!doneA) GR_SKIM_STEP(A);
-    while (!doneB) GR_SKIM_STEP(B);
-    GR_SKIM_STORE(A, a)
-    GR_SKIM_STORE(B, b)
-}
-
 inline int skim_frame(const unsigned char *stream, const FrameIndex &fi, uint32_t n, FrameDesc &d, std::vector<Checkpoint> &cps, uint32_t n_stop = 0xFFFFFFFFu,
                       uint64_t have_bytes = ~0ull) {
-    Skim s;
-    if (s.begin(stream, fi, n, d, cps, n_stop)) { if (have_bytes != ~0ull) s.have_bits = have_bytes * 8; skim_run(s); }
-    return s.finish();
+    if (n_stop > n) n_stop = n;
+    for (int k = 0; k < 3; ++k) { d.minint[k] = fi.minint[k]; d.sizeint[k] = (uint32_t)fi.maxint[k] - (uint32_t)fi.minint[k] + 1u; }
+    if (d.sizeint[0] == 0 || d.sizeint[1] == 0 || d.sizeint[2] == 0) return XTC_E_FORMAT;   // corrupt header (the decoder refuses it too)
+    d.bitsizeint[0] = d.bitsizeint[1] = d.bitsizeint[2] = 0;
+    int large_bits;
+    if ((d.sizeint[0] | d.sizeint[1] | d.sizeint[2]) > 0xffffffu) {
+        for (int k = 0; k < 3; ++k) { int b = bit_length(d.sizeint[k]); d.bitsizeint[k] = b > 32 ? 32 : b; }
+        d.bitsize = 0;
+        large_bits = d.bitsizeint[0] + d.bitsizeint[1] + d.bitsizeint[2];
+    } else {
+        d.bitsize = bit_length((unsigned __int128)d.sizeint[0] * d.sizeint[1] * d.sizeint[2]);
+        large_bits = d.bitsize;
+    }
+    d.inv_precision = (float)(1.0 / (double)fi.precision);
+    d.nbytes = (uint32_t)fi.nbytes;
+    if (fi.nbytes >= (1ull << 29)) return XTC_E_FORMAT;        // bit positions are 32-bit
+    const uint64_t limit_bits = (fi.nbytes + 8) * 8;
+    const uint64_t have_bits = have_bytes > (~0ull >> 3) ? ~0ull : have_bytes * 8;
+    const uint64_t safe_bits = limit_bits < have_bits ? limit_bits : have_bits;
+    const uint32_t want = (n_stop + GR_XTC_CP_ATOMS - 1) / GR_XTC_CP_ATOMS;
+    cps.resize((size_t)want + 1);                              // written through a bare pointer below: no capacity check per group
+    Checkpoint *cp = cps.data();
+    uint32_t n_cp = 0;
+    int smallidx = fi.smallidx, run = 0;
+    uint64_t bitpos = 0;
+    uint32_t i = 0, next_cp = 0;
+    while (i < n_stop) {
+        // (at most one window boundary is passed per group -- a group holds at most 9 atoms, a window 32 -- and i < n_stop
+        // keeps n_cp below `want`)
+        if (i >= next_cp) { cp[n_cp++] = Checkpoint{ (uint32_t)bitpos, i, (uint32_t)smallidx | ((uint32_t)run << 8) }; next_cp += GR_XTC_CP_ATOMS; }
+        {   // fast stretch: a group whose flag bit is clear has the shape of the one before it (same run, same small range) --
+            // the common case by far (3 % of the groups of a water frame carry a flag) -- so up to the next window boundary
+            // the walk is "test one bit, add a constant".  At most 32 groups fit (a group holds >= 1 atom), and the stretch
+            // is entered only when that many, plus the last flag / run field, lie inside the stream that is in memory.
+            const uint32_t adv = 1u + (uint32_t)run / 3u;
+            const uint64_t stride = (uint64_t)large_bits + 1u + (uint64_t)((uint32_t)run / 3u) * (uint64_t)smallidx;
+            const uint32_t lim = next_cp < n_stop ? next_cp : n_stop;
+            if (bitpos + GR_XTC_CP_ATOMS * stride + (uint64_t)large_bits + 6 <= safe_bits) {
+                while (i < lim) {
+                    const uint64_t fp = bitpos + (uint64_t)large_bits;
+                    if ((stream[fp >> 3] >> (7u - (unsigned)(fp & 7u))) & 1u) break;
+                    bitpos += stride; i += adv;
+                }
+                if (i > n) return XTC_E_FORMAT;                 // a run went past the last atom
+                if (i >= lim) continue;                         // next window (its checkpoint) or the end
+            }
+        }
+        bitpos += (uint64_t)large_bits;
+        if (bitpos + 6 > limit_bits) return XTC_E_FORMAT;       // the flag / run field below must lie inside the (padded) stream
+        ++i;
+        int change = 0;
+        const uint32_t six = peek_bits(stream, bitpos, 6);      // flag bit + the 5 run bits behind it, one load
+        if (six & 32u) { run = (int)(six & 31u); bitpos += 6; change = run % 3; run -= change; change -= 1; } else bitpos += 1;
+        if (run > 0) {
+            if ((uint64_t)i + (uint64_t)(run / 3) > n) return XTC_E_FORMAT;
+            bitpos += (uint64_t)(run / 3) * (uint64_t)smallidx;
+            i += (uint32_t)(run / 3);
+        }
+        if (bitpos > limit_bits) return XTC_E_FORMAT;
+        if (bitpos > have_bits) return XTC_E_RANGE;             // partial read: the walk left the prefix that is in memory
+        smallidx += change;
+        if (smallidx < kFirstIdx || smallidx >= kLastIdx) return XTC_E_FORMAT;
+    }
+    // one checkpoint per started window of 32 atoms of [0, n_stop); pad so that the count is exactly ceil(n_stop / 32)
+    while (n_cp < want) cp[n_cp++] = Checkpoint{ (uint32_t)bitpos, i, (uint32_t)smallidx };
+    cps.resize(want);
+    d.n_cp = want;
+    d.n_end = i < n ? i : n;                  // first atom NOT covered by the checkpoints' segments (partial: >= n_stop)
+    if (n_stop < n) d.nbytes = (uint32_t)std::min<uint64_t>((bitpos + 7) / 8 + 16, fi.nbytes);
+    return XTC_OK;
 }
 
 // ================================================================================================ writer

@@ -34,6 +34,37 @@ static void spit(const std::string &path, const std::vector<unsigned char> &v) {
 
 struct Tally { long ok = 0, rejected = 0; };
 
+// the skim without its fast stretch: one group at a time, every check per group -- the statement the library's walk is tested against
+static int skim_plain(const unsigned char *stream, const grx::FrameIndex &fi, uint32_t n, std::vector<grx::Checkpoint> &cps) {
+    uint32_t sz[3];
+    for (int k = 0; k < 3; ++k) { sz[k] = (uint32_t)fi.maxint[k] - (uint32_t)fi.minint[k] + 1u; if (!sz[k]) return grx::XTC_E_FORMAT; }
+    int large = 0;
+    if ((sz[0] | sz[1] | sz[2]) > 0xffffffu) for (int k = 0; k < 3; ++k) large += std::min(32, grx::bit_length(sz[k]));
+    else large = grx::bit_length((unsigned __int128)sz[0] * sz[1] * sz[2]);
+    if (fi.nbytes >= (1ull << 29)) return grx::XTC_E_FORMAT;
+    const uint64_t limit = (fi.nbytes + 8) * 8;
+    cps.clear();
+    int smallidx = fi.smallidx, run = 0;
+    uint64_t bitpos = 0;
+    uint32_t i = 0;
+    while (i < n) {
+        if (i >= cps.size() * GR_XTC_CP_ATOMS) cps.push_back(grx::Checkpoint{ (uint32_t)bitpos, i, (uint32_t)smallidx | ((uint32_t)run << 8) });
+        bitpos += (uint64_t)large;
+        if (bitpos + 6 > limit) return grx::XTC_E_FORMAT;
+        ++i;
+        int change = 0;
+        if (grx::peek_bits(stream, bitpos, 1)) { run = (int)grx::peek_bits(stream, bitpos + 1, 5); bitpos += 6; change = run % 3 - 1; run -= run % 3; }
+        else bitpos += 1;
+        if ((uint64_t)i + (uint64_t)(run / 3) > n) return grx::XTC_E_FORMAT;
+        bitpos += (uint64_t)(run / 3) * (uint64_t)smallidx; i += (uint32_t)(run / 3);
+        if (bitpos > limit) return grx::XTC_E_FORMAT;
+        smallidx += change;
+        if (smallidx < grx::kFirstIdx || smallidx >= grx::kLastIdx) return grx::XTC_E_FORMAT;
+    }
+    while (cps.size() < (n + GR_XTC_CP_ATOMS - 1) / GR_XTC_CP_ATOMS) cps.push_back(grx::Checkpoint{ (uint32_t)bitpos, i, (uint32_t)smallidx });
+    return grx::XTC_OK;
+}
+
 // open + decode + skim every frame of a (possibly corrupt) xtc file
 static void run_xtc(const std::string &path, Tally &t) {
     grx::File f;
@@ -63,6 +94,12 @@ static void run_xtc(const std::string &path, Tally &t) {
                     (void)grx::decode_frame_prefix(f, fi, stop, part.data(), sc2);
                 }
                 const int s = grx::skim_frame(scratch.data(), fi, f.natoms, d, cps);
+                {   // the fast stretch changes nothing: same verdict, same table as the group-by-group walk
+                    std::vector<grx::Checkpoint> ref;
+                    const int sp = skim_plain(scratch.data(), fi, f.natoms, ref);
+                    if (sp != s) { fprintf(stderr, "skim verdict %d vs plain walk %d\n", s, sp); abort(); }
+                    if (s == grx::XTC_OK && (ref.size() != cps.size() || memcmp(ref.data(), cps.data(), ref.size() * sizeof(grx::Checkpoint)) != 0)) { fprintf(stderr, "skim table differs from the plain walk\n"); abort(); }
+                }
                 // whatever the decoder accepts the skimmer must accept, with one checkpoint per 32 atoms inside the stream
                 if (r == grx::XTC_OK && s == grx::XTC_OK) {
                     if (cps.size() != (f.natoms + GR_XTC_CP_ATOMS - 1) / GR_XTC_CP_ATOMS) { fprintf(stderr, "checkpoint count\n"); abort(); }
