@@ -17,6 +17,7 @@
 #include "gr_container.h"
 #include "gr_kernels.h"
 #include "gr_hot.h"
+#include "gr_resident.h"
 #include "gr_xtc.h"
 #include "gr_shape.h"
 #include "gr_xtc_dev.h"
@@ -81,6 +82,14 @@ struct gr_ctx {
     double *fit_partials = nullptr;   // [frames of a segment][fit workgroups per frame]: sum w |R q - p|^2 of k_fit<true>
     size_t fit_partials_cap = 0;
     int two_pass = 1;                 // GR_TUNE_TWO_PASS 0: RMSD-fit keeps the closed-form single-pass rmsd (k_rmsd_accum<0>)
+    // resident RMSD fit (gr_resident.h): one cooperative launch per segment, the frame waits on chip for its rotation
+    int resident = 0;                 // GR_TUNE_RESIDENT 0 never, 1 when the frame fills most of the chip, 2 whenever it fits (tests)
+    uint32_t res_max_wgs = 0;         // workgroups of k_fit_resident the device holds at once (0: no cooperative launch)
+    unsigned long long *res_wgrec = nullptr; size_t res_wgrec_cap = 0;   // [frames][streaming workgroups, padded to 16][32] tagged words
+    unsigned long long *res_rec = nullptr;   // [GR_MAX_BATCH][16]
+    uint32_t *res_abort = nullptr;    // device word
+    uint32_t res_epoch = 0;
+    bool res_in_use = false;          // the pending segment took the resident pass (segment_end checks the abort word)
     GrFrameState *state_dev = nullptr;
     GrFrameState *state_host = nullptr;   // pinned
     uint32_t *bad_dev = nullptr;          // [4 * GR_MAX_BATCH]: per frame, first atom without position (rows / columns)
@@ -121,7 +130,7 @@ struct gr_ctx {
 };
 
 struct Pending {   // a segment between gr_rmsd_batch_begin and gr_rmsd_batch_end
-    bool active = false, any_ok = false, consistent = true, fused = false;
+    bool active = false, any_ok = false, consistent = true, fused = false, resident = false;
     uint32_t s0 = 0, nb = 0, n_prof_groups = 0;
     int fit = 0;
     std::vector<int> pre;
@@ -209,6 +218,18 @@ uint32_t fit_grid(const gr_ctx *c, uint32_t nf) {
     uint64_t gx = (tiles + GR_WG / 64 - 1) / (GR_WG / 64);
     if (gx >= 8) gx &= ~(uint64_t)7;
     return (uint32_t)(gx < 1 ? 1 : gx);
+}
+
+// Streaming workgroups of the resident RMSD-fit pass (gr_resident.h), or 0 when the two-pass path takes the segment: the
+// frame must fit (one 4-atom group per lane) beside at least two finalizer workgroups, and -- unless forced -- fill most of
+// the chip: a small frame streams faster through the two-pass kernels, which spread it over every CU.
+uint32_t resident_wgs(const gr_ctx *c, bool lite) {
+    if (!lite || !c->resident || !c->res_max_wgs) return 0;
+    const uint64_t groups = ((c->n + 255) >> 8) << 6;
+    const uint64_t wgs = (groups + GR_RES_LANES - 1) / GR_RES_LANES;
+    if (wgs + 2 > c->res_max_wgs || wgs > GR_MAX_CHUNKS) return 0;
+    if (c->resident == 1 && wgs * 4 < (uint64_t)c->res_max_wgs * 3) return 0;
+    return (uint32_t)wgs;
 }
 
 // a batch begun with gr_rmsd_batch_begin is still in flight on this context: only uploads may run beside it
@@ -513,6 +534,19 @@ gr_ctx *gr_ctx_create(int device, uint64_t n_atoms, uint32_t n_slots, int *statu
     ok = ok && hipMalloc(&c->bad_dev, 4 * GR_MAX_BATCH * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipHostMalloc(&c->bad_host, 4 * GR_MAX_BATCH * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess;
     ok = ok && hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess;
+    ok = ok && hipMalloc(&c->res_abort, sizeof(uint32_t)) == hipSuccess;
+    ok = ok && hipMemset(c->res_abort, 0, sizeof(uint32_t)) == hipSuccess;
+    ok = ok && hipMalloc(&c->res_rec, (size_t)GR_MAX_BATCH * 16 * sizeof(unsigned long long)) == hipSuccess;
+    ok = ok && hipMemset(c->res_rec, 0, (size_t)GR_MAX_BATCH * 16 * sizeof(unsigned long long)) == hipSuccess;
+    if (ok) {   // can the resident pass run here?  (cooperative launches, 160 KiB of LDS per workgroup, one workgroup per CU)
+        int coop = 0, per_cu = 0;
+        if (hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, device) == hipSuccess && coop &&
+            hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fit_resident<true>), hipFuncAttributeMaxDynamicSharedMemorySize, GR_RES_LDS_BYTES) == hipSuccess &&
+            hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fit_resident<false>), hipFuncAttributeMaxDynamicSharedMemorySize, GR_RES_LDS_BYTES) == hipSuccess &&
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_fit_resident<false>, GR_RES_LANES, GR_RES_LDS_BYTES) == hipSuccess && per_cu >= 1)
+            c->res_max_wgs = c->n_cus * (uint32_t)per_cu;
+        (void)hipGetLastError();
+    }
 
     if (!ok) { *status = GR_E_HIP; gr_ctx_destroy(c); return nullptr; }
     // masses undefined (None) until gr_set_masses; padding and frames zero
@@ -549,6 +583,9 @@ void gr_ctx_destroy(gr_ctx *c) try {
     if (c->acc_partials) (void)hipFree(c->acc_partials);
     if (c->fit_partials) (void)hipFree(c->fit_partials);
     if (c->fuse_cnt) (void)hipFree(c->fuse_cnt);
+    if (c->res_abort) (void)hipFree(c->res_abort);
+    if (c->res_wgrec) (void)hipFree(c->res_wgrec);
+    if (c->res_rec) (void)hipFree(c->res_rec);
     if (c->state_dev) (void)hipFree(c->state_dev);
     if (c->state_host) (void)hipHostFree(c->state_host);
     if (c->bad_dev) (void)hipFree(c->bad_dev);
@@ -1401,6 +1438,7 @@ int gr_ctx_set_tuning(gr_ctx *c, int key, int64_t value) try {
     case GR_TUNE_FIT_WGS: if (value < 0 || value > 65535) break; c->fit_wgs = (uint32_t)value; return GR_OK;
     case GR_TUNE_FUSE: c->fuse = value ? 1 : 0; return GR_OK;
     case GR_TUNE_TWO_PASS: c->two_pass = value ? 1 : 0; return GR_OK;
+    case GR_TUNE_RESIDENT: if (value < 0 || value > 2) break; c->resident = value; return GR_OK;
     default: break;
     }
     return fail(c, GR_E_INVALID_ARG, "unknown tuning key or value out of range");
@@ -1483,7 +1521,45 @@ static int segment_begin(gr_rmsd_plan *p, uint32_t s0, uint32_t nb, int fit) {
         const bool fused = lite && c->fuse;   // the finalize rides on the tail of the sums kernel
         q.fused = fused;
         hipStream_t S = c->stream;
-        for (uint32_t g = 0; g < n_groups; ++g) {
+        const uint32_t res_stream = resident_wgs(c, lite);
+        if (res_stream) {
+            // ONE cooperative launch for the segment: every frame is read once and written once (gr_resident.h)
+            const uint32_t n_fin = std::min<uint32_t>(GR_RES_MAX_FIN, c->res_max_wgs - res_stream);
+            if ((size_t)nb * res_stream > c->fit_partials_cap) {
+                if (c->fit_partials) (void)hipFree(c->fit_partials);
+                c->fit_partials = nullptr; c->fit_partials_cap = 0;
+                HIPCHK(c, hipMalloc(&c->fit_partials, (size_t)nb * res_stream * sizeof(double)));
+                c->fit_partials_cap = (size_t)nb * res_stream;
+            }
+            const size_t rec_words = (size_t)nb * ((res_stream + 15u) & ~15u) * GR_RES_REC_WORDS;
+            if (rec_words > c->res_wgrec_cap) {
+                if (c->res_wgrec) (void)hipFree(c->res_wgrec);
+                c->res_wgrec = nullptr; c->res_wgrec_cap = 0;
+                HIPCHK(c, hipMalloc(&c->res_wgrec, rec_words * sizeof(unsigned long long)));
+                HIPCHK(c, hipMemsetAsync(c->res_wgrec, 0, rec_words * sizeof(unsigned long long), S));   // tag 0 = no launch
+                c->res_wgrec_cap = rec_words;
+            }
+            GrResCtl ctl;
+            ctl.wgrec = c->res_wgrec; ctl.rec = c->res_rec; ctl.abort = c->res_abort; ctl.epoch = ++c->res_epoch; ctl.n_stream = res_stream; ctl.n_fin = n_fin;
+            float *frames = c->frames; size_t stride = c->frame_stride; uint32_t slot0 = s0, nfr = nb, natoms = (uint32_t)c->n;
+            const float *masses = c->masses; GrSel sel_arg = sel; const GrBox *boxes = c->boxes_dev; GrPlanDev plan = p->dev;
+            GrFrameState *states = c->state_dev; double *fparts = c->fit_partials;
+            void *args[] = { &frames, &stride, &slot0, &nfr, &natoms, &masses, &sel_arg, &boxes, &plan, &states, &fparts, &ctl };
+            const void *fn = p->dev.w_is_mass ? reinterpret_cast<const void *>(&k_fit_resident<true>) : reinterpret_cast<const void *>(&k_fit_resident<false>);
+            if (c->profile) EVREC(c, c->pev[0], true, S);
+            const hipError_t le = hipLaunchCooperativeKernel(fn, dim3(res_stream + n_fin), dim3(GR_RES_LANES), args, GR_RES_LDS_BYTES, S);
+            if (le == hipSuccess) {
+                if (c->profile) EVREC(c, c->pev[1], true, S);
+                k_rmsd_close<<<dim3(nb), dim3(64), 0, S>>>(c->fit_partials, res_stream, p->dev.sw, c->state_dev);
+                HIPCHK(c, hipGetLastError());
+                c->res_in_use = true;
+                q.resident = true;
+            } else {
+                (void)hipGetLastError();          // the grid does not fit right now: nothing ran, the two-pass path takes the segment
+                c->res_max_wgs = 0;
+            }
+        }
+        for (uint32_t g = 0; g < n_groups && !q.resident; ++g) {
             const uint32_t f0 = g * sb, nf = std::min<uint32_t>(sb, nb - f0), nch = batch_chunks(c, sel, nf), gx = fit_grid(c, nf);
             GrAccPartial *parts = c->acc_partials + (size_t)f0 * GR_MAX_CHUNKS;
             // each kernel is bracketed by its own pair of profiling events (gr_profile_*)
@@ -1508,7 +1584,7 @@ static int segment_begin(gr_rmsd_plan *p, uint32_t s0, uint32_t nb, int fit) {
             }
         }
         HIPCHK(c, hipGetLastError());
-        if (c->profile) q.n_prof_groups = n_groups;
+        if (c->profile) q.n_prof_groups = q.resident ? 0 : n_groups;
     }
     HIPCHK(c, hipMemcpyAsync(c->state_host, c->state_dev, nb * sizeof(GrFrameState), hipMemcpyDeviceToHost, c->stream));
     return GR_OK;
@@ -1534,6 +1610,21 @@ static int segment_end(gr_rmsd_plan *p, float *rmsd_out, int *status_out, float 
         if (!q.has_group) return fail(c, GR_E_INVALID_ARG, "batch state lost");
         const GrSel sel = q.sel;
         HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (q.resident) {
+            c->res_in_use = false;
+            uint32_t aborted = 0;
+            HIPCHK(c, hipMemcpy(&aborted, c->res_abort, sizeof aborted, hipMemcpyDeviceToHost));
+            if (aborted) {   // a wait inside the resident pass ran out of patience: the batch's frames are in an unknown state
+                (void)hipMemset(c->res_abort, 0, sizeof(uint32_t));
+                c->res_max_wgs = 0;
+                return fail(c, GR_E_HIP, "the resident RMSD-fit pass stalled (a workgroup of the cooperative launch made no progress); frames of the batch may be partly fitted");
+            }
+            if (c->profile) {
+                float ms = 0.f;
+                HIPCHK(c, hipEventElapsedTime(&ms, c->pev[0], c->pev[1]));
+                c->prof_ms[3] += ms; c->prof_launches[3] += 1; c->prof_frames[3] += nb;
+            }
+        }
         for (uint32_t gi = 0; gi < q.n_prof_groups; ++gi) {   // the stream is idle here: read this segment's event pairs
             const uint32_t nf = std::min<uint32_t>(c->sub_batch, nb - gi * c->sub_batch);
             for (int k = 0; k < 3; ++k) {     // 0 sums, 1 finalize (separate launch only when not fused), 2 fit
@@ -2411,7 +2502,7 @@ int gr_profile_enable(gr_ctx *c, int on) try {
     return GR_OK;
 } catch (...) { return gr_abi_guard(); }
 int gr_profile_read(const gr_ctx *c, int kernel, double *ms_total, uint64_t *launches, uint64_t *frames) try {
-    if (!c || kernel < 0 || kernel > 2) return GR_E_INVALID_ARG;
+    if (!c || kernel < 0 || kernel > 3) return GR_E_INVALID_ARG;
     if (ms_total) *ms_total = c->prof_ms[kernel];
     if (launches) *launches = c->prof_launches[kernel];
     if (frames) *frames = c->prof_frames[kernel];

@@ -62,12 +62,9 @@ struct GrSumsPk {
     float mn[3], mx3[3], fmn[3], fmx[3];  // Cartesian and fractional extents of v
 };
 
-// two atoms: v = image of (x - g) nearest to g, then every sum.  `p*` = reference coordinates (NOREF: unused), m = masses.
-template <bool NOREF>
-__device__ __forceinline__ void gr_sums_pair(GrSumsPk &S, gr_v2f x, gr_v2f y, gr_v2f z, gr_v2f px, gr_v2f py, gr_v2f pz, gr_v2f m,
-                                             const GrBoxU &B, const GrBox *__restrict__ boxp, float gx, float gy, float gz) {
-    gr_v2f vx = x - gr_v2(gx), vy = y - gr_v2(gy), vz = z - gr_v2(gz);
-    // closed-form brick reduction along c, b, a (gr_image_about)
+// two difference vectors -> their minimum images: closed-form brick reduction along c, b, a (gr_image_about), which in a
+// triclinic cell is already THE minimum image whenever |v| < r_ws; otherwise the image table is searched (rare: wave-uniform branch)
+__device__ __forceinline__ void gr_image_pair(gr_v2f &vx, gr_v2f &vy, gr_v2f &vz, const GrBoxU &B, const GrBox *__restrict__ boxp) {
     gr_v2f k = gr_v2_rint(vz * gr_v2(B.icz));
     vx = gr_v2_fma(-k, gr_v2(B.cx), vx); vy = gr_v2_fma(-k, gr_v2(B.cy), vy); vz = gr_v2_fma(-k, gr_v2(B.cz), vz);
     k = gr_v2_rint(vy * gr_v2(B.iby));
@@ -75,13 +72,20 @@ __device__ __forceinline__ void gr_sums_pair(GrSumsPk &S, gr_v2f x, gr_v2f y, gr
     k = gr_v2_rint(vx * gr_v2(B.iax));
     vx = gr_v2_fma(-k, gr_v2(B.ax), vx);
     if (B.tric) {
-        // already THE minimum image whenever |v| < r_ws; otherwise search the image table (rare: wave-uniform branch)
         const gr_v2f r2 = gr_v2_fma(vx, vx, gr_v2_fma(vy, vy, vz * vz));
         if (__builtin_amdgcn_ballot_w64(!(gr_fmaxf(r2.x, r2.y) < B.rws2)) != 0ull) {
             if (!(r2.x < B.rws2)) { float a = vx.x, b = vy.x, c = vz.x; gr_tric_refine(a, b, c, *boxp); vx.x = a; vy.x = b; vz.x = c; }
             if (!(r2.y < B.rws2)) { float a = vx.y, b = vy.y, c = vz.y; gr_tric_refine(a, b, c, *boxp); vx.y = a; vy.y = b; vz.y = c; }
         }
     }
+}
+
+// two atoms: v = image of (x - g) nearest to g, then every sum.  `p*` = reference coordinates (NOREF: unused), m = masses.
+template <bool NOREF>
+__device__ __forceinline__ void gr_sums_pair(GrSumsPk &S, gr_v2f x, gr_v2f y, gr_v2f z, gr_v2f px, gr_v2f py, gr_v2f pz, gr_v2f m,
+                                             const GrBoxU &B, const GrBox *__restrict__ boxp, float gx, float gy, float gz) {
+    gr_v2f vx = x - gr_v2(gx), vy = y - gr_v2(gy), vz = z - gr_v2(gz);
+    gr_image_pair(vx, vy, vz, B, boxp);
     // fractional coordinates of v: moments + extents feed the image proof (gr_finalize_math)
     const gr_v2f fc = vz * gr_v2(B.icz);
     const gr_v2f fb = gr_v2_fma(-fc, gr_v2(B.cy), vy) * gr_v2(B.iby);

@@ -153,6 +153,21 @@ __device__ __forceinline__ void gr_rs_step(float (&a)[32], const uint32_t lane) 
         a[k] = MAX ? gr_fmaxf(keep, got) : keep + got;
     }
 }
+// the two widest steps (partner 32 / 16 lanes away) as ONE lane-swap per pair of registers: v_permlane32_swap exchanges the
+// upper half of a[k] with the lower half of a[k + HALF] (v_permlane16_swap: the odd 16-lane rows of a[k] with the even rows of
+// a[k + HALF]), after which a[k] op a[k + HALF] is, in every lane, exactly "what I keep + what my partner sent" -- the same two
+// operands as gr_rs_step adds, so the results are bit-identical; 2 instructions per exchange instead of 4 (and no LDS crossbar)
+template <int HALF, int MASK, bool MAX>
+__device__ __forceinline__ void gr_rs_step_swap(float (&a)[32]) {
+    static_assert(MASK == 32 || MASK == 16, "lane swaps exist for 32 and 16");
+#pragma unroll
+    for (int k = 0; k < HALF; ++k) {
+        const auto r = MASK == 32 ? __builtin_amdgcn_permlane32_swap(__float_as_uint(a[k]), __float_as_uint(a[k + HALF]), false, false)
+                                  : __builtin_amdgcn_permlane16_swap(__float_as_uint(a[k]), __float_as_uint(a[k + HALF]), false, false);
+        const float x = __uint_as_float(r[0]), y = __uint_as_float(r[1]);
+        a[k] = MAX ? gr_fmaxf(x, y) : x + y;
+    }
+}
 template <int HALF, int MASK>
 __device__ __forceinline__ void gr_rs_step_f64(double (&a)[32], const uint32_t lane) {
     const bool hi = (lane & MASK) != 0;
@@ -170,13 +185,13 @@ __device__ __forceinline__ double gr_wave_sum_scatter32_f64(double (&a)[32], con
     return a[0] + __shfl_xor(a[0], 1, 64);
 }
 __device__ __forceinline__ float gr_wave_sum_scatter32(float (&a)[32], const uint32_t lane) {
-    gr_rs_step<16, 32, false>(a, lane); gr_rs_step<8, 16, false>(a, lane); gr_rs_step<4, 8, false>(a, lane);
+    gr_rs_step_swap<16, 32, false>(a); gr_rs_step_swap<8, 16, false>(a); gr_rs_step<4, 8, false>(a, lane);
     gr_rs_step<2, 4, false>(a, lane); gr_rs_step<1, 2, false>(a, lane);
     return a[0] + __shfl_xor(a[0], 1, 64);
 }
 // the same with max over the first 16 floats: lane l ends with the wave maximum of value (l >> 2)
 __device__ __forceinline__ float gr_wave_max_scatter16(float (&a)[32], const uint32_t lane) {
-    gr_rs_step<8, 32, true>(a, lane); gr_rs_step<4, 16, true>(a, lane); gr_rs_step<2, 8, true>(a, lane); gr_rs_step<1, 4, true>(a, lane);
+    gr_rs_step_swap<8, 32, true>(a); gr_rs_step_swap<4, 16, true>(a); gr_rs_step<2, 8, true>(a, lane); gr_rs_step<1, 4, true>(a, lane);
     const float m = gr_fmaxf(a[0], __shfl_xor(a[0], 2, 64));
     return gr_fmaxf(m, __shfl_xor(m, 1, 64));
 }
@@ -707,6 +722,9 @@ __device__ inline void gr_finalize_math(const double *acc, const float mn[3], co
         const float com[3] = { (float)(g[0] + cv[0]), (float)(g[1] + cv[1]), (float)(g[2] + cv[2]) };
         st.com[0] = com[0]; st.com[1] = com[1]; st.com[2] = com[2];
         st.shift[0] = b.bcx - com[0]; st.shift[1] = b.bcy - com[1]; st.shift[2] = b.bcz - com[2];
+#ifdef GR_DBG_FIN
+        printf("[fin] M %.6f mv %.6f %.6f %.6f g %.6f %.6f %.6f com %.6f %.6f %.6f A00 %.6f n %u\n", acc[0], acc[1], acc[2], acc[3], g[0], g[1], g[2], (double)com[0], (double)com[1], (double)com[2], acc[4], n_sel);
+#endif
     }
     double H[3][3], Hw[3][3];
     for (int a = 0; a < 3; ++a)

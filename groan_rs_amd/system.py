@@ -355,7 +355,7 @@ class System:
         if st != OK:
             raise DeviceError("set_masses", self._err(st)[1], st)
 
-    TUNE = {"sub_batch": 1, "chunks": 2, "fit_wgs": 3, "fuse": 4, "two_pass": 5}
+    TUNE = {"sub_batch": 1, "chunks": 2, "fit_wgs": 3, "fuse": 4, "two_pass": 5, "resident": 6}
 
     def set_tuning(self, **kw):
         """gr_ctx_set_tuning: launch geometry / path selection of the batched RMSD calls (measurement only; same results)"""
@@ -718,7 +718,7 @@ class System:
     def profile_read(self):
         """-> {kernel: (ms_total, launches, frames)} for the batched RMSD path"""
         out = {}
-        for k, name in enumerate(("k_sums_pk", "k_rmsd_finalize", "k_fit_pk")):
+        for k, name in enumerate(("k_sums_pk", "k_rmsd_finalize", "k_fit_pk", "k_fit_resident")):
             ms = C.c_double(0); n = C.c_uint64(0); f = C.c_uint64(0)
             self._lib.gr_profile_read(self._ctx, k, C.byref(ms), C.byref(n), C.byref(f))
             out[name] = (ms.value, int(n.value), int(f.value))

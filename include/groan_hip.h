@@ -255,8 +255,11 @@ int gr_rmsd_plan_force_exact(gr_rmsd_plan *plan, int on);
  *   GR_TUNE_FIT_WGS    workgroups per frame of the fit kernel (0 = automatic: one 256-atom tile per wave)
  *   GR_TUNE_FUSE       1 (default): the sums kernel's last workgroup per frame closes the frame; 0: separate finalize launch
  *   GR_TUNE_TWO_PASS   1 (default): RMSD-fit = sums pass + fit pass that evaluates the rmsd; 0: closed-form single-pass rmsd
+ *   GR_TUNE_RESIDENT   RMSD-fit as ONE pass over HBM, the frame waiting on chip for its rotation (one cooperative launch per
+ *                      segment; needs n_atoms <= ~1.04e6 on MI355X): 1 (default) when the frame fills at least 3/4 of the chip,
+ *                      0 never, 2 whenever it fits.  Same results as the two-pass path up to the order of the partial sums.
  * Every setting gives the same results within the parity tolerance (tests/test_gpu_tuning.py); they exist for measurement. */
-enum { GR_TUNE_SUB_BATCH = 1, GR_TUNE_CHUNKS = 2, GR_TUNE_FIT_WGS = 3, GR_TUNE_FUSE = 4, GR_TUNE_TWO_PASS = 5 };
+enum { GR_TUNE_SUB_BATCH = 1, GR_TUNE_CHUNKS = 2, GR_TUNE_FIT_WGS = 3, GR_TUNE_FUSE = 4, GR_TUNE_TWO_PASS = 5, GR_TUNE_RESIDENT = 6 };
 int gr_ctx_set_tuning(gr_ctx *ctx, int key, int64_t value);
 
 /* ---------------------------------------------------------------- text front end: gro structures, ndx index groups (host side)
@@ -464,7 +467,7 @@ int gr_xtc_read_frames_device_group(const gr_xtc *xtc, uint64_t first_frame, uin
 int gr_timer_start(gr_ctx *ctx);
 int gr_timer_stop(gr_ctx *ctx, float *milliseconds);
 /* Per-kernel HIP-event profile of the batched RMSD path, recorded on the context's stream around
- * each launch while enabled: kernel 0 = sums pass (k_sums_pk / k_rmsd_accum), 1 = k_rmsd_finalize (separate launch only), 2 = fit pass (k_fit_pk).  Enabling resets
+ * each launch while enabled: kernel 0 = sums pass (k_sums_pk / k_rmsd_accum), 1 = k_rmsd_finalize (separate launch only), 2 = fit pass (k_fit_pk), 3 = the resident single pass (k_fit_resident).  Enabling resets
  * the counters.  ms_total / launches = average launch duration; frames = frames those launches covered. */
 int gr_profile_enable(gr_ctx *ctx, int on);
 int gr_profile_read(const gr_ctx *ctx, int kernel, double *ms_total, uint64_t *launches, uint64_t *frames);

@@ -1,0 +1,103 @@
+"""The resident RMSD-fit pass (gr_resident.h: one cooperative launch, every frame read once and written once, the frame
+waiting on chip for its rotation) against the oracle and against the two-pass path on the same frames.  GR_TUNE_RESIDENT = 2
+forces it for systems far smaller than the chip (few streaming workgroups, a ragged last one, idle waves)."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from groan_rs_amd import workload as W
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def G():
+    import groan_rs_amd as g
+    g._lib.load()
+    return g
+
+
+def _systems(G, n, nf, box, sel):
+    masses = W.masses_cycle(n)
+    cur = G.System(n, masses=masses, n_slots=nf + 1)
+    cur.synth_reference(nf, box, 0.2 * min(box[0], box[1], box[2]), W.SEED)
+    cur.synth_frames(nf, 0, nf, 0, 0.04, W.SEED)
+    ref_pos = cur.get_positions(nf)
+    ref = G.System(n, masses=masses, box=box, positions=ref_pos)
+    for s in (ref, cur):
+        s.group_create_from_ranges("S", [sel])
+    frames = [cur.get_positions(f) for f in range(nf)]
+    return masses, cur, ref, ref_pos, frames
+
+
+@pytest.mark.parametrize("n,sel", [(70_001, (0, 70_000)), (70_001, (1003, 69_990)), (5_000, (17, 4_000)), (300, (0, 299))])
+@pytest.mark.parametrize("tric", [False, True])
+def test_resident_matches_oracle_and_two_pass(G, n, sel, tric):
+    nf = 11                                             # odd, longer than the pipeline (3 frames between sums and fit)
+    box = W.box_from_lengths_angles([7.0, 6.5, 6.0], [75.0, 80.0, 70.0]) if tric else W.box_from_lengths_angles([7.0, 6.5, 6.0], [90.0, 90.0, 90.0])
+    masses, cur, ref, ref_pos, frames = _systems(G, n, nf, box, sel)
+    idx = np.arange(sel[0], sel[1] + 1)
+    with O.acc64():
+        want = [O.calc_rmsd_and_fit(ref_pos, masses, idx, box, frames[f], masses, idx, box) for f in range(nf)]
+    plan = G.RMSDPlan(ref, cur, "S")
+    got = {}
+    for mode in (0, 2):
+        cur.set_tuning(resident=mode)
+        cur.profile_enable(True)
+        for f in range(nf):
+            cur.set_frame(frames[f], box, slot=f)
+        r, st = plan.rmsd_fit(0, nf)
+        assert (st == 0).all() and plan.last_fallbacks() == 0, mode
+        prof = cur.profile_read()
+        assert (prof["k_fit_resident"][1] > 0) == (mode == 2), (mode, prof)      # the pass that was asked for is the one that ran
+        got[mode] = (np.array(r), [cur.get_positions(f) for f in range(nf)])
+        for f in range(nf):
+            assert abs(float(r[f]) - want[f][0]) <= 1e-5, (mode, f, float(r[f]), want[f][0])
+            assert np.abs(got[mode][1][f] - want[f][1]).max() <= 5e-5, (mode, f)
+    assert np.abs(got[0][0] - got[2][0]).max() <= 2e-6
+    for f in range(nf):
+        assert np.abs(got[0][1][f] - got[2][1][f]).max() <= 2e-5
+    # the same launch again gives the same bits (order of arrival inside the launch does not reach the results)
+    for f in range(nf):
+        cur.set_frame(frames[f], box, slot=f)
+    r2, _ = plan.rmsd_fit(0, nf)
+    assert np.array_equal(np.array(r2), got[2][0])
+    for f in range(nf):
+        assert np.array_equal(cur.get_positions(f), got[2][1][f])
+    plan.close(); ref.close(); cur.close()
+
+
+def test_resident_short_batches_and_failed_frames(G):
+    """1, 2, 3 and 4 frames (shorter than, equal to and just longer than the pipeline); a frame without a box and a frame with a
+    missing position fail exactly as on the two-pass path and are left unmodified, the frames around them are fitted."""
+    n, nf = 20_000, 6
+    box = W.box_from_lengths_angles([6.0, 6.0, 6.0], [90.0, 90.0, 90.0])
+    masses, cur, ref, ref_pos, frames = _systems(G, n, nf, box, (0, n - 1))
+    plan = G.RMSDPlan(ref, cur, "S")
+    res = {}
+    for mode in (0, 2):
+        cur.set_tuning(resident=mode)
+        for nb in (1, 2, 3, 4):
+            for f in range(nb):
+                cur.set_frame(frames[f], box, slot=f)
+            r, st = plan.rmsd_fit(0, nb)
+            assert (st == 0).all()
+            res[(mode, nb)] = (np.array(r), [cur.get_positions(f) for f in range(nb)])
+        bad = frames[2].copy(); bad[777] = np.nan
+        for f in range(nf):
+            cur.set_frame(bad if f == 2 else frames[f], box, slot=f)
+        r, st = plan.rmsd_fit(0, nf, raise_on_error=False)
+        assert st[2] != 0 and all(st[f] == 0 for f in range(nf) if f != 2), (mode, st)
+        after = [cur.get_positions(f) for f in range(nf)]
+        assert np.array_equal(np.nan_to_num(after[2], nan=-1.0), np.nan_to_num(bad, nan=-1.0)), mode        # the failed frame is untouched
+        res[(mode, "bad")] = (np.array(r), np.array(st), after)
+    for nb in (1, 2, 3, 4):
+        assert np.abs(res[(0, nb)][0] - res[(2, nb)][0]).max() <= 2e-6
+        for f in range(nb):
+            assert np.abs(res[(0, nb)][1][f] - res[(2, nb)][1][f]).max() <= 2e-5
+    assert np.array_equal(res[(0, "bad")][1], res[(2, "bad")][1])
+    for f in range(nf):
+        if f != 2:
+            assert abs(res[(0, "bad")][0][f] - res[(2, "bad")][0][f]) <= 2e-6
+            assert np.abs(res[(0, "bad")][2][f] - res[(2, "bad")][2][f]).max() <= 2e-5
+    plan.close(); ref.close(); cur.close()
