@@ -226,7 +226,7 @@ uint32_t fit_grid(const gr_ctx *c, uint32_t nf) {
 uint32_t resident_wgs(const gr_ctx *c, bool lite) {
     if (!lite || !c->resident || !c->res_max_wgs) return 0;
     const uint64_t groups = ((c->n + 255) >> 8) << 6;
-    const uint64_t wgs = (groups + GR_RES_LANES - 1) / GR_RES_LANES;
+    const uint64_t wgs = (groups + GR_RES_GROUPS - 1) / GR_RES_GROUPS;
     if (wgs + 2 > c->res_max_wgs || wgs > GR_MAX_CHUNKS) return 0;
     if (c->resident == 1 && wgs * 4 < (uint64_t)c->res_max_wgs * 3) return 0;
     return (uint32_t)wgs;
@@ -541,9 +541,11 @@ gr_ctx *gr_ctx_create(int device, uint64_t n_atoms, uint32_t n_slots, int *statu
     if (ok) {   // can the resident pass run here?  (cooperative launches, 160 KiB of LDS per workgroup, one workgroup per CU)
         int coop = 0, per_cu = 0;
         if (hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, device) == hipSuccess && coop &&
-            hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fit_resident<true>), hipFuncAttributeMaxDynamicSharedMemorySize, GR_RES_LDS_BYTES) == hipSuccess &&
-            hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fit_resident<false>), hipFuncAttributeMaxDynamicSharedMemorySize, GR_RES_LDS_BYTES) == hipSuccess &&
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_fit_resident<false>, GR_RES_LANES, GR_RES_LDS_BYTES) == hipSuccess && per_cu >= 1)
+            hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fit_resident<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, GR_RES_LDS_BYTES) == hipSuccess &&
+            hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fit_resident<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, GR_RES_LDS_BYTES) == hipSuccess &&
+            hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fit_resident<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, GR_RES_LDS_BYTES) == hipSuccess &&
+            hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fit_resident<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, GR_RES_LDS_BYTES) == hipSuccess &&
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_fit_resident<false, false>, GR_RES_LANES, GR_RES_LDS_BYTES) == hipSuccess && per_cu >= 1)
             c->res_max_wgs = c->n_cus * (uint32_t)per_cu;
         (void)hipGetLastError();
     }
@@ -1531,7 +1533,7 @@ static int segment_begin(gr_rmsd_plan *p, uint32_t s0, uint32_t nb, int fit) {
                 HIPCHK(c, hipMalloc(&c->fit_partials, (size_t)nb * res_stream * sizeof(double)));
                 c->fit_partials_cap = (size_t)nb * res_stream;
             }
-            const size_t rec_words = (size_t)nb * ((res_stream + 15u) & ~15u) * GR_RES_REC_WORDS;
+            const size_t rec_words = (size_t)nb * ((res_stream + GR_RES_REC_PAD - 1u) & ~(uint32_t)(GR_RES_REC_PAD - 1u)) * GR_RES_REC_WORDS;
             if (rec_words > c->res_wgrec_cap) {
                 if (c->res_wgrec) (void)hipFree(c->res_wgrec);
                 c->res_wgrec = nullptr; c->res_wgrec_cap = 0;
@@ -1545,7 +1547,10 @@ static int segment_begin(gr_rmsd_plan *p, uint32_t s0, uint32_t nb, int fit) {
             const float *masses = c->masses; GrSel sel_arg = sel; const GrBox *boxes = c->boxes_dev; GrPlanDev plan = p->dev;
             GrFrameState *states = c->state_dev; double *fparts = c->fit_partials;
             void *args[] = { &frames, &stride, &slot0, &nfr, &natoms, &masses, &sel_arg, &boxes, &plan, &states, &fparts, &ctl };
-            const void *fn = p->dev.w_is_mass ? reinterpret_cast<const void *>(&k_fit_resident<true>) : reinterpret_cast<const void *>(&k_fit_resident<false>);
+            bool ubox = true;   // the same box in every frame of the segment (constant-volume runs): its constants are loaded once
+            for (uint32_t f = 1; f < nb && ubox; ++f) ubox = memcmp(&c->boxes_host[s0 + f], &c->boxes_host[s0], sizeof(GrBox)) == 0;
+            const void *fn = p->dev.w_is_mass ? (ubox ? reinterpret_cast<const void *>(&k_fit_resident<true, true>) : reinterpret_cast<const void *>(&k_fit_resident<true, false>))
+                                              : (ubox ? reinterpret_cast<const void *>(&k_fit_resident<false, true>) : reinterpret_cast<const void *>(&k_fit_resident<false, false>));
             if (c->profile) EVREC(c, c->pev[0], true, S);
             const hipError_t le = hipLaunchCooperativeKernel(fn, dim3(res_stream + n_fin), dim3(GR_RES_LANES), args, GR_RES_LDS_BYTES, S);
             if (le == hipSuccess) {

@@ -722,9 +722,6 @@ __device__ inline void gr_finalize_math(const double *acc, const float mn[3], co
         const float com[3] = { (float)(g[0] + cv[0]), (float)(g[1] + cv[1]), (float)(g[2] + cv[2]) };
         st.com[0] = com[0]; st.com[1] = com[1]; st.com[2] = com[2];
         st.shift[0] = b.bcx - com[0]; st.shift[1] = b.bcy - com[1]; st.shift[2] = b.bcz - com[2];
-#ifdef GR_DBG_FIN
-        printf("[fin] M %.6f mv %.6f %.6f %.6f g %.6f %.6f %.6f com %.6f %.6f %.6f A00 %.6f n %u\n", acc[0], acc[1], acc[2], acc[3], g[0], g[1], g[2], (double)com[0], (double)com[1], (double)com[2], acc[4], n_sel);
-#endif
     }
     double H[3][3], Hw[3][3];
     for (int a = 0; a < 3; ++a)

@@ -1,6 +1,7 @@
 """The resident RMSD-fit pass (gr_resident.h: one cooperative launch, every frame read once and written once, the frame
 waiting on chip for its rotation) against the oracle and against the two-pass path on the same frames.  GR_TUNE_RESIDENT = 2
-forces it for systems far smaller than the chip (few streaming workgroups, a ragged last one, idle waves)."""
+forces it for systems far smaller than the chip (few streaming workgroups, a ragged last one, idle waves).  The pass is opt-in
+(default: the two-pass path, which is faster on this hardware -- gr_resident.h STATUS)."""
 import numpy as np
 import pytest
 
@@ -100,4 +101,33 @@ def test_resident_short_batches_and_failed_frames(G):
         if f != 2:
             assert abs(res[(0, "bad")][0][f] - res[(2, "bad")][0][f]) <= 2e-6
             assert np.abs(res[(0, "bad")][2][f] - res[(2, "bad")][2][f]).max() <= 2e-5
+    plan.close(); ref.close(); cur.close()
+
+
+def test_resident_with_a_different_box_in_every_frame(G):
+    """constant-pressure runs: every frame has its own box -> the kernel variant that reads the box per frame"""
+    n, nf = 30_000, 9
+    masses = W.masses_cycle(n)
+    boxes = [W.box_from_lengths_angles([7.0 + 0.01 * f, 6.5 - 0.005 * f, 6.0 + 0.002 * f], [75.0, 80.0 + 0.1 * f, 70.0]) for f in range(nf)]
+    cur = G.System(n, masses=masses, n_slots=nf + 1)
+    cur.synth_reference(nf, boxes[0], 1.2, W.SEED)
+    cur.synth_frames(nf, 0, nf, 0, 0.04, W.SEED)
+    ref_pos = cur.get_positions(nf)
+    ref = G.System(n, masses=masses, box=boxes[0], positions=ref_pos)
+    for s_ in (ref, cur):
+        s_.group_create_from_ranges("S", [(5, n - 9)])
+    frames = [cur.get_positions(f) for f in range(nf)]
+    idx = np.arange(5, n - 8)
+    with O.acc64():
+        want = [O.calc_rmsd_and_fit(ref_pos, masses, idx, boxes[0], frames[f], masses, idx, boxes[f]) for f in range(nf)]
+    plan = G.RMSDPlan(ref, cur, "S")
+    cur.set_tuning(resident=2)
+    cur.profile_enable(True)
+    for f in range(nf):
+        cur.set_frame(frames[f], boxes[f], slot=f)
+    r, st = plan.rmsd_fit(0, nf)
+    assert (st == 0).all() and cur.profile_read()["k_fit_resident"][1] == 1
+    for f in range(nf):
+        assert abs(float(r[f]) - want[f][0]) <= 1e-5, (f, float(r[f]), want[f][0])
+        assert np.abs(cur.get_positions(f) - want[f][1]).max() <= 5e-5, f
     plan.close(); ref.close(); cur.close()
