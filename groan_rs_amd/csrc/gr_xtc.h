@@ -415,6 +415,11 @@ inline int skim_frame(const unsigned char *stream, const FrameIndex &fi, uint32_
 //     run of up to 8 small atoms; the range index moves down by one when a whole group stayed inside the next smaller
 //     range, up by one when the group's first atom was near its predecessor ("larger" range) ...
 //   * ... signalled by one flag bit + 5 bits (run length * 3 + change + 1) only when run length or index change.
+// Provenance: the xtc stream format has no specification beyond its one implementation, so `encode_coords` below FOLLOWS THE
+// DECISION PROCEDURE of xdrfile's `xdrfile_compress_coord_float` (xdrfile.c of the GROMACS xdrfile library, BSD 2-clause
+// licence, (c) 2009-2014 Erik Lindahl, David van der Spoel; the reference vendors it) -- which atoms are swapped, when a run
+// ends, when the small-range index moves, which bits announce it -- because any other valid encoding would differ from the
+// reference writer's bytes.  The code is written anew (64-bit packing, 32-bit bit writer, different structure); the decisions are theirs.
 // MSB-first bit writer
 struct BitWriter {
     std::vector<unsigned char> &out; unsigned char *p; uint64_t acc = 0; int nacc = 0;   // nacc < 32 pending bits at the bottom of acc
