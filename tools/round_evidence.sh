@@ -3,7 +3,9 @@
 set -o pipefail
 TAG=${1:-r02}
 mkdir -p gpurun_out
-PROFILE_ARGS="--steps 5 --warmup 2 --no-cpu-baseline" timeout -k 10 900 bash tools/profile.sh $TAG "--steps 5 --warmup 2 --no-cpu-baseline" > gpurun_out/${TAG}_profile.log 2>&1; echo "profile rc=$?"; tail -6 gpurun_out/${TAG}_profile.log
+# (the secondary pipelines first: freeing the gigabytes of an earlier section perturbs the next timed region for a while)
 timeout -k 10 300 python tools/secondary_bench.py > gpurun_out/${TAG}_secondary.json 2> gpurun_out/${TAG}_secondary.err; echo "secondary rc=$?"
+sleep 3
+PROFILE_ARGS="--steps 5 --warmup 2 --no-cpu-baseline" timeout -k 10 900 bash tools/profile.sh $TAG "--steps 5 --warmup 2 --no-cpu-baseline" > gpurun_out/${TAG}_profile.log 2>&1; echo "profile rc=$?"; tail -6 gpurun_out/${TAG}_profile.log
 timeout -k 10 300 python tools/pairdist_bench.py > gpurun_out/${TAG}_pairdist.json 2> gpurun_out/${TAG}_pairdist.err; echo "pairdist rc=$?"
 timeout -k 10 200 tools/bin/ceiling_bench > gpurun_out/${TAG}_ceiling.json 2> gpurun_out/${TAG}_ceiling.err; echo "ceiling rc=$?"
