@@ -5,7 +5,8 @@
 //   gr_polar_rotation   -- fast path for det H > 0 and a not-too-flat H: then the answer is the orthogonal polar factor
 //                          U V^T of H, which the scaled Newton iteration X <- (g X + X^-T / g) / 2 reaches in 5-7 steps
 //                          of plain 3x3 arithmetic (no eigen-decomposition): ~6x shorter on the GPU, where one lane
-//                          closes a frame and its latency is on the critical path of the persistent kernel
+//                          closes a frame (on the tail of the sums kernel, or in a finalizer workgroup of the resident pass, where its latency
+//                          is what the parked frames have to cover)
 //   gr_best_rotation    -- polar when it applies and converges, otherwise Jacobi
 #pragma once
 #include <math.h>

@@ -35,7 +35,7 @@ def main():
     base = np.repeat(ctr, 3, axis=0)
     base[1::3] += rng.normal(0, 0.055, (nm, 3)); base[2::3] += rng.normal(0, 0.055, (nm, 3))     # O H H within ~0.1 nm
     masses = np.array([15.999, 1.008, 1.008], np.float32)[np.arange(n) % 3]
-    slots = 128
+    slots = 256
     s = G.System(n, masses=masses, n_slots=slots)
     s.group_create_from_ranges("Solute", [(0, 29_999)])
     tmp = tempfile.mkdtemp()
@@ -65,7 +65,7 @@ def main():
     th = [threading.Thread(target=dec, args=(b,)) for b in range(T)]
     [t.start() for t in th]; [t.join() for t in th]
     out["host_decode_frames_per_s"] = round(NF / (time.perf_counter() - t0), 1)
-    for B in (8, 16, 32, 64):
+    for B in (8, 16, 32, 64, 128):
         if 2 * B > slots or B > NF:
             continue
         for w in range(2):                                   # both staging banks, both halves of the slots
