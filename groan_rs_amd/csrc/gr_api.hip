@@ -232,6 +232,8 @@ uint32_t resident_wgs(const gr_ctx *c, bool lite) {
     return (uint32_t)wgs;
 }
 
+static hipError_t hipModuleLaunchKernelCompat(const void *fn, dim3 grid, dim3 block, void **args, size_t lds, hipStream_t s) { return hipLaunchKernel(fn, grid, block, args, lds, s); }
+
 // a batch begun with gr_rmsd_batch_begin is still in flight on this context: only uploads may run beside it
 int busy_check(gr_ctx *c) {
     if (c && c->in_flight) return fail(c, GR_E_INVALID_ARG, "a batch begun with gr_rmsd_batch_begin is in flight on this context: only gr_frame_upload / gr_frame_upload_wait / gr_host_* / gr_*_read_frames_device may run before gr_rmsd_batch_end");
@@ -1440,7 +1442,7 @@ int gr_ctx_set_tuning(gr_ctx *c, int key, int64_t value) try {
     case GR_TUNE_FIT_WGS: if (value < 0 || value > 65535) break; c->fit_wgs = (uint32_t)value; return GR_OK;
     case GR_TUNE_FUSE: c->fuse = value ? 1 : 0; return GR_OK;
     case GR_TUNE_TWO_PASS: c->two_pass = value ? 1 : 0; return GR_OK;
-    case GR_TUNE_RESIDENT: if (value < 0 || value > 2) break; c->resident = value; return GR_OK;
+    case GR_TUNE_RESIDENT: if (value < 0 || value > 3) break; c->resident = value; return GR_OK;
     default: break;
     }
     return fail(c, GR_E_INVALID_ARG, "unknown tuning key or value out of range");
@@ -1552,7 +1554,10 @@ static int segment_begin(gr_rmsd_plan *p, uint32_t s0, uint32_t nb, int fit) {
             const void *fn = p->dev.w_is_mass ? (ubox ? reinterpret_cast<const void *>(&k_fit_resident<true, true>) : reinterpret_cast<const void *>(&k_fit_resident<true, false>))
                                               : (ubox ? reinterpret_cast<const void *>(&k_fit_resident<false, true>) : reinterpret_cast<const void *>(&k_fit_resident<false, false>));
             if (c->profile) EVREC(c, c->pev[0], true, S);
-            const hipError_t le = hipLaunchCooperativeKernel(fn, dim3(res_stream + n_fin), dim3(GR_RES_LANES), args, GR_RES_LDS_BYTES, S);
+            // (3 = an ordinary launch of the same grid, for counter collection only: rocprofv3 --pmc faults on cooperative launches;
+            // the grid is co-resident on an otherwise idle device, which is all the kernel needs)
+            const hipError_t le = c->resident == 3 ? hipModuleLaunchKernelCompat(fn, dim3(res_stream + n_fin), dim3(GR_RES_LANES), args, GR_RES_LDS_BYTES, S)
+                                                   : hipLaunchCooperativeKernel(fn, dim3(res_stream + n_fin), dim3(GR_RES_LANES), args, GR_RES_LDS_BYTES, S);
             if (le == hipSuccess) {
                 if (c->profile) EVREC(c, c->pev[1], true, S);
                 k_rmsd_close<<<dim3(nb), dim3(64), 0, S>>>(c->fit_partials, res_stream, p->dev.sw, c->state_dev);

@@ -27,15 +27,17 @@
 // HBM traffic: 12 bytes per atom read + 12 written per frame = 24 (was 36), and nothing from the caches.
 // Measured floor of that traffic at the same launch shape (tools/ceiling_bench.hip "resident copy"): 4.2 us per 1e6-atom frame.
 //
-// STATUS (round 2, MI355X, 1e6 atoms, 1024 frames per launch): 7.3 us per frame = 135 k frames/s, against 6.6-6.8 us = 149 k for the
+// STATUS (round 2, MI355X, 1e6 atoms, 1024 frames per launch): 7.2 us per frame = 137 k frames/s, against 6.6-6.8 us = 150 k for the
 // two-pass path -- so the pass is OPT-IN (GR_TUNE_RESIDENT), not the default.  What bounds it is not memory (a lane waits
 // 0.2-0.3 us per frame for its rows) and not the finalizers (no closing algebra at all: same time) but instruction issue: every
-// CU runs ALL of a frame's arithmetic for its 4096 atoms inside one frame period -- ~1250 wave-instructions per wave and frame
-// here (sums + the per-frame wave reduction + fit + the queue of parked register sets + SGPR spill traffic), two waves per
-// SIMD -- where the two-pass kernels spread 40 instructions per atom over far more resident waves and amortise one reduction
+// CU runs ALL of a frame's arithmetic for its 4096 atoms inside one frame period -- 934 VALU + 250 scalar instructions per wave
+// and frame (rocprofv3 --pmc on an ordinary launch of the same grid, GR_TUNE_RESIDENT = 3: sums + the per-frame wave reduction +
+// fit + the queue of parked register sets), two waves per SIMD that barely overlap (a wave alone takes ~3.7 us per frame, the
+// pair 7.2: the waves that are ahead spend a third of their time waiting for records, the last wave of a workgroup never waits) -- where the two-pass kernels spread 40 instructions per atom over far more resident waves and amortise one reduction
 // over ~120 atoms per lane.  History of the measurement: 1024 lanes x 1 group, 3 frames parked 9.1 us; + lane-swap reductions
 // 9.1; 512 lanes x 2 groups, 4 parked 8.4; 6 parked, register sets named by unrolling x6 7.6 (the loop body outgrew the
-// instruction cache); a queue of register sets + out-of-line rare paths 7.3.  rocprofv3 --pmc faults on the cooperative launch
+// instruction cache); a queue of register sets + out-of-line rare paths 7.3; lane facts as bits of one register + waiting waves at
+// low priority 7.2.  rocprofv3 --pmc faults on the cooperative launch
 // (ROCm 7.2), one more reason it is not the default: the round's counter evidence is collected on the two-pass path.
 //
 // Synchronisation.  All waiting is on data that a DIFFERENT workgroup produces, so every workgroup must be resident: the
@@ -85,8 +87,12 @@ __device__ __forceinline__ float gr_first_f(float v) { return __uint_as_float((u
 __device__ __forceinline__ float gr_lane_f(unsigned long long v, int l) { return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l)); }
 
 // one 4-atom group of a lane: which of its atoms belong to the selection, its reference rows, masses and weights (registers)
+// (the per-lane facts are bits of ONE register: seven `bool`s would be seven 64-bit lane masks -- 14 SGPRs per group held
+// across the whole loop, and the kernel was spilling SGPRs into vector lanes)
+enum { GR_RG_IN0 = 1u, GR_RG_IN1 = 2u, GR_RG_IN2 = 4u, GR_RG_IN3 = 8u, GR_RG_ANY = 16u /* some atom in the selection */, GR_RG_FULL = 32u /* all four */ };
 struct GrResGroup {
-    bool valid, in_sel, full, in0, in1, in2, in3;
+    bool valid;        // wave-uniform: the group lies inside the slot
+    uint32_t flags;
     size_t b;          // float4 index of the group's first row inside a slot
     GrP4 P;
     float4 mm, ww;
@@ -153,7 +159,7 @@ __device__ __forceinline__ void gr_res_fit_group(const GrResGroup &G, const floa
     n.x23 = gr_v2_fma(gr_v2(T.r02), q.z23, gr_v2_fma(gr_v2(T.r01), q.y23, gr_v2(T.r00) * q.x23));
     n.y23 = gr_v2_fma(gr_v2(T.r12), q.z23, gr_v2_fma(gr_v2(T.r11), q.y23, gr_v2(T.r10) * q.x23));
     n.z23 = gr_v2_fma(gr_v2(T.r22), q.z23, gr_v2_fma(gr_v2(T.r21), q.y23, gr_v2(T.r20) * q.x23));
-    if (G.in_sel) {   // sum w |R q - p|^2 (rmsd.rs:592-599); the weights of atoms outside the selection are zero
+    if (G.flags & GR_RG_ANY) {   // sum w |R q - p|^2 (rmsd.rs:592-599); the weights of atoms outside the selection are zero
         const gr_v2f w01 = WMASS ? gr_v2p(G.mm.x, G.mm.y) : gr_v2p(G.ww.x, G.ww.y), w23 = WMASS ? gr_v2p(G.mm.z, G.mm.w) : gr_v2p(G.ww.z, G.ww.w);
         gr_v2f dx = n.x01 - G.P.x01, dy = n.y01 - G.P.y01, dz = n.z01 - G.P.z01;
         gr_v2f part = w01 * gr_v2_fma(dx, dx, gr_v2_fma(dy, dy, dz * dz));
@@ -284,22 +290,22 @@ __global__ __launch_bounds__(GR_RES_LANES) __attribute__((amdgpu_waves_per_eu(1,
     auto setup = [&](uint32_t g, GrResGroup &G) {
         const uint32_t i0 = g << 2;
         G.valid = g < ngroups;                                        // wave-uniform
-        G.in_sel = G.valid && (i0 + 3u >= first) && (i0 < last);
-        G.full = G.valid && (i0 >= first) && (i0 + 3u < last);
-        G.in0 = G.valid && (i0 >= first) && (i0 < last); G.in1 = G.valid && (i0 + 1u >= first) && (i0 + 1u < last);
-        G.in2 = G.valid && (i0 + 2u >= first) && (i0 + 2u < last); G.in3 = G.valid && (i0 + 3u >= first) && (i0 + 3u < last);
+        const bool in0 = G.valid && (i0 >= first) && (i0 < last), in1 = G.valid && (i0 + 1u >= first) && (i0 + 1u < last);
+        const bool in2 = G.valid && (i0 + 2u >= first) && (i0 + 2u < last), in3 = G.valid && (i0 + 3u >= first) && (i0 + 3u < last);
+        const bool in_sel = in0 || in1 || in2 || in3, full = in0 && in1 && in2 && in3;
+        G.flags = (in0 ? GR_RG_IN0 : 0u) | (in1 ? GR_RG_IN1 : 0u) | (in2 ? GR_RG_IN2 : 0u) | (in3 ? GR_RG_IN3 : 0u) | (in_sel ? GR_RG_ANY : 0u) | (full ? GR_RG_FULL : 0u);
         G.b = gr_row_index(G.valid ? g : 0u, 0);
         float4 pa = zero4, pb = zero4, pc = zero4;
         G.mm = zero4; G.ww = zero4;
-        if (G.in_sel) {
+        if (in_sel) {
             gr_rows_load(reinterpret_cast<const float4 *>(plan.p), (size_t)(g - g0), pa, pb, pc);
             G.mm = reinterpret_cast<const float4 *>(masses)[g];
             if (!WMASS) G.ww = reinterpret_cast<const float4 *>(plan.w)[g - g0];
-            if (!G.full) {   // ragged end of the selection: atoms outside it weigh nothing and have no reference
-                if (!G.in0) { G.mm.x = 0.f; G.ww.x = 0.f; pa.x = 0.f; pa.z = 0.f; pb.x = 0.f; }
-                if (!G.in1) { G.mm.y = 0.f; G.ww.y = 0.f; pa.y = 0.f; pa.w = 0.f; pb.y = 0.f; }
-                if (!G.in2) { G.mm.z = 0.f; G.ww.z = 0.f; pb.z = 0.f; pc.x = 0.f; pc.z = 0.f; }
-                if (!G.in3) { G.mm.w = 0.f; G.ww.w = 0.f; pb.w = 0.f; pc.y = 0.f; pc.w = 0.f; }
+            if (!full) {   // ragged end of the selection: atoms outside it weigh nothing and have no reference
+                if (!in0) { G.mm.x = 0.f; G.ww.x = 0.f; pa.x = 0.f; pa.z = 0.f; pb.x = 0.f; }
+                if (!in1) { G.mm.y = 0.f; G.ww.y = 0.f; pa.y = 0.f; pa.w = 0.f; pb.y = 0.f; }
+                if (!in2) { G.mm.z = 0.f; G.ww.z = 0.f; pb.z = 0.f; pc.x = 0.f; pc.z = 0.f; }
+                if (!in3) { G.mm.w = 0.f; G.ww.w = 0.f; pb.w = 0.f; pc.y = 0.f; pc.w = 0.f; }
             }
         }
         G.P = gr_pairs_rows(pa, pb, pc);
@@ -324,11 +330,13 @@ __global__ __launch_bounds__(GR_RES_LANES) __attribute__((amdgpu_waves_per_eu(1,
     auto group_sums = [&](const GrResGroup &G, const float4 &r0, const float4 &r1, const float4 &r2, const GrBoxU &B, const GrBox *boxp,
                           float gx, float gy, float gz, float (&s32)[32], float (&e32)[32], bool init) {
         GrP4 q = gr_pairs_rows(r0, r1, r2);
-        if (!G.full) {   // atoms outside the selection become copies of the first atom: v = 0 adds nothing and lies inside every extent
-            if (!G.in0) { q.x01.x = gx; q.y01.x = gy; q.z01.x = gz; }
-            if (!G.in1) { q.x01.y = gx; q.y01.y = gy; q.z01.y = gz; }
-            if (!G.in2) { q.x23.x = gx; q.y23.x = gy; q.z23.x = gz; }
-            if (!G.in3) { q.x23.y = gx; q.y23.y = gy; q.z23.y = gz; }
+        // atoms outside the selection become copies of the first atom: v = 0 adds nothing and lies inside every extent (a whole
+        // wave of complete groups -- every wave but the two at the ends of the selection -- skips this on one scalar branch)
+        if (__builtin_amdgcn_ballot_w64((G.flags & GR_RG_FULL) == 0u) != 0ull) {
+            if (!(G.flags & GR_RG_IN0)) { q.x01.x = gx; q.y01.x = gy; q.z01.x = gz; }
+            if (!(G.flags & GR_RG_IN1)) { q.x01.y = gx; q.y01.y = gy; q.z01.y = gz; }
+            if (!(G.flags & GR_RG_IN2)) { q.x23.x = gx; q.y23.x = gy; q.z23.x = gz; }
+            if (!(G.flags & GR_RG_IN3)) { q.x23.y = gx; q.y23.y = gy; q.z23.y = gz; }
         }
         gr_v2f vxa = q.x01 - gr_v2(gx), vya = q.y01 - gr_v2(gy), vza = q.z01 - gr_v2(gz);
         gr_v2f vxb = q.x23 - gr_v2(gx), vyb = q.y23 - gr_v2(gy), vzb = q.z23 - gr_v2(gz);
@@ -394,10 +402,12 @@ __global__ __launch_bounds__(GR_RES_LANES) __attribute__((amdgpu_waves_per_eu(1,
     auto fit = [&](uint32_t j, uint32_t ps, unsigned long long rv, const float4 (&keep)[3], const GrBoxU &B) {
         uint32_t polls = 0;
         while (__builtin_amdgcn_ballot_w64(lane < 13u && (uint32_t)(rv >> 32) != ctl.epoch) != 0ull) {
+            __builtin_amdgcn_s_setprio(0);                             // a wave that is ahead waits below the wave it shares the SIMD with
             if (++polls > GR_RES_PATIENCE || ((polls & 255u) == 0 && gr_ld_agent(ctl.abort) != 0u)) { if (lane == 0) gr_st_agent(ctl.abort, 1u); bail = true; return; }
-            __builtin_amdgcn_s_sleep(2);
+            __builtin_amdgcn_s_sleep(8);
             rv = request_rec(j);
         }
+        __builtin_amdgcn_s_setprio(2);
         const int status = __builtin_amdgcn_readlane((int)(uint32_t)rv, 0);
         double rs = 0.0;
         if (status == 0) {
