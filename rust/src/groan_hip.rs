@@ -27,6 +27,10 @@ pub const GR_E_NO_POSITION: c_int = 6;
 pub const GR_E_NO_MASS: c_int = 7;
 pub const GR_E_GROUP_NOT_FOUND: c_int = 8;
 
+#[repr(C)] pub struct gr_pool { _private: [u8; 0] }
+#[repr(C)] pub struct gr_comm { _private: [u8; 0] }
+/// `body(ctx, worker, frame, user, result)` of gr_pool_map: non-zero return = the frame's error (the first one wins)
+pub type gr_pool_body = Option<unsafe extern "C" fn(ctx: *mut gr_ctx, worker: c_int, frame: u64, user: *mut c_void, result: *mut c_float) -> c_int>;
 extern "C" {
     pub fn gr_ctx_create(device: c_int, n_atoms: u64, n_slots: u32, status: *mut c_int) -> *mut gr_ctx;
     pub fn gr_ctx_destroy(ctx: *mut gr_ctx);
@@ -85,6 +89,44 @@ extern "C" {
     pub fn gr_xtc_close(xtc: *mut gr_xtc);
     pub fn gr_xtc_read_frames_device(xtc: *const gr_xtc, first_frame: u64, n_frames: u32, frame_step: u64, ctx: *mut gr_ctx,
                                      first_slot: u32, host_threads: c_int, steps: *mut u64, times: *mut c_float) -> c_int;
+    // asynchronous batches, one-shot calls, batched per-frame calls, tuning, host memory, diagnostics
+    pub fn gr_rmsd_batch_begin(plan: *mut gr_rmsd_plan, first_slot: u32, n_frames: u32, fit: c_int) -> c_int;
+    pub fn gr_rmsd_batch_end(plan: *mut gr_rmsd_plan, rmsd: *mut c_float, status: *mut c_int, rot: *mut c_float) -> c_int;
+    pub fn gr_rmsd_plan_last_fallbacks(plan: *const gr_rmsd_plan) -> u32;
+    pub fn gr_calc_rmsd(ctx: *mut gr_ctx, slot: u32, reference: *mut gr_ctx, ref_slot: u32, group: *const c_char, rmsd: *mut c_float, rot: *mut c_float) -> c_int;
+    pub fn gr_calc_rmsd_and_fit(ctx: *mut gr_ctx, slot: u32, reference: *mut gr_ctx, ref_slot: u32, group: *const c_char, rmsd: *mut c_float) -> c_int;
+    pub fn gr_group_center_batch(ctx: *mut gr_ctx, first_slot: u32, n_frames: u32, group: *const c_char, kind: c_int, weighted: c_int, out: *mut c_float, status: *mut c_int) -> c_int;
+    pub fn gr_group_translate_batch(ctx: *mut gr_ctx, first_slot: u32, n_frames: u32, group: *const c_char, v: *const c_float, status: *mut c_int) -> c_int;
+    pub fn gr_group_wrap_batch(ctx: *mut gr_ctx, first_slot: u32, n_frames: u32, group: *const c_char, status: *mut c_int) -> c_int;
+    pub fn gr_atoms_center_batch(ctx: *mut gr_ctx, first_slot: u32, n_frames: u32, ref_group: *const c_char, dim: c_int, weighted: c_int, status: *mut c_int) -> c_int;
+    pub fn gr_ctx_set_tuning(ctx: *mut gr_ctx, key: c_int, value: i64) -> c_int;   // GR_TUNE_* (include/groan_hip.h)
+    pub fn gr_host_alloc(bytes: usize) -> *mut c_void;                              // pinned memory: asynchronous gr_frame_upload
+    pub fn gr_host_free(p: *mut c_void);
+    pub fn gr_sync(ctx: *mut gr_ctx) -> c_int;
+    pub fn gr_last_error(ctx: *const gr_ctx) -> *const c_char;
+    pub fn gr_status_string(status: c_int) -> *const c_char;
+    // traj_iter_map_reduce across GPUs (src/system/parallel.rs:208-481): in one process ...
+    pub fn gr_pool_create(devices: *const c_int, n_workers: c_int, n_atoms: u64, n_slots: u32, status: *mut c_int) -> *mut gr_pool;
+    pub fn gr_pool_destroy(pool: *mut gr_pool);
+    pub fn gr_pool_size(pool: *const gr_pool) -> c_int;
+    pub fn gr_pool_ctx(pool: *mut gr_pool, worker: c_int) -> *mut gr_ctx;
+    pub fn gr_pool_last_error(pool: *const gr_pool) -> *const c_char;
+    pub fn gr_pool_map(pool: *mut gr_pool, n_frames: u64, body: gr_pool_body, user: *mut c_void, width: usize, results: *mut c_float,
+                       frames_done: *mut u64, error_frame: *mut u64) -> c_int;
+    // ... and one process per GPU (RCCL over xGMI: one final all-gather + the shared error flag)
+    pub fn gr_comm_unique_id(id128: *mut c_void) -> c_int;
+    pub fn gr_comm_create(device: c_int, rank: c_int, world: c_int, id128: *const c_void, status: *mut c_int) -> *mut gr_comm;
+    pub fn gr_comm_destroy(comm: *mut gr_comm);
+    pub fn gr_comm_last_error(comm: *const gr_comm) -> *const c_char;
+    pub fn gr_comm_library() -> *const c_char;
+    pub fn gr_comm_gather_per_frame(comm: *mut gr_comm, local: *const c_float, n_total: u64, width: usize, out: *mut c_float) -> c_int;
+    pub fn gr_comm_any_error(comm: *mut gr_comm, local_flag: c_int, any: *mut c_int) -> c_int;
+    pub fn gr_shard_deinterleave(gathered: *const c_float, world: c_int, n_total: u64, width: usize, out: *mut c_float);
+    // GroupXtcReader (partial-frame reads, molly_xtc.rs:475-560)
+    pub fn gr_xtc_read_frame_prefix(xtc: *const gr_xtc, frame: u64, n_prefix: u64, xyz: *mut c_float, box9: *mut c_float, step: *mut u64, time: *mut c_float,
+                                    precision: *mut c_float, stream_bytes_read: *mut u64) -> c_int;
+    pub fn gr_xtc_read_frames_device_group(xtc: *const gr_xtc, first_frame: u64, n_frames: u32, frame_step: u64, ctx: *mut gr_ctx, first_slot: u32,
+                                           group: *const c_char, host_threads: c_int, steps: *mut u64, times: *mut c_float) -> c_int;
 }
 
 #[repr(C)] pub struct gr_xtc { _private: [u8; 0] }
