@@ -85,6 +85,7 @@ struct gr_ctx {
     // resident RMSD fit (gr_resident.h): one cooperative launch per segment, the frame waits on chip for its rotation
     int resident = 0;                 // GR_TUNE_RESIDENT 0 never, 1 when the frame fills most of the chip, 2 whenever it fits (tests)
     uint32_t res_max_wgs = 0;         // workgroups of k_fit_resident the device holds at once (0: no cooperative launch)
+    int resident_groups = 2;          // GR_TUNE_RESIDENT_GROUPS: 4-atom groups per lane of the resident pass (1: 1024 lanes, 2: 512 lanes)
     unsigned long long *res_wgrec = nullptr; size_t res_wgrec_cap = 0;   // [frames][streaming workgroups, padded to 16][32] tagged words
     unsigned long long *res_rec = nullptr;   // [GR_MAX_BATCH][16]
     uint32_t *res_abort = nullptr;    // device word
@@ -220,13 +221,25 @@ uint32_t fit_grid(const gr_ctx *c, uint32_t nf) {
     return (uint32_t)(gx < 1 ? 1 : gx);
 }
 
+// the four variants of the resident kernel for G groups per lane: allow their LDS size, hand out the one a launch needs
+template <int G> static const void *resident_fn(bool wmass, bool ubox) {
+    return wmass ? (ubox ? reinterpret_cast<const void *>(&k_fit_resident<true, true, G>) : reinterpret_cast<const void *>(&k_fit_resident<true, false, G>))
+                 : (ubox ? reinterpret_cast<const void *>(&k_fit_resident<false, true, G>) : reinterpret_cast<const void *>(&k_fit_resident<false, false, G>));
+}
+template <int G> static bool resident_prepare() {
+    bool ok = true;
+    for (int v = 0; v < 4; ++v)
+        ok = ok && hipFuncSetAttribute(resident_fn<G>((v & 1) != 0, (v & 2) != 0), hipFuncAttributeMaxDynamicSharedMemorySize, GrResShape<G>::LDS_BYTES) == hipSuccess;
+    return ok;
+}
+
 // Streaming workgroups of the resident RMSD-fit pass (gr_resident.h), or 0 when the two-pass path takes the segment: the
 // frame must fit (one 4-atom group per lane) beside at least two finalizer workgroups, and -- unless forced -- fill most of
 // the chip: a small frame streams faster through the two-pass kernels, which spread it over every CU.
 uint32_t resident_wgs(const gr_ctx *c, bool lite) {
     if (!lite || !c->resident || !c->res_max_wgs) return 0;
     const uint64_t groups = ((c->n + 255) >> 8) << 6;
-    const uint64_t wgs = (groups + GR_RES_GROUPS - 1) / GR_RES_GROUPS;
+    const uint64_t wgs = (groups + GR_RES_GROUPS - 1) / GR_RES_GROUPS;   // (a workgroup owns 1024 groups whatever the groups per lane)
     if (wgs + 2 > c->res_max_wgs || wgs > GR_MAX_CHUNKS) return 0;
     if (c->resident == 1 && wgs * 4 < (uint64_t)c->res_max_wgs * 3) return 0;
     return (uint32_t)wgs;
@@ -543,11 +556,9 @@ gr_ctx *gr_ctx_create(int device, uint64_t n_atoms, uint32_t n_slots, int *statu
     if (ok) {   // can the resident pass run here?  (cooperative launches, 160 KiB of LDS per workgroup, one workgroup per CU)
         int coop = 0, per_cu = 0;
         if (hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, device) == hipSuccess && coop &&
-            hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fit_resident<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, GR_RES_LDS_BYTES) == hipSuccess &&
-            hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fit_resident<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, GR_RES_LDS_BYTES) == hipSuccess &&
-            hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fit_resident<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, GR_RES_LDS_BYTES) == hipSuccess &&
-            hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fit_resident<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, GR_RES_LDS_BYTES) == hipSuccess &&
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_fit_resident<false, false>, GR_RES_LANES, GR_RES_LDS_BYTES) == hipSuccess && per_cu >= 1)
+            resident_prepare<1>() && resident_prepare<2>() &&
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_fit_resident<false, false, 2>, GrResShape<2>::LANES, GrResShape<2>::LDS_BYTES) == hipSuccess && per_cu >= 1 &&
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_fit_resident<false, false, 1>, GrResShape<1>::LANES, GrResShape<1>::LDS_BYTES) == hipSuccess && per_cu >= 1)
             c->res_max_wgs = c->n_cus * (uint32_t)per_cu;
         (void)hipGetLastError();
     }
@@ -1443,6 +1454,7 @@ int gr_ctx_set_tuning(gr_ctx *c, int key, int64_t value) try {
     case GR_TUNE_FUSE: c->fuse = value ? 1 : 0; return GR_OK;
     case GR_TUNE_TWO_PASS: c->two_pass = value ? 1 : 0; return GR_OK;
     case GR_TUNE_RESIDENT: if (value < 0 || value > 3) break; c->resident = value; return GR_OK;
+    case GR_TUNE_RESIDENT_GROUPS: if (value < 1 || value > 2) break; c->resident_groups = (int)value; return GR_OK;
     default: break;
     }
     return fail(c, GR_E_INVALID_ARG, "unknown tuning key or value out of range");
@@ -1551,13 +1563,14 @@ static int segment_begin(gr_rmsd_plan *p, uint32_t s0, uint32_t nb, int fit) {
             void *args[] = { &frames, &stride, &slot0, &nfr, &natoms, &masses, &sel_arg, &boxes, &plan, &states, &fparts, &ctl };
             bool ubox = true;   // the same box in every frame of the segment (constant-volume runs): its constants are loaded once
             for (uint32_t f = 1; f < nb && ubox; ++f) ubox = memcmp(&c->boxes_host[s0 + f], &c->boxes_host[s0], sizeof(GrBox)) == 0;
-            const void *fn = p->dev.w_is_mass ? (ubox ? reinterpret_cast<const void *>(&k_fit_resident<true, true>) : reinterpret_cast<const void *>(&k_fit_resident<true, false>))
-                                              : (ubox ? reinterpret_cast<const void *>(&k_fit_resident<false, true>) : reinterpret_cast<const void *>(&k_fit_resident<false, false>));
+            const bool g1 = c->resident_groups == 1;
+            const void *fn = g1 ? resident_fn<1>(p->dev.w_is_mass != 0, ubox) : resident_fn<2>(p->dev.w_is_mass != 0, ubox);
+            const uint32_t lanes = g1 ? GrResShape<1>::LANES : GrResShape<2>::LANES, lds = g1 ? GrResShape<1>::LDS_BYTES : GrResShape<2>::LDS_BYTES;
             if (c->profile) EVREC(c, c->pev[0], true, S);
             // (3 = an ordinary launch of the same grid, for counter collection only: rocprofv3 --pmc faults on cooperative launches;
             // the grid is co-resident on an otherwise idle device, which is all the kernel needs)
-            const hipError_t le = c->resident == 3 ? hipModuleLaunchKernelCompat(fn, dim3(res_stream + n_fin), dim3(GR_RES_LANES), args, GR_RES_LDS_BYTES, S)
-                                                   : hipLaunchCooperativeKernel(fn, dim3(res_stream + n_fin), dim3(GR_RES_LANES), args, GR_RES_LDS_BYTES, S);
+            const hipError_t le = c->resident == 3 ? hipModuleLaunchKernelCompat(fn, dim3(res_stream + n_fin), dim3(lanes), args, lds, S)
+                                                   : hipLaunchCooperativeKernel(fn, dim3(res_stream + n_fin), dim3(lanes), args, lds, S);
             if (le == hipSuccess) {
                 if (c->profile) EVREC(c, c->pev[1], true, S);
                 k_rmsd_close<<<dim3(nb), dim3(64), 0, S>>>(c->fit_partials, res_stream, p->dev.sw, c->state_dev);

@@ -142,6 +142,31 @@ __device__ __forceinline__ void gr_stage_box(GrBox *lds_box, const GrBox *g) {
 // Wave reduce-scatter of 32 floats: afterwards lane l holds the wave total of value (l >> 1).  Each step halves the
 // values a lane still carries (it sends the half its partner keeps): 16+8+4+2+1+1 exchanges instead of 32 x 6.
 // Steps are template instances so every register-array index is a compile-time constant.
+// the value of lane (l ^ M) for M = 1, 2, 4, 8 as data-parallel-primitive moves inside the VALU (quad permutes, a row rotation by
+// 8, two masked row shifts for 4): no trip through the LDS crossbar (ds_bpermute: ~100 cycles, and the reductions chain 4-5 of them)
+template <int M> __device__ __forceinline__ float gr_xor_lane(float v) {
+    const int x = __float_as_int(v);
+    int r;
+#ifdef GR_NO_DPP
+    return __int_as_float(__shfl_xor(x, M, 64));
+#endif
+    if (M == 1) r = __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xf, 0xf, false);                 // quad_perm [1,0,3,2]
+    else if (M == 2) r = __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xf, 0xf, false);            // quad_perm [2,3,0,1]
+    else if (M == 4) { r = __builtin_amdgcn_update_dpp(0, x, 0x104, 0xf, 0x5, false);         // row_shl:4 into banks 0, 2
+                       r = __builtin_amdgcn_update_dpp(r, x, 0x114, 0xf, 0xA, false); }       // row_shr:4 into banks 1, 3
+    else if (M == 8) r = __builtin_amdgcn_update_dpp(0, x, 0x128, 0xf, 0xf, false);           // row_ror:8
+    else r = __shfl_xor(x, M, 64);
+    return __int_as_float(r);
+}
+// sum of a float over the 64 lanes, in every lane: four DPP steps, then the two lane swaps (swap(x, x) puts the two halves /
+// the odd and even rows side by side) -- no LDS crossbar anywhere
+__device__ __forceinline__ float gr_wave_allsum_f32(float x) {
+    x += gr_xor_lane<1>(x); x += gr_xor_lane<2>(x); x += gr_xor_lane<4>(x); x += gr_xor_lane<8>(x);
+    const auto r16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    x = __uint_as_float(r16[0]) + __uint_as_float(r16[1]);
+    const auto r32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r32[0]) + __uint_as_float(r32[1]);
+}
 template <int HALF, int MASK, bool MAX>
 __device__ __forceinline__ void gr_rs_step(float (&a)[32], const uint32_t lane) {
     const bool hi = (lane & MASK) != 0;
@@ -149,7 +174,7 @@ __device__ __forceinline__ void gr_rs_step(float (&a)[32], const uint32_t lane) 
     for (int k = 0; k < HALF; ++k) {
         const float send = hi ? a[k] : a[k + HALF];
         const float keep = hi ? a[k + HALF] : a[k];
-        const float got = __shfl_xor(send, MASK, 64);
+        const float got = gr_xor_lane<MASK>(send);
         a[k] = MAX ? gr_fmaxf(keep, got) : keep + got;
     }
 }
@@ -187,13 +212,13 @@ __device__ __forceinline__ double gr_wave_sum_scatter32_f64(double (&a)[32], con
 __device__ __forceinline__ float gr_wave_sum_scatter32(float (&a)[32], const uint32_t lane) {
     gr_rs_step_swap<16, 32, false>(a); gr_rs_step_swap<8, 16, false>(a); gr_rs_step<4, 8, false>(a, lane);
     gr_rs_step<2, 4, false>(a, lane); gr_rs_step<1, 2, false>(a, lane);
-    return a[0] + __shfl_xor(a[0], 1, 64);
+    return a[0] + gr_xor_lane<1>(a[0]);
 }
 // the same with max over the first 16 floats: lane l ends with the wave maximum of value (l >> 2)
 __device__ __forceinline__ float gr_wave_max_scatter16(float (&a)[32], const uint32_t lane) {
     gr_rs_step_swap<8, 32, true>(a); gr_rs_step_swap<4, 16, true>(a); gr_rs_step<2, 8, true>(a, lane); gr_rs_step<1, 4, true>(a, lane);
-    const float m = gr_fmaxf(a[0], __shfl_xor(a[0], 2, 64));
-    return gr_fmaxf(m, __shfl_xor(m, 1, 64));
+    const float m = gr_fmaxf(a[0], gr_xor_lane<2>(a[0]));
+    return gr_fmaxf(m, gr_xor_lane<1>(m));
 }
 
 // ------------------------------------------------------------------------------------------ centres

@@ -27,18 +27,25 @@
 // HBM traffic: 12 bytes per atom read + 12 written per frame = 24 (was 36), and nothing from the caches.
 // Measured floor of that traffic at the same launch shape (tools/ceiling_bench.hip "resident copy"): 4.2 us per 1e6-atom frame.
 //
-// STATUS (round 2, MI355X, 1e6 atoms, 1024 frames per launch): 7.2 us per frame = 137 k frames/s, against 6.6-6.8 us = 150 k for the
-// two-pass path -- so the pass is OPT-IN (GR_TUNE_RESIDENT), not the default.  What bounds it is not memory (a lane waits
-// 0.2-0.3 us per frame for its rows) and not the finalizers (no closing algebra at all: same time) but instruction issue: every
-// CU runs ALL of a frame's arithmetic for its 4096 atoms inside one frame period -- 934 VALU + 250 scalar instructions per wave
-// and frame (rocprofv3 --pmc on an ordinary launch of the same grid, GR_TUNE_RESIDENT = 3: sums + the per-frame wave reduction +
-// fit + the queue of parked register sets), two waves per SIMD that barely overlap (a wave alone takes ~3.7 us per frame, the
-// pair 7.2: the waves that are ahead spend a third of their time waiting for records, the last wave of a workgroup never waits) -- where the two-pass kernels spread 40 instructions per atom over far more resident waves and amortise one reduction
-// over ~120 atoms per lane.  History of the measurement: 1024 lanes x 1 group, 3 frames parked 9.1 us; + lane-swap reductions
-// 9.1; 512 lanes x 2 groups, 4 parked 8.4; 6 parked, register sets named by unrolling x6 7.6 (the loop body outgrew the
-// instruction cache); a queue of register sets + out-of-line rare paths 7.3; lane facts as bits of one register + waiting waves at
-// low priority 7.2.  rocprofv3 --pmc faults on the cooperative launch
-// (ROCm 7.2), one more reason it is not the default: the round's counter evidence is collected on the two-pass path.
+// STATUS (round 2, MI355X, 1e6 atoms, 1024 frames per launch): 6.5 us per frame = 151 k frames/s with two groups per lane -- level
+// with the two-pass path (6.5-6.6 us of kernel time, 149-151 k frames/s in the same runs), not ahead of it, so the pass stays
+// OPT-IN (GR_TUNE_RESIDENT): it needs a cooperative launch, and rocprofv3 --pmc faults on cooperative launches (ROCm 7.2;
+// GR_TUNE_RESIDENT = 3 launches the same grid the ordinary way for counter collection).  What bounds it is not memory (a lane
+// waits 0.2-0.3 us per frame for its rows; 24 MB per frame cross HBM where the floor of that traffic is 4.2 us) and not the
+// finalizers (no closing algebra at all: same time; 8 or 11 of them: same time) but the instruction streams themselves: every CU
+// runs ALL of a frame's arithmetic for its 4096 atoms within one frame period -- 934 VALU + 215 scalar instructions per wave
+// and frame (sums + the per-frame wave reduction + fit + the queue of parked register sets), two waves per SIMD that overlap
+// poorly: the VALU is busy 45-50 % of the time; the last wave of every workgroup (second on its SIMD, and the one that adds up
+// the workgroup's record) never waits for a record and sets the pace, the others wait for it a third of their time.  The two-pass
+// kernels run 20 % fewer VALU instructions per frame in total and keep 12-16 waves per CU in flight.
+// History of the measurement (us per frame): 1024 lanes x 1 group, three frames parked, records collected through seven
+// dependent round trips 9.1; tagged records read in one round trip, lane-swap reductions 9.1 (by then the spread between the
+// four waves of a SIMD was the longer pole); 512 lanes x 2 groups, four parked 8.4; six parked, register sets named by unrolling
+// x6 7.6 (the loop body, with the rare paths inlined in every copy, was ~140 KB of code against a 64 KB instruction cache); a
+// queue of register sets + the rare paths out of line 7.3; lane facts as bits of one register, waiting waves at low priority
+// 7.2; wave records of 32 floats and the parking moved out of the reduction lambdas 6.6; reductions on DPP moves instead of
+// ds_bpermute 6.5.  Frames parked: 4 -> 7.0, 5 -> 6.6, 6 -> 6.5 (LDS holds no more).  One group per lane (1024 lanes, five frames
+// parked, 128 registers): 9.3 -- the register budget spills into scratch memory inside the loop.
 //
 // Synchronisation.  All waiting is on data that a DIFFERENT workgroup produces, so every workgroup must be resident: the
 // kernel is launched with hipLaunchCooperativeKernel (refused by the runtime unless the whole grid fits at once) and is only
@@ -55,32 +62,41 @@
 #pragma once
 #include "gr_hot.h"
 
-// Shape.  512 lanes x 2 groups: 8 waves per CU, two per SIMD.  (The first version had 1024 lanes x 1 group: four waves per SIMD
-// each paid the per-frame wave reduction, ~9600 wave-instructions per CU and frame, compute ~4.5 us -- as long as the memory
-// time -- and the waves of a SIMD delivered their sums up to a whole compute time apart; with three frames parked the
-// rotation of a frame then came back too late: 9.1 us per frame.  Two groups per lane halve the number of reductions, leave
-// room for a fourth parked frame (group B waits in registers) and bring the spread between waves down with the compute.)
-#define GR_RES_LANES 512
-#define GR_RES_WAVES (GR_RES_LANES / 64)
-#define GR_RES_GROUPS (2 * GR_RES_LANES)   // 4-atom groups per workgroup
-#define GR_RES_K 6                 // frames between the sums stage and the fit stage (= frames parked on chip; even)
-#define GR_RES_R 8                 // ring of wave-record slots ( > GR_RES_K: no wave is more than K frames ahead of another)
+// Shape: G = 4-atom groups per lane.  A workgroup always owns 1024 groups (4096 atoms), so it has 1024 / G lanes:
+//   G = 2   512 lanes, 8 waves (two per SIMD, up to 256 registers); group A of a frame waits in LDS, group B in a queue of
+//           register sets; 6 frames parked.  Halves the number of per-frame wave reductions.
+//   G = 1   1024 lanes, 16 waves (four per SIMD, 128 registers): more waves to cover one another's latencies; a frame waits
+//           first in a short queue of register sets, then in one of three LDS slots.
+// (The first version -- G = 1 with three LDS slots only, records collected through seven dependent round trips -- ran at 9.1 us.)
+template <int G> struct GrResShape {
+    static constexpr int LANES = 1024 / G, WAVES = LANES / 64;
+    static constexpr int KL = G == 2 ? 6 : 3;        // LDS slots (a slot = three rows of one group for every lane: 48 KiB / G ... x KL = 144 KiB)
+    static constexpr int KV = G == 2 ? 6 : 2;        // register sets in the queue (G = 2: group B for its whole wait; G = 1: the first KV frames of the wait)
+    static constexpr int K = G == 2 ? 6 : KL + KV;   // frames between the sums stage and the fit stage
+    static constexpr int R = G == 2 ? 8 : 6;         // ring of wave-record slots ( > K: no wave is more than K frames ahead of another)
+    static constexpr int PARK_F4 = KL * 3 * LANES;   // float4
+    static constexpr int WSUM_F = R * WAVES * 32;    // float: a wave record = 19 sums + 12 extents
+    static constexpr int LDS_BYTES = PARK_F4 * 16 + WSUM_F * 4 + R * WAVES * 8 + 2 * R * 4;
+    static constexpr int REC_PER_WAVE = 256 / WAVES, LANES_PER_REC = 64 / REC_PER_WAVE, WORDS_PER_LANE = 32 / LANES_PER_REC;   // finalizer
+};
+#ifndef GR_RES_SLEEP
+#define GR_RES_SLEEP 8              // s_sleep argument between two looks at a record that is not there yet (x 64 clocks)
+#endif
+#ifndef GR_RES_PRIO
+#define GR_RES_PRIO 1
+#endif
+#define GR_RES_GROUPS 1024         // 4-atom groups per workgroup
 #define GR_RES_MAX_FIN 8
 #define GR_RES_PATIENCE 3000000u   // polls (each ~1 us) before a wait gives up
 
 #define GR_RES_REC_WORDS 32         // tagged words per workgroup record: 0..18 sums, 19..30 extents (as maxima), 31 unused
-#define GR_RES_REC_PAD 32           // workgroup records per frame are padded to a multiple of this (one finalizer wave reads 32)
+#define GR_RES_REC_PAD 32           // workgroup records per frame are padded to a multiple of this
 struct GrResCtl {
     unsigned long long *wgrec;     // [frames][n_stream padded][32] value | epoch << 32
     unsigned long long *rec;       // [frames][16] value | epoch << 32: 0 status, 1..3 shift, 4..12 R (column-major)
     uint32_t *abort;               // one word, 0 = fine
     uint32_t epoch, n_stream, n_fin;
 };
-
-// LDS of a streaming workgroup (dynamic: more than the 64 KiB static limit)
-#define GR_RES_PARK_F4 (GR_RES_K * 3 * GR_RES_LANES)                        // float4: group A of the parked frames
-#define GR_RES_WSUM_F (GR_RES_R * GR_RES_WAVES * 48)                        // float
-#define GR_RES_LDS_BYTES (GR_RES_PARK_F4 * 16 + GR_RES_WSUM_F * 4 + GR_RES_R * GR_RES_WAVES * 8 + 2 * GR_RES_R * 4)
 
 template <typename T> __device__ __forceinline__ T gr_ld_agent(const T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ float gr_first_f(float v) { return __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(v))); }
@@ -138,7 +154,7 @@ __device__ __forceinline__ void gr_res_image_pair(gr_v2f &vx, gr_v2f &vy, gr_v2f
 // wrap(x + shift) - box centre, rotate, (sum w |R q - p|^2), + reference COM: the arithmetic of k_fit_pk for one group
 template <bool WMASS>
 __device__ __forceinline__ void gr_res_fit_group(const GrResGroup &G, const float4 &r0, const float4 &r1, const float4 &r2, const GrResRot &T, const GrBoxU &B,
-                                                 const GrBox *__restrict__ boxp, float cx, float cy, float cz, float4 *__restrict__ f4, double &rs) {
+                                                 const GrBox *__restrict__ boxp, float cx, float cy, float cz, float4 *__restrict__ f4, float &rs) {
     GrP4 q = gr_pairs_rows(r0, r1, r2);
     q.x01 += gr_v2(T.sx); q.y01 += gr_v2(T.sy); q.z01 += gr_v2(T.sz); q.x23 += gr_v2(T.sx); q.y23 += gr_v2(T.sy); q.z23 += gr_v2(T.sz);
     gr_wrap_pair_fast(q.x01, q.y01, q.z01, B);
@@ -165,7 +181,7 @@ __device__ __forceinline__ void gr_res_fit_group(const GrResGroup &G, const floa
         gr_v2f part = w01 * gr_v2_fma(dx, dx, gr_v2_fma(dy, dy, dz * dz));
         dx = n.x23 - G.P.x23; dy = n.y23 - G.P.y23; dz = n.z23 - G.P.z23;
         part = gr_v2_fma(w23, gr_v2_fma(dx, dx, gr_v2_fma(dy, dy, dz * dz)), part);
-        rs += (double)(part.x + part.y);
+        rs += part.x + part.y;
     }
     n.x01 += gr_v2(cx); n.y01 += gr_v2(cy); n.z01 += gr_v2(cz); n.x23 += gr_v2(cx); n.y23 += gr_v2(cy); n.z23 += gr_v2(cz);
     float4 o0, o1, o2;
@@ -174,19 +190,22 @@ __device__ __forceinline__ void gr_res_fit_group(const GrResGroup &G, const floa
 }
 
 // UBOX: every frame of the launch has the same box (the host compared them): its constants are loaded once, not per frame
-template <bool WMASS, bool UBOX>
-__global__ __launch_bounds__(GR_RES_LANES) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_fit_resident(   // 2 waves per SIMD: up to 256 registers per lane
+template <bool WMASS, bool UBOX, int G>
+__global__ __launch_bounds__(GrResShape<G>::LANES) void k_fit_resident(
     float *__restrict__ frames, size_t frame_stride, uint32_t first_slot, uint32_t nframes, uint32_t n_atoms,
     const float *__restrict__ masses, GrSel sel, const GrBox *__restrict__ boxes, GrPlanDev plan,
     GrFrameState *state, double *__restrict__ fit_partials, GrResCtl ctl) {
+    typedef GrResShape<G> S;
+    constexpr uint32_t LANES = S::LANES, WAVES = S::WAVES, K = S::K, KL = S::KL, KV = S::KV, R = S::R;
     extern __shared__ float4 smem[];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t n_pad = (ctl.n_stream + GR_RES_REC_PAD - 1u) & ~(uint32_t)(GR_RES_REC_PAD - 1u);
 
     // ------------------------------------------------------------------------------------------ finalizers
     if (blockIdx.x >= ctl.n_stream) {
-        double *wtot = reinterpret_cast<double *>(smem);              // [8 waves][32] + [32] totals
-        const uint32_t r = wave * 32u + (lane >> 1), half = lane & 1u;   // this lane's record and its 16 words
+        constexpr uint32_t RPW = S::REC_PER_WAVE, LPR = S::LANES_PER_REC, W = S::WORDS_PER_LANE;
+        double *wtot = reinterpret_cast<double *>(smem);              // [WAVES][32] + [32] totals
+        const uint32_t r = wave * RPW + lane / LPR, part = lane % LPR;   // this lane's record and its W words
         const unsigned long long tagv = (unsigned long long)ctl.epoch << 32;
         for (uint32_t f = blockIdx.x - ctl.n_stream; f < nframes; f += ctl.n_fin) {
             // what the closing step needs besides the sums: requested now, in flight while the records are awaited
@@ -197,56 +216,56 @@ __global__ __launch_bounds__(GR_RES_LANES) __attribute__((amdgpu_waves_per_eu(1,
             float g0x, g0y, g0z;
             gr_pos_load(frames + (size_t)(first_slot + f) * frame_stride, sel.start, g0x, g0y, g0z);
             const int pre_status = state[f].status;
-            const unsigned long long *src = ctl.wgrec + ((size_t)f * n_pad + r) * GR_RES_REC_WORDS + half * 16u;
-            unsigned long long w[16];
+            const unsigned long long *src = ctl.wgrec + ((size_t)f * n_pad + r) * GR_RES_REC_WORDS + part * W;
+            unsigned long long w[W];
             uint32_t polls = 0;
             for (;;) {
                 bool ok = true;
                 if (r < ctl.n_stream) {
 #pragma unroll
-                    for (int k = 0; k < 16; ++k) w[k] = gr_ld_agent(src + k);
+                    for (uint32_t k = 0; k < W; ++k) w[k] = gr_ld_agent(src + k);
 #pragma unroll
-                    for (int k = 0; k < 16; ++k) ok = ok && ((uint32_t)(w[k] >> 32) == ctl.epoch || (half == 1u && k == 15));
+                    for (uint32_t k = 0; k < W; ++k) ok = ok && ((uint32_t)(w[k] >> 32) == ctl.epoch || part * W + k == 31u);
                 }
                 if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
                 if (++polls > GR_RES_PATIENCE || ((polls & 255u) == 0 && gr_ld_agent(ctl.abort) != 0u)) { if (lane == 0) gr_st_agent(ctl.abort, 1u); polls = 0xFFFFFFFFu; break; }
                 __builtin_amdgcn_s_sleep(1);
             }
             // (a wave that gave up still meets the others at the barriers; the abort word ends the launch)
-            // sums in fp64, extents as maxima: word index = half * 16 + k; 0..18 sums, 19..30 maxima
-            double v[16];
+            // sums in fp64, extents as maxima: word index = part * W + k; 0..18 sums, 19..30 maxima
+            double v[W];
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const bool mxw = half == 1u && k >= 3;
+            for (uint32_t k = 0; k < W; ++k) {
+                const bool mxw = part * W + k >= 19u;
                 const float x = (r < ctl.n_stream && polls != 0xFFFFFFFFu) ? __uint_as_float((uint32_t)w[k]) : (mxw ? -3.0e38f : 0.0f);
                 v[k] = (double)x;
             }
 #pragma unroll
-            for (int off = 2; off < 64; off <<= 1) {
+            for (uint32_t off = LPR; off < 64u; off <<= 1) {
 #pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    const double o = __shfl_xor(v[k], off, 64);
-                    const bool mxw = half == 1u && k >= 3;
+                for (uint32_t k = 0; k < W; ++k) {
+                    const double o = __shfl_xor(v[k], (int)off, 64);
+                    const bool mxw = part * W + k >= 19u;
                     v[k] = mxw ? fmax(v[k], o) : v[k] + o;
                 }
             }
-            if (lane < 2u) {
+            if (lane < LPR) {
 #pragma unroll
-                for (int k = 0; k < 16; ++k) wtot[wave * 32u + lane * 16u + k] = v[k];
+                for (uint32_t k = 0; k < W; ++k) wtot[wave * 32u + lane * W + k] = v[k];
             }
             __syncthreads();
-            if (wave == 0 && lane < 31u) {   // totals over the 8 waves, in wave order: lane k owns word k
+            if (wave == 0 && lane < 31u) {   // totals over the waves, in wave order: lane k owns word k
                 double a = wtot[lane];
                 const bool mx = lane >= 19u;
 #pragma unroll
-                for (uint32_t wv = 1; wv < GR_RES_WAVES; ++wv) { const double o = wtot[wv * 32u + lane]; a = mx ? fmax(a, o) : a + o; }
-                wtot[GR_RES_WAVES * 32u + lane] = a;
+                for (uint32_t wv = 1; wv < WAVES; ++wv) { const double o = wtot[wv * 32u + lane]; a = mx ? fmax(a, o) : a + o; }
+                wtot[WAVES * 32u + lane] = a;
             }
             gr_wave_sync();
             if (wave == 0 && lane == 0) {
                 GrFrameState &st = state[f];
                 if (pre_status == 0 && polls != 0xFFFFFFFFu) {
-                    const double *t = wtot + GR_RES_WAVES * 32u;
+                    const double *t = wtot + WAVES * 32u;
                     double acc[GR_ACC_K];
 #pragma unroll
                     for (int k = 0; k < GR_ACC_K; ++k) acc[k] = 0.0;
@@ -275,68 +294,69 @@ __global__ __launch_bounds__(GR_RES_LANES) __attribute__((amdgpu_waves_per_eu(1,
     // ------------------------------------------------------------------------------------------ streaming workgroups
     const uint32_t ngroups = ((n_atoms + 255u) >> 8) << 6;            // the slot is padded to whole tiles (a multiple of 64 groups)
     const uint32_t wg = blockIdx.x, base = wg * GR_RES_GROUPS;
-    if (base + wave * 64u >= ngroups) return;                         // both chunks of this wave lie behind the last tile
-    const uint32_t n_waves = min((uint32_t)GR_RES_WAVES, (ngroups - base) >> 6);
+    if (base + wave * 64u >= ngroups) return;                         // every chunk of this wave lies behind the last tile
+    const uint32_t n_waves = min(WAVES, (ngroups - base) >> 6);
     float4 *park = smem;
-    float *wsum = reinterpret_cast<float *>(smem + GR_RES_PARK_F4);
-    double *fsum = reinterpret_cast<double *>(wsum + GR_RES_WSUM_F);
-    uint32_t *cnt_s = reinterpret_cast<uint32_t *>(fsum + GR_RES_R * GR_RES_WAVES), *cnt_f = cnt_s + GR_RES_R;
-    if (tid < 2 * GR_RES_R) cnt_s[tid] = 0u;
+    float *wsum = reinterpret_cast<float *>(smem + S::PARK_F4);
+    double *fsum = reinterpret_cast<double *>(wsum + S::WSUM_F);
+    uint32_t *cnt_s = reinterpret_cast<uint32_t *>(fsum + R * WAVES), *cnt_f = cnt_s + R;
+    if (tid < 2 * R) cnt_s[tid] = 0u;
     __syncthreads();                                                  // the only barrier: before the first frame
 
     const uint32_t first = sel.start, last = sel.start + sel.n, g0 = sel.g0 << 6;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    // the lane's two groups: A = chunk `wave` of the workgroup's first 512 groups, B = the same chunk of its second 512
-    auto setup = [&](uint32_t g, GrResGroup &G) {
+    // the lane's groups: A = chunk `wave` of the workgroup's first LANES groups, B (G = 2) = the same chunk of its second LANES
+    auto setup = [&](uint32_t g, GrResGroup &Gr) {
         const uint32_t i0 = g << 2;
-        G.valid = g < ngroups;                                        // wave-uniform
-        const bool in0 = G.valid && (i0 >= first) && (i0 < last), in1 = G.valid && (i0 + 1u >= first) && (i0 + 1u < last);
-        const bool in2 = G.valid && (i0 + 2u >= first) && (i0 + 2u < last), in3 = G.valid && (i0 + 3u >= first) && (i0 + 3u < last);
+        Gr.valid = g < ngroups;                                       // wave-uniform
+        const bool in0 = Gr.valid && (i0 >= first) && (i0 < last), in1 = Gr.valid && (i0 + 1u >= first) && (i0 + 1u < last);
+        const bool in2 = Gr.valid && (i0 + 2u >= first) && (i0 + 2u < last), in3 = Gr.valid && (i0 + 3u >= first) && (i0 + 3u < last);
         const bool in_sel = in0 || in1 || in2 || in3, full = in0 && in1 && in2 && in3;
-        G.flags = (in0 ? GR_RG_IN0 : 0u) | (in1 ? GR_RG_IN1 : 0u) | (in2 ? GR_RG_IN2 : 0u) | (in3 ? GR_RG_IN3 : 0u) | (in_sel ? GR_RG_ANY : 0u) | (full ? GR_RG_FULL : 0u);
-        G.b = gr_row_index(G.valid ? g : 0u, 0);
+        Gr.flags = (in0 ? GR_RG_IN0 : 0u) | (in1 ? GR_RG_IN1 : 0u) | (in2 ? GR_RG_IN2 : 0u) | (in3 ? GR_RG_IN3 : 0u) | (in_sel ? GR_RG_ANY : 0u) | (full ? GR_RG_FULL : 0u);
+        Gr.b = gr_row_index(Gr.valid ? g : 0u, 0);
         float4 pa = zero4, pb = zero4, pc = zero4;
-        G.mm = zero4; G.ww = zero4;
+        Gr.mm = zero4; Gr.ww = zero4;
         if (in_sel) {
             gr_rows_load(reinterpret_cast<const float4 *>(plan.p), (size_t)(g - g0), pa, pb, pc);
-            G.mm = reinterpret_cast<const float4 *>(masses)[g];
-            if (!WMASS) G.ww = reinterpret_cast<const float4 *>(plan.w)[g - g0];
+            Gr.mm = reinterpret_cast<const float4 *>(masses)[g];
+            if (!WMASS) Gr.ww = reinterpret_cast<const float4 *>(plan.w)[g - g0];
             if (!full) {   // ragged end of the selection: atoms outside it weigh nothing and have no reference
-                if (!in0) { G.mm.x = 0.f; G.ww.x = 0.f; pa.x = 0.f; pa.z = 0.f; pb.x = 0.f; }
-                if (!in1) { G.mm.y = 0.f; G.ww.y = 0.f; pa.y = 0.f; pa.w = 0.f; pb.y = 0.f; }
-                if (!in2) { G.mm.z = 0.f; G.ww.z = 0.f; pb.z = 0.f; pc.x = 0.f; pc.z = 0.f; }
-                if (!in3) { G.mm.w = 0.f; G.ww.w = 0.f; pb.w = 0.f; pc.y = 0.f; pc.w = 0.f; }
+                if (!in0) { Gr.mm.x = 0.f; Gr.ww.x = 0.f; pa.x = 0.f; pa.z = 0.f; pb.x = 0.f; }
+                if (!in1) { Gr.mm.y = 0.f; Gr.ww.y = 0.f; pa.y = 0.f; pa.w = 0.f; pb.y = 0.f; }
+                if (!in2) { Gr.mm.z = 0.f; Gr.ww.z = 0.f; pb.z = 0.f; pc.x = 0.f; pc.z = 0.f; }
+                if (!in3) { Gr.mm.w = 0.f; Gr.ww.w = 0.f; pb.w = 0.f; pc.y = 0.f; pc.w = 0.f; }
             }
         }
-        G.P = gr_pairs_rows(pa, pb, pc);
+        Gr.P = gr_pairs_rows(pa, pb, pc);
     };
     GrResGroup GA, GB;
     setup(base + tid, GA);
-    setup(base + GR_RES_LANES + tid, GB);
+    if (G == 2) setup(base + LANES + tid, GB); else { GB.valid = false; GB.flags = 0u; GB.b = 0; GB.mm = GB.ww = zero4; GB.P = gr_pairs_rows(zero4, zero4, zero4); }
     const float cx = plan.ref_com[0], cy = plan.ref_com[1], cz = plan.ref_com[2];
 
-    struct Landing { float4 a0, a1, a2, b0, b1, b2; float gx, gy, gz; };
+    struct Rows { float4 r0, r1, r2; };
+    struct Landing { Rows a, b; float gx, gy, gz; };
     auto request = [&](uint32_t f, Landing &L) {
         const float *xyz = frames + (size_t)(first_slot + f) * frame_stride;
         const float4 *f4 = reinterpret_cast<const float4 *>(xyz);
-        L.a0 = gr_stream_load(f4 + GA.b); L.a1 = gr_stream_load(f4 + GA.b + 64); L.a2 = gr_stream_load(f4 + GA.b + 128);
-        if (GB.valid) { L.b0 = gr_stream_load(f4 + GB.b); L.b1 = gr_stream_load(f4 + GB.b + 64); L.b2 = gr_stream_load(f4 + GB.b + 128); }
+        L.a.r0 = gr_stream_load(f4 + GA.b); L.a.r1 = gr_stream_load(f4 + GA.b + 64); L.a.r2 = gr_stream_load(f4 + GA.b + 128);
+        if (G == 2 && GB.valid) { L.b.r0 = gr_stream_load(f4 + GB.b); L.b.r1 = gr_stream_load(f4 + GB.b + 64); L.b.r2 = gr_stream_load(f4 + GB.b + 128); }
         gr_pos_load(xyz, first, L.gx, L.gy, L.gz);                    // provisional centre: the first atom of the selection
     };
     auto request_rec = [&](uint32_t f) -> unsigned long long { return lane < 13u ? gr_ld_agent(ctl.rec + (size_t)f * 16 + lane) : 0ull; };
     bool bail = false;
 
     // the sums of one group added to the lane's 19 + 12 values
-    auto group_sums = [&](const GrResGroup &G, const float4 &r0, const float4 &r1, const float4 &r2, const GrBoxU &B, const GrBox *boxp,
+    auto group_sums = [&](const GrResGroup &Gr, const Rows &rw, const GrBoxU &B, const GrBox *boxp,
                           float gx, float gy, float gz, float (&s32)[32], float (&e32)[32], bool init) {
-        GrP4 q = gr_pairs_rows(r0, r1, r2);
+        GrP4 q = gr_pairs_rows(rw.r0, rw.r1, rw.r2);
         // atoms outside the selection become copies of the first atom: v = 0 adds nothing and lies inside every extent (a whole
         // wave of complete groups -- every wave but the two at the ends of the selection -- skips this on one scalar branch)
-        if (__builtin_amdgcn_ballot_w64((G.flags & GR_RG_FULL) == 0u) != 0ull) {
-            if (!(G.flags & GR_RG_IN0)) { q.x01.x = gx; q.y01.x = gy; q.z01.x = gz; }
-            if (!(G.flags & GR_RG_IN1)) { q.x01.y = gx; q.y01.y = gy; q.z01.y = gz; }
-            if (!(G.flags & GR_RG_IN2)) { q.x23.x = gx; q.y23.x = gy; q.z23.x = gz; }
-            if (!(G.flags & GR_RG_IN3)) { q.x23.y = gx; q.y23.y = gy; q.z23.y = gz; }
+        if (__builtin_amdgcn_ballot_w64((Gr.flags & GR_RG_FULL) == 0u) != 0ull) {
+            if (!(Gr.flags & GR_RG_IN0)) { q.x01.x = gx; q.y01.x = gy; q.z01.x = gz; }
+            if (!(Gr.flags & GR_RG_IN1)) { q.x01.y = gx; q.y01.y = gy; q.z01.y = gz; }
+            if (!(Gr.flags & GR_RG_IN2)) { q.x23.x = gx; q.y23.x = gy; q.z23.x = gz; }
+            if (!(Gr.flags & GR_RG_IN3)) { q.x23.y = gx; q.y23.y = gy; q.z23.y = gz; }
         }
         gr_v2f vxa = q.x01 - gr_v2(gx), vya = q.y01 - gr_v2(gy), vza = q.z01 - gr_v2(gz);
         gr_v2f vxb = q.x23 - gr_v2(gx), vyb = q.y23 - gr_v2(gy), vzb = q.z23 - gr_v2(gz);
@@ -345,12 +365,12 @@ __global__ __launch_bounds__(GR_RES_LANES) __attribute__((amdgpu_waves_per_eu(1,
         auto fold = [](gr_v2f v) { return v.x + v.y; };
         auto acc = [&](int k, float x) { s32[k] = init ? x : s32[k] + x; };
         auto ext = [&](int k, float x) { e32[k] = init ? x : gr_fmaxf(e32[k], x); };
-        const gr_v2f ma = gr_v2p(G.mm.x, G.mm.y), mb = gr_v2p(G.mm.z, G.mm.w);
+        const gr_v2f ma = gr_v2p(Gr.mm.x, Gr.mm.y), mb = gr_v2p(Gr.mm.z, Gr.mm.w);
         acc(0, fold(ma + mb));
         acc(1, fold(gr_v2_fma(ma, vxa, mb * vxb))); acc(2, fold(gr_v2_fma(ma, vya, mb * vyb))); acc(3, fold(gr_v2_fma(ma, vza, mb * vzb)));
-        acc(4, fold(gr_v2_fma(G.P.x01, vxa, G.P.x23 * vxb))); acc(5, fold(gr_v2_fma(G.P.x01, vya, G.P.x23 * vyb))); acc(6, fold(gr_v2_fma(G.P.x01, vza, G.P.x23 * vzb)));
-        acc(7, fold(gr_v2_fma(G.P.y01, vxa, G.P.y23 * vxb))); acc(8, fold(gr_v2_fma(G.P.y01, vya, G.P.y23 * vyb))); acc(9, fold(gr_v2_fma(G.P.y01, vza, G.P.y23 * vzb)));
-        acc(10, fold(gr_v2_fma(G.P.z01, vxa, G.P.z23 * vxb))); acc(11, fold(gr_v2_fma(G.P.z01, vya, G.P.z23 * vyb))); acc(12, fold(gr_v2_fma(G.P.z01, vza, G.P.z23 * vzb)));
+        acc(4, fold(gr_v2_fma(Gr.P.x01, vxa, Gr.P.x23 * vxb))); acc(5, fold(gr_v2_fma(Gr.P.x01, vya, Gr.P.x23 * vyb))); acc(6, fold(gr_v2_fma(Gr.P.x01, vza, Gr.P.x23 * vzb)));
+        acc(7, fold(gr_v2_fma(Gr.P.y01, vxa, Gr.P.y23 * vxb))); acc(8, fold(gr_v2_fma(Gr.P.y01, vya, Gr.P.y23 * vyb))); acc(9, fold(gr_v2_fma(Gr.P.y01, vza, Gr.P.y23 * vzb)));
+        acc(10, fold(gr_v2_fma(Gr.P.z01, vxa, Gr.P.z23 * vxb))); acc(11, fold(gr_v2_fma(Gr.P.z01, vya, Gr.P.z23 * vyb))); acc(12, fold(gr_v2_fma(Gr.P.z01, vza, Gr.P.z23 * vzb)));
         ext(0, -gr_fminf(gr_min3f(vxa.x, vxa.y, vxb.x), vxb.y)); ext(1, -gr_fminf(gr_min3f(vya.x, vya.y, vyb.x), vyb.y)); ext(2, -gr_fminf(gr_min3f(vza.x, vza.y, vzb.x), vzb.y));
         ext(3, gr_fmaxf(gr_max3f(vxa.x, vxa.y, vxb.x), vxb.y)); ext(4, gr_fmaxf(gr_max3f(vya.x, vya.y, vyb.x), vyb.y)); ext(5, gr_fmaxf(gr_max3f(vza.x, vza.y, vzb.x), vzb.y));
         // fractional coordinates of v: moments + extents feed the image proof (gr_finalize_math)
@@ -363,53 +383,56 @@ __global__ __launch_bounds__(GR_RES_LANES) __attribute__((amdgpu_waves_per_eu(1,
         ext(9, gr_fmaxf(gr_max3f(faa.x, faa.y, fab.x), fab.y)); ext(10, gr_fmaxf(gr_max3f(fba.x, fba.y, fbb.x), fbb.y)); ext(11, gr_fmaxf(gr_max3f(fca.x, fca.y, fcb.x), fcb.y));
     };
 
-    // ---- the sums stage of frame i (rows in L); group A goes to the LDS slot `ps`, group B into the register set `keep`
-    auto sums = [&](uint32_t i, uint32_t ps, const Landing &L, float4 (&keep)[3], const GrBoxU &B) {
-        const GrBox *boxp = boxes + first_slot + i;
-        const float gx = gr_first_f(L.gx), gy = gr_first_f(L.gy), gz = gr_first_f(L.gz);    // wave-uniform: SGPR operands
-        park[(ps * 3 + 0) * GR_RES_LANES + tid] = L.a0; park[(ps * 3 + 1) * GR_RES_LANES + tid] = L.a1; park[(ps * 3 + 2) * GR_RES_LANES + tid] = L.a2;
-        keep[0] = L.b0; keep[1] = L.b1; keep[2] = L.b2;
+    // ---- the sums stage of frame i (rows in L): the lane's 19 + 12 values -> wave (reduce-scatter) -> workgroup (LDS, the last
+    // wave to arrive adds the wave records in wave order) -> the frame's tagged record
+    auto sums = [&](uint32_t i, const Landing &L, const GrBoxU &B) {
         float s32[32], e32[32];
 #pragma unroll
         for (int k = 0; k < 32; ++k) { s32[k] = 0.0f; e32[k] = -3.0e38f; }
-        group_sums(GA, L.a0, L.a1, L.a2, B, boxp, gx, gy, gz, s32, e32, true);
-        if (GB.valid) group_sums(GB, L.b0, L.b1, L.b2, B, boxp, gx, gy, gz, s32, e32, false);
+        {
+            const GrBox *boxp = boxes + first_slot + i;
+            const float gx = gr_first_f(L.gx), gy = gr_first_f(L.gy), gz = gr_first_f(L.gz);    // wave-uniform: SGPR operands
+            group_sums(GA, L.a, B, boxp, gx, gy, gz, s32, e32, true);
+            if (G == 2 && GB.valid) group_sums(GB, L.b, B, boxp, gx, gy, gz, s32, e32, false);
+        }
         const float tot = gr_wave_sum_scatter32(s32, lane);
         const float emax = gr_wave_max_scatter16(e32, lane);
-        const uint32_t rs = i % GR_RES_R;
-        float *mine = wsum + (rs * GR_RES_WAVES + wave) * 48;
-        if ((lane & 1u) == 0) mine[lane >> 1] = tot;
-        if ((lane & 3u) == 0) mine[32 + (lane >> 2)] = emax;
+        const uint32_t rs = i % R;
+        float *mine = wsum + (rs * WAVES + wave) * 32;
+        if ((lane & 1u) == 0 && lane < 38u) mine[lane >> 1] = tot;                 // sums 0..18
+        if ((lane & 3u) == 0 && lane < 48u) mine[19 + (lane >> 2)] = emax;         // extents 0..11
         gr_wave_sync();
         uint32_t old = 0;
         if (lane == 0) old = __hip_atomic_fetch_add(cnt_s + rs, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if ((uint32_t)__builtin_amdgcn_readfirstlane((int)old) != n_waves - 1u) return;
         // this wave completed the workgroup's record of frame i: add the wave records in wave order, publish 31 tagged words
         gr_wave_sync();
-        const float *all = wsum + rs * GR_RES_WAVES * 48;
+        const float *all = wsum + rs * WAVES * 32;
         if (lane < 31u) {
-            const uint32_t src = lane < 19u ? lane : 32u + (lane - 19u);
-            float v = all[src];
-            if (lane < 19u) { for (uint32_t w = 1; w < n_waves; ++w) v += all[w * 48 + src]; }
-            else { for (uint32_t w = 1; w < n_waves; ++w) v = gr_fmaxf(v, all[w * 48 + src]); }
+            float v = all[lane];
+            if (lane < 19u) { for (uint32_t w = 1; w < n_waves; ++w) v += all[w * 32 + lane]; }
+            else { for (uint32_t w = 1; w < n_waves; ++w) v = gr_fmaxf(v, all[w * 32 + lane]); }
             gr_st_agent(ctl.wgrec + ((size_t)i * n_pad + wg) * GR_RES_REC_WORDS + lane, ((unsigned long long)ctl.epoch << 32) | __float_as_uint(v));
         }
         if (lane == 0) __hip_atomic_store(cnt_s + rs, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
 
-    // ---- the fit stage of frame j: `rv` = the frame's record as requested earlier (lanes 0..12); group A from the LDS slot
-    // `ps` (the slot the sums stage of frame j + K is about to reuse), group B from the register set `keep`
-    auto fit = [&](uint32_t j, uint32_t ps, unsigned long long rv, const float4 (&keep)[3], const GrBoxU &B) {
+    // ---- the fit stage of frame j: `rv` = the frame's record as requested earlier (lanes 0..12); rows as they were parked.
+    auto fit = [&](uint32_t j, unsigned long long rv, const Rows &ra, const Rows &rb, const GrBoxU &B) {
         uint32_t polls = 0;
         while (__builtin_amdgcn_ballot_w64(lane < 13u && (uint32_t)(rv >> 32) != ctl.epoch) != 0ull) {
-            __builtin_amdgcn_s_setprio(0);                             // a wave that is ahead waits below the wave it shares the SIMD with
+#if GR_RES_PRIO
+            __builtin_amdgcn_s_setprio(0);                             // a wave that is ahead waits below the waves it shares the SIMD with
+#endif
             if (++polls > GR_RES_PATIENCE || ((polls & 255u) == 0 && gr_ld_agent(ctl.abort) != 0u)) { if (lane == 0) gr_st_agent(ctl.abort, 1u); bail = true; return; }
-            __builtin_amdgcn_s_sleep(8);
+            __builtin_amdgcn_s_sleep(GR_RES_SLEEP);
             rv = request_rec(j);
         }
+#if GR_RES_PRIO
         __builtin_amdgcn_s_setprio(2);
+#endif
         const int status = __builtin_amdgcn_readlane((int)(uint32_t)rv, 0);
-        double rs = 0.0;
+        float rs = 0.0f;
         if (status == 0) {
             GrResRot T;
             T.sx = gr_lane_f(rv, 1); T.sy = gr_lane_f(rv, 2); T.sz = gr_lane_f(rv, 3);
@@ -417,14 +440,14 @@ __global__ __launch_bounds__(GR_RES_LANES) __attribute__((amdgpu_waves_per_eu(1,
             T.r02 = gr_lane_f(rv, 10); T.r12 = gr_lane_f(rv, 11); T.r22 = gr_lane_f(rv, 12);
             const GrBox *boxp = boxes + first_slot + j;
             float4 *f4 = reinterpret_cast<float4 *>(frames + (size_t)(first_slot + j) * frame_stride);
-            const float4 r0 = park[(ps * 3 + 0) * GR_RES_LANES + tid], r1 = park[(ps * 3 + 1) * GR_RES_LANES + tid], r2 = park[(ps * 3 + 2) * GR_RES_LANES + tid];
-            gr_res_fit_group<WMASS>(GA, r0, r1, r2, T, B, boxp, cx, cy, cz, f4, rs);
-            if (GB.valid) gr_res_fit_group<WMASS>(GB, keep[0], keep[1], keep[2], T, B, boxp, cx, cy, cz, f4, rs);
+            gr_res_fit_group<WMASS>(GA, ra.r0, ra.r1, ra.r2, T, B, boxp, cx, cy, cz, f4, rs);
+            if (G == 2 && GB.valid) gr_res_fit_group<WMASS>(GB, rb.r0, rb.r1, rb.r2, T, B, boxp, cx, cy, cz, f4, rs);
         }
-        // the workgroup's share of sum w |R q - p|^2: wave sums in wave order by the last wave to arrive
-        rs = gr_wave_sum(rs);
-        const uint32_t fs = j % GR_RES_R;
-        if (lane == 0) fsum[fs * GR_RES_WAVES + wave] = rs;
+        // the workgroup's share of sum w |R q - p|^2: the lane's eight atoms in f32, the wave in f32 (no LDS crossbar), waves in fp64
+        // in wave order by the last wave to arrive
+        const float wtot = gr_wave_allsum_f32(rs);
+        const uint32_t fs = j % R;
+        if (lane == 0) fsum[fs * WAVES + wave] = (double)wtot;
         gr_wave_sync();
         uint32_t old = 0;
         if (lane == 0) old = __hip_atomic_fetch_add(cnt_f + fs, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -432,37 +455,50 @@ __global__ __launch_bounds__(GR_RES_LANES) __attribute__((amdgpu_waves_per_eu(1,
         gr_wave_sync();
         if (lane == 0) {
             double t = 0.0;
-            for (uint32_t w = 0; w < n_waves; ++w) t += fsum[fs * GR_RES_WAVES + w];
+            for (uint32_t w = 0; w < n_waves; ++w) t += fsum[fs * WAVES + w];
             fit_partials[(size_t)j * ctl.n_stream + wg] = t;
             __hip_atomic_store(cnt_f + fs, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     };
 
-    // ---- the walk: iteration i = fit of frame i - K, then sums of frame i.  The register sets that hold group B of the parked
-    // frames form a queue (ring[0] = the oldest = the frame about to be fitted) that moves up by one set per iteration -- 15
-    // register moves; naming the sets by i % K instead means unrolling the loop K times, and six copies of this body (with the
-    // wrap / image fall-backs inlined in each) are far larger than the 64 KiB instruction cache: measured 7.6 us per frame.
+    // ---- the walk: iteration i = fit of frame i - K, then sums of frame i.  Where a frame waits:
+    //   G = 2   group A in LDS slot i % K for the whole wait, group B in the queue of register sets (Q[0] = the oldest);
+    //   G = 1   the first KV iterations in the queue, then KL iterations in LDS slot (i - KV) % KL  (K = KV + KL).
+    // The queue moves up by one set per iteration (register moves); naming the sets by i % K instead means unrolling the loop K
+    // times, and six copies of this body were far larger than the 64 KiB instruction cache.
     Landing L0, L1;
-    L0.a0 = L0.a1 = L0.a2 = L0.b0 = L0.b1 = L0.b2 = zero4; L0.gx = L0.gy = L0.gz = 0.f;
+    L0.a.r0 = L0.a.r1 = L0.a.r2 = L0.b.r0 = L0.b.r1 = L0.b.r2 = zero4; L0.gx = L0.gy = L0.gz = 0.f;
     L1 = L0;
-    float4 ring[GR_RES_K][3];
+    Rows Q[KV];
 #pragma unroll
-    for (int u = 0; u < GR_RES_K; ++u) ring[u][0] = ring[u][1] = ring[u][2] = zero4;
+    for (uint32_t u = 0; u < KV; ++u) Q[u].r0 = Q[u].r1 = Q[u].r2 = zero4;
     unsigned long long rv = 0ull;
     request(0, L0);
-    const uint32_t n_iter = nframes + GR_RES_K;
+    const uint32_t n_iter = nframes + K;
     const GrBoxU B0 = gr_box_uniform(boxes + first_slot);
+    auto lds_put = [&](uint32_t slot, const Rows &rw) { park[(slot * 3 + 0) * LANES + tid] = rw.r0; park[(slot * 3 + 1) * LANES + tid] = rw.r1; park[(slot * 3 + 2) * LANES + tid] = rw.r2; };
+    auto lds_get = [&](uint32_t slot) { Rows rw; rw.r0 = park[(slot * 3 + 0) * LANES + tid]; rw.r1 = park[(slot * 3 + 1) * LANES + tid]; rw.r2 = park[(slot * 3 + 2) * LANES + tid]; return rw; };
     auto step = [&](uint32_t i, Landing &cur, Landing &nxt) {
         if (i + 1 < nframes) request(i + 1, nxt);
         // both boxes of the iteration are requested here (scalar loads): they arrive while the record is checked
-        const GrBoxU Bf = UBOX ? B0 : gr_box_uniform(boxes + first_slot + (i >= GR_RES_K ? i - GR_RES_K : 0u));
+        const GrBoxU Bf = UBOX ? B0 : gr_box_uniform(boxes + first_slot + (i >= K ? i - K : 0u));
         const GrBoxU Bs = UBOX ? B0 : gr_box_uniform(boxes + first_slot + (i < nframes ? i : 0u));
-        const uint32_t ps = i % GR_RES_K;                     // LDS slot: frame i - K leaves it, frame i takes it
-        if (i >= GR_RES_K) { fit(i - GR_RES_K, ps, rv, ring[0], Bf); if (bail) return; }
-        if (i + 1 >= GR_RES_K && i + 1 < n_iter) rv = request_rec(i + 1 - GR_RES_K);
+        if (G == 2) {
+            const uint32_t ps = i % K;                         // LDS slot: frame i - K leaves it, frame i takes it
+            if (i >= K) { fit(i - K, rv, lds_get(ps), Q[0], Bf); if (bail) return; }
+            if (i + 1 >= K && i + 1 < n_iter) rv = request_rec(i + 1 - K);
 #pragma unroll
-        for (int u = 0; u + 1 < GR_RES_K; ++u) { ring[u][0] = ring[u + 1][0]; ring[u][1] = ring[u + 1][1]; ring[u][2] = ring[u + 1][2]; }
-        if (i < nframes) sums(i, ps, cur, ring[GR_RES_K - 1], Bs);
+            for (uint32_t u = 0; u + 1 < KV; ++u) Q[u] = Q[u + 1];
+            if (i < nframes) { lds_put(ps, cur.a); Q[KV - 1] = cur.b; sums(i, cur, Bs); }
+        } else {
+            const uint32_t pl = (i + KL - (K % KL)) % KL;       // LDS slot of frame i - K = the slot frame i - KV is about to take
+            if (i >= K) { fit(i - K, rv, lds_get(pl), cur.b, Bf); if (bail) return; }
+            if (i + 1 >= K && i + 1 < n_iter) rv = request_rec(i + 1 - K);
+            if (i >= KV && i - KV < nframes) lds_put(pl, Q[0]); // frame i - KV moves from the queue into LDS
+#pragma unroll
+            for (uint32_t u = 0; u + 1 < KV; ++u) Q[u] = Q[u + 1];
+            if (i < nframes) { Q[KV - 1] = cur.a; sums(i, cur, Bs); }
+        }
     };
     for (uint32_t i = 0; i < n_iter; i += 2) {
         step(i, L0, L1);

@@ -33,7 +33,8 @@ def _systems(G, n, nf, box, sel):
 
 @pytest.mark.parametrize("n,sel", [(70_001, (0, 70_000)), (70_001, (1003, 69_990)), (5_000, (17, 4_000)), (300, (0, 299))])
 @pytest.mark.parametrize("tric", [False, True])
-def test_resident_matches_oracle_and_two_pass(G, n, sel, tric):
+@pytest.mark.parametrize("groups", [2, 1])
+def test_resident_matches_oracle_and_two_pass(G, n, sel, tric, groups):
     nf = 11                                             # odd, longer than the pipeline (3 frames between sums and fit)
     box = W.box_from_lengths_angles([7.0, 6.5, 6.0], [75.0, 80.0, 70.0]) if tric else W.box_from_lengths_angles([7.0, 6.5, 6.0], [90.0, 90.0, 90.0])
     masses, cur, ref, ref_pos, frames = _systems(G, n, nf, box, sel)
@@ -43,7 +44,7 @@ def test_resident_matches_oracle_and_two_pass(G, n, sel, tric):
     plan = G.RMSDPlan(ref, cur, "S")
     got = {}
     for mode in (0, 2):
-        cur.set_tuning(resident=mode)
+        cur.set_tuning(resident=mode, resident_groups=groups)
         cur.profile_enable(True)
         for f in range(nf):
             cur.set_frame(frames[f], box, slot=f)
@@ -68,17 +69,18 @@ def test_resident_matches_oracle_and_two_pass(G, n, sel, tric):
     plan.close(); ref.close(); cur.close()
 
 
-def test_resident_short_batches_and_failed_frames(G):
+@pytest.mark.parametrize("groups", [2, 1])
+def test_resident_short_batches_and_failed_frames(G, groups):
     """1, 2, 3 and 4 frames (shorter than, equal to and just longer than the pipeline); a frame without a box and a frame with a
     missing position fail exactly as on the two-pass path and are left unmodified, the frames around them are fitted."""
-    n, nf = 20_000, 6
+    n, nf = 20_000, 8
     box = W.box_from_lengths_angles([6.0, 6.0, 6.0], [90.0, 90.0, 90.0])
     masses, cur, ref, ref_pos, frames = _systems(G, n, nf, box, (0, n - 1))
     plan = G.RMSDPlan(ref, cur, "S")
     res = {}
     for mode in (0, 2):
-        cur.set_tuning(resident=mode)
-        for nb in (1, 2, 3, 4):
+        cur.set_tuning(resident=mode, resident_groups=groups)
+        for nb in (1, 2, 3, 4, 7):
             for f in range(nb):
                 cur.set_frame(frames[f], box, slot=f)
             r, st = plan.rmsd_fit(0, nb)
@@ -92,7 +94,7 @@ def test_resident_short_batches_and_failed_frames(G):
         after = [cur.get_positions(f) for f in range(nf)]
         assert np.array_equal(np.nan_to_num(after[2], nan=-1.0), np.nan_to_num(bad, nan=-1.0)), mode        # the failed frame is untouched
         res[(mode, "bad")] = (np.array(r), np.array(st), after)
-    for nb in (1, 2, 3, 4):
+    for nb in (1, 2, 3, 4, 7):
         assert np.abs(res[(0, nb)][0] - res[(2, nb)][0]).max() <= 2e-6
         for f in range(nb):
             assert np.abs(res[(0, nb)][1][f] - res[(2, nb)][1][f]).max() <= 2e-5
@@ -104,7 +106,8 @@ def test_resident_short_batches_and_failed_frames(G):
     plan.close(); ref.close(); cur.close()
 
 
-def test_resident_with_a_different_box_in_every_frame(G):
+@pytest.mark.parametrize("groups", [2, 1])
+def test_resident_with_a_different_box_in_every_frame(G, groups):
     """constant-pressure runs: every frame has its own box -> the kernel variant that reads the box per frame"""
     n, nf = 30_000, 9
     masses = W.masses_cycle(n)
@@ -121,7 +124,7 @@ def test_resident_with_a_different_box_in_every_frame(G):
     with O.acc64():
         want = [O.calc_rmsd_and_fit(ref_pos, masses, idx, boxes[0], frames[f], masses, idx, boxes[f]) for f in range(nf)]
     plan = G.RMSDPlan(ref, cur, "S")
-    cur.set_tuning(resident=2)
+    cur.set_tuning(resident=2, resident_groups=groups)
     cur.profile_enable(True)
     for f in range(nf):
         cur.set_frame(frames[f], boxes[f], slot=f)
