@@ -195,13 +195,14 @@ def main():
 
     # ---- roofline of the dominant kernel (HIP events on the library's stream, timed region)
     # algorithmic bytes per frame: sums pass 28 B/atom (cur 12 + ref 12 + mass 4), fit pass 24 B/atom (12 r + 12 w)
-    # the resident single pass (gr_resident.h): every frame read once and written once, 24 B/atom; the reference coordinates and
-    # the masses are read ONCE PER LAUNCH into registers (16 B/atom per launch, added below), not once per frame
-    alg_bytes = {"k_sums_pk": 28.0 * n, "k_rmsd_finalize": 0.0, "k_fit_pk": 24.0 * n, "k_fit_resident": 24.0 * n}
+    # the resident single pass (gr_resident.h) is the WHOLE RMSD-fit of a frame in one kernel: its algorithmic bytes are SURVEY 8d's
+    # 40 B/atom/frame (cur 12 + ref 12 + mass 4 + 12 written).  What it actually moves is less -- every frame read once and written
+    # once, 24 B/atom, + reference and masses once per launch -- and is reported as `traffic` (PMC) and `hbm_compulsory_bytes_per_launch`.
+    alg_bytes = {"k_sums_pk": 28.0 * n, "k_rmsd_finalize": 0.0, "k_fit_pk": 24.0 * n, "k_fit_resident": 40.0 * n}
     dom = max(("k_sums_pk", "k_fit_pk", "k_fit_resident"), key=lambda k: prof[k][0] if k in prof else -1.0)
     ms_total, launches, frames = prof[dom]
     avg_ms = ms_total / max(launches, 1)
-    bytes_per_launch = alg_bytes[dom] * (frames / max(launches, 1)) + (16.0 * n if dom == "k_fit_resident" else 0.0)
+    bytes_per_launch = alg_bytes[dom] * (frames / max(launches, 1))
     achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (separate --pmc runs,
     # FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; profiles/*_pmc_summary.json) -- only when the launch shape matches
@@ -222,14 +223,12 @@ def main():
                 "avg_launch_ms": round(avg_ms, 4), "launches": launches, "frames_per_launch": frames / max(launches, 1),
                 "algorithmic_bytes_per_launch": bytes_per_launch}
     kernels = {k: {"ms_total": round(v[0], 3), "launches": v[1], "us_per_frame": round(1e3 * v[0] / max(v[2], 1), 3)} for k, v in prof.items()}
-    # whole step.  Two-pass path: 40 B/atom/frame algorithmic (cur 12 + ref 12 + mass 4 + 12 written).  Resident path:
-    # the bytes that must cross HBM are 24 B/atom/frame + 16 B/atom per launch; the SURVEY figure (every array once PER FRAME)
-    # is reported beside it as `survey_40B_GBs` -- it may exceed the HBM peak, because ref + mass no longer move per frame.
+    # whole step: 40 B/atom/frame algorithmic whichever pass runs
     resident = prof.get("k_fit_resident", (0.0, 0, 0))[1] > 0
-    path_bytes_frame = 24.0 * n if resident else 40.0 * n
-    path_bytes = path_bytes_frame * (K * B) + (16.0 * n * prof["k_fit_resident"][1] if resident else 0.0)
-    path_gbs = path_bytes / (gpu_ms * 1e-3) / 1e9
-    survey_gbs = 40.0 * n * (K * B) / (gpu_ms * 1e-3) / 1e9
+    path_gbs = 40.0 * n * (K * B) / (gpu_ms * 1e-3) / 1e9
+    if resident:
+        roofline["hbm_compulsory_bytes_per_launch"] = 24.0 * n * (frames / max(launches, 1)) + 16.0 * n
+        roofline["hbm_compulsory_GBs"] = round(roofline["hbm_compulsory_bytes_per_launch"] / (avg_ms * 1e-3) / 1e9, 1)
 
     out = {
         "metric": "frames/sec RMSD-fit, 1e6 atoms triclinic, 1/2/4/8 GPUs; HBM GB/s vs peak",
@@ -245,8 +244,7 @@ def main():
         "roofline": roofline,
         "kernels": kernels,
         "path": {"algorithmic_GBs": round(path_gbs, 1), "frac_of_peak": round(path_gbs / HBM_PEAK_GBS, 4), "gpu_ms_timed_region": round(gpu_ms, 3),
-                 "bytes_per_frame": path_bytes_frame, "pass": "resident (one pass over HBM)" if resident else "two-pass (sums, fit)",
-                 "survey_40B_GBs": round(survey_gbs, 1)},
+                 "bytes_per_frame": 40.0 * n, "pass": "resident (one pass over HBM: 24 B/atom/frame actually move)" if resident else "two-pass (sums, fit)"},
     }
 
     # ---- CPU baseline: the oracle's restatement of the reference path on a bounded sample of the SAME frames (rank 0, N=1 only),

@@ -82,9 +82,9 @@ struct gr_ctx {
     double *fit_partials = nullptr;   // [frames of a segment][fit workgroups per frame]: sum w |R q - p|^2 of k_fit<true>
     size_t fit_partials_cap = 0;
     int two_pass = 1;                 // GR_TUNE_TWO_PASS 0: RMSD-fit keeps the closed-form single-pass rmsd (k_rmsd_accum<0>)
-    // resident RMSD fit (gr_resident.h): one cooperative launch per segment, the frame waits on chip for its rotation
-    int resident = 0;                 // GR_TUNE_RESIDENT 0 never, 1 when the frame fills most of the chip, 2 whenever it fits (tests)
-    uint32_t res_max_wgs = 0;         // workgroups of k_fit_resident the device holds at once (0: no cooperative launch)
+    // resident RMSD fit (gr_resident.h): one launch per segment, the frame waits on chip for its rotation
+    int resident = 1;                 // GR_TUNE_RESIDENT 0 never, 1 when the frame fills the chip, 2 whenever it fits (tests)
+    uint32_t res_max_wgs = 0;         // workgroups of k_fit_resident the device holds at once (0: the pass cannot run here)
     int resident_groups = 2;          // GR_TUNE_RESIDENT_GROUPS: 4-atom groups per lane of the resident pass (1: 1024 lanes, 2: 512 lanes)
     unsigned long long *res_wgrec = nullptr; size_t res_wgrec_cap = 0;   // [frames][streaming workgroups, padded to 16][32] tagged words
     unsigned long long *res_rec = nullptr;   // [GR_MAX_BATCH][16]
@@ -241,11 +241,17 @@ uint32_t resident_wgs(const gr_ctx *c, bool lite) {
     const uint64_t groups = ((c->n + 255) >> 8) << 6;
     const uint64_t wgs = (groups + GR_RES_GROUPS - 1) / GR_RES_GROUPS;   // (a workgroup owns 1024 groups whatever the groups per lane)
     if (wgs + 2 > c->res_max_wgs || wgs > GR_MAX_CHUNKS) return 0;
-    if (c->resident == 1 && wgs * 4 < (uint64_t)c->res_max_wgs * 3) return 0;
+    // the pass costs the same per frame whatever the frame's size (every CU runs its 4096 atoms' worth or idles): it only
+    // beats the two passes, whose time shrinks with the frame, when the frame fills at least 15/16 of the chip
+    if (c->resident == 1 && wgs * 16 < (uint64_t)c->res_max_wgs * 15) return 0;
     return (uint32_t)wgs;
 }
 
-static hipError_t hipModuleLaunchKernelCompat(const void *fn, dim3 grid, dim3 block, void **args, size_t lds, hipStream_t s) { return hipLaunchKernel(fn, grid, block, args, lds, s); }
+// One resident launch at a time per device and process: its workgroups wait for one another, so two of them sharing the CUs could
+// each hold half the chip and starve.  A context that finds the device taken lets the two-pass path handle its segment.
+static std::atomic<int> g_resident_in_flight[64];
+static bool resident_acquire(int device) { int z = 0; return device >= 0 && device < 64 && g_resident_in_flight[device].compare_exchange_strong(z, 1); }
+static void resident_release(int device) { if (device >= 0 && device < 64) g_resident_in_flight[device].store(0); }
 
 // a batch begun with gr_rmsd_batch_begin is still in flight on this context: only uploads may run beside it
 int busy_check(gr_ctx *c) {
@@ -553,10 +559,9 @@ gr_ctx *gr_ctx_create(int device, uint64_t n_atoms, uint32_t n_slots, int *statu
     ok = ok && hipMemset(c->res_abort, 0, sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipMalloc(&c->res_rec, (size_t)GR_MAX_BATCH * 16 * sizeof(unsigned long long)) == hipSuccess;
     ok = ok && hipMemset(c->res_rec, 0, (size_t)GR_MAX_BATCH * 16 * sizeof(unsigned long long)) == hipSuccess;
-    if (ok) {   // can the resident pass run here?  (cooperative launches, 160 KiB of LDS per workgroup, one workgroup per CU)
-        int coop = 0, per_cu = 0;
-        if (hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, device) == hipSuccess && coop &&
-            resident_prepare<1>() && resident_prepare<2>() &&
+    if (ok) {   // can the resident pass run here?  (160 KiB of LDS per workgroup, one workgroup per CU)
+        int per_cu = 0;
+        if (            resident_prepare<1>() && resident_prepare<2>() &&
             hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_fit_resident<false, false, 2>, GrResShape<2>::LANES, GrResShape<2>::LDS_BYTES) == hipSuccess && per_cu >= 1 &&
             hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_fit_resident<false, false, 1>, GrResShape<1>::LANES, GrResShape<1>::LDS_BYTES) == hipSuccess && per_cu >= 1)
             c->res_max_wgs = c->n_cus * (uint32_t)per_cu;
@@ -1453,7 +1458,7 @@ int gr_ctx_set_tuning(gr_ctx *c, int key, int64_t value) try {
     case GR_TUNE_FIT_WGS: if (value < 0 || value > 65535) break; c->fit_wgs = (uint32_t)value; return GR_OK;
     case GR_TUNE_FUSE: c->fuse = value ? 1 : 0; return GR_OK;
     case GR_TUNE_TWO_PASS: c->two_pass = value ? 1 : 0; return GR_OK;
-    case GR_TUNE_RESIDENT: if (value < 0 || value > 3) break; c->resident = value; return GR_OK;
+    case GR_TUNE_RESIDENT: if (value < 0 || value > 2) break; c->resident = value; return GR_OK;
     case GR_TUNE_RESIDENT_GROUPS: if (value < 1 || value > 2) break; c->resident_groups = (int)value; return GR_OK;
     default: break;
     }
@@ -1537,9 +1542,11 @@ static int segment_begin(gr_rmsd_plan *p, uint32_t s0, uint32_t nb, int fit) {
         const bool fused = lite && c->fuse;   // the finalize rides on the tail of the sums kernel
         q.fused = fused;
         hipStream_t S = c->stream;
-        const uint32_t res_stream = resident_wgs(c, lite);
+        uint32_t res_stream = resident_wgs(c, lite);
+        if (res_stream && !resident_acquire(c->device)) res_stream = 0;
+        if (res_stream) c->res_in_use = true;           // (released in segment_end, or by the caller when this function fails)
         if (res_stream) {
-            // ONE cooperative launch for the segment: every frame is read once and written once (gr_resident.h)
+            // ONE launch for the segment: every frame is read once and written once (gr_resident.h)
             const uint32_t n_fin = std::min<uint32_t>(GR_RES_MAX_FIN, c->res_max_wgs - res_stream);
             if ((size_t)nb * res_stream > c->fit_partials_cap) {
                 if (c->fit_partials) (void)hipFree(c->fit_partials);
@@ -1567,19 +1574,21 @@ static int segment_begin(gr_rmsd_plan *p, uint32_t s0, uint32_t nb, int fit) {
             const void *fn = g1 ? resident_fn<1>(p->dev.w_is_mass != 0, ubox) : resident_fn<2>(p->dev.w_is_mass != 0, ubox);
             const uint32_t lanes = g1 ? GrResShape<1>::LANES : GrResShape<2>::LANES, lds = g1 ? GrResShape<1>::LDS_BYTES : GrResShape<2>::LDS_BYTES;
             if (c->profile) EVREC(c, c->pev[0], true, S);
-            // (3 = an ordinary launch of the same grid, for counter collection only: rocprofv3 --pmc faults on cooperative launches;
-            // the grid is co-resident on an otherwise idle device, which is all the kernel needs)
-            const hipError_t le = c->resident == 3 ? hipModuleLaunchKernelCompat(fn, dim3(res_stream + n_fin), dim3(lanes), args, lds, S)
-                                                   : hipLaunchCooperativeKernel(fn, dim3(res_stream + n_fin), dim3(lanes), args, lds, S);
+            // An ORDINARY launch: the grid fits the device with one workgroup per CU (resident_wgs checked), other kernels that hold
+            // CUs when it starts finish on their own, and the guard above keeps a second resident launch of this process away.
+            // (hipLaunchCooperativeKernel, which has the runtime check co-residency, was used at first: rocprofv3 --pmc faults on
+            // it, and a process that issued it from two host threads crashed inside the runtime at exit -- ROCm 7.2.)
+            const hipError_t le = hipLaunchKernel(fn, dim3(res_stream + n_fin), dim3(lanes), args, lds, S);
             if (le == hipSuccess) {
                 if (c->profile) EVREC(c, c->pev[1], true, S);
                 k_rmsd_close<<<dim3(nb), dim3(64), 0, S>>>(c->fit_partials, res_stream, p->dev.sw, c->state_dev);
                 HIPCHK(c, hipGetLastError());
-                c->res_in_use = true;
                 q.resident = true;
             } else {
-                (void)hipGetLastError();          // the grid does not fit right now: nothing ran, the two-pass path takes the segment
+                (void)hipGetLastError();          // nothing ran: the two-pass path takes the segment
                 c->res_max_wgs = 0;
+                c->res_in_use = false;
+                resident_release(c->device);
             }
         }
         for (uint32_t g = 0; g < n_groups && !q.resident; ++g) {
@@ -1635,12 +1644,13 @@ static int segment_end(gr_rmsd_plan *p, float *rmsd_out, int *status_out, float 
         HIPCHK(c, hipStreamSynchronize(c->stream));
         if (q.resident) {
             c->res_in_use = false;
+            resident_release(c->device);
             uint32_t aborted = 0;
             HIPCHK(c, hipMemcpy(&aborted, c->res_abort, sizeof aborted, hipMemcpyDeviceToHost));
             if (aborted) {   // a wait inside the resident pass ran out of patience: the batch's frames are in an unknown state
                 (void)hipMemset(c->res_abort, 0, sizeof(uint32_t));
                 c->res_max_wgs = 0;
-                return fail(c, GR_E_HIP, "the resident RMSD-fit pass stalled (a workgroup of the cooperative launch made no progress); frames of the batch may be partly fitted");
+                return fail(c, GR_E_HIP, "the resident RMSD-fit pass stalled (a workgroup of the launch made no progress: was the device shared with another process?); frames of the batch may be partly fitted");
             }
             if (c->profile) {
                 float ms = 0.f;
@@ -1697,7 +1707,8 @@ static int rmsd_batch_impl(gr_rmsd_plan *p, uint32_t first_slot, uint32_t n_fram
     int first_err = GR_OK; uint64_t e_idx = 0; std::string e_msg; uint64_t e_cnt[2] = { 0, 0 };
     for (uint32_t b0 = 0; b0 < n_frames; b0 += GR_MAX_BATCH) {
         const uint32_t nb = std::min<uint32_t>(GR_MAX_BATCH, n_frames - b0);
-        st = segment_begin(p, first_slot + b0, nb, fit); if (st) { p->pend.active = false; return st; }
+        st = segment_begin(p, first_slot + b0, nb, fit);
+        if (st) { p->pend.active = false; if (c->res_in_use) { c->res_in_use = false; resident_release(c->device); } return st; }
         st = segment_end(p, rmsd_out ? rmsd_out + b0 : nullptr, status_out ? status_out + b0 : nullptr, R_out ? R_out + 9 * (size_t)b0 : nullptr);
         if (st == GR_E_HIP) return st;
         if (st != GR_OK && first_err == GR_OK) { first_err = st; e_idx = c->err_index; e_msg = c->err; e_cnt[0] = c->counts[0]; e_cnt[1] = c->counts[1]; }
@@ -1715,7 +1726,7 @@ int gr_rmsd_batch_begin(gr_rmsd_plan *p, uint32_t first_slot, uint32_t n, int fi
     (void)hipSetDevice(c->device);
     p->last_fallbacks = 0;
     st = segment_begin(p, first_slot, n, fit ? 1 : 0);
-    if (st) p->pend.active = false; else { c->in_flight = p; c->in_flight_s0 = first_slot; c->in_flight_n = n; }
+    if (st) { p->pend.active = false; if (c->res_in_use) { c->res_in_use = false; resident_release(c->device); } } else { c->in_flight = p; c->in_flight_s0 = first_slot; c->in_flight_n = n; }
     return st;
 } catch (...) { return gr_abi_guard(); }
 int gr_rmsd_batch_end(gr_rmsd_plan *p, float *rmsd_out, int *status_out, float *R_out) try {

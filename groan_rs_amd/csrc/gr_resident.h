@@ -6,7 +6,7 @@
 // weights from the L2 / Infinity Cache.  But a 1e6-atom frame is 12 MB, and the chip has 256 CUs x 512 KiB of vector
 // registers + 160 KiB of LDS: the frame can WAIT ON CHIP for its rotation.
 //
-//   k_fit_resident   one cooperative launch for a whole batch: `n_stream` workgroups of 512 lanes, TWO 4-atom groups per lane
+//   k_fit_resident   one launch for a whole batch: `n_stream` workgroups of 512 lanes, TWO 4-atom groups per lane
 //                    for the whole launch (its reference coordinates, masses and weights are loaded once and stay in
 //                    registers); a lane walks the frames of the batch with its own group:
 //                       sums stage, frame i      rows arrive (requested one frame earlier), image about the first atom, the
@@ -27,11 +27,11 @@
 // HBM traffic: 12 bytes per atom read + 12 written per frame = 24 (was 36), and nothing from the caches.
 // Measured floor of that traffic at the same launch shape (tools/ceiling_bench.hip "resident copy"): 4.2 us per 1e6-atom frame.
 //
-// STATUS (round 2, MI355X, 1e6 atoms, 1024 frames per launch): 6.5 us per frame = 151 k frames/s with two groups per lane -- level
-// with the two-pass path (6.5-6.6 us of kernel time, 149-151 k frames/s in the same runs), not ahead of it, so the pass stays
-// OPT-IN (GR_TUNE_RESIDENT): it needs a cooperative launch, and rocprofv3 --pmc faults on cooperative launches (ROCm 7.2;
-// GR_TUNE_RESIDENT = 3 launches the same grid the ordinary way for counter collection).  What bounds it is not memory (a lane
-// waits 0.2-0.3 us per frame for its rows; 24 MB per frame cross HBM where the floor of that traffic is 4.2 us) and not the
+// STATUS (round 2, MI355X, 1e6 atoms, 768-1024 frames per launch): 6.35 us per frame = 155 k frames/s with two groups per lane,
+// against 6.6-6.8 us = 148-151 k for the two-pass path in the same jobs: the pass is the DEFAULT for frames that fill at least
+// 15/16 of the chip (GR_TUNE_RESIDENT = 1; every CU runs its 4096 atoms' worth of a frame or idles, so a smaller frame is
+// better off with the two passes, whose time shrinks with it).  What bounds it is not memory (a lane waits 0.2-0.3 us per frame
+// for its rows; 24 MB per frame cross HBM where the floor of that traffic is 4.2 us) and not the
 // finalizers (no closing algebra at all: same time; 8 or 11 of them: same time) but the instruction streams themselves: every CU
 // runs ALL of a frame's arithmetic for its 4096 atoms within one frame period -- 934 VALU + 215 scalar instructions per wave
 // and frame (sums + the per-frame wave reduction + fit + the queue of parked register sets), two waves per SIMD that overlap
@@ -44,12 +44,16 @@
 // x6 7.6 (the loop body, with the rare paths inlined in every copy, was ~140 KB of code against a 64 KB instruction cache); a
 // queue of register sets + the rare paths out of line 7.3; lane facts as bits of one register, waiting waves at low priority
 // 7.2; wave records of 32 floats and the parking moved out of the reduction lambdas 6.6; reductions on DPP moves instead of
-// ds_bpermute 6.5.  Frames parked: 4 -> 7.0, 5 -> 6.6, 6 -> 6.5 (LDS holds no more).  One group per lane (1024 lanes, five frames
+// ds_bpermute 6.5; an ordinary launch instead of hipLaunchCooperativeKernel 6.35.  Frames parked: 4 -> 7.0, 5 -> 6.6, 6 -> 6.5
+// (before the last step; LDS holds no more).  One group per lane (1024 lanes, five frames
 // parked, 128 registers): 9.3 -- the register budget spills into scratch memory inside the loop.
 //
-// Synchronisation.  All waiting is on data that a DIFFERENT workgroup produces, so every workgroup must be resident: the
-// kernel is launched with hipLaunchCooperativeKernel (refused by the runtime unless the whole grid fits at once) and is only
-// chosen when the grid fits with one workgroup per CU.  Every wait is bounded (GR_RES_PATIENCE polls with s_sleep, a few
+// Synchronisation.  All waiting is on data that a DIFFERENT workgroup produces, so every workgroup must become resident: the
+// pass is only chosen when the grid fits the device with one workgroup per CU (occupancy query at context creation), the host
+// lets one such launch run per device and process at a time (a second one would share the CUs with the first and both could
+// starve; the loser takes the two-pass path), and kernels of other streams that hold CUs when it starts end on their own.  The
+// launch is an ordinary one: hipLaunchCooperativeKernel -- the runtime's own co-residency check -- makes rocprofv3 --pmc fault
+// and crashed a process that issued it from two host threads at exit (ROCm 7.2).  Every wait is bounded (GR_RES_PATIENCE polls with s_sleep, a few
 // seconds): a wave that runs out of patience raises `abort` and leaves, every other wait then ends too, the grid drains and
 // the host reports the batch as failed.  Every word that crosses between workgroups carries the launch's epoch in its upper
 // half and is written / read as ONE 64-bit access at agent scope (bypassing the non-coherent caches): a reader can never

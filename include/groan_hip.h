@@ -255,11 +255,11 @@ int gr_rmsd_plan_force_exact(gr_rmsd_plan *plan, int on);
  *   GR_TUNE_FIT_WGS    workgroups per frame of the fit kernel (0 = automatic: one 256-atom tile per wave)
  *   GR_TUNE_FUSE       1 (default): the sums kernel's last workgroup per frame closes the frame; 0: separate finalize launch
  *   GR_TUNE_TWO_PASS   1 (default): RMSD-fit = sums pass + fit pass that evaluates the rmsd; 0: closed-form single-pass rmsd
- *   GR_TUNE_RESIDENT   RMSD-fit as ONE pass over HBM, the frame waiting on chip for its rotation (gr_resident.h: one cooperative
- *                      launch per segment; needs n_atoms <= ~1.04e6 on MI355X).  0 (default) never -- the two-pass path is the
- *                      one the profiling tools can see, and no slower (151 k vs 150 k frames/s at 1e6 atoms); 1 when the frame fills at
- *                      least 3/4 of the chip; 2 whenever it fits; 3 as 2 but an ordinary (non-cooperative) launch -- for counter
- *                      collection on an idle device only.  Same results as the two-pass path up to the order of the partial sums.
+ *   GR_TUNE_RESIDENT   RMSD-fit as ONE pass over HBM, the frame waiting on chip for its rotation (gr_resident.h: one launch per
+ *                      segment whose workgroups wait for one another; needs n_atoms <= ~1.04e6 on MI355X).  1 (default): when the
+ *                      frame fills at least 15/16 of the chip (155 k vs 150 k frames/s at 1e6 atoms); 0: never; 2: whenever it
+ *                      fits.  One such launch runs per device and process at a time (a context that finds the device taken uses
+ *                      the two-pass path).  Same results as the two-pass path up to the order of the partial sums.
  *   GR_TUNE_RESIDENT_GROUPS  4-atom groups per lane of the resident pass: 2 (default; 512 lanes per workgroup) or 1 (1024 lanes)
  */
 enum { GR_TUNE_SUB_BATCH = 1, GR_TUNE_CHUNKS = 2, GR_TUNE_FIT_WGS = 3, GR_TUNE_FUSE = 4, GR_TUNE_TWO_PASS = 5, GR_TUNE_RESIDENT = 6, GR_TUNE_RESIDENT_GROUPS = 7 };

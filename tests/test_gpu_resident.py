@@ -1,4 +1,4 @@
-"""The resident RMSD-fit pass (gr_resident.h: one cooperative launch, every frame read once and written once, the frame
+"""The resident RMSD-fit pass (gr_resident.h: one launch, every frame read once and written once, the frame
 waiting on chip for its rotation) against the oracle and against the two-pass path on the same frames.  GR_TUNE_RESIDENT = 2
 forces it for systems far smaller than the chip (few streaming workgroups, a ragged last one, idle waves).  The pass is opt-in
 (default: the two-pass path, which is faster on this hardware -- gr_resident.h STATUS)."""
