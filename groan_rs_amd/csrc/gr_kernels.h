@@ -214,6 +214,12 @@ __device__ __forceinline__ float gr_wave_sum_scatter32(float (&a)[32], const uin
     gr_rs_step<2, 4, false>(a, lane); gr_rs_step<1, 2, false>(a, lane);
     return a[0] + gr_xor_lane<1>(a[0]);
 }
+// 16 floats: afterwards lane l holds the wave total of value (l >> 2)
+__device__ __forceinline__ float gr_wave_sum_scatter16(float (&a)[32], const uint32_t lane) {
+    gr_rs_step_swap<8, 32, false>(a); gr_rs_step_swap<4, 16, false>(a); gr_rs_step<2, 8, false>(a, lane); gr_rs_step<1, 4, false>(a, lane);
+    const float m = a[0] + gr_xor_lane<2>(a[0]);
+    return m + gr_xor_lane<1>(m);
+}
 // the same with max over the first 16 floats: lane l ends with the wave maximum of value (l >> 2)
 __device__ __forceinline__ float gr_wave_max_scatter16(float (&a)[32], const uint32_t lane) {
     gr_rs_step_swap<8, 32, true>(a); gr_rs_step_swap<4, 16, true>(a); gr_rs_step<2, 8, true>(a, lane); gr_rs_step<1, 4, true>(a, lane);

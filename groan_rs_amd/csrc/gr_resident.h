@@ -27,13 +27,13 @@
 // HBM traffic: 12 bytes per atom read + 12 written per frame = 24 (was 36), and nothing from the caches.
 // Measured floor of that traffic at the same launch shape (tools/ceiling_bench.hip "resident copy"): 4.2 us per 1e6-atom frame.
 //
-// STATUS (round 2, MI355X, 1e6 atoms, 768-1024 frames per launch): 6.35 us per frame = 155 k frames/s with two groups per lane,
+// STATUS (round 2, MI355X, 1e6 atoms, 768-1024 frames per launch): 6.27 us per frame = 157 k frames/s with two groups per lane,
 // against 6.6-6.8 us = 148-151 k for the two-pass path in the same jobs: the pass is the DEFAULT for frames that fill at least
 // 15/16 of the chip (GR_TUNE_RESIDENT = 1; every CU runs its 4096 atoms' worth of a frame or idles, so a smaller frame is
 // better off with the two passes, whose time shrinks with it).  What bounds it is not memory (a lane waits 0.2-0.3 us per frame
 // for its rows; 24 MB per frame cross HBM where the floor of that traffic is 4.2 us) and not the
 // finalizers (no closing algebra at all: same time; 8 or 11 of them: same time) but the instruction streams themselves: every CU
-// runs ALL of a frame's arithmetic for its 4096 atoms within one frame period -- 934 VALU + 215 scalar instructions per wave
+// runs ALL of a frame's arithmetic for its 4096 atoms within one frame period -- 909 VALU + 227 scalar instructions per wave
 // and frame (sums + the per-frame wave reduction + fit + the queue of parked register sets), two waves per SIMD that overlap
 // poorly: the VALU is busy 45-50 % of the time; the last wave of every workgroup (second on its SIMD, and the one that adds up
 // the workgroup's record) never waits for a record and sets the pace, the others wait for it a third of their time.  The two-pass
@@ -44,7 +44,8 @@
 // x6 7.6 (the loop body, with the rare paths inlined in every copy, was ~140 KB of code against a 64 KB instruction cache); a
 // queue of register sets + the rare paths out of line 7.3; lane facts as bits of one register, waiting waves at low priority
 // 7.2; wave records of 32 floats and the parking moved out of the reduction lambdas 6.6; reductions on DPP moves instead of
-// ds_bpermute 6.5; an ordinary launch instead of hipLaunchCooperativeKernel 6.35.  Frames parked: 4 -> 7.0, 5 -> 6.6, 6 -> 6.5
+// ds_bpermute 6.5; an ordinary launch instead of hipLaunchCooperativeKernel 6.35; 19 sums = a 16-wide scatter + three plain wave
+// sums 6.27.  Frames parked: 4 -> 7.0, 5 -> 6.6, 6 -> 6.5
 // (before the last step; LDS holds no more).  One group per lane (1024 lanes, five frames
 // parked, 128 registers): 9.3 -- the register budget spills into scratch memory inside the loop.
 //
@@ -399,11 +400,15 @@ __global__ __launch_bounds__(GrResShape<G>::LANES) void k_fit_resident(
             group_sums(GA, L.a, B, boxp, gx, gy, gz, s32, e32, true);
             if (G == 2 && GB.valid) group_sums(GB, L.b, B, boxp, gx, gy, gz, s32, e32, false);
         }
-        const float tot = gr_wave_sum_scatter32(s32, lane);
+        // 19 sums = a reduce-scatter of the first 16 + three plain wave sums (a 32-wide scatter would push 13 zeros through its
+        // two widest steps); 12 extents = a 16-wide scatter with max
+        const float tot = gr_wave_sum_scatter16(s32, lane);
+        const float t16 = gr_wave_allsum_f32(s32[16]), t17 = gr_wave_allsum_f32(s32[17]), t18 = gr_wave_allsum_f32(s32[18]);
         const float emax = gr_wave_max_scatter16(e32, lane);
         const uint32_t rs = i % R;
         float *mine = wsum + (rs * WAVES + wave) * 32;
-        if ((lane & 1u) == 0 && lane < 38u) mine[lane >> 1] = tot;                 // sums 0..18
+        if ((lane & 3u) == 0) mine[lane >> 2] = tot;                               // sums 0..15
+        if (lane == 1u) { mine[16] = t16; mine[17] = t17; mine[18] = t18; }        // sums 16..18
         if ((lane & 3u) == 0 && lane < 48u) mine[19 + (lane >> 2)] = emax;         // extents 0..11
         gr_wave_sync();
         uint32_t old = 0;

@@ -257,7 +257,7 @@ int gr_rmsd_plan_force_exact(gr_rmsd_plan *plan, int on);
  *   GR_TUNE_TWO_PASS   1 (default): RMSD-fit = sums pass + fit pass that evaluates the rmsd; 0: closed-form single-pass rmsd
  *   GR_TUNE_RESIDENT   RMSD-fit as ONE pass over HBM, the frame waiting on chip for its rotation (gr_resident.h: one launch per
  *                      segment whose workgroups wait for one another; needs n_atoms <= ~1.04e6 on MI355X).  1 (default): when the
- *                      frame fills at least 15/16 of the chip (155 k vs 150 k frames/s at 1e6 atoms); 0: never; 2: whenever it
+ *                      frame fills at least 15/16 of the chip (157 k vs 150 k frames/s at 1e6 atoms); 0: never; 2: whenever it
  *                      fits.  One such launch runs per device and process at a time (a context that finds the device taken uses
  *                      the two-pass path).  Same results as the two-pass path up to the order of the partial sums.
  *   GR_TUNE_RESIDENT_GROUPS  4-atom groups per lane of the resident pass: 2 (default; 512 lanes per workgroup) or 1 (1024 lanes)
