@@ -338,6 +338,8 @@ __global__ __launch_bounds__(GrResShape<G>::LANES) void k_fit_resident(
     setup(base + tid, GA);
     if (G == 2) setup(base + LANES + tid, GB); else { GB.valid = false; GB.flags = 0u; GB.b = 0; GB.mm = GB.ww = zero4; GB.P = gr_pairs_rows(zero4, zero4, zero4); }
     const float cx = plan.ref_com[0], cy = plan.ref_com[1], cz = plan.ref_com[2];
+    // sum of the masses of the wave's atoms inside the selection: the same for every frame of the launch
+    const float m_wave = gr_wave_allsum_f32(((GA.mm.x + GA.mm.y) + (GA.mm.z + GA.mm.w)) + ((GB.mm.x + GB.mm.y) + (GB.mm.z + GB.mm.w)));
 
     struct Rows { float4 r0, r1, r2; };
     struct Landing { Rows a, b; float gx, gy, gz; };
@@ -368,10 +370,9 @@ __global__ __launch_bounds__(GrResShape<G>::LANES) void k_fit_resident(
         gr_res_image_pair(vxa, vya, vza, B, boxp);
         gr_res_image_pair(vxb, vyb, vzb, B, boxp);
         auto fold = [](gr_v2f v) { return v.x + v.y; };
-        auto acc = [&](int k, float x) { s32[k] = init ? x : s32[k] + x; };
+        auto acc = [&](int k, float x) { s32[k - 1] = init ? x : s32[k - 1] + x; };   // value k (1..18) lives at s32[k - 1]; value 0 = sum m is not per frame
         auto ext = [&](int k, float x) { e32[k] = init ? x : gr_fmaxf(e32[k], x); };
         const gr_v2f ma = gr_v2p(Gr.mm.x, Gr.mm.y), mb = gr_v2p(Gr.mm.z, Gr.mm.w);
-        acc(0, fold(ma + mb));
         acc(1, fold(gr_v2_fma(ma, vxa, mb * vxb))); acc(2, fold(gr_v2_fma(ma, vya, mb * vyb))); acc(3, fold(gr_v2_fma(ma, vza, mb * vzb)));
         acc(4, fold(gr_v2_fma(Gr.P.x01, vxa, Gr.P.x23 * vxb))); acc(5, fold(gr_v2_fma(Gr.P.x01, vya, Gr.P.x23 * vyb))); acc(6, fold(gr_v2_fma(Gr.P.x01, vza, Gr.P.x23 * vzb)));
         acc(7, fold(gr_v2_fma(Gr.P.y01, vxa, Gr.P.y23 * vxb))); acc(8, fold(gr_v2_fma(Gr.P.y01, vya, Gr.P.y23 * vyb))); acc(9, fold(gr_v2_fma(Gr.P.y01, vza, Gr.P.y23 * vzb)));
@@ -400,15 +401,15 @@ __global__ __launch_bounds__(GrResShape<G>::LANES) void k_fit_resident(
             group_sums(GA, L.a, B, boxp, gx, gy, gz, s32, e32, true);
             if (G == 2 && GB.valid) group_sums(GB, L.b, B, boxp, gx, gy, gz, s32, e32, false);
         }
-        // 19 sums = a reduce-scatter of the first 16 + three plain wave sums (a 32-wide scatter would push 13 zeros through its
-        // two widest steps); 12 extents = a 16-wide scatter with max
-        const float tot = gr_wave_sum_scatter16(s32, lane);
-        const float t16 = gr_wave_allsum_f32(s32[16]), t17 = gr_wave_allsum_f32(s32[17]), t18 = gr_wave_allsum_f32(s32[18]);
+        // 18 sums per frame (the 19th, sum m, does not depend on the frame: m_wave below) = a reduce-scatter of 16 + two plain wave
+        // sums (a 32-wide scatter would push 14 zeros through its two widest steps); 12 extents = a 16-wide scatter with max
+        const float tot = gr_wave_sum_scatter16(s32, lane);                       // values 1..16
+        const float t17 = gr_wave_allsum_f32(s32[16]), t18 = gr_wave_allsum_f32(s32[17]);
         const float emax = gr_wave_max_scatter16(e32, lane);
         const uint32_t rs = i % R;
         float *mine = wsum + (rs * WAVES + wave) * 32;
-        if ((lane & 3u) == 0) mine[lane >> 2] = tot;                               // sums 0..15
-        if (lane == 1u) { mine[16] = t16; mine[17] = t17; mine[18] = t18; }        // sums 16..18
+        if ((lane & 3u) == 0) mine[1 + (lane >> 2)] = tot;                         // sums 1..16
+        if (lane == 1u) { mine[0] = m_wave; mine[17] = t17; mine[18] = t18; }      // sum m (the same every frame), sums 17, 18
         if ((lane & 3u) == 0 && lane < 48u) mine[19 + (lane >> 2)] = emax;         // extents 0..11
         gr_wave_sync();
         uint32_t old = 0;
