@@ -236,7 +236,7 @@ template <int G> static bool resident_prepare() {
 // Streaming workgroups of the resident RMSD-fit pass (gr_resident.h), or 0 when the two-pass path takes the segment: the
 // frame must fit (one 4-atom group per lane) beside at least two finalizer workgroups, and -- unless forced -- fill most of
 // the chip: a small frame streams faster through the two-pass kernels, which spread it over every CU.
-uint32_t resident_wgs(const gr_ctx *c, bool lite) {
+uint32_t resident_wgs(const gr_ctx *c, bool lite, uint32_t nb) {
     if (!lite || !c->resident || !c->res_max_wgs) return 0;
     const uint64_t groups = ((c->n + 255) >> 8) << 6;
     const uint64_t wgs = (groups + GR_RES_GROUPS - 1) / GR_RES_GROUPS;   // (a workgroup owns 1024 groups whatever the groups per lane)
@@ -244,6 +244,9 @@ uint32_t resident_wgs(const gr_ctx *c, bool lite) {
     // the pass costs the same per frame whatever the frame's size (every CU runs its 4096 atoms' worth or idles): it only
     // beats the two passes, whose time shrinks with the frame, when the frame fills at least 15/16 of the chip
     if (c->resident == 1 && wgs * 16 < (uint64_t)c->res_max_wgs * 15) return 0;
+    // ... and when the segment is long enough to pay for filling and draining the six-frame pipeline (measured at 16 frames per
+    // call: 9.8 us per frame against 10.6 for the two passes; single frames are a chain of waits)
+    if (c->resident == 1 && nb < 16) return 0;
     return (uint32_t)wgs;
 }
 
@@ -1542,7 +1545,7 @@ static int segment_begin(gr_rmsd_plan *p, uint32_t s0, uint32_t nb, int fit) {
         const bool fused = lite && c->fuse;   // the finalize rides on the tail of the sums kernel
         q.fused = fused;
         hipStream_t S = c->stream;
-        uint32_t res_stream = resident_wgs(c, lite);
+        uint32_t res_stream = resident_wgs(c, lite, nb);
         if (res_stream && !resident_acquire(c->device)) res_stream = 0;
         if (res_stream) c->res_in_use = true;           // (released in segment_end, or by the caller when this function fails)
         if (res_stream) {
