@@ -85,6 +85,7 @@ struct gr_ctx {
     // resident RMSD fit (gr_resident.h): one launch per segment, the frame waits on chip for its rotation
     int resident = 1;                 // GR_TUNE_RESIDENT 0 never, 1 when the frame fills the chip, 2 whenever it fits (tests)
     uint32_t res_max_wgs = 0;         // workgroups of k_fit_resident the device holds at once (0: the pass cannot run here)
+    int res_test_no_start = 0;        // GR_TUNE_TEST_RESIDENT_NO_START (tests): the next resident launch finds its start verdict already "never started"
     int resident_groups = 2;          // GR_TUNE_RESIDENT_GROUPS: 4-atom groups per lane of the resident pass (1: 1024 lanes, 2: 512 lanes)
     unsigned long long *res_wgrec = nullptr; size_t res_wgrec_cap = 0;   // [frames][streaming workgroups, padded to 16][32] tagged words
     unsigned long long *res_rec = nullptr;   // [GR_MAX_BATCH][16]
@@ -558,8 +559,8 @@ gr_ctx *gr_ctx_create(int device, uint64_t n_atoms, uint32_t n_slots, int *statu
     ok = ok && hipMalloc(&c->bad_dev, 4 * GR_MAX_BATCH * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipHostMalloc(&c->bad_host, 4 * GR_MAX_BATCH * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess;
     ok = ok && hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess;
-    ok = ok && hipMalloc(&c->res_abort, sizeof(uint32_t)) == hipSuccess;
-    ok = ok && hipMemset(c->res_abort, 0, sizeof(uint32_t)) == hipSuccess;
+    ok = ok && hipMalloc(&c->res_abort, 4 * sizeof(uint32_t)) == hipSuccess;
+    ok = ok && hipMemset(c->res_abort, 0, 4 * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipMalloc(&c->res_rec, (size_t)GR_MAX_BATCH * 16 * sizeof(unsigned long long)) == hipSuccess;
     ok = ok && hipMemset(c->res_rec, 0, (size_t)GR_MAX_BATCH * 16 * sizeof(unsigned long long)) == hipSuccess;
     if (ok) {   // can the resident pass run here?  (160 KiB of LDS per workgroup, one workgroup per CU)
@@ -1463,6 +1464,7 @@ int gr_ctx_set_tuning(gr_ctx *c, int key, int64_t value) try {
     case GR_TUNE_TWO_PASS: c->two_pass = value ? 1 : 0; return GR_OK;
     case GR_TUNE_RESIDENT: if (value < 0 || value > 2) break; c->resident = value; return GR_OK;
     case GR_TUNE_RESIDENT_GROUPS: if (value < 1 || value > 2) break; c->resident_groups = (int)value; return GR_OK;
+    case GR_TUNE_TEST_RESIDENT_NO_START: c->res_test_no_start = value ? 1 : 0; return GR_OK;
     default: break;
     }
     return fail(c, GR_E_INVALID_ARG, "unknown tuning key or value out of range");
@@ -1576,6 +1578,8 @@ static int segment_begin(gr_rmsd_plan *p, uint32_t s0, uint32_t nb, int fit) {
             const bool g1 = c->resident_groups == 1;
             const void *fn = g1 ? resident_fn<1>(p->dev.w_is_mass != 0, ubox) : resident_fn<2>(p->dev.w_is_mass != 0, ubox);
             const uint32_t lanes = g1 ? GrResShape<1>::LANES : GrResShape<2>::LANES, lds = g1 ? GrResShape<1>::LDS_BYTES : GrResShape<2>::LDS_BYTES;
+            HIPCHK(c, hipMemsetAsync(c->res_abort + 1, 0, 2 * sizeof(uint32_t), S));   // start handshake: count, verdict
+            if (c->res_test_no_start) { const uint32_t two = 2u; c->res_test_no_start = 0; HIPCHK(c, hipMemcpyAsync(c->res_abort + 2, &two, sizeof two, hipMemcpyHostToDevice, S)); HIPCHK(c, hipStreamSynchronize(S)); }
             if (c->profile) EVREC(c, c->pev[0], true, S);
             // An ORDINARY launch: the grid fits the device with one workgroup per CU (resident_wgs checked), other kernels that hold
             // CUs when it starts finish on their own, and the guard above keeps a second resident launch of this process away.
@@ -1648,8 +1652,19 @@ static int segment_end(gr_rmsd_plan *p, float *rmsd_out, int *status_out, float 
         if (q.resident) {
             c->res_in_use = false;
             resident_release(c->device);
-            uint32_t aborted = 0;
-            HIPCHK(c, hipMemcpy(&aborted, c->res_abort, sizeof aborted, hipMemcpyDeviceToHost));
+            uint32_t words[3] = { 0, 0, 0 };
+            HIPCHK(c, hipMemcpy(words, c->res_abort, sizeof words, hipMemcpyDeviceToHost));
+            if (words[2] != 1u) {
+                // the launch never started (its workgroups did not all get onto the chip: the device is shared): no frame was
+                // touched -- this context stops using the pass and the segment runs on the two-pass path
+                c->res_max_wgs = 0;
+                const int fit_again = q.fit;
+                const uint32_t s0_again = q.s0, nb_again = q.nb;
+                int st2 = segment_begin(p, s0_again, nb_again, fit_again);
+                if (st2) { p->pend.active = false; return st2; }
+                return segment_end(p, rmsd_out, status_out, R_out);
+            }
+            const uint32_t aborted = words[0];
             if (aborted) {   // a wait inside the resident pass ran out of patience: the batch's frames are in an unknown state
                 (void)hipMemset(c->res_abort, 0, sizeof(uint32_t));
                 c->res_max_wgs = 0;

@@ -52,7 +52,10 @@
 // Synchronisation.  All waiting is on data that a DIFFERENT workgroup produces, so every workgroup must become resident: the
 // pass is only chosen when the grid fits the device with one workgroup per CU (occupancy query at context creation), the host
 // lets one such launch run per device and process at a time (a second one would share the CUs with the first and both could
-// starve; the loser takes the two-pass path), and kernels of other streams that hold CUs when it starts end on their own.  The
+// starve; the loser takes the two-pass path), kernels of other streams that hold CUs when it starts end on their own, and the
+// kernel opens with a START HANDSHAKE: every workgroup checks in and the last one opens the launch; when that does not happen
+// within ~0.2 s the launch closes itself and every workgroup leaves before any frame is touched (the host then runs the
+// segment on the two-pass path).  Past the handshake every workgroup is on the chip and no wait can last.  The
 // launch is an ordinary one: hipLaunchCooperativeKernel -- the runtime's own co-residency check -- makes rocprofv3 --pmc fault
 // and crashed a process that issued it from two host threads at exit (ROCm 7.2).  Every wait is bounded (GR_RES_PATIENCE polls with s_sleep, a few
 // seconds): a wave that runs out of patience raises `abort` and leaves, every other wait then ends too, the grid drains and
@@ -93,13 +96,15 @@ template <int G> struct GrResShape {
 #define GR_RES_GROUPS 1024         // 4-atom groups per workgroup
 #define GR_RES_MAX_FIN 8
 #define GR_RES_PATIENCE 3000000u   // polls (each ~1 us) before a wait gives up
+#define GR_RES_START_PATIENCE 200000u   // polls of the start handshake (~0.2 s: other kernels may hold CUs when the launch begins)
 
 #define GR_RES_REC_WORDS 32         // tagged words per workgroup record: 0..18 sums, 19..30 extents (as maxima), 31 unused
 #define GR_RES_REC_PAD 32           // workgroup records per frame are padded to a multiple of this
 struct GrResCtl {
     unsigned long long *wgrec;     // [frames][n_stream padded][32] value | epoch << 32
     unsigned long long *rec;       // [frames][16] value | epoch << 32: 0 status, 1..3 shift, 4..12 R (column-major)
-    uint32_t *abort;               // one word, 0 = fine
+    uint32_t *abort;               // [3]: 0 abort (0 = fine), 1 workgroups that have started, 2 start verdict (0 open, 1 go, 2 never started);
+                                   // words 1 and 2 are zeroed by the host before every launch
     uint32_t epoch, n_stream, n_fin;
 };
 
@@ -205,6 +210,28 @@ __global__ __launch_bounds__(GrResShape<G>::LANES) void k_fit_resident(
     extern __shared__ float4 smem[];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t n_pad = (ctl.n_stream + GR_RES_REC_PAD - 1u) & ~(uint32_t)(GR_RES_REC_PAD - 1u);
+
+    // ------------------------------------------------------------------------------------------ start handshake
+    // Every workgroup waits for data other workgroups produce, so nothing may begin before ALL of them are on the chip: each one
+    // checks in, the one that completes the count opens the launch (verdict 1).  A workgroup that waits too long -- the device is
+    // shared with another process's kernels that will not leave, or two of these launches hold half the chip each -- closes it
+    // (verdict 2) and everybody leaves WITHOUT having touched a frame: the host then runs the segment on the two-pass path.
+    {
+        __shared__ uint32_t verdict;
+        if (tid == 0) {
+            const uint32_t n = __hip_atomic_fetch_add(ctl.abort + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+            uint32_t zero = 0u;
+            if (n == gridDim.x) (void)__hip_atomic_compare_exchange_strong(ctl.abort + 2, &zero, 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            uint32_t v, polls = 0;
+            while ((v = gr_ld_agent(ctl.abort + 2)) == 0u) {
+                if (++polls > GR_RES_START_PATIENCE) { zero = 0u; (void)__hip_atomic_compare_exchange_strong(ctl.abort + 2, &zero, 2u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+                __builtin_amdgcn_s_sleep(16);
+            }
+            verdict = v;
+        }
+        __syncthreads();
+        if (verdict != 1u) return;
+    }
 
     // ------------------------------------------------------------------------------------------ finalizers
     if (blockIdx.x >= ctl.n_stream) {

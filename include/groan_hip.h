@@ -259,10 +259,12 @@ int gr_rmsd_plan_force_exact(gr_rmsd_plan *plan, int on);
  *                      segment whose workgroups wait for one another; needs n_atoms <= ~1.04e6 on MI355X).  1 (default): when the
  *                      frame fills at least 15/16 of the chip (157 k vs 150 k frames/s at 1e6 atoms); 0: never; 2: whenever it
  *                      fits.  One such launch runs per device and process at a time (a context that finds the device taken uses
- *                      the two-pass path).  Same results as the two-pass path up to the order of the partial sums.
+ *                      the two-pass path); a launch whose workgroups do not all get onto the chip (a device shared with another
+ *                      process) leaves without touching a frame and the segment runs on the two-pass path.  Same results as the two-pass path up to the order of the partial sums.
  *   GR_TUNE_RESIDENT_GROUPS  4-atom groups per lane of the resident pass: 2 (default; 512 lanes per workgroup) or 1 (1024 lanes)
  */
-enum { GR_TUNE_SUB_BATCH = 1, GR_TUNE_CHUNKS = 2, GR_TUNE_FIT_WGS = 3, GR_TUNE_FUSE = 4, GR_TUNE_TWO_PASS = 5, GR_TUNE_RESIDENT = 6, GR_TUNE_RESIDENT_GROUPS = 7 };
+enum { GR_TUNE_SUB_BATCH = 1, GR_TUNE_CHUNKS = 2, GR_TUNE_FIT_WGS = 3, GR_TUNE_FUSE = 4, GR_TUNE_TWO_PASS = 5, GR_TUNE_RESIDENT = 6, GR_TUNE_RESIDENT_GROUPS = 7,
+       GR_TUNE_TEST_RESIDENT_NO_START = 100 /* tests: the next resident launch behaves as if its workgroups never got onto the chip */ };
 int gr_ctx_set_tuning(gr_ctx *ctx, int key, int64_t value);
 
 /* ---------------------------------------------------------------- text front end: gro structures, ndx index groups (host side)

@@ -134,3 +134,33 @@ def test_resident_with_a_different_box_in_every_frame(G, groups):
         assert abs(float(r[f]) - want[f][0]) <= 1e-5, (f, float(r[f]), want[f][0])
         assert np.abs(cur.get_positions(f) - want[f][1]).max() <= 5e-5, f
     plan.close(); ref.close(); cur.close()
+
+
+def test_resident_launch_that_never_starts_falls_back_cleanly(G):
+    """a launch whose workgroups do not all get onto the chip (a shared device) must leave every frame untouched; the segment then
+    runs on the two-pass path and the context stops choosing the resident pass"""
+    n, nf = 20_000, 24
+    box = W.box_from_lengths_angles([6.0, 6.0, 6.0], [90.0, 90.0, 90.0])
+    masses, cur, ref, ref_pos, frames = _systems(G, n, nf, box, (0, n - 1))
+    plan = G.RMSDPlan(ref, cur, "S")
+    cur.set_tuning(resident=0)
+    for f in range(nf):
+        cur.set_frame(frames[f], box, slot=f)
+    want_r, st = plan.rmsd_fit(0, nf)
+    want = [cur.get_positions(f) for f in range(nf)]
+    cur.set_tuning(resident=2, test_resident_no_start=1)
+    cur.profile_enable(True)
+    for f in range(nf):
+        cur.set_frame(frames[f], box, slot=f)
+    r, st = plan.rmsd_fit(0, nf)
+    prof = cur.profile_read()
+    assert (st == 0).all() and prof["k_fit_pk"][1] > 0                     # the two-pass kernels did the work
+    assert np.array_equal(np.array(r), np.array(want_r))
+    for f in range(nf):
+        assert np.array_equal(cur.get_positions(f), want[f])
+    cur.profile_enable(True)
+    for f in range(nf):
+        cur.set_frame(frames[f], box, slot=f)
+    plan.rmsd_fit(0, nf)
+    assert cur.profile_read()["k_fit_resident"][1] == 0                   # ... and the context no longer tries the resident pass
+    plan.close(); ref.close(); cur.close()
