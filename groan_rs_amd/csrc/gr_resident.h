@@ -8,15 +8,15 @@
 //
 //   k_fit_resident   one launch for a whole batch: `n_stream` workgroups of 512 lanes, TWO 4-atom groups per lane
 //                    for the whole launch (its reference coordinates, masses and weights are loaded once and stay in
-//                    registers); a lane walks the frames of the batch with its own group:
+//                    registers); a lane walks the frames of the batch with its own groups:
 //                       sums stage, frame i      rows arrive (requested one frame earlier), image about the first atom, the
-//                                                19 sums + 12 extents of its 4 atoms -> wave reduce-scatter -> LDS; the last
-//                                                wave of the workgroup adds the 16 wave records in wave order and writes the
+//                                                18 sums + 12 extents of its 8 atoms -> wave reduce-scatter -> LDS; the last
+//                                                wave of the workgroup adds the 8 wave records in wave order and writes the
 //                                                workgroup's record: 31 tagged words (value | epoch << 32), no flag, no fence;
 //                                                the rows are parked: group A in LDS (24 KiB per frame and CU), group B in
 //                                                registers (12 per frame)
-//                       fit stage, frame i - 4   the frame's record (status, shift, R) has come back from a finalizer ->
-//                                                rows out of LDS, wrap + rotate + translate, sum w |R q - p|^2, one
+//                       fit stage, frame i - 6   the frame's record (status, shift, R) has come back from a finalizer ->
+//                                                rows out of LDS / the register queue, wrap + rotate + translate, sum w |R q - p|^2, one
 //                                                non-temporal store per row
 //                    + `n_fin` workgroups that stream nothing: finalizer j owns the frames j, j + n_fin, ...; its 8 waves
 //                    read 32 workgroup records each (one load round trip for the whole frame), re-reading until every
@@ -27,13 +27,13 @@
 // HBM traffic: 12 bytes per atom read + 12 written per frame = 24 (was 36), and nothing from the caches.
 // Measured floor of that traffic at the same launch shape (tools/ceiling_bench.hip "resident copy"): 4.2 us per 1e6-atom frame.
 //
-// STATUS (round 2, MI355X, 1e6 atoms, 768-1024 frames per launch): 6.27 us per frame = 157 k frames/s with two groups per lane,
+// STATUS (round 2, MI355X, 1e6 atoms, 768-1024 frames per launch): 6.26 us per frame = 156-157 k frames/s with two groups per lane,
 // against 6.6-6.8 us = 148-151 k for the two-pass path in the same jobs: the pass is the DEFAULT for frames that fill at least
 // 15/16 of the chip (GR_TUNE_RESIDENT = 1; every CU runs its 4096 atoms' worth of a frame or idles, so a smaller frame is
 // better off with the two passes, whose time shrinks with it).  What bounds it is not memory (a lane waits 0.2-0.3 us per frame
 // for its rows; 24 MB per frame cross HBM where the floor of that traffic is 4.2 us) and not the
 // finalizers (no closing algebra at all: same time; 8 or 11 of them: same time) but the instruction streams themselves: every CU
-// runs ALL of a frame's arithmetic for its 4096 atoms within one frame period -- 909 VALU + 227 scalar instructions per wave
+// runs ALL of a frame's arithmetic for its 4096 atoms within one frame period -- ~900 VALU + ~220 scalar instructions per wave
 // and frame (sums + the per-frame wave reduction + fit + the queue of parked register sets), two waves per SIMD that overlap
 // poorly: the VALU is busy 45-50 % of the time; the last wave of every workgroup (second on its SIMD, and the one that adds up
 // the workgroup's record) never waits for a record and sets the pace, the others wait for it a third of their time.  The two-pass
@@ -44,8 +44,8 @@
 // x6 7.6 (the loop body, with the rare paths inlined in every copy, was ~140 KB of code against a 64 KB instruction cache); a
 // queue of register sets + the rare paths out of line 7.3; lane facts as bits of one register, waiting waves at low priority
 // 7.2; wave records of 32 floats and the parking moved out of the reduction lambdas 6.6; reductions on DPP moves instead of
-// ds_bpermute 6.5; an ordinary launch instead of hipLaunchCooperativeKernel 6.35; 19 sums = a 16-wide scatter + three plain wave
-// sums 6.27.  Frames parked: 4 -> 7.0, 5 -> 6.6, 6 -> 6.5
+// ds_bpermute 6.5; an ordinary launch instead of hipLaunchCooperativeKernel 6.35; the per-frame sums as a 16-wide scatter + two
+// plain wave sums (the mass sum does not depend on the frame) 6.26.  Frames parked: 4 -> 7.0, 5 -> 6.6, 6 -> 6.5
 // (before the last step; LDS holds no more).  One group per lane (1024 lanes, five frames
 // parked, 128 registers): 9.3 -- the register budget spills into scratch memory inside the loop.
 //
