@@ -98,6 +98,7 @@ SIGNATURES = {
     "gr_rmsd_plan_last_fallbacks": (C.c_uint32, [C.c_void_p]),
     "gr_rmsd_plan_force_exact": (C.c_int, [C.c_void_p, C.c_int]),
     "gr_ctx_set_tuning": (C.c_int, [C.c_void_p, C.c_int, C.c_int64]),
+    "gr_ctx_stat": (C.c_int, [C.c_void_p, C.c_int, c_u64p]),
     "gr_ctx_set_center_onepass_min": (C.c_int, [C.c_void_p, C.c_uint32]),
     "gr_center_fallbacks": (C.c_uint64, [C.c_void_p]),
     "gr_gro_read": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_char_p, C.c_size_t]),

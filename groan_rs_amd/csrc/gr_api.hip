@@ -92,6 +92,7 @@ struct gr_ctx {
     uint32_t *res_abort = nullptr;    // device word
     uint32_t res_epoch = 0;
     bool res_in_use = false;          // the pending segment took the resident pass (segment_end checks the abort word)
+    uint64_t res_launches = 0, res_handshake_misses = 0, res_aborts = 0, res_redone_frames = 0;   // gr_ctx_stat
     GrFrameState *state_dev = nullptr;
     GrFrameState *state_host = nullptr;   // pinned
     uint32_t *bad_dev = nullptr;          // [4 * GR_MAX_BATCH]: per frame, first atom without position (rows / columns)
@@ -1453,6 +1454,18 @@ uint32_t gr_rmsd_plan_last_fallbacks(const gr_rmsd_plan *p) { return p ? p->last
 int gr_rmsd_plan_force_exact(gr_rmsd_plan *p, int on) { if (!p) return GR_E_INVALID_ARG; p->exact = on ? 1 : 0; return GR_OK; }
 int gr_ctx_set_center_onepass_min(gr_ctx *c, uint32_t min_atoms) { if (!c) return GR_E_INVALID_ARG; c->com_onepass_min = min_atoms; return GR_OK; }
 uint64_t gr_center_fallbacks(const gr_ctx *c) { return c ? c->center_fallbacks : 0; }
+int gr_ctx_stat(const gr_ctx *c, int key, uint64_t *value) {
+    if (!c || !value) return GR_E_INVALID_ARG;
+    switch (key) {
+    case GR_STAT_N_CUS: *value = c->n_cus; return GR_OK;
+    case GR_STAT_RES_MAX_WGS: *value = c->res_max_wgs; return GR_OK;
+    case GR_STAT_RES_LAUNCHES: *value = c->res_launches; return GR_OK;
+    case GR_STAT_RES_HANDSHAKE_MISSES: *value = c->res_handshake_misses; return GR_OK;
+    case GR_STAT_RES_ABORTS: *value = c->res_aborts; return GR_OK;
+    case GR_STAT_RES_REDONE_FRAMES: *value = c->res_redone_frames; return GR_OK;
+    default: return GR_E_INVALID_ARG;
+    }
+}
 int gr_ctx_set_tuning(gr_ctx *c, int key, int64_t value) try {
     if (!c) return GR_E_INVALID_ARG;
     { int st = busy_check(c); if (st) return st; }
@@ -1658,6 +1671,7 @@ static int segment_end(gr_rmsd_plan *p, float *rmsd_out, int *status_out, float 
                 // the launch never started (its workgroups did not all get onto the chip: the device is shared): no frame was
                 // touched -- this context stops using the pass and the segment runs on the two-pass path
                 c->res_max_wgs = 0;
+                c->res_handshake_misses++;
                 const int fit_again = q.fit;
                 const uint32_t s0_again = q.s0, nb_again = q.nb;
                 int st2 = segment_begin(p, s0_again, nb_again, fit_again);
@@ -1668,8 +1682,10 @@ static int segment_end(gr_rmsd_plan *p, float *rmsd_out, int *status_out, float 
             if (aborted) {   // a wait inside the resident pass ran out of patience: the batch's frames are in an unknown state
                 (void)hipMemset(c->res_abort, 0, sizeof(uint32_t));
                 c->res_max_wgs = 0;
+                c->res_aborts++;
                 return fail(c, GR_E_HIP, "the resident RMSD-fit pass stalled (a workgroup of the launch made no progress: was the device shared with another process?); frames of the batch may be partly fitted");
             }
+            c->res_launches++;
             if (c->profile) {
                 float ms = 0.f;
                 HIPCHK(c, hipEventElapsedTime(&ms, c->pev[0], c->pev[1]));

@@ -364,6 +364,16 @@ class System:
             if st != OK:
                 raise DeviceError("set_tuning", self._err(st)[1], st)
 
+    STAT = {"n_cus": 1, "res_max_wgs": 2, "res_launches": 3, "res_handshake_misses": 4, "res_aborts": 5, "res_redone_frames": 6}
+
+    def stat(self, key):
+        """gr_ctx_stat: device facts and counters of the batched RMSD path"""
+        v = C.c_uint64(0)
+        st = self._lib.gr_ctx_stat(self._ctx, self.STAT[key], C.byref(v))
+        if st != OK:
+            raise DeviceError("stat", self._err(st)[1], st)
+        return int(v.value)
+
     def set_center_onepass_min(self, min_atoms):
         """get_center / get_com of contiguous groups of at least `min_atoms` atoms in one pass (0 = always two passes)"""
         self._lib.gr_ctx_set_center_onepass_min(self._ctx, int(min_atoms))

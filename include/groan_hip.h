@@ -266,6 +266,16 @@ int gr_rmsd_plan_force_exact(gr_rmsd_plan *plan, int on);
 enum { GR_TUNE_SUB_BATCH = 1, GR_TUNE_CHUNKS = 2, GR_TUNE_FIT_WGS = 3, GR_TUNE_FUSE = 4, GR_TUNE_TWO_PASS = 5, GR_TUNE_RESIDENT = 6, GR_TUNE_RESIDENT_GROUPS = 7,
        GR_TUNE_TEST_RESIDENT_NO_START = 100 /* tests: the next resident launch behaves as if its workgroups never got onto the chip */ };
 int gr_ctx_set_tuning(gr_ctx *ctx, int key, int64_t value);
+/* Read-only facts about a context and its device, and counters of what the batched RMSD path did since the context was created
+ * (unknown key: GR_E_INVALID_ARG).
+ *   GR_STAT_N_CUS                  compute units of the device
+ *   GR_STAT_RES_MAX_WGS            workgroups of the resident pass the device holds at once (0: the pass cannot run / was switched off)
+ *   GR_STAT_RES_LAUNCHES           resident launches that ran to the end
+ *   GR_STAT_RES_HANDSHAKE_MISSES   resident launches that closed themselves at the start handshake (the segment then took the two-pass path)
+ *   GR_STAT_RES_ABORTS             resident launches in which a wait ran out of patience (see gr_rmsd_fit_batch)
+ *   GR_STAT_RES_REDONE_FRAMES      frames of such launches that were still untouched and were redone on the two-pass path */
+enum { GR_STAT_N_CUS = 1, GR_STAT_RES_MAX_WGS = 2, GR_STAT_RES_LAUNCHES = 3, GR_STAT_RES_HANDSHAKE_MISSES = 4, GR_STAT_RES_ABORTS = 5, GR_STAT_RES_REDONE_FRAMES = 6 };
+int gr_ctx_stat(const gr_ctx *ctx, int key, uint64_t *value);
 
 /* ---------------------------------------------------------------- text front end: gro structures, ndx index groups (host side)
  * read_gro (src/io/gro_io/structure.rs:120-231, gro_io/mod.rs:21-72) and Groups::from_ndx (src/io/ndx_io.rs:104-230): what is

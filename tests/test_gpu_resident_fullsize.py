@@ -1,0 +1,115 @@
+"""The resident RMSD-fit pass (k_fit_resident, gr_resident.h) AT THE SHAPE THE BENCHMARK TIMES: 1e6 atoms in the rhombic
+dodecahedron of BASELINE configs[3] (d = 24.18 nm, blob of 0.2 x the shortest height, noise 0.05 nm), DEFAULT tuning, >= 24
+frames per call -- the launch of ~245 streaming + 8 finalizer workgroups that occupies every CU, which the small forced
+launches of test_gpu_resident.py (1-18 workgroups) never reach: the start handshake with the whole grid, 2^20-range indexing,
+the frame pipeline filling (frames 0..5), running (>= 6) and draining (the last 6 frames), the record arrays of a long segment.
+Every case asserts that the resident kernel is the one that ran, and compares RMSD (<= 1e-5 nm) and fitted coordinates
+(<= 5e-5 nm) with the oracle's restatement of rmsd.rs:425-603 (sums in double: DESIGN.md section 2) on the first frame, frames
+on either side of the pipeline depth, a steady-state frame and the last frame."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from groan_rs_amd import workload as W
+
+pytestmark = pytest.mark.gpu
+
+N = 1_000_000
+
+
+@pytest.fixture(scope="module")
+def G():
+    import groan_rs_amd as g
+    g._lib.load()
+    return g
+
+
+def _check(cur, plan, ref_pos, masses, idx, ref_box, boxes, nf, frames_to_check, noise=0.05):
+    """run ONE default-tuned gr_rmsd_fit_batch over nf fresh frames; oracle on the chosen frames"""
+    before = {f: cur.get_positions(f) for f in frames_to_check}
+    cur.profile_enable(True)
+    r, st = plan.rmsd_fit(0, nf)
+    prof = cur.profile_read()
+    assert (st == 0).all() and plan.last_fallbacks() == 0, (st, plan.last_fallbacks())
+    assert np.isfinite(r).all()
+    with O.acc64():
+        for f in frames_to_check:
+            ro, want = O.calc_rmsd_and_fit(ref_pos, masses, idx, ref_box, before[f], masses, idx, boxes[f])
+            assert abs(float(r[f]) - ro) <= 1e-5, (f, float(r[f]), ro)
+            got = cur.get_positions(f)
+            assert np.abs(got - want).max() <= 5e-5, (f, float(np.abs(got - want).max()))
+    return prof, r
+
+
+def _c4(G, n, nf, sel=None, boxes=None):
+    box = W.c4_box()
+    masses = W.masses_cycle(n)
+    cur = G.System(n, masses=masses, n_slots=nf + 1)
+    cur.synth_reference(nf, box, W.blob_radius(box), W.SEED)
+    cur.synth_frames(nf, 0, nf, 0, 0.05, W.SEED)
+    ref_pos = cur.get_positions(nf)
+    ref = G.System(n, masses=masses, box=box, positions=ref_pos)
+    name = "all"
+    if sel is not None:
+        name = "S"
+        for s in (ref, cur):
+            s.group_create_from_ranges("S", [sel])
+    if boxes is not None:
+        for f in range(nf):
+            cur.set_box(boxes[f], slot=f)
+    plan = G.RMSDPlan(ref, cur, name)
+    return box, masses, cur, ref, ref_pos, plan
+
+
+def test_headline_shape_default_tuning_all_atoms(G):
+    """bench.py's exact workload (S = N), 32 frames, default tuning: k_fit_resident<.., UBOX = true, 2>"""
+    nf = 32
+    box, masses, cur, ref, ref_pos, plan = _c4(G, N, nf)
+    prof, r = _check(cur, plan, ref_pos, masses, np.arange(N), box, [box] * nf, nf, [0, 5, 6, 17, nf - 1])
+    assert prof["k_fit_resident"][1] == 1 and prof["k_fit_resident"][2] == nf, prof      # ONE resident launch did all 32 frames
+    assert prof["k_fit_pk"][1] == 0 and prof["k_sums_pk"][1] == 0, prof
+    # a second call over fresh copies of the same frames reproduces the bits (arrival order does not reach the results)
+    cur.synth_frames(nf, 0, nf, 0, 0.05, W.SEED)
+    r2, st2 = plan.rmsd_fit(0, nf)
+    assert np.array_equal(np.asarray(r), np.asarray(r2))
+    plan.close(); ref.close(); cur.close()
+
+
+def test_headline_shape_prefix_selection(G):
+    """SURVEY 8(d)'s S = 1e5 prefix variant at full size: the first 25 workgroups carry the selection (the last of them a ragged
+    end inside a lane's 4-atom group), the other 220 only stream + fit"""
+    nf, s_last = 24, 99_998
+    box, masses, cur, ref, ref_pos, plan = _c4(G, N, nf, sel=(0, s_last))
+    prof, _ = _check(cur, plan, ref_pos, masses, np.arange(s_last + 1), box, [box] * nf, nf, [0, 6, 11, nf - 1])
+    assert prof["k_fit_resident"][1] == 1 and prof["k_fit_pk"][1] == 0, prof
+    plan.close(); ref.close(); cur.close()
+
+
+def test_headline_shape_with_a_different_box_in_every_frame(G):
+    """constant-pressure run at full size: every frame has its own (slightly breathing) dodecahedron -> UBOX = false, the box
+    constants are scalar loads per frame in both stages"""
+    nf = 24
+    d = [24.18 * (1.0 + 2.0e-4 * ((f * 7) % 11 - 5)) for f in range(nf)]
+    boxes = [W.c4_box(x) for x in d]
+    box, masses, cur, ref, ref_pos, plan = _c4(G, N, nf, boxes=boxes)
+    prof, _ = _check(cur, plan, ref_pos, masses, np.arange(N), box, boxes, nf, [0, 7, 13, nf - 1])
+    assert prof["k_fit_resident"][1] == 1 and prof["k_fit_pk"][1] == 0, prof
+    plan.close(); ref.close(); cur.close()
+
+
+def test_largest_frame_the_pass_accepts_and_the_first_it_refuses(G):
+    """the `streaming workgroups + 2 finalizers <= workgroups the device holds` boundary (gr_api.hip resident_wgs): the
+    largest system takes the pass with only two finalizer workgroups; one workgroup more and the two-pass path runs"""
+    nf = 24
+    box = W.c4_box()
+    probe = G.System(1024, n_slots=1)
+    max_wgs = probe.stat("res_max_wgs")
+    probe.close()
+    assert max_wgs >= 64, max_wgs
+    n_in = (max_wgs - 2) * 4096 - 77            # ragged last tile, streaming workgroups = max_wgs - 2
+    n_out = (max_wgs - 2) * 4096 + 1            # one more workgroup
+    for n, resident in ((n_in, True), (n_out, False)):
+        box, masses, cur, ref, ref_pos, plan = _c4(G, n, nf)
+        prof, _ = _check(cur, plan, ref_pos, masses, np.arange(n), box, [box] * nf, nf, [0, nf - 1])
+        assert (prof["k_fit_resident"][1] == 1) == resident and (prof["k_fit_pk"][1] > 0) == (not resident), (n, prof)
+        plan.close(); ref.close(); cur.close()
