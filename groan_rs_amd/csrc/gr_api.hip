@@ -86,7 +86,9 @@ struct gr_ctx {
     int resident = 1;                 // GR_TUNE_RESIDENT 0 never, 1 when the frame fills the chip, 2 whenever it fits (tests)
     uint32_t res_max_wgs = 0;         // workgroups of k_fit_resident the device holds at once (0: the pass cannot run here)
     int res_test_no_start = 0;        // GR_TUNE_TEST_RESIDENT_NO_START (tests): the next resident launch finds its start verdict already "never started"
-    int resident_groups = 2;          // GR_TUNE_RESIDENT_GROUPS: 4-atom groups per lane of the resident pass (1: 1024 lanes, 2: 512 lanes)
+    uint32_t res_test_abort_at = 0xFFFFFFFFu;   // GR_TUNE_TEST_RESIDENT_ABORT_AT (tests): the finalizer of this frame of the next resident launch raises `abort`
+    uint32_t res_skip = 0, res_backoff = 0;     // segments the pass sits out after a missed start handshake (doubles with every miss in a row)
+    uint32_t *res_progress = nullptr;           // [GR_MAX_CHUNKS][8]: frames each streaming wave of the last resident launch had fitted when it left
     unsigned long long *res_wgrec = nullptr; size_t res_wgrec_cap = 0;   // [frames][streaming workgroups, padded to 16][32] tagged words
     unsigned long long *res_rec = nullptr;   // [GR_MAX_BATCH][16]
     uint32_t *res_abort = nullptr;    // device word
@@ -134,7 +136,7 @@ struct gr_ctx {
 
 struct Pending {   // a segment between gr_rmsd_batch_begin and gr_rmsd_batch_end
     bool active = false, any_ok = false, consistent = true, fused = false, resident = false;
-    uint32_t s0 = 0, nb = 0, n_prof_groups = 0;
+    uint32_t s0 = 0, nb = 0, n_prof_groups = 0, res_stream = 0;
     int fit = 0;
     std::vector<int> pre;
     std::vector<uint64_t> pre_idx;
@@ -223,22 +225,27 @@ uint32_t fit_grid(const gr_ctx *c, uint32_t nf) {
     return (uint32_t)(gx < 1 ? 1 : gx);
 }
 
-// the four variants of the resident kernel for G groups per lane: allow their LDS size, hand out the one a launch needs
-template <int G> static const void *resident_fn(bool wmass, bool ubox) {
-    return wmass ? (ubox ? reinterpret_cast<const void *>(&k_fit_resident<true, true, G>) : reinterpret_cast<const void *>(&k_fit_resident<true, false, G>))
-                 : (ubox ? reinterpret_cast<const void *>(&k_fit_resident<false, true, G>) : reinterpret_cast<const void *>(&k_fit_resident<false, false, G>));
+// the eight variants of the resident kernel (weights are the masses / every frame has the same box / the selection is the whole
+// system): allow their LDS size, hand out the one a launch needs
+static const void *resident_fn(bool wmass, bool ubox, bool v) {
+    static const void *const fn[8] = {
+        reinterpret_cast<const void *>(&k_fit_resident<false, false, false>), reinterpret_cast<const void *>(&k_fit_resident<true, false, false>),
+        reinterpret_cast<const void *>(&k_fit_resident<false, true, false>), reinterpret_cast<const void *>(&k_fit_resident<true, true, false>),
+        reinterpret_cast<const void *>(&k_fit_resident<false, false, true>), reinterpret_cast<const void *>(&k_fit_resident<true, false, true>),
+        reinterpret_cast<const void *>(&k_fit_resident<false, true, true>), reinterpret_cast<const void *>(&k_fit_resident<true, true, true>) };
+    return fn[(wmass ? 1 : 0) | (ubox ? 2 : 0) | (v ? 4 : 0)];
 }
-template <int G> static bool resident_prepare() {
+static bool resident_prepare() {
     bool ok = true;
-    for (int v = 0; v < 4; ++v)
-        ok = ok && hipFuncSetAttribute(resident_fn<G>((v & 1) != 0, (v & 2) != 0), hipFuncAttributeMaxDynamicSharedMemorySize, GrResShape<G>::LDS_BYTES) == hipSuccess;
+    for (int v = 0; v < 8; ++v)
+        ok = ok && hipFuncSetAttribute(resident_fn((v & 1) != 0, (v & 2) != 0, (v & 4) != 0), hipFuncAttributeMaxDynamicSharedMemorySize, GrResShape::LDS_BYTES) == hipSuccess;
     return ok;
 }
 
 // Streaming workgroups of the resident RMSD-fit pass (gr_resident.h), or 0 when the two-pass path takes the segment: the
 // frame must fit (one 4-atom group per lane) beside at least two finalizer workgroups, and -- unless forced -- fill most of
 // the chip: a small frame streams faster through the two-pass kernels, which spread it over every CU.
-uint32_t resident_wgs(const gr_ctx *c, bool lite, uint32_t nb) {
+uint32_t resident_wgs(gr_ctx *c, bool lite, uint32_t nb) {
     if (!lite || !c->resident || !c->res_max_wgs) return 0;
     const uint64_t groups = ((c->n + 255) >> 8) << 6;
     const uint64_t wgs = (groups + GR_RES_GROUPS - 1) / GR_RES_GROUPS;   // (a workgroup owns 1024 groups whatever the groups per lane)
@@ -249,6 +256,9 @@ uint32_t resident_wgs(const gr_ctx *c, bool lite, uint32_t nb) {
     // ... and when the segment is long enough to pay for filling and draining the six-frame pipeline (measured at 16 frames per
     // call: 9.8 us per frame against 10.6 for the two passes; single frames are a chain of waits)
     if (c->resident == 1 && nb < 16) return 0;
+    // a launch that missed its start handshake (the device was busy with somebody else's kernels) makes the context sit out a few
+    // segments -- twice as many after every miss in a row -- instead of giving the pass up for good (gr_ctx_stat counts the misses)
+    if (c->res_skip) { c->res_skip--; return 0; }
     return (uint32_t)wgs;
 }
 
@@ -257,6 +267,9 @@ uint32_t resident_wgs(const gr_ctx *c, bool lite, uint32_t nb) {
 static std::atomic<int> g_resident_in_flight[64];
 static bool resident_acquire(int device) { int z = 0; return device >= 0 && device < 64 && g_resident_in_flight[device].compare_exchange_strong(z, 1); }
 static void resident_release(int device) { if (device >= 0 && device < 64) g_resident_in_flight[device].store(0); }
+// the context's pending segment no longer owns the device's resident slot (normal end, failure, or the plan / context going away
+// with a batch in flight): every path that ends a segment comes through here, so the slot cannot leak
+static void resident_done(gr_ctx *c) { if (c && c->res_in_use) { c->res_in_use = false; resident_release(c->device); } }
 
 // a batch begun with gr_rmsd_batch_begin is still in flight on this context: only uploads may run beside it
 int busy_check(gr_ctx *c) {
@@ -564,12 +577,14 @@ gr_ctx *gr_ctx_create(int device, uint64_t n_atoms, uint32_t n_slots, int *statu
     ok = ok && hipMemset(c->res_abort, 0, 4 * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipMalloc(&c->res_rec, (size_t)GR_MAX_BATCH * 16 * sizeof(unsigned long long)) == hipSuccess;
     ok = ok && hipMemset(c->res_rec, 0, (size_t)GR_MAX_BATCH * 16 * sizeof(unsigned long long)) == hipSuccess;
+    ok = ok && hipMalloc(&c->res_progress, (size_t)GR_MAX_CHUNKS * 8 * sizeof(uint32_t)) == hipSuccess;
     if (ok) {   // can the resident pass run here?  (160 KiB of LDS per workgroup, one workgroup per CU)
         int per_cu = 0;
-        if (            resident_prepare<1>() && resident_prepare<2>() &&
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_fit_resident<false, false, 2>, GrResShape<2>::LANES, GrResShape<2>::LDS_BYTES) == hipSuccess && per_cu >= 1 &&
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_fit_resident<false, false, 1>, GrResShape<1>::LANES, GrResShape<1>::LDS_BYTES) == hipSuccess && per_cu >= 1)
-            c->res_max_wgs = c->n_cus * (uint32_t)per_cu;
+        int per_cu_x = 0;
+        if (resident_prepare() &&
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_fit_resident<false, false, true>, GrResShape::LANES, GrResShape::LDS_BYTES) == hipSuccess && per_cu >= 1 &&
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_x, k_fit_resident<false, false, false>, GrResShape::LANES, GrResShape::LDS_BYTES) == hipSuccess && per_cu_x >= 1)
+            c->res_max_wgs = c->n_cus * (uint32_t)std::min(per_cu, per_cu_x);
         (void)hipGetLastError();
     }
 
@@ -597,6 +612,7 @@ void gr_ctx_destroy(gr_ctx *c) try {
     (void)hipSetDevice(c->device);
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    resident_done(c);
     for (auto &kv : c->groups) { if (kv.second.idx_dev) (void)hipFree(kv.second.idx_dev); if (kv.second.mask_dev) (void)hipFree(kv.second.mask_dev); }
     if (c->frames) (void)hipFree(c->frames);
     if (c->aos_up) (void)hipFree(c->aos_up);
@@ -611,6 +627,7 @@ void gr_ctx_destroy(gr_ctx *c) try {
     if (c->res_abort) (void)hipFree(c->res_abort);
     if (c->res_wgrec) (void)hipFree(c->res_wgrec);
     if (c->res_rec) (void)hipFree(c->res_rec);
+    if (c->res_progress) (void)hipFree(c->res_progress);
     if (c->state_dev) (void)hipFree(c->state_dev);
     if (c->state_host) (void)hipHostFree(c->state_host);
     if (c->bad_dev) (void)hipFree(c->bad_dev);
@@ -1397,7 +1414,7 @@ int gr_atoms_center_batch(gr_ctx *c, uint32_t first_slot, uint32_t n_frames, con
 void gr_rmsd_plan_destroy(gr_rmsd_plan *p) try {
     if (!p) return;
     if (p->target) (void)hipSetDevice(p->target->device);
-    if (p->target && p->target->in_flight == p) { (void)hipStreamSynchronize(p->target->stream); p->target->in_flight = nullptr; }
+    if (p->target && (p->target->in_flight == p || p->pend.active)) { (void)hipStreamSynchronize(p->target->stream); if (p->target->in_flight == p) p->target->in_flight = nullptr; if (p->pend.resident) resident_done(p->target); }
     if (p->p_dev) (void)hipFree(p->p_dev);
     if (p->w_dev) (void)hipFree(p->w_dev);
     delete p;
@@ -1476,8 +1493,9 @@ int gr_ctx_set_tuning(gr_ctx *c, int key, int64_t value) try {
     case GR_TUNE_FUSE: c->fuse = value ? 1 : 0; return GR_OK;
     case GR_TUNE_TWO_PASS: c->two_pass = value ? 1 : 0; return GR_OK;
     case GR_TUNE_RESIDENT: if (value < 0 || value > 2) break; c->resident = value; return GR_OK;
-    case GR_TUNE_RESIDENT_GROUPS: if (value < 1 || value > 2) break; c->resident_groups = (int)value; return GR_OK;
+    case GR_TUNE_RESIDENT_GROUPS: if (value != 2) break; return GR_OK;   // (the one-group shape was removed: gr_resident.h)
     case GR_TUNE_TEST_RESIDENT_NO_START: c->res_test_no_start = value ? 1 : 0; return GR_OK;
+    case GR_TUNE_TEST_RESIDENT_ABORT_AT: c->res_test_abort_at = value < 0 ? 0xFFFFFFFFu : (uint32_t)value; return GR_OK;
     default: break;
     }
     return fail(c, GR_E_INVALID_ARG, "unknown tuning key or value out of range");
@@ -1581,17 +1599,20 @@ static int segment_begin(gr_rmsd_plan *p, uint32_t s0, uint32_t nb, int fit) {
                 c->res_wgrec_cap = rec_words;
             }
             GrResCtl ctl;
-            ctl.wgrec = c->res_wgrec; ctl.rec = c->res_rec; ctl.abort = c->res_abort; ctl.epoch = ++c->res_epoch; ctl.n_stream = res_stream; ctl.n_fin = n_fin;
+            ctl.wgrec = c->res_wgrec; ctl.rec = c->res_rec; ctl.abort = c->res_abort; ctl.progress = c->res_progress; ctl.epoch = ++c->res_epoch; ctl.n_stream = res_stream; ctl.n_fin = n_fin;
+            ctl.test_abort_frame = c->res_test_abort_at; c->res_test_abort_at = 0xFFFFFFFFu;
             float *frames = c->frames; size_t stride = c->frame_stride; uint32_t slot0 = s0, nfr = nb, natoms = (uint32_t)c->n;
             const float *masses = c->masses; GrSel sel_arg = sel; const GrBox *boxes = c->boxes_dev; GrPlanDev plan = p->dev;
             GrFrameState *states = c->state_dev; double *fparts = c->fit_partials;
             void *args[] = { &frames, &stride, &slot0, &nfr, &natoms, &masses, &sel_arg, &boxes, &plan, &states, &fparts, &ctl };
             bool ubox = true;   // the same box in every frame of the segment (constant-volume runs): its constants are loaded once
             for (uint32_t f = 1; f < nb && ubox; ++f) ubox = memcmp(&c->boxes_host[s0 + f], &c->boxes_host[s0], sizeof(GrBox)) == 0;
-            const bool g1 = c->resident_groups == 1;
-            const void *fn = g1 ? resident_fn<1>(p->dev.w_is_mass != 0, ubox) : resident_fn<2>(p->dev.w_is_mass != 0, ubox);
-            const uint32_t lanes = g1 ? GrResShape<1>::LANES : GrResShape<2>::LANES, lds = g1 ? GrResShape<1>::LDS_BYTES : GrResShape<2>::LDS_BYTES;
+            // the selection is the whole system: the kernel that parks image vectors (gr_resident.h, V)
+            const bool whole = sel.start == 0 && sel.n == c->n;
+            const void *fn = resident_fn(p->dev.w_is_mass != 0, ubox, whole);
+            const uint32_t lanes = GrResShape::LANES, lds = GrResShape::LDS_BYTES;
             HIPCHK(c, hipMemsetAsync(c->res_abort + 1, 0, 2 * sizeof(uint32_t), S));   // start handshake: count, verdict
+            HIPCHK(c, hipMemsetAsync(c->res_progress, 0, (size_t)res_stream * 8 * sizeof(uint32_t), S));
             if (c->res_test_no_start) { const uint32_t two = 2u; c->res_test_no_start = 0; HIPCHK(c, hipMemcpyAsync(c->res_abort + 2, &two, sizeof two, hipMemcpyHostToDevice, S)); HIPCHK(c, hipStreamSynchronize(S)); }
             if (c->profile) EVREC(c, c->pev[0], true, S);
             // An ORDINARY launch: the grid fits the device with one workgroup per CU (resident_wgs checked), other kernels that hold
@@ -1603,12 +1624,11 @@ static int segment_begin(gr_rmsd_plan *p, uint32_t s0, uint32_t nb, int fit) {
                 if (c->profile) EVREC(c, c->pev[1], true, S);
                 k_rmsd_close<<<dim3(nb), dim3(64), 0, S>>>(c->fit_partials, res_stream, p->dev.sw, c->state_dev);
                 HIPCHK(c, hipGetLastError());
-                q.resident = true;
+                q.resident = true; q.res_stream = res_stream;
             } else {
                 (void)hipGetLastError();          // nothing ran: the two-pass path takes the segment
                 c->res_max_wgs = 0;
-                c->res_in_use = false;
-                resident_release(c->device);
+                resident_done(c);
             }
         }
         for (uint32_t g = 0; g < n_groups && !q.resident; ++g) {
@@ -1662,30 +1682,50 @@ static int segment_end(gr_rmsd_plan *p, float *rmsd_out, int *status_out, float 
         if (!q.has_group) return fail(c, GR_E_INVALID_ARG, "batch state lost");
         const GrSel sel = q.sel;
         HIPCHK(c, hipStreamSynchronize(c->stream));
+        std::vector<uint8_t> redo;      // frames of an aborted resident launch that nobody touched: redone on the two-pass path below
+        std::vector<uint8_t> torn;      // ... and frames that SOME waves fitted and others did not
         if (q.resident) {
-            c->res_in_use = false;
-            resident_release(c->device);
+            resident_done(c);
             uint32_t words[3] = { 0, 0, 0 };
             HIPCHK(c, hipMemcpy(words, c->res_abort, sizeof words, hipMemcpyDeviceToHost));
             if (words[2] != 1u) {
                 // the launch never started (its workgroups did not all get onto the chip: the device is shared): no frame was
-                // touched -- this context stops using the pass and the segment runs on the two-pass path
-                c->res_max_wgs = 0;
+                // touched -- the segment runs on the two-pass path, and this context sits out the next segments (twice as many after
+                // every miss in a row) before it tries the pass again
                 c->res_handshake_misses++;
+                c->res_backoff = c->res_backoff ? std::min<uint32_t>(c->res_backoff * 2u, 1024u) : 4u;
+                c->res_skip = c->res_backoff + 1u;      // (+ 1: the re-run of this segment)
                 const int fit_again = q.fit;
                 const uint32_t s0_again = q.s0, nb_again = q.nb;
                 int st2 = segment_begin(p, s0_again, nb_again, fit_again);
-                if (st2) { p->pend.active = false; return st2; }
+                if (st2) { p->pend.active = false; resident_done(c); return st2; }
                 return segment_end(p, rmsd_out, status_out, R_out);
             }
+            c->res_backoff = 0;
             const uint32_t aborted = words[0];
-            if (aborted) {   // a wait inside the resident pass ran out of patience: the batch's frames are in an unknown state
+            if (aborted) {
+                // A wait inside the launch ran out of patience (or a test asked for it) and the grid drained.  Every streaming wave left
+                // word of how many frames it had been through (ctl.progress; waves only ever leave between two frames):
+                //   frames below the smallest count are complete (their records, fitted coordinates and rmsd are final);
+                //   frames at or above the largest count -- and frames whose finalizer gave up (GR_ST_ABORTED) -- are untouched: redone below;
+                //   frames in between were fitted by some waves only (possible when a wave gives up in the instant its record
+                //   arrives for the others): their coordinates are lost and they are reported as GR_E_HIP, frame by frame.
                 (void)hipMemset(c->res_abort, 0, sizeof(uint32_t));
-                c->res_max_wgs = 0;
                 c->res_aborts++;
-                return fail(c, GR_E_HIP, "the resident RMSD-fit pass stalled (a workgroup of the launch made no progress: was the device shared with another process?); frames of the batch may be partly fitted");
+                std::vector<uint32_t> prog((size_t)q.res_stream * 8);
+                HIPCHK(c, hipMemcpy(prog.data(), c->res_progress, prog.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+                uint32_t lo = nb, hi = 0;
+                for (uint32_t v : prog) { lo = std::min(lo, v); hi = std::max(hi, v); }
+                redo.assign(nb, 0); torn.assign(nb, 0);
+                for (uint32_t f = 0; f < nb; ++f) {
+                    if (q.pre[f] != GR_OK) continue;
+                    const bool finalizer_gave_up = c->state_host[f].status == GR_ST_ABORTED;
+                    if (f >= hi || finalizer_gave_up) redo[f] = 1;
+                    else if (f >= lo) torn[f] = 1;
+                }
+            } else {
+                c->res_launches++;
             }
-            c->res_launches++;
             if (c->profile) {
                 float ms = 0.f;
                 HIPCHK(c, hipEventElapsedTime(&ms, c->pev[0], c->pev[1]));
@@ -1702,6 +1742,28 @@ static int segment_end(gr_rmsd_plan *p, float *rmsd_out, int *status_out, float 
             }
         }
         std::vector<GrFrameState> res(c->state_host, c->state_host + nb);
+        if (!redo.empty()) {
+            // runs of untouched frames go through the two-pass path as segments of their own (the pass is off meanwhile)
+            const int keep = c->resident;
+            c->resident = 0;
+            int st_redo = GR_OK;
+            for (uint32_t f0 = 0; f0 < nb && st_redo == GR_OK; ) {
+                if (!redo[f0]) { ++f0; continue; }
+                uint32_t f1 = f0;
+                while (f1 < nb && redo[f1]) ++f1;
+                std::vector<float> r2(f1 - f0);
+                std::vector<int> s2(f1 - f0);
+                Pending sub;
+                std::swap(sub, p->pend);                      // (segment_begin / _end work on p->pend)
+                st_redo = segment_begin(p, s0 + f0, f1 - f0, fit);
+                if (st_redo == GR_OK) { (void)segment_end(p, r2.data(), s2.data(), nullptr); for (uint32_t f = f0; f < f1; ++f) res[f] = c->state_host[f - f0]; }
+                std::swap(sub, p->pend);
+                c->res_redone_frames += f1 - f0;
+                f0 = f1;
+            }
+            c->resident = keep;
+            if (st_redo != GR_OK) return st_redo;
+        }
         // frames whose single-pass image proof failed are redone on the exact path, one by one
         for (uint32_t f = 0; f < nb; ++f) {
             if (res[f].status != GR_ST_FALLBACK) continue;
@@ -1715,6 +1777,7 @@ static int segment_end(gr_rmsd_plan *p, float *rmsd_out, int *status_out, float 
         for (uint32_t f = 0; f < nb; ++f) {
             int s = res[f].status;
             if (q.pre[f] != GR_OK) { s = q.pre[f]; c->err = q.pre_msg[f]; c->err_index = q.pre_idx[f]; }
+            else if (!torn.empty() && torn[f]) s = fail(c, GR_E_HIP, "the resident RMSD-fit pass stalled while this frame was being fitted: some of its atoms carry the fitted coordinates, others the original ones (frame index in gr_last_error_index)", f);
             else if (s == GR_OK && !q.consistent) {
                 c->counts[0] = p->n_ref; c->counts[1] = q.group_n;
                 s = fail(c, GR_E_INCONSISTENT_GROUP, p->group);
@@ -1742,7 +1805,7 @@ static int rmsd_batch_impl(gr_rmsd_plan *p, uint32_t first_slot, uint32_t n_fram
     for (uint32_t b0 = 0; b0 < n_frames; b0 += GR_MAX_BATCH) {
         const uint32_t nb = std::min<uint32_t>(GR_MAX_BATCH, n_frames - b0);
         st = segment_begin(p, first_slot + b0, nb, fit);
-        if (st) { p->pend.active = false; if (c->res_in_use) { c->res_in_use = false; resident_release(c->device); } return st; }
+        if (st) { p->pend.active = false; resident_done(c); return st; }
         st = segment_end(p, rmsd_out ? rmsd_out + b0 : nullptr, status_out ? status_out + b0 : nullptr, R_out ? R_out + 9 * (size_t)b0 : nullptr);
         if (st == GR_E_HIP) return st;
         if (st != GR_OK && first_err == GR_OK) { first_err = st; e_idx = c->err_index; e_msg = c->err; e_cnt[0] = c->counts[0]; e_cnt[1] = c->counts[1]; }
@@ -1760,7 +1823,7 @@ int gr_rmsd_batch_begin(gr_rmsd_plan *p, uint32_t first_slot, uint32_t n, int fi
     (void)hipSetDevice(c->device);
     p->last_fallbacks = 0;
     st = segment_begin(p, first_slot, n, fit ? 1 : 0);
-    if (st) { p->pend.active = false; if (c->res_in_use) { c->res_in_use = false; resident_release(c->device); } } else { c->in_flight = p; c->in_flight_s0 = first_slot; c->in_flight_n = n; }
+    if (st) { p->pend.active = false; resident_done(c); } else { c->in_flight = p; c->in_flight_s0 = first_slot; c->in_flight_n = n; }
     return st;
 } catch (...) { return gr_abi_guard(); }
 int gr_rmsd_batch_end(gr_rmsd_plan *p, float *rmsd_out, int *status_out, float *R_out) try {

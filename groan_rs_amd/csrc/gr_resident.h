@@ -6,48 +6,51 @@
 // weights from the L2 / Infinity Cache.  But a 1e6-atom frame is 12 MB, and the chip has 256 CUs x 512 KiB of vector
 // registers + 160 KiB of LDS: the frame can WAIT ON CHIP for its rotation.
 //
-//   k_fit_resident   one launch for a whole batch: `n_stream` workgroups of 512 lanes, TWO 4-atom groups per lane
-//                    for the whole launch (its reference coordinates, masses and weights are loaded once and stay in
+//   k_fit_resident   one launch for a whole batch: `n_stream` workgroups of 512 lanes (8 waves, two per SIMD), TWO 4-atom groups
+//                    per lane for the whole launch (their reference coordinates, masses and weights are loaded once and stay in
 //                    registers); a lane walks the frames of the batch with its own groups:
-//                       sums stage, frame i      rows arrive (requested one frame earlier), image about the first atom, the
-//                                                18 sums + 12 extents of its 8 atoms -> wave reduce-scatter -> LDS; the last
-//                                                wave of the workgroup adds the 8 wave records in wave order and writes the
-//                                                workgroup's record: 31 tagged words (value | epoch << 32), no flag, no fence;
-//                                                the rows are parked: group A in LDS (24 KiB per frame and CU), group B in
-//                                                registers (12 per frame)
-//                       fit stage, frame i - 6   the frame's record (status, shift, R) has come back from a finalizer ->
-//                                                rows out of LDS / the register queue, wrap + rotate + translate, sum w |R q - p|^2, one
-//                                                non-temporal store per row
+//                       sums stage, frame i      rows arrive (requested one frame earlier), image v of every atom about the first
+//                                                atom of the selection, the 18 sums + 12 extents of the lane's 8 atoms -> wave
+//                                                reduce-scatter -> LDS; the last wave of the workgroup to arrive adds the 8 wave
+//                                                records in wave order and writes the workgroup's record: 31 tagged words
+//                                                (value | epoch << 32), no flag, no fence; the frame is parked: group A in LDS
+//                                                (24 KiB per frame and CU), group B in one of six register sets (12 registers)
+//                       fit stage, frame i - 6   the frame's record (status, shift, R, t0) has come back from a finalizer ->
+//                                                the parked data out of LDS / the register set, rotate + translate,
+//                                                sum w |R q - p|^2, one non-temporal store per row
 //                    + `n_fin` workgroups that stream nothing: finalizer j owns the frames j, j + n_fin, ...; its 8 waves
 //                    read 32 workgroup records each (one load round trip for the whole frame), re-reading until every
 //                    word carries the launch's tag; a fixed tree adds them in fp64, one lane closes the frame exactly as
 //                    the two-pass path does (gr_finalize_math: image proof, Kabsch rotation in fp64) and publishes
-//                    status | shift | R as 13 tagged 64-bit words.  The frame's box, first atom and host-side status are
+//                    status | shift | R | t0 as 16 tagged 64-bit words.  The frame's box, first atom and host-side status are
 //                    requested BEFORE the wait: the finalize is the latency the parked frames have to cover.
-// HBM traffic: 12 bytes per atom read + 12 written per frame = 24 (was 36), and nothing from the caches.
+// HBM traffic: 12 bytes per atom read + 12 written per frame = 24 (two passes: 36), and nothing from the caches.
 // Measured floor of that traffic at the same launch shape (tools/ceiling_bench.hip "resident copy"): 4.2 us per 1e6-atom frame.
 //
-// STATUS (round 2, MI355X, 1e6 atoms, 768-1024 frames per launch): 6.26 us per frame = 156-157 k frames/s with two groups per lane,
-// against 6.6-6.8 us = 148-151 k for the two-pass path in the same jobs: the pass is the DEFAULT for frames that fill at least
-// 15/16 of the chip (GR_TUNE_RESIDENT = 1; every CU runs its 4096 atoms' worth of a frame or idles, so a smaller frame is
-// better off with the two passes, whose time shrinks with it).  What bounds it is not memory (a lane waits 0.2-0.3 us per frame
-// for its rows; 24 MB per frame cross HBM where the floor of that traffic is 4.2 us) and not the
-// finalizers (no closing algebra at all: same time; 8 or 11 of them: same time) but the instruction streams themselves: every CU
-// runs ALL of a frame's arithmetic for its 4096 atoms within one frame period -- ~900 VALU + ~220 scalar instructions per wave
-// and frame (sums + the per-frame wave reduction + fit + the queue of parked register sets), two waves per SIMD that overlap
-// poorly: the VALU is busy 45-50 % of the time; the last wave of every workgroup (second on its SIMD, and the one that adds up
-// the workgroup's record) never waits for a record and sets the pace, the others wait for it a third of their time.  The two-pass
-// kernels run 20 % fewer VALU instructions per frame in total and keep 12-16 waves per CU in flight.
-// History of the measurement (us per frame): 1024 lanes x 1 group, three frames parked, records collected through seven
-// dependent round trips 9.1; tagged records read in one round trip, lane-swap reductions 9.1 (by then the spread between the
-// four waves of a SIMD was the longer pole); 512 lanes x 2 groups, four parked 8.4; six parked, register sets named by unrolling
-// x6 7.6 (the loop body, with the rare paths inlined in every copy, was ~140 KB of code against a 64 KB instruction cache); a
-// queue of register sets + the rare paths out of line 7.3; lane facts as bits of one register, waiting waves at low priority
-// 7.2; wave records of 32 floats and the parking moved out of the reduction lambdas 6.6; reductions on DPP moves instead of
-// ds_bpermute 6.5; an ordinary launch instead of hipLaunchCooperativeKernel 6.35; the per-frame sums as a 16-wide scatter + two
-// plain wave sums (the mass sum does not depend on the frame) 6.26.  Frames parked: 4 -> 7.0, 5 -> 6.6, 6 -> 6.5
-// (before the last step; LDS holds no more).  One group per lane (1024 lanes, five frames
-// parked, 128 registers): 9.3 -- the register budget spills into scratch memory inside the loop.
+// Two kernels, chosen by the host:
+//   V = true   the selection is the WHOLE system (the all-atom fit of the benchmark).  What is parked is not the frame's rows x but
+//              the image vectors v = image of (x - first atom) that the sums stage computes anyway.  Once the frame's image proof
+//              holds (gr_finalize_math: every atom inside the brick about the COM with 1e-3 nm to spare), the path's
+//              q = wrap(x + shift) - box centre (rmsd.rs:479-492) IS v - cv (cv = COM - first atom), so the fit stage is
+//                  R q = R v + t0,   t0 = -R cv (published by the finalizer),   z = R q + reference COM      (rmsd.rs:508-528)
+//              -- 18 packed FMAs per group instead of shift + three-stage wrap + range check + centre + rotation.
+//   V = false  any other contiguous selection: atoms outside it have no proven image, so rows are parked and the fit stage is the
+//              literal arithmetic of k_fit_pk (wrap with its general fall-back); waves without any atom of the selection skip
+//              the sums arithmetic.
+//
+// What set the pace in round 2 (6.26 us per frame) was not memory and not the finalizers but how the two waves of a SIMD shared
+// it: the hardware lets the OLDER wave issue first, so the older wave of each pair ran ahead until it had to wait for a record,
+// and the younger one -- whose sums every record needs -- was left the slots the older one did not use; on top of that the wave
+// that arrived last combined the workgroup's record through a chain of dependent LDS reads.  Round 3 (us per frame, 1e6 atoms,
+// 768 frames per launch): each wave publishes its progress and takes PRIORITY WHEN IT IS BEHIND ITS SIMD PARTNER 5.44; the
+// combine as independent loads 5.30; register sets picked by frame % 6 instead of a queue that moves up every iteration 5.27;
+// image vectors parked (V) + the sums of both groups in one chain of four FMAs ... (see DESIGN.md for the current figure).
+// History of round 2: 1024 lanes x 1 group, three frames parked 9.1; tagged records read in one round trip, lane-swap reductions
+// 9.1; 512 lanes x 2 groups, four parked 8.4; six parked, register sets named by unrolling x6 7.6 (the loop body did not fit the
+// instruction cache); a queue of register sets + the rare paths out of line 7.3; lane facts as bits of one register, waiting waves
+// at low priority 7.2; wave records of 32 floats 6.6; reductions on DPP moves instead of ds_bpermute 6.5; an ordinary launch
+// instead of hipLaunchCooperativeKernel 6.35; the per-frame sums as a 16-wide scatter + two plain wave sums 6.26.  The one-group
+// shape (1024 lanes, 128 registers, 9.3 us: spills inside the loop) was removed in round 3.
 //
 // Synchronisation.  All waiting is on data that a DIFFERENT workgroup produces, so every workgroup must become resident: the
 // pass is only chosen when the grid fits the device with one workgroup per CU (occupancy query at context creation), the host
@@ -57,60 +60,67 @@
 // within ~0.2 s the launch closes itself and every workgroup leaves before any frame is touched (the host then runs the
 // segment on the two-pass path).  Past the handshake every workgroup is on the chip and no wait can last.  The
 // launch is an ordinary one: hipLaunchCooperativeKernel -- the runtime's own co-residency check -- makes rocprofv3 --pmc fault
-// and crashed a process that issued it from two host threads at exit (ROCm 7.2).  Every wait is bounded (GR_RES_PATIENCE polls with s_sleep, a few
-// seconds): a wave that runs out of patience raises `abort` and leaves, every other wait then ends too, the grid drains and
-// the host reports the batch as failed.  Every word that crosses between workgroups carries the launch's epoch in its upper
-// half and is written / read as ONE 64-bit access at agent scope (bypassing the non-coherent caches): a reader can never
-// take a word of an older launch for a new one, nothing has to be cleared between launches, and no store has to be ordered
-// against another -- which keeps "s_waitcnt vmcnt(0)" (a drain of the wave's prefetched rows) out of the streaming loop.
-// Order within a workgroup is free (waves combine through LDS counters, no barrier); results do not depend on it: the wave
-// records are added in wave order by whichever wave arrives last, the workgroup records by a fixed tree in the finalizer.
+// and crashed a process that issued it from two host threads at exit (ROCm 7.2).  Every wait is bounded (GR_RES_PATIENCE polls
+// with s_sleep, a few seconds): a wave that runs out of patience raises `abort` and leaves, every other wait then ends too and
+// the grid drains.  Every streaming wave records how many frames it has fitted when it leaves (`progress`): after an abort the
+// host knows which frames are complete, which are untouched (those it redoes on the two-pass path) and which -- if a wave gave
+// up in the instant its record arrived for the others -- are torn.
+// Between workgroups: every word carries the launch's epoch in its upper half and is written / read as ONE 64-bit access at
+// agent scope (bypassing the non-coherent caches): a reader can never take a word of an older launch for a new one, nothing has
+// to be cleared between launches, and no store has to be ordered against another -- which keeps "s_waitcnt vmcnt(0)" (a drain
+// of the wave's prefetched rows) out of the streaming loop.
+// Inside a workgroup (no barrier in the loop): a wave writes its record to LDS, RELEASES it with a workgroup-scope fence
+// restricted to the LDS address space (one s_waitcnt lgkmcnt(0); the unrestricted fence would drain the prefetched rows too)
+// and bumps the frame's LDS counter; the wave whose bump completes the count ACQUIRES with the same kind of fence before it
+// reads the other waves' records.  Results do not depend on the order of arrival: the wave records are added in wave order by
+// whichever wave arrives last, the workgroup records by a fixed tree in the finalizer.
 // Precision: a workgroup record is the f32 sum of 16 f32 wave sums (4096 atoms; the two-pass path sums ~7800 atoms in f32
 // before it widens), the finalizer adds the workgroup records in fp64.
 #pragma once
+#include <type_traits>
 #include "gr_hot.h"
 
-// Shape: G = 4-atom groups per lane.  A workgroup always owns 1024 groups (4096 atoms), so it has 1024 / G lanes:
-//   G = 2   512 lanes, 8 waves (two per SIMD, up to 256 registers); group A of a frame waits in LDS, group B in a queue of
-//           register sets; 6 frames parked.  Halves the number of per-frame wave reductions.
-//   G = 1   1024 lanes, 16 waves (four per SIMD, 128 registers): more waves to cover one another's latencies; a frame waits
-//           first in a short queue of register sets, then in one of three LDS slots.
-// (The first version -- G = 1 with three LDS slots only, records collected through seven dependent round trips -- ran at 9.1 us.)
-template <int G> struct GrResShape {
-    static constexpr int LANES = 1024 / G, WAVES = LANES / 64;
-    static constexpr int KL = G == 2 ? 6 : 3;        // LDS slots (a slot = three rows of one group for every lane: 48 KiB / G ... x KL = 144 KiB)
-    static constexpr int KV = G == 2 ? 6 : 2;        // register sets in the queue (G = 2: group B for its whole wait; G = 1: the first KV frames of the wait)
-    static constexpr int K = G == 2 ? 6 : KL + KV;   // frames between the sums stage and the fit stage
-    static constexpr int R = G == 2 ? 8 : 6;         // ring of wave-record slots ( > K: no wave is more than K frames ahead of another)
-    static constexpr int PARK_F4 = KL * 3 * LANES;   // float4
+// Shape: a workgroup owns 1024 4-atom groups (4096 atoms) = 512 lanes x 2 groups; 8 waves, two per SIMD, up to 256 registers.
+struct GrResShape {
+    static constexpr int LANES = 512, WAVES = LANES / 64;
+    static constexpr int K = 6;                      // frames between the sums stage and the fit stage = LDS slots = register sets
+    static constexpr int R = 8;                      // ring of wave-record slots ( > K: no wave is more than K frames ahead of another)
+    static constexpr int PARK_F4 = K * 3 * LANES;    // float4: a slot = three rows of group A for every lane (24 KiB) x K = 144 KiB
     static constexpr int WSUM_F = R * WAVES * 32;    // float: a wave record = 19 sums + 12 extents
-    static constexpr int LDS_BYTES = PARK_F4 * 16 + WSUM_F * 4 + R * WAVES * 8 + 2 * R * 4;
+    static constexpr int LDS_BYTES = PARK_F4 * 16 + WSUM_F * 4 + R * WAVES * 8 + 2 * R * 4 + 2 * WAVES * 4;   // ... + fit sums, counters, progress and SIMD of every wave
     static constexpr int REC_PER_WAVE = 256 / WAVES, LANES_PER_REC = 64 / REC_PER_WAVE, WORDS_PER_LANE = 32 / LANES_PER_REC;   // finalizer
 };
 #ifndef GR_RES_SLEEP
-#define GR_RES_SLEEP 8              // s_sleep argument between two looks at a record that is not there yet (x 64 clocks)
+#define GR_RES_SLEEP 2              // s_sleep argument between two looks at a record that is not there yet (x 64 clocks)
 #endif
-#ifndef GR_RES_PRIO
-#define GR_RES_PRIO 1
+#ifndef GR_RES_BAL
+#define GR_RES_BAL 1               // priority by progress relative to the wave's SIMD partner (the wave that is behind runs first); 0: A/B only
 #endif
 #define GR_RES_GROUPS 1024         // 4-atom groups per workgroup
 #define GR_RES_MAX_FIN 8
 #define GR_RES_PATIENCE 3000000u   // polls (each ~1 us) before a wait gives up
 #define GR_RES_START_PATIENCE 200000u   // polls of the start handshake (~0.2 s: other kernels may hold CUs when the launch begins)
+#define GR_ST_ABORTED 102          /* internal: the frame's finalizer gave up (abort): the frame is untouched and is redone on the two-pass path */
 
 #define GR_RES_REC_WORDS 32         // tagged words per workgroup record: 0..18 sums, 19..30 extents (as maxima), 31 unused
 #define GR_RES_REC_PAD 32           // workgroup records per frame are padded to a multiple of this
 struct GrResCtl {
     unsigned long long *wgrec;     // [frames][n_stream padded][32] value | epoch << 32
-    unsigned long long *rec;       // [frames][16] value | epoch << 32: 0 status, 1..3 shift, 4..12 R (column-major)
+    unsigned long long *rec;       // [frames][16] value | epoch << 32: 0 status, 1..3 shift, 4..12 R (column-major), 13..15 t0 = -R (COM - first atom)
     uint32_t *abort;               // [3]: 0 abort (0 = fine), 1 workgroups that have started, 2 start verdict (0 open, 1 go, 2 never started);
                                    // words 1 and 2 are zeroed by the host before every launch
+    uint32_t *progress;            // [n_stream][8]: frames each streaming wave had fitted (or skipped: failed frames) when it left
     uint32_t epoch, n_stream, n_fin;
+    uint32_t test_abort_frame;     // tests: the finalizer of this frame raises `abort` instead of closing it (0xFFFFFFFF: never)
 };
 
 template <typename T> __device__ __forceinline__ T gr_ld_agent(const T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ float gr_first_f(float v) { return __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(v))); }
 __device__ __forceinline__ float gr_lane_f(unsigned long long v, int l) { return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l)); }
+// release / acquire of LDS data between the waves of a workgroup: fences restricted to the LDS address space -- the unrestricted
+// workgroup fence also waits for the wave's outstanding global loads (vmcnt(0)), i.e. for the rows it prefetched a frame ahead
+__device__ __forceinline__ void gr_lds_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); }
+__device__ __forceinline__ void gr_lds_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local"); }
 
 // one 4-atom group of a lane: which of its atoms belong to the selection, its reference rows, masses and weights (registers)
 // (the per-lane facts are bits of ONE register: seven `bool`s would be seven 64-bit lane masks -- 14 SGPRs per group held
@@ -119,7 +129,7 @@ enum { GR_RG_IN0 = 1u, GR_RG_IN1 = 2u, GR_RG_IN2 = 4u, GR_RG_IN3 = 8u, GR_RG_ANY
 struct GrResGroup {
     bool valid;        // wave-uniform: the group lies inside the slot
     uint32_t flags;
-    size_t b;          // float4 index of the group's first row inside a slot
+    uint32_t b;        // float4 index of the group's first row inside a slot
     GrP4 P;
     float4 mm, ww;
 };
@@ -163,7 +173,7 @@ __device__ __forceinline__ void gr_res_image_pair(gr_v2f &vx, gr_v2f &vy, gr_v2f
 
 // wrap(x + shift) - box centre, rotate, (sum w |R q - p|^2), + reference COM: the arithmetic of k_fit_pk for one group
 template <bool WMASS>
-__device__ __forceinline__ void gr_res_fit_group(const GrResGroup &G, const float4 &r0, const float4 &r1, const float4 &r2, const GrResRot &T, const GrBoxU &B,
+__device__ __forceinline__ void gr_res_fit_group(const GrResGroup &Gr, const float4 &r0, const float4 &r1, const float4 &r2, const GrResRot &T, const GrBoxU &B,
                                                  const GrBox *__restrict__ boxp, float cx, float cy, float cz, float4 *__restrict__ f4, float &rs) {
     GrP4 q = gr_pairs_rows(r0, r1, r2);
     q.x01 += gr_v2(T.sx); q.y01 += gr_v2(T.sy); q.z01 += gr_v2(T.sz); q.x23 += gr_v2(T.sx); q.y23 += gr_v2(T.sy); q.z23 += gr_v2(T.sz);
@@ -185,28 +195,29 @@ __device__ __forceinline__ void gr_res_fit_group(const GrResGroup &G, const floa
     n.x23 = gr_v2_fma(gr_v2(T.r02), q.z23, gr_v2_fma(gr_v2(T.r01), q.y23, gr_v2(T.r00) * q.x23));
     n.y23 = gr_v2_fma(gr_v2(T.r12), q.z23, gr_v2_fma(gr_v2(T.r11), q.y23, gr_v2(T.r10) * q.x23));
     n.z23 = gr_v2_fma(gr_v2(T.r22), q.z23, gr_v2_fma(gr_v2(T.r21), q.y23, gr_v2(T.r20) * q.x23));
-    if (G.flags & GR_RG_ANY) {   // sum w |R q - p|^2 (rmsd.rs:592-599); the weights of atoms outside the selection are zero
-        const gr_v2f w01 = WMASS ? gr_v2p(G.mm.x, G.mm.y) : gr_v2p(G.ww.x, G.ww.y), w23 = WMASS ? gr_v2p(G.mm.z, G.mm.w) : gr_v2p(G.ww.z, G.ww.w);
-        gr_v2f dx = n.x01 - G.P.x01, dy = n.y01 - G.P.y01, dz = n.z01 - G.P.z01;
+    if (Gr.flags & GR_RG_ANY) {   // sum w |R q - p|^2 (rmsd.rs:592-599); the weights of atoms outside the selection are zero
+        const gr_v2f w01 = WMASS ? gr_v2p(Gr.mm.x, Gr.mm.y) : gr_v2p(Gr.ww.x, Gr.ww.y), w23 = WMASS ? gr_v2p(Gr.mm.z, Gr.mm.w) : gr_v2p(Gr.ww.z, Gr.ww.w);
+        gr_v2f dx = n.x01 - Gr.P.x01, dy = n.y01 - Gr.P.y01, dz = n.z01 - Gr.P.z01;
         gr_v2f part = w01 * gr_v2_fma(dx, dx, gr_v2_fma(dy, dy, dz * dz));
-        dx = n.x23 - G.P.x23; dy = n.y23 - G.P.y23; dz = n.z23 - G.P.z23;
+        dx = n.x23 - Gr.P.x23; dy = n.y23 - Gr.P.y23; dz = n.z23 - Gr.P.z23;
         part = gr_v2_fma(w23, gr_v2_fma(dx, dx, gr_v2_fma(dy, dy, dz * dz)), part);
         rs += part.x + part.y;
     }
     n.x01 += gr_v2(cx); n.y01 += gr_v2(cy); n.z01 += gr_v2(cz); n.x23 += gr_v2(cx); n.y23 += gr_v2(cy); n.z23 += gr_v2(cz);
     float4 o0, o1, o2;
     gr_rows_pairs(n, o0, o1, o2);
-    gr_stream_store(f4 + G.b, o0); gr_stream_store(f4 + G.b + 64, o1); gr_stream_store(f4 + G.b + 128, o2);
+    gr_stream_store(f4 + Gr.b, o0); gr_stream_store(f4 + Gr.b + 64, o1); gr_stream_store(f4 + Gr.b + 128, o2);
 }
 
-// UBOX: every frame of the launch has the same box (the host compared them): its constants are loaded once, not per frame
-template <bool WMASS, bool UBOX, int G>
-__global__ __launch_bounds__(GrResShape<G>::LANES) void k_fit_resident(
+// UBOX: every frame of the launch has the same box (the host compared them): its constants are loaded once, not per frame.
+// V: the selection is the whole system -> image vectors are parked (see the header of this file).
+template <bool WMASS, bool UBOX, bool V>
+__global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
     float *__restrict__ frames, size_t frame_stride, uint32_t first_slot, uint32_t nframes, uint32_t n_atoms,
     const float *__restrict__ masses, GrSel sel, const GrBox *__restrict__ boxes, GrPlanDev plan,
     GrFrameState *state, double *__restrict__ fit_partials, GrResCtl ctl) {
-    typedef GrResShape<G> S;
-    constexpr uint32_t LANES = S::LANES, WAVES = S::WAVES, K = S::K, KL = S::KL, KV = S::KV, R = S::R;
+    typedef GrResShape S;
+    constexpr uint32_t LANES = S::LANES, WAVES = S::WAVES, K = S::K, R = S::R;
     extern __shared__ float4 smem[];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t n_pad = (ctl.n_stream + GR_RES_REC_PAD - 1u) & ~(uint32_t)(GR_RES_REC_PAD - 1u);
@@ -237,6 +248,9 @@ __global__ __launch_bounds__(GrResShape<G>::LANES) void k_fit_resident(
     if (blockIdx.x >= ctl.n_stream) {
         constexpr uint32_t RPW = S::REC_PER_WAVE, LPR = S::LANES_PER_REC, W = S::WORDS_PER_LANE;
         double *wtot = reinterpret_cast<double *>(smem);              // [WAVES][32] + [32] totals
+        uint32_t *gave_up = reinterpret_cast<uint32_t *>(wtot + (WAVES + 1) * 32u);   // some wave of this workgroup ran out of patience
+        if (tid == 0) *gave_up = 0u;
+        __syncthreads();
         const uint32_t r = wave * RPW + lane / LPR, part = lane % LPR;   // this lane's record and its W words
         const unsigned long long tagv = (unsigned long long)ctl.epoch << 32;
         for (uint32_t f = blockIdx.x - ctl.n_stream; f < nframes; f += ctl.n_fin) {
@@ -251,7 +265,8 @@ __global__ __launch_bounds__(GrResShape<G>::LANES) void k_fit_resident(
             const unsigned long long *src = ctl.wgrec + ((size_t)f * n_pad + r) * GR_RES_REC_WORDS + part * W;
             unsigned long long w[W];
             uint32_t polls = 0;
-            for (;;) {
+            if (f == ctl.test_abort_frame) { if (lane == 0) { gr_st_agent(ctl.abort, 1u); __hip_atomic_store(gave_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } polls = 0xFFFFFFFFu; }
+            while (polls != 0xFFFFFFFFu) {
                 bool ok = true;
                 if (r < ctl.n_stream) {
 #pragma unroll
@@ -260,10 +275,14 @@ __global__ __launch_bounds__(GrResShape<G>::LANES) void k_fit_resident(
                     for (uint32_t k = 0; k < W; ++k) ok = ok && ((uint32_t)(w[k] >> 32) == ctl.epoch || part * W + k == 31u);
                 }
                 if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
-                if (++polls > GR_RES_PATIENCE || ((polls & 255u) == 0 && gr_ld_agent(ctl.abort) != 0u)) { if (lane == 0) gr_st_agent(ctl.abort, 1u); polls = 0xFFFFFFFFu; break; }
+                if (++polls > GR_RES_PATIENCE || ((polls & 255u) == 0 && gr_ld_agent(ctl.abort) != 0u)) {
+                    if (lane == 0) { gr_st_agent(ctl.abort, 1u); __hip_atomic_store(gave_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+                    polls = 0xFFFFFFFFu;
+                    break;
+                }
                 __builtin_amdgcn_s_sleep(1);
             }
-            // (a wave that gave up still meets the others at the barriers; the abort word ends the launch)
+            // (a wave that gave up still meets the others at the barriers; the frame is then published as ABORTED, never as closed)
             // sums in fp64, extents as maxima: word index = part * W + k; 0..18 sums, 19..30 maxima
             double v[W];
 #pragma unroll
@@ -285,7 +304,7 @@ __global__ __launch_bounds__(GrResShape<G>::LANES) void k_fit_resident(
 #pragma unroll
                 for (uint32_t k = 0; k < W; ++k) wtot[wave * 32u + lane * W + k] = v[k];
             }
-            __syncthreads();
+            __syncthreads();                                          // (also publishes gave_up)
             if (wave == 0 && lane < 31u) {   // totals over the waves, in wave order: lane k owns word k
                 double a = wtot[lane];
                 const bool mx = lane >= 19u;
@@ -296,8 +315,11 @@ __global__ __launch_bounds__(GrResShape<G>::LANES) void k_fit_resident(
             gr_wave_sync();
             if (wave == 0 && lane == 0) {
                 GrFrameState &st = state[f];
-                if (pre_status == 0 && polls != 0xFFFFFFFFu) {
-                    const double *t = wtot + WAVES * 32u;
+                const bool lost = *gave_up != 0u;                      // ANY wave of the workgroup gave up on a record of this or an earlier frame
+                const double *t = wtot + WAVES * 32u;
+                if (lost) {
+                    if (pre_status == 0) st.status = GR_ST_ABORTED;
+                } else if (pre_status == 0) {
                     double acc[GR_ACC_K];
 #pragma unroll
                     for (int k = 0; k < GR_ACC_K; ++k) acc[k] = 0.0;
@@ -311,12 +333,20 @@ __global__ __launch_bounds__(GrResShape<G>::LANES) void k_fit_resident(
                     gr_finalize_math<0, true, false>(acc, mn, mx3, fmn, fmx, GR_NOIDX, GR_NOIDX, lb, plan, g, sel.n, st);
                 }
                 unsigned long long *o = ctl.rec + (size_t)f * 16;
-                // (a finalizer that gave up publishes a failed frame: the streaming waves leave it unmodified and move on)
-                gr_st_agent(o + 0, tagv | (uint32_t)(polls != 0xFFFFFFFFu ? st.status : 1));
+                // (a frame that was not closed is published as failed: the streaming waves leave it unmodified and move on)
+                gr_st_agent(o + 0, tagv | (uint32_t)st.status);
 #pragma unroll
                 for (int k = 0; k < 3; ++k) gr_st_agent(o + 1 + k, tagv | __float_as_uint(st.shift[k]));
 #pragma unroll
                 for (int k = 0; k < 9; ++k) gr_st_agent(o + 4 + k, tagv | __float_as_uint(st.R[k]));
+                // t0 = -R cv, cv = COM - first atom (the sums are relative to the first atom): what the V kernel adds to R v; formed from
+                // the f32 R that every wave applies, so that R v + t0 is R (v - cv) to rounding
+                const double cvx = t[1] / t[0], cvy = t[2] / t[0], cvz = t[3] / t[0];
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    const float t0 = (float)(-((double)st.R[a] * cvx + (double)st.R[3 + a] * cvy + (double)st.R[6 + a] * cvz));
+                    gr_st_agent(o + 13 + a, tagv | __float_as_uint(t0));
+                }
             }
             __syncthreads();                                          // wtot is free again
         }
@@ -326,18 +356,33 @@ __global__ __launch_bounds__(GrResShape<G>::LANES) void k_fit_resident(
     // ------------------------------------------------------------------------------------------ streaming workgroups
     const uint32_t ngroups = ((n_atoms + 255u) >> 8) << 6;            // the slot is padded to whole tiles (a multiple of 64 groups)
     const uint32_t wg = blockIdx.x, base = wg * GR_RES_GROUPS;
-    if (base + wave * 64u >= ngroups) return;                         // every chunk of this wave lies behind the last tile
+    if (base + wave * 64u >= ngroups) {                               // every chunk of this wave lies behind the last tile: nothing to fit
+        if (lane == 0) ctl.progress[wg * WAVES + wave] = nframes;
+        return;
+    }
     const uint32_t n_waves = min(WAVES, (ngroups - base) >> 6);
     float4 *park = smem;
     float *wsum = reinterpret_cast<float *>(smem + S::PARK_F4);
     double *fsum = reinterpret_cast<double *>(wsum + S::WSUM_F);
     uint32_t *cnt_s = reinterpret_cast<uint32_t *>(fsum + R * WAVES), *cnt_f = cnt_s + R;
+    uint32_t *prog = cnt_f + R, *simd_of = prog + WAVES;             // iterations each wave has begun; the SIMD each wave runs on
     if (tid < 2 * R) cnt_s[tid] = 0u;
+    if (lane == 0) { prog[wave] = 0u; simd_of[wave] = (uint32_t)__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4) /* HW_ID.SIMD_ID */; }
     __syncthreads();                                                  // the only barrier: before the first frame
+    // the other wave of this workgroup on the same SIMD: the two share the SIMD's issue slots, and whichever of them is BEHIND gets
+    // them first (see `balance` below)
+    uint32_t partner = WAVES;
+    if (GR_RES_BAL) {
+        const uint32_t mine = simd_of[wave];
+        uint32_t found = 0;
+        for (uint32_t w = 0; w < n_waves; ++w) if (w != wave && simd_of[w] == mine) { partner = w; ++found; }
+        if (found != 1u) partner = WAVES;
+        partner = (uint32_t)__builtin_amdgcn_readfirstlane((int)partner);
+    }
 
     const uint32_t first = sel.start, last = sel.start + sel.n, g0 = sel.g0 << 6;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    // the lane's groups: A = chunk `wave` of the workgroup's first LANES groups, B (G = 2) = the same chunk of its second LANES
+    // the lane's groups: A = chunk `wave` of the workgroup's first LANES groups, B = the same chunk of its second LANES
     auto setup = [&](uint32_t g, GrResGroup &Gr) {
         const uint32_t i0 = g << 2;
         Gr.valid = g < ngroups;                                       // wave-uniform
@@ -345,7 +390,7 @@ __global__ __launch_bounds__(GrResShape<G>::LANES) void k_fit_resident(
         const bool in2 = Gr.valid && (i0 + 2u >= first) && (i0 + 2u < last), in3 = Gr.valid && (i0 + 3u >= first) && (i0 + 3u < last);
         const bool in_sel = in0 || in1 || in2 || in3, full = in0 && in1 && in2 && in3;
         Gr.flags = (in0 ? GR_RG_IN0 : 0u) | (in1 ? GR_RG_IN1 : 0u) | (in2 ? GR_RG_IN2 : 0u) | (in3 ? GR_RG_IN3 : 0u) | (in_sel ? GR_RG_ANY : 0u) | (full ? GR_RG_FULL : 0u);
-        Gr.b = gr_row_index(Gr.valid ? g : 0u, 0);
+        Gr.b = (uint32_t)gr_row_index(Gr.valid ? g : 0u, 0);
         float4 pa = zero4, pb = zero4, pc = zero4;
         Gr.mm = zero4; Gr.ww = zero4;
         if (in_sel) {
@@ -363,10 +408,12 @@ __global__ __launch_bounds__(GrResShape<G>::LANES) void k_fit_resident(
     };
     GrResGroup GA, GB;
     setup(base + tid, GA);
-    if (G == 2) setup(base + LANES + tid, GB); else { GB.valid = false; GB.flags = 0u; GB.b = 0; GB.mm = GB.ww = zero4; GB.P = gr_pairs_rows(zero4, zero4, zero4); }
+    setup(base + LANES + tid, GB);
     const float cx = plan.ref_com[0], cy = plan.ref_com[1], cz = plan.ref_com[2];
-    // sum of the masses of the wave's atoms inside the selection: the same for every frame of the launch
-    const float m_wave = gr_wave_allsum_f32(((GA.mm.x + GA.mm.y) + (GA.mm.z + GA.mm.w)) + ((GB.mm.x + GB.mm.y) + (GB.mm.z + GB.mm.w)));
+    // sum of the masses of the wave's atoms inside the selection: the same for every frame of the launch (an SGPR)
+    const float m_wave = gr_first_f(gr_wave_allsum_f32(((GA.mm.x + GA.mm.y) + (GA.mm.z + GA.mm.w)) + ((GB.mm.x + GB.mm.y) + (GB.mm.z + GB.mm.w))));
+    // does the wave hold any atom of the selection?  (V: always; otherwise most waves of a small selection do not, and skip the sums arithmetic)
+    const bool wave_sel = V || __builtin_amdgcn_ballot_w64(((GA.flags | GB.flags) & GR_RG_ANY) != 0u) != 0ull;
 
     struct Rows { float4 r0, r1, r2; };
     struct Landing { Rows a, b; float gx, gy, gz; };
@@ -374,141 +421,245 @@ __global__ __launch_bounds__(GrResShape<G>::LANES) void k_fit_resident(
         const float *xyz = frames + (size_t)(first_slot + f) * frame_stride;
         const float4 *f4 = reinterpret_cast<const float4 *>(xyz);
         L.a.r0 = gr_stream_load(f4 + GA.b); L.a.r1 = gr_stream_load(f4 + GA.b + 64); L.a.r2 = gr_stream_load(f4 + GA.b + 128);
-        if (G == 2 && GB.valid) { L.b.r0 = gr_stream_load(f4 + GB.b); L.b.r1 = gr_stream_load(f4 + GB.b + 64); L.b.r2 = gr_stream_load(f4 + GB.b + 128); }
+        if (GB.valid) { L.b.r0 = gr_stream_load(f4 + GB.b); L.b.r1 = gr_stream_load(f4 + GB.b + 64); L.b.r2 = gr_stream_load(f4 + GB.b + 128); }
         gr_pos_load(xyz, first, L.gx, L.gy, L.gz);                    // provisional centre: the first atom of the selection
     };
-    auto request_rec = [&](uint32_t f) -> unsigned long long { return lane < 13u ? gr_ld_agent(ctl.rec + (size_t)f * 16 + lane) : 0ull; };
+    auto request_rec = [&](uint32_t f) -> unsigned long long { return lane < 16u ? gr_ld_agent(ctl.rec + (size_t)f * 16 + lane) : 0ull; };
     bool bail = false;
+    uint32_t n_fitted = 0;                                             // frames whose fit stage this wave has been through (-> ctl.progress)
+    // Two waves share a SIMD, and the frame rate of the whole launch is the rate of its SLOWEST wave (every frame's record needs
+    // every wave's sums).  Left to the hardware's tie-break -- the older wave first -- the older wave of each pair runs ahead until
+    // it has to wait for a record, and the younger one gets the issue slots that are left over.  So each wave publishes how many
+    // iterations it has begun, looks at its partner's count once per iteration, and takes priority 3 when it is behind, 2 level, 1 ahead
+    // (0 while it polls for a record): the pair advances together and neither waits for the other.
+    // (Measured: 6.26 -> 5.44 us per frame.  The counts are hints: relaxed LDS accesses, nothing depends on their order.)
+    uint32_t my_prio = 2u;
+    auto set_prio = [&]() {
+        if (my_prio == 3u) __builtin_amdgcn_s_setprio(3); else if (my_prio == 2u) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1);
+    };
+    auto balance = [&](uint32_t i) {
+        if (!GR_RES_BAL || partner >= WAVES) return;
+        if (lane == 0) __hip_atomic_store(prog + wave, i + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const uint32_t pp = (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(prog + partner, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+        my_prio = pp > i + 1u ? 3u : (pp == i + 1u ? 2u : 1u);
+        set_prio();
+    };
 
-    // the sums of one group added to the lane's 19 + 12 values
-    auto group_sums = [&](const GrResGroup &Gr, const Rows &rw, const GrBoxU &B, const GrBox *boxp,
-                          float gx, float gy, float gz, float (&s32)[32], float (&e32)[32], bool init) {
+    // the image vectors of one group: v = image of (x - first atom) nearest to the first atom
+    auto images = [&](const GrResGroup &Gr, const Rows &rw, const GrBoxU &B, const GrBox *boxp, float gx, float gy, float gz) -> GrP4 {
         GrP4 q = gr_pairs_rows(rw.r0, rw.r1, rw.r2);
-        // atoms outside the selection become copies of the first atom: v = 0 adds nothing and lies inside every extent (a whole
-        // wave of complete groups -- every wave but the two at the ends of the selection -- skips this on one scalar branch)
+        // atoms outside the selection (V: the pad atoms behind the last one) become copies of the first atom: v = 0 adds nothing and
+        // lies inside every extent (a whole wave of complete groups skips this on one scalar branch)
         if (__builtin_amdgcn_ballot_w64((Gr.flags & GR_RG_FULL) == 0u) != 0ull) {
             if (!(Gr.flags & GR_RG_IN0)) { q.x01.x = gx; q.y01.x = gy; q.z01.x = gz; }
             if (!(Gr.flags & GR_RG_IN1)) { q.x01.y = gx; q.y01.y = gy; q.z01.y = gz; }
             if (!(Gr.flags & GR_RG_IN2)) { q.x23.x = gx; q.y23.x = gy; q.z23.x = gz; }
             if (!(Gr.flags & GR_RG_IN3)) { q.x23.y = gx; q.y23.y = gy; q.z23.y = gz; }
         }
-        gr_v2f vxa = q.x01 - gr_v2(gx), vya = q.y01 - gr_v2(gy), vza = q.z01 - gr_v2(gz);
-        gr_v2f vxb = q.x23 - gr_v2(gx), vyb = q.y23 - gr_v2(gy), vzb = q.z23 - gr_v2(gz);
-        gr_res_image_pair(vxa, vya, vza, B, boxp);
-        gr_res_image_pair(vxb, vyb, vzb, B, boxp);
-        auto fold = [](gr_v2f v) { return v.x + v.y; };
-        auto acc = [&](int k, float x) { s32[k - 1] = init ? x : s32[k - 1] + x; };   // value k (1..18) lives at s32[k - 1]; value 0 = sum m is not per frame
-        auto ext = [&](int k, float x) { e32[k] = init ? x : gr_fmaxf(e32[k], x); };
-        const gr_v2f ma = gr_v2p(Gr.mm.x, Gr.mm.y), mb = gr_v2p(Gr.mm.z, Gr.mm.w);
-        acc(1, fold(gr_v2_fma(ma, vxa, mb * vxb))); acc(2, fold(gr_v2_fma(ma, vya, mb * vyb))); acc(3, fold(gr_v2_fma(ma, vza, mb * vzb)));
-        acc(4, fold(gr_v2_fma(Gr.P.x01, vxa, Gr.P.x23 * vxb))); acc(5, fold(gr_v2_fma(Gr.P.x01, vya, Gr.P.x23 * vyb))); acc(6, fold(gr_v2_fma(Gr.P.x01, vza, Gr.P.x23 * vzb)));
-        acc(7, fold(gr_v2_fma(Gr.P.y01, vxa, Gr.P.y23 * vxb))); acc(8, fold(gr_v2_fma(Gr.P.y01, vya, Gr.P.y23 * vyb))); acc(9, fold(gr_v2_fma(Gr.P.y01, vza, Gr.P.y23 * vzb)));
-        acc(10, fold(gr_v2_fma(Gr.P.z01, vxa, Gr.P.z23 * vxb))); acc(11, fold(gr_v2_fma(Gr.P.z01, vya, Gr.P.z23 * vyb))); acc(12, fold(gr_v2_fma(Gr.P.z01, vza, Gr.P.z23 * vzb)));
-        ext(0, -gr_fminf(gr_min3f(vxa.x, vxa.y, vxb.x), vxb.y)); ext(1, -gr_fminf(gr_min3f(vya.x, vya.y, vyb.x), vyb.y)); ext(2, -gr_fminf(gr_min3f(vza.x, vza.y, vzb.x), vzb.y));
-        ext(3, gr_fmaxf(gr_max3f(vxa.x, vxa.y, vxb.x), vxb.y)); ext(4, gr_fmaxf(gr_max3f(vya.x, vya.y, vyb.x), vyb.y)); ext(5, gr_fmaxf(gr_max3f(vza.x, vza.y, vzb.x), vzb.y));
-        // fractional coordinates of v: moments + extents feed the image proof (gr_finalize_math)
-        const gr_v2f fca = vza * gr_v2(B.icz), fcb = vzb * gr_v2(B.icz);
-        const gr_v2f fba = gr_v2_fma(-fca, gr_v2(B.cy), vya) * gr_v2(B.iby), fbb = gr_v2_fma(-fcb, gr_v2(B.cy), vyb) * gr_v2(B.iby);
-        const gr_v2f faa = gr_v2_fma(-fca, gr_v2(B.cx), gr_v2_fma(-fba, gr_v2(B.bx), vxa)) * gr_v2(B.iax), fab = gr_v2_fma(-fcb, gr_v2(B.cx), gr_v2_fma(-fbb, gr_v2(B.bx), vxb)) * gr_v2(B.iax);
-        acc(13, fold(faa + fab)); acc(14, fold(fba + fbb)); acc(15, fold(fca + fcb));
-        acc(16, fold(gr_v2_fma(faa, faa, fab * fab))); acc(17, fold(gr_v2_fma(fba, fba, fbb * fbb))); acc(18, fold(gr_v2_fma(fca, fca, fcb * fcb)));
-        ext(6, -gr_fminf(gr_min3f(faa.x, faa.y, fab.x), fab.y)); ext(7, -gr_fminf(gr_min3f(fba.x, fba.y, fbb.x), fbb.y)); ext(8, -gr_fminf(gr_min3f(fca.x, fca.y, fcb.x), fcb.y));
-        ext(9, gr_fmaxf(gr_max3f(faa.x, faa.y, fab.x), fab.y)); ext(10, gr_fmaxf(gr_max3f(fba.x, fba.y, fbb.x), fbb.y)); ext(11, gr_fmaxf(gr_max3f(fca.x, fca.y, fcb.x), fcb.y));
+        GrP4 v;
+        v.x01 = q.x01 - gr_v2(gx); v.y01 = q.y01 - gr_v2(gy); v.z01 = q.z01 - gr_v2(gz);
+        v.x23 = q.x23 - gr_v2(gx); v.y23 = q.y23 - gr_v2(gy); v.z23 = q.z23 - gr_v2(gz);
+        gr_res_image_pair(v.x01, v.y01, v.z01, B, boxp);
+        gr_res_image_pair(v.x23, v.y23, v.z23, B, boxp);
+        return v;
     };
 
-    // ---- the sums stage of frame i (rows in L): the lane's 19 + 12 values -> wave (reduce-scatter) -> workgroup (LDS, the last
-    // wave to arrive adds the wave records in wave order) -> the frame's tagged record
-    auto sums = [&](uint32_t i, const Landing &L, const GrBoxU &B) {
+    // ---- the sums stage of frame i (rows in L): the lane's 18 + 12 values -> wave (reduce-scatter) -> workgroup (LDS, the last
+    // wave to arrive adds the wave records in wave order) -> the frame's tagged record.  V: `va`, `vb` receive the image vectors.
+    auto sums = [&](uint32_t i, const Landing &L, const GrBoxU &B, Rows &va, Rows &vb) {
         float s32[32], e32[32];
 #pragma unroll
         for (int k = 0; k < 32; ++k) { s32[k] = 0.0f; e32[k] = -3.0e38f; }
-        {
+        if (wave_sel) {
             const GrBox *boxp = boxes + first_slot + i;
             const float gx = gr_first_f(L.gx), gy = gr_first_f(L.gy), gz = gr_first_f(L.gz);    // wave-uniform: SGPR operands
-            group_sums(GA, L.a, B, boxp, gx, gy, gz, s32, e32, true);
-            if (G == 2 && GB.valid) group_sums(GB, L.b, B, boxp, gx, gy, gz, s32, e32, false);
+            // the lane's two groups together (a group that does not exist contributes v = 0 with zero mass and reference): every sum
+            // is ONE chain of four packed FMAs over the 8 atoms + one fold, every extent three v_min3 / v_max3 + one v_min / v_max
+            const GrP4 a = images(GA, L.a, B, boxp, gx, gy, gz);
+            GrP4 b;
+            b.x01 = b.y01 = b.z01 = b.x23 = b.y23 = b.z23 = gr_v2(0.0f);
+            if (GB.valid) b = images(GB, L.b, B, boxp, gx, gy, gz);
+            if (V) { gr_rows_pairs(a, va.r0, va.r1, va.r2); gr_rows_pairs(b, vb.r0, vb.r1, vb.r2); }
+            auto fold = [](gr_v2f v) { return v.x + v.y; };
+            auto dot8 = [&](gr_v2f w0, gr_v2f w1, gr_v2f w2, gr_v2f w3, gr_v2f x0, gr_v2f x1, gr_v2f x2, gr_v2f x3) {
+                return fold(gr_v2_fma(w3, x3, gr_v2_fma(w2, x2, gr_v2_fma(w1, x1, w0 * x0))));
+            };
+            auto min8 = [](gr_v2f p0, gr_v2f p1, gr_v2f p2, gr_v2f p3) { return gr_fminf(gr_min3f(gr_min3f(gr_min3f(p0.x, p0.y, p1.x), p1.y, p2.x), p2.y, p3.x), p3.y); };
+            auto max8 = [](gr_v2f p0, gr_v2f p1, gr_v2f p2, gr_v2f p3) { return gr_fmaxf(gr_max3f(gr_max3f(gr_max3f(p0.x, p0.y, p1.x), p1.y, p2.x), p2.y, p3.x), p3.y); };
+            // fractional coordinates of v, axis by axis (c, then b, then a: each axis' values are dead once its four results are
+            // formed -- the lane is close to its register budget here): moments + extents feed the image proof (gr_finalize_math)
+            {
+                const gr_v2f icz = gr_v2(B.icz), ncy = gr_v2(-B.cy), ncx = gr_v2(-B.cx);
+                const gr_v2f fc0 = a.z01 * icz, fc1 = a.z23 * icz, fc2 = b.z01 * icz, fc3 = b.z23 * icz;
+                gr_v2f ub0 = gr_v2_fma(fc0, ncy, a.y01), ub1 = gr_v2_fma(fc1, ncy, a.y23), ub2 = gr_v2_fma(fc2, ncy, b.y01), ub3 = gr_v2_fma(fc3, ncy, b.y23);
+                gr_v2f ua0 = gr_v2_fma(fc0, ncx, a.x01), ua1 = gr_v2_fma(fc1, ncx, a.x23), ua2 = gr_v2_fma(fc2, ncx, b.x01), ua3 = gr_v2_fma(fc3, ncx, b.x23);
+                s32[14] = fold((fc0 + fc1) + (fc2 + fc3)); s32[17] = dot8(fc0, fc1, fc2, fc3, fc0, fc1, fc2, fc3);
+                e32[8] = -min8(fc0, fc1, fc2, fc3); e32[11] = max8(fc0, fc1, fc2, fc3);
+                const gr_v2f iby = gr_v2(B.iby), nbx = gr_v2(-B.bx);
+                ub0 *= iby; ub1 *= iby; ub2 *= iby; ub3 *= iby;                       // = fb
+                ua0 = gr_v2_fma(ub0, nbx, ua0); ua1 = gr_v2_fma(ub1, nbx, ua1); ua2 = gr_v2_fma(ub2, nbx, ua2); ua3 = gr_v2_fma(ub3, nbx, ua3);
+                s32[13] = fold((ub0 + ub1) + (ub2 + ub3)); s32[16] = dot8(ub0, ub1, ub2, ub3, ub0, ub1, ub2, ub3);
+                e32[7] = -min8(ub0, ub1, ub2, ub3); e32[10] = max8(ub0, ub1, ub2, ub3);
+                const gr_v2f iax = gr_v2(B.iax);
+                ua0 *= iax; ua1 *= iax; ua2 *= iax; ua3 *= iax;                       // = fa
+                s32[12] = fold((ua0 + ua1) + (ua2 + ua3)); s32[15] = dot8(ua0, ua1, ua2, ua3, ua0, ua1, ua2, ua3);
+                e32[6] = -min8(ua0, ua1, ua2, ua3); e32[9] = max8(ua0, ua1, ua2, ua3);
+            }
+            e32[0] = -min8(a.x01, a.x23, b.x01, b.x23); e32[1] = -min8(a.y01, a.y23, b.y01, b.y23); e32[2] = -min8(a.z01, a.z23, b.z01, b.z23);
+            e32[3] = max8(a.x01, a.x23, b.x01, b.x23); e32[4] = max8(a.y01, a.y23, b.y01, b.y23); e32[5] = max8(a.z01, a.z23, b.z01, b.z23);
+            const gr_v2f m0 = gr_v2p(GA.mm.x, GA.mm.y), m1 = gr_v2p(GA.mm.z, GA.mm.w), m2 = gr_v2p(GB.mm.x, GB.mm.y), m3 = gr_v2p(GB.mm.z, GB.mm.w);
+            // value k (1..18) lives at s32[k - 1]; value 0 = sum m does not depend on the frame (m_wave)
+            s32[0] = dot8(m0, m1, m2, m3, a.x01, a.x23, b.x01, b.x23); s32[1] = dot8(m0, m1, m2, m3, a.y01, a.y23, b.y01, b.y23); s32[2] = dot8(m0, m1, m2, m3, a.z01, a.z23, b.z01, b.z23);
+            s32[3] = dot8(GA.P.x01, GA.P.x23, GB.P.x01, GB.P.x23, a.x01, a.x23, b.x01, b.x23); s32[4] = dot8(GA.P.x01, GA.P.x23, GB.P.x01, GB.P.x23, a.y01, a.y23, b.y01, b.y23);
+            s32[5] = dot8(GA.P.x01, GA.P.x23, GB.P.x01, GB.P.x23, a.z01, a.z23, b.z01, b.z23);
+            s32[6] = dot8(GA.P.y01, GA.P.y23, GB.P.y01, GB.P.y23, a.x01, a.x23, b.x01, b.x23); s32[7] = dot8(GA.P.y01, GA.P.y23, GB.P.y01, GB.P.y23, a.y01, a.y23, b.y01, b.y23);
+            s32[8] = dot8(GA.P.y01, GA.P.y23, GB.P.y01, GB.P.y23, a.z01, a.z23, b.z01, b.z23);
+            s32[9] = dot8(GA.P.z01, GA.P.z23, GB.P.z01, GB.P.z23, a.x01, a.x23, b.x01, b.x23); s32[10] = dot8(GA.P.z01, GA.P.z23, GB.P.z01, GB.P.z23, a.y01, a.y23, b.y01, b.y23);
+            s32[11] = dot8(GA.P.z01, GA.P.z23, GB.P.z01, GB.P.z23, a.z01, a.z23, b.z01, b.z23);
         }
-        // 18 sums per frame (the 19th, sum m, does not depend on the frame: m_wave below) = a reduce-scatter of 16 + two plain wave
-        // sums (a 32-wide scatter would push 14 zeros through its two widest steps); 12 extents = a 16-wide scatter with max
-        const float tot = gr_wave_sum_scatter16(s32, lane);                       // values 1..16
-        const float t17 = gr_wave_allsum_f32(s32[16]), t18 = gr_wave_allsum_f32(s32[17]);
-        const float emax = gr_wave_max_scatter16(e32, lane);
         const uint32_t rs = i % R;
         float *mine = wsum + (rs * WAVES + wave) * 32;
-        if ((lane & 3u) == 0) mine[1 + (lane >> 2)] = tot;                         // sums 1..16
-        if (lane == 1u) { mine[0] = m_wave; mine[17] = t17; mine[18] = t18; }      // sum m (the same every frame), sums 17, 18
-        if ((lane & 3u) == 0 && lane < 48u) mine[19 + (lane >> 2)] = emax;         // extents 0..11
-        gr_wave_sync();
+        if (wave_sel) {
+            // 18 sums per frame (the 19th, sum m, does not depend on the frame: m_wave) = a reduce-scatter of 16 + two plain wave
+            // sums (a 32-wide scatter would push 14 zeros through its two widest steps); 12 extents = a 16-wide scatter with max
+            const float tot = gr_wave_sum_scatter16(s32, lane);                       // values 1..16
+            const float t17 = gr_wave_allsum_f32(s32[16]), t18 = gr_wave_allsum_f32(s32[17]);
+            const float emax = gr_wave_max_scatter16(e32, lane);
+            if ((lane & 3u) == 0) mine[1 + (lane >> 2)] = tot;                         // sums 1..16
+            if (lane == 1u) { mine[0] = m_wave; mine[17] = t17; mine[18] = t18; }      // sum m (the same every frame), sums 17, 18
+            if ((lane & 3u) == 0 && lane < 48u) mine[19 + (lane >> 2)] = emax;         // extents 0..11
+        } else if (lane < 31u) {
+            mine[lane] = lane < 19u ? 0.0f : -3.0e38f;                                 // nothing of the selection here: the neutral record
+        }
+        // hand-off to the wave that completes the count: the record is RELEASED before the arrival is counted (LDS-only fence: one
+        // s_waitcnt lgkmcnt(0)); the completing wave ACQUIRES before it reads the other waves' records
+        gr_lds_release();
         uint32_t old = 0;
         if (lane == 0) old = __hip_atomic_fetch_add(cnt_s + rs, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if ((uint32_t)__builtin_amdgcn_readfirstlane((int)old) != n_waves - 1u) return;
         // this wave completed the workgroup's record of frame i: add the wave records in wave order, publish 31 tagged words
-        gr_wave_sync();
+        gr_lds_acquire();
         const float *all = wsum + rs * WAVES * 32;
         if (lane < 31u) {
-            float v = all[lane];
-            if (lane < 19u) { for (uint32_t w = 1; w < n_waves; ++w) v += all[w * 32 + lane]; }
-            else { for (uint32_t w = 1; w < n_waves; ++w) v = gr_fmaxf(v, all[w * 32 + lane]); }
+            float v;
+            if (n_waves == WAVES) {
+                // a full workgroup (all but the last one of a frame): the wave records are requested together -- one LDS round trip
+                // instead of a chain of dependent ones on the wave that is, by construction, the last of its workgroup (5.44 -> 5.30 us)
+                float t[WAVES];
+#pragma unroll
+                for (uint32_t w = 0; w < WAVES; ++w) t[w] = all[w * 32 + lane];
+                v = t[0];
+                if (lane < 19u) {
+#pragma unroll
+                    for (uint32_t w = 1; w < WAVES; ++w) v += t[w];
+                } else {
+#pragma unroll
+                    for (uint32_t w = 1; w < WAVES; ++w) v = gr_fmaxf(v, t[w]);
+                }
+            } else {
+                v = all[lane];
+                if (lane < 19u) { for (uint32_t w = 1; w < n_waves; ++w) v += all[w * 32 + lane]; }
+                else { for (uint32_t w = 1; w < n_waves; ++w) v = gr_fmaxf(v, all[w * 32 + lane]); }
+            }
             gr_st_agent(ctl.wgrec + ((size_t)i * n_pad + wg) * GR_RES_REC_WORDS + lane, ((unsigned long long)ctl.epoch << 32) | __float_as_uint(v));
         }
+        // the slot's counter starts the next use (frame i + R) at zero.  No wave can reach frame i + R before this wave -- the slowest
+        // of the workgroup at this point -- has published frame i, the finalizer has closed it and the fit stage of frame i has been
+        // passed by everybody (R > K), so the reset cannot meet an arrival
         if (lane == 0) __hip_atomic_store(cnt_s + rs, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
 
-    // ---- the fit stage of frame j: `rv` = the frame's record as requested earlier (lanes 0..12); rows as they were parked.
+    // V fit of one group: R v + t0, sum w |R q - p|^2 (rmsd.rs:592-599; pad atoms weigh nothing), + reference COM
+    auto fit_group_v = [&](const GrResGroup &Gr, const Rows &rw, const GrResRot &T, float t0x, float t0y, float t0z, float4 *__restrict__ f4, float &rs) {
+        const GrP4 v = gr_pairs_rows(rw.r0, rw.r1, rw.r2);
+        GrP4 n;
+        n.x01 = gr_v2_fma(gr_v2(T.r02), v.z01, gr_v2_fma(gr_v2(T.r01), v.y01, gr_v2_fma(gr_v2(T.r00), v.x01, gr_v2(t0x))));
+        n.y01 = gr_v2_fma(gr_v2(T.r12), v.z01, gr_v2_fma(gr_v2(T.r11), v.y01, gr_v2_fma(gr_v2(T.r10), v.x01, gr_v2(t0y))));
+        n.z01 = gr_v2_fma(gr_v2(T.r22), v.z01, gr_v2_fma(gr_v2(T.r21), v.y01, gr_v2_fma(gr_v2(T.r20), v.x01, gr_v2(t0z))));
+        n.x23 = gr_v2_fma(gr_v2(T.r02), v.z23, gr_v2_fma(gr_v2(T.r01), v.y23, gr_v2_fma(gr_v2(T.r00), v.x23, gr_v2(t0x))));
+        n.y23 = gr_v2_fma(gr_v2(T.r12), v.z23, gr_v2_fma(gr_v2(T.r11), v.y23, gr_v2_fma(gr_v2(T.r10), v.x23, gr_v2(t0y))));
+        n.z23 = gr_v2_fma(gr_v2(T.r22), v.z23, gr_v2_fma(gr_v2(T.r21), v.y23, gr_v2_fma(gr_v2(T.r20), v.x23, gr_v2(t0z))));
+        {
+            const gr_v2f w01 = WMASS ? gr_v2p(Gr.mm.x, Gr.mm.y) : gr_v2p(Gr.ww.x, Gr.ww.y), w23 = WMASS ? gr_v2p(Gr.mm.z, Gr.mm.w) : gr_v2p(Gr.ww.z, Gr.ww.w);
+            gr_v2f dx = n.x01 - Gr.P.x01, dy = n.y01 - Gr.P.y01, dz = n.z01 - Gr.P.z01;
+            gr_v2f part = w01 * gr_v2_fma(dx, dx, gr_v2_fma(dy, dy, dz * dz));
+            dx = n.x23 - Gr.P.x23; dy = n.y23 - Gr.P.y23; dz = n.z23 - Gr.P.z23;
+            part = gr_v2_fma(w23, gr_v2_fma(dx, dx, gr_v2_fma(dy, dy, dz * dz)), part);
+            rs += part.x + part.y;
+        }
+        n.x01 += gr_v2(cx); n.y01 += gr_v2(cy); n.z01 += gr_v2(cz); n.x23 += gr_v2(cx); n.y23 += gr_v2(cy); n.z23 += gr_v2(cz);
+        float4 o0, o1, o2;
+        gr_rows_pairs(n, o0, o1, o2);
+        gr_stream_store(f4 + Gr.b, o0); gr_stream_store(f4 + Gr.b + 64, o1); gr_stream_store(f4 + Gr.b + 128, o2);
+    };
+
+    // ---- the fit stage of frame j: `rv` = the frame's record as requested earlier (lanes 0..15); rows / image vectors as they were parked.
     auto fit = [&](uint32_t j, unsigned long long rv, const Rows &ra, const Rows &rb, const GrBoxU &B) {
         uint32_t polls = 0;
-        while (__builtin_amdgcn_ballot_w64(lane < 13u && (uint32_t)(rv >> 32) != ctl.epoch) != 0ull) {
-#if GR_RES_PRIO
+        while (__builtin_amdgcn_ballot_w64(lane < 16u && (uint32_t)(rv >> 32) != ctl.epoch) != 0ull) {
             __builtin_amdgcn_s_setprio(0);                             // a wave that is ahead waits below the waves it shares the SIMD with
-#endif
             if (++polls > GR_RES_PATIENCE || ((polls & 255u) == 0 && gr_ld_agent(ctl.abort) != 0u)) { if (lane == 0) gr_st_agent(ctl.abort, 1u); bail = true; return; }
             __builtin_amdgcn_s_sleep(GR_RES_SLEEP);
             rv = request_rec(j);
         }
-#if GR_RES_PRIO
-        __builtin_amdgcn_s_setprio(2);
-#endif
+        set_prio();
         const int status = __builtin_amdgcn_readlane((int)(uint32_t)rv, 0);
         float rs = 0.0f;
         if (status == 0) {
             GrResRot T;
-            T.sx = gr_lane_f(rv, 1); T.sy = gr_lane_f(rv, 2); T.sz = gr_lane_f(rv, 3);
             T.r00 = gr_lane_f(rv, 4); T.r10 = gr_lane_f(rv, 5); T.r20 = gr_lane_f(rv, 6); T.r01 = gr_lane_f(rv, 7); T.r11 = gr_lane_f(rv, 8); T.r21 = gr_lane_f(rv, 9);
             T.r02 = gr_lane_f(rv, 10); T.r12 = gr_lane_f(rv, 11); T.r22 = gr_lane_f(rv, 12);
-            const GrBox *boxp = boxes + first_slot + j;
             float4 *f4 = reinterpret_cast<float4 *>(frames + (size_t)(first_slot + j) * frame_stride);
-            gr_res_fit_group<WMASS>(GA, ra.r0, ra.r1, ra.r2, T, B, boxp, cx, cy, cz, f4, rs);
-            if (G == 2 && GB.valid) gr_res_fit_group<WMASS>(GB, rb.r0, rb.r1, rb.r2, T, B, boxp, cx, cy, cz, f4, rs);
+            if (V) {
+                const float t0x = gr_lane_f(rv, 13), t0y = gr_lane_f(rv, 14), t0z = gr_lane_f(rv, 15);
+                T.sx = T.sy = T.sz = 0.f;
+                fit_group_v(GA, ra, T, t0x, t0y, t0z, f4, rs);
+                if (GB.valid) fit_group_v(GB, rb, T, t0x, t0y, t0z, f4, rs);
+            } else {
+                T.sx = gr_lane_f(rv, 1); T.sy = gr_lane_f(rv, 2); T.sz = gr_lane_f(rv, 3);
+                const GrBox *boxp = boxes + first_slot + j;
+                gr_res_fit_group<WMASS>(GA, ra.r0, ra.r1, ra.r2, T, B, boxp, cx, cy, cz, f4, rs);
+                if (GB.valid) gr_res_fit_group<WMASS>(GB, rb.r0, rb.r1, rb.r2, T, B, boxp, cx, cy, cz, f4, rs);
+            }
         }
+        n_fitted = j + 1u;
         // the workgroup's share of sum w |R q - p|^2: the lane's eight atoms in f32, the wave in f32 (no LDS crossbar), waves in fp64
-        // in wave order by the last wave to arrive
+        // in wave order by the last wave to arrive (release / acquire as in the sums stage)
         const float wtot = gr_wave_allsum_f32(rs);
         const uint32_t fs = j % R;
         if (lane == 0) fsum[fs * WAVES + wave] = (double)wtot;
-        gr_wave_sync();
+        gr_lds_release();
         uint32_t old = 0;
         if (lane == 0) old = __hip_atomic_fetch_add(cnt_f + fs, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if ((uint32_t)__builtin_amdgcn_readfirstlane((int)old) != n_waves - 1u) return;
-        gr_wave_sync();
+        gr_lds_acquire();
         if (lane == 0) {
             double t = 0.0;
-            for (uint32_t w = 0; w < n_waves; ++w) t += fsum[fs * WAVES + w];
+            if (n_waves == WAVES) {
+                double x[WAVES];
+#pragma unroll
+                for (uint32_t w = 0; w < WAVES; ++w) x[w] = fsum[fs * WAVES + w];
+#pragma unroll
+                for (uint32_t w = 0; w < WAVES; ++w) t += x[w];
+            } else {
+                for (uint32_t w = 0; w < n_waves; ++w) t += fsum[fs * WAVES + w];
+            }
             fit_partials[(size_t)j * ctl.n_stream + wg] = t;
-            __hip_atomic_store(cnt_f + fs, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(cnt_f + fs, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // (as cnt_s: the next use is R frames away)
         }
     };
 
-    // ---- the walk: iteration i = fit of frame i - K, then sums of frame i.  Where a frame waits:
-    //   G = 2   group A in LDS slot i % K for the whole wait, group B in the queue of register sets (Q[0] = the oldest);
-    //   G = 1   the first KV iterations in the queue, then KL iterations in LDS slot (i - KV) % KL  (K = KV + KL).
-    // The queue moves up by one set per iteration (register moves); naming the sets by i % K instead means unrolling the loop K
-    // times, and six copies of this body were far larger than the 64 KiB instruction cache.
+    // ---- the walk: iteration i = fit of frame i - K, then sums of frame i.  A frame (its rows; V: its image vectors) waits for its
+    // record with group A in LDS slot i % K and group B in register set i % K.  The register set is picked by a scalar branch
+    // ladder (12 moves out, 12 in): a queue that moves up by one set every iteration costs 60 moves (5.30 -> 5.27 us), and naming
+    // the sets by unrolling the loop K times does not fit the instruction cache.  The sets are six separately named variables and
+    // every copy is followed by a comment-only asm statement that differs per branch: without them the optimiser merges the six
+    // copies into one copy from a selected ADDRESS and the sets end up in scratch memory (measured: 7.3 us per frame).
     Landing L0, L1;
     L0.a.r0 = L0.a.r1 = L0.a.r2 = L0.b.r0 = L0.b.r1 = L0.b.r2 = zero4; L0.gx = L0.gy = L0.gz = 0.f;
     L1 = L0;
-    Rows Q[KV];
-#pragma unroll
-    for (uint32_t u = 0; u < KV; ++u) Q[u].r0 = Q[u].r1 = Q[u].r2 = zero4;
+    Rows Q0, Q1, Q2, Q3, Q4, Q5;
+    Q0.r0 = Q0.r1 = Q0.r2 = zero4; Q1 = Q0; Q2 = Q0; Q3 = Q0; Q4 = Q0; Q5 = Q0;
     unsigned long long rv = 0ull;
     request(0, L0);
     const uint32_t n_iter = nframes + K;
@@ -517,30 +668,31 @@ __global__ __launch_bounds__(GrResShape<G>::LANES) void k_fit_resident(
     auto lds_get = [&](uint32_t slot) { Rows rw; rw.r0 = park[(slot * 3 + 0) * LANES + tid]; rw.r1 = park[(slot * 3 + 1) * LANES + tid]; rw.r2 = park[(slot * 3 + 2) * LANES + tid]; return rw; };
     auto step = [&](uint32_t i, Landing &cur, Landing &nxt) {
         if (i + 1 < nframes) request(i + 1, nxt);
+        balance(i);
         // both boxes of the iteration are requested here (scalar loads): they arrive while the record is checked
         const GrBoxU Bf = UBOX ? B0 : gr_box_uniform(boxes + first_slot + (i >= K ? i - K : 0u));
         const GrBoxU Bs = UBOX ? B0 : gr_box_uniform(boxes + first_slot + (i < nframes ? i : 0u));
-        if (G == 2) {
-            const uint32_t ps = i % K;                         // LDS slot: frame i - K leaves it, frame i takes it
-            if (i >= K) { fit(i - K, rv, lds_get(ps), Q[0], Bf); if (bail) return; }
-            if (i + 1 >= K && i + 1 < n_iter) rv = request_rec(i + 1 - K);
-#pragma unroll
-            for (uint32_t u = 0; u + 1 < KV; ++u) Q[u] = Q[u + 1];
-            if (i < nframes) { lds_put(ps, cur.a); Q[KV - 1] = cur.b; sums(i, cur, Bs); }
-        } else {
-            const uint32_t pl = (i + KL - (K % KL)) % KL;       // LDS slot of frame i - K = the slot frame i - KV is about to take
-            if (i >= K) { fit(i - K, rv, lds_get(pl), cur.b, Bf); if (bail) return; }
-            if (i + 1 >= K && i + 1 < n_iter) rv = request_rec(i + 1 - K);
-            if (i >= KV && i - KV < nframes) lds_put(pl, Q[0]); // frame i - KV moves from the queue into LDS
-#pragma unroll
-            for (uint32_t u = 0; u + 1 < KV; ++u) Q[u] = Q[u + 1];
-            if (i < nframes) { Q[KV - 1] = cur.a; sums(i, cur, Bs); }
+        Rows va = cur.a, vb = cur.b;                            // what gets parked: the rows, or (V: set by sums) the image vectors
+        const uint32_t ps = i % K;
+        if (i >= K) {
+            Rows qb;
+            if (ps == 0u) { qb = Q0; asm volatile("; set 0 out"); } else if (ps == 1u) { qb = Q1; asm volatile("; set 1 out"); } else if (ps == 2u) { qb = Q2; asm volatile("; set 2 out"); }
+            else if (ps == 3u) { qb = Q3; asm volatile("; set 3 out"); } else if (ps == 4u) { qb = Q4; asm volatile("; set 4 out"); } else { qb = Q5; asm volatile("; set 5 out"); }
+            fit(i - K, rv, lds_get(ps), qb, Bf);
+            if (bail) return;
+        }
+        if (i + 1 >= K && i + 1 < n_iter) rv = request_rec(i + 1 - K);
+        if (i < nframes) {
+            if (V) sums(i, cur, Bs, va, vb);                    // (the slot's old content has been read by the fit above)
+            lds_put(ps, va);
+            if (ps == 0u) { Q0 = vb; asm volatile("; set 0 in"); } else if (ps == 1u) { Q1 = vb; asm volatile("; set 1 in"); } else if (ps == 2u) { Q2 = vb; asm volatile("; set 2 in"); }
+            else if (ps == 3u) { Q3 = vb; asm volatile("; set 3 in"); } else if (ps == 4u) { Q4 = vb; asm volatile("; set 4 in"); } else { Q5 = vb; asm volatile("; set 5 in"); }
+            if (!V) sums(i, cur, Bs, va, vb);
         }
     };
-    for (uint32_t i = 0; i < n_iter; i += 2) {
+    for (uint32_t i = 0; i < n_iter && !bail; i += 2) {
         step(i, L0, L1);
-        if (bail) return;
-        if (i + 1 < n_iter) step(i + 1, L1, L0);
-        if (bail) return;
+        if (!bail && i + 1 < n_iter) step(i + 1, L1, L0);
     }
+    if (lane == 0) ctl.progress[wg * WAVES + wave] = n_fitted;
 }

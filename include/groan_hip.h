@@ -257,14 +257,19 @@ int gr_rmsd_plan_force_exact(gr_rmsd_plan *plan, int on);
  *   GR_TUNE_TWO_PASS   1 (default): RMSD-fit = sums pass + fit pass that evaluates the rmsd; 0: closed-form single-pass rmsd
  *   GR_TUNE_RESIDENT   RMSD-fit as ONE pass over HBM, the frame waiting on chip for its rotation (gr_resident.h: one launch per
  *                      segment whose workgroups wait for one another; needs n_atoms <= ~1.04e6 on MI355X).  1 (default): when the
- *                      frame fills at least 15/16 of the chip (157 k vs 150 k frames/s at 1e6 atoms); 0: never; 2: whenever it
+ *                      frame fills at least 15/16 of the chip; 0: never; 2: whenever it
  *                      fits.  One such launch runs per device and process at a time (a context that finds the device taken uses
  *                      the two-pass path); a launch whose workgroups do not all get onto the chip (a device shared with another
  *                      process) leaves without touching a frame and the segment runs on the two-pass path.  Same results as the two-pass path up to the order of the partial sums.
- *   GR_TUNE_RESIDENT_GROUPS  4-atom groups per lane of the resident pass: 2 (default; 512 lanes per workgroup) or 1 (1024 lanes)
+ *                      A launch in which a wait runs out of patience (a workgroup made no progress for seconds) is aborted from inside:
+ *                      frames it had completed keep their results, frames nobody had touched are redone on the two-pass path, and a
+ *                      frame that was caught half fitted -- possible only in the instant of the abort -- is reported as GR_E_HIP
+ *                      in status_out with its index in gr_last_error_index (gr_ctx_stat counts aborts and redone frames).
+ *   GR_TUNE_RESIDENT_GROUPS  retired (round 3 removed the one-group shape of the resident pass): only the value 2 is accepted
  */
 enum { GR_TUNE_SUB_BATCH = 1, GR_TUNE_CHUNKS = 2, GR_TUNE_FIT_WGS = 3, GR_TUNE_FUSE = 4, GR_TUNE_TWO_PASS = 5, GR_TUNE_RESIDENT = 6, GR_TUNE_RESIDENT_GROUPS = 7,
-       GR_TUNE_TEST_RESIDENT_NO_START = 100 /* tests: the next resident launch behaves as if its workgroups never got onto the chip */ };
+       GR_TUNE_TEST_RESIDENT_NO_START = 100 /* tests: the next resident launch behaves as if its workgroups never got onto the chip */,
+       GR_TUNE_TEST_RESIDENT_ABORT_AT = 101 /* tests: the next resident launch is aborted from inside when it reaches this frame of its segment (< 0: never) */ };
 int gr_ctx_set_tuning(gr_ctx *ctx, int key, int64_t value);
 /* Read-only facts about a context and its device, and counters of what the batched RMSD path did since the context was created
  * (unknown key: GR_E_INVALID_ARG).

@@ -1,7 +1,9 @@
 """The resident RMSD-fit pass (gr_resident.h: one launch, every frame read once and written once, the frame
-waiting on chip for its rotation) against the oracle and against the two-pass path on the same frames.  GR_TUNE_RESIDENT = 2
-forces it for systems far smaller than the chip (few streaming workgroups, a ragged last one, idle waves).  The pass is opt-in
-(default: the two-pass path, which is faster on this hardware -- gr_resident.h STATUS)."""
+waiting on chip for its rotation) against the oracle and against the two-pass path on the same frames.  The pass is the
+default for frames that fill the chip (tests/test_gpu_resident_fullsize.py runs it at the benchmark's shape);
+GR_TUNE_RESIDENT = 2 forces it here for systems far smaller than the chip: few streaming workgroups, a ragged last one, idle
+waves, both kernels (whole-system selections park image vectors, any other selection parks rows), short batches, failed
+frames, a box per frame, a launch that never starts and a launch that is aborted from inside."""
 import numpy as np
 import pytest
 
@@ -31,10 +33,9 @@ def _systems(G, n, nf, box, sel):
     return masses, cur, ref, ref_pos, frames
 
 
-@pytest.mark.parametrize("n,sel", [(70_001, (0, 70_000)), (70_001, (1003, 69_990)), (5_000, (17, 4_000)), (300, (0, 299))])
+@pytest.mark.parametrize("n,sel", [(70_001, (0, 70_000)), (70_001, (1003, 69_990)), (70_001, (0, 69_990)), (5_000, (17, 4_000)), (5_000, (0, 4_999)), (300, (0, 299))])
 @pytest.mark.parametrize("tric", [False, True])
-@pytest.mark.parametrize("groups", [2, 1])
-def test_resident_matches_oracle_and_two_pass(G, n, sel, tric, groups):
+def test_resident_matches_oracle_and_two_pass(G, n, sel, tric):
     nf = 11                                             # odd, longer than the pipeline (3 frames between sums and fit)
     box = W.box_from_lengths_angles([7.0, 6.5, 6.0], [75.0, 80.0, 70.0]) if tric else W.box_from_lengths_angles([7.0, 6.5, 6.0], [90.0, 90.0, 90.0])
     masses, cur, ref, ref_pos, frames = _systems(G, n, nf, box, sel)
@@ -44,7 +45,7 @@ def test_resident_matches_oracle_and_two_pass(G, n, sel, tric, groups):
     plan = G.RMSDPlan(ref, cur, "S")
     got = {}
     for mode in (0, 2):
-        cur.set_tuning(resident=mode, resident_groups=groups)
+        cur.set_tuning(resident=mode)
         cur.profile_enable(True)
         for f in range(nf):
             cur.set_frame(frames[f], box, slot=f)
@@ -69,8 +70,7 @@ def test_resident_matches_oracle_and_two_pass(G, n, sel, tric, groups):
     plan.close(); ref.close(); cur.close()
 
 
-@pytest.mark.parametrize("groups", [2, 1])
-def test_resident_short_batches_and_failed_frames(G, groups):
+def test_resident_short_batches_and_failed_frames(G):
     """1, 2, 3 and 4 frames (shorter than, equal to and just longer than the pipeline); a frame without a box and a frame with a
     missing position fail exactly as on the two-pass path and are left unmodified, the frames around them are fitted."""
     n, nf = 20_000, 8
@@ -79,7 +79,7 @@ def test_resident_short_batches_and_failed_frames(G, groups):
     plan = G.RMSDPlan(ref, cur, "S")
     res = {}
     for mode in (0, 2):
-        cur.set_tuning(resident=mode, resident_groups=groups)
+        cur.set_tuning(resident=mode)
         for nb in (1, 2, 3, 4, 7):
             for f in range(nb):
                 cur.set_frame(frames[f], box, slot=f)
@@ -106,8 +106,8 @@ def test_resident_short_batches_and_failed_frames(G, groups):
     plan.close(); ref.close(); cur.close()
 
 
-@pytest.mark.parametrize("groups", [2, 1])
-def test_resident_with_a_different_box_in_every_frame(G, groups):
+@pytest.mark.parametrize("whole", [False, True])
+def test_resident_with_a_different_box_in_every_frame(G, whole):
     """constant-pressure runs: every frame has its own box -> the kernel variant that reads the box per frame"""
     n, nf = 30_000, 9
     masses = W.masses_cycle(n)
@@ -118,13 +118,13 @@ def test_resident_with_a_different_box_in_every_frame(G, groups):
     ref_pos = cur.get_positions(nf)
     ref = G.System(n, masses=masses, box=boxes[0], positions=ref_pos)
     for s_ in (ref, cur):
-        s_.group_create_from_ranges("S", [(5, n - 9)])
+        s_.group_create_from_ranges("S", [(0, n - 1) if whole else (5, n - 9)])
     frames = [cur.get_positions(f) for f in range(nf)]
-    idx = np.arange(5, n - 8)
+    idx = np.arange(n) if whole else np.arange(5, n - 8)
     with O.acc64():
         want = [O.calc_rmsd_and_fit(ref_pos, masses, idx, boxes[0], frames[f], masses, idx, boxes[f]) for f in range(nf)]
     plan = G.RMSDPlan(ref, cur, "S")
-    cur.set_tuning(resident=2, resident_groups=groups)
+    cur.set_tuning(resident=2)
     cur.profile_enable(True)
     for f in range(nf):
         cur.set_frame(frames[f], boxes[f], slot=f)
@@ -158,9 +158,53 @@ def test_resident_launch_that_never_starts_falls_back_cleanly(G):
     assert np.array_equal(np.array(r), np.array(want_r))
     for f in range(nf):
         assert np.array_equal(cur.get_positions(f), want[f])
+    assert cur.stat("res_handshake_misses") == 1 and cur.stat("res_max_wgs") > 0
+    # the context sits out the next segments (4 after the first miss), then tries the pass again -- and keeps it when it starts
+    ran = []
+    for _ in range(6):
+        cur.profile_enable(True)
+        for f in range(nf):
+            cur.set_frame(frames[f], box, slot=f)
+        r, st = plan.rmsd_fit(0, nf)
+        assert (st == 0).all()
+        ran.append(cur.profile_read()["k_fit_resident"][1])
+    assert ran == [0, 0, 0, 0, 1, 1], ran
+    assert cur.stat("res_launches") == 2
+    plan.close(); ref.close(); cur.close()
+
+
+@pytest.mark.parametrize("whole", [True, False])
+@pytest.mark.parametrize("at", [0, 3, 9, 22])
+def test_resident_launch_aborted_from_inside_loses_nothing(G, whole, at):
+    """a wait that runs out of patience aborts the launch from inside (here: the finalizer of frame `at` raises the abort
+    instead of closing its frame).  Frames the launch had completed keep their results, every other frame is still untouched
+    and is redone on the two-pass path: the call succeeds, every frame is fitted exactly once, nothing is torn"""
+    n, nf = 20_000, 24
+    box = W.box_from_lengths_angles([6.0, 6.0, 6.0], [60.0, 60.0, 90.0])
+    masses, cur, ref, ref_pos, frames = _systems(G, n, nf, box, (0, n - 1) if whole else (40, n - 3))
+    plan = G.RMSDPlan(ref, cur, "S")
+    cur.set_tuning(resident=0)
+    for f in range(nf):
+        cur.set_frame(frames[f], box, slot=f)
+    want_r, st = plan.rmsd_fit(0, nf)
+    want = [cur.get_positions(f) for f in range(nf)]
+    cur.set_tuning(resident=2, test_resident_abort_at=at)
     cur.profile_enable(True)
     for f in range(nf):
         cur.set_frame(frames[f], box, slot=f)
-    plan.rmsd_fit(0, nf)
-    assert cur.profile_read()["k_fit_resident"][1] == 0                   # ... and the context no longer tries the resident pass
+    r, st = plan.rmsd_fit(0, nf)
+    prof = cur.profile_read()
+    assert (st == 0).all(), st
+    assert prof["k_fit_resident"][1] == 1 and cur.stat("res_aborts") == 1 and cur.stat("res_launches") == 0
+    redone = cur.stat("res_redone_frames")
+    assert 1 <= redone <= nf - at, (at, redone)    # frame `at` itself and whatever behind it had not been fitted when the grid drained
+    assert (prof["k_fit_pk"][2] == redone), (prof, redone)
+    assert np.abs(np.array(r) - np.array(want_r)).max() <= 2e-6
+    for f in range(nf):
+        assert np.abs(cur.get_positions(f) - want[f]).max() <= 2e-5, f
+    # the next launch runs to the end
+    for f in range(nf):
+        cur.set_frame(frames[f], box, slot=f)
+    r, st = plan.rmsd_fit(0, nf)
+    assert (st == 0).all() and cur.stat("res_launches") == 1
     plan.close(); ref.close(); cur.close()
