@@ -60,6 +60,8 @@ def main():
     ap.add_argument("--gather", choices=["torch", "abi"], default="torch", help="final gather of the per-frame RMSDs at N > 1: torch.distributed "
                     "all_gather (backend nccl = RCCL; the launch contract's own channel) or the library's C-ABI communicator (gr_comm_*: "
                     "ncclCommInitRank + ncclAllGather; the unique id travels through torch.distributed)")
+    ap.add_argument("--dump-rmsd", default=None, metavar="PATH", help="rank 0 writes the per-frame RMSDs of the timed steps, in GLOBAL frame "
+                    "order (after the gather at N > 1), as a .npy file: what tests/test_gpu_multirank.py compares between rank counts")
     ap.add_argument("--cpu-baseline-child", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--with-torch", action="store_true", help="import torch first even at N=1 (coexistence check)")
     args = ap.parse_args()
@@ -194,15 +196,18 @@ def main():
     value = total_frames / elapsed
 
     # ---- roofline of the dominant kernel (HIP events on the library's stream, timed region)
-    # algorithmic bytes per frame: sums pass 28 B/atom (cur 12 + ref 12 + mass 4), fit pass 24 B/atom (12 r + 12 w)
-    # the resident single pass (gr_resident.h) is the WHOLE RMSD-fit of a frame in one kernel: its algorithmic bytes are SURVEY 8d's
-    # 40 B/atom/frame (cur 12 + ref 12 + mass 4 + 12 written).  What it actually moves is less -- every frame read once and written
-    # once, 24 B/atom, + reference and masses once per launch -- and is reported as `traffic` (PMC) and `hbm_compulsory_bytes_per_launch`.
-    alg_bytes = {"k_sums_pk": 28.0 * n, "k_rmsd_finalize": 0.0, "k_fit_pk": 24.0 * n, "k_fit_resident": 40.0 * n}
+    # `achieved` counts the bytes the kernel HAS TO MOVE through HBM per launch, every array once:
+    #   k_sums_pk 28 B/atom/frame (cur 12 + ref 12 + mass 4), k_fit_pk 24 B/atom/frame (12 read + 12 written);
+    #   k_fit_resident -- the whole RMSD-fit of a frame in ONE pass, reference rows and masses held in registers for the whole launch --
+    #   24 B/atom/frame (12 read + 12 written) + 16 B/atom ONCE per launch.  That is what the PMC counters measure (`traffic`).
+    # SURVEY 8d prices the RMSD-fit at 40 B/atom/frame (it counts the reference and the masses once per FRAME): that figure is kept
+    # as `survey_8d_equivalent_GBs` -- a throughput in the contract's unit, NOT a bandwidth: it is never divided by the HBM peak.
+    fpl = {k: (prof[k][2] / max(prof[k][1], 1) if k in prof else 0.0) for k in ("k_sums_pk", "k_fit_pk", "k_fit_resident")}
+    alg_bytes = {"k_sums_pk": 28.0 * n * fpl["k_sums_pk"], "k_fit_pk": 24.0 * n * fpl["k_fit_pk"], "k_fit_resident": 24.0 * n * fpl["k_fit_resident"] + 16.0 * n}
     dom = max(("k_sums_pk", "k_fit_pk", "k_fit_resident"), key=lambda k: prof[k][0] if k in prof else -1.0)
     ms_total, launches, frames = prof[dom]
     avg_ms = ms_total / max(launches, 1)
-    bytes_per_launch = alg_bytes[dom] * (frames / max(launches, 1))
+    bytes_per_launch = alg_bytes[dom]
     achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (separate --pmc runs,
     # FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; profiles/*_pmc_summary.json) -- only when the launch shape matches
@@ -218,17 +223,39 @@ def main():
                     break
     except Exception:
         pass
+    # the arithmetic-free floor of the same traffic at the same launch shape (tools/ceiling_bench.hip, committed per round)
+    copy_floor_us, copy_floor_src = None, None
+    try:
+        import glob
+        for pf in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_ceiling.json")), reverse=True):
+            cj = json.load(open(pf))
+            if cj.get("n_atoms") != n:
+                continue
+            want_k = "resident copy" if dom == "k_fit_resident" else ("copy+pw" if dom == "k_fit_pk" else "read+pw")
+            cand = [r["us_per_frame"] for r in cj["results"] if r["kernel"].startswith(want_k) and "us_per_frame" in r]
+            if cand:
+                copy_floor_us, copy_floor_src = min(cand), os.path.basename(pf)
+                break
+    except Exception:
+        pass
+    us_per_frame_dom = 1e3 * ms_total / max(frames, 1)
+    moved = traffic if traffic is not None else bytes_per_launch
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                "hbm_moved_GBs": round(moved / (avg_ms * 1e-3) / 1e9, 1) if avg_ms > 0 else 0.0,
+                "frac_hbm_moved": round(moved / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if avg_ms > 0 else 0.0,
+                "hbm_moved_source": "PMC (%s)" % traffic_src if traffic is not None else "bytes that have to move (no PMC pass of this launch shape is committed)",
+                "copy_floor_us_per_frame": copy_floor_us, "copy_floor_source": copy_floor_src,
+                "frac_of_copy_floor": round(copy_floor_us / us_per_frame_dom, 4) if copy_floor_us and us_per_frame_dom > 0 else None,
+                "us_per_frame": round(us_per_frame_dom, 4),
                 "avg_launch_ms": round(avg_ms, 4), "launches": launches, "frames_per_launch": frames / max(launches, 1),
-                "algorithmic_bytes_per_launch": bytes_per_launch}
+                "algorithmic_bytes_per_launch": bytes_per_launch,
+                "algorithmic_bytes_note": "every array the launch has to move through HBM, once" + (": 24 B/atom/frame + 16 B/atom per launch (reference rows and masses stay in registers)" if dom == "k_fit_resident" else "")}
     kernels = {k: {"ms_total": round(v[0], 3), "launches": v[1], "us_per_frame": round(1e3 * v[0] / max(v[2], 1), 3)} for k, v in prof.items()}
-    # whole step: 40 B/atom/frame algorithmic whichever pass runs
+    # whole step in the contract's unit: SURVEY 8d's 40 B/atom/frame whichever pass runs (a throughput, not a bandwidth)
     resident = prof.get("k_fit_resident", (0.0, 0, 0))[1] > 0
     path_gbs = 40.0 * n * (K * B) / (gpu_ms * 1e-3) / 1e9
-    if resident:
-        roofline["hbm_compulsory_bytes_per_launch"] = 24.0 * n * (frames / max(launches, 1)) + 16.0 * n
-        roofline["hbm_compulsory_GBs"] = round(roofline["hbm_compulsory_bytes_per_launch"] / (avg_ms * 1e-3) / 1e9, 1)
+    roofline["survey_8d_equivalent_GBs"] = round(40.0 * n * (frames / max(launches, 1)) / (avg_ms * 1e-3) / 1e9, 1) if dom == "k_fit_resident" and avg_ms > 0 else None
 
     out = {
         "metric": "frames/sec RMSD-fit, 1e6 atoms triclinic, 1/2/4/8 GPUs; HBM GB/s vs peak",
@@ -243,8 +270,12 @@ def main():
                    "per_rank_frames_per_s": [round(v, 1) for v in per_rank_fps]},
         "roofline": roofline,
         "kernels": kernels,
-        "path": {"algorithmic_GBs": round(path_gbs, 1), "frac_of_peak": round(path_gbs / HBM_PEAK_GBS, 4), "gpu_ms_timed_region": round(gpu_ms, 3),
-                 "bytes_per_frame": 40.0 * n, "pass": "resident (one pass over HBM: 24 B/atom/frame actually move)" if resident else "two-pass (sums, fit)"},
+        "path": {"survey_8d_equivalent_GBs": round(path_gbs, 1), "survey_8d_bytes_per_frame": 40.0 * n, "gpu_ms_timed_region": round(gpu_ms, 3),
+                 "timed_region_note": "the timed region is %.2f s of GPU work (%d steps); per-step times in config.step_ms" % (gpu_ms * 1e-3, K),
+                 "hbm_bytes_per_frame_moved": (24.0 * n if resident else 36.0 * n),
+                 "hbm_moved_GBs": round((24.0 if resident else 36.0) * n * (K * B) / (gpu_ms * 1e-3) / 1e9, 1),
+                 "frac_hbm_moved": round((24.0 if resident else 36.0) * n * (K * B) / (gpu_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                 "pass": "resident (one pass over HBM: 24 B/atom/frame move)" if resident else "two-pass (sums, fit: 36 B/atom/frame move + 16 B/atom/frame from L2 / Infinity Cache)"},
     }
 
     # ---- CPU baseline: the oracle's restatement of the reference path on a bounded sample of the SAME frames (rank 0, N=1 only),
@@ -282,7 +313,17 @@ def main():
             if tmpdir:
                 import shutil
                 shutil.rmtree(tmpdir, ignore_errors=True)
+    # what the resident pass did on every rank (ranks that share a device take turns on it or fall back to the two passes: gr_resident.h)
+    res_stats = {k: cur.stat(k) for k in ("res_launches", "res_handshake_misses", "res_aborts", "res_redone_frames")}
+    if dist is not None:
+        every_stats = [None] * world
+        dist.all_gather_object(every_stats, res_stats)
+    else:
+        every_stats = [res_stats]
+    out["config"]["per_rank_resident"] = every_stats
     if rank == 0:
+        if args.dump_rmsd:
+            np.save(args.dump_rmsd, gathered if gathered is not None else rmsd_all.reshape(-1))
         if gathered is not None:
             out["config"]["gathered_frames"] = int(gathered.shape[0])      # == n_gpus * steps * frames_per_step (asserted above)
         sys.stdout.flush()

@@ -146,11 +146,13 @@ SIGNATURES = {
     "gr_pool_ctx": (C.c_void_p, [C.c_void_p, C.c_int]),
     "gr_pool_last_error": (C.c_char_p, [C.c_void_p]),
     "gr_pool_map": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, c_u64p, c_u64p]),
+    "gr_pool_map_range": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, c_u64p, c_u64p]),
     "gr_comm_unique_id": (C.c_int, [C.c_void_p]),
     "gr_comm_create": (C.c_void_p, [C.c_int, C.c_int, C.c_int, C.c_void_p, c_i32p]),
     "gr_comm_destroy": (None, [C.c_void_p]),
     "gr_comm_last_error": (C.c_char_p, [C.c_void_p]),
     "gr_comm_library": (C.c_char_p, []),
+    "gr_comm_set_library": (C.c_int, [C.c_char_p]),
     "gr_comm_gather_per_frame": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_size_t, C.c_void_p]),
     "gr_comm_any_error": (C.c_int, [C.c_void_p, C.c_int, c_i32p]),
     "gr_shard_deinterleave": (None, [C.c_void_p, C.c_int, C.c_uint64, C.c_size_t, C.c_void_p]),

@@ -1607,6 +1607,9 @@ static int segment_begin(gr_rmsd_plan *p, uint32_t s0, uint32_t nb, int fit) {
             void *args[] = { &frames, &stride, &slot0, &nfr, &natoms, &masses, &sel_arg, &boxes, &plan, &states, &fparts, &ctl };
             bool ubox = true;   // the same box in every frame of the segment (constant-volume runs): its constants are loaded once
             for (uint32_t f = 1; f < nb && ubox; ++f) ubox = memcmp(&c->boxes_host[s0 + f], &c->boxes_host[s0], sizeof(GrBox)) == 0;
+#ifdef GR_EXP_NO_UBOX
+            ubox = false;
+#endif
             // the selection is the whole system: the kernel that parks image vectors (gr_resident.h, V)
             const bool whole = sel.start == 0 && sel.n == c->n;
             const void *fn = resident_fn(p->dev.w_is_mass != 0, ubox, whole);
@@ -2492,25 +2495,32 @@ int gr_pool_size(const gr_pool *p) { return p ? (int)p->ctx.size() : 0; }
 gr_ctx *gr_pool_ctx(gr_pool *p, int worker) { return (p && worker >= 0 && worker < (int)p->ctx.size()) ? p->ctx[worker] : nullptr; }
 const char *gr_pool_last_error(const gr_pool *p) { return p ? p->err.c_str() : "null pool"; }
 
-int gr_pool_map(gr_pool *p, uint64_t n_frames, gr_pool_body body, void *user, size_t width, float *results, uint64_t *frames_done, uint64_t *error_frame) try {
-    if (!p || !body || (width && !results)) return GR_E_INVALID_ARG;
+int gr_pool_map_range(gr_pool *p, uint64_t first_frame, uint64_t end_frame, uint64_t step, gr_pool_body body, void *user, size_t width, float *results,
+                      gr_pool_progress progress, void *progress_user, uint64_t *frames_done, uint64_t *error_frame) try {
+    if (!p || !body || (width && !results) || step == 0) return GR_E_INVALID_ARG;
     const uint64_t T = p->ctx.size();
+    const uint64_t n_visit = end_frame > first_frame ? (end_frame - first_frame + step - 1) / step : 0;   // frames first, first + step, ... < end
     std::atomic<int> flag(0);                 // the shared AtomicBool of parallel.rs:230
     std::atomic<int> first_status(GR_OK);
-    std::atomic<uint64_t> first_frame(0), done(0);
+    std::atomic<uint64_t> first_frame_err(0), done(0), last_read(first_frame);
     auto worker = [&](uint64_t w) {
         (void)hipSetDevice(p->device[w]);
-        uint64_t k = 0;
-        for (uint64_t f = w; f < n_frames; f += T, ++k) {                // frames w, w + T, ... (parallel.rs:424-448)
-            if (k % GR_POOL_ERROR_FLAG_FREQ == 0 && flag.load()) return;  // polled every 10 frames (:453-459)
+        uint64_t i = 0;
+        // worker w skips w * step frames, then advances by step * T (parallel.rs:425-448): ordinals k = w, w + T, ...
+        for (uint64_t k = w; k < n_visit; k += T, ++i) {
+            if (i % GR_POOL_ERROR_FLAG_FREQ == 0 && flag.load()) return;  // polled every 10 frames (:453-459)
+            const uint64_t f = first_frame + k * step;
             int st;
-            try { st = body(p->ctx[w], (int)w, f, user, width ? results + f * width : nullptr); } catch (...) { st = GR_E_HIP; }
+            try { st = body(p->ctx[w], (int)w, f, user, width ? results + k * width : nullptr); } catch (...) { st = GR_E_HIP; }
             if (st != GR_OK) {                                            // the first error wins (:468-471)
                 int expect = 0;
-                if (flag.compare_exchange_strong(expect, 1)) { first_status = st; first_frame = f; }
+                if (flag.compare_exchange_strong(expect, 1)) { first_status = st; first_frame_err = f; }
                 return;
             }
-            done.fetch_add(1);
+            const uint64_t d = done.fetch_add(1) + 1;
+            uint64_t seen = last_read.load();
+            while (f > seen && !last_read.compare_exchange_weak(seen, f)) { }
+            if (w == 0 && progress) progress(progress_user, GR_PROGRESS_RUNNING, f, d);   // the master thread's printer (:417-422)
         }
     };
     std::vector<std::thread> th;
@@ -2519,14 +2529,26 @@ int gr_pool_map(gr_pool *p, uint64_t n_frames, gr_pool_body body, void *user, si
     for (auto &t : th) t.join();
     if (frames_done) *frames_done = done.load();
     if (flag.load()) {
-        if (error_frame) *error_frame = first_frame.load();
-        p->err = "frame body failed at frame " + std::to_string(first_frame.load());
+        if (error_frame) *error_frame = first_frame_err.load();
+        if (progress) progress(progress_user, GR_PROGRESS_FAILED, first_frame_err.load(), done.load());
+        p->err = "frame body failed at frame " + std::to_string(first_frame_err.load());
         return first_status.load();                                       // Err for the whole call (:288-321)
     }
+    if (progress) progress(progress_user, GR_PROGRESS_COMPLETED, last_read.load(), done.load());   // the last frame ANY worker read (:300-317)
     return GR_OK;
 } catch (...) { return gr_abi_guard(); }
 
+int gr_pool_map(gr_pool *p, uint64_t n_frames, gr_pool_body body, void *user, size_t width, float *results, uint64_t *frames_done, uint64_t *error_frame) {
+    return gr_pool_map_range(p, 0, n_frames, 1, body, user, width, results, nullptr, nullptr, frames_done, error_frame);
+}
+
 /* ------------------------------------------------------------ frame-sharded map-reduce: one process per GPU, RCCL over xGMI */
+int gr_comm_set_library(const char *path) try {
+    if (!path) return GR_E_INVALID_ARG;
+    grn::library_override() = path;
+    return GR_OK;
+} catch (...) { return gr_abi_guard(); }
+
 int gr_comm_unique_id(void *id128) try {
     if (!id128) return GR_E_INVALID_ARG;
     grn::Api &a = grn::api();

@@ -50,18 +50,26 @@ struct Api {
     std::string source;
     bool ok = false;
 };
-inline Api &api() {
-    static Api a;
-    static bool tried = false;
-    if (tried) return a;
-    tried = true;
+// the RCCL library a host wants used instead of the default search (gr_comm_set_library, before the first gr_comm_* call)
+inline std::string &library_override() { static std::string s; return s; }
+inline Api load_api() {
+    Api a;
     void *h = RTLD_DEFAULT;
     a.source = "already loaded in the process";
-    if (!dlsym(h, "ncclCommInitRank")) {
-        h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-        if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-        a.source = "librccl.so.1";
-        if (!h) { a.source = std::string("RCCL not found: ") + (dlerror() ? dlerror() : ""); return a; }
+    const std::string &want = library_override();
+    if (!want.empty() || !dlsym(h, "ncclCommInitRank")) {
+        (void)dlerror();                                    // (clear: the text below must belong to OUR failure)
+        if (!want.empty()) { h = dlopen(want.c_str(), RTLD_NOW | RTLD_GLOBAL); a.source = want; }
+        else {
+            h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+            if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+            a.source = "librccl.so.1";
+        }
+        if (!h) {
+            const char *e = dlerror();                      // ONE call: it returns the message and clears it
+            a.source = std::string("RCCL not found: ") + (e ? e : "(no loader message)");
+            return a;
+        }
     }
     a.GetUniqueId = reinterpret_cast<decltype(a.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
     a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
@@ -71,6 +79,12 @@ inline Api &api() {
     a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
     a.ok = a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.AllGather && a.AllReduce;
     if (!a.ok) a.source += " (symbols missing)";
+    return a;
+}
+// resolved once, by whichever thread asks first (a function-local static: its initialisation is thread-safe, and nobody can see
+// a half-filled table)
+inline Api &api() {
+    static Api a = load_api();
     return a;
 }
 }  // namespace grn

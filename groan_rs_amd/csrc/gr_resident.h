@@ -83,7 +83,10 @@
 // Shape: a workgroup owns 1024 4-atom groups (4096 atoms) = 512 lanes x 2 groups; 8 waves, two per SIMD, up to 256 registers.
 struct GrResShape {
     static constexpr int LANES = 512, WAVES = LANES / 64;
-    static constexpr int K = 6;                      // frames between the sums stage and the fit stage = LDS slots = register sets
+#ifndef GR_RES_K
+#define GR_RES_K 6
+#endif
+    static constexpr int K = GR_RES_K;               // frames between the sums stage and the fit stage = LDS slots = register sets
     static constexpr int R = 8;                      // ring of wave-record slots ( > K: no wave is more than K frames ahead of another)
     static constexpr int PARK_F4 = K * 3 * LANES;    // float4: a slot = three rows of group A for every lane (24 KiB) x K = 144 KiB
     static constexpr int WSUM_F = R * WAVES * 32;    // float: a wave record = 19 sums + 12 extents
@@ -330,7 +333,11 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
                     const float mn[3] = { -(float)t[19], -(float)t[20], -(float)t[21] }, mx3[3] = { (float)t[22], (float)t[23], (float)t[24] };
                     const float fmn[3] = { -(float)t[25], -(float)t[26], -(float)t[27] }, fmx[3] = { (float)t[28], (float)t[29], (float)t[30] };
                     const double g[3] = { g0x, g0y, g0z };
+#ifdef GR_EXP_NOFINMATH
+                    st.R[0] = st.R[4] = st.R[8] = 1.0f; st.R[1] = st.R[2] = st.R[3] = st.R[5] = st.R[6] = st.R[7] = 0.0f; st.shift[0] = st.shift[1] = st.shift[2] = (float)(acc[1] * 1e-9); st.status = 0;
+#else
                     gr_finalize_math<0, true, false>(acc, mn, mx3, fmn, fmx, GR_NOIDX, GR_NOIDX, lb, plan, g, sel.n, st);
+#endif
                 }
                 unsigned long long *o = ctl.rec + (size_t)f * 16;
                 // (a frame that was not closed is published as failed: the streaming waves leave it unmodified and move on)
@@ -590,7 +597,10 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
         n.x01 += gr_v2(cx); n.y01 += gr_v2(cy); n.z01 += gr_v2(cz); n.x23 += gr_v2(cx); n.y23 += gr_v2(cy); n.z23 += gr_v2(cz);
         float4 o0, o1, o2;
         gr_rows_pairs(n, o0, o1, o2);
-        gr_stream_store(f4 + Gr.b, o0); gr_stream_store(f4 + Gr.b + 64, o1); gr_stream_store(f4 + Gr.b + 128, o2);
+#ifdef GR_EXP_NOSTORE
+        if (o0.x == 1.2345e30f)   // (experiment: no stores; the condition keeps the arithmetic alive)
+#endif
+        { gr_stream_store(f4 + Gr.b, o0); gr_stream_store(f4 + Gr.b + 64, o1); gr_stream_store(f4 + Gr.b + 128, o2); }
     };
 
     // ---- the fit stage of frame j: `rv` = the frame's record as requested earlier (lanes 0..15); rows / image vectors as they were parked.
@@ -667,7 +677,11 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
     auto lds_put = [&](uint32_t slot, const Rows &rw) { park[(slot * 3 + 0) * LANES + tid] = rw.r0; park[(slot * 3 + 1) * LANES + tid] = rw.r1; park[(slot * 3 + 2) * LANES + tid] = rw.r2; };
     auto lds_get = [&](uint32_t slot) { Rows rw; rw.r0 = park[(slot * 3 + 0) * LANES + tid]; rw.r1 = park[(slot * 3 + 1) * LANES + tid]; rw.r2 = park[(slot * 3 + 2) * LANES + tid]; return rw; };
     auto step = [&](uint32_t i, Landing &cur, Landing &nxt) {
+#ifdef GR_EXP_NOLOAD
+        if (i < 2) request(i + 1, nxt);
+#else
         if (i + 1 < nframes) request(i + 1, nxt);
+#endif
         balance(i);
         // both boxes of the iteration are requested here (scalar loads): they arrive while the record is checked
         const GrBoxU Bf = UBOX ? B0 : gr_box_uniform(boxes + first_slot + (i >= K ? i - K : 0u));

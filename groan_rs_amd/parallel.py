@@ -172,27 +172,39 @@ class Pool:
         except Exception:
             pass
 
-    def map(self, n_frames, body, width):
-        """-> float32 [n_frames, width]; raises the first failing frame's exception (the call as a whole fails, parallel.rs:288-321)"""
-        out = np.full((n_frames, max(width, 1)), np.nan, np.float32)
+    PROGRESS = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_uint64, C.c_uint64)
+    RUNNING, COMPLETED, FAILED = 0, 1, 2
+
+    def map(self, n_frames, body, width, start=0, step=1, progress=None):
+        """traj_iter_map_reduce's frame loop (parallel.rs:208-222,425-448): the frames start, start + step, ... below n_frames,
+        worker w of T taking every T-th of them from the w-th on.  -> float32 [number of visited frames, width], row k = the k-th
+        visited frame; raises the first failing frame's exception (the call as a whole fails, :288-321).
+        progress(status, frame, frames_done): the ProgressPrinter -- RUNNING after every frame of worker 0, then once COMPLETED
+        (frame = the last one any worker read) or FAILED (frame = the one that failed)."""
+        if step < 1:
+            raise ValueError("step must be >= 1 (ReadTrajError::InvalidStep)")
+        n_visit = len(range(int(start), int(n_frames), int(step)))
+        out = np.full((n_visit, max(width, 1)), np.nan, np.float32)
         errors = {}
 
         def trampoline(ctx, worker, frame, user, result):
             try:
-                row = np.ctypeslib.as_array(result, shape=(max(width, 1),))
+                row = np.ctypeslib.as_array(result, shape=(width,)) if width else None    # width 0: the body returns nothing per frame
                 body(self.systems[worker], worker, int(frame), row)
                 return 0
             except Exception as e:   # the body's error: reported through the status, re-raised by map()
                 errors[int(frame)] = e
                 return getattr(e, "status", None) or 10
         cb = self.BODY(trampoline)
+        pcb = self.PROGRESS((lambda user, status, frame, done: progress(int(status), int(frame), int(done))) if progress else 0)
         done, bad = C.c_uint64(0), C.c_uint64(0)
-        st = self._lib.gr_pool_map(self._pool, int(n_frames), cb, None, int(width), out.ctypes.data_as(C.c_void_p), C.byref(done), C.byref(bad))
+        st = self._lib.gr_pool_map_range(self._pool, int(start), int(n_frames), int(step), cb, None, int(width),
+                                         out.ctypes.data_as(C.c_void_p) if width else None, pcb if progress else None, None, C.byref(done), C.byref(bad))
         self.frames_done = int(done.value)
         if st != 0:
             self.last_error = (int(bad.value), errors.get(int(bad.value)))
-            raise errors.get(int(bad.value)) or RuntimeError("gr_pool_map failed at frame %d (status %d)" % (bad.value, st))
-        return out
+            raise errors.get(int(bad.value)) or RuntimeError("gr_pool_map_range failed at frame %d (status %d)" % (bad.value, st))
+        return out if width else out[:, :0]
 
 
 class Comm:
@@ -225,6 +237,10 @@ class Comm:
     def gather_per_frame(self, local_values, n_total):
         local = np.ascontiguousarray(local_values, dtype=np.float32)
         width = int(np.prod(local.shape[1:])) if local.ndim > 1 else 1
+        mine = len(range(self.rank, int(n_total), self.world))         # rows the C side reads: this rank's frames rank, rank + G, ...
+        if local.shape[0] < mine:
+            raise ValueError("gather_per_frame: rank %d of %d holds %d of %d frames and must pass at least %d rows, got %d"
+                             % (self.rank, self.world, mine, n_total, mine, local.shape[0]))
         out = np.zeros((n_total,) + tuple(local.shape[1:]), np.float32)
         st = self._lib.gr_comm_gather_per_frame(self._comm, local.ctypes.data_as(C.c_void_p), int(n_total), width, out.ctypes.data_as(C.c_void_p))
         if st != 0:

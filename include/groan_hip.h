@@ -450,6 +450,20 @@ gr_ctx *gr_pool_ctx(gr_pool *pool, int worker);
 const char *gr_pool_last_error(const gr_pool *pool);
 int gr_pool_map(gr_pool *pool, uint64_t n_frames, gr_pool_body body, void *user, size_t width, float *results,
                 uint64_t *frames_done, uint64_t *error_frame);
+/* The same with the reference's range / step arguments and its progress printer (traj_iter_map_reduce's start_time, end_time, step,
+ * progress_printer, parallel.rs:208-222; frame-index form: a reader's index turns times into frame numbers, gr_xtc_frame_info):
+ * the frames visited are first_frame + k * step for k = 0, 1, ... while < end_frame; worker w of T takes k = w, w + T, ... -- it skips
+ * w * step frames and then advances by step * T, exactly parallel.rs:425-448 -- and `result` is row k of `results` (rows in visiting
+ * order, ceil((end_frame - first_frame) / step) of them).  `body` receives the FRAME number.  `progress` (may be NULL) is the
+ * ProgressPrinter: called on worker 0's thread after every frame that worker completes (GR_PROGRESS_RUNNING; the reference
+ * attaches the printer to the master thread's iterator only, parallel.rs:417-422) and once after all workers have joined with
+ * GR_PROGRESS_COMPLETED and the last frame any worker read, or GR_PROGRESS_FAILED and the frame that failed (:288-321).
+ * step = 0 is GR_E_INVALID_ARG (the reference's ReadTrajError::InvalidStep). */
+enum { GR_PROGRESS_RUNNING = 0, GR_PROGRESS_COMPLETED = 1, GR_PROGRESS_FAILED = 2 };
+typedef void (*gr_pool_progress)(void *progress_user, int status, uint64_t frame, uint64_t frames_done);
+int gr_pool_map_range(gr_pool *pool, uint64_t first_frame, uint64_t end_frame, uint64_t step, gr_pool_body body, void *user,
+                      size_t width, float *results, gr_pool_progress progress, void *progress_user,
+                      uint64_t *frames_done, uint64_t *error_frame);
 /* Multi-process form (one process per GPU, e.g. under torchrun / mpirun): an RCCL communicator over xGMI for the two exchanges
  * the path has -- the final gather of the per-frame results and the shared error flag.  Rank 0 calls gr_comm_unique_id and
  * hands the 128 bytes to every rank by whatever the launcher offers (a file, MPI_Bcast, torch.distributed ...); every rank
@@ -463,6 +477,10 @@ gr_comm *gr_comm_create(int device, int rank, int world, const void *id128, int 
 void gr_comm_destroy(gr_comm *comm);
 const char *gr_comm_last_error(const gr_comm *comm);
 const char *gr_comm_library(void);
+/* use this RCCL build instead of the default search (the process's own copy, then librccl.so.1); call before the first gr_comm_* call
+ * of the process -- the library is resolved once.  A path that cannot be loaded makes every gr_comm_* call return GR_E_NO_DEVICE and
+ * gr_comm_library() say why. */
+int gr_comm_set_library(const char *path);
 int gr_comm_gather_per_frame(gr_comm *comm, const float *local, uint64_t n_total, size_t width, float *out);
 int gr_comm_any_error(gr_comm *comm, int local_flag, int *any);
 /* the host half of the gather on its own (no device, no RCCL): `gathered` = G shards of ceil(n_total / G) rows -> frame order */

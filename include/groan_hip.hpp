@@ -485,38 +485,54 @@ class XtcWriter {
 // ---- ParallelTrajData + traj_iter_map_reduce (src/system/parallel.rs:31-49,208-481)
 // One worker thread per device; worker n takes frames n, n+T, ... (parallel.rs:424-448); a shared AtomicBool
 // polled every ERROR_FLAG_FREQ = 10 frames stops the others after the first failure (parallel.rs:28,453-475).
+// start_frame / end_frame / step = the reference's start_time / end_time / step in frame-index form (a reader's index turns times
+// into frame numbers): the frames visited are start_frame + k * step below end_frame, worker n skips n * step of them and then
+// advances by step * T (parallel.rs:425-448).  progress = the ProgressPrinter: called from worker 0 after every frame it completes
+// (ProgressStatus::Running; the reference attaches the printer to the master thread only, :417-422) and once at the end with
+// Completed and the last frame ANY worker read, or Failed and the frame that failed (:288-321).
+enum class ProgressStatus { Running, Completed, Failed };
+using ProgressPrinter = std::function<void(ProgressStatus, uint64_t frame)>;
 template <typename Data>
 Data traj_iter_map_reduce(const std::vector<int> &devices, uint64_t n_frames,
                           const std::function<System(int device)> &make_system,                       // System clone per worker
                           const std::function<bool(uint64_t frame_index, Frame &out)> &read_frame,    // random access frame source
-                          const std::function<void(System &, Data &)> &body, const Data &init_data) {
+                          const std::function<void(System &, Data &)> &body, const Data &init_data,
+                          uint64_t start_frame = 0, uint64_t end_frame = UINT64_MAX, uint64_t step = 1,
+                          const ProgressPrinter &progress = nullptr) {
     const size_t T = devices.size();
     if (T == 0) throw std::invalid_argument("Number of threads to spawn must be > 0.");
+    if (step == 0) throw std::invalid_argument("ReadTrajError::InvalidStep");
+    const uint64_t end = std::min(end_frame, n_frames);
     std::vector<Data> data(T, init_data);
     std::vector<std::string> errors(T);
+    std::vector<uint64_t> last_frame(T, start_frame), failed_at(T, 0);
     std::atomic<bool> error_flag{false};
     std::vector<std::thread> workers;
     for (size_t n = 0; n < T; ++n) {
         data[n].initialize(n);
         workers.emplace_back([&, n] {
+            uint64_t f = start_frame + n * step;
             try {
                 System system = make_system(devices[n]);
-                uint64_t i = 0;
-                for (uint64_t f = n; f < n_frames; f += T, ++i) {
+                for (uint64_t i = 0; f < end; f += step * T, ++i) {
                     if (i % 10 == 0 && error_flag.load(std::memory_order_relaxed)) return;
                     Frame fr;
                     if (!read_frame(f, fr)) return;
                     system.set_frame(fr.xyz, fr.box);
                     body(system, data[n]);
+                    last_frame[n] = f;
+                    if (n == 0 && progress) progress(ProgressStatus::Running, f);
                 }
             } catch (const std::exception &e) {
                 error_flag.store(true, std::memory_order_relaxed);
-                errors[n] = e.what();
+                errors[n] = e.what(); failed_at[n] = f;
             }
         });
     }
     for (auto &w : workers) w.join();
-    for (const auto &e : errors) if (!e.empty()) throw std::runtime_error(e);
+    for (size_t n = 0; n < T; ++n)
+        if (!errors[n].empty()) { if (progress) progress(ProgressStatus::Failed, failed_at[n]); throw std::runtime_error(errors[n]); }
+    if (progress) progress(ProgressStatus::Completed, *std::max_element(last_frame.begin(), last_frame.end()));
     return Data::reduce(std::move(data));
 }
 

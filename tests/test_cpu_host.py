@@ -129,3 +129,26 @@ def test_container_validate_refuses_what_from_indices_lets_through(G):
     assert validate([256 + 3])[1:] == (G._lib.E_OUT_OF_RANGE, 259)                   # beyond the padded slot as well
     assert validate([5, 6, 7, 250])[1] == G._lib.OK                                  # out-of-range tail: clamped by the reference's scan
     assert validate([0, 99])[1] == G._lib.OK and validate([])[1] == G._lib.OK
+
+
+def test_comm_without_rccl_reports_no_device_instead_of_crashing(tmp_path):
+    """a host whose RCCL cannot be loaded: every gr_comm_* entry point returns GR_E_NO_DEVICE and gr_comm_library() carries the
+    loader's message (the first version of the loader called dlerror() twice and dereferenced the NULL of the second call).  Run
+    in a fresh process: the library is resolved once per process."""
+    import subprocess
+    import sys
+    code = (
+        "import ctypes as C, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "import groan_rs_amd as G\n"
+        "lib = G._lib.load()\n"
+        "assert lib.gr_comm_set_library(%r.encode()) == 0\n"
+        "buf = C.create_string_buffer(128)\n"
+        "st = C.c_int(0)\n"
+        "assert lib.gr_comm_unique_id(buf) == 13, 'unique_id'\n"
+        "assert not lib.gr_comm_create(0, 0, 1, buf, C.byref(st)) and st.value == 13, 'create'\n"
+        "msg = lib.gr_comm_library().decode()\n"
+        "assert msg.startswith('RCCL not found: ') and 'no_such_rccl' in msg, msg\n"
+        "print('ok')\n") % (ROOT, str(tmp_path / "no_such_rccl.so"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.returncode, r.stdout[-300:], r.stderr[-600:])

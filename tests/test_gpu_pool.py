@@ -19,7 +19,7 @@ def G():
     return g
 
 
-def run(G, n_workers, example, fail_at=None):
+def run(G, n_workers, example, fail_at=None, start=0, step=1, progress=None):
     x = G.XtcFile(os.path.join(GOLD, "short_trajectory.xtc"))       # indexed, random access, thread-safe reads: every worker reads its own frames
     n, nf = x.n_atoms, x.n_frames
     masses = np.full(n, np.nan, np.float32); masses[:61] = example["protein_masses"]
@@ -41,7 +41,7 @@ def run(G, n_workers, example, fail_at=None):
         out[3] = plans[worker].rmsd(0, 1)[0][0]
         visited[worker].append(frame)
     try:
-        res = pool.map(nf, body, width=4)
+        res = pool.map(nf, body, width=4, start=start, step=step, progress=progress)
         return res, visited, pool.frames_done
     finally:
         for p in plans: p.close()
@@ -64,6 +64,41 @@ def test_two_workers_equal_one_worker_bit_for_bit(G, example):
 def test_a_failing_body_fails_the_whole_call(G, example):
     with pytest.raises(RuntimeError, match="frame 5"):
         run(G, 2, example, fail_at=5)
+
+
+def test_range_step_and_progress_printer(G, example):
+    """traj_iter_map_reduce's start / step / progress_printer (parallel.rs:208-222): frames start, start + step, ...; worker w skips
+    w * step of them, then advances by step * T (:425-448); the printer runs in the master worker and closes with the last frame
+    ANY worker read (:300-317)"""
+    full, _, _ = run(G, 1, example)
+    log = []
+    got, v, done = run(G, 2, example, start=1, step=3, progress=lambda st, fr, d: log.append((st, fr, d)))
+    assert v == [[1, 7], [4, 10]] and done == 4                              # visited 1, 4, 7, 10: worker 0 -> k = 0, 2; worker 1 -> k = 1, 3
+    assert np.array_equal(got.view(np.uint32), full[1::3].view(np.uint32))   # rows in visiting order
+    assert [e[:2] for e in log if e[0] == 0] == [(0, 1), (0, 7)]             # RUNNING: the master worker's frames only
+    assert log[-1][0] == 1 and log[-1][1] == 10 and log[-1][2] == 4          # COMPLETED with the last frame any worker read
+    log = []
+    with pytest.raises(RuntimeError, match="frame 4"):
+        run(G, 2, example, fail_at=4, start=1, step=3, progress=lambda st, fr, d: log.append((st, fr, d)))
+    assert log[-1][0] == 2 and log[-1][1] == 4                               # FAILED with the failing frame
+    three, v3, _ = run(G, 3, example, start=2, step=2)
+    assert v3 == [[2, 8], [4, 10], [6]] and np.array_equal(three.view(np.uint32), full[2::2].view(np.uint32))
+    with pytest.raises(ValueError):
+        run(G, 1, example, step=0)
+
+
+def test_width_zero_bodies_and_short_gather_buffers_are_refused_cleanly(G, example):
+    """a body that returns nothing per frame (width 0: the reduce happens in the caller's own Data) must not be handed a NULL row;
+    a rank that passes fewer rows than its share of the frames is refused on the host instead of read past"""
+    pool = G.Pool([0, 0], 100)
+    seen = []
+    out = pool.map(7, lambda system, worker, frame, row: seen.append((frame, row)), width=0)
+    assert out.shape == (7, 0) and sorted(f for f, _ in seen) == list(range(7)) and all(r is None for _, r in seen)
+    pool.close()
+    comm = G.Comm(0, 0, 1, G.Comm.unique_id())
+    with pytest.raises(ValueError):
+        comm.gather_per_frame(np.zeros((3, 2), np.float32), 5)
+    comm.close()
 
 
 def test_comm_single_rank_gather_and_flag(G):

@@ -3,12 +3,12 @@ of every frame of the batch in parallel) must be BIT-IDENTICAL to the host decod
 bit-identical to the reference's decoders (tests/test_xtc_decoder.py).  Reference: XtcReader / update_system
 (src/io/xtc_io/mod.rs, molly_xtc.rs:268-308, xdrfile_xtc.rs:42-104)."""
 import os
-import zlib
 
 import numpy as np
 import pytest
 
-from test_xtc_decoder import GOLD, REF_SO, water_like, write_with_ref
+import xtc_cases as XC
+from test_xtc_decoder import GOLD
 
 pytestmark = pytest.mark.gpu
 
@@ -42,25 +42,14 @@ def test_reference_data_files(G, name):
     check_file(G, os.path.join(GOLD, name), batch=4, frame_step=2, host_threads=3)    # ragged last batch, strided frames, slot reuse
 
 
-@pytest.mark.parametrize("case", ["tiny9", "water", "gas", "wide_range", "wide_product", "high_precision", "mixed", "big_water"])
+@pytest.mark.parametrize("case", XC.CASES)
 def test_every_branch_of_the_format(G, tmp_path, case):
-    if not os.path.exists(REF_SO):
-        pytest.skip("oracle/_ref not built (reference tree absent)")
-    rng = np.random.default_rng(zlib.crc32(case.encode()))
-    box = np.array([[30, 0, 0], [0, 30, 0], [10, 10, 25]], np.float32)
-    prec = 1000.0
-    if case == "tiny9": frames = [rng.uniform(0, 5, (9, 3)).astype(np.float32)] * 3
-    elif case == "water": frames = [water_like(rng, 30000, 20.0) for _ in range(3)]
-    elif case == "gas": frames = [rng.uniform(-50, 50, (5000, 3)).astype(np.float32) for _ in range(3)]
-    elif case == "wide_range": frames = [np.concatenate([rng.uniform(0, 10, (4000, 3)), [[20000.0, 3.0, 4.0]]]).astype(np.float32) for _ in range(2)]
-    elif case == "wide_product": frames = [rng.uniform(0, 8000, (3000, 3)).astype(np.float32) for _ in range(2)]
-    elif case == "high_precision":
-        prec = 100000.0
-        frames = [water_like(rng, 3000, 6.0) for _ in range(3)]
-    elif case == "big_water": frames = [water_like(rng, 500_000, 17.0) for _ in range(2)]                  # config 5 size
-    else: frames = [np.concatenate([water_like(rng, 9000, 12.0), rng.uniform(0, 12, (1000, 3)).astype(np.float32), water_like(rng, 2001, 3.0)]) for _ in range(4)]
+    """files written HERE by the library's own encoder; their sha256 is the one of the file the reference's writer produces from
+    the same coordinates (tests/golden/xtc_pins.json, made in the build container by make_xtc_pins.py)"""
+    frames, box, prec = XC.branch_case(case)
     path = tmp_path / (case + ".xtc")
-    write_with_ref(path, frames, box, prec)
+    XC.write_own(G, path, frames, box, prec)
+    assert XC.sha256_file(path) == XC.pin(case)["sha256"], case
     check_file(G, path)
 
 
@@ -107,7 +96,7 @@ def test_group_limited_device_read(G, tmp_path):
     atom of the slot is left as it was ("all other atoms are left unchanged", molly_xtc.rs:585-587), box / step / time are set."""
     rng = np.random.default_rng(11)
     n, nf = 32817, 6
-    frames = [water_like(rng, n, 7.0) for _ in range(nf)]
+    frames = [XC.water_like(rng, n, 7.0) for _ in range(nf)]
     path = tmp_path / "aa_shaped.xtc"
     box = [6.44, 6.76, 7.26, 0, 0, 0, 0, 0, 0]
     with G.XtcWriter(path) as w:

@@ -1,7 +1,7 @@
 """config[4]-style pipeline on the GPU box: host xtc decode (the library's decoder, one frame per thread, straight into
 pinned buffers) overlapped with H2D on the copy stream and the GPU COM + centre/wrap work, double-buffered.
-The 5e5-atom truncated-octahedron trajectory is written at run time with the reference's xdrfile writer (oracle/_ref,
-test infrastructure).  Parity: per-frame COM and wrapped coordinates against the oracle; throughput and the stage times
+The 5e5-atom truncated-octahedron trajectory is written at run time with the library's own encoder; its sha256 is pinned to
+the file the reference's xdrfile writer produces from the same coordinates (tests/golden/xtc_pins.json).  Parity: per-frame COM and wrapped coordinates against the oracle; throughput and the stage times
 go to gpurun_out/xtc_pipeline.json."""
 import json
 import os
@@ -13,35 +13,22 @@ import numpy as np
 import pytest
 
 import oracle_lib as O
-from test_xtc_decoder import REF_SO, write_with_ref
+import xtc_cases as XC
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_decode_upload_com_wrap_pipeline(tmp_path):
-    if not os.path.exists(REF_SO):
-        pytest.skip("oracle/_ref not built")
     import groan_rs_amd as G
     n, n_frames, n_threads, n_buf = 500_000, 32, 8, 8
-    box9 = O.box_from_lengths_angles([18.0, 18.0, 18.0], [70.53, 109.47, 70.53])     # truncated octahedron (simbox.rs:329-342)
-    boxm = np.array([[box9[0], 0, 0], [box9[5], box9[1], 0], [box9[7], box9[8], box9[2]]], np.float32)
-    rng = np.random.default_rng(5)
-    nm = n // 3
-    mol = rng.uniform(0, 1, (nm, 3)) @ boxm.astype(np.float64)
-    base = (np.repeat(mol, 3, axis=0) + rng.normal(0, 0.06, (nm * 3, 3)))
-    base = np.concatenate([base, rng.uniform(0, 1, (n - 3 * nm, 3)) @ boxm.astype(np.float64)])
+    frames, box9, boxm = XC.octahedron_case(n)                                      # truncated octahedron (simbox.rs:329-342)
     prot = slice(0, 30_000)                                                        # a compact "solute" to take the COM of
-    base[prot] = O.box_center(box9) + rng.normal(0, 1.2, (30_000, 3))
-    frames = []
-    for f in range(4):                                                             # 4 distinct frames, cycled
-        fr = base + rng.normal(0, 0.02, base.shape)
-        fr[prot] += rng.uniform(-6, 6, 3)                                          # solute drifts through the periodic boundary
-        frames.append(O.wrap_atoms(fr.astype(np.float32), np.arange(n), box9))
     path = tmp_path / "octa_5e5.xtc"
     t0 = time.time()
-    write_with_ref(path, [frames[f % 4] for f in range(n_frames)], boxm, 1000.0)
+    XC.write_own(G, path, [frames[f % 4] for f in range(n_frames)], boxm, 1000.0)
     t_write = time.time() - t0
+    assert XC.sha256_file(path) == XC.pin("octahedron_5e5_x32")["sha256"]           # = the reference writer's bytes
     masses = np.array([15.999, 1.008, 1.008], np.float32)[np.arange(n) % 3]
 
     x = G.XtcFile(path)
@@ -116,7 +103,7 @@ def test_decode_upload_com_wrap_pipeline(tmp_path):
         O.set_accumulate_f64(False)
     out = {"n_atoms": n, "n_frames": n_frames, "decode_threads": n_threads, "file_MB": round(os.path.getsize(path) / 1e6, 1),
            "decode_one_thread_frames_per_s": round(1.0 / t_dec1, 1), "pipeline_frames_per_s": round(n_frames / t_all, 1),
-           "pipeline_wall_s": round(t_all, 3), "reference_writer_s": round(t_write, 2),
+           "pipeline_wall_s": round(t_all, 3), "own_writer_one_thread_s": round(t_write, 2),
            "stages": "xtc decode (host threads) || H2D copy stream || group_get_com + atoms_center_mass (all atoms) on the GPU"}
     # ---- the same pipeline with the frames unpacked ON THE DEVICE: host skims the framing (n_threads workers), the
     # compressed stream crosses PCIe, k_xtc_unpack decodes a batch of frames in one launch on the copy stream

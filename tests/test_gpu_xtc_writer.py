@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from test_xtc_decoder import GOLD, REF_SO, write_with_ref
+from test_xtc_decoder import GOLD
 
 pytestmark = pytest.mark.gpu
 
@@ -67,16 +67,8 @@ def test_decode_fit_write_matches_the_reference_fit_golden(G, tmp_path, example,
         assert np.array_equal(z.read_frame(f)[0], y.read_frame(f)[0][:61])
     with pytest.raises(G.XtcError):
         G.XtcWriter(tmp_path / "x.xtc").write_slots(cur, 0, 1, group="nope")
-    if os.path.exists(REF_SO):                                          # and against the reference's writer on the same coordinates
-        frames = [cur.get_positions(f) for f in range(nf)]
-        b9 = cur.get_box(0)
-        boxm = np.array([[b9[0], b9[3], b9[4]], [b9[5], b9[1], b9[6]], [b9[7], b9[8], b9[2]]], np.float32)
-        refp, ours = tmp_path / "ref.xtc", tmp_path / "ours.xtc"
-        write_with_ref(refp, frames, boxm, prec)
-        with G.XtcWriter(ours) as w:
-            for i, fr in enumerate(frames):
-                w.write_frame(fr, b9, step=i * 10, time=i * 0.5, precision=prec)
-        assert open(refp, "rb").read() == open(ours, "rb").read()
+    # (the encoder against the reference's writer byte for byte: tests/test_xtc_writer.py in the CPU suite, and the pinned files of
+    # tests/test_gpu_xtc_device.py here)
     x.close(); y.close(); z.close(); ref.close(); cur.close()
 
 

@@ -148,3 +148,26 @@ def test_random_systems_encode_to_the_reference_writers_bytes(G, tmp_path, seed)
     for i in range(3):
         assert np.array_equal(x.read_frame(i)[0], want[i])
     x.close()
+
+
+# ------------------------------------------------------------------ the pins the GPU suite relies on (tests/xtc_cases.py)
+import xtc_cases as XC   # noqa: E402
+
+
+@pytest.mark.parametrize("case", XC.CASES + ["octahedron_5e5_x32"])
+def test_pinned_cases_own_encoder_and_reference_writer(G, tmp_path, case):
+    """tests/golden/xtc_pins.json holds the sha256 of each synthetic trajectory as the REFERENCE's writer encodes it (made by
+    tests/golden/make_xtc_pins.py).  Here: the library's own encoder produces exactly those files -- which is what lets the -m gpu
+    tests write their inputs without the reference's compiled code -- and, where oracle/_ref exists, so does the reference."""
+    if case == "octahedron_5e5_x32":
+        fr, _, box = XC.octahedron_case()
+        frames, prec = [fr[f % 4] for f in range(32)], 1000.0
+    else:
+        frames, box, prec = XC.branch_case(case)
+    ours = tmp_path / "ours.xtc"
+    XC.write_own(G, ours, frames, box, prec)
+    assert XC.sha256_file(ours) == XC.pin(case)["sha256"] and os.path.getsize(ours) == XC.pin(case)["bytes"]
+    if os.path.exists(REF_SO) and case != "octahedron_5e5_x32":
+        refp = tmp_path / "ref.xtc"
+        write_with_ref(refp, frames, box, prec)
+        assert XC.sha256_file(refp) == XC.pin(case)["sha256"]
