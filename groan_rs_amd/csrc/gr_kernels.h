@@ -1067,6 +1067,55 @@ __device__ __forceinline__ gr_v2f gr_pd_tric2(const float4 t, gr_v2f jx, gr_v2f 
     return r;
 }
 
+// The same search when the VECTOR is needed (1-D / 2-D Dimensions of a triclinic cell are components of the 3-D minimum image,
+// vector3d.rs:458-486): all NC gains are kept, their minimum is found with the same v_min3 chain, and a reverse scan names the
+// FIRST entry that attains it -- the entry the sequential search of gr_tric_refine (strictly smaller wins) ends on; the entry's
+// vector comes from an LDS copy of the table (one 16-byte read per pair: a per-lane index cannot address the SGPR copy), and its
+// sign from one more dot product.  ~60 lane-instructions per pair against 124-180 for the rolled per-pair search.
+// `tab` = float4 {tx, ty, tz, 0} x NC in LDS, entry NC = zeros (no image wins).
+template <int NC, int DIM>
+__device__ __forceinline__ gr_v2f gr_pd_tric_vec2(const float4 t, gr_v2f jx, gr_v2f jy, gr_v2f jz, const GrBox &b, const float4 *tab) {
+    gr_v2f dx = gr_v2(t.x) - jx, dy = gr_v2(t.y) - jy, dz = gr_v2(t.z) - jz;
+    // brick reduction with k = rint(d / L) per axis (an ulp outside the brick is harmless: the image table covers it)
+    gr_v2f q = dz * gr_v2(b.icz);
+    gr_v2f k = { -rintf(q.x), -rintf(q.y) };
+    dx = gr_v2_fma(k, gr_v2(b.cx), dx); dy = gr_v2_fma(k, gr_v2(b.cy), dy); dz = gr_v2_fma(k, gr_v2(b.cz), dz);
+    q = dy * gr_v2(b.iby); k.x = -rintf(q.x); k.y = -rintf(q.y);
+    dx = gr_v2_fma(k, gr_v2(b.bx), dx); dy = gr_v2_fma(k, gr_v2(b.by), dy);
+    q = dx * gr_v2(b.iax); k.x = -rintf(q.x); k.y = -rintf(q.y);
+    dx = gr_v2_fma(k, gr_v2(b.ax), dx);
+    const gr_v2f r2 = dx * dx + dy * dy + dz * dz;
+    gr_v2f g[NC];
+    gr_v2f best = { 0.0f, 0.0f };
+#pragma unroll
+    for (int m = 0; m < NC; m += 2) {
+        const gr_v2f d0 = gr_v2_fma(gr_v2(b.cand[m][0]), dx, gr_v2_fma(gr_v2(b.cand[m][1]), dy, gr_v2(b.cand[m][2]) * dz));
+        const gr_v2f d1 = gr_v2_fma(gr_v2(b.cand[m + 1][0]), dx, gr_v2_fma(gr_v2(b.cand[m + 1][1]), dy, gr_v2(b.cand[m + 1][2]) * dz));
+        g[m].x = fmaf(-2.0f, __builtin_fabsf(d0.x), b.cand_t2[m]); g[m].y = fmaf(-2.0f, __builtin_fabsf(d0.y), b.cand_t2[m]);
+        g[m + 1].x = fmaf(-2.0f, __builtin_fabsf(d1.x), b.cand_t2[m + 1]); g[m + 1].y = fmaf(-2.0f, __builtin_fabsf(d1.y), b.cand_t2[m + 1]);
+        best.x = gr_min3f(best.x, g[m].x, g[m + 1].x); best.y = gr_min3f(best.y, g[m].y, g[m + 1].y);
+    }
+    // (a vector shorter than r_ws is its own minimum image whatever the table says: gr_tric_refine returns before the search)
+    const float rws2 = b.r_ws * b.r_ws;
+    int ix = NC, iy = NC;
+#pragma unroll
+    for (int m = NC - 1; m >= 0; --m) { ix = g[m].x == best.x ? m : ix; iy = g[m].y == best.y ? m : iy; }
+    ix = (best.x < 0.0f && !(r2.x < rws2)) ? ix : NC; iy = (best.y < 0.0f && !(r2.y < rws2)) ? iy : NC;
+    const float4 tx = tab[ix], ty = tab[iy];
+    // add t when d.t < 0, subtract it otherwise (gr_tric_refine)
+    const float sx = __builtin_copysignf(1.0f, -fmaf(tx.x, dx.x, fmaf(tx.y, dy.x, tx.z * dz.x))), sy = __builtin_copysignf(1.0f, -fmaf(ty.x, dx.y, fmaf(ty.y, dy.y, ty.z * dz.y)));
+    const float ax_ = dx.x + sx * tx.x, ay_ = dy.x + sx * tx.y, az_ = dz.x + sx * tx.z;
+    const float bx_ = dx.y + sy * ty.x, by_ = dy.y + sy * ty.y, bz_ = dz.y + sy * ty.z;
+    gr_v2f r;
+    if (DIM == 1) { r.x = ax_; r.y = bx_; }
+    else if (DIM == 2) { r.x = ay_; r.y = by_; }
+    else if (DIM == 3) { r.x = az_; r.y = bz_; }
+    else if (DIM == 4) { r.x = gr_mag3(ax_, ay_, 0.0f); r.y = gr_mag3(bx_, by_, 0.0f); }
+    else if (DIM == 5) { r.x = gr_mag3(ax_, 0.0f, az_); r.y = gr_mag3(bx_, 0.0f, bz_); }
+    else { r.x = gr_mag3(0.0f, ay_, az_); r.y = gr_mag3(0.0f, by_, bz_); }
+    return r;
+}
+
 template <int NC>
 __global__ __launch_bounds__(GR_WG) void k_pairdist(
     const float *__restrict__ xyz, size_t frame_stride, GrSel s1, GrSel s2, const GrBox *__restrict__ boxes, int dim,
@@ -1075,6 +1124,8 @@ __global__ __launch_bounds__(GR_WG) void k_pairdist(
     xyz += (size_t)blockIdx.z * frame_stride; out += (size_t)blockIdx.z * out_stride; bad_out += 4 * blockIdx.z;
     __shared__ float ti[GR_PD_TI][4];
     __shared__ uint32_t ldsu[GR_WG / 64];
+    __shared__ float4 ttab[NC + 1];            // the image table for per-lane look-ups (1-D / 2-D dimensions of a triclinic cell)
+    if (threadIdx.x <= NC) ttab[threadIdx.x] = threadIdx.x < NC ? make_float4(box.cand[threadIdx.x][0], box.cand[threadIdx.x][1], box.cand[threadIdx.x][2], 0.0f) : make_float4(0.f, 0.f, 0.f, 0.f);
     const uint32_t i0 = blockIdx.y * GR_PD_TI, j0 = blockIdx.x * (GR_WG * 4) + threadIdx.x * 4;
     uint32_t bad = GR_NOIDX, badj = GR_NOIDX;   // first atom without position among the rows / the columns
     // every coordinate of the tile within a quarter box of the cell (NaN fails the test): licence for gr_mi_near
@@ -1158,6 +1209,24 @@ __global__ __launch_bounds__(GR_WG) void k_pairdist(
             const gr_v2f a = gr_pd_tric2<NC>(t, jx01, jy01, jz01, box), b = gr_pd_tric2<NC>(t, jx23, jy23, jz23, box);
             const float d[4] = { a.x, a.y, b.x, b.y };
             put(r, d);
+        }
+    } else if (dim != 0 && !box.ortho) {
+        // 1-D / 2-D dimensions of a triclinic cell: components of the 3-D minimum-image vector
+        auto rows = [&](auto D) {
+            for (uint32_t r = 0; r < ni; ++r) {
+                const float4 t = *reinterpret_cast<const float4 *>(&ti[r][0]);
+                const gr_v2f a = gr_pd_tric_vec2<NC, decltype(D)::value>(t, jx01, jy01, jz01, box, ttab), b = gr_pd_tric_vec2<NC, decltype(D)::value>(t, jx23, jy23, jz23, box, ttab);
+                const float d[4] = { a.x, a.y, b.x, b.y };
+                put(r, d);
+            }
+        };
+        switch (dim) {
+        case 1: rows(std::integral_constant<int, 1>()); break;
+        case 2: rows(std::integral_constant<int, 2>()); break;
+        case 3: rows(std::integral_constant<int, 3>()); break;
+        case 4: rows(std::integral_constant<int, 4>()); break;
+        case 5: rows(std::integral_constant<int, 5>()); break;
+        default: rows(std::integral_constant<int, 6>()); break;
         }
     } else {
         for (uint32_t r = 0; r < ni; ++r) {

@@ -76,6 +76,19 @@ def test_triclinic_packed_loop_vs_oracle(G, angles):
     got = s.group_all_distances("A", "B", G.Dimension.XYZ)
     want = O.group_all_distances(pos, ia, ib, "xyz", box)
     np.testing.assert_allclose(got, want, atol=1e-5, rtol=0)
+    # 1-D (signed) and 2-D dimensions: components of the 3-D minimum-image vector (vector3d.rs:458-486 generalised) -- the packed
+    # search that names the winning image.  A pair whose two best images are equally long to within the f32 rounding of their
+    # squared lengths (~1e-7 relative) may legitimately resolve to either: such pairs are excluded, everything else must agree.
+    L = np.array([[box[0], 0, 0], [box[5], box[1], 0], [box[7], box[8], box[2]]], np.float64)
+    ks = np.array([(i, j, k) for i in range(-2, 3) for j in range(-2, 3) for k in range(-2, 3)], np.float64) @ L
+    d = pos[ia].astype(np.float64)[:, None, :] - pos[ib].astype(np.float64)[None, :, :]
+    r2 = np.sort(((d[:, :, None, :] + ks[None, None, :, :]) ** 2).sum(-1), axis=-1)
+    clear = (r2[:, :, 1] - r2[:, :, 0]) > 1e-4                                        # nm^2 between the best and the second-best image
+    assert clear.mean() > 0.999
+    for dim in ("X", "Y", "Z", "XY", "XZ", "YZ"):
+        got = s.group_all_distances("A", "B", G.Dimension[dim])
+        want = O.group_all_distances(pos, ia, ib, dim.lower(), box)
+        assert np.abs(got - want)[clear].max() <= 1e-5, dim
     s.close()
 
 

@@ -24,14 +24,14 @@ for name, (l, a) in {"triclinic": ([24.0, 23.0, 22.0], [75.0, 80.0, 70.0]), "dod
     s.group_create_from_ranges("S", [(0, S - 1)])
     lib = s._lib
     dev = C.c_void_p(); n1 = C.c_uint64(); n2 = C.c_uint64()
-    for dim in (7, 4):
+    for dim in (7, 4, 1):
         lib.gr_group_all_distances_device(s._ctx, 0, b"S", b"S", dim, C.byref(dev), C.byref(n1), C.byref(n2))   # warm-up + alloc
         s.sync(); s.timer_start()
         for _ in range(reps):
             st = lib.gr_group_all_distances_device(s._ctx, 0, b"S", b"S", dim, C.byref(dev), C.byref(n1), C.byref(n2))
             assert st == 0
         ms = s.timer_stop() / reps
-        out["%s/%s" % (name, "XYZ" if dim == 7 else "XY")] = {"ms_per_frame": round(ms, 4), "frames_per_s": round(1e3 / ms, 1),
+        out["%s/%s" % (name, {7: "XYZ", 4: "XY", 1: "X (signed)"}[dim])] = {"ms_per_frame": round(ms, 4), "frames_per_s": round(1e3 / ms, 1),
                                                              "write_GBps": round(4.0 * S * S / (ms * 1e-3) / 1e9, 1)}
         if dim == 7:   # the same matrices for NB resident frames per call: one launch, one synchronisation
             status = (C.c_int * NB)()
