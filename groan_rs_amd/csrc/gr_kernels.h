@@ -235,24 +235,6 @@ __device__ __forceinline__ float gr_wave_max_scatter16(float (&a)[32], const uin
 #define GR_CEN_K 8
 struct GrCenPartial { double s[GR_CEN_K]; uint32_t bad_pos, bad_mass; };
 
-// sine and cosine of an f32 angle in [0, 2 pi] (any |theta| < ~1e3 works): q = nearest multiple of pi/2, Cody-Waite
-// reduction with pi/2 split in two f32 (q <= 4: q * hi is exact), |r| <= pi/4, Taylor polynomials to r^9 / r^10 (truncation
-// < 2e-9), then the quarter-turn symmetries.  Within ~1e-7 of the correctly rounded values, like libm's sincosf.
-__device__ __forceinline__ void gr_sincos_2pi(float theta, float &s, float &c) {
-    const float q = rintf(theta * 0.636619772367581343f);
-    float t = fmaf(-q, 1.57079637050628662109375f, theta);
-    t = fmaf(q, 4.37113900018624283e-8f, t);            // pi/2 = hi - 4.3711e-8
-    const float t2 = t * t;
-    float sp = fmaf(t2, 2.7557319e-6f, -1.9841270e-4f); sp = fmaf(sp, t2, 8.3333333e-3f); sp = fmaf(sp, t2, -1.6666667e-1f);
-    const float sn = fmaf(t * t2, sp, t);
-    float cp = fmaf(t2, -2.7557319e-7f, 2.4801587e-5f); cp = fmaf(cp, t2, -1.3888889e-3f); cp = fmaf(cp, t2, 4.1666667e-2f); cp = fmaf(cp, t2, -0.5f);
-    const float cs = fmaf(t2, cp, 1.0f);
-    const int qi = (int)q & 3;
-    const float a = (qi & 1) ? cs : sn, b = (qi & 1) ? sn : cs;
-    s = (qi & 2) ? -a : a;
-    c = ((qi + 1) & 2) ? -b : b;
-}
-
 template <int KIND>   // 0 naive, 1 Bai-Breen, 2 unwrapped about state.center (compile-time: the naive sums need neither box nor branches)
 __global__ __launch_bounds__(GR_WG) void k_center_sums(
     const float *__restrict__ frames, size_t frame_stride, uint32_t first_slot,
@@ -292,10 +274,25 @@ __global__ __launch_bounds__(GR_WG) void k_center_sums(
                 x = ux; y = uy;
             }
             // the reference's own f32 angle theta = wrap(x) * (2 pi / L) (auxiliary.rs:59-84), bit for bit -- for a group spread
-            // over the whole box the resultant is short and the estimate amplifies every 1e-7 in theta -- but its sine and
-            // cosine by quarter-turn reduction + two short polynomials instead of libm's sincosf (the pass was VALU-bound)
+            // over the whole box the resultant is short and the estimate amplifies every 1e-7 in theta
+            // and its sine and cosine from the hardware: v_sin_f32 / v_cos_f32 take their argument in REVOLUTIONS, so theta / 2 pi --
+            // a number in [0, 1] -- needs no range reduction at all.  Measured on gfx950 over 4.2 M arguments in [0, 1)
+            // (tools/microbench/vsin_accuracy.hip): max |error| 1.25e-7, rms 3.5e-8, mean 1e-13 -- libm's sinf quality, at 2
+            // quarter-rate instructions per pair instead of the ~25 of a Cody-Waite reduction + two polynomials (round 2; the pass
+            // was VALU-bound: 3.9 -> 2.x us per 1e6-atom frame).  u = theta / 2 pi is formed with its rounding error e (the exact
+            // residual of the product + the low part of 1 / 2 pi) and the two results are corrected to first order, sin(2 pi (u + e))
+            // = s + 2 pi e c: without that the rounding of u (up to 3.7e-7 rad near a full turn) is the largest error in the sum, and
+            // a group spread evenly over the whole box -- the water of example.gro: a resultant of ~1 from 10 399 unit vectors --
+            // turns every 1e-7 per atom into 1e-5 nm of the estimate
             float s0, c0, s1, c1, s2, c2;
-            gr_sincos_2pi(x * scx, s0, c0); gr_sincos_2pi(y * scy, s1, c1); gr_sincos_2pi(z * scz, s2, c2);
+            auto sincos_rev = [](float theta, float &sn, float &cs) {
+                const float IH = 0.15915493667125702f, IL = 6.4206382432985265e-09f, TWO_PI = 6.283185307179586f;
+                const float u = theta * IH;
+                const float e = fmaf(theta, IL, fmaf(theta, IH, -u));
+                const float s = __builtin_amdgcn_sinf(u), c = __builtin_amdgcn_cosf(u), k = TWO_PI * e;
+                sn = fmaf(k, c, s); cs = fmaf(-k, s, c);
+            };
+            sincos_rev(x * scx, s0, c0); sincos_rev(y * scy, s1, c1); sincos_rev(z * scz, s2, c2);
             p[0] = fmaf(m, c0, p[0]); p[1] = fmaf(m, c1, p[1]); p[2] = fmaf(m, c2, p[2]);
             p[3] = fmaf(m, s0, p[3]); p[4] = fmaf(m, s1, p[4]); p[5] = fmaf(m, s2, p[5]);
             p[6] += 1.0f;
