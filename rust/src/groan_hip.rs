@@ -30,6 +30,9 @@ pub const GR_E_GROUP_NOT_FOUND: c_int = 8;
 #[repr(C)] pub struct gr_pool { _private: [u8; 0] }
 #[repr(C)] pub struct gr_comm { _private: [u8; 0] }
 /// `body(ctx, worker, frame, user, result)` of gr_pool_map: non-zero return = the frame's error (the first one wins)
+/// `progress(user, status, frame, frames_done)` of gr_pool_map_range: GR_PROGRESS_RUNNING = 0 after every frame of worker 0,
+/// then once GR_PROGRESS_COMPLETED = 1 / GR_PROGRESS_FAILED = 2 (ProgressPrinter + ProgressStatus, src/progress.rs)
+pub type gr_pool_progress = Option<unsafe extern "C" fn(user: *mut c_void, status: c_int, frame: u64, frames_done: u64)>;
 pub type gr_pool_body = Option<unsafe extern "C" fn(ctx: *mut gr_ctx, worker: c_int, frame: u64, user: *mut c_void, result: *mut c_float) -> c_int>;
 extern "C" {
     pub fn gr_ctx_create(device: c_int, n_atoms: u64, n_slots: u32, status: *mut c_int) -> *mut gr_ctx;
@@ -113,6 +116,11 @@ extern "C" {
     pub fn gr_pool_last_error(pool: *const gr_pool) -> *const c_char;
     pub fn gr_pool_map(pool: *mut gr_pool, n_frames: u64, body: gr_pool_body, user: *mut c_void, width: usize, results: *mut c_float,
                        frames_done: *mut u64, error_frame: *mut u64) -> c_int;
+    /// traj_iter_map_reduce's start_time / end_time / step (frame-index form) and its progress printer (parallel.rs:208-222,417-448)
+    pub fn gr_pool_map_range(pool: *mut gr_pool, first_frame: u64, end_frame: u64, step: u64, body: gr_pool_body, user: *mut c_void, width: usize,
+                             results: *mut c_float, progress: gr_pool_progress, progress_user: *mut c_void, frames_done: *mut u64, error_frame: *mut u64) -> c_int;
+    pub fn gr_comm_set_library(path: *const c_char) -> c_int;
+    pub fn gr_ctx_stat(ctx: *const gr_ctx, key: c_int, value: *mut u64) -> c_int;   // GR_STAT_* (include/groan_hip.h)
     // ... and one process per GPU (RCCL over xGMI: one final all-gather + the shared error flag)
     pub fn gr_comm_unique_id(id128: *mut c_void) -> c_int;
     pub fn gr_comm_create(device: c_int, rank: c_int, world: c_int, id128: *const c_void, status: *mut c_int) -> *mut gr_comm;
@@ -272,7 +280,11 @@ impl<'a> HipAtomIterator<'a> {
 
 /// Batched form of `HipRmsd` for trajectory loops that can look ahead: `push` stages a frame into the next free slot (one
 /// copy out of the `System`, one asynchronous upload), `flush` runs ONE `gr_rmsd_batch` over everything staged -- the
-/// library's batched path (256-frame launch groups) instead of one launch + synchronisation per frame.
+/// library's batched path instead of one launch + synchronisation per frame.
+/// THIS is the adapter to use for throughput.  The per-frame `HipRmsd` below keeps the reference's `FrameAnalyze` contract (one
+/// result per `analyze` call) and therefore runs batches of ONE frame: a launch + a synchronisation per frame and, for systems
+/// that fill the chip, never the single-pass resident kernel (which needs >= 16 frames per call) --
+/// about a tenth of the batched rate at 1e6 atoms.  Use a capacity of >= 64 (256-1024 for large systems).
 pub struct HipRmsdBatch { inner: HipRmsd, staged: u32, capacity: u32, pinned: Vec<Vec<[f32; 3]>> }
 impl HipRmsdBatch {
     pub fn new(reference: &System, target: &System, group: &str, device: i32, capacity: u32) -> Result<Self, RMSDError> {
