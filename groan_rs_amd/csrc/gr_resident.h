@@ -679,7 +679,7 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
     auto step = [&](uint32_t i, Landing &cur, Landing &nxt) {
 #ifdef GR_EXP_NOLOAD
         if (i < 2) request(i + 1, nxt);
-#else
+#elif !defined(GR_EXP_LATE_REQUEST)
         if (i + 1 < nframes) request(i + 1, nxt);
 #endif
         balance(i);
@@ -696,6 +696,9 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
             if (bail) return;
         }
         if (i + 1 >= K && i + 1 < n_iter) rv = request_rec(i + 1 - K);
+#ifdef GR_EXP_LATE_REQUEST
+        if (i + 1 < nframes) request(i + 1, nxt);               // (experiment: the next frame's rows requested after this step's stores)
+#endif
         if (i < nframes) {
             if (V) sums(i, cur, Bs, va, vb);                    // (the slot's old content has been read by the fit above)
             lds_put(ps, va);

@@ -1,14 +1,15 @@
 #!/bin/bash
-# Round evidence on the GPU box (-> gpurun_out/): kernel trace + PMC passes of the bench command, secondary pipelines, pair distances
+# Round evidence on the GPU box (-> gpurun_out/): kernel trace + PMC passes of the bench command, the memory floors, the secondary
+# pipelines, pair distances.  Copy what is to be judged into profiles/ afterwards (tools/collect_evidence.sh).
 set -o pipefail
-TAG=${1:-r02}
+TAG=${1:-r03}
 mkdir -p gpurun_out
 # (the secondary pipelines first: freeing the gigabytes of an earlier section perturbs the next timed region for a while)
 timeout -k 10 300 python tools/secondary_bench.py > gpurun_out/${TAG}_secondary.json 2> gpurun_out/${TAG}_secondary.err; echo "secondary rc=$?"
 sleep 3
-PROFILE_ARGS="--steps 5 --warmup 2 --frames-per-step 768 --no-cpu-baseline" timeout -k 10 900 bash tools/profile.sh $TAG "--steps 5 --warmup 2 --frames-per-step 768 --no-cpu-baseline" > gpurun_out/${TAG}_profile.log 2>&1; echo "profile rc=$?"; tail -6 gpurun_out/${TAG}_profile.log
-timeout -k 10 300 python tools/pairdist_bench.py > gpurun_out/${TAG}_pairdist.json 2> gpurun_out/${TAG}_pairdist.err; echo "pairdist rc=$?"
 timeout -k 10 200 tools/bin/ceiling_bench > gpurun_out/${TAG}_ceiling.json 2> gpurun_out/${TAG}_ceiling.err; echo "ceiling rc=$?"
-# the two-pass path (what frames that do not fill the chip, sub-selections and gathers take): same command with the resident pass off
-PROFILE_ARGS="--steps 5 --warmup 2 --no-cpu-baseline --tune resident=0" timeout -k 10 900 bash tools/profile.sh ${TAG}_twopass "--steps 5 --warmup 2 --no-cpu-baseline --tune resident=0" > gpurun_out/${TAG}_twopass_profile.log 2>&1; echo "two-pass profile rc=$?"
+PROFILE_ARGS="--steps 5 --warmup 2 --frames-per-step 768 --no-cpu-baseline" timeout -k 10 900 bash tools/profile.sh $TAG "--steps 5 --warmup 2 --frames-per-step 768 --no-cpu-baseline" > gpurun_out/${TAG}_profile.log 2>&1; echo "profile rc=$?"; tail -4 gpurun_out/${TAG}_profile.log
+timeout -k 10 300 python tools/pairdist_bench.py > gpurun_out/${TAG}_pairdist.json 2> gpurun_out/${TAG}_pairdist.err; echo "pairdist rc=$?"
+timeout -k 10 300 bash tools/pmc_pairdist.sh > gpurun_out/${TAG}_pmc_pairdist.txt 2>&1; echo "pmc pairdist rc=$?"
+# the two-pass path (what frames that do not fill the chip, sub-selections that are not the whole system ... take): resident pass off
 timeout -k 10 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --tune resident=0 > gpurun_out/${TAG}_bench_twopass.json 2> gpurun_out/${TAG}_bench_twopass.err; echo "two-pass bench rc=$?"
