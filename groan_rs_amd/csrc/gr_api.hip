@@ -245,7 +245,7 @@ static bool resident_prepare() {
 // Streaming workgroups of the resident RMSD-fit pass (gr_resident.h), or 0 when the two-pass path takes the segment: the
 // frame must fit (one 4-atom group per lane) beside at least two finalizer workgroups, and -- unless forced -- fill most of
 // the chip: a small frame streams faster through the two-pass kernels, which spread it over every CU.
-uint32_t resident_wgs(gr_ctx *c, bool lite, uint32_t nb) {
+uint32_t resident_wgs(gr_ctx *c, bool lite, uint32_t nb, const GrSel &sel) {
     if (!lite || !c->resident || !c->res_max_wgs) return 0;
     const uint64_t groups = ((c->n + 255) >> 8) << 6;
     const uint64_t wgs = (groups + GR_RES_GROUPS - 1) / GR_RES_GROUPS;   // (a workgroup owns 1024 groups whatever the groups per lane)
@@ -256,6 +256,11 @@ uint32_t resident_wgs(gr_ctx *c, bool lite, uint32_t nb) {
     // ... and when the segment is long enough to pay for filling and draining the six-frame pipeline (measured at 16 frames per
     // call: 9.8 us per frame against 10.6 for the two passes; single frames are a chain of waits)
     if (c->resident == 1 && nb < 16) return 0;
+    // ... and when the selection is (nearly) the whole system.  Every workgroup of the pass advances at the pace of the slowest one
+    // (a frame's record needs all of them), and with a partial selection the workgroups that hold it run sums AND the literal fit
+    // arithmetic while the others only fit: measured at 1e6 atoms with a tenth of them selected, 6.3 us per frame against 4.5 for
+    // the two passes, whose sums pass shrinks with the selection (profiles/r03_secondary.json)
+    if (c->resident == 1 && (uint64_t)sel.n * 10 < c->n * 9) return 0;
     // a launch that missed its start handshake (the device was busy with somebody else's kernels) makes the context sit out a few
     // segments -- twice as many after every miss in a row -- instead of giving the pass up for good (gr_ctx_stat counts the misses)
     if (c->res_skip) { c->res_skip--; return 0; }
@@ -1578,7 +1583,7 @@ static int segment_begin(gr_rmsd_plan *p, uint32_t s0, uint32_t nb, int fit) {
         const bool fused = lite && c->fuse;   // the finalize rides on the tail of the sums kernel
         q.fused = fused;
         hipStream_t S = c->stream;
-        uint32_t res_stream = resident_wgs(c, lite, nb);
+        uint32_t res_stream = resident_wgs(c, lite, nb, sel);
         if (res_stream && !resident_acquire(c->device)) res_stream = 0;
         if (res_stream) c->res_in_use = true;           // (released in segment_end, or by the caller when this function fails)
         if (res_stream) {

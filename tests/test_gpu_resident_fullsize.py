@@ -75,14 +75,50 @@ def test_headline_shape_default_tuning_all_atoms(G):
     plan.close(); ref.close(); cur.close()
 
 
-def test_headline_shape_prefix_selection(G):
-    """SURVEY 8(d)'s S = 1e5 prefix variant at full size: the first 25 workgroups carry the selection (the last of them a ragged
-    end inside a lane's 4-atom group), the other 220 only stream + fit"""
+@pytest.mark.parametrize("forced", [False, True])
+def test_headline_shape_prefix_selection(G, forced):
+    """SURVEY 8(d)'s S = 1e5 prefix variant at full size.  By default a selection of less than 9/10 of the system takes the two
+    passes (the resident pass advances at the pace of the workgroups that hold the selection: 6.3 us per frame against 4.5);
+    forced (GR_TUNE_RESIDENT = 2) it runs the row-parking kernel variant: the first 25 workgroups carry the selection (the last
+    of them a ragged end inside a lane's 4-atom group), the other 220 skip the sums arithmetic and only stream + fit"""
     nf, s_last = 24, 99_998
     box, masses, cur, ref, ref_pos, plan = _c4(G, N, nf, sel=(0, s_last))
+    if forced:
+        cur.set_tuning(resident=2)
     prof, _ = _check(cur, plan, ref_pos, masses, np.arange(s_last + 1), box, [box] * nf, nf, [0, 6, 11, nf - 1])
+    assert (prof["k_fit_resident"][1] == 1) == forced and (prof["k_fit_pk"][1] > 0) == (not forced), prof
+    plan.close(); ref.close(); cur.close()
+
+
+def test_nearly_whole_selection_takes_the_row_parking_variant(G):
+    """a selection of more than 9/10 of the system that is not the whole system: resident by default, kernel variant V = false"""
+    nf = 24
+    box, masses, cur, ref, ref_pos, plan = _c4(G, N, nf, sel=(1_000, N - 3))
+    prof, _ = _check(cur, plan, ref_pos, masses, np.arange(1_000, N - 2), box, [box] * nf, nf, [0, 7, nf - 1])
     assert prof["k_fit_resident"][1] == 1 and prof["k_fit_pk"][1] == 0, prof
     plan.close(); ref.close(); cur.close()
+
+
+def test_a_plan_destroyed_with_a_batch_in_flight_gives_the_device_back(G):
+    """gr_rmsd_batch_begin takes the per-device slot of the resident pass; destroying the plan (or the context) before
+    gr_rmsd_batch_end must hand it back, or every later context of the process would silently fall to the two passes"""
+    nf = 24
+    box, masses, cur, ref, ref_pos, plan = _c4(G, N, nf)
+    plan.begin(0, nf, fit=True)
+    plan.close()                                                                   # mid-batch
+    plan2 = G.RMSDPlan(ref, cur, "all")
+    cur.synth_frames(nf, 0, nf, 0, 0.05, W.SEED)
+    cur.profile_enable(True)
+    r, st = plan2.rmsd_fit(0, nf)
+    assert (st == 0).all() and cur.profile_read()["k_fit_resident"][1] == 1
+    plan2.begin(0, nf, fit=True)                                                   # ... and the context destroyed mid-batch
+    cur.close()
+    plan2._plan = None                                                             # (its context is gone: the handle must not be used again)
+    box, masses, cur3, ref3, ref_pos3, plan3 = _c4(G, N, nf)
+    cur3.profile_enable(True)
+    r, st = plan3.rmsd_fit(0, nf)
+    assert (st == 0).all() and cur3.profile_read()["k_fit_resident"][1] == 1
+    plan3.close(); ref3.close(); cur3.close(); ref.close()
 
 
 def test_headline_shape_with_a_different_box_in_every_frame(G):
