@@ -314,12 +314,20 @@ def main():
                 import shutil
                 shutil.rmtree(tmpdir, ignore_errors=True)
     # what the resident pass did on every rank (ranks that share a device take turns on it or fall back to the two passes: gr_resident.h)
-    res_stats = {k: cur.stat(k) for k in ("res_launches", "res_handshake_misses", "res_aborts", "res_redone_frames")}
+    res_stats = {}
+    for k in ("res_launches", "res_handshake_misses", "res_aborts", "res_redone_frames", "res_last_streams"):
+        try:
+            res_stats[k] = cur.stat(k)
+        except Exception:                         # (an older build of the library under GR_LIB_PATH: A/B runs)
+            res_stats[k] = None
+    every_stats = [res_stats]
     if dist is not None:
-        every_stats = [None] * world
-        dist.all_gather_object(every_stats, res_stats)
-    else:
-        every_stats = [res_stats]
+        try:                                      # (diagnostics only: never allowed to take the benchmark line down)
+            gathered_stats = [None] * world
+            dist.all_gather_object(gathered_stats, res_stats)
+            every_stats = gathered_stats
+        except Exception as e:
+            every_stats = [res_stats, {"all_gather_object": repr(e)}]
     out["config"]["per_rank_resident"] = every_stats
     if rank == 0:
         if args.dump_rmsd:

@@ -84,6 +84,9 @@ struct gr_ctx {
     int two_pass = 1;                 // GR_TUNE_TWO_PASS 0: RMSD-fit keeps the closed-form single-pass rmsd (k_rmsd_accum<0>)
     // resident RMSD fit (gr_resident.h): one launch per segment, the frame waits on chip for its rotation
     int resident = 1;                 // GR_TUNE_RESIDENT 0 never, 1 when the frame fills the chip, 2 whenever it fits (tests)
+    int res_streams = 0;              // GR_TUNE_RESIDENT_STREAMS 0 automatic, 1..GR_RES_MAX_STREAMS: at most so many frame streams per resident launch
+    int res_fill16 = 15;              // GR_TUNE_RESIDENT_FILL: sixteenths of the chip the streaming workgroups must fill for the pass to be chosen (resident = 1)
+    uint32_t res_last_streams = 0;    // frame streams of the last resident launch (gr_ctx_stat)
     uint32_t res_max_wgs = 0;         // workgroups of k_fit_resident the device holds at once (0: the pass cannot run here)
     int res_test_no_start = 0;        // GR_TUNE_TEST_RESIDENT_NO_START (tests): the next resident launch finds its start verdict already "never started"
     uint32_t res_test_abort_at = 0xFFFFFFFFu;   // GR_TUNE_TEST_RESIDENT_ABORT_AT (tests): the finalizer of this frame of the next resident launch raises `abort`
@@ -136,7 +139,7 @@ struct gr_ctx {
 
 struct Pending {   // a segment between gr_rmsd_batch_begin and gr_rmsd_batch_end
     bool active = false, any_ok = false, consistent = true, fused = false, resident = false;
-    uint32_t s0 = 0, nb = 0, n_prof_groups = 0, res_stream = 0;
+    uint32_t s0 = 0, nb = 0, n_prof_groups = 0, res_stream = 0, res_streams = 1;   // (resident launch: streaming workgroups, frame streams)
     int fit = 0;
     std::vector<int> pre;
     std::vector<uint64_t> pre_idx;
@@ -242,20 +245,30 @@ static bool resident_prepare() {
     return ok;
 }
 
-// Streaming workgroups of the resident RMSD-fit pass (gr_resident.h), or 0 when the two-pass path takes the segment: the
-// frame must fit (one 4-atom group per lane) beside at least two finalizer workgroups, and -- unless forced -- fill most of
-// the chip: a small frame streams faster through the two-pass kernels, which spread it over every CU.
-uint32_t resident_wgs(gr_ctx *c, bool lite, uint32_t nb, const GrSel &sel) {
+// Workgroups per frame of the resident RMSD-fit pass (gr_resident.h) and the number of frame streams the launch runs side by
+// side (*streams), or 0 when the two-pass path takes the segment: streams x workgroups must fit the device beside at least two
+// finalizer workgroups, and -- unless forced -- fill most of the chip: a launch that leaves CUs idle streams slower than the
+// two-pass kernels, which spread every frame over all of them.
+uint32_t resident_wgs(gr_ctx *c, bool lite, uint32_t nb, const GrSel &sel, uint32_t *streams) {
+    *streams = 1;
     if (!lite || !c->resident || !c->res_max_wgs) return 0;
     const uint64_t groups = ((c->n + 255) >> 8) << 6;
     const uint64_t wgs = (groups + GR_RES_GROUPS - 1) / GR_RES_GROUPS;   // (a workgroup owns 1024 groups whatever the groups per lane)
     if (wgs + 2 > c->res_max_wgs || wgs > GR_MAX_CHUNKS) return 0;
-    // the pass costs the same per frame whatever the frame's size (every CU runs its 4096 atoms' worth or idles): it only
-    // beats the two passes, whose time shrinks with the frame, when the frame fills at least 15/16 of the chip
-    if (c->resident == 1 && wgs * 16 < (uint64_t)c->res_max_wgs * 15) return 0;
+    // frames that fill less than half of the chip: several of them in flight side by side, each on its own share of the CUs (at
+    // least two finalizer workgroups however many streams; a segment gives every stream 16 frames or more, see below).  Forced
+    // launches (tests) stay with one stream unless GR_TUNE_RESIDENT_STREAMS asks for more.
+    uint64_t s_max = c->res_streams ? (uint64_t)c->res_streams : (c->resident == 1 ? (uint64_t)GR_RES_MAX_STREAMS : 1u);
+    s_max = std::min<uint64_t>(s_max, (c->res_max_wgs - 2) / wgs);
+    if (c->resident == 1) s_max = std::min<uint64_t>(s_max, nb / 16u);
+    else s_max = std::min<uint64_t>(s_max, nb);
+    // the pass costs the same per turn whatever the frame's size (every CU runs its 4096 atoms' worth or idles): it only beats
+    // the two passes, whose time shrinks with the frame, when the streams together fill enough of the chip
+    if (c->resident == 1 && (s_max == 0 || s_max * wgs * 16 < (uint64_t)c->res_max_wgs * (uint64_t)c->res_fill16)) return 0;
     // ... and when the segment is long enough to pay for filling and draining the six-frame pipeline (measured at 16 frames per
     // call: 9.8 us per frame against 10.6 for the two passes; single frames are a chain of waits)
     if (c->resident == 1 && nb < 16) return 0;
+    if (s_max == 0) s_max = 1;
     // ... and when the selection is (nearly) the whole system.  Every workgroup of the pass advances at the pace of the slowest one
     // (a frame's record needs all of them), and with a partial selection the workgroups that hold it run sums AND the literal fit
     // arithmetic while the others only fit: measured at 1e6 atoms with a tenth of them selected, 6.3 us per frame against 4.5 for
@@ -264,6 +277,7 @@ uint32_t resident_wgs(gr_ctx *c, bool lite, uint32_t nb, const GrSel &sel) {
     // a launch that missed its start handshake (the device was busy with somebody else's kernels) makes the context sit out a few
     // segments -- twice as many after every miss in a row -- instead of giving the pass up for good (gr_ctx_stat counts the misses)
     if (c->res_skip) { c->res_skip--; return 0; }
+    *streams = (uint32_t)s_max;
     return (uint32_t)wgs;
 }
 
@@ -1481,6 +1495,7 @@ int gr_ctx_stat(const gr_ctx *c, int key, uint64_t *value) {
     switch (key) {
     case GR_STAT_N_CUS: *value = c->n_cus; return GR_OK;
     case GR_STAT_RES_MAX_WGS: *value = c->res_max_wgs; return GR_OK;
+    case GR_STAT_RES_LAST_STREAMS: *value = c->res_last_streams; return GR_OK;
     case GR_STAT_RES_LAUNCHES: *value = c->res_launches; return GR_OK;
     case GR_STAT_RES_HANDSHAKE_MISSES: *value = c->res_handshake_misses; return GR_OK;
     case GR_STAT_RES_ABORTS: *value = c->res_aborts; return GR_OK;
@@ -1498,6 +1513,8 @@ int gr_ctx_set_tuning(gr_ctx *c, int key, int64_t value) try {
     case GR_TUNE_FUSE: c->fuse = value ? 1 : 0; return GR_OK;
     case GR_TUNE_TWO_PASS: c->two_pass = value ? 1 : 0; return GR_OK;
     case GR_TUNE_RESIDENT: if (value < 0 || value > 2) break; c->resident = value; return GR_OK;
+    case GR_TUNE_RESIDENT_STREAMS: if (value < 0 || value > GR_RES_MAX_STREAMS) break; c->res_streams = (int)value; return GR_OK;
+    case GR_TUNE_RESIDENT_FILL: if (value < 1 || value > 16) break; c->res_fill16 = (int)value; return GR_OK;
     case GR_TUNE_RESIDENT_GROUPS: if (value != 2) break; return GR_OK;   // (the one-group shape was removed: gr_resident.h)
     case GR_TUNE_TEST_RESIDENT_NO_START: c->res_test_no_start = value ? 1 : 0; return GR_OK;
     case GR_TUNE_TEST_RESIDENT_ABORT_AT: c->res_test_abort_at = value < 0 ? 0xFFFFFFFFu : (uint32_t)value; return GR_OK;
@@ -1583,19 +1600,21 @@ static int segment_begin(gr_rmsd_plan *p, uint32_t s0, uint32_t nb, int fit) {
         const bool fused = lite && c->fuse;   // the finalize rides on the tail of the sums kernel
         q.fused = fused;
         hipStream_t S = c->stream;
-        uint32_t res_stream = resident_wgs(c, lite, nb, sel);
-        if (res_stream && !resident_acquire(c->device)) res_stream = 0;
-        if (res_stream) c->res_in_use = true;           // (released in segment_end, or by the caller when this function fails)
-        if (res_stream) {
+        uint32_t res_streams = 1;
+        uint32_t res_wgs = resident_wgs(c, lite, nb, sel, &res_streams);   // workgroups per frame x frame streams
+        if (res_wgs && !resident_acquire(c->device)) res_wgs = 0;
+        if (res_wgs) c->res_in_use = true;           // (released in segment_end, or by the caller when this function fails)
+        if (res_wgs) {
             // ONE launch for the segment: every frame is read once and written once (gr_resident.h)
+            const uint32_t res_stream = res_wgs * res_streams;
             const uint32_t n_fin = std::min<uint32_t>(GR_RES_MAX_FIN, c->res_max_wgs - res_stream);
-            if ((size_t)nb * res_stream > c->fit_partials_cap) {
+            if ((size_t)nb * res_wgs > c->fit_partials_cap) {
                 if (c->fit_partials) (void)hipFree(c->fit_partials);
                 c->fit_partials = nullptr; c->fit_partials_cap = 0;
-                HIPCHK(c, hipMalloc(&c->fit_partials, (size_t)nb * res_stream * sizeof(double)));
-                c->fit_partials_cap = (size_t)nb * res_stream;
+                HIPCHK(c, hipMalloc(&c->fit_partials, (size_t)nb * res_wgs * sizeof(double)));
+                c->fit_partials_cap = (size_t)nb * res_wgs;
             }
-            const size_t rec_words = (size_t)nb * ((res_stream + GR_RES_REC_PAD - 1u) & ~(uint32_t)(GR_RES_REC_PAD - 1u)) * GR_RES_REC_WORDS;
+            const size_t rec_words = (size_t)nb * ((res_wgs + GR_RES_REC_PAD - 1u) & ~(uint32_t)(GR_RES_REC_PAD - 1u)) * GR_RES_REC_WORDS;
             if (rec_words > c->res_wgrec_cap) {
                 if (c->res_wgrec) (void)hipFree(c->res_wgrec);
                 c->res_wgrec = nullptr; c->res_wgrec_cap = 0;
@@ -1605,6 +1624,16 @@ static int segment_begin(gr_rmsd_plan *p, uint32_t s0, uint32_t nb, int fit) {
             }
             GrResCtl ctl;
             ctl.wgrec = c->res_wgrec; ctl.rec = c->res_rec; ctl.abort = c->res_abort; ctl.progress = c->res_progress; ctl.epoch = ++c->res_epoch; ctl.n_stream = res_stream; ctl.n_fin = n_fin;
+            ctl.wgs_frame = res_wgs; ctl.streams = res_streams;
+            // waves per finalizer team: enough for the frame's records (32 per wave), and no more frames per finalizer workgroup and
+            // round than there are streams -- the frames of a round are closed together, so they must be frames that become ready
+            // together (the same turn of different streams): frames of ONE stream in a round would hold the earlier one back until
+            // the later one's sums exist, and 7 or more of them would wait for each other for ever (the stream runs 6 frames ahead)
+            {
+                uint32_t tw = res_wgs <= 32 ? 1u : res_wgs <= 64 ? 2u : res_wgs <= 128 ? 4u : 8u;
+                while (GrResShape::WAVES / tw > res_streams) tw *= 2u;
+                ctl.team_waves = tw;
+            }
             ctl.test_abort_frame = c->res_test_abort_at; c->res_test_abort_at = 0xFFFFFFFFu;
             float *frames = c->frames; size_t stride = c->frame_stride; uint32_t slot0 = s0, nfr = nb, natoms = (uint32_t)c->n;
             const float *masses = c->masses; GrSel sel_arg = sel; const GrBox *boxes = c->boxes_dev; GrPlanDev plan = p->dev;
@@ -1630,9 +1659,10 @@ static int segment_begin(gr_rmsd_plan *p, uint32_t s0, uint32_t nb, int fit) {
             const hipError_t le = hipLaunchKernel(fn, dim3(res_stream + n_fin), dim3(lanes), args, lds, S);
             if (le == hipSuccess) {
                 if (c->profile) EVREC(c, c->pev[1], true, S);
-                k_rmsd_close<<<dim3(nb), dim3(64), 0, S>>>(c->fit_partials, res_stream, p->dev.sw, c->state_dev);
+                k_rmsd_close<<<dim3(nb), dim3(64), 0, S>>>(c->fit_partials, res_wgs, p->dev.sw, c->state_dev);
                 HIPCHK(c, hipGetLastError());
-                q.resident = true; q.res_stream = res_stream;
+                q.resident = true; q.res_stream = res_stream; q.res_streams = res_streams;
+                c->res_last_streams = res_streams;
             } else {
                 (void)hipGetLastError();          // nothing ran: the two-pass path takes the segment
                 c->res_max_wgs = 0;
@@ -1718,18 +1748,23 @@ static int segment_end(gr_rmsd_plan *p, float *rmsd_out, int *status_out, float 
                 //   frames at or above the largest count -- and frames whose finalizer gave up (GR_ST_ABORTED) -- are untouched: redone below;
                 //   frames in between were fitted by some waves only (possible when a wave gives up in the instant its record
                 //   arrives for the others): their coordinates are lost and they are reported as GR_E_HIP, frame by frame.
+                // (Counts are per frame STREAM: frame f is turn f / streams of stream f % streams, whose workgroups are the
+                // res_stream / streams consecutive ones from (f % streams) * that many.)
                 (void)hipMemset(c->res_abort, 0, sizeof(uint32_t));
                 c->res_aborts++;
                 std::vector<uint32_t> prog((size_t)q.res_stream * 8);
                 HIPCHK(c, hipMemcpy(prog.data(), c->res_progress, prog.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
-                uint32_t lo = nb, hi = 0;
-                for (uint32_t v : prog) { lo = std::min(lo, v); hi = std::max(hi, v); }
+                const uint32_t ns = q.res_streams, per = q.res_stream / ns * 8u;
+                std::vector<uint32_t> lo(ns, nb), hi(ns, 0u);
+                for (uint32_t s = 0; s < ns; ++s)
+                    for (uint32_t k = 0; k < per; ++k) { const uint32_t v = prog[(size_t)s * per + k]; lo[s] = std::min(lo[s], v); hi[s] = std::max(hi[s], v); }
                 redo.assign(nb, 0); torn.assign(nb, 0);
                 for (uint32_t f = 0; f < nb; ++f) {
                     if (q.pre[f] != GR_OK) continue;
                     const bool finalizer_gave_up = c->state_host[f].status == GR_ST_ABORTED;
-                    if (f >= hi || finalizer_gave_up) redo[f] = 1;
-                    else if (f >= lo) torn[f] = 1;
+                    const uint32_t s = f % ns, turn = f / ns;
+                    if (turn >= hi[s] || finalizer_gave_up) redo[f] = 1;
+                    else if (turn >= lo[s]) torn[f] = 1;
                 }
             } else {
                 c->res_launches++;

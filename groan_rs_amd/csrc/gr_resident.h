@@ -101,6 +101,7 @@ struct GrResShape {
 #endif
 #define GR_RES_GROUPS 1024         // 4-atom groups per workgroup
 #define GR_RES_MAX_FIN 8
+#define GR_RES_MAX_STREAMS 16  // frame streams side by side in one launch (frames that fill a fraction of the chip)
 #define GR_RES_PATIENCE 3000000u   // polls (each ~1 us) before a wait gives up
 #define GR_RES_START_PATIENCE 200000u   // polls of the start handshake (~0.2 s: other kernels may hold CUs when the launch begins)
 #define GR_ST_ABORTED 102          /* internal: the frame's finalizer gave up (abort): the frame is untouched and is redone on the two-pass path */
@@ -112,8 +113,10 @@ struct GrResCtl {
     unsigned long long *rec;       // [frames][16] value | epoch << 32: 0 status, 1..3 shift, 4..12 R (column-major), 13..15 t0 = -R (COM - first atom)
     uint32_t *abort;               // [3]: 0 abort (0 = fine), 1 workgroups that have started, 2 start verdict (0 open, 1 go, 2 never started);
                                    // words 1 and 2 are zeroed by the host before every launch
-    uint32_t *progress;            // [n_stream][8]: frames each streaming wave had fitted (or skipped: failed frames) when it left
-    uint32_t epoch, n_stream, n_fin;
+    uint32_t *progress;            // [n_stream][8]: turns (frames of its stream) each streaming wave had been through when it left
+    uint32_t epoch, n_stream, n_fin;   // n_stream = streams x wgs_frame streaming workgroups, then n_fin finalizers
+    uint32_t wgs_frame, streams;   // workgroups one frame needs; frame streams the launch runs side by side (stream s: frames s, s + streams, ...)
+    uint32_t team_waves;           // waves of a finalizer workgroup that close one frame together: 1, 2, 4 or 8 with 32 x that >= wgs_frame
     uint32_t test_abort_frame;     // tests: the finalizer of this frame raises `abort` instead of closing it (0xFFFFFFFF: never)
 };
 
@@ -223,7 +226,7 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
     constexpr uint32_t LANES = S::LANES, WAVES = S::WAVES, K = S::K, R = S::R;
     extern __shared__ float4 smem[];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint32_t n_pad = (ctl.n_stream + GR_RES_REC_PAD - 1u) & ~(uint32_t)(GR_RES_REC_PAD - 1u);
+    const uint32_t n_pad = (ctl.wgs_frame + GR_RES_REC_PAD - 1u) & ~(uint32_t)(GR_RES_REC_PAD - 1u);
 
     // ------------------------------------------------------------------------------------------ start handshake
     // Every workgroup waits for data other workgroups produce, so nothing may begin before ALL of them are on the chip: each one
@@ -250,13 +253,20 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
     // ------------------------------------------------------------------------------------------ finalizers
     if (blockIdx.x >= ctl.n_stream) {
         constexpr uint32_t RPW = S::REC_PER_WAVE, LPR = S::LANES_PER_REC, W = S::WORDS_PER_LANE;
-        double *wtot = reinterpret_cast<double *>(smem);              // [WAVES][32] + [32] totals
-        uint32_t *gave_up = reinterpret_cast<uint32_t *>(wtot + (WAVES + 1) * 32u);   // some wave of this workgroup ran out of patience
+        // A frame of up to 32 / 64 / 128 / 256 workgroups is closed by a TEAM of 1 / 2 / 4 / 8 waves (a wave collects 32 records),
+        // and a finalizer workgroup closes 8 / 4 / 2 / 1 consecutive frames at a time, one per team: the closing arithmetic is one
+        // lane's chain of fp64 operations (~10 us), so with several frame streams the frames per second the finalizers can close
+        // is what bounds the launch -- teams in different waves run their chains side by side.
+        const uint32_t TW = ctl.team_waves, NT = WAVES / TW, team = wave / TW, wt = wave % TW;
+        double *wtot = reinterpret_cast<double *>(smem);              // [WAVES][32] per wave + [teams <= WAVES][32] totals
+        uint32_t *gave_up = reinterpret_cast<uint32_t *>(wtot + 2u * WAVES * 32u);   // some wave of this workgroup ran out of patience
         if (tid == 0) *gave_up = 0u;
         __syncthreads();
-        const uint32_t r = wave * RPW + lane / LPR, part = lane % LPR;   // this lane's record and its W words
+        const uint32_t r = wt * RPW + lane / LPR, part = lane % LPR;   // this lane's record (of its team's frame) and its W words
         const unsigned long long tagv = (unsigned long long)ctl.epoch << 32;
-        for (uint32_t f = blockIdx.x - ctl.n_stream; f < nframes; f += ctl.n_fin) {
+        for (uint32_t f0 = (blockIdx.x - ctl.n_stream) * NT; f0 < nframes; f0 += ctl.n_fin * NT) {
+            const uint32_t f = f0 + team < nframes ? f0 + team : nframes - 1u;
+            const bool live = f0 + team < nframes;                   // (a team without a frame in the last round only keeps the barriers)
             // what the closing step needs besides the sums: requested now, in flight while the records are awaited
             const GrBox *bp = boxes + first_slot + f;
             GrBox lb;
@@ -265,13 +275,14 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
             float g0x, g0y, g0z;
             gr_pos_load(frames + (size_t)(first_slot + f) * frame_stride, sel.start, g0x, g0y, g0z);
             const int pre_status = state[f].status;
+            const bool mine = live && r < ctl.wgs_frame;
             const unsigned long long *src = ctl.wgrec + ((size_t)f * n_pad + r) * GR_RES_REC_WORDS + part * W;
             unsigned long long w[W];
             uint32_t polls = 0;
-            if (f == ctl.test_abort_frame) { if (lane == 0) { gr_st_agent(ctl.abort, 1u); __hip_atomic_store(gave_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } polls = 0xFFFFFFFFu; }
+            if (live && f == ctl.test_abort_frame) { if (lane == 0) { gr_st_agent(ctl.abort, 1u); __hip_atomic_store(gave_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } polls = 0xFFFFFFFFu; }
             while (polls != 0xFFFFFFFFu) {
                 bool ok = true;
-                if (r < ctl.n_stream) {
+                if (mine) {
 #pragma unroll
                     for (uint32_t k = 0; k < W; ++k) w[k] = gr_ld_agent(src + k);
 #pragma unroll
@@ -291,7 +302,7 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
 #pragma unroll
             for (uint32_t k = 0; k < W; ++k) {
                 const bool mxw = part * W + k >= 19u;
-                const float x = (r < ctl.n_stream && polls != 0xFFFFFFFFu) ? __uint_as_float((uint32_t)w[k]) : (mxw ? -3.0e38f : 0.0f);
+                const float x = (mine && polls != 0xFFFFFFFFu) ? __uint_as_float((uint32_t)w[k]) : (mxw ? -3.0e38f : 0.0f);
                 v[k] = (double)x;
             }
 #pragma unroll
@@ -308,18 +319,17 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
                 for (uint32_t k = 0; k < W; ++k) wtot[wave * 32u + lane * W + k] = v[k];
             }
             __syncthreads();                                          // (also publishes gave_up)
-            if (wave == 0 && lane < 31u) {   // totals over the waves, in wave order: lane k owns word k
-                double a = wtot[lane];
+            if (wt == 0 && lane < 31u) {     // totals over the team's waves, in wave order: lane k owns word k
+                double a = wtot[wave * 32u + lane];
                 const bool mx = lane >= 19u;
-#pragma unroll
-                for (uint32_t wv = 1; wv < WAVES; ++wv) { const double o = wtot[wv * 32u + lane]; a = mx ? fmax(a, o) : a + o; }
-                wtot[WAVES * 32u + lane] = a;
+                for (uint32_t wv = 1; wv < TW; ++wv) { const double o = wtot[(wave + wv) * 32u + lane]; a = mx ? fmax(a, o) : a + o; }
+                wtot[(WAVES + team) * 32u + lane] = a;
             }
             gr_wave_sync();
-            if (wave == 0 && lane == 0) {
-                GrFrameState &st = state[f];
-                const bool lost = *gave_up != 0u;                      // ANY wave of the workgroup gave up on a record of this or an earlier frame
-                const double *t = wtot + WAVES * 32u;
+            if (wt == 0 && lane == 0 && live) {
+                GrFrameState st = state[f];                            // (closed in registers, stored once: results are read back below)
+                const bool lost = *gave_up != 0u;                      // ANY wave of the workgroup gave up on a record of this round or an earlier one
+                const double *t = wtot + (WAVES + team) * 32u;
                 if (lost) {
                     if (pre_status == 0) st.status = GR_ST_ABORTED;
                 } else if (pre_status == 0) {
@@ -354,6 +364,7 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
                     const float t0 = (float)(-((double)st.R[a] * cvx + (double)st.R[3 + a] * cvy + (double)st.R[6 + a] * cvz));
                     gr_st_agent(o + 13 + a, tagv | __float_as_uint(t0));
                 }
+                state[f] = st;
             }
             __syncthreads();                                          // wtot is free again
         }
@@ -362,9 +373,14 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
 
     // ------------------------------------------------------------------------------------------ streaming workgroups
     const uint32_t ngroups = ((n_atoms + 255u) >> 8) << 6;            // the slot is padded to whole tiles (a multiple of 64 groups)
-    const uint32_t wg = blockIdx.x, base = wg * GR_RES_GROUPS;
+    // Frames smaller than half the chip run as several STREAMS side by side: workgroup b belongs to stream b / wgs_frame and owns
+    // the atoms of workgroup b % wgs_frame of every frame of its stream (frames s, s + streams, ...): each stream is the pipeline
+    // described above on its own share of the CUs, the finalizers serve them all.  `kf(k)` = the frame of the stream's k-th turn.
+    const uint32_t wg_all = blockIdx.x, stream = wg_all / ctl.wgs_frame, wg = wg_all % ctl.wgs_frame, base = wg * GR_RES_GROUPS;
+    const uint32_t n_turns = nframes > stream ? (nframes - stream + ctl.streams - 1u) / ctl.streams : 0u;
+    auto kf = [&](uint32_t k) { return stream + k * ctl.streams; };
     if (base + wave * 64u >= ngroups) {                               // every chunk of this wave lies behind the last tile: nothing to fit
-        if (lane == 0) ctl.progress[wg * WAVES + wave] = nframes;
+        if (lane == 0) ctl.progress[wg_all * WAVES + wave] = n_turns;
         return;
     }
     const uint32_t n_waves = min(WAVES, (ngroups - base) >> 6);
@@ -424,14 +440,14 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
 
     struct Rows { float4 r0, r1, r2; };
     struct Landing { Rows a, b; float gx, gy, gz; };
-    auto request = [&](uint32_t f, Landing &L) {
-        const float *xyz = frames + (size_t)(first_slot + f) * frame_stride;
+    auto request = [&](uint32_t k, Landing &L) {
+        const float *xyz = frames + (size_t)(first_slot + kf(k)) * frame_stride;
         const float4 *f4 = reinterpret_cast<const float4 *>(xyz);
         L.a.r0 = gr_stream_load(f4 + GA.b); L.a.r1 = gr_stream_load(f4 + GA.b + 64); L.a.r2 = gr_stream_load(f4 + GA.b + 128);
         if (GB.valid) { L.b.r0 = gr_stream_load(f4 + GB.b); L.b.r1 = gr_stream_load(f4 + GB.b + 64); L.b.r2 = gr_stream_load(f4 + GB.b + 128); }
         gr_pos_load(xyz, first, L.gx, L.gy, L.gz);                    // provisional centre: the first atom of the selection
     };
-    auto request_rec = [&](uint32_t f) -> unsigned long long { return lane < 16u ? gr_ld_agent(ctl.rec + (size_t)f * 16 + lane) : 0ull; };
+    auto request_rec = [&](uint32_t k) -> unsigned long long { return lane < 16u ? gr_ld_agent(ctl.rec + (size_t)kf(k) * 16 + lane) : 0ull; };
     bool bail = false;
     uint32_t n_fitted = 0;                                             // frames whose fit stage this wave has been through (-> ctl.progress)
     // Two waves share a SIMD, and the frame rate of the whole launch is the rate of its SLOWEST wave (every frame's record needs
@@ -478,7 +494,7 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
 #pragma unroll
         for (int k = 0; k < 32; ++k) { s32[k] = 0.0f; e32[k] = -3.0e38f; }
         if (wave_sel) {
-            const GrBox *boxp = boxes + first_slot + i;
+            const GrBox *boxp = boxes + first_slot + kf(i);
             const float gx = gr_first_f(L.gx), gy = gr_first_f(L.gy), gz = gr_first_f(L.gz);    // wave-uniform: SGPR operands
             // the lane's two groups together (a group that does not exist contributes v = 0 with zero mass and reference): every sum
             // is ONE chain of four packed FMAs over the 8 atoms + one fold, every extent three v_min3 / v_max3 + one v_min / v_max
@@ -568,7 +584,7 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
                 if (lane < 19u) { for (uint32_t w = 1; w < n_waves; ++w) v += all[w * 32 + lane]; }
                 else { for (uint32_t w = 1; w < n_waves; ++w) v = gr_fmaxf(v, all[w * 32 + lane]); }
             }
-            gr_st_agent(ctl.wgrec + ((size_t)i * n_pad + wg) * GR_RES_REC_WORDS + lane, ((unsigned long long)ctl.epoch << 32) | __float_as_uint(v));
+            gr_st_agent(ctl.wgrec + ((size_t)kf(i) * n_pad + wg) * GR_RES_REC_WORDS + lane, ((unsigned long long)ctl.epoch << 32) | __float_as_uint(v));
         }
         // the slot's counter starts the next use (frame i + R) at zero.  No wave can reach frame i + R before this wave -- the slowest
         // of the workgroup at this point -- has published frame i, the finalizer has closed it and the fit stage of frame i has been
@@ -619,7 +635,7 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
             GrResRot T;
             T.r00 = gr_lane_f(rv, 4); T.r10 = gr_lane_f(rv, 5); T.r20 = gr_lane_f(rv, 6); T.r01 = gr_lane_f(rv, 7); T.r11 = gr_lane_f(rv, 8); T.r21 = gr_lane_f(rv, 9);
             T.r02 = gr_lane_f(rv, 10); T.r12 = gr_lane_f(rv, 11); T.r22 = gr_lane_f(rv, 12);
-            float4 *f4 = reinterpret_cast<float4 *>(frames + (size_t)(first_slot + j) * frame_stride);
+            float4 *f4 = reinterpret_cast<float4 *>(frames + (size_t)(first_slot + kf(j)) * frame_stride);
             if (V) {
                 const float t0x = gr_lane_f(rv, 13), t0y = gr_lane_f(rv, 14), t0z = gr_lane_f(rv, 15);
                 T.sx = T.sy = T.sz = 0.f;
@@ -627,7 +643,7 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
                 if (GB.valid) fit_group_v(GB, rb, T, t0x, t0y, t0z, f4, rs);
             } else {
                 T.sx = gr_lane_f(rv, 1); T.sy = gr_lane_f(rv, 2); T.sz = gr_lane_f(rv, 3);
-                const GrBox *boxp = boxes + first_slot + j;
+                const GrBox *boxp = boxes + first_slot + kf(j);
                 gr_res_fit_group<WMASS>(GA, ra.r0, ra.r1, ra.r2, T, B, boxp, cx, cy, cz, f4, rs);
                 if (GB.valid) gr_res_fit_group<WMASS>(GB, rb.r0, rb.r1, rb.r2, T, B, boxp, cx, cy, cz, f4, rs);
             }
@@ -654,7 +670,7 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
             } else {
                 for (uint32_t w = 0; w < n_waves; ++w) t += fsum[fs * WAVES + w];
             }
-            fit_partials[(size_t)j * ctl.n_stream + wg] = t;
+            fit_partials[(size_t)kf(j) * ctl.wgs_frame + wg] = t;
             __hip_atomic_store(cnt_f + fs, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // (as cnt_s: the next use is R frames away)
         }
     };
@@ -671,8 +687,8 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
     Rows Q0, Q1, Q2, Q3, Q4, Q5;
     Q0.r0 = Q0.r1 = Q0.r2 = zero4; Q1 = Q0; Q2 = Q0; Q3 = Q0; Q4 = Q0; Q5 = Q0;
     unsigned long long rv = 0ull;
-    request(0, L0);
-    const uint32_t n_iter = nframes + K;
+    if (n_turns) request(0, L0);
+    const uint32_t n_iter = n_turns + K;
     const GrBoxU B0 = gr_box_uniform(boxes + first_slot);
     auto lds_put = [&](uint32_t slot, const Rows &rw) { park[(slot * 3 + 0) * LANES + tid] = rw.r0; park[(slot * 3 + 1) * LANES + tid] = rw.r1; park[(slot * 3 + 2) * LANES + tid] = rw.r2; };
     auto lds_get = [&](uint32_t slot) { Rows rw; rw.r0 = park[(slot * 3 + 0) * LANES + tid]; rw.r1 = park[(slot * 3 + 1) * LANES + tid]; rw.r2 = park[(slot * 3 + 2) * LANES + tid]; return rw; };
@@ -680,12 +696,12 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
 #ifdef GR_EXP_NOLOAD
         if (i < 2) request(i + 1, nxt);
 #elif !defined(GR_EXP_LATE_REQUEST)
-        if (i + 1 < nframes) request(i + 1, nxt);
+        if (i + 1 < n_turns) request(i + 1, nxt);
 #endif
         balance(i);
         // both boxes of the iteration are requested here (scalar loads): they arrive while the record is checked
-        const GrBoxU Bf = UBOX ? B0 : gr_box_uniform(boxes + first_slot + (i >= K ? i - K : 0u));
-        const GrBoxU Bs = UBOX ? B0 : gr_box_uniform(boxes + first_slot + (i < nframes ? i : 0u));
+        const GrBoxU Bf = UBOX ? B0 : gr_box_uniform(boxes + first_slot + kf(i >= K ? i - K : 0u));
+        const GrBoxU Bs = UBOX ? B0 : gr_box_uniform(boxes + first_slot + kf(i < n_turns ? i : 0u));
         Rows va = cur.a, vb = cur.b;                            // what gets parked: the rows, or (V: set by sums) the image vectors
         const uint32_t ps = i % K;
         if (i >= K) {
@@ -697,9 +713,9 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
         }
         if (i + 1 >= K && i + 1 < n_iter) rv = request_rec(i + 1 - K);
 #ifdef GR_EXP_LATE_REQUEST
-        if (i + 1 < nframes) request(i + 1, nxt);               // (experiment: the next frame's rows requested after this step's stores)
+        if (i + 1 < n_turns) request(i + 1, nxt);               // (experiment: the next frame's rows requested after this step's stores)
 #endif
-        if (i < nframes) {
+        if (i < n_turns) {
             if (V) sums(i, cur, Bs, va, vb);                    // (the slot's old content has been read by the fit above)
             lds_put(ps, va);
             if (ps == 0u) { Q0 = vb; asm volatile("; set 0 in"); } else if (ps == 1u) { Q1 = vb; asm volatile("; set 1 in"); } else if (ps == 2u) { Q2 = vb; asm volatile("; set 2 in"); }
@@ -711,5 +727,5 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
         step(i, L0, L1);
         if (!bail && i + 1 < n_iter) step(i + 1, L1, L0);
     }
-    if (lane == 0) ctl.progress[wg * WAVES + wave] = n_fitted;
+    if (lane == 0) ctl.progress[wg_all * WAVES + wave] = n_fitted;
 }

@@ -265,9 +265,16 @@ int gr_rmsd_plan_force_exact(gr_rmsd_plan *plan, int on);
  *                      frames it had completed keep their results, frames nobody had touched are redone on the two-pass path, and a
  *                      frame that was caught half fitted -- possible only in the instant of the abort -- is reported as GR_E_HIP
  *                      in status_out with its index in gr_last_error_index (gr_ctx_stat counts aborts and redone frames).
+ *   GR_TUNE_RESIDENT_STREAMS frames that fill half of the chip or less run as several frame STREAMS side by side in one resident
+ *                      launch (stream s of S owns frames s, s + S, ... of the segment and its own share of the CUs).  0 (default):
+ *                      as many as fit, up to 16, when GR_TUNE_RESIDENT is 1 (each stream needs 16 frames of the segment), one when
+ *                      it is 2; 1 .. 16: at most so many.  Results do not depend on the number of streams.
+ *   GR_TUNE_RESIDENT_FILL    sixteenths of the chip (1 .. 16, default 15) the streams of a launch must fill together for
+ *                      GR_TUNE_RESIDENT = 1 to choose the pass
  *   GR_TUNE_RESIDENT_GROUPS  retired (round 3 removed the one-group shape of the resident pass): only the value 2 is accepted
  */
 enum { GR_TUNE_SUB_BATCH = 1, GR_TUNE_CHUNKS = 2, GR_TUNE_FIT_WGS = 3, GR_TUNE_FUSE = 4, GR_TUNE_TWO_PASS = 5, GR_TUNE_RESIDENT = 6, GR_TUNE_RESIDENT_GROUPS = 7,
+       GR_TUNE_RESIDENT_STREAMS = 8, GR_TUNE_RESIDENT_FILL = 9,
        GR_TUNE_TEST_RESIDENT_NO_START = 100 /* tests: the next resident launch behaves as if its workgroups never got onto the chip */,
        GR_TUNE_TEST_RESIDENT_ABORT_AT = 101 /* tests: the next resident launch is aborted from inside when it reaches this frame of its segment (< 0: never) */ };
 int gr_ctx_set_tuning(gr_ctx *ctx, int key, int64_t value);
@@ -278,8 +285,9 @@ int gr_ctx_set_tuning(gr_ctx *ctx, int key, int64_t value);
  *   GR_STAT_RES_LAUNCHES           resident launches that ran to the end
  *   GR_STAT_RES_HANDSHAKE_MISSES   resident launches that closed themselves at the start handshake (the segment then took the two-pass path)
  *   GR_STAT_RES_ABORTS             resident launches in which a wait ran out of patience (see gr_rmsd_fit_batch)
- *   GR_STAT_RES_REDONE_FRAMES      frames of such launches that were still untouched and were redone on the two-pass path */
-enum { GR_STAT_N_CUS = 1, GR_STAT_RES_MAX_WGS = 2, GR_STAT_RES_LAUNCHES = 3, GR_STAT_RES_HANDSHAKE_MISSES = 4, GR_STAT_RES_ABORTS = 5, GR_STAT_RES_REDONE_FRAMES = 6 };
+ *   GR_STAT_RES_REDONE_FRAMES      frames of such launches that were still untouched and were redone on the two-pass path
+ *   GR_STAT_RES_LAST_STREAMS       frame streams of the context's last resident launch (GR_TUNE_RESIDENT_STREAMS) */
+enum { GR_STAT_N_CUS = 1, GR_STAT_RES_MAX_WGS = 2, GR_STAT_RES_LAUNCHES = 3, GR_STAT_RES_HANDSHAKE_MISSES = 4, GR_STAT_RES_ABORTS = 5, GR_STAT_RES_REDONE_FRAMES = 6, GR_STAT_RES_LAST_STREAMS = 7 };
 int gr_ctx_stat(const gr_ctx *ctx, int key, uint64_t *value);
 
 /* ---------------------------------------------------------------- text front end: gro structures, ndx index groups (host side)

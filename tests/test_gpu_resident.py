@@ -34,9 +34,9 @@ def _systems(G, n, nf, box, sel):
 
 
 @pytest.mark.parametrize("n,sel", [(70_001, (0, 70_000)), (70_001, (1003, 69_990)), (70_001, (0, 69_990)), (5_000, (17, 4_000)), (5_000, (0, 4_999)), (300, (0, 299))])
-@pytest.mark.parametrize("tric", [False, True])
-def test_resident_matches_oracle_and_two_pass(G, n, sel, tric):
-    nf = 11                                             # odd, longer than the pipeline (3 frames between sums and fit)
+@pytest.mark.parametrize("tric,streams", [(False, 1), (True, 1), (True, 3)])
+def test_resident_matches_oracle_and_two_pass(G, n, sel, tric, streams):
+    nf = 11                                             # odd, longer than the pipeline (6 frames between sums and fit); 3 streams: 4 + 4 + 3 turns
     box = W.box_from_lengths_angles([7.0, 6.5, 6.0], [75.0, 80.0, 70.0]) if tric else W.box_from_lengths_angles([7.0, 6.5, 6.0], [90.0, 90.0, 90.0])
     masses, cur, ref, ref_pos, frames = _systems(G, n, nf, box, sel)
     idx = np.arange(sel[0], sel[1] + 1)
@@ -45,7 +45,7 @@ def test_resident_matches_oracle_and_two_pass(G, n, sel, tric):
     plan = G.RMSDPlan(ref, cur, "S")
     got = {}
     for mode in (0, 2):
-        cur.set_tuning(resident=mode)
+        cur.set_tuning(resident=mode, resident_streams=streams)
         cur.profile_enable(True)
         for f in range(nf):
             cur.set_frame(frames[f], box, slot=f)
@@ -53,6 +53,7 @@ def test_resident_matches_oracle_and_two_pass(G, n, sel, tric):
         assert (st == 0).all() and plan.last_fallbacks() == 0, mode
         prof = cur.profile_read()
         assert (prof["k_fit_resident"][1] > 0) == (mode == 2), (mode, prof)      # the pass that was asked for is the one that ran
+        assert mode == 0 or cur.stat("res_last_streams") == streams
         got[mode] = (np.array(r), [cur.get_positions(f) for f in range(nf)])
         for f in range(nf):
             assert abs(float(r[f]) - want[f][0]) <= 1e-5, (mode, f, float(r[f]), want[f][0])
@@ -103,6 +104,44 @@ def test_resident_short_batches_and_failed_frames(G):
         if f != 2:
             assert abs(res[(0, "bad")][0][f] - res[(2, "bad")][0][f]) <= 2e-6
             assert np.abs(res[(0, "bad")][2][f] - res[(2, "bad")][2][f]).max() <= 2e-5
+    plan.close(); ref.close(); cur.close()
+
+
+@pytest.mark.parametrize("whole", [False, True])
+def test_frame_streams_do_not_reach_the_results(G, whole):
+    """frames that fill a fraction of the chip run as several frame streams side by side in one launch (stream s of S: frames s,
+    s + S, ...; the finalizer workgroups then close 2, 4 or 8 frames at a time, one per team of waves).  Which stream a frame
+    rides in must not show in its results: 1, 2, 3, 4, 8 and 13 streams give the same bits, for segments that give every stream
+    the same number of turns and for ragged ones (13 = 4 + 3 + 3 + 3 frames; 3 frames with room for 4 streams), with a failed
+    frame in the middle and a box per frame"""
+    n, nf = 20_000, 13
+    masses = W.masses_cycle(n)
+    boxes = [W.box_from_lengths_angles([6.0 + 0.01 * f, 6.0, 6.0 - 0.004 * f], [80.0, 85.0 + 0.1 * f, 75.0]) for f in range(nf)]
+    cur = G.System(n, masses=masses, n_slots=nf + 1)
+    cur.synth_reference(nf, boxes[0], 1.1, W.SEED)
+    cur.synth_frames(nf, 0, nf, 0, 0.04, W.SEED)
+    ref = G.System(n, masses=masses, box=boxes[0], positions=cur.get_positions(nf))
+    for s_ in (ref, cur):
+        s_.group_create_from_ranges("S", [(0, n - 1) if whole else (3, n - 2)])
+    frames = [cur.get_positions(f) for f in range(nf)]
+    frames[6] = frames[6].copy(); frames[6][4321] = np.nan
+    plan = G.RMSDPlan(ref, cur, "S")
+    res = {}
+    for streams in (1, 2, 3, 4, 8, 13):
+        cur.set_tuning(resident=2, resident_streams=streams)
+        for nb in (nf, 3):
+            for f in range(nb):
+                cur.set_frame(frames[f], boxes[f], slot=f)
+            r, st = plan.rmsd_fit(0, nb, raise_on_error=False)
+            assert cur.stat("res_last_streams") == min(streams, nb)
+            assert [f for f in range(nb) if st[f] != 0] == ([6] if nb > 6 else []), (streams, nb, st)
+            res[(streams, nb)] = (np.array(r), [cur.get_positions(f) for f in range(nb)])
+    for streams in (2, 3, 4, 8, 13):
+        for nb in (nf, 3):
+            assert np.array_equal(res[(streams, nb)][0], res[(1, nb)][0], equal_nan=True), (streams, nb)
+            for f in range(nb):
+                assert np.array_equal(res[(streams, nb)][1][f], res[(1, nb)][1][f], equal_nan=True), (streams, nb, f)
+    assert cur.stat("res_launches") == 12 and cur.stat("res_aborts") == 0
     plan.close(); ref.close(); cur.close()
 
 
@@ -173,9 +212,9 @@ def test_resident_launch_that_never_starts_falls_back_cleanly(G):
     plan.close(); ref.close(); cur.close()
 
 
-@pytest.mark.parametrize("whole", [True, False])
+@pytest.mark.parametrize("whole,streams", [(True, 1), (False, 1), (True, 3)])
 @pytest.mark.parametrize("at", [0, 3, 9, 22])
-def test_resident_launch_aborted_from_inside_loses_nothing(G, whole, at):
+def test_resident_launch_aborted_from_inside_loses_nothing(G, whole, streams, at):
     """a wait that runs out of patience aborts the launch from inside (here: the finalizer of frame `at` raises the abort
     instead of closing its frame).  Frames the launch had completed keep their results, every other frame is still untouched
     and is redone on the two-pass path: the call succeeds, every frame is fitted exactly once, nothing is torn"""
@@ -188,7 +227,7 @@ def test_resident_launch_aborted_from_inside_loses_nothing(G, whole, at):
         cur.set_frame(frames[f], box, slot=f)
     want_r, st = plan.rmsd_fit(0, nf)
     want = [cur.get_positions(f) for f in range(nf)]
-    cur.set_tuning(resident=2, test_resident_abort_at=at)
+    cur.set_tuning(resident=2, resident_streams=streams, test_resident_abort_at=at)
     cur.profile_enable(True)
     for f in range(nf):
         cur.set_frame(frames[f], box, slot=f)
@@ -197,7 +236,9 @@ def test_resident_launch_aborted_from_inside_loses_nothing(G, whole, at):
     assert (st == 0).all(), st
     assert prof["k_fit_resident"][1] == 1 and cur.stat("res_aborts") == 1 and cur.stat("res_launches") == 0
     redone = cur.stat("res_redone_frames")
-    assert 1 <= redone <= nf - at, (at, redone)    # frame `at` itself and whatever behind it had not been fitted when the grid drained
+    # frame `at` itself and whatever had not been fitted when the grid drained: the frames behind it and, with several streams,
+    # frames of the other streams a little ahead of it
+    assert 1 <= redone <= (nf - at if streams == 1 else nf), (at, redone)
     assert (prof["k_fit_pk"][2] == redone), (prof, redone)
     assert np.abs(np.array(r) - np.array(want_r)).max() <= 2e-6
     for f in range(nf):
