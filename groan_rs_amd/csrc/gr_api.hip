@@ -85,7 +85,7 @@ struct gr_ctx {
     // resident RMSD fit (gr_resident.h): one launch per segment, the frame waits on chip for its rotation
     int resident = 1;                 // GR_TUNE_RESIDENT 0 never, 1 when the frame fills the chip, 2 whenever it fits (tests)
     int res_streams = 0;              // GR_TUNE_RESIDENT_STREAMS 0 automatic, 1..GR_RES_MAX_STREAMS: at most so many frame streams per resident launch
-    int res_fill16 = 15;              // GR_TUNE_RESIDENT_FILL: sixteenths of the chip the streaming workgroups must fill for the pass to be chosen (resident = 1)
+    int res_fill16 = 10;              // GR_TUNE_RESIDENT_FILL: sixteenths of the chip the streaming workgroups must fill for the pass to be chosen (resident = 1)
     uint32_t res_last_streams = 0;    // frame streams of the last resident launch (gr_ctx_stat)
     uint32_t res_max_wgs = 0;         // workgroups of k_fit_resident the device holds at once (0: the pass cannot run here)
     int res_test_no_start = 0;        // GR_TUNE_TEST_RESIDENT_NO_START (tests): the next resident launch finds its start verdict already "never started"
@@ -263,7 +263,8 @@ uint32_t resident_wgs(gr_ctx *c, bool lite, uint32_t nb, const GrSel &sel, uint3
     if (c->resident == 1) s_max = std::min<uint64_t>(s_max, nb / 16u);
     else s_max = std::min<uint64_t>(s_max, nb);
     // the pass costs the same per turn whatever the frame's size (every CU runs its 4096 atoms' worth or idles): it only beats
-    // the two passes, whose time shrinks with the frame, when the streams together fill enough of the chip
+    // the two passes, whose time shrinks with the frame, when the streams together fill enough of the chip (measured,
+    // profiles/r03_size_sweep.txt: + 3 % at 0.67 of the chip, - 8 % at 0.57; the default asks for 10/16)
     if (c->resident == 1 && (s_max == 0 || s_max * wgs * 16 < (uint64_t)c->res_max_wgs * (uint64_t)c->res_fill16)) return 0;
     // ... and when the segment is long enough to pay for filling and draining the six-frame pipeline (measured at 16 frames per
     // call: 9.8 us per frame against 10.6 for the two passes; single frames are a chain of waits)
@@ -1607,7 +1608,7 @@ static int segment_begin(gr_rmsd_plan *p, uint32_t s0, uint32_t nb, int fit) {
         if (res_wgs) {
             // ONE launch for the segment: every frame is read once and written once (gr_resident.h)
             const uint32_t res_stream = res_wgs * res_streams;
-            const uint32_t n_fin = std::min<uint32_t>(GR_RES_MAX_FIN, c->res_max_wgs - res_stream);
+            const uint32_t n_fin = std::min<uint32_t>(res_streams > 8 ? GR_RES_MAX_FIN : 8, c->res_max_wgs - res_stream);
             if ((size_t)nb * res_wgs > c->fit_partials_cap) {
                 if (c->fit_partials) (void)hipFree(c->fit_partials);
                 c->fit_partials = nullptr; c->fit_partials_cap = 0;

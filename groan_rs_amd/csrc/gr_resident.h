@@ -100,8 +100,12 @@ struct GrResShape {
 #define GR_RES_BAL 1               // priority by progress relative to the wave's SIMD partner (the wave that is behind runs first); 0: A/B only
 #endif
 #define GR_RES_GROUPS 1024         // 4-atom groups per workgroup
-#define GR_RES_MAX_FIN 8
-#define GR_RES_MAX_STREAMS 16  // frame streams side by side in one launch (frames that fill a fraction of the chip)
+#ifndef GR_RES_MAX_FIN
+#define GR_RES_MAX_FIN 16          // finalizer workgroups of a launch with more than 8 frame streams, 8 otherwise (fewer when the streaming workgroups leave fewer CUs)
+#endif
+#ifndef GR_RES_MAX_STREAMS
+#define GR_RES_MAX_STREAMS 32      // frame streams side by side in one launch (frames that fill a fraction of the chip)
+#endif
 #define GR_RES_PATIENCE 3000000u   // polls (each ~1 us) before a wait gives up
 #define GR_RES_START_PATIENCE 200000u   // polls of the start handshake (~0.2 s: other kernels may hold CUs when the launch begins)
 #define GR_ST_ABORTED 102          /* internal: the frame's finalizer gave up (abort): the frame is untouched and is redone on the two-pass path */

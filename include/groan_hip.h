@@ -257,7 +257,8 @@ int gr_rmsd_plan_force_exact(gr_rmsd_plan *plan, int on);
  *   GR_TUNE_TWO_PASS   1 (default): RMSD-fit = sums pass + fit pass that evaluates the rmsd; 0: closed-form single-pass rmsd
  *   GR_TUNE_RESIDENT   RMSD-fit as ONE pass over HBM, the frame waiting on chip for its rotation (gr_resident.h: one launch per
  *                      segment whose workgroups wait for one another; needs n_atoms <= ~1.04e6 on MI355X).  1 (default): when the
- *                      frame fills at least 15/16 of the chip; 0: never; 2: whenever it
+ *                      frames in flight (GR_TUNE_RESIDENT_STREAMS) fill at least 10/16 of the chip, the selection is at least 9/10
+ *                      of the system and every stream gets 16 frames of the call or more; 0: never; 2: whenever it
  *                      fits.  One such launch runs per device and process at a time (a context that finds the device taken uses
  *                      the two-pass path); a launch whose workgroups do not all get onto the chip (a device shared with another
  *                      process) leaves without touching a frame and the segment runs on the two-pass path.  Same results as the two-pass path up to the order of the partial sums.
@@ -267,9 +268,9 @@ int gr_rmsd_plan_force_exact(gr_rmsd_plan *plan, int on);
  *                      in status_out with its index in gr_last_error_index (gr_ctx_stat counts aborts and redone frames).
  *   GR_TUNE_RESIDENT_STREAMS frames that fill half of the chip or less run as several frame STREAMS side by side in one resident
  *                      launch (stream s of S owns frames s, s + S, ... of the segment and its own share of the CUs).  0 (default):
- *                      as many as fit, up to 16, when GR_TUNE_RESIDENT is 1 (each stream needs 16 frames of the segment), one when
- *                      it is 2; 1 .. 16: at most so many.  Results do not depend on the number of streams.
- *   GR_TUNE_RESIDENT_FILL    sixteenths of the chip (1 .. 16, default 15) the streams of a launch must fill together for
+ *                      as many as fit, up to 32, when GR_TUNE_RESIDENT is 1 (each stream needs 16 frames of the segment), one when
+ *                      it is 2; 1 .. 32: at most so many.  Results do not depend on the number of streams.
+ *   GR_TUNE_RESIDENT_FILL    sixteenths of the chip (1 .. 16, default 10) the streams of a launch must fill together for
  *                      GR_TUNE_RESIDENT = 1 to choose the pass
  *   GR_TUNE_RESIDENT_GROUPS  retired (round 3 removed the one-group shape of the resident pass): only the value 2 is accepted
  */

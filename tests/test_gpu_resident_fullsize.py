@@ -133,22 +133,25 @@ def test_headline_shape_with_a_different_box_in_every_frame(G):
     plan.close(); ref.close(); cur.close()
 
 
-@pytest.mark.parametrize("n,nf,streams", [(500_000, 40, 2), (330_000, 50, 3), (250_000, 70, 4), (125_000, 150, 8), (62_000, 260, 15)])
+@pytest.mark.parametrize("n,nf,streams", [(500_000, 40, 2), (330_000, 50, 3), (250_000, 70, 4), (125_000, 150, 8), (62_000, 260, 15), (20_000, 600, 32)])
 def test_frames_that_fill_a_fraction_of_the_chip_run_as_streams_by_default(G, n, nf, streams):
-    """DEFAULT tuning, systems of a half, a third, a quarter, an eighth and a sixteenth of the chip: 2, 3, 4, 8, 15 frame streams side
+    """DEFAULT tuning, systems of a half, a third, a quarter, an eighth, a sixteenth and 1/50 of the chip: 2, 3, 4, 8, 15, 32 frame streams side
     by side in ONE resident launch (stream s: frames s, s + S, ...; ragged: 50 = 17 + 17 + 16 turns, 70 = 18 + 18 + 17 + 17), every
-    stream with 16 frames or more; the finalizer workgroups close 2, 2, 4, 8, 8 frames at a time.  Oracle on frames of every stream, at the start, around the pipeline depth of each stream and at the end."""
+    stream with 16 frames or more; the finalizer workgroups close 2, 2, 4, 8, 8, 8 frames at a time.  Oracle on frames of every stream, at the start, around the pipeline depth of each stream and at the end."""
     box, masses, cur, ref, ref_pos, plan = _c4(G, n, nf)
     check = sorted({0, 1, streams - 1, 6 * streams - 1, 6 * streams, 6 * streams + 1, nf - streams, nf - 1})
     prof, r = _check(cur, plan, ref_pos, masses, np.arange(n), box, [box] * nf, nf, check)
     assert prof["k_fit_resident"][1] == 1 and prof["k_fit_resident"][2] == nf and prof["k_fit_pk"][1] == 0, prof
     assert cur.stat("res_last_streams") == streams
-    # one stream less than the segment can feed (16 frames each): the launch would leave CUs idle -> the two passes, same results
+    # a call that can feed one stream less (16 frames each): the pass with S - 1 streams if they still fill 10/16 of the chip,
+    # the two passes otherwise -- the same results either way
     cur.synth_frames(nf, 0, nf, 0, 0.05, W.SEED)
     cur.profile_enable(True)
     r2, st2 = plan.rmsd_fit(0, 16 * streams - 1)
     prof = cur.profile_read()
-    assert (st2 == 0).all() and prof["k_fit_resident"][1] == 0 and prof["k_fit_pk"][1] > 0, prof
+    still = (streams - 1) * ((n + 4095) // 4096) * 16 >= cur.stat("res_max_wgs") * 10
+    assert (st2 == 0).all() and (prof["k_fit_resident"][1] == 1) == still and (prof["k_fit_pk"][1] > 0) == (not still), prof
+    assert not still or cur.stat("res_last_streams") == streams - 1
     assert np.abs(np.asarray(r2) - np.asarray(r)[:16 * streams - 1]).max() <= 2e-6
     plan.close(); ref.close(); cur.close()
 

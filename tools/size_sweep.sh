@@ -22,6 +22,8 @@ PY
 for n in ${SIZES:-1000000 800000 700000 500000 400000 330000 250000 200000 125000}; do
     run $n two-pass resident=0 || exit 1
     run $n default || exit 1
+    # QUICK=1: only the two passes against the pass with as many streams as fit, whatever part of the chip they fill
+    if [ -n "$QUICK" ]; then run $n "any fill" resident=1 resident_fill=1 || exit 1; continue; fi
     for s in ${STREAMS:-1 2 3 4 6 8 12 16}; do
         wg=$(( (n + 4095) / 4096 ))
         if [ $(( wg * s + 2 )) -le 256 ]; then run $n "forced streams=$s" resident=2 resident_streams=$s || exit 1; fi
