@@ -1,4 +1,4 @@
-// gr_resident.h -- the RMSD fit as ONE pass over HBM when a frame fits on the chip.
+// gr_resident.h -- the RMSD fit as ONE pass over HBM when a frame (or several frames side by side) fits on the chip.
 //
 // The two-pass path (gr_hot.h) reads every frame twice: once for the sums that give the rotation, once to apply it -- the
 // rotation of a frame depends on all of its atoms, so no atom can be written before every atom has been read.  36 bytes per
@@ -24,6 +24,17 @@
 //                    the two-pass path does (gr_finalize_math: image proof, Kabsch rotation in fp64) and publishes
 //                    status | shift | R | t0 as 16 tagged 64-bit words.  The frame's box, first atom and host-side status are
 //                    requested BEFORE the wait: the finalize is the latency the parked frames have to cover.
+//                    FRAME STREAMS.  A frame that fills a fraction of the chip does not get the launch to itself: S = 2 .. 32
+//                    streams of `wgs_frame` workgroups run side by side, stream s walking the frames s, s + S, ... of the batch
+//                    (workgroup b: stream b / wgs_frame, atoms of workgroup b % wgs_frame).  Each stream is the pipeline above on
+//                    its own share of the CUs; nothing couples them but the finalizers, which then close several frames at a
+//                    time: a frame of <= 32 / 64 / 128 workgroups needs only 1 / 2 / 4 of a finalizer's waves for its records,
+//                    so the 8 waves form TEAMS that close 8 / 4 / 2 consecutive frames together (never more frames than there
+//                    are streams: the frames of a round must be frames that become ready together).  The closing arithmetic
+//                    is one lane's chain of fp64 operations, ~15 us per frame: 8 finalizer workgroups x 1 frame capped the
+//                    launch at 0.54 M frames/s whatever the size of the frame; teams lift that to ~4 M.  Measured against the
+//                    two-pass path (profiles/r03_size_sweep.txt): + 39 % at 500 000 atoms (2 streams), + 51 % at 250 000 (4),
+//                    + 53 % at 125 000 (8), + 57 % at 62 000 (15).
 // HBM traffic: 12 bytes per atom read + 12 written per frame = 24 (two passes: 36), and nothing from the caches.
 // Measured floor of that traffic at the same launch shape (tools/ceiling_bench.hip "resident copy"): 4.2 us per 1e6-atom frame.
 //
@@ -53,7 +64,7 @@
 // shape (1024 lanes, 128 registers, 9.3 us: spills inside the loop) was removed in round 3.
 //
 // Synchronisation.  All waiting is on data that a DIFFERENT workgroup produces, so every workgroup must become resident: the
-// pass is only chosen when the grid fits the device with one workgroup per CU (occupancy query at context creation), the host
+// pass is only chosen when the grid (streams x workgroups per frame + finalizers) fits the device with one workgroup per CU (occupancy query at context creation), the host
 // lets one such launch run per device and process at a time (a second one would share the CUs with the first and both could
 // starve; the loser takes the two-pass path), kernels of other streams that hold CUs when it starts end on their own, and the
 // kernel opens with a START HANDSHAKE: every workgroup checks in and the last one opens the launch; when that does not happen
