@@ -84,6 +84,7 @@ struct gr_ctx {
     int two_pass = 1;                 // GR_TUNE_TWO_PASS 0: RMSD-fit keeps the closed-form single-pass rmsd (k_rmsd_accum<0>)
     // resident RMSD fit (gr_resident.h): one launch per segment, the frame waits on chip for its rotation
     int resident = 1;                 // GR_TUNE_RESIDENT 0 never, 1 when the frame fills the chip, 2 whenever it fits (tests)
+    int pd_sym = 1;                   // GR_TUNE_PAIRDIST_SYMMETRIC: the pair matrix of a selection with itself computes one triangle and mirrors it
     int res_streams = 0;              // GR_TUNE_RESIDENT_STREAMS 0 automatic, 1..GR_RES_MAX_STREAMS: at most so many frame streams per resident launch
     int res_fill16 = 10;              // GR_TUNE_RESIDENT_FILL: sixteenths of the chip the streaming workgroups must fill for the pass to be chosen (resident = 1)
     uint32_t res_last_streams = 0;    // frame streams of the last resident launch (gr_ctx_stat)
@@ -896,7 +897,20 @@ static int pairdist_launch(gr_ctx *c, uint32_t s0, uint32_t nb, const GrSel &s1,
         // unrolled length of the minimum-image table: the smallest of 4 / 8 / 16 that holds every frame's entries
         int ncand = 0;
         for (uint32_t f = 0; f < nb; ++f) ncand = std::max(ncand, c->boxes_host[s0 + f].ncand);
-        if (ncand <= 4) k_pairdist<4><<<grid, dim3(GR_WG), 0, c->stream>>>(fr, c->frame_stride, s1, s2, c->boxes_dev + s0, dim, out_dev, out_stride, c->bad_dev);
+        // a selection with itself: the symmetric kernel computes the tiles on and above the diagonal and writes every one twice
+        // -- on non-orthogonal cells, where the kernel is bound by the VALU (measured, 1e4 x 1e4: XYZ 168 -> 111 us, XY 235 -> 163); the
+        // orthorhombic loops are bound by the stores, and the mirror image's 256-byte runs cost more than half the arithmetic saves
+        bool skewed = true;
+        for (uint32_t f = 0; f < nb; ++f) skewed = skewed && !c->boxes_host[s0 + f].ortho;
+        const bool self = c->pd_sym && skewed && s1.n == s2.n && s1.contiguous == s2.contiguous && s1.start == s2.start && s1.idx == s2.idx && s1.n >= 4 * GR_PDS_T;
+        if (self) {
+            const uint32_t nbk = (s1.n + GR_PDS_T - 1) / GR_PDS_T;
+            dim3 tiles(nbk, nbk, nb);
+            if (ncand <= 4) k_pairdist_sym<4><<<tiles, dim3(GR_WG), 0, c->stream>>>(fr, c->frame_stride, s1, c->boxes_dev + s0, dim, out_dev, out_stride, c->bad_dev);
+            else if (ncand <= 8) k_pairdist_sym<8><<<tiles, dim3(GR_WG), 0, c->stream>>>(fr, c->frame_stride, s1, c->boxes_dev + s0, dim, out_dev, out_stride, c->bad_dev);
+            else k_pairdist_sym<16><<<tiles, dim3(GR_WG), 0, c->stream>>>(fr, c->frame_stride, s1, c->boxes_dev + s0, dim, out_dev, out_stride, c->bad_dev);
+        }
+        else if (ncand <= 4) k_pairdist<4><<<grid, dim3(GR_WG), 0, c->stream>>>(fr, c->frame_stride, s1, s2, c->boxes_dev + s0, dim, out_dev, out_stride, c->bad_dev);
         else if (ncand <= 8) k_pairdist<8><<<grid, dim3(GR_WG), 0, c->stream>>>(fr, c->frame_stride, s1, s2, c->boxes_dev + s0, dim, out_dev, out_stride, c->bad_dev);
         else k_pairdist<16><<<grid, dim3(GR_WG), 0, c->stream>>>(fr, c->frame_stride, s1, s2, c->boxes_dev + s0, dim, out_dev, out_stride, c->bad_dev);
         HIPCHK(c, hipGetLastError());
@@ -1514,6 +1528,7 @@ int gr_ctx_set_tuning(gr_ctx *c, int key, int64_t value) try {
     case GR_TUNE_FUSE: c->fuse = value ? 1 : 0; return GR_OK;
     case GR_TUNE_TWO_PASS: c->two_pass = value ? 1 : 0; return GR_OK;
     case GR_TUNE_RESIDENT: if (value < 0 || value > 2) break; c->resident = value; return GR_OK;
+    case GR_TUNE_PAIRDIST_SYMMETRIC: if (value != 0 && value != 1) break; c->pd_sym = (int)value; return GR_OK;
     case GR_TUNE_RESIDENT_STREAMS: if (value < 0 || value > GR_RES_MAX_STREAMS) break; c->res_streams = (int)value; return GR_OK;
     case GR_TUNE_RESIDENT_FILL: if (value < 1 || value > 16) break; c->res_fill16 = (int)value; return GR_OK;
     case GR_TUNE_RESIDENT_GROUPS: if (value != 2) break; return GR_OK;   // (the one-group shape was removed: gr_resident.h)

@@ -1240,6 +1240,150 @@ __global__ __launch_bounds__(GR_WG) void k_pairdist(
     if (threadIdx.x == 0 && badj != GR_NOIDX) atomicMin(bad_out + 1, badj);
 }
 
+// The matrix of a selection WITH ITSELF (BASELINE configs[2]: "pair distances for a 10k-atom selection") is symmetric, and on
+// this chip the XYZ matrix of a triclinic cell is bound by the VALU, not by its 400 MB of stores: only the tiles on and above the
+// diagonal are computed, and every tile above it is written twice -- as it stands, and transposed through LDS so that the mirror
+// image is written in rows as well (256-byte runs).  distance(x_i, x_j) and distance(x_j, x_i) are the same bits in the fast paths
+// used here (d -> -d commutes with rint, fma and the |d.t| gains; the 1-D dimensions are signed: the mirror is the negation); the
+// generic path (Dimension::None) makes no such promise and computes its mirror explicitly.  Only non-orthogonal cells come here:
+// the orthorhombic loops are bound by the stores, and there the mirror image's shorter runs cost more than the arithmetic saves.
+// Tile: 64 x 64 (128 x 128 measured 7 % slower on single calls: 3 160 long workgroups leave a tail), 256 lanes = 16 row groups x
+// 16 column groups; a lane holds 4 consecutive column atoms and walks 4 rows.
+#ifndef GR_PDS_T
+#define GR_PDS_T 64
+#endif
+template <int NC, int MODE, int DIM>   // MODE 1: triclinic XYZ; 2: triclinic 1-D / 2-D; 3: generic (Dimension::None)
+__device__ __forceinline__ void gr_pds_quad(const float4 t, const float (&jx)[4], const float (&jy)[4], const float (&jz)[4], const GrBox &box,
+                                            const float4 *ttab, int dim, float (&d)[4], float (&m)[4]) {
+    const gr_v2f jx01 = { jx[0], jx[1] }, jy01 = { jy[0], jy[1] }, jz01 = { jz[0], jz[1] };
+    const gr_v2f jx23 = { jx[2], jx[3] }, jy23 = { jy[2], jy[3] }, jz23 = { jz[2], jz[3] };
+    if (MODE == 3) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { d[k] = gr_distance<NC>(t.x, t.y, t.z, jx[k], jy[k], jz[k], dim, box); m[k] = gr_distance<NC>(jx[k], jy[k], jz[k], t.x, t.y, t.z, dim, box); }
+        return;
+    }
+    gr_v2f a, b;
+    if (MODE == 1) { a = gr_pd_tric2<NC>(t, jx01, jy01, jz01, box); b = gr_pd_tric2<NC>(t, jx23, jy23, jz23, box); }
+    else { a = gr_pd_tric_vec2<NC, DIM>(t, jx01, jy01, jz01, box, ttab); b = gr_pd_tric_vec2<NC, DIM>(t, jx23, jy23, jz23, box, ttab); }
+    d[0] = a.x; d[1] = a.y; d[2] = b.x; d[3] = b.y;
+    constexpr bool SIGNED = DIM >= 1 && DIM <= 3;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) m[k] = SIGNED ? 0.0f - d[k] : d[k];   // (0 - d: coincident coordinates give +0 in both directions, never -0)
+}
+
+template <int NC>
+__global__ __launch_bounds__(GR_WG) void k_pairdist_sym(
+    const float *__restrict__ xyz, size_t frame_stride, GrSel s, const GrBox *__restrict__ boxes, int dim,
+    float *__restrict__ out, size_t out_stride, uint32_t *__restrict__ bad_out) {
+    // T x T tile: T / 4 column groups (a lane holds 4 column atoms) x 1024 / T row groups; the mirror image is staged H = 64 rows
+    // at a time; a lane walks T / H phases x G groups of 4 rows
+    constexpr uint32_t T = GR_PDS_T, CG = T / 4, RG = GR_WG / CG, H = 64, PH = T / H, G = H / RG / 4, LD = H + 4;
+    static_assert(GR_WG == 256 && (T == 128 || T == 64), "tile shape");
+    const uint32_t bi = blockIdx.y, bj = blockIdx.x;
+    if (bi > bj) return;                                   // below the diagonal: written by the tile above it
+    const GrBox &box = boxes[blockIdx.z];
+    xyz += (size_t)blockIdx.z * frame_stride; out += (size_t)blockIdx.z * out_stride; bad_out += 4 * blockIdx.z;
+    __shared__ float ti[T][4];
+    __shared__ float tt[T][LD];                            // the mirror image of half a tile: [column][row]
+    __shared__ uint32_t ldsu[GR_WG / 64];
+    __shared__ float4 ttab[NC + 1];
+    const uint32_t tid = threadIdx.x, cg = tid % CG, rg = tid / CG, n = s.n;
+    if (tid <= NC) ttab[tid] = tid < NC ? make_float4(box.cand[tid][0], box.cand[tid][1], box.cand[tid][2], 0.0f) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const uint32_t i0 = bi * T, j0 = bj * T + cg * 4;
+    uint32_t bad = GR_NOIDX, badj = GR_NOIDX;
+    if (tid < T) {
+        const uint32_t i = i0 + tid;
+        float x = 0.f, y = 0.f, z = 0.f;
+        if (i < n) {
+            const uint32_t a = s.contiguous ? s.start + i : s.idx[i];
+            gr_pos_load(xyz, a, x, y, z);
+            if (x != x) bad = min(bad, a);
+        }
+        ti[tid][0] = x; ti[tid][1] = y; ti[tid][2] = z; ti[tid][3] = 0.f;
+    }
+    float jx[4], jy[4], jz[4];
+    if (s.contiguous && j0 + 3 < n && ((s.start + j0) & 3u) == 0u) {
+        float4 r0, r1, r2;
+        gr_rows_load(reinterpret_cast<const float4 *>(xyz), (size_t)((s.start + j0) >> 2), r0, r1, r2);
+        gr_rows_unpack(r0, r1, r2, jx, jy, jz);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (jx[k] != jx[k]) badj = min(badj, s.start + j0 + k);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t j = j0 + k;
+            jx[k] = jy[k] = jz[k] = 0.f;
+            if (j < n) {
+                const uint32_t a = s.contiguous ? s.start + j : s.idx[j];
+                gr_pos_load(xyz, a, jx[k], jy[k], jz[k]);
+                if (jx[k] != jx[k]) badj = min(badj, a);
+            }
+        }
+    }
+    __syncthreads();               // (publishes ti and ttab)
+    const bool vec_ok = (n & 3u) == 0u, diag = bi == bj;
+    auto run = [&](auto M, auto D) {
+        constexpr int MODE = decltype(M)::value, DIM = decltype(D)::value;
+        for (uint32_t h = 0; h < PH; ++h) {
+#pragma unroll 1
+            for (uint32_t g = 0; g < G; ++g) {
+                const uint32_t rl = 4u * G * rg + 4u * g;      // row inside this phase: 0 .. 63
+                float m[4][4];
+#pragma unroll
+                for (uint32_t r = 0; r < 4; ++r) {
+                    const uint32_t row = H * h + rl + r;
+                    const float4 t = *reinterpret_cast<const float4 *>(&ti[row][0]);
+                    float d[4];
+                    gr_pds_quad<NC, MODE, DIM>(t, jx, jy, jz, box, ttab, dim, d, m[r]);
+                    if (i0 + row < n) {
+                        float *dst = out + (size_t)(i0 + row) * n + j0;
+                        if (vec_ok && j0 + 3 < n) gr_stream_store(reinterpret_cast<float4 *>(dst), make_float4(d[0], d[1], d[2], d[3]));
+                        else {
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) if (j0 + k < n) dst[k] = d[k];
+                        }
+                    }
+                }
+                if (!diag) {
+#pragma unroll
+                    for (uint32_t c = 0; c < 4; ++c) *reinterpret_cast<float4 *>(&tt[4u * cg + c][rl]) = make_float4(m[0][c], m[1][c], m[2][c], m[3][c]);
+                }
+            }
+            __syncthreads();
+            if (!diag) {
+#pragma unroll 2
+                for (uint32_t p = 0; p < T / 16u; ++p) {
+                    const uint32_t jr = p * 16u + (tid >> 4), seg = tid & 15u;
+                    const uint32_t jg = bj * T + jr, ig = i0 + H * h + 4u * seg;
+                    if (jg < n) {
+                        const float4 v = *reinterpret_cast<const float4 *>(&tt[jr][4u * seg]);
+                        float *dst = out + (size_t)jg * n + ig;
+                        if (vec_ok && ig + 3 < n) gr_stream_store(reinterpret_cast<float4 *>(dst), v);
+                        else { if (ig < n) dst[0] = v.x; if (ig + 1 < n) dst[1] = v.y; if (ig + 2 < n) dst[2] = v.z; if (ig + 3 < n) dst[3] = v.w; }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    };
+    // (the host sends only non-orthogonal cells here: the orthorhombic loops are bound by the stores, not by the arithmetic)
+    if (dim == 7) run(std::integral_constant<int, 1>(), std::integral_constant<int, 7>());
+    else if (dim != 0) {
+        switch (dim) {
+        case 1: run(std::integral_constant<int, 2>(), std::integral_constant<int, 1>()); break;
+        case 2: run(std::integral_constant<int, 2>(), std::integral_constant<int, 2>()); break;
+        case 3: run(std::integral_constant<int, 2>(), std::integral_constant<int, 3>()); break;
+        case 4: run(std::integral_constant<int, 2>(), std::integral_constant<int, 4>()); break;
+        case 5: run(std::integral_constant<int, 2>(), std::integral_constant<int, 5>()); break;
+        default: run(std::integral_constant<int, 2>(), std::integral_constant<int, 6>()); break;
+        }
+    } else run(std::integral_constant<int, 3>(), std::integral_constant<int, 0>());
+    bad = gr_block_min_u32(bad, ldsu);
+    badj = gr_block_min_u32(badj, ldsu);
+    if (tid == 0 && bad != GR_NOIDX) atomicMin(bad_out, bad);
+    if (tid == 0 && badj != GR_NOIDX) atomicMin(bad_out + 1, badj);
+}
+
 // ------------------------------------------------------------------------------------------ synthetic frames
 __device__ __forceinline__ uint64_t gr_mix64(uint64_t z) {
     z += 0x9E3779B97F4A7C15ull;

@@ -15,8 +15,11 @@ import oracle_lib as O
 n, S, reps = 1_000_000, int(sys.argv[1]) if len(sys.argv) > 1 else 10_000, 20
 NB = 16   # frames per batched call (16 x 400 MB of matrices)
 out = {}
-for name, (l, a) in {"triclinic": ([24.0, 23.0, 22.0], [75.0, 80.0, 70.0]), "dodecahedron": ([24.18] * 3, [60.0, 60.0, 90.0]),
-                     "orthorhombic": ([24.0, 23.0, 22.0], [90.0, 90.0, 90.0])}.items():
+CELLS = {"triclinic": ([24.0, 23.0, 22.0], [75.0, 80.0, 70.0]), "dodecahedron": ([24.18] * 3, [60.0, 60.0, 90.0]),
+         "orthorhombic": ([24.0, 23.0, 22.0], [90.0, 90.0, 90.0])}
+if os.environ.get("PD_ONLY"):                     # (profiling runs: one cell)
+    CELLS = {k: v for k, v in CELLS.items() if k in os.environ["PD_ONLY"].split(",")}
+for name, (l, a) in CELLS.items():
     box = O.box_from_lengths_angles(l, a)
     s = G.System(n, n_slots=NB)
     for f in range(NB):
