@@ -1052,12 +1052,23 @@ __device__ __forceinline__ gr_v2f gr_pd_tric2(const float4 t, gr_v2f jx, gr_v2f 
     const gr_v2f r2 = dx * dx + dy * dy + dz * dz;
     gr_v2f best = { 0.0f, 0.0f };
     static_assert(NC % 2 == 0, "image table is searched two entries at a time");
+    if (b.cand_pairs) {            // entry m + 1 = entry m + a (or a pad): d.(t + a) = d.t + ax dx   (gr_box_setup)
+        const gr_v2f pa = gr_v2(b.ax) * dx;
 #pragma unroll
-    for (int m = 0; m < NC; m += 2) {
-        const gr_v2f d0 = gr_v2_fma(gr_v2(b.cand[m][0]), dx, gr_v2_fma(gr_v2(b.cand[m][1]), dy, gr_v2(b.cand[m][2]) * dz));
-        const gr_v2f d1 = gr_v2_fma(gr_v2(b.cand[m + 1][0]), dx, gr_v2_fma(gr_v2(b.cand[m + 1][1]), dy, gr_v2(b.cand[m + 1][2]) * dz));
-        best.x = gr_min3f(best.x, fmaf(-2.0f, __builtin_fabsf(d0.x), b.cand_t2[m]), fmaf(-2.0f, __builtin_fabsf(d1.x), b.cand_t2[m + 1]));
-        best.y = gr_min3f(best.y, fmaf(-2.0f, __builtin_fabsf(d0.y), b.cand_t2[m]), fmaf(-2.0f, __builtin_fabsf(d1.y), b.cand_t2[m + 1]));
+        for (int m = 0; m < NC; m += 2) {
+            const gr_v2f d0 = gr_v2_fma(gr_v2(b.cand[m][0]), dx, gr_v2_fma(gr_v2(b.cand[m][1]), dy, gr_v2(b.cand[m][2]) * dz));
+            const gr_v2f d1 = d0 + pa;
+            best.x = gr_min3f(best.x, fmaf(-2.0f, __builtin_fabsf(d0.x), b.cand_t2[m]), fmaf(-2.0f, __builtin_fabsf(d1.x), b.cand_t2[m + 1]));
+            best.y = gr_min3f(best.y, fmaf(-2.0f, __builtin_fabsf(d0.y), b.cand_t2[m]), fmaf(-2.0f, __builtin_fabsf(d1.y), b.cand_t2[m + 1]));
+        }
+    } else {
+#pragma unroll
+        for (int m = 0; m < NC; m += 2) {
+            const gr_v2f d0 = gr_v2_fma(gr_v2(b.cand[m][0]), dx, gr_v2_fma(gr_v2(b.cand[m][1]), dy, gr_v2(b.cand[m][2]) * dz));
+            const gr_v2f d1 = gr_v2_fma(gr_v2(b.cand[m + 1][0]), dx, gr_v2_fma(gr_v2(b.cand[m + 1][1]), dy, gr_v2(b.cand[m + 1][2]) * dz));
+            best.x = gr_min3f(best.x, fmaf(-2.0f, __builtin_fabsf(d0.x), b.cand_t2[m]), fmaf(-2.0f, __builtin_fabsf(d1.x), b.cand_t2[m + 1]));
+            best.y = gr_min3f(best.y, fmaf(-2.0f, __builtin_fabsf(d0.y), b.cand_t2[m]), fmaf(-2.0f, __builtin_fabsf(d1.y), b.cand_t2[m + 1]));
+        }
     }
     const gr_v2f s = r2 + best;
     gr_v2f r = { __builtin_amdgcn_sqrtf(fmaxf(s.x, 0.0f)), __builtin_amdgcn_sqrtf(fmaxf(s.y, 0.0f)) };
@@ -1084,14 +1095,20 @@ __device__ __forceinline__ gr_v2f gr_pd_tric_vec2(const float4 t, gr_v2f jx, gr_
     const gr_v2f r2 = dx * dx + dy * dy + dz * dz;
     gr_v2f g[NC];
     gr_v2f best = { 0.0f, 0.0f };
+    auto gains = [&](auto PAIRS) {            // PAIRS: entry m + 1 = entry m + a (or a pad): d.(t + a) = d.t + ax dx   (gr_box_setup)
+        const gr_v2f pa = gr_v2(b.ax) * dx;
 #pragma unroll
-    for (int m = 0; m < NC; m += 2) {
-        const gr_v2f d0 = gr_v2_fma(gr_v2(b.cand[m][0]), dx, gr_v2_fma(gr_v2(b.cand[m][1]), dy, gr_v2(b.cand[m][2]) * dz));
-        const gr_v2f d1 = gr_v2_fma(gr_v2(b.cand[m + 1][0]), dx, gr_v2_fma(gr_v2(b.cand[m + 1][1]), dy, gr_v2(b.cand[m + 1][2]) * dz));
-        g[m].x = fmaf(-2.0f, __builtin_fabsf(d0.x), b.cand_t2[m]); g[m].y = fmaf(-2.0f, __builtin_fabsf(d0.y), b.cand_t2[m]);
-        g[m + 1].x = fmaf(-2.0f, __builtin_fabsf(d1.x), b.cand_t2[m + 1]); g[m + 1].y = fmaf(-2.0f, __builtin_fabsf(d1.y), b.cand_t2[m + 1]);
-        best.x = gr_min3f(best.x, g[m].x, g[m + 1].x); best.y = gr_min3f(best.y, g[m].y, g[m + 1].y);
-    }
+        for (int m = 0; m < NC; m += 2) {
+            const gr_v2f d0 = gr_v2_fma(gr_v2(b.cand[m][0]), dx, gr_v2_fma(gr_v2(b.cand[m][1]), dy, gr_v2(b.cand[m][2]) * dz));
+            gr_v2f d1;
+            if (decltype(PAIRS)::value) d1 = d0 + pa;
+            else d1 = gr_v2_fma(gr_v2(b.cand[m + 1][0]), dx, gr_v2_fma(gr_v2(b.cand[m + 1][1]), dy, gr_v2(b.cand[m + 1][2]) * dz));
+            g[m].x = fmaf(-2.0f, __builtin_fabsf(d0.x), b.cand_t2[m]); g[m].y = fmaf(-2.0f, __builtin_fabsf(d0.y), b.cand_t2[m]);
+            g[m + 1].x = fmaf(-2.0f, __builtin_fabsf(d1.x), b.cand_t2[m + 1]); g[m + 1].y = fmaf(-2.0f, __builtin_fabsf(d1.y), b.cand_t2[m + 1]);
+            best.x = gr_min3f(best.x, g[m].x, g[m + 1].x); best.y = gr_min3f(best.y, g[m].y, g[m + 1].y);
+        }
+    };
+    if (b.cand_pairs) gains(std::true_type()); else gains(std::false_type());
     // (a vector shorter than r_ws is its own minimum image whatever the table says: gr_tric_refine returns before the search)
     const float rws2 = b.r_ws * b.r_ws;
     int ix = NC, iy = NC;

@@ -45,7 +45,8 @@ struct GrBox {
     int ortho;             // v2x == v3x == v3y == 0
     int ncand;             // number of entries in cand
     int valid;             // 0: the frame has no box
-    float cand[GR_MAX_CAND][3];   // one of each +-t pair; unused entries are 0 with cand_t2 = 1e30 (never win)
+    int cand_pairs;        // 1: the table is laid out in pairs -- entry 2m + 1 is entry 2m + the first box vector (or a never-winning pad)
+    float cand[GR_MAX_CAND][3];   // one of each +-t pair; unused entries and pads are 0 with cand_t2 = 1e30 (never win)
     float cand_t2[GR_MAX_CAND];   // |t|^2
 };
 
@@ -281,7 +282,7 @@ GR_HD float gr_distance(float ax_, float ay_, float az_, float px, float py, flo
 // Host-side preparation of a GrBox from the gro-order box9 (simbox.rs:13-26). Returns 0 when the
 // diagonal is not strictly positive / not finite (the reference panics or never terminates there).
 inline int gr_box_setup(const float *box9, GrBox *b) {
-    b->valid = 0; b->ncand = 0; b->iax = b->iby = b->icz = 0;
+    b->valid = 0; b->ncand = 0; b->cand_pairs = 0; b->iax = b->iby = b->icz = 0;
     if (!box9) { b->ax = b->by = b->cz = b->bx = b->cx = b->cy = 0; b->ortho = 1; b->bcx = b->bcy = b->bcz = 0; b->r_ws = 0; return 1; }
     b->ax = box9[0]; b->by = box9[1]; b->cz = box9[2];
     b->bx = box9[5]; b->cx = box9[7]; b->cy = box9[8];
@@ -319,6 +320,26 @@ inline int gr_box_setup(const float *box9, GrBox *b) {
                 }
             }
     if (overflow) b->ncand = GR_MAX_CAND + 1;   // too skewed for the table -> GR_E_UNSUPPORTED_BOX
+    else if (b->ncand) {
+        // Pair layout for the packed searches (gr_kernels.h): after the x step of the brick reduction the entries of one (j, k)
+        // come as neighbours i, i + 1 -- t and t + a -- and d.(t + a) = d.t + ax dx is one addition instead of three FMAs.  The
+        // order of the entries is kept (ties go to the first entry on every path); an entry without its neighbour gets a pad that
+        // never wins.  When the pads do not fit the table stays as it is and the searches take all dot products.
+        float pc[GR_MAX_CAND][3], pt2[GR_MAX_CAND];
+        int pn = 0, fits = 1;
+        for (int m = 0; m < b->ncand && fits; ++m) {
+            const bool partner = (pn & 1) && b->cand_t2[m] < 1.0e29f && pt2[pn - 1] < 1.0e29f &&
+                                 b->cand[m][1] == pc[pn - 1][1] && b->cand[m][2] == pc[pn - 1][2] &&
+                                 fabsf(b->cand[m][0] - (pc[pn - 1][0] + b->ax)) <= 1e-5f * b->ax;
+            if ((pn & 1) && !partner) { if (pn < GR_MAX_CAND) { pc[pn][0] = pc[pn][1] = pc[pn][2] = 0.0f; pt2[pn] = 1.0e30f; pn++; } else fits = 0; }
+            if (pn < GR_MAX_CAND) { pc[pn][0] = b->cand[m][0]; pc[pn][1] = b->cand[m][1]; pc[pn][2] = b->cand[m][2]; pt2[pn] = b->cand_t2[m]; pn++; } else fits = 0;
+        }
+        if (fits && (pn & 1)) { if (pn < GR_MAX_CAND) { pc[pn][0] = pc[pn][1] = pc[pn][2] = 0.0f; pt2[pn] = 1.0e30f; pn++; } else fits = 0; }
+        if (fits) {
+            for (int m = 0; m < pn; ++m) { b->cand[m][0] = pc[m][0]; b->cand[m][1] = pc[m][1]; b->cand[m][2] = pc[m][2]; b->cand_t2[m] = pt2[m]; }
+            b->ncand = pn; b->cand_pairs = 1;
+        }
+    }
     b->r_ws = (float)(0.5 * sqrt(tmin2));
     return 1;
 }
