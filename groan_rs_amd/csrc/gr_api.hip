@@ -260,7 +260,7 @@ uint32_t resident_wgs(gr_ctx *c, bool lite, uint32_t nb, const GrSel &sel, uint3
     // least two finalizer workgroups however many streams; a segment gives every stream 16 frames or more, see below).  Forced
     // launches (tests) stay with one stream unless GR_TUNE_RESIDENT_STREAMS asks for more.
     uint64_t s_max = c->res_streams ? (uint64_t)c->res_streams : (c->resident == 1 ? (uint64_t)GR_RES_MAX_STREAMS : 1u);
-    s_max = std::min<uint64_t>(s_max, (c->res_max_wgs - 2) / wgs);
+    s_max = std::min<uint64_t>(s_max, std::min<uint64_t>(c->res_max_wgs - 2, GR_MAX_CHUNKS) / wgs);   // (res_progress holds GR_MAX_CHUNKS workgroups)
     if (c->resident == 1) s_max = std::min<uint64_t>(s_max, nb / 16u);
     else s_max = std::min<uint64_t>(s_max, nb);
     // the pass costs the same per turn whatever the frame's size (every CU runs its 4096 atoms' worth or idles): it only beats
