@@ -298,27 +298,35 @@ inline int gr_box_setup(const float *box9, GrBox *b) {
     double tmin2 = 1e300;
     for (int q = 0; q < GR_MAX_CAND; ++q) { b->cand[q][0] = b->cand[q][1] = b->cand[q][2] = 0.0f; b->cand_t2[q] = 1.0e30f; }
     int overflow = 0;
-    for (int k = -2; k <= 2; ++k)
-        for (int j = -2; j <= 2; ++j)
-            for (int i = -2; i <= 2; ++i) {
-                if (!i && !j && !k) continue;
-                double tx = (double)i * b->ax + (double)j * b->bx + (double)k * b->cx;
-                double ty = (double)j * b->by + (double)k * b->cy;
-                double tz = (double)k * b->cz;
-                double t2 = tx * tx + ty * ty + tz * tz;
+    // Every lattice vector t that can shorten SOME vector of the brick satisfies |t|^2 < |tx| ax + |ty| by + |tz| cz <= |t| D with
+    // D the brick's diagonal, so |t| < D: the enumeration below covers exactly the (k, j, i) that can reach that ball -- a flat
+    // cell (cz much shorter than the skew of c) needs k = 3, 4, ... where a compact one needs |i|, |j|, |k| <= 1.  (Rounds 1-3
+    // enumerated -2 .. 2 whatever the cell: flat cells got an incomplete table and silently longer "minimum" images;
+    // tests/cpp/test_boxtable.cpp.)  One of each +-t pair: k >= 0, then j >= 0, then i > 0; order k, j, i ascending.
+    const double D = sqrt((double)b->ax * b->ax + (double)b->by * b->by + (double)b->cz * b->cz);
+    const int kmax = (int)floor(D / b->cz);
+    for (int k = 0; k <= kmax && !overflow; ++k) {
+        const double tz = (double)k * b->cz, cyk = (double)k * b->cy, cxk = (double)k * b->cx;
+        const int jlo = k == 0 ? 0 : (int)ceil((-D - cyk) / b->by), jhi = (int)floor((D - cyk) / b->by);
+        for (int j = jlo; j <= jhi && !overflow; ++j) {
+            const double ty = (double)j * b->by + cyk, x0 = (double)j * b->bx + cxk;
+            const int ilo = (k == 0 && j == 0) ? 1 : (int)ceil((-D - x0) / b->ax), ihi = (int)floor((D - x0) / b->ax);
+            for (int i = ilo; i <= ihi; ++i) {
+                const double tx = (double)i * b->ax + x0;
+                const double t2 = tx * tx + ty * ty + tz * tz;
                 if (t2 < tmin2) tmin2 = t2;
                 if (b->ortho) continue;
-                // one representative of each +-t pair: the first non-zero of (k, j, i) is positive
-                if (k < 0 || (k == 0 && (j < 0 || (j == 0 && i < 0)))) continue;
-                double lhs = fabs(tx) * b->ax + fabs(ty) * b->by + fabs(tz) * b->cz;
+                const double lhs = fabs(tx) * b->ax + fabs(ty) * b->by + fabs(tz) * b->cz;
                 if (lhs > t2 * (1.0 + 1e-6)) {
                     if (b->ncand < GR_MAX_CAND) {
                         b->cand[b->ncand][0] = (float)tx; b->cand[b->ncand][1] = (float)ty; b->cand[b->ncand][2] = (float)tz;
                         b->cand_t2[b->ncand] = (float)t2;
                         b->ncand++;
-                    } else overflow = 1;
+                    } else { overflow = 1; break; }
                 }
             }
+        }
+    }
     if (overflow) b->ncand = GR_MAX_CAND + 1;   // too skewed for the table -> GR_E_UNSUPPORTED_BOX
     else if (b->ncand) {
         // Pair layout for the packed searches (gr_kernels.h): after the x step of the brick reduction the entries of one (j, k)

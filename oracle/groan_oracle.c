@@ -119,16 +119,17 @@ float go_min_image(float dx, float box_len) {
  * Triclinic extension helpers (no reference arithmetic).  Box vectors
  *   a = (v1x,0,0)  b = (v2x,v2y,0)  c = (v3x,v3y,v3z)
  * Candidate lattice translations that can shorten a vector already reduced to the brick
- * |d.z|<=cz/2, |d.y|<=by/2, |d.x|<=ax/2:  t = i a + j b + k c, i,j,k in [-2,2], with
+ * |d.z|<=cz/2, |d.y|<=by/2, |d.x|<=ax/2:  t = i a + j b + k c, i,j,k in [-8,8] (rounds 1-3: [-2,2], too few for flat cells), with
  *   |t.x| ax + |t.y| by + |t.z| cz > |t|^2     (otherwise |d+t| >= |d| for every d in the brick).
  * ------------------------------------------------------------------------------------------ */
-typedef struct { int n; float t[124][3]; } tric_cand;
+#define TRIC_R 8        /* |i|, |j|, |k| <= 8: every candidate has |t| < the brick's diagonal; flatter cells than that are refused */
+typedef struct { int n; float t[(2 * TRIC_R + 1) * (2 * TRIC_R + 1) * (2 * TRIC_R + 1)][3]; } tric_cand;
 
 static void tric_candidates(const float *b, tric_cand *c) {
     c->n = 0;
-    for (int k = -2; k <= 2; ++k)
-        for (int j = -2; j <= 2; ++j)
-            for (int i = -2; i <= 2; ++i) {
+    for (int k = -TRIC_R; k <= TRIC_R; ++k)
+        for (int j = -TRIC_R; j <= TRIC_R; ++j)
+            for (int i = -TRIC_R; i <= TRIC_R; ++i) {
                 if (!i && !j && !k) continue;
                 double tx = (double)i * V1X(b) + (double)j * V2X(b) + (double)k * V3X(b);
                 double ty = (double)j * V2Y(b) + (double)k * V3Y(b);

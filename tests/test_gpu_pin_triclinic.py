@@ -244,3 +244,60 @@ def test_config3_first_rows_against_brute_force_images(G):
             best = np.minimum(best, (dd ** 2).sum(2).min(1))
         assert np.abs(got[i] - np.sqrt(best)).max() <= 2e-5
     s.close()
+
+
+FLAT_CELLS = {
+    # one box vector much shorter than the skew of the others: the closest image is 3-5 lattice steps from the brick-reduced
+    # vector.  Rounds 1-3 built the image table from |i|, |j|, |k| <= 2 whatever the cell and returned longer vectors here.
+    "flat_a": [12.8942, 29.4173, 3.27353, 0, 0, -4.28403, 0, -1.85917, -4.05997],
+    "flat_b": [20.0702, 24.0458, 2.42171, 0, 0, -8.9196, 0, -6.97267, -6.8196],
+    "flat_on_the_limits": [7.0228, 23.7485, 2.67607, 0, 0, 3.5114, 0, 3.5114, 11.8743],
+    "mildly_flat": [12.0, 11.0, 5.0, 0, 0, 3.0, 0, -4.0, 4.5],
+}
+
+
+@pytest.mark.parametrize("cell", list(FLAT_CELLS))
+def test_flat_cells_are_exact_or_refused(G, cell):
+    """pair distances (plain and self-matrix kernels, XYZ and a 2-D dimension) and the centre of a group in flat cells: equal to an
+    fp64 search over 19 x 19 x 19 lattice images -- or the cell is refused with "box too skewed for the minimum-image table"
+    (more than 16 +- pairs of lattice vectors can win): never a silently longer vector"""
+    import itertools
+    box = np.array(FLAT_CELLS[cell], np.float32)
+    L = np.array([[box[0], 0, 0], [box[5], box[1], 0], [box[7], box[8], box[2]]], np.float64)
+    rng = np.random.default_rng(4)
+    n = 600
+    pos = (rng.random((n, 3)) @ L).astype(np.float32)
+    s = G.System(n, n_slots=1)
+    s.set_frame(pos, box, slot=0)
+    s.group_create_from_ranges("A", [(0, 299)])
+    s.group_create_from_ranges("B", [(300, n - 1)])
+    s.group_create_from_ranges("S", [(0, n - 1)])
+    try:
+        d_ab = s.group_all_distances("A", "B", G.Dimension.XYZ)
+    except G.DeviceError as e:
+        assert "skewed" in str(e), e
+        assert cell != "mildly_flat"            # (8 +- pairs: must be supported)
+        s.close()
+        return
+    ks = np.array(list(itertools.product(range(-9, 10), repeat=3)), np.float64) @ L               # 6859 images
+    def brute(a, b):
+        d = pos[a].astype(np.float64)[:, None, :] - pos[b].astype(np.float64)[None, :, :]
+        best = np.full(d.shape[:2], np.inf)
+        vec = np.zeros(d.shape)
+        for t in ks:
+            v = d + t
+            r = (v ** 2).sum(-1)
+            m = r < best
+            best[m] = r[m]; vec[m] = v[m]
+        return np.sqrt(best), vec
+    want, _ = brute(np.arange(300), np.arange(300, n))
+    tol = 2e-6 + 2.5e-7 * (box[:3].astype(np.float64) ** 2).sum() / 4 / np.maximum(want, 1e-3)   # (the length-only search: DESIGN.md "Pair distances")
+    assert (np.abs(d_ab - want) <= tol).all(), float(np.abs(d_ab - want).max())
+    d_ss = s.group_all_distances("S", "S", G.Dimension.XYZ)
+    want_ss, vec_ss = brute(np.arange(n), np.arange(n))
+    tol = 2e-6 + 2.5e-7 * (box[:3].astype(np.float64) ** 2).sum() / 4 / np.maximum(want_ss, 1e-3)
+    assert (np.abs(d_ss - want_ss) <= tol).all(), float(np.abs(d_ss - want_ss).max())
+    d_xy = s.group_all_distances("S", "S", G.Dimension.XY)
+    ok = np.abs(d_xy - np.hypot(vec_ss[..., 0], vec_ss[..., 1])) <= 5e-6
+    assert ok.mean() > 0.999, ok.mean()          # (pairs whose two best images tie to rounding may pick either one)
+    s.close()
