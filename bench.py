@@ -127,7 +127,14 @@ def main():
     radius = WL.blob_radius(box)
     masses = WL.masses_cycle(n)
 
+    trace_on = bool(os.environ.get("GROAN_BENCH_TRACE"))
+
+    def trace(what):                          # GROAN_BENCH_TRACE=1: progress lines on stderr (where does a run under a profiler stop?)
+        if trace_on:
+            print("[bench %.3f] rank %d: %s" % (time.time() % 1000.0, rank, what), file=sys.stderr, flush=True)
+
     dev = local_rank
+    trace("creating the system: %d atoms, %d slots" % (n, pool + 1))
     cur = G.System(n, masses=masses, n_slots=pool + 1, device=dev)      # slot `pool` holds the reference blob
     if args.tune:
         cur.set_tuning(**{kv.split("=")[0]: int(kv.split("=")[1]) for kv in args.tune})
@@ -137,8 +144,10 @@ def main():
     plan = G.RMSDPlan(ref, cur, "all")
     # local frame j of this rank is global frame j*world + rank
     t_gen = time.time()
+    trace("synthesising %d frames" % pool)
     cur.synth_frames(pool, 0, pool, rank, 0.05, SEED, frame_index_stride=world)
     cur.sync()
+    trace("frames ready")
     t_gen = time.time() - t_gen
 
     def barrier():
@@ -154,6 +163,7 @@ def main():
     # ---- warmup (untimed); profiling already on so the first use of the profiling events is not timed
     cur.profile_enable(True)
     for s in range(W):
+        trace("warmup step %d" % s)
         r, st = plan.rmsd_fit(step_slot(s), B)
         assert (st == 0).all(), st
     fallbacks = 0
@@ -163,6 +173,7 @@ def main():
     t0 = time.perf_counter()
     t_prev = t0
     for s in range(K):
+        trace("step %d" % s)
         r, st = plan.rmsd_fit(step_slot(W + s), B)       # synchronous: returns with the step's results on the host
         rmsd_all[s] = r
         fallbacks += plan.last_fallbacks()
@@ -175,6 +186,7 @@ def main():
         else:
             gathered = G.gather_per_frame(rmsd_all.reshape(-1), K * B * world, dist=dist, device=tdev)
     gpu_ms = cur.timer_stop()
+    trace("timed steps done")
     barrier()
     t1 = time.perf_counter()
     prof = cur.profile_read()

@@ -88,6 +88,7 @@ struct gr_ctx {
     int res_streams = 0;              // GR_TUNE_RESIDENT_STREAMS 0 automatic, 1..GR_RES_MAX_STREAMS: at most so many frame streams per resident launch
     int res_fill16 = 10;              // GR_TUNE_RESIDENT_FILL: sixteenths of the chip the streaming workgroups must fill for the pass to be chosen (resident = 1)
     uint32_t res_last_streams = 0;    // frame streams of the last resident launch (gr_ctx_stat)
+    int wall_khz = 100000;            // rate of the device's wall_clock64() (hipDeviceAttributeWallClockRate)
     uint32_t res_max_wgs = 0;         // workgroups of k_fit_resident the device holds at once (0: the pass cannot run here)
     int res_test_no_start = 0;        // GR_TUNE_TEST_RESIDENT_NO_START (tests): the next resident launch finds its start verdict already "never started"
     uint32_t res_test_abort_at = 0xFFFFFFFFu;   // GR_TUNE_TEST_RESIDENT_ABORT_AT (tests): the finalizer of this frame of the next resident launch raises `abort`
@@ -599,6 +600,11 @@ gr_ctx *gr_ctx_create(int device, uint64_t n_atoms, uint32_t n_slots, int *statu
     ok = ok && hipMalloc(&c->res_rec, (size_t)GR_MAX_BATCH * 16 * sizeof(unsigned long long)) == hipSuccess;
     ok = ok && hipMemset(c->res_rec, 0, (size_t)GR_MAX_BATCH * 16 * sizeof(unsigned long long)) == hipSuccess;
     ok = ok && hipMalloc(&c->res_progress, (size_t)GR_MAX_CHUNKS * 8 * sizeof(uint32_t)) == hipSuccess;
+    if (ok) {   // the clock the resident pass bounds its waits with
+        int khz = 0;
+        if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->device) == hipSuccess && khz > 0) c->wall_khz = khz;
+        (void)hipGetLastError();
+    }
     if (ok) {   // can the resident pass run here?  (160 KiB of LDS per workgroup, one workgroup per CU)
         int per_cu = 0;
         int per_cu_x = 0;
@@ -1650,6 +1656,7 @@ static int segment_begin(gr_rmsd_plan *p, uint32_t s0, uint32_t nb, int fit) {
                 while (GrResShape::WAVES / tw > res_streams) tw *= 2u;
                 ctl.team_waves = tw;
             }
+            ctl.patience_ticks = (unsigned long long)c->wall_khz * 3000ull; ctl.start_ticks = (unsigned long long)c->wall_khz * 200ull;   // 3 s, 0.2 s
             ctl.test_abort_frame = c->res_test_abort_at; c->res_test_abort_at = 0xFFFFFFFFu;
             float *frames = c->frames; size_t stride = c->frame_stride; uint32_t slot0 = s0, nfr = nb, natoms = (uint32_t)c->n;
             const float *masses = c->masses; GrSel sel_arg = sel; const GrBox *boxes = c->boxes_dev; GrPlanDev plan = p->dev;

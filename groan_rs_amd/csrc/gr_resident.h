@@ -71,7 +71,7 @@
 // within ~0.2 s the launch closes itself and every workgroup leaves before any frame is touched (the host then runs the
 // segment on the two-pass path).  Past the handshake every workgroup is on the chip and no wait can last.  The
 // launch is an ordinary one: hipLaunchCooperativeKernel -- the runtime's own co-residency check -- makes rocprofv3 --pmc fault
-// and crashed a process that issued it from two host threads at exit (ROCm 7.2).  Every wait is bounded (GR_RES_PATIENCE polls
+// and crashed a process that issued it from two host threads at exit (ROCm 7.2).  Every wait is bounded (ctl.patience_ticks of the device clock, GR_RES_PATIENCE polls
 // with s_sleep, a few seconds): a wave that runs out of patience raises `abort` and leaves, every other wait then ends too and
 // the grid drains.  Every streaming wave records how many frames it has fitted when it leaves (`progress`): after an abort the
 // host knows which frames are complete, which are untouched (those it redoes on the two-pass path) and which -- if a wave gave
@@ -117,8 +117,12 @@ struct GrResShape {
 #ifndef GR_RES_MAX_STREAMS
 #define GR_RES_MAX_STREAMS 32      // frame streams side by side in one launch (frames that fill a fraction of the chip)
 #endif
-#define GR_RES_PATIENCE 3000000u   // polls (each ~1 us) before a wait gives up
-#define GR_RES_START_PATIENCE 200000u   // polls of the start handshake (~0.2 s: other kernels may hold CUs when the launch begins)
+// Every wait is bounded in TIME (the device's constant-rate clock, wall_clock64: read every 256 polls) -- ctl.patience_ticks, ~3 s,
+// for a record, ctl.start_ticks, ~0.2 s, for the start handshake (other kernels may hold CUs when the launch begins) -- and, as a
+// second line, in polls: a poll costs ~1 us on an idle device but many times that under a profiler's counter collection, where a
+// bound in polls alone let a stuck launch sit for minutes.
+#define GR_RES_PATIENCE 30000000u        // polls before a wait gives up whatever the clock says
+#define GR_RES_START_PATIENCE 2000000u   // ... of the start handshake
 #define GR_ST_ABORTED 102          /* internal: the frame's finalizer gave up (abort): the frame is untouched and is redone on the two-pass path */
 
 #define GR_RES_REC_WORDS 32         // tagged words per workgroup record: 0..18 sums, 19..30 extents (as maxima), 31 unused
@@ -132,6 +136,7 @@ struct GrResCtl {
     uint32_t epoch, n_stream, n_fin;   // n_stream = streams x wgs_frame streaming workgroups, then n_fin finalizers
     uint32_t wgs_frame, streams;   // workgroups one frame needs; frame streams the launch runs side by side (stream s: frames s, s + streams, ...)
     uint32_t team_waves;           // waves of a finalizer workgroup that close one frame together: 1, 2, 4 or 8 with 32 x that >= wgs_frame
+    unsigned long long patience_ticks, start_ticks;   // bounds of the waits in ticks of wall_clock64() (the host knows the rate)
     uint32_t test_abort_frame;     // tests: the finalizer of this frame raises `abort` instead of closing it (0xFFFFFFFF: never)
 };
 
@@ -255,8 +260,9 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
             uint32_t zero = 0u;
             if (n == gridDim.x) (void)__hip_atomic_compare_exchange_strong(ctl.abort + 2, &zero, 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             uint32_t v, polls = 0;
+            const unsigned long long t0 = wall_clock64();
             while ((v = gr_ld_agent(ctl.abort + 2)) == 0u) {
-                if (++polls > GR_RES_START_PATIENCE) { zero = 0u; (void)__hip_atomic_compare_exchange_strong(ctl.abort + 2, &zero, 2u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+                if (++polls > GR_RES_START_PATIENCE || ((polls & 255u) == 0 && wall_clock64() - t0 > ctl.start_ticks)) { zero = 0u; (void)__hip_atomic_compare_exchange_strong(ctl.abort + 2, &zero, 2u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
                 __builtin_amdgcn_s_sleep(16);
             }
             verdict = v;
@@ -294,6 +300,7 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
             const unsigned long long *src = ctl.wgrec + ((size_t)f * n_pad + r) * GR_RES_REC_WORDS + part * W;
             unsigned long long w[W];
             uint32_t polls = 0;
+            const unsigned long long t0 = wall_clock64();
             if (live && f == ctl.test_abort_frame) { if (lane == 0) { gr_st_agent(ctl.abort, 1u); __hip_atomic_store(gave_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } polls = 0xFFFFFFFFu; }
             while (polls != 0xFFFFFFFFu) {
                 bool ok = true;
@@ -304,7 +311,7 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
                     for (uint32_t k = 0; k < W; ++k) ok = ok && ((uint32_t)(w[k] >> 32) == ctl.epoch || part * W + k == 31u);
                 }
                 if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
-                if (++polls > GR_RES_PATIENCE || ((polls & 255u) == 0 && gr_ld_agent(ctl.abort) != 0u)) {
+                if (++polls > GR_RES_PATIENCE || ((polls & 255u) == 0 && (gr_ld_agent(ctl.abort) != 0u || wall_clock64() - t0 > ctl.patience_ticks))) {
                     if (lane == 0) { gr_st_agent(ctl.abort, 1u); __hip_atomic_store(gave_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
                     polls = 0xFFFFFFFFu;
                     break;
@@ -637,9 +644,11 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
     // ---- the fit stage of frame j: `rv` = the frame's record as requested earlier (lanes 0..15); rows / image vectors as they were parked.
     auto fit = [&](uint32_t j, unsigned long long rv, const Rows &ra, const Rows &rb, const GrBoxU &B) {
         uint32_t polls = 0;
+        unsigned long long t0 = 0ull;
         while (__builtin_amdgcn_ballot_w64(lane < 16u && (uint32_t)(rv >> 32) != ctl.epoch) != 0ull) {
             __builtin_amdgcn_s_setprio(0);                             // a wave that is ahead waits below the waves it shares the SIMD with
-            if (++polls > GR_RES_PATIENCE || ((polls & 255u) == 0 && gr_ld_agent(ctl.abort) != 0u)) { if (lane == 0) gr_st_agent(ctl.abort, 1u); bail = true; return; }
+            if (polls == 0) t0 = wall_clock64();                       // (only a wave that has to wait reads the clock)
+            if (++polls > GR_RES_PATIENCE || ((polls & 255u) == 0 && (gr_ld_agent(ctl.abort) != 0u || wall_clock64() - t0 > ctl.patience_ticks))) { if (lane == 0) gr_st_agent(ctl.abort, 1u); bail = true; return; }
             __builtin_amdgcn_s_sleep(GR_RES_SLEEP);
             rv = request_rec(j);
         }

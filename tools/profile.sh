@@ -10,11 +10,12 @@ OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $REPO/bench.py $ARGS > $OUT/trace.log 2>&1
+timeout -k 10 ${PASS_TIMEOUT:-240} rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $REPO/bench.py $ARGS > $OUT/trace.log 2>&1
 echo "trace rc=$?"
 for C in FETCH_SIZE WRITE_SIZE "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" "TCC_HIT_sum TCC_MISS_sum" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SALU SQ_INST_CYCLES_VMEM" ; do
   N=$(echo $C | tr ' ' '_' | cut -c1-40)
-  rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_$N -- python3 $REPO/bench.py $ARGS > $OUT/pmc_$N.log 2>&1
+  # (a pass that hangs -- seen with rocprofv3 --pmc around the frame generator's largest launches -- must not take the others with it)
+  timeout -k 10 ${PASS_TIMEOUT:-240} rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_$N -- python3 $REPO/bench.py $ARGS > $OUT/pmc_$N.log 2>&1
   echo "pmc $N rc=$?"
 done
 python3 $REPO/tools/pmc_summary.py $OUT $OUT/$TAG
