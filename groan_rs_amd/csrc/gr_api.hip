@@ -247,6 +247,22 @@ static bool resident_prepare() {
     return ok;
 }
 
+// waves of a finalizer workgroup that close one frame together (gr_resident.h, "teams"): enough for the frame's records (32 per
+// wave), and no more frames per workgroup and round than there are streams -- the frames of a round are closed together, so they
+// must be frames that become ready together (the same turn of different streams): frames of ONE stream in a round would hold the
+// earlier one back until the later one's sums exist, and 7 or more of them would wait for each other for ever (a stream runs 6
+// frames ahead)
+static uint32_t resident_team_waves(uint32_t wgs, uint32_t streams) {
+    uint32_t tw = wgs <= 32 ? 1u : wgs <= 64 ? 2u : wgs <= 128 ? 4u : 8u;
+    while (GrResShape::WAVES / tw > streams) tw *= 2u;
+    return tw;
+}
+static uint32_t resident_finalizers_needed(uint32_t wgs, uint32_t streams) {
+    if (streams <= 1) return 2;
+    const uint32_t teams = GrResShape::WAVES / resident_team_waves(wgs, streams);
+    return std::min<uint32_t>(GR_RES_MAX_FIN, (4u * streams + teams - 1u) / teams);
+}
+
 // Workgroups per frame of the resident RMSD-fit pass (gr_resident.h) and the number of frame streams the launch runs side by
 // side (*streams), or 0 when the two-pass path takes the segment: streams x workgroups must fit the device beside at least two
 // finalizer workgroups, and -- unless forced -- fill most of the chip: a launch that leaves CUs idle streams slower than the
@@ -262,6 +278,10 @@ uint32_t resident_wgs(gr_ctx *c, bool lite, uint32_t nb, const GrSel &sel, uint3
     // launches (tests) stay with one stream unless GR_TUNE_RESIDENT_STREAMS asks for more.
     uint64_t s_max = c->res_streams ? (uint64_t)c->res_streams : (c->resident == 1 ? (uint64_t)GR_RES_MAX_STREAMS : 1u);
     s_max = std::min<uint64_t>(s_max, std::min<uint64_t>(c->res_max_wgs - 2, GR_MAX_CHUNKS) / wgs);   // (res_progress holds GR_MAX_CHUNKS workgroups)
+    // ... and the streams must leave the finalizers they need: a finalizer workgroup closes `teams` frames in ~15 us while the
+    // streams deliver one frame each per ~5 us turn, so 4 S / teams workgroups keep up with a margin (measured without this rule:
+    // 23 streams of 45 000 atoms squeezed the finalizers down to 3 and ran 20 % SLOWER than the two passes)
+    while (s_max > 1 && s_max * wgs + resident_finalizers_needed((uint32_t)wgs, (uint32_t)s_max) > c->res_max_wgs) s_max--;
     if (c->resident == 1) s_max = std::min<uint64_t>(s_max, nb / 16u);
     else s_max = std::min<uint64_t>(s_max, nb);
     // the pass costs the same per turn whatever the frame's size (every CU runs its 4096 atoms' worth or idles): it only beats
@@ -1647,15 +1667,7 @@ static int segment_begin(gr_rmsd_plan *p, uint32_t s0, uint32_t nb, int fit) {
             GrResCtl ctl;
             ctl.wgrec = c->res_wgrec; ctl.rec = c->res_rec; ctl.abort = c->res_abort; ctl.progress = c->res_progress; ctl.epoch = ++c->res_epoch; ctl.n_stream = res_stream; ctl.n_fin = n_fin;
             ctl.wgs_frame = res_wgs; ctl.streams = res_streams;
-            // waves per finalizer team: enough for the frame's records (32 per wave), and no more frames per finalizer workgroup and
-            // round than there are streams -- the frames of a round are closed together, so they must be frames that become ready
-            // together (the same turn of different streams): frames of ONE stream in a round would hold the earlier one back until
-            // the later one's sums exist, and 7 or more of them would wait for each other for ever (the stream runs 6 frames ahead)
-            {
-                uint32_t tw = res_wgs <= 32 ? 1u : res_wgs <= 64 ? 2u : res_wgs <= 128 ? 4u : 8u;
-                while (GrResShape::WAVES / tw > res_streams) tw *= 2u;
-                ctl.team_waves = tw;
-            }
+            ctl.team_waves = resident_team_waves(res_wgs, res_streams);
             ctl.patience_ticks = (unsigned long long)c->wall_khz * 3000ull; ctl.start_ticks = (unsigned long long)c->wall_khz * 200ull;   // 3 s, 0.2 s
             ctl.test_abort_frame = c->res_test_abort_at; c->res_test_abort_at = 0xFFFFFFFFu;
             float *frames = c->frames; size_t stride = c->frame_stride; uint32_t slot0 = s0, nfr = nb, natoms = (uint32_t)c->n;
