@@ -85,6 +85,7 @@ struct gr_ctx {
     // resident RMSD fit (gr_resident.h): one launch per segment, the frame waits on chip for its rotation
     int resident = 1;                 // GR_TUNE_RESIDENT 0 never, 1 when the frame fills the chip, 2 whenever it fits (tests)
     int pd_sym = 1;                   // GR_TUNE_PAIRDIST_SYMMETRIC: the pair matrix of a selection with itself computes one triangle and mirrors it
+    int res_wg_groups = 0;            // GR_TUNE_RESIDENT_WG_GROUPS 0: automatic, 64 .. 1024 (multiple of 64): 4-atom groups per streaming workgroup
     int res_streams = 0;              // GR_TUNE_RESIDENT_STREAMS 0 automatic, 1..GR_RES_MAX_STREAMS: at most so many frame streams per resident launch
     int res_fill16 = 10;              // GR_TUNE_RESIDENT_FILL: sixteenths of the chip the streaming workgroups must fill for the pass to be chosen (resident = 1)
     uint32_t res_last_streams = 0;    // frame streams of the last resident launch (gr_ctx_stat)
@@ -267,11 +268,14 @@ static uint32_t resident_finalizers_needed(uint32_t wgs, uint32_t streams) {
 // side (*streams), or 0 when the two-pass path takes the segment: streams x workgroups must fit the device beside at least two
 // finalizer workgroups, and -- unless forced -- fill most of the chip: a launch that leaves CUs idle streams slower than the
 // two-pass kernels, which spread every frame over all of them.
-uint32_t resident_wgs(gr_ctx *c, bool lite, uint32_t nb, const GrSel &sel, uint32_t *streams) {
-    *streams = 1;
+uint32_t resident_wgs(gr_ctx *c, bool lite, uint32_t nb, const GrSel &sel, uint32_t *streams, uint32_t *groups_wg) {
+    *streams = 1; *groups_wg = GR_RES_GROUPS;
     if (!lite || !c->resident || !c->res_max_wgs) return 0;
     const uint64_t groups = ((c->n + 255) >> 8) << 6;
-    const uint64_t wgs = (groups + GR_RES_GROUPS - 1) / GR_RES_GROUPS;   // (a workgroup owns 1024 groups whatever the groups per lane)
+    // groups per workgroup (GR_TUNE_RESIDENT_WG_GROUPS; 0: 1024, two per lane)
+    const uint64_t gwg = c->res_wg_groups ? (uint64_t)c->res_wg_groups : (uint64_t)GR_RES_GROUPS;
+    const uint64_t wgs = (groups + gwg - 1) / gwg;
+    *groups_wg = (uint32_t)gwg;
     if (wgs + 2 > c->res_max_wgs || wgs > GR_MAX_CHUNKS) return 0;
     // frames that fill less than half of the chip: several of them in flight side by side, each on its own share of the CUs (at
     // least two finalizer workgroups however many streams; a segment gives every stream 16 frames or more, see below).  Forced
@@ -1555,6 +1559,7 @@ int gr_ctx_set_tuning(gr_ctx *c, int key, int64_t value) try {
     case GR_TUNE_TWO_PASS: c->two_pass = value ? 1 : 0; return GR_OK;
     case GR_TUNE_RESIDENT: if (value < 0 || value > 2) break; c->resident = value; return GR_OK;
     case GR_TUNE_PAIRDIST_SYMMETRIC: if (value != 0 && value != 1) break; c->pd_sym = (int)value; return GR_OK;
+    case GR_TUNE_RESIDENT_WG_GROUPS: if (value != 0 && (value < 64 || value > GR_RES_GROUPS || value % 64 != 0)) break; c->res_wg_groups = (int)value; return GR_OK;
     case GR_TUNE_RESIDENT_STREAMS: if (value < 0 || value > GR_RES_MAX_STREAMS) break; c->res_streams = (int)value; return GR_OK;
     case GR_TUNE_RESIDENT_FILL: if (value < 1 || value > 16) break; c->res_fill16 = (int)value; return GR_OK;
     case GR_TUNE_RESIDENT_GROUPS: if (value != 2) break; return GR_OK;   // (the one-group shape was removed: gr_resident.h)
@@ -1642,8 +1647,8 @@ static int segment_begin(gr_rmsd_plan *p, uint32_t s0, uint32_t nb, int fit) {
         const bool fused = lite && c->fuse;   // the finalize rides on the tail of the sums kernel
         q.fused = fused;
         hipStream_t S = c->stream;
-        uint32_t res_streams = 1;
-        uint32_t res_wgs = resident_wgs(c, lite, nb, sel, &res_streams);   // workgroups per frame x frame streams
+        uint32_t res_streams = 1, res_gwg = GR_RES_GROUPS;
+        uint32_t res_wgs = resident_wgs(c, lite, nb, sel, &res_streams, &res_gwg);   // workgroups per frame x frame streams
         if (res_wgs && !resident_acquire(c->device)) res_wgs = 0;
         if (res_wgs) c->res_in_use = true;           // (released in segment_end, or by the caller when this function fails)
         if (res_wgs) {
@@ -1666,7 +1671,7 @@ static int segment_begin(gr_rmsd_plan *p, uint32_t s0, uint32_t nb, int fit) {
             }
             GrResCtl ctl;
             ctl.wgrec = c->res_wgrec; ctl.rec = c->res_rec; ctl.abort = c->res_abort; ctl.progress = c->res_progress; ctl.epoch = ++c->res_epoch; ctl.n_stream = res_stream; ctl.n_fin = n_fin;
-            ctl.wgs_frame = res_wgs; ctl.streams = res_streams;
+            ctl.wgs_frame = res_wgs; ctl.streams = res_streams; ctl.groups_wg = res_gwg;
             ctl.team_waves = resident_team_waves(res_wgs, res_streams);
             ctl.patience_ticks = (unsigned long long)c->wall_khz * 3000ull; ctl.start_ticks = (unsigned long long)c->wall_khz * 200ull;   // 3 s, 0.2 s
             ctl.test_abort_frame = c->res_test_abort_at; c->res_test_abort_at = 0xFFFFFFFFu;

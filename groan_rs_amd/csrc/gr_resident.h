@@ -110,7 +110,7 @@ struct GrResShape {
 #ifndef GR_RES_BAL
 #define GR_RES_BAL 1               // priority by progress relative to the wave's SIMD partner (the wave that is behind runs first); 0: A/B only
 #endif
-#define GR_RES_GROUPS 1024         // 4-atom groups per workgroup
+#define GR_RES_GROUPS 1024         // 4-atom groups per workgroup at most (two per lane)
 #ifndef GR_RES_MAX_FIN
 #define GR_RES_MAX_FIN 16          // finalizer workgroups of a launch with more than 8 frame streams, 8 otherwise (fewer when the streaming workgroups leave fewer CUs)
 #endif
@@ -135,6 +135,7 @@ struct GrResCtl {
     uint32_t *progress;            // [n_stream][8]: turns (frames of its stream) each streaming wave had been through when it left
     uint32_t epoch, n_stream, n_fin;   // n_stream = streams x wgs_frame streaming workgroups, then n_fin finalizers
     uint32_t wgs_frame, streams;   // workgroups one frame needs; frame streams the launch runs side by side (stream s: frames s, s + streams, ...)
+    uint32_t groups_wg;            // 4-atom groups per streaming workgroup: a multiple of 64, 64 .. GR_RES_GROUPS
     uint32_t team_waves;           // waves of a finalizer workgroup that close one frame together: 1, 2, 4 or 8 with 32 x that >= wgs_frame
     unsigned long long patience_ticks, start_ticks;   // bounds of the waits in ticks of wall_clock64() (the host knows the rate)
     uint32_t test_abort_frame;     // tests: the finalizer of this frame raises `abort` instead of closing it (0xFFFFFFFF: never)
@@ -398,14 +399,18 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
     // Frames smaller than half the chip run as several STREAMS side by side: workgroup b belongs to stream b / wgs_frame and owns
     // the atoms of workgroup b % wgs_frame of every frame of its stream (frames s, s + streams, ...): each stream is the pipeline
     // described above on its own share of the CUs, the finalizers serve them all.  `kf(k)` = the frame of the stream's k-th turn.
-    const uint32_t wg_all = blockIdx.x, stream = wg_all / ctl.wgs_frame, wg = wg_all % ctl.wgs_frame, base = wg * GR_RES_GROUPS;
+    // A workgroup owns ctl.groups_wg consecutive groups of the frame -- 1024 (two per lane) when whole frames fill the chip, fewer
+    // (a multiple of 64: whole waves) when a frame cut into 1024s would leave CUs idle: the first 512 are the lanes' groups A, the
+    // rest groups B of the first waves -- one wave per SIMD first, so 768 groups load every SIMD with 3 group-units instead of 4.
+    const uint32_t wg_all = blockIdx.x, stream = wg_all / ctl.wgs_frame, wg = wg_all % ctl.wgs_frame, base = wg * ctl.groups_wg;
+    const uint32_t glimit = min(base + ctl.groups_wg, ngroups);   // one past the workgroup's last group
     const uint32_t n_turns = nframes > stream ? (nframes - stream + ctl.streams - 1u) / ctl.streams : 0u;
     auto kf = [&](uint32_t k) { return stream + k * ctl.streams; };
-    if (base + wave * 64u >= ngroups) {                               // every chunk of this wave lies behind the last tile: nothing to fit
+    if (base + wave * 64u >= glimit) {                                // every chunk of this wave lies behind the workgroup's last group: nothing to fit
         if (lane == 0) ctl.progress[wg_all * WAVES + wave] = n_turns;
         return;
     }
-    const uint32_t n_waves = min(WAVES, (ngroups - base) >> 6);
+    const uint32_t n_waves = min(WAVES, (glimit - base) >> 6);
     float4 *park = smem;
     float *wsum = reinterpret_cast<float *>(smem + S::PARK_F4);
     double *fsum = reinterpret_cast<double *>(wsum + S::WSUM_F);
@@ -430,7 +435,7 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
     // the lane's groups: A = chunk `wave` of the workgroup's first LANES groups, B = the same chunk of its second LANES
     auto setup = [&](uint32_t g, GrResGroup &Gr) {
         const uint32_t i0 = g << 2;
-        Gr.valid = g < ngroups;                                       // wave-uniform
+        Gr.valid = g < glimit;                                        // wave-uniform
         const bool in0 = Gr.valid && (i0 >= first) && (i0 < last), in1 = Gr.valid && (i0 + 1u >= first) && (i0 + 1u < last);
         const bool in2 = Gr.valid && (i0 + 2u >= first) && (i0 + 2u < last), in3 = Gr.valid && (i0 + 3u >= first) && (i0 + 3u < last);
         const bool in_sel = in0 || in1 || in2 || in3, full = in0 && in1 && in2 && in3;

@@ -272,13 +272,17 @@ int gr_rmsd_plan_force_exact(gr_rmsd_plan *plan, int on);
  *                      it is 2; 1 .. 32: at most so many.  Results do not depend on the number of streams.
  *   GR_TUNE_RESIDENT_FILL    sixteenths of the chip (1 .. 16, default 10) the streams of a launch must fill together for
  *                      GR_TUNE_RESIDENT = 1 to choose the pass
+ *   GR_TUNE_RESIDENT_WG_GROUPS  4-atom groups per streaming workgroup of the resident pass: 0 (default) = 1024, two per lane; 64 ..
+ *                      1024 in steps of 64 cuts a frame into more, smaller workgroups.  An experiment's knob: a turn of the pass is
+ *                      bound by instruction issue and latency, not by the work per CU -- 768 groups instead of 1024 gave 5 % at
+ *                      600 000 atoms, where frame streams give 40 % (DESIGN.md "Frame streams").  Same results to rounding.
  *   GR_TUNE_PAIRDIST_SYMMETRIC  1 (default): the all-pairs matrix of a group with ITSELF computes the tiles on and above the
  *                      diagonal and writes each of them twice (the mirror image transposed on chip); 0: every element on its own.
  *                      Same bits either way.
  *   GR_TUNE_RESIDENT_GROUPS  retired (round 3 removed the one-group shape of the resident pass): only the value 2 is accepted
  */
 enum { GR_TUNE_SUB_BATCH = 1, GR_TUNE_CHUNKS = 2, GR_TUNE_FIT_WGS = 3, GR_TUNE_FUSE = 4, GR_TUNE_TWO_PASS = 5, GR_TUNE_RESIDENT = 6, GR_TUNE_RESIDENT_GROUPS = 7,
-       GR_TUNE_RESIDENT_STREAMS = 8, GR_TUNE_RESIDENT_FILL = 9, GR_TUNE_PAIRDIST_SYMMETRIC = 10,
+       GR_TUNE_RESIDENT_STREAMS = 8, GR_TUNE_RESIDENT_FILL = 9, GR_TUNE_PAIRDIST_SYMMETRIC = 10, GR_TUNE_RESIDENT_WG_GROUPS = 11,
        GR_TUNE_TEST_RESIDENT_NO_START = 100 /* tests: the next resident launch behaves as if its workgroups never got onto the chip */,
        GR_TUNE_TEST_RESIDENT_ABORT_AT = 101 /* tests: the next resident launch is aborted from inside when it reaches this frame of its segment (< 0: never) */ };
 int gr_ctx_set_tuning(gr_ctx *ctx, int key, int64_t value);

@@ -146,6 +146,34 @@ def test_frame_streams_do_not_reach_the_results(G, whole):
 
 
 @pytest.mark.parametrize("whole", [False, True])
+def test_workgroups_of_fewer_than_1024_groups_give_the_same_results(G, whole):
+    """a frame that would leave CUs idle when cut into 1024-group workgroups is cut into smaller ones (GR_TUNE_RESIDENT_WG_GROUPS: 576,
+    768, 960 groups -- the lanes' second groups only in the first waves -- and 320: no second groups at all, three idle waves):
+    the per-workgroup partial sums change, the results stay within the tolerance against the two-pass path and the oracle"""
+    n, nf = 41_111, 9
+    box = W.box_from_lengths_angles([7.0, 6.5, 6.0], [75.0, 80.0, 70.0])
+    sel = (0, n - 1) if whole else (700, n - 4)
+    masses, cur, ref, ref_pos, frames = _systems(G, n, nf, box, sel)
+    idx = np.arange(sel[0], sel[1] + 1)
+    with O.acc64():
+        want = [O.calc_rmsd_and_fit(ref_pos, masses, idx, box, frames[f], masses, idx, box) for f in range(nf)]
+    plan = G.RMSDPlan(ref, cur, "S")
+    for gwg, streams in ((1024, 1), (960, 1), (768, 2), (576, 1), (320, 3)):
+        cur.set_tuning(resident=2, resident_streams=streams, resident_wg_groups=gwg)
+        cur.profile_enable(True)
+        for f in range(nf):
+            cur.set_frame(frames[f], box, slot=f)
+        r, st = plan.rmsd_fit(0, nf)
+        assert (st == 0).all() and cur.profile_read()["k_fit_resident"][1] == 1, gwg
+        for f in range(nf):
+            assert abs(float(r[f]) - want[f][0]) <= 1e-5, (gwg, f, float(r[f]), want[f][0])
+            assert np.abs(cur.get_positions(f) - want[f][1]).max() <= 5e-5, (gwg, f)
+    with pytest.raises(Exception):
+        cur.set_tuning(resident_wg_groups=100)          # not a multiple of 64
+    plan.close(); ref.close(); cur.close()
+
+
+@pytest.mark.parametrize("whole", [False, True])
 def test_resident_with_a_different_box_in_every_frame(G, whole):
     """constant-pressure runs: every frame has its own box -> the kernel variant that reads the box per frame"""
     n, nf = 30_000, 9
