@@ -119,30 +119,39 @@ float go_min_image(float dx, float box_len) {
  * Triclinic extension helpers (no reference arithmetic).  Box vectors
  *   a = (v1x,0,0)  b = (v2x,v2y,0)  c = (v3x,v3y,v3z)
  * Candidate lattice translations that can shorten a vector already reduced to the brick
- * |d.z|<=cz/2, |d.y|<=by/2, |d.x|<=ax/2:  t = i a + j b + k c, i,j,k in [-8,8] (rounds 1-3: [-2,2], too few for flat cells), with
+ * |d.z|<=cz/2, |d.y|<=by/2, |d.x|<=ax/2:  t = i a + j b + k c with
  *   |t.x| ax + |t.y| by + |t.z| cz > |t|^2     (otherwise |d+t| >= |d| for every d in the brick).
  * ------------------------------------------------------------------------------------------ */
-#define TRIC_R 8        /* |i|, |j|, |k| <= 8: every candidate has |t| < the brick's diagonal; flatter cells than that are refused */
-typedef struct { int n; float t[(2 * TRIC_R + 1) * (2 * TRIC_R + 1) * (2 * TRIC_R + 1)][3]; } tric_cand;
+#define TRIC_MAX 1024   /* candidates kept (both signs); cells flat enough to need more are not used by any test */
+typedef struct { int n; float t[TRIC_MAX][3]; } tric_cand;
 
+/* every candidate satisfies |t|^2 < |t.x| ax + |t.y| by + |t.z| cz <= |t| D (D = the brick's diagonal), so |t| < D: the loops
+ * visit exactly the (k, j, i) that can reach that ball (rounds 1-3 visited -2 .. 2 whatever the cell: too few for flat cells) */
 static void tric_candidates(const float *b, tric_cand *c) {
     c->n = 0;
-    for (int k = -TRIC_R; k <= TRIC_R; ++k)
-        for (int j = -TRIC_R; j <= TRIC_R; ++j)
-            for (int i = -TRIC_R; i <= TRIC_R; ++i) {
+    const double ax = V1X(b), by = V2Y(b), cz = V3Z(b);
+    const double D = sqrt(ax * ax + by * by + cz * cz);
+    const int kmax = (int)floor(D / cz);
+    for (int k = -kmax; k <= kmax; ++k) {
+        const double tz = (double)k * cz, cyk = (double)k * V3Y(b), cxk = (double)k * V3X(b);
+        const int jlo = (int)ceil((-D - cyk) / by), jhi = (int)floor((D - cyk) / by);
+        for (int j = jlo; j <= jhi; ++j) {
+            const double ty = (double)j * by + cyk, x0 = (double)j * V2X(b) + cxk;
+            const int ilo = (int)ceil((-D - x0) / ax), ihi = (int)floor((D - x0) / ax);
+            for (int i = ilo; i <= ihi; ++i) {
                 if (!i && !j && !k) continue;
-                double tx = (double)i * V1X(b) + (double)j * V2X(b) + (double)k * V3X(b);
-                double ty = (double)j * V2Y(b) + (double)k * V3Y(b);
-                double tz = (double)k * V3Z(b);
-                double lhs = fabs(tx) * V1X(b) + fabs(ty) * V2Y(b) + fabs(tz) * V3Z(b);
+                const double tx = (double)i * ax + x0;
+                double lhs = fabs(tx) * ax + fabs(ty) * by + fabs(tz) * cz;
                 double t2 = tx * tx + ty * ty + tz * tz;
-                if (lhs > t2 * (1.0 + 1e-6)) {
+                if (lhs > t2 * (1.0 + 1e-6) && c->n < TRIC_MAX) {
                     c->t[c->n][0] = (float)tx;
                     c->t[c->n][1] = (float)ty;
                     c->t[c->n][2] = (float)tz;
                     c->n++;
                 }
             }
+        }
+    }
 }
 
 /* pick the shortest of d and d + t over the candidate set (strictly shorter only) */
