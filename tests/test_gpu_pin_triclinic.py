@@ -253,6 +253,9 @@ FLAT_CELLS = {
     "flat_b": [20.0702, 24.0458, 2.42171, 0, 0, -8.9196, 0, -6.97267, -6.8196],
     "flat_on_the_limits": [7.0228, 23.7485, 2.67607, 0, 0, 3.5114, 0, 3.5114, 11.8743],
     "mildly_flat": [12.0, 11.0, 5.0, 0, 0, 3.0, 0, -4.0, 4.5],
+    # 14 / 16 entries that do NOT fit the (t, t + a) pair layout with its pads: the searches take every dot product (cand_pairs = 0)
+    "unpaired_14": [14.4384, 13.3817, 2.28351, 0, 0, 1.70626, 0, 0.773115, 4.72202],
+    "unpaired_16": [12.7645, 23.762, 4.77463, 0, 0, -4.08967, 0, 4.0417, -5.41221],
 }
 
 
@@ -276,7 +279,7 @@ def test_flat_cells_are_exact_or_refused(G, cell):
         d_ab = s.group_all_distances("A", "B", G.Dimension.XYZ)
     except G.DeviceError as e:
         assert "skewed" in str(e), e
-        assert cell != "mildly_flat"            # (8 +- pairs: must be supported)
+        assert cell not in ("mildly_flat", "unpaired_14", "unpaired_16")            # (<= 16 +- pairs: must be supported)
         s.close()
         return
     ks = np.array(list(itertools.product(range(-7, 8), repeat=3)), np.float64) @ L                # 3375 images
