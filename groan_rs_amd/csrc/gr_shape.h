@@ -54,7 +54,7 @@ GR_HD float gr_prism_sign(float u1, float v1, float u2, float v2, float u3, floa
 // (non-periodic) body anchored at its position -- which is what the orthorhombic arithmetic of the reference computes for its
 // boxes, where "some image" can be found per axis (`if d < 0 { d += L }`).  In a triclinic cell the lattice vectors couple the
 // axes, so the images are enumerated: the difference to the anchor is reduced into the brick about it (k = rint(d / L) along
-// c, b, a) and the 125 images i a + j b + k c, |i|,|j|,|k| <= 2, around it are tested (the shapes are smaller than the cell).
+// c, b, a) and the images i a + j b + k c around it that the body can reach are tested (see gr_shape_inside_tric).
 // The boundary conventions are the PBC variants' (Rectangular and Cylinder closed, the prism's height half-open).  Every
 // operation is rounded on its own, in this order, on the device and in the oracle alike.
 GR_HD bool gr_shape_free_inside(const GrShapeDev &s, float ex, float ey, float ez) {
@@ -92,14 +92,36 @@ GR_HD bool gr_shape_inside_tric(const GrShapeDev &s, float x, float y, float z, 
     dx = dx - k * b.bx; dy = dy - k * b.by;
     k = rintf(dx / b.ax);
     dx = dx - k * b.ax;
-    for (int kc = -2; kc <= 2; ++kc)
-        for (int kb = -2; kb <= 2; ++kb)
-            for (int ka = -2; ka <= 2; ++ka) {
+    // Which images: every point of the body lies within its REACH of the anchor (rectangle: its diagonal; cylinder: |(radius,
+    // height)|; prism: height + the longer base edge from the anchor), and the brick-reduced difference is at most half the
+    // brick's diagonal long, so only lattice vectors with |t| <= T = reach + D / 2 can bring the point inside: the loops visit the
+    // (k, j, i) whose components can stay below T -- 3 x 5 x 5 or fewer for bodies smaller than an ordinary cell, as many as it
+    // takes in a flat one (rounds 1-3 visited |i|, |j|, |k| <= 2 whatever the cell and the body).
+    double reach;
+    if (s.kind == GR_SH_RECTANGULAR) reach = sqrt((double)s.a * s.a + (double)s.b * s.b + (double)s.c * s.c);
+    else if (s.kind == GR_SH_CYLINDER) reach = sqrt((double)s.a * s.a + (double)s.b * s.b);
+    else {
+        const double e2 = ((double)s.b2x - s.px) * ((double)s.b2x - s.px) + ((double)s.b2y - s.py) * ((double)s.b2y - s.py) + ((double)s.b2z - s.pz) * ((double)s.b2z - s.pz);
+        const double e3 = ((double)s.b3x - s.px) * ((double)s.b3x - s.px) + ((double)s.b3y - s.py) * ((double)s.b3y - s.py) + ((double)s.b3z - s.pz) * ((double)s.b3z - s.pz);
+        reach = (double)s.a + sqrt(e2 > e3 ? e2 : e3);
+    }
+    const double T = (reach + 0.5 * sqrt((double)b.ax * b.ax + (double)b.by * b.by + (double)b.cz * b.cz)) * (1.0 + 1e-6);
+    const double ia = 1.0 / b.ax, ib = 1.0 / b.by, ic = 1.0 / b.cz;    // (the bounds are generous by 1e-6 T: no division per level needed)
+    const int kmax = (int)floor(T * ic);
+    for (int kc = -kmax; kc <= kmax; ++kc) {
+        const double cyk = (double)kc * b.cy, cxk = (double)kc * b.cx;
+        const int jlo = (int)ceil((-T - cyk) * ib), jhi = (int)floor((T - cyk) * ib);
+        for (int kb = jlo; kb <= jhi; ++kb) {
+            const double x0 = (double)kb * b.bx + cxk;
+            const int ilo = (int)ceil((-T - x0) * ia), ihi = (int)floor((T - x0) * ia);
+            for (int ka = ilo; ka <= ihi; ++ka) {
                 const float tx = ((float)ka * b.ax + (float)kb * b.bx) + (float)kc * b.cx;
                 const float ty = (float)kb * b.by + (float)kc * b.cy;
                 const float tz = (float)kc * b.cz;
                 if (gr_shape_free_inside(s, dx + tx, dy + ty, dz + tz)) return true;
             }
+        }
+    }
     return false;
 }
 

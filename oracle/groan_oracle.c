@@ -957,7 +957,7 @@ static float prism_sign(const float p1[3], const float p2[3], const float p3[3],
 static float box_len(const float *b, int dim) { return dim == GO_DIM_X ? V1X(b) : (dim == GO_DIM_Y ? V2Y(b) : V3Z(b)); }
 
 /* Non-orthogonal boxes (extension, same definition as groan_rs_amd/csrc/gr_shape.h: SOME lattice image of the point lies inside
- * the shape taken as a plain body anchored at its position; images = 125 around the brick-reduced difference).  Operation by
+ * the shape taken as a plain body anchored at its position; images = those the body can reach from the brick-reduced difference).  Operation by
  * operation the device code's arithmetic (this file is built with -ffp-contract=off). */
 static int shape_free_inside(const go_shape *s, float ex, float ey, float ez) {
     switch (s->kind) {
@@ -995,14 +995,35 @@ static int shape_inside_tric(const go_shape *s, const float pt[3], const float *
     dx = dx - k * V2X(b); dy = dy - k * V2Y(b);
     k = rintf(dx / V1X(b));
     dx = dx - k * V1X(b);
-    for (int kc = -2; kc <= 2; ++kc)
-        for (int kb = -2; kb <= 2; ++kb)
-            for (int ka = -2; ka <= 2; ++ka) {
+    /* the images the body can reach: |t| <= reach + half the brick's diagonal (gr_shape.h, gr_shape_inside_tric) */
+    double reach;
+    if (s->kind == GO_SHAPE_RECTANGULAR) reach = sqrt((double)s->size[0] * s->size[0] + (double)s->size[1] * s->size[1] + (double)s->size[2] * s->size[2]);
+    else if (s->kind == GO_SHAPE_CYLINDER) reach = sqrt((double)s->size[0] * s->size[0] + (double)s->size[1] * s->size[1]);
+    else {
+        double e2 = 0.0, e3 = 0.0;
+        for (int a = 0; a < 3; ++a) {
+            e2 += ((double)s->base2[a] - s->position[a]) * ((double)s->base2[a] - s->position[a]);
+            e3 += ((double)s->base3[a] - s->position[a]) * ((double)s->base3[a] - s->position[a]);
+        }
+        reach = (double)s->size[0] + sqrt(e2 > e3 ? e2 : e3);
+    }
+    const double T = (reach + 0.5 * sqrt((double)V1X(b) * V1X(b) + (double)V2Y(b) * V2Y(b) + (double)V3Z(b) * V3Z(b))) * (1.0 + 1e-6);
+    const double ia = 1.0 / V1X(b), ib = 1.0 / V2Y(b), ic = 1.0 / V3Z(b);
+    const int kmax = (int)floor(T * ic);
+    for (int kc = -kmax; kc <= kmax; ++kc) {
+        const double cyk = (double)kc * V3Y(b), cxk = (double)kc * V3X(b);
+        const int jlo = (int)ceil((-T - cyk) * ib), jhi = (int)floor((T - cyk) * ib);
+        for (int kb = jlo; kb <= jhi; ++kb) {
+            const double x0 = (double)kb * V2X(b) + cxk;
+            const int ilo = (int)ceil((-T - x0) * ia), ihi = (int)floor((T - x0) * ia);
+            for (int ka = ilo; ka <= ihi; ++ka) {
                 const float tx = ((float)ka * V1X(b) + (float)kb * V2X(b)) + (float)kc * V3X(b);
                 const float ty = (float)kb * V2Y(b) + (float)kc * V3Y(b);
                 const float tz = (float)kc * V3Z(b);
                 if (shape_free_inside(s, dx + tx, dy + ty, dz + tz)) return 1;
             }
+        }
+    }
     return 0;
 }
 

@@ -132,7 +132,9 @@ def test_random_shapes_on_synthetic_systems(G, seed):
 
 
 TRIC_CELLS = {"triclinic_75_80_70": ([7.0, 6.5, 6.0], [75.0, 80.0, 70.0]), "dodecahedron": ([6.0, 6.0, 6.0], [60.0, 60.0, 90.0]),
-              "octahedron": ([6.0, 6.0, 6.0], [70.53, 109.47, 70.53]), "skewed_negative": ([6.5, 7.5, 6.0], [100.0, 95.0, 110.0])}
+              "octahedron": ([6.0, 6.0, 6.0], [70.53, 109.47, 70.53]), "skewed_negative": ([6.5, 7.5, 6.0], [100.0, 95.0, 110.0]),
+              # a flat cell, given as the box itself: the images a body can reach include |k| = 3 (rounds 1-3 tested |i|, |j|, |k| <= 2 only)
+              "flat": np.array([12.0, 11.0, 3.5, 0, 0, 3.0, 0, -4.0, 4.5], np.float32)}
 
 
 @pytest.mark.parametrize("cell", sorted(TRIC_CELLS))
@@ -143,8 +145,7 @@ def test_shapes_in_non_orthogonal_boxes(G, cell):
     definition, and -- independently of both -- equal to an fp64 search over 7 x 7 x 7 lattice images for every atom that is
     not within 2e-5 nm of a shape's surface."""
     from groan_rs_amd import workload as W
-    lengths, angles = TRIC_CELLS[cell]
-    box = W.box_from_lengths_angles(lengths, angles)
+    box = TRIC_CELLS[cell] if cell == "flat" else W.box_from_lengths_angles(*TRIC_CELLS[cell])
     L = np.array([[box[0], 0, 0], [box[5], box[1], 0], [box[7], box[8], box[2]]], np.float64)
     rng = np.random.default_rng(len(cell) * 7 + 5)
     n = 30000
@@ -159,7 +160,8 @@ def test_shapes_in_non_orthogonal_boxes(G, cell):
     shapes = [G.Sphere(specs[0]["position"], 1.7), G.Rectangular(specs[1]["position"], 2.5, 1.5, 2.0),
               G.Cylinder(specs[2]["position"], 1.4, 2.5, G.Dimension.Z), G.Cylinder(specs[3]["position"], 1.1, 3.0, G.Dimension.X),
               G.TriangularPrism(specs[4]["base1"], specs[4]["base2"], specs[4]["base3"], 2.2)]
-    images = np.array([(i, j, k) for i in range(-3, 4) for j in range(-3, 4) for k in range(-3, 4)], np.float64) @ L
+    R = 5 if cell == "flat" else 3
+    images = np.array([(i, j, k) for i in range(-R, R + 1) for j in range(-R, R + 1) for k in range(-R, R + 1)], np.float64) @ L
     for spec, shape in zip(specs, shapes):
         for src, idx in (("all", np.arange(n)), ("Odd", np.arange(1, n, 2))):
             s.group_create_from_geometry("Sel", src, shape)
@@ -172,8 +174,9 @@ def test_shapes_in_non_orthogonal_boxes(G, cell):
             continue
         anchor = np.asarray(spec["position"], np.float64)
         inside = np.zeros(n, bool); near = np.zeros(n, bool)
-        for a0 in range(0, n, 2000):
-            e = pos[a0:a0 + 2000, None, :].astype(np.float64) - anchor + images[None, :, :]
+        step = 500 if cell == "flat" else 2000
+        for a0 in range(0, n, step):
+            e = pos[a0:a0 + step, None, :].astype(np.float64) - anchor + images[None, :, :]
             # vectorised per shape kind
             if spec["kind"] == "sphere":
                 r = np.linalg.norm(e, axis=2); ins = r < spec["radius"]; dist = np.abs(r - spec["radius"])
@@ -183,7 +186,7 @@ def test_shapes_in_non_orthogonal_boxes(G, cell):
                 ax = "xyz".index(spec["orientation"].lower())
                 along = e[:, :, ax]; planar = np.linalg.norm(np.delete(e, ax, axis=2), axis=2)
                 m = np.minimum(np.minimum(along, spec["height"] - along), spec["radius"] - planar); ins = m >= 0; dist = np.abs(m)
-            inside[a0:a0 + 2000] = ins.any(axis=1); near[a0:a0 + 2000] = (dist.min(axis=1) < 2e-5)
+            inside[a0:a0 + step] = ins.any(axis=1); near[a0:a0 + step] = (dist.min(axis=1) < 2e-5)
         s.group_create_from_geometry("Sel", "all", shape)
         got = np.zeros(n, bool); got[members(s, "Sel")] = True
         assert np.array_equal(got[~near], inside[~near]), (cell, spec["kind"], int((got[~near] != inside[~near]).sum()))
