@@ -116,3 +116,40 @@ def test_self_matrix_batch(G):
     assert np.array_equal(res[0].view(np.uint32), res[1].view(np.uint32))
     np.testing.assert_allclose(res[1][3], O.group_all_distances(frames[3], np.arange(n), np.arange(n), "xyz", boxes[3]), atol=2e-6, rtol=0)
     s.close()
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_cells_and_sizes(G, seed):
+    """random GROMACS-reduced cells (|bx| <= ax/2, |cx| <= ax/2, |cy| <= by/2; some flat, some on the limits), random sizes: the
+    symmetric kernel gives the bits of the plain one in every Dimension, XYZ agrees with the oracle (whose image table is checked
+    against an fp64 lattice search in the CPU suite); cells too skewed for the table are refused by both"""
+    rng = np.random.default_rng(900 + seed)
+    ax, by, cz = rng.uniform(3.0, 9.0, 3)
+    if seed % 3 == 0:
+        cz = rng.uniform(1.2, 2.5)                                   # flat
+    f = rng.uniform(-0.5, 0.5, 3)
+    if seed % 4 == 1:
+        f = np.sign(f) * 0.5                                          # on the limits
+    box = np.array([ax, by, cz, 0, 0, f[0] * ax, 0, f[1] * ax, f[2] * by], np.float32)
+    L = np.array([[box[0], 0, 0], [box[5], box[1], 0], [box[7], box[8], box[2]]], np.float64)
+    n = int(rng.integers(256, 2200))
+    pos = (rng.uniform(-0.2, 1.2, (n, 3)) @ L).astype(np.float32)
+    s = G.System(n, n_slots=1)
+    s.set_frame(pos, box, slot=0)
+    s.group_create_from_ranges("S", [(0, n - 1)])
+    try:
+        a, b = both(G, s, "S", "XYZ")
+    except G.DeviceError as e:
+        assert "skewed" in str(e)
+        s.close()
+        return
+    idx = np.arange(n)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    want = O.group_all_distances(pos, idx, idx, "xyz", box)
+    tol = 3e-6 + 2.5e-7 * float((box[:3].astype(np.float64) ** 2).sum()) / np.maximum(want, 1e-3)   # (length-only search: its stated cancellation error)
+    assert (np.abs(a - want) <= tol).all(), float(np.abs(a - want).max())
+    for dim in ("X", "Z", "XY", "YZ"):
+        a, b = both(G, s, "S", dim)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), dim
+        assert np.array_equal(a, -a.T) if len(dim) == 1 else np.array_equal(a, a.T), dim
+    s.close()
