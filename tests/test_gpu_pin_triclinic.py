@@ -33,6 +33,7 @@ CELLS = {
     "dodecahedron": ([6.0, 6.0, 6.0], [60.0, 60.0, 90.0]),
     "octahedron": ([6.0, 6.0, 6.0], [70.53, 109.47, 70.53]),
     "skewed_negative": ([6.5, 7.5, 6.0], [100.0, 95.0, 110.0]),
+    "flat_60_70_80": ([8.0, 7.0, 3.0], [60.0, 70.0, 80.0]),          # cz = 2.48 nm: images two steps of c away can win (14 table entries)
 }
 
 
