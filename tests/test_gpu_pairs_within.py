@@ -89,13 +89,14 @@ def test_errors(G, example):
 
 
 @pytest.mark.parametrize("lengths,angles,cutoff", [([7.0, 6.5, 6.0], [75.0, 80.0, 70.0], 0.45), ([6.0, 6.0, 6.0], [60.0, 60.0, 90.0], 0.6),
-                                                   ([6.0, 6.0, 6.0], [70.53, 109.47, 70.53], 1.3), ([6.5, 7.5, 6.0], [100.0, 95.0, 110.0], 2.4)])
+                                                   ([6.0, 6.0, 6.0], [70.53, 109.47, 70.53], 1.3), ([6.5, 7.5, 6.0], [100.0, 95.0, 110.0], 2.4),
+                                                   ([8.0, 7.0, 3.0], [60.0, 70.0, 80.0], 0.9)])        # (a flat cell: images two steps of c away)
 def test_pairs_within_in_non_orthogonal_boxes(G, lengths, angles, cutoff):
     """NEXT-2, triclinic cell lists (the reference's CellGrid is orthogonal-only, cellgrid.rs:423): the
     grid lives in fractional coordinates with slabs at least one cut-off thick, the filter is the triclinic minimum-image
     distance.  Pairs identical to the oracle's brute force over all pairs (a pair whose distance is within 2e-6 nm of the
     cut-off may fall on either side: the two sides round the minimum image differently), distances within 2e-6 nm, and the
-    distances themselves checked against an fp64 search over 5 x 5 x 5 lattice images.  Cut-offs from many cells per axis
+    distances themselves checked against an fp64 search over 7 x 7 x 9 lattice images.  Cut-offs from many cells per axis
     down to fewer than three (no cell visited twice)."""
     from groan_rs_amd import workload as W
     box = W.box_from_lengths_angles(lengths, angles)
@@ -116,7 +117,7 @@ def test_pairs_within_in_non_orthogonal_boxes(G, lengths, angles, cutoff):
         assert abs(d - cutoff) <= 2e-6, (key, d)
     common = sorted(set(got) & set(want))
     assert max(abs(got[k] - want[k]) for k in common) <= 2e-6
-    images = np.array([(i, j, k) for i in range(-2, 3) for j in range(-2, 3) for k in range(-2, 3)], np.float64) @ L
+    images = np.array([(i, j, k) for i in range(-3, 4) for j in range(-3, 4) for k in range(-4, 5)], np.float64) @ L
     for a, b in common[:: max(1, len(common) // 300)]:
         d = pos[b].astype(np.float64) - pos[a].astype(np.float64)
         assert abs(np.sqrt(((d[None, :] + images) ** 2).sum(1).min()) - got[(a, b)]) <= 1e-5
