@@ -55,7 +55,9 @@ enum {
     GR_E_GROUP_EXISTS = 11,      /* GroupError::AlreadyExistsWarning                        */
     GR_E_HIP = 12,               /* HIP runtime failure: see gr_last_error                  */
     GR_E_NO_DEVICE = 13,         /* no usable gfx950 device: the library has NO CPU fallback */
-    GR_E_UNSUPPORTED_BOX = 14,   /* box too skewed for the minimum-image candidate table    */
+    GR_E_UNSUPPORTED_BOX = 14,   /* non-orthogonal box that needs more than 16 +- pairs of lattice vectors in the minimum-image table
+                                    (a FLAT cell: one box vector much shorter than the skew of the others); ordinary triclinic,
+                                    dodecahedral and octahedral cells need 4-8.  Refused rather than answered approximately. */
     GR_E_IO = 15,                /* ReadTrajError::FileNotFound / read failure              */
     GR_E_FORMAT = 16,            /* ReadTrajError::NotXtc / FrameNotFound (corrupt stream)  */
     GR_E_INVALID_NAME = 17       /* GroupError::InvalidName (auxiliary.rs:37-51)            */
