@@ -441,6 +441,22 @@ int set_box(gr_ctx *c, uint32_t slot, const float *box9, hipStream_t on = nullpt
     return GR_OK;
 }
 
+// the same box for `n` consecutive slots: one gr_box_setup, n host copies, ONE contiguous H2D copy
+int set_boxes_same(gr_ctx *c, uint32_t first_slot, uint32_t n, const float *box9, hipStream_t on = nullptr) {
+    if (n == 0) return GR_OK;
+    float keep[9];
+    if (box9) memcpy(keep, box9, sizeof keep);                 // (box9 may point into box9_host, which the loop below rewrites)
+    box_fill(c, first_slot, box9 ? keep : nullptr);
+    for (uint32_t f = 1; f < n; ++f) {
+        const uint32_t s = first_slot + f;
+        c->boxes_host[s] = c->boxes_host[first_slot];
+        c->box_status[s] = c->box_status[first_slot]; c->box9_set[s] = c->box9_set[first_slot];
+        if (box9) memcpy(&c->box9_host[9 * (size_t)s], keep, sizeof keep);
+    }
+    HIPCHK(c, hipMemcpyAsync(c->boxes_dev + first_slot, c->boxes_host + first_slot, (size_t)n * sizeof(GrBox), hipMemcpyHostToDevice, on ? on : c->stream));
+    return GR_OK;
+}
+
 // packed-record staging buffers (the C ABI speaks rvec[n], the slots are pair-tiled): allocated on first use, pad atoms zero
 int ensure_staging(gr_ctx *c, float **buf) {
     if (*buf) return GR_OK;
@@ -1118,6 +1134,10 @@ static int geometry_filter(gr_ctx *c, uint32_t slot, const Group &g, const gr_sh
     GrShapeSet set; set.n = (int)ns; set.naive = naive ? 1 : 0;
     for (size_t q = 0; q < ns; ++q) if (!shape_to_dev(shapes[q], naive, &set.s[q])) return fail(c, GR_E_INVALID_ARG, "invalid shape");
     picked.clear();
+    if (!naive)
+        for (size_t q = 0; q < ns; ++q)
+            if (gr_shape_tric_walk(set.s[q], c->boxes_host[slot]) > GR_SHAPE_WALK_MAX)
+                return fail(c, GR_E_UNSUPPORTED_BOX, "the shape reaches more lattice images of this cell than the geometry selection enumerates");
     if (!g.n) return GR_OK;
     const GrSel sel = make_sel(g);
     const size_t words = ((size_t)g.n + 63) / 64;
@@ -1740,7 +1760,10 @@ static int segment_begin(gr_rmsd_plan *p, uint32_t s0, uint32_t nb, int fit) {
     return GR_OK;
 }
 
-static int segment_end(gr_rmsd_plan *p, float *rmsd_out, int *status_out, float *R_out) {
+// `final_states` (optional) receives the frames' closing records as the results below are read from them -- after the exact-path
+// redo of frames whose image proof failed: what a caller that ran this segment on behalf of another one (the redo of an aborted
+// resident launch) needs; c->state_host is scratch that the redo loops overwrite.
+static int segment_end(gr_rmsd_plan *p, float *rmsd_out, int *status_out, float *R_out, std::vector<GrFrameState> *final_states = nullptr) {
     gr_ctx *c = p->target;
     Pending &q = p->pend;
     if (!q.active) return fail(c, GR_E_INVALID_ARG, "no batch in flight");
@@ -1756,6 +1779,7 @@ static int segment_end(gr_rmsd_plan *p, float *rmsd_out, int *status_out, float 
             if (rmsd_out) rmsd_out[f] = NAN;
             if (R_out) for (int k = 0; k < 9; ++k) R_out[9 * (size_t)f + k] = NAN;
         }
+        if (final_states) { final_states->assign(nb, GrFrameState{}); for (uint32_t f = 0; f < nb; ++f) { (*final_states)[f].status = q.pre[f]; (*final_states)[f].err_index = GR_NOIDX; } }
     } else {
         if (!q.has_group) return fail(c, GR_E_INVALID_ARG, "batch state lost");
         const GrSel sel = q.sel;
@@ -1777,7 +1801,7 @@ static int segment_end(gr_rmsd_plan *p, float *rmsd_out, int *status_out, float 
                 const uint32_t s0_again = q.s0, nb_again = q.nb;
                 int st2 = segment_begin(p, s0_again, nb_again, fit_again);
                 if (st2) { p->pend.active = false; resident_done(c); return st2; }
-                return segment_end(p, rmsd_out, status_out, R_out);
+                return segment_end(p, rmsd_out, status_out, R_out, final_states);
             }
             c->res_backoff = 0;
             const uint32_t aborted = words[0];
@@ -1796,8 +1820,15 @@ static int segment_end(gr_rmsd_plan *p, float *rmsd_out, int *status_out, float 
                 HIPCHK(c, hipMemcpy(prog.data(), c->res_progress, prog.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
                 const uint32_t ns = q.res_streams, per = q.res_stream / ns * 8u;
                 std::vector<uint32_t> lo(ns, nb), hi(ns, 0u);
+                // (a wave whose chunk lies behind the workgroup's last group fits nothing and says so with GR_RES_IDLE_WAVE: it must not
+                // count -- as "all turns done" it used to lift hi[s] to the end of the stream, and a frame that the finalizer had
+                // closed but no working wave had reached was then classed as torn instead of untouched)
                 for (uint32_t s = 0; s < ns; ++s)
-                    for (uint32_t k = 0; k < per; ++k) { const uint32_t v = prog[(size_t)s * per + k]; lo[s] = std::min(lo[s], v); hi[s] = std::max(hi[s], v); }
+                    for (uint32_t k = 0; k < per; ++k) {
+                        const uint32_t v = prog[(size_t)s * per + k];
+                        if (v == GR_RES_IDLE_WAVE) continue;
+                        lo[s] = std::min(lo[s], v); hi[s] = std::max(hi[s], v);
+                    }
                 redo.assign(nb, 0); torn.assign(nb, 0);
                 for (uint32_t f = 0; f < nb; ++f) {
                     if (q.pre[f] != GR_OK) continue;
@@ -1834,12 +1865,18 @@ static int segment_end(gr_rmsd_plan *p, float *rmsd_out, int *status_out, float 
                 if (!redo[f0]) { ++f0; continue; }
                 uint32_t f1 = f0;
                 while (f1 < nb && redo[f1]) ++f1;
-                std::vector<float> r2(f1 - f0);
-                std::vector<int> s2(f1 - f0);
+                // The run's results are the nested call's FINAL records (after its own exact-path redo of frames whose image proof
+                // failed), not c->state_host, which that redo overwrites frame by frame.  The nested return value is a per-frame data
+                // error (reported again below, frame by frame) unless the records did not come back: then the device failed.
+                std::vector<GrFrameState> fs2;
                 Pending sub;
                 std::swap(sub, p->pend);                      // (segment_begin / _end work on p->pend)
                 st_redo = segment_begin(p, s0 + f0, f1 - f0, fit);
-                if (st_redo == GR_OK) { (void)segment_end(p, r2.data(), s2.data(), nullptr); for (uint32_t f = f0; f < f1; ++f) res[f] = c->state_host[f - f0]; }
+                if (st_redo == GR_OK) {
+                    const int st_nested = segment_end(p, nullptr, nullptr, nullptr, &fs2);
+                    if (fs2.size() != (size_t)(f1 - f0)) st_redo = st_nested != GR_OK ? st_nested : GR_E_HIP;
+                    else for (uint32_t f = f0; f < f1; ++f) res[f] = fs2[f - f0];
+                } else { p->pend.active = false; resident_done(c); }
                 std::swap(sub, p->pend);
                 c->res_redone_frames += f1 - f0;
                 f0 = f1;
@@ -1850,6 +1887,7 @@ static int segment_end(gr_rmsd_plan *p, float *rmsd_out, int *status_out, float 
         // frames whose single-pass image proof failed are redone on the exact path, one by one
         for (uint32_t f = 0; f < nb; ++f) {
             if (res[f].status != GR_ST_FALLBACK) continue;
+            if (!redo.empty() && redo[f]) continue;          // (closed by the nested segment above, its own fallbacks included)
             p->last_fallbacks++;
             SlotUse use(c, s0 + f);
             int st = state_reset(c, 1); if (st) return st;
@@ -1872,6 +1910,7 @@ static int segment_end(gr_rmsd_plan *p, float *rmsd_out, int *status_out, float 
             if (rmsd_out) rmsd_out[f] = (s == GR_OK) ? res[f].rmsd : NAN;
             if (R_out) for (int k = 0; k < 9; ++k) R_out[9 * (size_t)f + k] = (s == GR_OK) ? res[f].R[k] : NAN;
         }
+        if (final_states) *final_states = res;
     }
     if (first_err != GR_OK) { c->err = first_err_msg; c->err_index = first_err_index; c->counts[0] = first_counts[0]; c->counts[1] = first_counts[1]; }
     return first_err;
@@ -2625,8 +2664,8 @@ int gr_pool_map(gr_pool *p, uint64_t n_frames, gr_pool_body body, void *user, si
 /* ------------------------------------------------------------ frame-sharded map-reduce: one process per GPU, RCCL over xGMI */
 int gr_comm_set_library(const char *path) try {
     if (!path) return GR_E_INVALID_ARG;
-    grn::library_override() = path;
-    return GR_OK;
+    // the library is resolved ONCE per process: an override that arrives after that could not take effect and is refused
+    return grn::library_override_set(path) ? GR_OK : GR_E_INVALID_ARG;
 } catch (...) { return gr_abi_guard(); }
 
 int gr_comm_unique_id(void *id128) try {
@@ -2764,7 +2803,11 @@ int gr_synth_frames(gr_ctx *c, uint32_t ref_slot, uint32_t first_slot, uint32_t 
     st = box_check(c, ref_slot); if (st) return st;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, sync_ingest(c));
-    for (uint32_t f = 0; f < n_frames; ++f) { st = set_box(c, first_slot + f, &c->box9_host[9 * (size_t)ref_slot]); if (st) return st; }
+    // every generated frame carries the reference's box: the table is built ONCE, replicated on the host, and the whole range goes
+    // over in ONE copy.  (Rounds 1-3 queued one 444-byte hipMemcpyAsync per slot -- 9216 back-to-back blit dispatches ahead of the
+    // generator kernels for the 3072-frames-per-step shape; under `rocprofv3 --pmc`, which brackets every dispatch with a counter
+    // read-out, that queue is where the profiled runs stopped: DESIGN.md "The --pmc stall".)
+    st = set_boxes_same(c, first_slot, n_frames, c->box9_set[ref_slot] ? &c->box9_host[9 * (size_t)ref_slot] : nullptr); if (st) return st;
     for (uint32_t f0 = 0; f0 < n_frames; f0 += 1024) {
         const uint32_t nf = std::min<uint32_t>(1024, n_frames - f0);
         k_synth_frames<<<dim3((uint32_t)((c->n + 255) / 256), nf), dim3(256), 0, c->stream>>>(c->frames + (size_t)ref_slot * c->frame_stride, c->frames, c->frame_stride, first_slot + f0, (uint32_t)c->n, c->boxes_dev + ref_slot, first_frame_index + (uint64_t)f0 * frame_index_stride, frame_index_stride, sigma, seed);

@@ -281,6 +281,7 @@ GR_HD float gr_distance(float ax_, float ay_, float az_, float px, float py, flo
 
 // Host-side preparation of a GrBox from the gro-order box9 (simbox.rs:13-26). Returns 0 when the
 // diagonal is not strictly positive / not finite (the reference panics or never terminates there).
+#define GR_BOX_WALK_MAX 2.0e5
 inline int gr_box_setup(const float *box9, GrBox *b) {
     b->valid = 0; b->ncand = 0; b->cand_pairs = 0; b->iax = b->iby = b->icz = 0;
     if (!box9) { b->ax = b->by = b->cz = b->bx = b->cx = b->cy = 0; b->ortho = 1; b->bcx = b->bcy = b->bcz = 0; b->r_ws = 0; return 1; }
@@ -304,7 +305,21 @@ inline int gr_box_setup(const float *box9, GrBox *b) {
     // enumerated -2 .. 2 whatever the cell: flat cells got an incomplete table and silently longer "minimum" images;
     // tests/cpp/test_boxtable.cpp.)  One of each +-t pair: k >= 0, then j >= 0, then i > 0; order k, j, i ascending.
     const double D = sqrt((double)b->ax * b->ax + (double)b->by * b->by + (double)b->cz * b->cz);
-    const int kmax = (int)floor(D / b->cz);
+    int kmax = 0;
+    if (b->ortho) {
+        // an orthorhombic cell has no table and its shortest lattice vector is its shortest edge: no enumeration (a 100 x 0.1 x 0.1 nm
+        // cell would walk millions of lattice points here on every set_box)
+        const double m = fmin((double)b->ax, fmin((double)b->by, (double)b->cz));
+        tmin2 = m * m;
+        kmax = -1;
+    } else {
+        // the walk is bounded: a cell whose brick diagonal spans more than GR_BOX_WALK_MAX lattice points along its axes is far beyond
+        // what the 16-pair table can serve -- refused like any other over-skewed cell instead of enumerated (and no double -> int
+        // conversion of an unbounded quotient)
+        const double nk = D / b->cz + 1.0, nj = 2.0 * D / b->by + 1.0, ni = 2.0 * D / b->ax + 1.0;
+        if (!(nk * nj * ni <= GR_BOX_WALK_MAX)) { overflow = 1; kmax = -1; tmin2 = 0.0; }
+        else kmax = (int)floor(D / b->cz);
+    }
     for (int k = 0; k <= kmax && !overflow; ++k) {
         const double tz = (double)k * b->cz, cyk = (double)k * b->cy, cxk = (double)k * b->cx;
         const int jlo = k == 0 ? 0 : (int)ceil((-D - cyk) / b->by), jhi = (int)floor((D - cyk) / b->by);
@@ -315,7 +330,6 @@ inline int gr_box_setup(const float *box9, GrBox *b) {
                 const double tx = (double)i * b->ax + x0;
                 const double t2 = tx * tx + ty * ty + tz * tz;
                 if (t2 < tmin2) tmin2 = t2;
-                if (b->ortho) continue;
                 const double lhs = fabs(tx) * b->ax + fabs(ty) * b->by + fabs(tz) * b->cz;
                 if (lhs > t2 * (1.0 + 1e-6)) {
                     if (b->ncand < GR_MAX_CAND) {

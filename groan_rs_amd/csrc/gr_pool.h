@@ -16,6 +16,7 @@
 // process first (a host that already loaded RCCL, e.g. through torch.distributed, gets THAT copy: two RCCLs in one process
 // would each claim the GPU's IPC resources), else from librccl.so.1 of the ROCm installation.
 #pragma once
+#include <mutex>
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
@@ -51,12 +52,23 @@ struct Api {
     bool ok = false;
 };
 // the RCCL library a host wants used instead of the default search (gr_comm_set_library, before the first gr_comm_* call)
-inline std::string &library_override() { static std::string s; return s; }
+// (guarded: a setter on one thread and the first gr_comm_* call on another meet here; `resolved` = the table has been built, a later
+// override could not take effect any more and is refused)
+struct LibraryChoice { std::mutex mu; std::string path; bool resolved = false; };
+inline LibraryChoice &library_choice() { static LibraryChoice c; return c; }
+inline bool library_override_set(const char *path) {
+    LibraryChoice &c = library_choice();
+    std::lock_guard<std::mutex> g(c.mu);
+    if (c.resolved) return false;
+    c.path = path;
+    return true;
+}
 inline Api load_api() {
     Api a;
     void *h = RTLD_DEFAULT;
     a.source = "already loaded in the process";
-    const std::string &want = library_override();
+    std::string want;
+    { LibraryChoice &c = library_choice(); std::lock_guard<std::mutex> g(c.mu); c.resolved = true; want = c.path; }
     if (!want.empty() || !dlsym(h, "ncclCommInitRank")) {
         (void)dlerror();                                    // (clear: the text below must belong to OUR failure)
         if (!want.empty()) { h = dlopen(want.c_str(), RTLD_NOW | RTLD_GLOBAL); a.source = want; }

@@ -123,6 +123,7 @@ struct GrResShape {
 // bound in polls alone let a stuck launch sit for minutes.
 #define GR_RES_PATIENCE 30000000u        // polls before a wait gives up whatever the clock says
 #define GR_RES_START_PATIENCE 2000000u   // ... of the start handshake
+#define GR_RES_IDLE_WAVE 0xFFFFFFFFu /* ctl.progress word of a streaming wave without atoms (the ragged last workgroup of a frame) */
 #define GR_ST_ABORTED 102          /* internal: the frame's finalizer gave up (abort): the frame is untouched and is redone on the two-pass path */
 
 #define GR_RES_REC_WORDS 32         // tagged words per workgroup record: 0..18 sums, 19..30 extents (as maxima), 31 unused
@@ -407,7 +408,7 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
     const uint32_t n_turns = nframes > stream ? (nframes - stream + ctl.streams - 1u) / ctl.streams : 0u;
     auto kf = [&](uint32_t k) { return stream + k * ctl.streams; };
     if (base + wave * 64u >= glimit) {                                // every chunk of this wave lies behind the workgroup's last group: nothing to fit
-        if (lane == 0) ctl.progress[wg_all * WAVES + wave] = n_turns;
+        if (lane == 0) ctl.progress[wg_all * WAVES + wave] = GR_RES_IDLE_WAVE;   // (not "all turns done": the host skips this word)
         return;
     }
     const uint32_t n_waves = min(WAVES, (glimit - base) >> 6);

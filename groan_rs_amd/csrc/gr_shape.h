@@ -125,6 +125,24 @@ GR_HD bool gr_shape_inside_tric(const GrShapeDev &s, float x, float y, float z, 
     return false;
 }
 
+// how many lattice images gr_shape_inside_tric visits per point at most (host: a body / cell pair whose walk is unreasonable is
+// refused with GR_E_UNSUPPORTED_BOX instead of enumerated per atom on the device)
+inline double gr_shape_tric_walk(const GrShapeDev &s, const GrBox &b) {
+    if (b.ortho || s.kind == GR_SH_SPHERE) return 1.0;
+    double reach;
+    if (s.kind == GR_SH_RECTANGULAR) reach = sqrt((double)s.a * s.a + (double)s.b * s.b + (double)s.c * s.c);
+    else if (s.kind == GR_SH_CYLINDER) reach = sqrt((double)s.a * s.a + (double)s.b * s.b);
+    else {
+        const double e2 = ((double)s.b2x - s.px) * ((double)s.b2x - s.px) + ((double)s.b2y - s.py) * ((double)s.b2y - s.py) + ((double)s.b2z - s.pz) * ((double)s.b2z - s.pz);
+        const double e3 = ((double)s.b3x - s.px) * ((double)s.b3x - s.px) + ((double)s.b3y - s.py) * ((double)s.b3y - s.py) + ((double)s.b3z - s.pz) * ((double)s.b3z - s.pz);
+        reach = (double)s.a + sqrt(e2 > e3 ? e2 : e3);
+    }
+    const double T = reach + 0.5 * sqrt((double)b.ax * b.ax + (double)b.by * b.by + (double)b.cz * b.cz);
+    if (!(T == T) || !(b.ax > 0.0f && b.by > 0.0f && b.cz > 0.0f)) return 1.0e300;
+    return (2.0 * T / b.cz + 1.0) * (2.0 * T / b.by + 1.0) * (2.0 * T / b.ax + 1.0);
+}
+#define GR_SHAPE_WALK_MAX 4096.0
+
 template <int NC = GR_MAX_CAND>
 GR_HD bool gr_shape_inside_pbc(const GrShapeDev &s, float x, float y, float z, const GrBox &box) {
     if (!box.ortho && s.kind != GR_SH_SPHERE) return gr_shape_inside_tric(s, x, y, z, box);   // (the sphere is the minimum-image distance either way)

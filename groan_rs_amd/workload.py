@@ -56,3 +56,46 @@ def c5_box(d=24.0):
 def blob_radius(box9, frac=0.2):
     """radius of the RMSD-fit blob: 0.2 x the shortest box height (the diagonal of the lower-triangular box matrix)"""
     return frac * float(min(box9[0], box9[1], box9[2]))
+
+
+def box_matrix(box9):
+    """rows = the box vectors a, b, c (gro order -> lower-triangular matrix), float64"""
+    b = np.asarray(box9, np.float64)
+    return np.array([[b[0], 0.0, 0.0], [b[5], b[1], 0.0], [b[7], b[8], b[2]]])
+
+
+def wrap_into_cell(pos, box9):
+    """positions -> the rectangular cell 0 <= x < ax, 0 <= y < by, 0 <= z < cz (shifts along c, then b, then a), float32.
+    Input preparation for synthetic frames: any periodic image is as good as another to the path under test."""
+    L = box_matrix(box9)
+    p = np.array(pos, np.float64)
+    for axis in (2, 1, 0):
+        k = np.floor(p[:, axis] / L[axis, axis])
+        p -= k[:, None] * L[axis][None, :]
+    return p.astype(np.float32)
+
+
+def proof_failing_frame(ref_pos, box9, kind, seed, noise=0.04):
+    """A frame the one-pass RMSD paths must HAND BACK to the literal multi-pass path: the group is wider than half the cell, so no
+    single choice of periodic images about its first atom can be proven to be the reference's (DESIGN.md "Image proof"), while
+    every atom stays well inside the minimum-image cell about the group's centre, so the reference's own answer is stable.
+      "stretched"  the reference blob scaled along x to 0.62 of the cell's a edge
+      "two_lobes"  the blob shrunk to half its size, every third atom moved 0.42 a along x
+    then noise, a rigid translation to anywhere in the cell, and the wrap into the cell (the group arrives PBC-broken)."""
+    rng = np.random.default_rng(seed)
+    p = np.asarray(ref_pos, np.float64)
+    c = p.mean(axis=0)
+    d = p - c
+    ax = float(box9[0])
+    if kind == "stretched":
+        d[:, 0] *= 0.62 * ax / (d[:, 0].max() - d[:, 0].min())
+    elif kind == "two_lobes":
+        d *= 0.5
+        d[::3, 0] += 0.42 * ax
+    else:
+        raise ValueError(kind)
+    frac = d @ np.linalg.inv(box_matrix(box9))
+    assert (frac.max(axis=0) - frac.min(axis=0)).max() > 0.52, "the group does not span half the cell"
+    d += rng.normal(0.0, noise, d.shape)
+    t = rng.uniform(0.0, 1.0, 3) @ box_matrix(box9)
+    return wrap_into_cell(c + d + t, box9)

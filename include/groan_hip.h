@@ -496,7 +496,8 @@ void gr_comm_destroy(gr_comm *comm);
 const char *gr_comm_last_error(const gr_comm *comm);
 const char *gr_comm_library(void);
 /* use this RCCL build instead of the default search (the process's own copy, then librccl.so.1); call before the first gr_comm_* call
- * of the process -- the library is resolved once.  A path that cannot be loaded makes every gr_comm_* call return GR_E_NO_DEVICE and
+ * of the process -- the library is resolved once, and a call that comes after that returns GR_E_INVALID_ARG (thread-safe against a
+ * concurrent first gr_comm_* call).  A path that cannot be loaded makes every gr_comm_* call return GR_E_NO_DEVICE and
  * gr_comm_library() say why. */
 int gr_comm_set_library(const char *path);
 int gr_comm_gather_per_frame(gr_comm *comm, const float *local, uint64_t n_total, size_t width, float *out);

@@ -149,6 +149,7 @@ def test_comm_without_rccl_reports_no_device_instead_of_crashing(tmp_path):
         "assert not lib.gr_comm_create(0, 0, 1, buf, C.byref(st)) and st.value == 13, 'create'\n"
         "msg = lib.gr_comm_library().decode()\n"
         "assert msg.startswith('RCCL not found: ') and 'no_such_rccl' in msg, msg\n"
+        "assert lib.gr_comm_set_library(b'librccl.so.1') == 10, 'an override after the library was resolved must be refused'\n"
         "print('ok')\n") % (ROOT, str(tmp_path / "no_such_rccl.so"))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.returncode, r.stdout[-300:], r.stderr[-600:])

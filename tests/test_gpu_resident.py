@@ -277,3 +277,78 @@ def test_resident_launch_aborted_from_inside_loses_nothing(G, whole, streams, at
     r, st = plan.rmsd_fit(0, nf)
     assert (st == 0).all() and cur.stat("res_launches") == 1
     plan.close(); ref.close(); cur.close()
+
+
+@pytest.mark.parametrize("whole", [True, False])
+@pytest.mark.parametrize("cell,streams", [("ortho", 1), ("tric", 1), ("tric", 3), ("dodeca", 8)])
+def test_frames_whose_image_proof_fails_inside_a_resident_launch(G, whole, cell, streams):
+    """The switch-off of the shortcut the resident pass rests on.  The V kernel parks image vectors and fits with R v + t0, which is
+    the path's q only "once the frame's image proof holds" (gr_resident.h); a frame whose proof FAILS -- a group wider than half
+    the cell: stretched, or two lobes -- must come out of the launch untouched (status GR_ST_FALLBACK published by its finalizer,
+    the fit stage skipped) and be redone by the literal multi-pass path (rmsd.rs:425-446,508-528), without disturbing the frames
+    that share its stream, its finalizer round and its LDS / register slots.  Frames 0, 6 (the first frame fitted after the
+    pipeline has filled) and the last one are such frames; both kernel variants; 1, 3 and 8 streams (8: the finalizer teams close
+    several frames per round, proof-failing and ordinary ones side by side).  Every frame against the oracle."""
+    n, nf = 20_000, 26
+    box = {"ortho": W.box_from_lengths_angles([6.0, 6.0, 6.0], [90.0, 90.0, 90.0]), "tric": W.box_from_lengths_angles([7.0, 6.5, 6.0], [75.0, 80.0, 70.0]),
+           "dodeca": W.c4_box(6.5)}[cell]
+    sel = (0, n - 1) if whole else (40, n - 3)
+    masses, cur, ref, ref_pos, frames = _systems(G, n, nf, box, sel)
+    bad = {0: "stretched", 6: "two_lobes", nf - 1: "stretched"}
+    for f, kind in bad.items():
+        frames[f] = W.proof_failing_frame(ref_pos, box, kind, 100 + f)
+    idx = np.arange(sel[0], sel[1] + 1)
+    with O.acc64():
+        want = [O.calc_rmsd_and_fit(ref_pos, masses, idx, box, frames[f], masses, idx, box) for f in range(nf)]
+    plan = G.RMSDPlan(ref, cur, "S")
+    cur.set_tuning(resident=2, resident_streams=streams)
+    cur.profile_enable(True)
+    for f in range(nf):
+        cur.set_frame(frames[f], box, slot=f)
+    r, st = plan.rmsd_fit(0, nf)
+    prof = cur.profile_read()
+    assert (st == 0).all(), st
+    assert prof["k_fit_resident"][1] == 1 and prof["k_fit_resident"][2] == nf, prof          # ONE resident launch saw all 26 frames
+    assert plan.last_fallbacks() == len(bad), plan.last_fallbacks()                           # ... and handed back exactly the three
+    assert cur.stat("res_aborts") == 0 and cur.stat("res_launches") == 1 and cur.stat("res_last_streams") == streams
+    for f in range(nf):
+        assert abs(float(r[f]) - want[f][0]) <= 1e-5, (f, f in bad, float(r[f]), want[f][0])
+        assert np.abs(cur.get_positions(f) - want[f][1]).max() <= 5e-5, (f, f in bad)
+    # the RMSD alone (no fit) over the same frames: the frames are left as they are, the same three are handed back
+    for f in range(nf):
+        cur.set_frame(frames[f], box, slot=f)
+    r2, st2 = plan.rmsd(0, nf)
+    assert (st2 == 0).all() and plan.last_fallbacks() == len(bad)
+    for f in range(nf):
+        assert abs(float(r2[f]) - want[f][0]) <= 1e-5, (f, float(r2[f]), want[f][0])
+        assert np.array_equal(cur.get_positions(f), frames[f]), f
+    plan.close(); ref.close(); cur.close()
+
+
+@pytest.mark.parametrize("whole", [True, False])
+def test_aborted_launch_whose_redone_run_holds_a_proof_failing_frame(G, whole):
+    """the frames an aborted launch never touched are redone as a nested two-pass segment; when that run contains a frame
+    whose image proof fails, the nested call's own exact-path redo used to overwrite the scratch records the outer call then read
+    (the run's first frame silently got another frame's rmsd).  Abort at frame 9 of 24; frames 12 and 20 are proof-failing; the
+    system's last workgroup has 128 of 1024 groups (6 of its 8 waves idle: the progress words the host must skip)."""
+    n, nf = 70_001, 24
+    box = W.box_from_lengths_angles([9.0, 9.0, 9.0], [60.0, 60.0, 90.0])
+    sel = (0, n - 1) if whole else (40, n - 3)
+    masses, cur, ref, ref_pos, frames = _systems(G, n, nf, box, sel)
+    for f, kind in ((12, "two_lobes"), (20, "stretched")):
+        frames[f] = W.proof_failing_frame(ref_pos, box, kind, 200 + f)
+    idx = np.arange(sel[0], sel[1] + 1)
+    with O.acc64():
+        want = [O.calc_rmsd_and_fit(ref_pos, masses, idx, box, frames[f], masses, idx, box) for f in range(nf)]
+    plan = G.RMSDPlan(ref, cur, "S")
+    cur.set_tuning(resident=2, resident_streams=1, test_resident_abort_at=9)
+    for f in range(nf):
+        cur.set_frame(frames[f], box, slot=f)
+    r, st = plan.rmsd_fit(0, nf)
+    assert (st == 0).all(), st
+    assert cur.stat("res_aborts") == 1 and cur.stat("res_redone_frames") >= nf - 9, cur.stat("res_redone_frames")
+    assert plan.last_fallbacks() == 2
+    for f in range(nf):
+        assert abs(float(r[f]) - want[f][0]) <= 1e-5, (f, float(r[f]), want[f][0])
+        assert np.abs(cur.get_positions(f) - want[f][1]).max() <= 5e-5, f
+    plan.close(); ref.close(); cur.close()

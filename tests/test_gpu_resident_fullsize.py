@@ -172,3 +172,33 @@ def test_largest_frame_the_pass_accepts_and_the_first_it_refuses(G):
         prof, _ = _check(cur, plan, ref_pos, masses, np.arange(n), box, [box] * nf, nf, [0, nf - 1])
         assert (prof["k_fit_resident"][1] == 1) == resident and (prof["k_fit_pk"][1] > 0) == (not resident), (n, prof)
         plan.close(); ref.close(); cur.close()
+
+
+def test_headline_shape_with_frames_whose_image_proof_fails(G):
+    """The benchmark's launch (1e6 atoms, rhombic dodecahedron, default tuning, k_fit_resident<.., V = true>) with three frames whose
+    image proof FAILS among the 26 -- frame 0, frame 6 (the first one fitted once the pipeline is full) and the last: a group
+    stretched to 0.62 of the cell / two lobes 0.42 a apart (workload.proof_failing_frame).  The shortcut `R v + t0` must switch
+    itself off for exactly those frames: the launch leaves them untouched, the host redoes them on the literal path
+    (rmsd.rs:425-446,508-528), and their neighbours in the stream, in the finalizer rounds and in the LDS / register slots are
+    fitted as if nothing had happened.  Oracle on the three frames and on the frames either side of each."""
+    nf = 26
+    box, masses, cur, ref, ref_pos, plan = _c4(G, N, nf)
+    bad = {0: "stretched", 6: "two_lobes", nf - 1: "stretched"}
+    for f, kind in bad.items():
+        cur.set_frame(W.proof_failing_frame(ref_pos, box, kind, 300 + f), box, slot=f)
+    check = [0, 1, 5, 6, 7, nf - 2, nf - 1]
+    before = {f: cur.get_positions(f) for f in check}
+    cur.profile_enable(True)
+    r, st = plan.rmsd_fit(0, nf)
+    prof = cur.profile_read()
+    assert (st == 0).all(), st
+    assert prof["k_fit_resident"][1] == 1 and prof["k_fit_resident"][2] == nf, prof
+    assert plan.last_fallbacks() == len(bad) and cur.stat("res_aborts") == 0, (plan.last_fallbacks(), cur.stat("res_aborts"))
+    idx = np.arange(N)
+    with O.acc64():
+        for f in check:
+            ro, want = O.calc_rmsd_and_fit(ref_pos, masses, idx, box, before[f], masses, idx, box)
+            assert abs(float(r[f]) - ro) <= 1e-5, (f, f in bad, float(r[f]), ro)
+            got = cur.get_positions(f)
+            assert np.abs(got - want).max() <= 5e-5, (f, f in bad, float(np.abs(got - want).max()))
+    plan.close(); ref.close(); cur.close()

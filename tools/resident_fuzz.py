@@ -51,6 +51,13 @@ while time.time() < t_end:
     if bad_frame >= 0:
         p = cur.get_positions(bad_frame); p[int(rng.integers(sel[0], sel[1] + 1))] = np.nan
         cur.set_frame(p, cur.get_box(bad_frame), slot=bad_frame)
+    # now and then a frame whose image proof fails (a group wider than half the cell): the launch must hand it back untouched
+    wide_frame = int(rng.integers(0, nf)) if (nf > 2 and n * nf <= 6_000_000 and rng.integers(0, 3) == 0) else -1
+    if wide_frame >= 0 and wide_frame != bad_frame:
+        wide = W.proof_failing_frame(ref.get_positions(0), cur.get_box(wide_frame), "two_lobes" if rng.integers(0, 2) else "stretched", 11 + case)
+        cur.set_frame(wide, cur.get_box(wide_frame), slot=wide_frame)
+    else:
+        wide_frame = -1
     keep = [cur.get_positions(f) for f in range(nf)] if n * nf <= 6_000_000 else None
     plan = G.RMSDPlan(ref, cur, "S")
     res = {}
@@ -86,8 +93,9 @@ while time.time() < t_end:
     ran = res["resident"][3]
     stats["resident" if ran else "two_pass"] += 1
     stats["aborts"] += cur.stat("res_aborts"); stats["misses"] += cur.stat("res_handshake_misses")
-    print("case %3d n=%7d nf=%3d streams=%2d(%d) forced=%d whole=%d cell=%s boxes=%d bad=%d resident=%d %s %s" % (
-        case, n, nf, streams, cur.stat("res_last_streams"), forced, whole, a, per_frame_box, bad_frame, ran, "ok" if ok else "MISMATCH", why), flush=True)
+    if ok and ran and wide_frame >= 0 and plan.last_fallbacks() < 1: ok, why = False, "the wide frame %d was not handed back" % wide_frame
+    print("case %3d n=%7d nf=%3d streams=%2d(%d) forced=%d whole=%d cell=%s boxes=%d bad=%d wide=%d resident=%d %s %s" % (
+        case, n, nf, streams, cur.stat("res_last_streams"), forced, whole, a, per_frame_box, bad_frame, wide_frame, ran, "ok" if ok else "MISMATCH", why), flush=True)
     bad += 0 if ok else 1
     plan.close(); ref.close(); cur.close()
 print("cases %d, mismatches %d, %s" % (case, bad, stats), flush=True)
