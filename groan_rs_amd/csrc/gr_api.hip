@@ -82,6 +82,9 @@ struct gr_ctx {
     double *fit_partials = nullptr;   // [frames of a segment][fit workgroups per frame]: sum w |R q - p|^2 of k_fit<true>
     size_t fit_partials_cap = 0;
     int two_pass = 1;                 // GR_TUNE_TWO_PASS 0: RMSD-fit keeps the closed-form single-pass rmsd (k_rmsd_accum<0>)
+    int rmsd_fast = 1;                // GR_TUNE_RMSD_FAST 0: the RMSD without fit always takes the exact-product pass (k_rmsd_accum<0>)
+    uint32_t rmsd_fast_min = 16384;   // GR_TUNE_RMSD_FAST_MIN: smallest contiguous mass-weighted selection that takes k_sums_pk<false, true>
+    uint64_t rmsd_fast_frames = 0, rmsd_exact_redos = 0;   // frames closed by the f32-chain pass / handed back to the exact-product pass
     // resident RMSD fit (gr_resident.h): one launch per segment, the frame waits on chip for its rotation
     int resident = 1;                 // GR_TUNE_RESIDENT 0 never, 1 when the frame fills the chip, 2 whenever it fits (tests)
     int pd_sym = 1;                   // GR_TUNE_PAIRDIST_SYMMETRIC: the pair matrix of a selection with itself computes one triangle and mirrors it
@@ -141,7 +144,7 @@ struct gr_ctx {
 };
 
 struct Pending {   // a segment between gr_rmsd_batch_begin and gr_rmsd_batch_end
-    bool active = false, any_ok = false, consistent = true, fused = false, resident = false;
+    bool active = false, any_ok = false, consistent = true, fused = false, resident = false, rmsd_fast = false;
     uint32_t s0 = 0, nb = 0, n_prof_groups = 0, res_stream = 0, res_streams = 1;   // (resident launch: streaming workgroups, frame streams)
     int fit = 0;
     std::vector<int> pre;
@@ -206,7 +209,9 @@ uint32_t batch_chunks(const gr_ctx *c, const GrSel &s, uint32_t nf) {
     uint64_t by_work = units / GR_WG;            // at least one trip per lane
     if (by_work < 1) by_work = 1;
     uint64_t want = (1536 + nf - 1) / nf;        // ~2 rounds of 768 resident workgroups
-    if (want < 4) want = 4;
+    // (never fewer than 8 when the selection has the work for it: 8 is the smallest count that keeps chunk c on XCD c % 8 for every
+    // frame -- 256-frame launches used to get 6 chunks per frame: 2.65 instead of 2.54 us per 1e6-atom frame in the RMSD pass)
+    if (want < 8) want = 8;
     uint64_t ch = want < by_work ? want : by_work;
     if (ch > GR_MAX_CHUNKS) ch = GR_MAX_CHUNKS;
     // XCD-aware: workgroups are dealt round-robin over the 8 XCDs, and block (chunk, frame) has linear id
@@ -1565,6 +1570,8 @@ int gr_ctx_stat(const gr_ctx *c, int key, uint64_t *value) {
     case GR_STAT_RES_HANDSHAKE_MISSES: *value = c->res_handshake_misses; return GR_OK;
     case GR_STAT_RES_ABORTS: *value = c->res_aborts; return GR_OK;
     case GR_STAT_RES_REDONE_FRAMES: *value = c->res_redone_frames; return GR_OK;
+    case GR_STAT_RMSD_FAST_FRAMES: *value = c->rmsd_fast_frames; return GR_OK;
+    case GR_STAT_RMSD_EXACT_REDOS: *value = c->rmsd_exact_redos; return GR_OK;
     default: return GR_E_INVALID_ARG;
     }
 }
@@ -1578,6 +1585,8 @@ int gr_ctx_set_tuning(gr_ctx *c, int key, int64_t value) try {
     case GR_TUNE_FUSE: c->fuse = value ? 1 : 0; return GR_OK;
     case GR_TUNE_TWO_PASS: c->two_pass = value ? 1 : 0; return GR_OK;
     case GR_TUNE_RESIDENT: if (value < 0 || value > 2) break; c->resident = value; return GR_OK;
+    case GR_TUNE_RMSD_FAST: if (value != 0 && value != 1) break; c->rmsd_fast = (int)value; return GR_OK;
+    case GR_TUNE_RMSD_FAST_MIN: if (value < 0 || value > 0x7fffffff) break; c->rmsd_fast_min = (uint32_t)value; return GR_OK;
     case GR_TUNE_PAIRDIST_SYMMETRIC: if (value != 0 && value != 1) break; c->pd_sym = (int)value; return GR_OK;
     case GR_TUNE_RESIDENT_WG_GROUPS: if (value != 0 && (value < 64 || value > GR_RES_GROUPS || value % 64 != 0)) break; c->res_wg_groups = (int)value; return GR_OK;
     case GR_TUNE_RESIDENT_STREAMS: if (value < 0 || value > GR_RES_MAX_STREAMS) break; c->res_streams = (int)value; return GR_OK;
@@ -1653,6 +1662,11 @@ static int segment_begin(gr_rmsd_plan *p, uint32_t s0, uint32_t nb, int fit) {
         // RMSD-fit of a contiguous selection: the sums pass only steers R and the centre, the fit pass evaluates
         // sum w |R q - p|^2 on the way (k_fit_pk<true>) and k_rmsd_close turns it into the rmsd
         const bool lite = fit && sel.contiguous && c->two_pass;
+        // RMSD WITHOUT fit of a contiguous mass-weighted selection: the sums pass of the fit path + the closed-form RMSD's sums as f32
+        // chains widened to fp64 (k_sums_pk<false, true>); frames whose rmsd comes out too close to the rounding of its own sums
+        // are handed back (GR_ST_REDO_EXACT) and redone below by the exact-product pass that every other selection takes
+        const bool fast = !fit && sel.contiguous && c->two_pass && c->rmsd_fast && p->dev.w_is_mass != 0 && g->n >= c->rmsd_fast_min;
+        q.rmsd_fast = fast;
         const uint32_t n_groups = (nb + sb - 1) / sb;
         if (lite) {
             size_t need = 0;
@@ -1664,7 +1678,7 @@ static int segment_begin(gr_rmsd_plan *p, uint32_t s0, uint32_t nb, int fit) {
                 c->fit_partials_cap = need;
             }
         }
-        const bool fused = lite && c->fuse;   // the finalize rides on the tail of the sums kernel
+        const bool fused = (lite || fast) && c->fuse;   // the finalize rides on the tail of the sums kernel
         q.fused = fused;
         hipStream_t S = c->stream;
         uint32_t res_streams = 1, res_gwg = GR_RES_GROUPS;
@@ -1736,11 +1750,14 @@ static int segment_begin(gr_rmsd_plan *p, uint32_t s0, uint32_t nb, int fit) {
             if (c->profile) EVREC(c, c->pev[6 * g], true, S);
             if (lite) k_sums_pk<false><<<dim3(nch, nf), dim3(GR_WG), 0, S>>>(c->frames, c->frame_stride, s0 + f0, c->masses, sel, c->boxes_dev, p->dev, parts,
                                                                              fused ? c->fuse_cnt + f0 : nullptr, c->state_dev + f0);
+            else if (fast) k_sums_pk<false, true><<<dim3(nch, nf), dim3(GR_WG), 0, S>>>(c->frames, c->frame_stride, s0 + f0, c->masses, sel, c->boxes_dev, p->dev, parts,
+                                                                                        fused ? c->fuse_cnt + f0 : nullptr, c->state_dev + f0);
             else k_rmsd_accum<0><<<dim3(nch, nf), dim3(GR_WG), 0, S>>>(c->frames, c->frame_stride, s0 + f0, c->masses, sel, c->boxes_dev, p->dev, c->state_dev + f0, parts);
             if (c->profile) EVREC(c, c->pev[6 * g + 1], true, S);
             if (!fused) {
                 if (c->profile) EVREC(c, c->pev[6 * g + 2], true, S);
                 if (lite) k_rmsd_finalize_lite<false><<<dim3(nf), dim3(64), 0, S>>>(parts, nch, c->frames, c->frame_stride, s0 + f0, sel, c->boxes_dev, p->dev, c->state_dev + f0);
+                else if (fast) k_rmsd_finalize_lite<false, true><<<dim3(nf), dim3(64), 0, S>>>(parts, nch, c->frames, c->frame_stride, s0 + f0, sel, c->boxes_dev, p->dev, c->state_dev + f0);
                 else k_rmsd_finalize<0><<<dim3(nf), dim3(GR_WG), 0, S>>>(parts, nch, c->frames, c->frame_stride, s0 + f0, sel, c->boxes_dev, p->dev, c->state_dev + f0);
                 if (c->profile) EVREC(c, c->pev[6 * g + 3], true, S);
             }
@@ -1883,6 +1900,27 @@ static int segment_end(gr_rmsd_plan *p, float *rmsd_out, int *status_out, float 
             }
             c->resident = keep;
             if (st_redo != GR_OK) return st_redo;
+        }
+        // frames the f32-chain RMSD pass handed back (rmsd too close to the rounding of its own sums: rigid copies of the reference)
+        // take the exact-product pass, in runs of consecutive frames; that pass may in turn flag a frame GR_ST_FALLBACK (it cannot:
+        // the image proof is the same one the first pass has already held -- but the loop below would pick it up)
+        if (q.rmsd_fast) {
+            for (uint32_t f0 = 0; f0 < nb; ) {
+                if (res[f0].status != GR_ST_REDO_EXACT) { if (q.pre[f0] == GR_OK) c->rmsd_fast_frames++; ++f0; continue; }
+                uint32_t f1 = f0;
+                while (f1 < nb && res[f1].status == GR_ST_REDO_EXACT) ++f1;
+                const uint32_t nf = f1 - f0, nch = batch_chunks(c, sel, nf);
+                SlotUse use(c, s0 + f0, nf);
+                int st = state_reset(c, nf); if (st) return st;
+                GrAccPartial *parts = c->acc_partials;
+                k_rmsd_accum<0><<<dim3(nch, nf), dim3(GR_WG), 0, c->stream>>>(c->frames, c->frame_stride, s0 + f0, c->masses, sel, c->boxes_dev, p->dev, c->state_dev, parts);
+                k_rmsd_finalize<0><<<dim3(nf), dim3(GR_WG), 0, c->stream>>>(parts, nch, c->frames, c->frame_stride, s0 + f0, sel, c->boxes_dev, p->dev, c->state_dev);
+                HIPCHK(c, hipGetLastError());
+                st = fetch_states(c, nf); if (st) return st;
+                for (uint32_t f = f0; f < f1; ++f) res[f] = c->state_host[f - f0];
+                c->rmsd_exact_redos += nf;
+                f0 = f1;
+            }
         }
         // frames whose single-pass image proof failed are redone on the exact path, one by one
         for (uint32_t f = 0; f < nb; ++f) {

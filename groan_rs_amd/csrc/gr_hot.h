@@ -62,6 +62,13 @@ struct GrSumsPk {
     float mn[3], mx3[3], fmn[3], fmx[3];  // Cartesian and fractional extents of v
 };
 
+// the sums the closed-form RMSD needs on top of the rotation's (k_sums_pk<false, true>): B = sum (w p) v^T, sum w |v|^2 -- f32 products
+// in SHORT chains (GR_RMSD_FLUSH trips = 8 atoms per half) that are widened to fp64 per lane before they grow: see k_sums_pk
+struct GrRmsdPk { gr_v2f b[9]; gr_v2f wvv; };
+#ifndef GR_RMSD_FLUSH
+#define GR_RMSD_FLUSH 4            // trips (4 atoms per lane each) between two flushes of the f32 chains into the lane's fp64 sums
+#endif
+
 // two difference vectors -> their minimum images: closed-form brick reduction along c, b, a (gr_image_about), which in a
 // triclinic cell is already THE minimum image whenever |v| < r_ws; otherwise the image table is searched (rare: wave-uniform branch)
 __device__ __forceinline__ void gr_image_pair(gr_v2f &vx, gr_v2f &vy, gr_v2f &vz, const GrBoxU &B, const GrBox *__restrict__ boxp) {
@@ -81,9 +88,9 @@ __device__ __forceinline__ void gr_image_pair(gr_v2f &vx, gr_v2f &vy, gr_v2f &vz
 }
 
 // two atoms: v = image of (x - g) nearest to g, then every sum.  `p*` = reference coordinates (NOREF: unused), m = masses.
-template <bool NOREF>
+template <bool NOREF, bool RMSD = false>
 __device__ __forceinline__ void gr_sums_pair(GrSumsPk &S, gr_v2f x, gr_v2f y, gr_v2f z, gr_v2f px, gr_v2f py, gr_v2f pz, gr_v2f m,
-                                             const GrBoxU &B, const GrBox *__restrict__ boxp, float gx, float gy, float gz) {
+                                             const GrBoxU &B, const GrBox *__restrict__ boxp, float gx, float gy, float gz, GrRmsdPk *Rm = nullptr) {
     gr_v2f vx = x - gr_v2(gx), vy = y - gr_v2(gy), vz = z - gr_v2(gz);
     gr_image_pair(vx, vy, vz, B, boxp);
     // fractional coordinates of v: moments + extents feed the image proof (gr_finalize_math)
@@ -103,16 +110,36 @@ __device__ __forceinline__ void gr_sums_pair(GrSumsPk &S, gr_v2f x, gr_v2f y, gr
         S.a[3] = gr_v2_fma(py, vx, S.a[3]); S.a[4] = gr_v2_fma(py, vy, S.a[4]); S.a[5] = gr_v2_fma(py, vz, S.a[5]);
         S.a[6] = gr_v2_fma(pz, vx, S.a[6]); S.a[7] = gr_v2_fma(pz, vy, S.a[7]); S.a[8] = gr_v2_fma(pz, vz, S.a[8]);
     }
+    if (RMSD) {   // weights = masses (the caller checked): B = sum (m p) v^T, sum m |v|^2; sum m v is S.mx / my / mz
+        const gr_v2f wx = m * px, wy = m * py, wz = m * pz;
+        Rm->b[0] = gr_v2_fma(wx, vx, Rm->b[0]); Rm->b[1] = gr_v2_fma(wx, vy, Rm->b[1]); Rm->b[2] = gr_v2_fma(wx, vz, Rm->b[2]);
+        Rm->b[3] = gr_v2_fma(wy, vx, Rm->b[3]); Rm->b[4] = gr_v2_fma(wy, vy, Rm->b[4]); Rm->b[5] = gr_v2_fma(wy, vz, Rm->b[5]);
+        Rm->b[6] = gr_v2_fma(wz, vx, Rm->b[6]); Rm->b[7] = gr_v2_fma(wz, vy, Rm->b[7]); Rm->b[8] = gr_v2_fma(wz, vz, Rm->b[8]);
+        Rm->wvv = gr_v2_fma(m, gr_v2_fma(vx, vx, gr_v2_fma(vy, vy, vz * vz)), Rm->wvv);
+    }
 }
 
 // Same contract as k_rmsd_accum<0, true, NOREF> for a CONTIGUOUS selection (the caller checks): partial record per workgroup
 // in `partials`, optional fused closing of the frame through `fuse` / `state_out` (see k_rmsd_accum).
-template <bool NOREF = false>
+//
+// RMSD = true: the RMSD WITHOUT fit of a contiguous, mass-weighted selection in this one read-only pass (calc_rmsd, rmsd.rs:75-129,
+// 141-166; round 3 ran it through k_rmsd_accum<0>: exact fp64 products, 74 instructions per atom, 3.8 us per 1e6-atom frame against
+// a 1.7 us read stream).  On top of the rotation's sums the lane keeps B = sum (m p) v^T, sum m |v|^2 and sum m v as packed-f32
+// chains of GR_RMSD_FLUSH trips (8 atoms per half) and widens them to fp64 before they grow -- 13 folds + conversions + fp64 adds
+// per 16 atoms; the closing step evaluates rmsd^2 = (sum w|p|^2 + sum w|q|^2 - 2 tr(R^T Hw)) / W (rmsd.rs:592-599 expanded, as
+// k_rmsd_finalize<0> does).  That expression is a small difference of large sums, and what the short chains leave of the f32
+// rounding is a random walk over ~n / 8 independent partials: the closing step ESTIMATES it from the magnitudes of the sums and
+// hands the frame back (GR_ST_REDO_EXACT -> the exact-product pass) when the estimate is not far below the 1e-5 nm bar --
+// rigid copies of the reference (rmsd ~ 0), tiny groups; see gr_finalize_math<.., FAST>.
+template <bool NOREF = false, bool RMSD = false>
 __global__ __launch_bounds__(GR_WG) void k_sums_pk(
     const float *__restrict__ frames, size_t frame_stride, uint32_t first_slot,
     const float *__restrict__ masses, GrSel sel, const GrBox *__restrict__ boxes,
     GrPlanDev plan, GrAccPartial *partials, uint32_t *fuse, GrFrameState *state_out) {
+    static_assert(!(NOREF && RMSD), "the RMSD needs the reference");
     __shared__ double lds[(GR_WG / 64) * GR_ACC_K];
+    __shared__ double lds_pd[RMSD ? (GR_WG / 64) * 16 : 1];
+    __shared__ double lds_acc[RMSD ? 13 * GR_WG : 1];        // RMSD: the lanes' fp64 sums [13][GR_WG] (26 KiB: no registers, one ds_add_f64 per value and flush)
     const uint32_t frame = blockIdx.y, chunk = blockIdx.x, nchunks = gridDim.x;
     const float *xyz = frames + (size_t)(first_slot + frame) * frame_stride;
     const GrBox *boxp = boxes + first_slot + frame;
@@ -127,6 +154,25 @@ __global__ __launch_bounds__(GR_WG) void k_sums_pk(
     S.f1a = S.f1b = S.f1c = S.f2a = S.f2b = S.f2c = gr_v2(0.0f);
 #pragma unroll
     for (int a = 0; a < 3; ++a) { S.mn[a] = S.fmn[a] = 3.0e38f; S.mx3[a] = S.fmx[a] = -3.0e38f; }
+    GrRmsdPk Rm;
+    // RMSD: the lane's fp64 sums -- B (9), sum m |v|^2, sum m v (3) -- live in LDS, one column per lane (as registers they cost the
+    // kernel a wave per SIMD: 178 VGPRs, 2.8 us per 1e6-atom frame)
+    uint32_t trips = 0;
+    if (RMSD) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) Rm.b[k] = gr_v2(0.0f);
+        Rm.wvv = gr_v2(0.0f);
+#pragma unroll
+        for (int k = 0; k < 13; ++k) lds_acc[k * GR_WG + threadIdx.x] = 0.0;
+    }
+    auto widen = [&](int k, gr_v2f v) { (void)__hip_atomic_fetch_add(&lds_acc[k * GR_WG + threadIdx.x], (double)(v.x + v.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); };
+    auto flush = [&]() {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { widen(k, Rm.b[k]); Rm.b[k] = gr_v2(0.0f); }
+        widen(9, Rm.wvv); Rm.wvv = gr_v2(0.0f);
+        widen(10, S.mx); widen(11, S.my); widen(12, S.mz);
+        S.mx = S.my = S.mz = gr_v2(0.0f);
+    };
 
     const uint32_t first = sel.start, last = sel.start + sel.n;
     const uint32_t g0 = sel.g0 << 6, g1 = (last + 3u) >> 2;      // float4 groups [g0, g1): g0 = first group of the first tile
@@ -134,43 +180,81 @@ __global__ __launch_bounds__(GR_WG) void k_sums_pk(
     const float4 *p4 = reinterpret_cast<const float4 *>(plan.p);
     const float4 *m4 = reinterpret_cast<const float4 *>(masses);
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // software pipeline of depth one: the rows of trip k + 1 are requested before the arithmetic of trip k and waited for after
-    // it (measured at 1e6 atoms, 256 frames per launch: 1.7 us per frame with the prefetch, 2.3 without -- with ~40 VALU
-    // instructions per atom the loop no longer hides its own load latency behind issue slots at 4 waves per SIMD)
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f), one4 = make_float4(1.f, 1.f, 1.f, 1.f);
-    float4 r0 = zero4, r1 = zero4, r2 = zero4, q0 = zero4, q1 = zero4, q2 = zero4, mm = one4;
-    auto request = [&](uint32_t gg, float4 &a0, float4 &a1, float4 &a2, float4 &b0, float4 &b1, float4 &b2, float4 &m) {
-        gr_rows_load<true>(f4, gg, a0, a1, a2);
-        if (!NOREF) gr_rows_load(p4, (size_t)(gg - g0), b0, b1, b2);
-        if (!(NOREF && !wm)) m = m4[gg];
-    };
-    uint32_t g = g0 + chunk * GR_WG + threadIdx.x;
-    if (g < g1) request(g, r0, r1, r2, q0, q1, q2, mm);
-    while (g < g1) {
-        const uint32_t gn = g + nchunks * GR_WG;
-        float4 n0 = zero4, n1 = zero4, n2 = zero4, nq0 = zero4, nq1 = zero4, nq2 = zero4, nm = one4;
-        if (gn < g1) request(gn, n0, n1, n2, nq0, nq1, nq2, nm);
-        GrP4 q = gr_pairs_rows(r0, r1, r2), p;
-        if (!NOREF) p = gr_pairs_rows(q0, q1, q2); else p.x01 = p.y01 = p.z01 = p.x23 = p.y23 = p.z23 = gr_v2(0.0f);
-        const uint32_t i = g << 2;
-        if (!(i >= first && i + 3 < last)) {
-            // a ragged end of the selection: atoms outside it become copies of the first atom with zero mass and zero
-            // reference coordinates -- v = 0 adds nothing to any sum and lies inside every extent (the first atom's own v is 0)
-            if (!(i >= first && i < last)) { q.x01.x = gx; q.y01.x = gy; q.z01.x = gz; mm.x = 0.f; p.x01.x = p.y01.x = p.z01.x = 0.f; }
-            if (!(i + 1 >= first && i + 1 < last)) { q.x01.y = gx; q.y01.y = gy; q.z01.y = gz; mm.y = 0.f; p.x01.y = p.y01.y = p.z01.y = 0.f; }
-            if (!(i + 2 >= first && i + 2 < last)) { q.x23.x = gx; q.y23.x = gy; q.z23.x = gz; mm.z = 0.f; p.x23.x = p.y23.x = p.z23.x = 0.f; }
-            if (!(i + 3 >= first && i + 3 < last)) { q.x23.y = gx; q.y23.y = gy; q.z23.y = gz; mm.w = 0.f; p.x23.y = p.y23.y = p.z23.y = 0.f; }
+    // Software pipeline of depth one with TWO NAMED register sets and the loop unrolled by two: the rows of trip k + 1 are requested
+    // before the arithmetic of trip k, and the only wait before that arithmetic is "all but the seven loads just issued".  (Rounds
+    // 2-3 wrote this as `if (next < end) request(next, n..); ...; r = n` -- and the compiler, which has to merge the loaded and the
+    // not-loaded value at the join and to copy the landing registers at the end of the body, waited for the new loads right after
+    // issuing them (s_waitcnt vmcnt(5) of 7) and drained the queue at the end of every trip: nothing was prefetched, only the
+    // other waves of the SIMD hid the latency.)  Every request is unconditional: a lane that has no further trip re-reads the
+    // selection's first group, and a trip that lies behind the selection is turned into copies of the first atom with zero mass
+    // by the same masking that handles the selection's ragged ends -- so the trip count is wave-uniform and nothing diverges.
+    const float4 one4 = make_float4(1.f, 1.f, 1.f, 1.f);
+#ifndef GR_SUMS_PREFETCH_PM
+#define GR_SUMS_PREFETCH_PM 1
+#endif
+    struct Trip { float4 r0, r1, r2, q0, q1, q2, mm; };
+    auto request = [&](uint32_t gg, Trip &t) {
+        const uint32_t gc = gg < g1 ? gg : g0;
+        gr_rows_load<true>(f4, gc, t.r0, t.r1, t.r2);
+        if (GR_SUMS_PREFETCH_PM) {
+            if (!NOREF) gr_rows_load(p4, (size_t)(gc - g0), t.q0, t.q1, t.q2);
+            if (!(NOREF && !wm)) t.mm = m4[gc]; else t.mm = one4;
         }
-        gr_sums_pair<NOREF>(S, q.x01, q.y01, q.z01, p.x01, p.y01, p.z01, gr_v2p(mm.x, mm.y), B, boxp, gx, gy, gz);
-        gr_sums_pair<NOREF>(S, q.x23, q.y23, q.z23, p.x23, p.y23, p.z23, gr_v2p(mm.z, mm.w), B, boxp, gx, gy, gz);
-        g = gn;
-        r0 = n0; r1 = n1; r2 = n2; q0 = nq0; q1 = nq1; q2 = nq2; mm = nm;
+    };
+    auto process = [&](const Trip &t, uint32_t gg) {
+        float4 q0 = t.q0, q1 = t.q1, q2 = t.q2, mm = t.mm;
+        if (!GR_SUMS_PREFETCH_PM) {
+            const uint32_t gc = gg < g1 ? gg : g0;
+            if (!NOREF) gr_rows_load(p4, (size_t)(gc - g0), q0, q1, q2);
+            if (!(NOREF && !wm)) mm = m4[gc]; else mm = one4;
+        }
+        GrP4 q = gr_pairs_rows(t.r0, t.r1, t.r2), p;
+        if (!NOREF) p = gr_pairs_rows(q0, q1, q2); else p.x01 = p.y01 = p.z01 = p.x23 = p.y23 = p.z23 = gr_v2(0.0f);
+        const uint32_t i = gg << 2;
+        if (!(gg < g1 && i >= first && i + 3 < last)) {
+            // a ragged end of the selection (or a trip behind it): atoms outside become copies of the first atom with zero mass and
+            // zero reference coordinates -- v = 0 adds nothing to any sum and lies inside every extent (the first atom's own v is 0)
+            const bool in = gg < g1;
+            if (!(in && i >= first && i < last)) { q.x01.x = gx; q.y01.x = gy; q.z01.x = gz; mm.x = 0.f; p.x01.x = p.y01.x = p.z01.x = 0.f; }
+            if (!(in && i + 1 >= first && i + 1 < last)) { q.x01.y = gx; q.y01.y = gy; q.z01.y = gz; mm.y = 0.f; p.x01.y = p.y01.y = p.z01.y = 0.f; }
+            if (!(in && i + 2 >= first && i + 2 < last)) { q.x23.x = gx; q.y23.x = gy; q.z23.x = gz; mm.z = 0.f; p.x23.x = p.y23.x = p.z23.x = 0.f; }
+            if (!(in && i + 3 >= first && i + 3 < last)) { q.x23.y = gx; q.y23.y = gy; q.z23.y = gz; mm.w = 0.f; p.x23.y = p.y23.y = p.z23.y = 0.f; }
+        }
+        gr_sums_pair<NOREF, RMSD>(S, q.x01, q.y01, q.z01, p.x01, p.y01, p.z01, gr_v2p(mm.x, mm.y), B, boxp, gx, gy, gz, &Rm);
+        gr_sums_pair<NOREF, RMSD>(S, q.x23, q.y23, q.z23, p.x23, p.y23, p.z23, gr_v2p(mm.z, mm.w), B, boxp, gx, gy, gz, &Rm);
+        if (RMSD && (++trips % GR_RMSD_FLUSH) == 0) flush();
+    };
+    const uint32_t gstep = nchunks * GR_WG;
+    uint32_t g = g0 + chunk * GR_WG + threadIdx.x;
+    if (__builtin_amdgcn_ballot_w64(g < g1) != 0ull) {
+        Trip TA, TB;
+        request(g, TA);
+        for (;;) {
+            request(g + gstep, TB);
+            process(TA, g);
+            g += gstep;
+            if (__builtin_amdgcn_ballot_w64(g < g1) == 0ull) break;
+            request(g + gstep, TA);
+            process(TB, g);
+            g += gstep;
+            if (__builtin_amdgcn_ballot_w64(g < g1) == 0ull) break;
+        }
     }
     // epilogue (as k_rmsd_accum's LITE epilogue): every wave reduce-scatters its 19 sums and 12 extents, the four waves
     // meet in LDS once, and 33 lanes of wave 0 write the record
     float s32[32], e32[32];
 #pragma unroll
     for (int k = 0; k < 32; ++k) { s32[k] = 0.0f; e32[k] = -3.0e38f; }
+    if (RMSD) {
+        // the lane's fp64 sums -> the wave (reduce-scatter in fp64) -> LDS; sum m v of the record is the fp64 one, rounded
+        flush();
+        double d32[32];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) d32[k] = k < 13 ? lds_acc[k * GR_WG + threadIdx.x] : 0.0;
+        S.mx = gr_v2p((float)d32[10], 0.0f); S.my = gr_v2p((float)d32[11], 0.0f); S.mz = gr_v2p((float)d32[12], 0.0f);
+        const double dt = gr_wave_sum_scatter16_f64(d32, lane);           // lane l: the wave total of value l >> 2
+        if ((lane & 3u) == 0) lds_pd[wave * 16 + (lane >> 2)] = dt;
+    }
     s32[0] = S.m.x + S.m.y; s32[1] = S.mx.x + S.mx.y; s32[2] = S.my.x + S.my.y; s32[3] = S.mz.x + S.mz.y;
 #pragma unroll
     for (int k = 0; k < 9; ++k) s32[4 + k] = S.a[k].x + S.a[k].y;
@@ -190,7 +274,10 @@ __global__ __launch_bounds__(GR_WG) void k_sums_pk(
         const double v = (double)wsum[lane] + (double)wsum[48 + lane] + (double)wsum[96 + lane] + (double)wsum[144 + lane];
         gr_st_agent(&o.s[lane < 13 ? lane : 13 + lane], v);           // sums 13..18 are the moments: record slots 26..31
     } else if (lane < 32) {
-        gr_st_agent(&o.s[lane - 6], 0.0);                             // slots 13..25 are not used by the two-pass sums
+        // slots 13..25: B (Hw before the centring), sum w |v|^2, sum w v -- the closed-form RMSD's sums; unused (zero) by the two-pass fit
+        double v = 0.0;
+        if (RMSD) { const uint32_t q = lane - 19; v = ((lds_pd[q] + lds_pd[16 + q]) + lds_pd[32 + q]) + lds_pd[48 + q]; }
+        gr_st_agent(&o.s[lane - 6], v);
     } else if (lane < 44) {
         const uint32_t q = lane - 32;
         const float m = gr_fmaxf(gr_fmaxf(wsum[32 + q], wsum[48 + 32 + q]), gr_fmaxf(wsum[96 + 32 + q], wsum[144 + 32 + q]));
@@ -207,7 +294,7 @@ __global__ __launch_bounds__(GR_WG) void k_sums_pk(
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             double *totd = lds;                                       // wsum (same LDS) has been consumed by this wave
             float *ext = reinterpret_cast<float *>(lds + 32);
-            gr_finalize_frame_lite<NOREF>(partials, nchunks, frame, frames, frame_stride, first_slot, sel, boxes, plan, state_out, totd, ext, lane);
+            gr_finalize_frame_lite<NOREF, RMSD>(partials, nchunks, frame, frames, frame_stride, first_slot, sel, boxes, plan, state_out, totd, ext, lane);
             if (lane == 0) fuse[frame] = 0u;
         }
     }

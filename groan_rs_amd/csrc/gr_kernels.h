@@ -34,6 +34,7 @@
 #define GR_WG 256
 #define GR_NOIDX 0xFFFFFFFFu
 #define GR_ST_FALLBACK 100 /* internal: frame must be redone on the multi-pass exact path */
+#define GR_ST_REDO_EXACT 103 /* internal (RMSD without fit, f32 chains): rmsd too close to the rounding of its own sums -> the exact-product pass */
 #define GR_ST_AMBIG 101    /* internal (one-pass centre): images proven, but the periodic copy needs the Bai-Breen estimate itself */
 
 struct GrSel {
@@ -213,6 +214,12 @@ __device__ __forceinline__ float gr_wave_sum_scatter32(float (&a)[32], const uin
     gr_rs_step_swap<16, 32, false>(a); gr_rs_step_swap<8, 16, false>(a); gr_rs_step<4, 8, false>(a, lane);
     gr_rs_step<2, 4, false>(a, lane); gr_rs_step<1, 2, false>(a, lane);
     return a[0] + gr_xor_lane<1>(a[0]);
+}
+// 16 doubles (a[0..15]): afterwards lane l holds the wave total of value (l >> 2)
+__device__ __forceinline__ double gr_wave_sum_scatter16_f64(double (&a)[32], const uint32_t lane) {
+    gr_rs_step_f64<8, 32>(a, lane); gr_rs_step_f64<4, 16>(a, lane); gr_rs_step_f64<2, 8>(a, lane); gr_rs_step_f64<1, 4>(a, lane);
+    const double m = a[0] + __shfl_xor(a[0], 2, 64);
+    return m + __shfl_xor(m, 1, 64);
 }
 // 16 floats: afterwards lane l holds the wave total of value (l >> 2)
 __device__ __forceinline__ float gr_wave_sum_scatter16(float (&a)[32], const uint32_t lane) {
@@ -559,7 +566,7 @@ __device__ __forceinline__ void gr_flush4(GrLaneAcc &L, const GrA4 &a, const boo
     for (int k = 0; k < 9; ++k) L.acc[4 + k] += (double)part[k];
 }
 
-template <bool NOREF = false>
+template <bool NOREF = false, bool RMSD = false>
 __device__ __forceinline__ void gr_finalize_frame_lite(const GrAccPartial *partials, uint32_t nchunks, uint32_t frame, const float *frames, size_t frame_stride,
                                                        uint32_t first_slot, const GrSel &sel, const GrBox *boxes, const GrPlanDev &plan, GrFrameState *state,
                                                        double *tot, float *ext, uint32_t lane);
@@ -667,7 +674,10 @@ __global__ __launch_bounds__(GR_WG) void k_rmsd_accum(
 // (wherever in its rigorously bounded region it is) and the COM; otherwise the frame is flagged GR_ST_FALLBACK
 // and redone by the multi-pass path.
 // Closing algebra of the single pass for one frame (one lane).  `st` receives centre / com / shift / R / rmsd / status.
-template <int MODE, bool LITE = false, bool NOREF = false>
+// FAST (k_sums_pk<false, true>): the RMSD sums (acc[13..25]) come from f32 products in 8-atom chains, widened to fp64; M is the plan's
+// own fp64 sum of the weights (they ARE the masses: the caller checked element by element), and the rounding left in rmsd^2 is estimated
+// from the magnitudes of the sums -- a frame whose rmsd is not well above that estimate goes to the exact-product pass (GR_ST_REDO_EXACT).
+template <int MODE, bool LITE = false, bool NOREF = false, bool FAST = false>
 __device__ inline void gr_finalize_math(const double *acc, const float mn[3], const float mx[3], const float fmn[3], const float fmx[3],
                                         uint32_t bad_pos, uint32_t bad_mass, const GrBox &b, const GrPlanDev &plan,
                                         const double g[3], uint32_t n_sel, GrFrameState &st) {
@@ -681,7 +691,7 @@ __device__ inline void gr_finalize_math(const double *acc, const float mn[3], co
         for (int k = 0; k < 26; ++k) if (acc[k] != acc[k]) poisoned = true;
         if (poisoned) { st.status = GR_ST_FALLBACK; return; }
     }
-    const double M = acc[0];
+    const double M = FAST ? plan.sw : acc[0];
     double cv[3] = { 0, 0, 0 };
     if (MODE == 0) { cv[0] = acc[1] / M; cv[1] = acc[2] / M; cv[2] = acc[3] / M; }
     if (MODE == 0) {
@@ -779,6 +789,18 @@ __device__ inline void gr_finalize_math(const double *acc, const float mn[3], co
         double tr = 0;
         for (int a = 0; a < 3; ++a) for (int c = 0; c < 3; ++c) tr += R[a][c] * Hw[a][c];
         double r2 = (plan.swpp + swqq - 2.0 * tr) / plan.sw;
+        if (FAST) {
+            // What the f32 chains leave in r2.  Every term w p_a v_b / w v_a^2 / w v_a carries ~2 roundings of relative size <= 2^-24
+            // (product, one add of an 8-term chain whose partial is at most 8 terms long); they are independent from atom to atom, so
+            // the sums pick up a random walk: sigma(sum) ~ 2^-24 * rms(term) * sqrt(terms) <= 2^-24 * sqrt(sum w|p|^2 * sum w|v|^2 / n) * c
+            // per entry of Hw, likewise for sum w|v|^2 and cv . sum w v.  With S = (sum w|p|^2 + sum w|v|^2) / W (nm^2) bounding every
+            // such product, sigma(r2) ~ 6e-8 * S * sqrt(20 / n): 13 sums enter r2 with coefficients of size <= 2 (measured on the
+            // benchmark's frames: 1.5e-9 at n = 1e6, S = 21; tests/test_gpu_rmsd_fast.py holds the estimate against the exact pass).
+            // The frame is kept when 32 sigma moves the rmsd by less than 2e-6 nm: d(rmsd) = d(r2) / (2 rmsd).
+            const double S = (plan.swpp + acc[22]) / plan.sw;
+            const double sigma = 6.0e-8 * S * sqrt(20.0 / (double)n_sel);
+            if (!(r2 > 0.0) || !(32.0 * sigma < 4.0e-6 * sqrt(r2))) { st.status = GR_ST_REDO_EXACT; return; }
+        }
         if (r2 < 0.0) r2 = 0.0;
         st.rmsd = (float)sqrt(r2);
     }   // LITE: the fit pass sums w |R q - p|^2 and k_rmsd_close writes the rmsd
@@ -830,7 +852,8 @@ __global__ __launch_bounds__(GR_WG) void k_rmsd_finalize(
 // The same for the two-pass sums records, ONE WAVE per frame and no barrier: lane c sums the records c, c + 64, ..., a
 // reduce-scatter leaves the 19 totals / 12 extents spread over the lanes, LDS hands them to lane 0.
 // (tot: 32 doubles, ext: 16 floats of LDS owned by the calling wave)
-template <bool NOREF>
+// RMSD: the records also carry the closed-form RMSD's sums (slots 13..25, k_sums_pk<false, true>): values 19..31 of the scatter
+template <bool NOREF, bool RMSD>
 __device__ __forceinline__ void gr_finalize_frame_lite(const GrAccPartial *partials, uint32_t nchunks, uint32_t frame, const float *frames, size_t frame_stride,
                                                        uint32_t first_slot, const GrSel &sel, const GrBox *boxes, const GrPlanDev &plan, GrFrameState *state,
                                                        double *tot, float *ext, uint32_t lane) {
@@ -845,6 +868,10 @@ __device__ __forceinline__ void gr_finalize_frame_lite(const GrAccPartial *parti
         for (int k = 0; k < 13; ++k) s[k] += p.s[k];
 #pragma unroll
         for (int k = 0; k < 6; ++k) s[13 + k] += p.s[26 + k];
+        if (RMSD) {
+#pragma unroll
+            for (int k = 0; k < 13; ++k) s[19 + k] += p.s[13 + k];
+        }
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             e[a] = gr_fmaxf(e[a], -p.vmin[a]); e[3 + a] = gr_fmaxf(e[3 + a], p.vmax[a]);
@@ -866,23 +893,24 @@ __device__ __forceinline__ void gr_finalize_frame_lite(const GrAccPartial *parti
     for (int k = 0; k < GR_ACC_K; ++k) acc[k] = 0.0;
     for (int k = 0; k < 13; ++k) acc[k] = tot[k];
     for (int k = 0; k < 6; ++k) acc[26 + k] = tot[13 + k];
+    if (RMSD) for (int k = 0; k < 13; ++k) acc[13 + k] = tot[19 + k];
     const float mn[3] = { -ext[0], -ext[1], -ext[2] }, mx[3] = { ext[3], ext[4], ext[5] };
     const float fmn[3] = { -ext[6], -ext[7], -ext[8] }, fmx[3] = { ext[9], ext[10], ext[11] };
     const float *xyz = frames + (size_t)(first_slot + frame) * frame_stride;
     float g0x, g0y, g0z;
     gr_pos_load(xyz, sel.contiguous ? sel.start : sel.idx[0], g0x, g0y, g0z);
     const double g[3] = { g0x, g0y, g0z };
-    gr_finalize_math<0, true, NOREF>(acc, mn, mx, fmn, fmx, bad_pos, bad_mass, boxes[first_slot + frame], plan, g, sel.n, st);
+    gr_finalize_math<0, !RMSD, NOREF, RMSD>(acc, mn, mx, fmn, fmx, bad_pos, bad_mass, boxes[first_slot + frame], plan, g, sel.n, st);
 }
 
-template <bool NOREF = false>
+template <bool NOREF = false, bool RMSD = false>
 __global__ __launch_bounds__(64) void k_rmsd_finalize_lite(
     const GrAccPartial *__restrict__ partials, uint32_t nchunks,
     const float *__restrict__ frames, size_t frame_stride, uint32_t first_slot, GrSel sel,
     const GrBox *__restrict__ boxes, GrPlanDev plan, GrFrameState *__restrict__ state) {
     __shared__ double tot[32];
     __shared__ float ext[16];
-    gr_finalize_frame_lite<NOREF>(partials, nchunks, blockIdx.x, frames, frame_stride, first_slot, sel, boxes, plan, state, tot, ext, threadIdx.x);
+    gr_finalize_frame_lite<NOREF, RMSD>(partials, nchunks, blockIdx.x, frames, frame_stride, first_slot, sel, boxes, plan, state, tot, ext, threadIdx.x);
 }
 
 // rmsd = sqrt(sum of the fit pass's workgroup partials / sum w)  (rmsd.rs:599); one wave per frame, fixed summation order

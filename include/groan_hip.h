@@ -282,9 +282,14 @@ int gr_rmsd_plan_force_exact(gr_rmsd_plan *plan, int on);
  *                      diagonal and writes each of them twice (the mirror image transposed on chip); 0: every element on its own.
  *                      Same bits either way.
  *   GR_TUNE_RESIDENT_GROUPS  retired (round 3 removed the one-group shape of the resident pass): only the value 2 is accepted
- */
+ *   GR_TUNE_RMSD_FAST  1 (default): the RMSD WITHOUT fit (gr_rmsd_batch, gr_calc_rmsd) of a contiguous mass-weighted selection of at
+ *                      least GR_TUNE_RMSD_FAST_MIN atoms runs as the fit path's sums pass with the closed-form RMSD's sums kept as short
+ *                      f32 chains widened to fp64; a frame whose rmsd is too close to the rounding of those sums (a rigid copy of the
+ *                      reference) is redone by the exact-product pass, counted in GR_STAT_RMSD_EXACT_REDOS.  0: always the exact pass
+ *   GR_TUNE_RMSD_FAST_MIN  smallest selection (atoms, default 16384) that takes it */
 enum { GR_TUNE_SUB_BATCH = 1, GR_TUNE_CHUNKS = 2, GR_TUNE_FIT_WGS = 3, GR_TUNE_FUSE = 4, GR_TUNE_TWO_PASS = 5, GR_TUNE_RESIDENT = 6, GR_TUNE_RESIDENT_GROUPS = 7,
        GR_TUNE_RESIDENT_STREAMS = 8, GR_TUNE_RESIDENT_FILL = 9, GR_TUNE_PAIRDIST_SYMMETRIC = 10, GR_TUNE_RESIDENT_WG_GROUPS = 11,
+       GR_TUNE_RMSD_FAST = 12, GR_TUNE_RMSD_FAST_MIN = 13,
        GR_TUNE_TEST_RESIDENT_NO_START = 100 /* tests: the next resident launch behaves as if its workgroups never got onto the chip */,
        GR_TUNE_TEST_RESIDENT_ABORT_AT = 101 /* tests: the next resident launch is aborted from inside when it reaches this frame of its segment (< 0: never) */ };
 int gr_ctx_set_tuning(gr_ctx *ctx, int key, int64_t value);
@@ -297,7 +302,9 @@ int gr_ctx_set_tuning(gr_ctx *ctx, int key, int64_t value);
  *   GR_STAT_RES_ABORTS             resident launches in which a wait ran out of patience (see gr_rmsd_fit_batch)
  *   GR_STAT_RES_REDONE_FRAMES      frames of such launches that were still untouched and were redone on the two-pass path
  *   GR_STAT_RES_LAST_STREAMS       frame streams of the context's last resident launch (GR_TUNE_RESIDENT_STREAMS) */
-enum { GR_STAT_N_CUS = 1, GR_STAT_RES_MAX_WGS = 2, GR_STAT_RES_LAUNCHES = 3, GR_STAT_RES_HANDSHAKE_MISSES = 4, GR_STAT_RES_ABORTS = 5, GR_STAT_RES_REDONE_FRAMES = 6, GR_STAT_RES_LAST_STREAMS = 7 };
+enum { GR_STAT_N_CUS = 1, GR_STAT_RES_MAX_WGS = 2, GR_STAT_RES_LAUNCHES = 3, GR_STAT_RES_HANDSHAKE_MISSES = 4, GR_STAT_RES_ABORTS = 5, GR_STAT_RES_REDONE_FRAMES = 6, GR_STAT_RES_LAST_STREAMS = 7,
+       GR_STAT_RMSD_FAST_FRAMES = 8 /* frames of RMSD-without-fit calls closed by the f32-chain pass (GR_TUNE_RMSD_FAST) */,
+       GR_STAT_RMSD_EXACT_REDOS = 9 /* ... and frames that pass handed back to the exact-product pass */ };
 int gr_ctx_stat(const gr_ctx *ctx, int key, uint64_t *value);
 
 /* ---------------------------------------------------------------- text front end: gro structures, ndx index groups (host side)
