@@ -150,6 +150,34 @@ __device__ __forceinline__ float gr_lane_f(unsigned long long v, int l) { return
 __device__ __forceinline__ void gr_lds_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); }
 __device__ __forceinline__ void gr_lds_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local"); }
 
+// Frame rows through BUFFER loads: the frame's slot is a buffer resource (its base a wave-uniform pointer, its size the slot's),
+// the lane's rows 32-bit byte offsets into it.  What that buys the streaming loop is loads WITHOUT CONDITIONS: a turn that does not
+// exist gets a resource of zero records, a group that does not exist an offset beyond every slot -- the hardware's bounds check
+// returns zeros and touches no memory.  With `if (turn exists) load` / `if (group B exists) load` the compiler has to merge loaded
+// and not-loaded values where the branches join, does it with register copies, and waits for the loads it has just issued in
+// order to copy them (round 4 found `s_waitcnt vmcnt(3)` + six moves right behind the row request of every other turn).
+typedef int gr_i4 __attribute__((ext_vector_type(4)));
+#define GR_BUF_NOWHERE 0xFFFFF000u      /* byte offset of a group that does not exist: out of range of every slot (+ 2 KiB of row offsets) */
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t gr_buf_rsrc(const void *base, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float4 gr_buf_load_stream(__amdgpu_buffer_rsrc_t r, uint32_t byte_off) {
+    const gr_i4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 2 /* nt */);
+    return make_float4(__int_as_float(v.x), __int_as_float(v.y), __int_as_float(v.z), __int_as_float(v.w));
+}
+// the fitted rows leave as agent-scope non-temporal stores (sc1 nt): measured on a persistent copy of this launch shape
+// (tools/store_variants.hip, three runs): 4.31-4.35 us per 1e6-atom frame against 4.45-4.49 with plain non-temporal stores
+#ifndef GR_RES_STORE_AUX
+#define GR_RES_STORE_AUX 18        /* 1 sc0, 2 nt, 16 sc1 */
+#endif
+__device__ __forceinline__ void gr_buf_store_stream(__amdgpu_buffer_rsrc_t r, uint32_t byte_off, const float4 &v) {
+    gr_i4 t; t.x = __float_as_int(v.x); t.y = __float_as_int(v.y); t.z = __float_as_int(v.z); t.w = __float_as_int(v.w);
+    __builtin_amdgcn_raw_buffer_store_b128(t, r, (int)byte_off, 0, GR_RES_STORE_AUX);
+}
+__device__ __forceinline__ float gr_buf_load_f32(__amdgpu_buffer_rsrc_t r, uint32_t byte_off) {
+    return __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, 0));
+}
+
 // one 4-atom group of a lane: which of its atoms belong to the selection, its reference rows, masses and weights (registers)
 // (the per-lane facts are bits of ONE register: seven `bool`s would be seven 64-bit lane masks -- 14 SGPRs per group held
 // across the whole loop, and the kernel was spilling SGPRs into vector lanes)
@@ -202,7 +230,7 @@ __device__ __forceinline__ void gr_res_image_pair(gr_v2f &vx, gr_v2f &vy, gr_v2f
 // wrap(x + shift) - box centre, rotate, (sum w |R q - p|^2), + reference COM: the arithmetic of k_fit_pk for one group
 template <bool WMASS>
 __device__ __forceinline__ void gr_res_fit_group(const GrResGroup &Gr, const float4 &r0, const float4 &r1, const float4 &r2, const GrResRot &T, const GrBoxU &B,
-                                                 const GrBox *__restrict__ boxp, float cx, float cy, float cz, float4 *__restrict__ f4, float &rs) {
+                                                 const GrBox *__restrict__ boxp, float cx, float cy, float cz, __amdgpu_buffer_rsrc_t out, float &rs) {
     GrP4 q = gr_pairs_rows(r0, r1, r2);
     q.x01 += gr_v2(T.sx); q.y01 += gr_v2(T.sy); q.z01 += gr_v2(T.sz); q.x23 += gr_v2(T.sx); q.y23 += gr_v2(T.sy); q.z23 += gr_v2(T.sz);
     gr_wrap_pair_fast(q.x01, q.y01, q.z01, B);
@@ -234,7 +262,7 @@ __device__ __forceinline__ void gr_res_fit_group(const GrResGroup &Gr, const flo
     n.x01 += gr_v2(cx); n.y01 += gr_v2(cy); n.z01 += gr_v2(cz); n.x23 += gr_v2(cx); n.y23 += gr_v2(cy); n.z23 += gr_v2(cz);
     float4 o0, o1, o2;
     gr_rows_pairs(n, o0, o1, o2);
-    gr_stream_store(f4 + Gr.b, o0); gr_stream_store(f4 + Gr.b + 64, o1); gr_stream_store(f4 + Gr.b + 128, o2);
+    gr_buf_store_stream(out, Gr.b * 16u, o0); gr_buf_store_stream(out, Gr.b * 16u + 1024u, o1); gr_buf_store_stream(out, Gr.b * 16u + 2048u, o2);
 }
 
 // UBOX: every frame of the launch has the same box (the host compared them): its constants are loaded once, not per frame.
@@ -468,12 +496,16 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
 
     struct Rows { float4 r0, r1, r2; };
     struct Landing { Rows a, b; float gx, gy, gz; };
+    // (unconditional: a turn behind the stream's last one reads a resource of zero records, a missing group B an offset nowhere)
+    const uint32_t slot_bytes = (uint32_t)(frame_stride * sizeof(float));
+    const uint32_t offA = GA.b * 16u, offB = GB.valid ? GB.b * 16u : GR_BUF_NOWHERE;
+    const uint32_t offgx = (uint32_t)gr_tile_index(first, 0) * 4u, offgy = (uint32_t)gr_tile_index(first, 1) * 4u, offgz = (uint32_t)gr_tile_index(first, 2) * 4u;
     auto request = [&](uint32_t k, Landing &L) {
-        const float *xyz = frames + (size_t)(first_slot + kf(k)) * frame_stride;
-        const float4 *f4 = reinterpret_cast<const float4 *>(xyz);
-        L.a.r0 = gr_stream_load(f4 + GA.b); L.a.r1 = gr_stream_load(f4 + GA.b + 64); L.a.r2 = gr_stream_load(f4 + GA.b + 128);
-        if (GB.valid) { L.b.r0 = gr_stream_load(f4 + GB.b); L.b.r1 = gr_stream_load(f4 + GB.b + 64); L.b.r2 = gr_stream_load(f4 + GB.b + 128); }
-        gr_pos_load(xyz, first, L.gx, L.gy, L.gz);                    // provisional centre: the first atom of the selection
+        const bool live = k < n_turns;
+        const __amdgpu_buffer_rsrc_t rs = gr_buf_rsrc(frames + (size_t)(first_slot + (live ? kf(k) : 0u)) * frame_stride, live ? slot_bytes : 0u);
+        L.a.r0 = gr_buf_load_stream(rs, offA); L.a.r1 = gr_buf_load_stream(rs, offA + 1024u); L.a.r2 = gr_buf_load_stream(rs, offA + 2048u);
+        L.b.r0 = gr_buf_load_stream(rs, offB); L.b.r1 = gr_buf_load_stream(rs, offB + 1024u); L.b.r2 = gr_buf_load_stream(rs, offB + 2048u);
+        L.gx = gr_buf_load_f32(rs, offgx); L.gy = gr_buf_load_f32(rs, offgy); L.gz = gr_buf_load_f32(rs, offgz);   // provisional centre: the first atom of the selection
     };
     auto request_rec = [&](uint32_t k) -> unsigned long long { return lane < 16u ? gr_ld_agent(ctl.rec + (size_t)kf(k) * 16 + lane) : 0ull; };
     bool bail = false;
@@ -621,7 +653,7 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
     };
 
     // V fit of one group: R v + t0, sum w |R q - p|^2 (rmsd.rs:592-599; pad atoms weigh nothing), + reference COM
-    auto fit_group_v = [&](const GrResGroup &Gr, const Rows &rw, const GrResRot &T, float t0x, float t0y, float t0z, float4 *__restrict__ f4, float &rs) {
+    auto fit_group_v = [&](const GrResGroup &Gr, const Rows &rw, const GrResRot &T, float t0x, float t0y, float t0z, __amdgpu_buffer_rsrc_t out, float &rs) {
         const GrP4 v = gr_pairs_rows(rw.r0, rw.r1, rw.r2);
         GrP4 n;
         n.x01 = gr_v2_fma(gr_v2(T.r02), v.z01, gr_v2_fma(gr_v2(T.r01), v.y01, gr_v2_fma(gr_v2(T.r00), v.x01, gr_v2(t0x))));
@@ -644,35 +676,56 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
 #ifdef GR_EXP_NOSTORE
         if (o0.x == 1.2345e30f)   // (experiment: no stores; the condition keeps the arithmetic alive)
 #endif
-        { gr_stream_store(f4 + Gr.b, o0); gr_stream_store(f4 + Gr.b + 64, o1); gr_stream_store(f4 + Gr.b + 128, o2); }
+        { gr_buf_store_stream(out, Gr.b * 16u, o0); gr_buf_store_stream(out, Gr.b * 16u + 1024u, o1); gr_buf_store_stream(out, Gr.b * 16u + 2048u, o2); }
     };
 
     // ---- the fit stage of frame j: `rv` = the frame's record as requested earlier (lanes 0..15); rows / image vectors as they were parked.
+    // The record was requested one turn ago -- BEFORE this turn's row request -- so the common case (it has arrived) needs only "all but
+    // the loads issued since".  The compiler can count that only when the first look is not the head of the polling loop (whose
+    // re-requests are younger than everything: a merged loop head waits for vmcnt(0), i.e. for the rows just requested) and when the
+    // record is taken apart into scalars on each path separately (a register read behind the join inherits the slow path's wait).
+    struct Rec { int status; float sx, sy, sz, r00, r10, r20, r01, r11, r21, r02, r12, r22, t0x, t0y, t0z; };
+    auto take = [&](unsigned long long rv) {
+        Rec r;
+        r.status = __builtin_amdgcn_readlane((int)(uint32_t)rv, 0);
+        r.sx = gr_lane_f(rv, 1); r.sy = gr_lane_f(rv, 2); r.sz = gr_lane_f(rv, 3);
+        r.r00 = gr_lane_f(rv, 4); r.r10 = gr_lane_f(rv, 5); r.r20 = gr_lane_f(rv, 6); r.r01 = gr_lane_f(rv, 7); r.r11 = gr_lane_f(rv, 8); r.r21 = gr_lane_f(rv, 9);
+        r.r02 = gr_lane_f(rv, 10); r.r12 = gr_lane_f(rv, 11); r.r22 = gr_lane_f(rv, 12);
+        r.t0x = gr_lane_f(rv, 13); r.t0y = gr_lane_f(rv, 14); r.t0z = gr_lane_f(rv, 15);
+        return r;
+    };
     auto fit = [&](uint32_t j, unsigned long long rv, const Rows &ra, const Rows &rb, const GrBoxU &B) {
-        uint32_t polls = 0;
-        unsigned long long t0 = 0ull;
-        while (__builtin_amdgcn_ballot_w64(lane < 16u && (uint32_t)(rv >> 32) != ctl.epoch) != 0ull) {
+        Rec rec;
+        if (__builtin_amdgcn_ballot_w64(lane < 16u && (uint32_t)(rv >> 32) != ctl.epoch) == 0ull) {
+            rec = take(rv);
+            asm volatile("; record had arrived");
+        } else {
+            uint32_t polls = 0;
+            const unsigned long long t0 = wall_clock64();
             __builtin_amdgcn_s_setprio(0);                             // a wave that is ahead waits below the waves it shares the SIMD with
-            if (polls == 0) t0 = wall_clock64();                       // (only a wave that has to wait reads the clock)
-            if (++polls > GR_RES_PATIENCE || ((polls & 255u) == 0 && (gr_ld_agent(ctl.abort) != 0u || wall_clock64() - t0 > ctl.patience_ticks))) { if (lane == 0) gr_st_agent(ctl.abort, 1u); bail = true; return; }
-            __builtin_amdgcn_s_sleep(GR_RES_SLEEP);
-            rv = request_rec(j);
+            do {
+                if (++polls > GR_RES_PATIENCE || ((polls & 255u) == 0 && (gr_ld_agent(ctl.abort) != 0u || wall_clock64() - t0 > ctl.patience_ticks))) { if (lane == 0) gr_st_agent(ctl.abort, 1u); bail = true; return; }
+                __builtin_amdgcn_s_sleep(GR_RES_SLEEP);
+                rv = request_rec(j);
+            } while (__builtin_amdgcn_ballot_w64(lane < 16u && (uint32_t)(rv >> 32) != ctl.epoch) != 0ull);
+            rec = take(rv);
+            asm volatile("; record polled for");
         }
         set_prio();
-        const int status = __builtin_amdgcn_readlane((int)(uint32_t)rv, 0);
+        const int status = rec.status;
         float rs = 0.0f;
         if (status == 0) {
             GrResRot T;
-            T.r00 = gr_lane_f(rv, 4); T.r10 = gr_lane_f(rv, 5); T.r20 = gr_lane_f(rv, 6); T.r01 = gr_lane_f(rv, 7); T.r11 = gr_lane_f(rv, 8); T.r21 = gr_lane_f(rv, 9);
-            T.r02 = gr_lane_f(rv, 10); T.r12 = gr_lane_f(rv, 11); T.r22 = gr_lane_f(rv, 12);
-            float4 *f4 = reinterpret_cast<float4 *>(frames + (size_t)(first_slot + kf(j)) * frame_stride);
+            T.r00 = rec.r00; T.r10 = rec.r10; T.r20 = rec.r20; T.r01 = rec.r01; T.r11 = rec.r11; T.r21 = rec.r21;
+            T.r02 = rec.r02; T.r12 = rec.r12; T.r22 = rec.r22;
+            const __amdgpu_buffer_rsrc_t f4 = gr_buf_rsrc(frames + (size_t)(first_slot + kf(j)) * frame_stride, slot_bytes);
             if (V) {
-                const float t0x = gr_lane_f(rv, 13), t0y = gr_lane_f(rv, 14), t0z = gr_lane_f(rv, 15);
+                const float t0x = rec.t0x, t0y = rec.t0y, t0z = rec.t0z;
                 T.sx = T.sy = T.sz = 0.f;
                 fit_group_v(GA, ra, T, t0x, t0y, t0z, f4, rs);
                 if (GB.valid) fit_group_v(GB, rb, T, t0x, t0y, t0z, f4, rs);
             } else {
-                T.sx = gr_lane_f(rv, 1); T.sy = gr_lane_f(rv, 2); T.sz = gr_lane_f(rv, 3);
+                T.sx = rec.sx; T.sy = rec.sy; T.sz = rec.sz;
                 const GrBox *boxp = boxes + first_slot + kf(j);
                 gr_res_fit_group<WMASS>(GA, ra.r0, ra.r1, ra.r2, T, B, boxp, cx, cy, cz, f4, rs);
                 if (GB.valid) gr_res_fit_group<WMASS>(GB, rb.r0, rb.r1, rb.r2, T, B, boxp, cx, cy, cz, f4, rs);
@@ -726,7 +779,7 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
 #ifdef GR_EXP_NOLOAD
         if (i < 2) request(i + 1, nxt);
 #elif !defined(GR_EXP_LATE_REQUEST)
-        if (i + 1 < n_turns) request(i + 1, nxt);
+        request(i + 1, nxt);
 #endif
         balance(i);
         // both boxes of the iteration are requested here (scalar loads): they arrive while the record is checked
@@ -743,7 +796,7 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
         }
         if (i + 1 >= K && i + 1 < n_iter) rv = request_rec(i + 1 - K);
 #ifdef GR_EXP_LATE_REQUEST
-        if (i + 1 < n_turns) request(i + 1, nxt);               // (experiment: the next frame's rows requested after this step's stores)
+        request(i + 1, nxt);                                    // (experiment: the next frame's rows requested after this step's stores)
 #endif
         if (i < n_turns) {
             if (V) sums(i, cur, Bs, va, vb);                    // (the slot's old content has been read by the fit above)

@@ -124,6 +124,45 @@ __global__ __launch_bounds__(LANES) void k_rcopy_pipelined(float *frames, float 
     if (MODE == 1 && acc == 0x12345678) dst_frames[0] = (float)acc;
 }
 
+// ---- deeper prefetch: D frames ahead with D + 1 named register sets, the loop unrolled by D + 1 (compile-time rotation, no copies).
+// How much of the persistent shape's deficit against a grid-launched copy is bytes in flight per CU?  (8 waves x 6 KB one frame
+// ahead = 48 KB per CU; a grid launch keeps 32 waves x 3 KB = 96 KB in flight.)
+template <int D>
+__global__ __launch_bounds__(512) void k_rcopy_deep(float *frames, size_t stride, uint32_t nframes, uint32_t ngroups, int lag) {
+    const uint32_t base = blockIdx.x * 1024;
+    uint32_t off[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) { const uint32_t g = base + q * 512 + threadIdx.x; off[q] = g < ngroups ? ((g >> 6) * 192 + (g & 63)) * 16u : 0xFFFFF000u; }
+    const uint32_t fbytes = (uint32_t)(stride * 4);
+    i4v R[D + 1][2][3];
+    auto load = [&](uint32_t f, i4v (&X)[2][3]) {
+        const bool live = f < nframes;
+        __amdgpu_buffer_rsrc_t s = GR_RSRC(frames + (size_t)(live ? f : 0u) * stride, live ? fbytes : 0u);
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int r = 0; r < 3; ++r) X[q][r] = __builtin_amdgcn_raw_buffer_load_b128(s, off[q] + 1024 * r, 0, 2);
+    };
+    auto store = [&](uint32_t i, i4v (&X)[2][3]) {
+        if (i >= nframes) return;
+        const uint32_t it = i >= (uint32_t)lag ? i - lag : i + nframes - lag;
+        __amdgpu_buffer_rsrc_t d = GR_RSRC(frames + (size_t)it * stride, fbytes);
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int r = 0; r < 3; ++r) { X[q][r] = touch_i(X[q][r]); __builtin_amdgcn_raw_buffer_store_b128(X[q][r], d, off[q] + 1024 * r, 0, 2); }
+    };
+#pragma unroll
+    for (int d = 0; d < D; ++d) load(d, R[d]);
+    for (uint32_t i = 0; i < nframes; i += D + 1) {
+#pragma unroll
+        for (int u = 0; u <= D; ++u) {
+            load(i + u + D, R[(u + D) % (D + 1)]);
+            store(i + u, R[u]);
+        }
+    }
+}
+
 int main(int argc, char **argv) {
     const uint32_t frames = argc > 1 ? (uint32_t)atoi(argv[1]) : 256u;
     const uint32_t n_big = 1048576u;
@@ -205,6 +244,24 @@ int main(int argc, char **argv) {
             printf(",\n  {\"kernel\": \"%s\", \"n_atoms\": %u, \"workgroups\": %u, \"us_per_frame\": %.3f, \"us_per_frame_mean\": %.3f, \"us_per_1e6_atoms\": %.3f, \"hbm_GBs\": %.0f}",
                    c.name, n1, wgs, us, us_mean, us, c.bytes * n1 / (us * 1e-6) / 1e9);
         }
+    }
+    for (int D = 1; D <= 4; ++D) {
+        const uint32_t ngroups = ((n1 + 255) / 256) * 64;
+        float best = 1e30f;
+        const uint32_t fr = frames - frames % (D + 1);
+        for (int rep = 0; rep < 7; ++rep) {
+            CHECK(hipEventRecord(e0));
+            if (D == 1) k_rcopy_deep<1><<<245, 512>>>(F, stride, fr, ngroups, 6);
+            else if (D == 2) k_rcopy_deep<2><<<245, 512>>>(F, stride, fr, ngroups, 6);
+            else if (D == 3) k_rcopy_deep<3><<<245, 512>>>(F, stride, fr, ngroups, 6);
+            else k_rcopy_deep<4><<<245, 512>>>(F, stride, fr, ngroups, 6);
+            CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+            float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+            if (rep > 0 && ms < best) best = ms;
+        }
+        const double us = 1e3 * best / fr;
+        printf(",\n  {\"kernel\": \"pipelined copy, %d frames ahead (245 x 512 x 2, lag 6)\", \"n_atoms\": %u, \"workgroups\": 245, \"us_per_frame\": %.3f, \"us_per_1e6_atoms\": %.3f, \"hbm_GBs\": %.0f}",
+               D, n1, us, us, 24.0 * n1 / (us * 1e-6) / 1e9);
     }
     printf("\n]}\n");
     return 0;
