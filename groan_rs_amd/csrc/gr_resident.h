@@ -230,7 +230,7 @@ __device__ __forceinline__ void gr_res_image_pair(gr_v2f &vx, gr_v2f &vy, gr_v2f
 // wrap(x + shift) - box centre, rotate, (sum w |R q - p|^2), + reference COM: the arithmetic of k_fit_pk for one group
 template <bool WMASS>
 __device__ __forceinline__ void gr_res_fit_group(const GrResGroup &Gr, const float4 &r0, const float4 &r1, const float4 &r2, const GrResRot &T, const GrBoxU &B,
-                                                 const GrBox *__restrict__ boxp, float cx, float cy, float cz, __amdgpu_buffer_rsrc_t out, float &rs) {
+                                                 const GrBox *__restrict__ boxp, float cx, float cy, float cz, float4 &o0, float4 &o1, float4 &o2, float &rs) {
     GrP4 q = gr_pairs_rows(r0, r1, r2);
     q.x01 += gr_v2(T.sx); q.y01 += gr_v2(T.sy); q.z01 += gr_v2(T.sz); q.x23 += gr_v2(T.sx); q.y23 += gr_v2(T.sy); q.z23 += gr_v2(T.sz);
     gr_wrap_pair_fast(q.x01, q.y01, q.z01, B);
@@ -260,9 +260,7 @@ __device__ __forceinline__ void gr_res_fit_group(const GrResGroup &Gr, const flo
         rs += part.x + part.y;
     }
     n.x01 += gr_v2(cx); n.y01 += gr_v2(cy); n.z01 += gr_v2(cz); n.x23 += gr_v2(cx); n.y23 += gr_v2(cy); n.z23 += gr_v2(cz);
-    float4 o0, o1, o2;
-    gr_rows_pairs(n, o0, o1, o2);
-    gr_buf_store_stream(out, Gr.b * 16u, o0); gr_buf_store_stream(out, Gr.b * 16u + 1024u, o1); gr_buf_store_stream(out, Gr.b * 16u + 2048u, o2);
+    gr_rows_pairs(n, o0, o1, o2);                     // (stored by the caller: unconditionally, see `fit`)
 }
 
 // UBOX: every frame of the launch has the same box (the host compared them): its constants are loaded once, not per frame.
@@ -653,7 +651,7 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
     };
 
     // V fit of one group: R v + t0, sum w |R q - p|^2 (rmsd.rs:592-599; pad atoms weigh nothing), + reference COM
-    auto fit_group_v = [&](const GrResGroup &Gr, const Rows &rw, const GrResRot &T, float t0x, float t0y, float t0z, __amdgpu_buffer_rsrc_t out, float &rs) {
+    auto fit_group_v = [&](const GrResGroup &Gr, const Rows &rw, const GrResRot &T, float t0x, float t0y, float t0z, Rows &o, float &rs) {
         const GrP4 v = gr_pairs_rows(rw.r0, rw.r1, rw.r2);
         GrP4 n;
         n.x01 = gr_v2_fma(gr_v2(T.r02), v.z01, gr_v2_fma(gr_v2(T.r01), v.y01, gr_v2_fma(gr_v2(T.r00), v.x01, gr_v2(t0x))));
@@ -671,12 +669,7 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
             rs += part.x + part.y;
         }
         n.x01 += gr_v2(cx); n.y01 += gr_v2(cy); n.z01 += gr_v2(cz); n.x23 += gr_v2(cx); n.y23 += gr_v2(cy); n.z23 += gr_v2(cz);
-        float4 o0, o1, o2;
-        gr_rows_pairs(n, o0, o1, o2);
-#ifdef GR_EXP_NOSTORE
-        if (o0.x == 1.2345e30f)   // (experiment: no stores; the condition keeps the arithmetic alive)
-#endif
-        { gr_buf_store_stream(out, Gr.b * 16u, o0); gr_buf_store_stream(out, Gr.b * 16u + 1024u, o1); gr_buf_store_stream(out, Gr.b * 16u + 2048u, o2); }
+        gr_rows_pairs(n, o.r0, o.r1, o.r2);
     };
 
     // ---- the fit stage of frame j: `rv` = the frame's record as requested earlier (lanes 0..15); rows / image vectors as they were parked.
@@ -714,22 +707,36 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
         set_prio();
         const int status = rec.status;
         float rs = 0.0f;
+        Rows oa, ob;
+        oa.r0 = oa.r1 = oa.r2 = ob.r0 = ob.r1 = ob.r2 = zero4;
         if (status == 0) {
             GrResRot T;
             T.r00 = rec.r00; T.r10 = rec.r10; T.r20 = rec.r20; T.r01 = rec.r01; T.r11 = rec.r11; T.r21 = rec.r21;
             T.r02 = rec.r02; T.r12 = rec.r12; T.r22 = rec.r22;
-            const __amdgpu_buffer_rsrc_t f4 = gr_buf_rsrc(frames + (size_t)(first_slot + kf(j)) * frame_stride, slot_bytes);
             if (V) {
                 const float t0x = rec.t0x, t0y = rec.t0y, t0z = rec.t0z;
                 T.sx = T.sy = T.sz = 0.f;
-                fit_group_v(GA, ra, T, t0x, t0y, t0z, f4, rs);
-                if (GB.valid) fit_group_v(GB, rb, T, t0x, t0y, t0z, f4, rs);
+                fit_group_v(GA, ra, T, t0x, t0y, t0z, oa, rs);
+                if (GB.valid) fit_group_v(GB, rb, T, t0x, t0y, t0z, ob, rs);
             } else {
                 T.sx = rec.sx; T.sy = rec.sy; T.sz = rec.sz;
                 const GrBox *boxp = boxes + first_slot + kf(j);
-                gr_res_fit_group<WMASS>(GA, ra.r0, ra.r1, ra.r2, T, B, boxp, cx, cy, cz, f4, rs);
-                if (GB.valid) gr_res_fit_group<WMASS>(GB, rb.r0, rb.r1, rb.r2, T, B, boxp, cx, cy, cz, f4, rs);
+                gr_res_fit_group<WMASS>(GA, ra.r0, ra.r1, ra.r2, T, B, boxp, cx, cy, cz, oa.r0, oa.r1, oa.r2, rs);
+                if (GB.valid) gr_res_fit_group<WMASS>(GB, rb.r0, rb.r1, rb.r2, T, B, boxp, cx, cy, cz, ob.r0, ob.r1, ob.r2, rs);
             }
+        }
+        // The six stores are issued on EVERY path -- a frame that was not closed gets a resource of zero records, a group B that does
+        // not exist the offset nowhere: the hardware drops them -- so that the number of memory operations between the row request of
+        // this turn and the first use of those rows (next turn's sums stage) is the same whatever happened here, and the compiler's
+        // s_waitcnt before that use is exact instead of a lower bound that drains part of the prefetch.
+        {
+#ifdef GR_EXP_NOSTORE
+            const __amdgpu_buffer_rsrc_t out = gr_buf_rsrc(frames + (size_t)(first_slot + kf(j)) * frame_stride, 0u);
+#else
+            const __amdgpu_buffer_rsrc_t out = gr_buf_rsrc(frames + (size_t)(first_slot + kf(j)) * frame_stride, status == 0 ? slot_bytes : 0u);
+#endif
+            gr_buf_store_stream(out, offA, oa.r0); gr_buf_store_stream(out, offA + 1024u, oa.r1); gr_buf_store_stream(out, offA + 2048u, oa.r2);
+            gr_buf_store_stream(out, offB, ob.r0); gr_buf_store_stream(out, offB + 1024u, ob.r1); gr_buf_store_stream(out, offB + 2048u, ob.r2);
         }
         n_fitted = j + 1u;
         // the workgroup's share of sum w |R q - p|^2: the lane's eight atoms in f32, the wave in f32 (no LDS crossbar), waves in fp64
@@ -794,7 +801,9 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
             fit(i - K, rv, lds_get(ps), qb, Bf);
             if (bail) return;
         }
-        if (i + 1 >= K && i + 1 < n_iter) rv = request_rec(i + 1 - K);
+        // (unconditional -- the record of the stream's first frame when there is nothing to fit next turn: an `if` here makes the new
+        // value depend on the old register, and the compiler waits for the rows just requested before it reads that)
+        rv = request_rec(i + 1 >= K && i + 1 < n_iter ? i + 1 - K : 0u);
 #ifdef GR_EXP_LATE_REQUEST
         request(i + 1, nxt);                                    // (experiment: the next frame's rows requested after this step's stores)
 #endif

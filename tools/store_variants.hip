@@ -83,6 +83,10 @@ int main(int argc, char **argv) {
     if (run<1, 2>("sc0", F, stride, frames, ngroups, e0, e1, first)) return 1;
     if (run<18, 2>("sc1 nt", F, stride, frames, ngroups, e0, e1, first)) return 1;
     if (run<3, 2>("sc0 nt", F, stride, frames, ngroups, e0, e1, first)) return 1;
+    if (run<18, 18>("sc1 nt (loads sc1 nt)", F, stride, frames, ngroups, e0, e1, first)) return 1;
+    if (run<18, 19>("sc1 nt (loads sc0 sc1 nt)", F, stride, frames, ngroups, e0, e1, first)) return 1;
+    if (run<18, 3>("sc1 nt (loads sc0 nt)", F, stride, frames, ngroups, e0, e1, first)) return 1;
+    if (run<18, 16>("sc1 nt (loads sc1)", F, stride, frames, ngroups, e0, e1, first)) return 1;
     if (run<2, 0>("nt (loads plain)", F, stride, frames, ngroups, e0, e1, first)) return 1;
     if (run<2, 17>("nt (loads sc0 sc1)", F, stride, frames, ngroups, e0, e1, first)) return 1;
     if (run<2, 19>("nt (loads sc0 sc1 nt)", F, stride, frames, ngroups, e0, e1, first)) return 1;
