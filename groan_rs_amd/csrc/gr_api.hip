@@ -293,10 +293,19 @@ uint32_t resident_wgs(gr_ctx *c, bool lite, uint32_t nb, const GrSel &sel, uint3
     while (s_max > 1 && s_max * wgs + resident_finalizers_needed((uint32_t)wgs, (uint32_t)s_max) > c->res_max_wgs) s_max--;
     if (c->resident == 1) s_max = std::min<uint64_t>(s_max, nb / 16u);
     else s_max = std::min<uint64_t>(s_max, nb);
+    // ONE stream of a frame that fills between a half and two thirds of the chip (510-700 k atoms on MI355X: two of them do not fit):
+    // cut into workgroups of 768 groups -- three group-units per SIMD instead of four -- the frame spreads over a third more CUs
+    // and a turn gets shorter with it.  Measured (profiles/r04_hole_sweep.txt, frames/s, two passes / 1024 / 768): 520 k atoms
+    // 274 k / 281 k / 291 k, 600 k 242 k / 271 k / 278 k, 650 k 229 k / 268 k / 273 k, 690 k 212 k / 265 k / 267 k.
+    uint64_t wgs_used = wgs;
+    if (c->resident == 1 && !c->res_wg_groups && s_max <= 1 && wgs <= 170) {
+        const uint64_t w768 = (groups + 767) / 768;
+        if (w768 + 2 <= c->res_max_wgs && w768 <= GR_MAX_CHUNKS) { wgs_used = w768; *groups_wg = 768; }
+    }
     // the pass costs the same per turn whatever the frame's size (every CU runs its 4096 atoms' worth or idles): it only beats
     // the two passes, whose time shrinks with the frame, when the streams together fill enough of the chip (measured,
     // profiles/r03_size_sweep.txt: + 3 % at 0.67 of the chip, - 8 % at 0.57; the default asks for 10/16)
-    if (c->resident == 1 && (s_max == 0 || s_max * wgs * 16 < (uint64_t)c->res_max_wgs * (uint64_t)c->res_fill16)) return 0;
+    if (c->resident == 1 && (s_max == 0 || s_max * wgs_used * 16 < (uint64_t)c->res_max_wgs * (uint64_t)c->res_fill16)) return 0;
     // ... and when the segment is long enough to pay for filling and draining the six-frame pipeline (measured at 16 frames per
     // call: 9.8 us per frame against 10.6 for the two passes; single frames are a chain of waits)
     if (c->resident == 1 && nb < 16) return 0;
@@ -310,7 +319,7 @@ uint32_t resident_wgs(gr_ctx *c, bool lite, uint32_t nb, const GrSel &sel, uint3
     // segments -- twice as many after every miss in a row -- instead of giving the pass up for good (gr_ctx_stat counts the misses)
     if (c->res_skip) { c->res_skip--; return 0; }
     *streams = (uint32_t)s_max;
-    return (uint32_t)wgs;
+    return (uint32_t)wgs_used;
 }
 
 // One resident launch at a time per device and process: its workgroups wait for one another, so two of them sharing the CUs could

@@ -149,7 +149,10 @@ def test_frames_that_fill_a_fraction_of_the_chip_run_as_streams_by_default(G, n,
     cur.profile_enable(True)
     r2, st2 = plan.rmsd_fit(0, 16 * streams - 1)
     prof = cur.profile_read()
-    still = (streams - 1) * ((n + 4095) // 4096) * 16 >= cur.stat("res_max_wgs") * 10
+    wgs_less = (n + 4095) // 4096
+    if streams - 1 == 1 and wgs_less <= 170:          # ONE stream of a frame that fills half of the chip: workgroups of 768 groups (gr_api.hip resident_wgs)
+        wgs_less = ((n + 255) // 256 * 64 + 767) // 768
+    still = (streams - 1) * wgs_less * 16 >= cur.stat("res_max_wgs") * 10
     assert (st2 == 0).all() and (prof["k_fit_resident"][1] == 1) == still and (prof["k_fit_pk"][1] > 0) == (not still), prof
     assert not still or cur.stat("res_last_streams") == streams - 1
     assert np.abs(np.asarray(r2) - np.asarray(r)[:16 * streams - 1]).max() <= 2e-6
