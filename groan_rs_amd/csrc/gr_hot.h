@@ -59,6 +59,7 @@ struct GrSumsPk {
     gr_v2f m, mx, my, mz;                 // sum m, sum m v
     gr_v2f a[9];                          // A = sum p v^T (unweighted, rmsd.rs:567-570)
     gr_v2f f1a, f1b, f1c, f2a, f2b, f2c;  // first / second moments of the fractional coordinates of v
+    gr_v2f f3a, f3b, f3c;                 // third moments (NOREF, get_center / get_com: they pin the Bai-Breen estimate to within ~1e-3 of the mean)
     float mn[3], mx3[3], fmn[3], fmx[3];  // Cartesian and fractional extents of v
 };
 
@@ -99,6 +100,7 @@ __device__ __forceinline__ void gr_sums_pair(GrSumsPk &S, gr_v2f x, gr_v2f y, gr
     const gr_v2f fa = gr_v2_fma(-fc, gr_v2(B.cx), gr_v2_fma(-fb, gr_v2(B.bx), vx)) * gr_v2(B.iax);
     S.f1a += fa; S.f1b += fb; S.f1c += fc;
     S.f2a = gr_v2_fma(fa, fa, S.f2a); S.f2b = gr_v2_fma(fb, fb, S.f2b); S.f2c = gr_v2_fma(fc, fc, S.f2c);
+    if (NOREF) { S.f3a = gr_v2_fma(fa * fa, fa, S.f3a); S.f3b = gr_v2_fma(fb * fb, fb, S.f3b); S.f3c = gr_v2_fma(fc * fc, fc, S.f3c); }
     S.fmn[0] = gr_min3f(S.fmn[0], fa.x, fa.y); S.fmn[1] = gr_min3f(S.fmn[1], fb.x, fb.y); S.fmn[2] = gr_min3f(S.fmn[2], fc.x, fc.y);
     S.fmx[0] = gr_max3f(S.fmx[0], fa.x, fa.y); S.fmx[1] = gr_max3f(S.fmx[1], fb.x, fb.y); S.fmx[2] = gr_max3f(S.fmx[2], fc.x, fc.y);
     S.mn[0] = gr_min3f(S.mn[0], vx.x, vx.y); S.mn[1] = gr_min3f(S.mn[1], vy.x, vy.y); S.mn[2] = gr_min3f(S.mn[2], vz.x, vz.y);
@@ -151,7 +153,7 @@ __global__ __launch_bounds__(GR_WG) void k_sums_pk(
     S.m = S.mx = S.my = S.mz = gr_v2(0.0f);
 #pragma unroll
     for (int k = 0; k < 9; ++k) S.a[k] = gr_v2(0.0f);
-    S.f1a = S.f1b = S.f1c = S.f2a = S.f2b = S.f2c = gr_v2(0.0f);
+    S.f1a = S.f1b = S.f1c = S.f2a = S.f2b = S.f2c = S.f3a = S.f3b = S.f3c = gr_v2(0.0f);
 #pragma unroll
     for (int a = 0; a < 3; ++a) { S.mn[a] = S.fmn[a] = 3.0e38f; S.mx3[a] = S.fmx[a] = -3.0e38f; }
     GrRmsdPk Rm;
@@ -260,6 +262,7 @@ __global__ __launch_bounds__(GR_WG) void k_sums_pk(
     for (int k = 0; k < 9; ++k) s32[4 + k] = S.a[k].x + S.a[k].y;
     s32[13] = S.f1a.x + S.f1a.y; s32[14] = S.f1b.x + S.f1b.y; s32[15] = S.f1c.x + S.f1c.y;
     s32[16] = S.f2a.x + S.f2a.y; s32[17] = S.f2b.x + S.f2b.y; s32[18] = S.f2c.x + S.f2c.y;
+    if (NOREF) { s32[19] = S.f3a.x + S.f3a.y; s32[20] = S.f3b.x + S.f3b.y; s32[21] = S.f3c.x + S.f3c.y; }
 #pragma unroll
     for (int k = 0; k < 3; ++k) { e32[k] = -S.mn[k]; e32[3 + k] = S.mx3[k]; e32[6 + k] = -S.fmn[k]; e32[9 + k] = S.fmx[k]; }
     const float tot = gr_wave_sum_scatter32(s32, lane);
@@ -277,6 +280,7 @@ __global__ __launch_bounds__(GR_WG) void k_sums_pk(
         // slots 13..25: B (Hw before the centring), sum w |v|^2, sum w v -- the closed-form RMSD's sums; unused (zero) by the two-pass fit
         double v = 0.0;
         if (RMSD) { const uint32_t q = lane - 19; v = ((lds_pd[q] + lds_pd[16 + q]) + lds_pd[32 + q]) + lds_pd[48 + q]; }
+        else if (NOREF && lane < 22) v = (double)wsum[lane] + (double)wsum[48 + lane] + (double)wsum[96 + lane] + (double)wsum[144 + lane];   // third moments: slots 13..15
         gr_st_agent(&o.s[lane - 6], v);
     } else if (lane < 44) {
         const uint32_t q = lane - 32;

@@ -711,10 +711,26 @@ __device__ inline void gr_finalize_math(const double *acc, const float mn[3], co
             double T = TWO_PI * TWO_PI * (acc[29 + a] - nsel * mu[a] * mu[a]);
             if (T < 0) T = 0;
             T *= 1.0 + 1e-4; T += 1e-3;                       // f32 rounding of the two moments
-            const double Theta = TWO_PI * E * (1.0 + 1e-6);
+            // |theta_i| = 2 pi |f_i - mu| <= 2 pi max(fmax - mu, mu - fmin): the larger distance of mu from the two ends of the extent, not the
+            // whole extent (rounds 1-3 used the extent: twice the bound for a symmetric group, hence twice the radius eps and -- in
+            // get_com / get_center below -- twice as many frames whose periodic copy had to be settled by the estimate pass)
+            const double dev = fmax((double)fmx[a] - mu[a], mu[a] - (double)fmn[a]) + 1.0e-6;
+            const double Theta = TWO_PI * (dev < E ? dev : E) * (1.0 + 1e-6);
             const double den = nsel - 0.5 * T;
             if (!(E < 0.4999) || !(den > 0.0)) { ok = false; eps[a] = 0; continue; }
             eps[a] = (Theta * T / 6.0) / den / TWO_PI;        // atan(x) <= x for x >= 0: a (slightly) larger, still rigorous radius
+            if (NOREF && LITE) {
+                // get_center / get_com carry the THIRD central moment too (k_sums_pk<true>): sin x = x - x^3 / 6 + r, |r| <= |x|^5 / 120, so
+                //   |sum sin theta_i| <= (2 pi)^3 |M3| / 6 + Theta^3 T / 120,     M3 = sum (f_i - mu)^3
+                // -- for a roughly symmetric group M3 ~ 0 and the radius shrinks from ~Theta T / 6 to ~Theta^3 T / 120 (a blob of 0.4
+                // cell widths: 1.3e-2 -> 1e-3), and with it the share of frames whose periodic copy the estimate pass has to settle.
+                // The moments are f32 lane sums: 1e-4 of every raw term is added as their rounding (generous by orders of magnitude).
+                const double s1 = acc[26 + a], s2 = acc[29 + a], s3 = acc[13 + a], m = mu[a];
+                const double m3 = s3 - 3.0 * m * s2 + 3.0 * m * m * s1 - nsel * m * m * m;
+                const double m3e = 1.0e-4 * (fabs(s3) + 3.0 * fabs(m) * s2 + 3.0 * m * m * fabs(s1) + nsel * fabs(m * m * m)) + 1.0e-6;
+                const double e3 = (TWO_PI * TWO_PI * TWO_PI * (fabs(m3) + m3e) / 6.0 + Theta * Theta * Theta * T / 120.0) / den / TWO_PI;
+                if (e3 < eps[a]) eps[a] = e3;
+            }
         }
         // centre candidate in Cartesian coordinates and the radius of the region c' is confined to
         const double ce[3] = { mu[0] * b.ax + mu[1] * b.bx + mu[2] * b.cx, mu[1] * b.by + mu[2] * b.cy, mu[2] * b.cz };
@@ -871,6 +887,9 @@ __device__ __forceinline__ void gr_finalize_frame_lite(const GrAccPartial *parti
         if (RMSD) {
 #pragma unroll
             for (int k = 0; k < 13; ++k) s[19 + k] += p.s[13 + k];
+        } else if (NOREF) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) s[19 + k] += p.s[13 + k];      // third moments of the fractional coordinates
         }
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
@@ -894,6 +913,7 @@ __device__ __forceinline__ void gr_finalize_frame_lite(const GrAccPartial *parti
     for (int k = 0; k < 13; ++k) acc[k] = tot[k];
     for (int k = 0; k < 6; ++k) acc[26 + k] = tot[13 + k];
     if (RMSD) for (int k = 0; k < 13; ++k) acc[13 + k] = tot[19 + k];
+    else if (NOREF) for (int k = 0; k < 3; ++k) acc[13 + k] = tot[19 + k];
     const float mn[3] = { -ext[0], -ext[1], -ext[2] }, mx[3] = { ext[3], ext[4], ext[5] };
     const float fmn[3] = { -ext[6], -ext[7], -ext[8] }, fmx[3] = { ext[9], ext[10], ext[11] };
     const float *xyz = frames + (size_t)(first_slot + frame) * frame_stride;
@@ -1328,7 +1348,12 @@ __global__ __launch_bounds__(GR_WG) void k_pairdist_sym(
     float *__restrict__ out, size_t out_stride, uint32_t *__restrict__ bad_out) {
     // T x T tile: T / 4 column groups (a lane holds 4 column atoms) x 1024 / T row groups; the mirror image is staged H = 64 rows
     // at a time; a lane walks T / H phases x G groups of 4 rows
-    constexpr uint32_t T = GR_PDS_T, CG = T / 4, RG = GR_WG / CG, H = 64, PH = T / H, G = H / RG / 4, LD = H + 4;
+    // The mirror image in LDS is XOR-SWIZZLED by quads: element (column j, row quad q) lives at tt[j][4 (q ^ (j >> 2 & 15))].  A wave
+    // writes one quad of 64 different columns (16 column groups x 4 row groups): with a plain or padded row stride (round 3: H + 4)
+    // the 16-byte writes of lanes that share a row group land on two alternating sets of four banks -- 87.7 M bank-conflict cycles
+    // per config-3 launch (profiles/r03_pmc_pairdist_sym.txt) -- with the swizzle the eight lanes of a pass cover all 32 banks,
+    // and the row-wise reads (16 lanes x 16 bytes of one row) stay a permutation of one contiguous 256-byte row.
+    constexpr uint32_t T = GR_PDS_T, CG = T / 4, RG = GR_WG / CG, H = 64, PH = T / H, G = H / RG / 4, LD = H;
     static_assert(GR_WG == 256 && (T == 128 || T == 64), "tile shape");
     const uint32_t bi = blockIdx.y, bj = blockIdx.x;
     if (bi > bj) return;                                   // below the diagonal: written by the tile above it
@@ -1397,7 +1422,7 @@ __global__ __launch_bounds__(GR_WG) void k_pairdist_sym(
                 }
                 if (!diag) {
 #pragma unroll
-                    for (uint32_t c = 0; c < 4; ++c) *reinterpret_cast<float4 *>(&tt[4u * cg + c][rl]) = make_float4(m[0][c], m[1][c], m[2][c], m[3][c]);
+                    for (uint32_t c = 0; c < 4; ++c) *reinterpret_cast<float4 *>(&tt[4u * cg + c][4u * ((rl >> 2) ^ (cg & 15u))]) = make_float4(m[0][c], m[1][c], m[2][c], m[3][c]);
                 }
             }
             __syncthreads();
@@ -1407,7 +1432,7 @@ __global__ __launch_bounds__(GR_WG) void k_pairdist_sym(
                     const uint32_t jr = p * 16u + (tid >> 4), seg = tid & 15u;
                     const uint32_t jg = bj * T + jr, ig = i0 + H * h + 4u * seg;
                     if (jg < n) {
-                        const float4 v = *reinterpret_cast<const float4 *>(&tt[jr][4u * seg]);
+                        const float4 v = *reinterpret_cast<const float4 *>(&tt[jr][4u * (seg ^ ((jr >> 2) & 15u))]);
                         float *dst = out + (size_t)jg * n + ig;
                         if (vec_ok && ig + 3 < n) gr_stream_store(reinterpret_cast<float4 *>(dst), v);
                         else { if (ig < n) dst[0] = v.x; if (ig + 1 < n) dst[1] = v.y; if (ig + 2 < n) dst[2] = v.z; if (ig + 3 < n) dst[3] = v.w; }

@@ -134,7 +134,10 @@ def test_centre_on_a_cell_face_takes_the_copy_the_estimate_selects(G, bname):
     s.group_create_from_ranges("G", [(0, n - 1)])
     idx = np.arange(n)
     for cf in ([1.0 - 1e-5, 0.5, 0.5], [1e-5, 1.0 - 2e-5, 0.5], [3e-6, 1.0 - 3e-6, 1e-6], [0.0, 0.0, 0.0], [0.5, 0.99999, 0.00001]):
-        pos = O.wrap_atoms(cluster(rng, n, box, cf, 0.25), idx, box)
+        raw = cluster(rng, n, box, cf, 0.25).astype(np.float64)
+        boxm = np.array([[box[0], 0, 0], [box[5], box[1], 0], [box[7], box[8], box[2]]], np.float64)
+        raw += np.asarray(cf, np.float64) @ boxm - raw.mean(axis=0)               # the SAMPLE mean on the face (the proof's radius is ~3e-4 cell widths
+        pos = O.wrap_atoms(raw.astype(np.float32), idx, box)                      # since round 4's third-moment bound: a sample mean 5e-4 off is no longer ambiguous)
         fb0 = s.center_fallbacks()
         s.set_frame(pos, box)
         for weighted in (True, False):
