@@ -4,7 +4,7 @@
 # Summaries land in gpurun_out/prof_<tag>/; copy the ones to be judged into profiles/.
 set -o pipefail
 TAG=${1:-r01}
-ARGS=${2:-"--steps 3 --warmup 1 --no-cpu-baseline"}
+ARGS=${2:-"--steps 3 --warmup 1 --warmup-seconds 0 --no-cpu-baseline"}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
