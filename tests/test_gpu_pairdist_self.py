@@ -57,9 +57,24 @@ def test_self_matrix_is_the_bits_of_the_plain_kernel_and_the_oracle(G, cell, n):
         elif cell == "ortho" or dim == "XYZ":
             np.testing.assert_allclose(a, want, atol=2e-6, rtol=0, err_msg=dim)
         else:
-            # components of the 3-D minimum image: pairs whose two best images tie to rounding may pick either one
-            ok = np.abs(a - want) <= 2e-6
-            assert ok.mean() > 0.999, (dim, ok.mean())
+            # components of the 3-D minimum image: a pair whose two best images tie to rounding may pick either one.  Every entry that
+            # differs from the oracle's is therefore checked on its own against an fp64 search over 7 x 7 x 7 lattice images that
+            # shares nothing with the library or the oracle: the entry must be the requested component(s) of SOME image whose length
+            # is within 1e-5 nm of the shortest one (round 3 tolerated 0.1 % of the entries without looking at them)
+            off = np.argwhere(np.abs(a - want) > 2e-6)
+            assert off.shape[0] <= a.size // 200, (dim, off.shape[0])
+            if off.shape[0]:
+                Lm = np.array([[box[0], 0, 0], [box[5], box[1], 0], [box[7], box[8], box[2]]], np.float64)
+                rng3 = np.arange(-3, 4)
+                imgs = np.array([(i, j, k) for i in rng3 for j in rng3 for k in rng3], np.float64) @ Lm
+                p64 = pos.astype(np.float64)
+                axes = ["XYZ".index(ch) for ch in dim]
+                for (i, j) in off:
+                    e = p64[idx[i]] - p64[idx[j]] + imgs                       # distance(x_i, x_j): the vector from j to i, every image
+                    ln = np.linalg.norm(e, axis=1)
+                    near = e[ln <= ln.min() + 1e-5]
+                    val = near[:, axes[0]] if len(axes) == 1 else np.linalg.norm(near[:, axes], axis=1)
+                    assert near.shape[0] >= 2 and np.abs(val - float(a[i, j])).min() <= 2e-6, (dim, int(i), int(j), float(a[i, j]), float(want[i, j]), val, ln.min())
         if len(dim) == 1:
             assert np.array_equal(a, -a.T), dim                 # signed: D[j][i] = -D[i][j]
         else:
