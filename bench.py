@@ -262,6 +262,23 @@ def main():
                 break
     except Exception:
         pass
+    # ... and the arithmetic-free PROBE of the same shape measured NOW, on this box, by a child process beside the (idle) frame pool:
+    # the persistent copy of the resident pass's address stream (tools/ceiling_resident.hip --quick, warmed up, as many frames per
+    # launch as this run's launches; built by __graft_entry__.build()).  Round 3's ratio used a committed figure from another box.
+    # It is a probe, not a bound: from box to box it reads 4.3-4.65 us per 1e6-atom frame while the pass itself stays at 4.32-4.35,
+    # so the ratio may exceed 1 (a copy issues its loads and stores in bursts; the pass spreads them over its arithmetic).  Never fatal.
+    copy_floor_live = None
+    if rank == 0 and dom == "k_fit_resident":
+        try:
+            exe = os.path.join(ROOT, "tools", "bin", "ceiling_resident")
+            if os.path.isfile(exe):
+                cp = subprocess.run([exe, "--quick", str(n), str(int(frames / max(launches, 1)))], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=120,
+                                    env=dict(os.environ, HIP_VISIBLE_DEVICES=os.environ.get("HIP_VISIBLE_DEVICES", str(dev)) if world == 1 else str(dev)))
+                line = [ln for ln in cp.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]
+                if cp.returncode == 0 and line:
+                    copy_floor_live = json.loads(line[-1])
+        except Exception:
+            copy_floor_live = None
     us_per_frame_dom = 1e3 * ms_total / max(frames, 1)
     moved = traffic if traffic is not None else bytes_per_launch
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -271,6 +288,9 @@ def main():
                 "hbm_moved_source": "PMC (%s)" % traffic_src if traffic is not None else "bytes that have to move (no PMC pass of this launch shape is committed)",
                 "copy_floor_us_per_frame": copy_floor_us, "copy_floor_source": copy_floor_src,
                 "frac_of_copy_floor": round(copy_floor_us / us_per_frame_dom, 4) if copy_floor_us and us_per_frame_dom > 0 else None,
+                "copy_floor_live": copy_floor_live,
+                "frac_of_copy_floor_live": (round(copy_floor_live["persistent_copy_us_per_frame_stores_sc1_nt"] / us_per_frame_dom, 4)
+                                            if copy_floor_live and us_per_frame_dom > 0 else None),
                 "us_per_frame": round(us_per_frame_dom, 4),
                 "avg_launch_ms": round(avg_ms, 4), "launches": launches, "frames_per_launch": frames / max(launches, 1),
                 "algorithmic_bytes_per_launch": bytes_per_launch,

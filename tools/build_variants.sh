@@ -3,7 +3,7 @@
 # (built in parallel; run them on the GPU box with tools/ab_bench.sh <tag> tools/bin/ab_*.so)
 cd "$(dirname "$0")/../groan_rs_amd/csrc" || exit 1
 mkdir -p ../../tools/bin
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wall -Wno-unused-function -fno-fast-math"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wall -Wno-unused-function -fno-fast-math -fno-slp-vectorize"
 for SPEC in "$@"; do
   NAME=${SPEC%%:*}; DEFS=${SPEC#*:}
   [ "$NAME" = "$SPEC" ] && DEFS=""

@@ -77,7 +77,7 @@ __global__ __launch_bounds__(LANES) void k_rcopy(const float *src, float *dst, s
 typedef int i4v __attribute__((ext_vector_type(4)));
 #define GR_RSRC(ptr, bytes) __builtin_amdgcn_make_buffer_rsrc((void *)(ptr), 0, (int)(bytes), 0x00020000)
 __device__ __forceinline__ i4v touch_i(i4v v) { v.x += 1; v.y ^= 3; v.z += 5; v.w ^= 7; return v; }
-template <int LANES, int MODE>
+template <int LANES, int MODE, int STORE_AUX = 2>
 __global__ __launch_bounds__(LANES) void k_rcopy_pipelined(float *frames, float *dst_frames, size_t stride, uint32_t nframes, uint32_t ngroups, int lag) {
     const uint32_t base = blockIdx.x * LANES * 2;
     uint32_t off[2];
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(LANES) void k_rcopy_pipelined(float *frames, float 
 #pragma unroll
         for (int q = 0; q < 2; ++q)
 #pragma unroll
-            for (int r = 0; r < 3; ++r) { R[q][r] = touch_i(R[q][r]); __builtin_amdgcn_raw_buffer_store_b128(R[q][r], d, off[q] + 1024 * r, 0, 2); }
+            for (int r = 0; r < 3; ++r) { R[q][r] = touch_i(R[q][r]); __builtin_amdgcn_raw_buffer_store_b128(R[q][r], d, off[q] + 1024 * r, 0, STORE_AUX); }
     };
     int acc = 0;
     auto fold = [&](i4v (&R)[2][3]) {
@@ -163,7 +163,47 @@ __global__ __launch_bounds__(512) void k_rcopy_deep(float *frames, size_t stride
     }
 }
 
+// --quick [atoms] : the two rows bench.py wants from the SAME box and process tree as its own line -- the persistent copy of the resident
+// pass's shape (waits written out, one frame of prefetch, stores six frames behind) with the stores the pass uses (sc1 nt) and with plain
+// nt stores; as many frames per launch as the bench's own launches walk (768 by default: the floor rises with the footprint), best of 5 launches
+static int quick(uint32_t n, uint32_t frames) {
+    const uint32_t ntiles = (n + 255) / 256, ngroups = ntiles * 64;
+    const size_t stride = (size_t)ntiles * 768;
+    float *F;
+    CHECK(hipMalloc(&F, stride * frames * sizeof(float)));
+    CHECK(hipMemset(F, 0, stride * frames * sizeof(float)));
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    const uint32_t wgs = (ngroups + 1023) / 1024;
+    double us[2] = { 0, 0 };
+    {   // a device that has been idle runs its first tenths of a second slow (clocks): warm up for ~0.6 s before anything is timed
+        float total = 0.f;
+        while (total < 600.f) {
+            CHECK(hipEventRecord(e0));
+            k_rcopy_pipelined<512, 0, 18><<<wgs, 512>>>(F, F, stride, frames, ngroups, 6);
+            CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+            float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+            total += ms > 0.f ? ms : 1.f;
+        }
+    }
+    for (int v = 0; v < 2; ++v) {
+        float best = 1e30f;
+        for (int rep = 0; rep < 6; ++rep) {
+            CHECK(hipEventRecord(e0));
+            if (v == 0) k_rcopy_pipelined<512, 0, 18><<<wgs, 512>>>(F, F, stride, frames, ngroups, 6);
+            else k_rcopy_pipelined<512, 0, 2><<<wgs, 512>>>(F, F, stride, frames, ngroups, 6);
+            CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+            float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+            if (rep > 0 && ms < best) best = ms;
+        }
+        us[v] = 1e3 * best / frames;
+    }
+    printf("{\"n_atoms\": %u, \"frames_per_launch\": %u, \"workgroups\": %u, \"persistent_copy_us_per_frame_stores_sc1_nt\": %.4f, \"persistent_copy_us_per_frame_stores_nt\": %.4f}\n", n, frames, wgs, us[0], us[1]);
+    return 0;
+}
+
 int main(int argc, char **argv) {
+    if (argc > 1 && !strcmp(argv[1], "--quick")) return quick(argc > 2 ? (uint32_t)atoi(argv[2]) : 1000000u, argc > 3 ? (uint32_t)atoi(argv[3]) & ~1u : 768u);
     const uint32_t frames = argc > 1 ? (uint32_t)atoi(argv[1]) : 256u;
     const uint32_t n_big = 1048576u;
     const uint32_t ntiles_big = n_big / 256;
