@@ -1931,16 +1931,21 @@ static int segment_end(gr_rmsd_plan *p, float *rmsd_out, int *status_out, float 
                 f0 = f1;
             }
         }
-        // frames whose single-pass image proof failed are redone on the exact path, one by one
-        for (uint32_t f = 0; f < nb; ++f) {
-            if (res[f].status != GR_ST_FALLBACK) continue;
-            if (!redo.empty() && redo[f]) continue;          // (closed by the nested segment above, its own fallbacks included)
-            p->last_fallbacks++;
-            SlotUse use(c, s0 + f);
-            int st = state_reset(c, 1); if (st) return st;
-            st = rmsd_exact(p, c, sel, s0 + f, 1, fit); if (st) return st;
-            st = fetch_states(c, 1); if (st) return st;
-            res[f] = c->state_host[0];
+        // frames whose single-pass image proof failed are redone on the exact (literal multi-pass) path -- in RUNS of consecutive frames,
+        // one set of launches and one read-back per run: a group that spans the cell in some direction (a membrane) fails the proof in
+        // EVERY frame, and frame-by-frame redo (rounds 1-3) turned such a trajectory into a per-frame loop of six launches and a wait
+        for (uint32_t f0 = 0; f0 < nb; ) {
+            if (res[f0].status != GR_ST_FALLBACK || (!redo.empty() && redo[f0])) { ++f0; continue; }   // (redo[]: closed by the nested segment above, its own fallbacks included)
+            uint32_t f1 = f0;
+            while (f1 < nb && res[f1].status == GR_ST_FALLBACK && (redo.empty() || !redo[f1])) ++f1;
+            const uint32_t nf = f1 - f0;
+            p->last_fallbacks += nf;
+            SlotUse use(c, s0 + f0, nf);
+            int st = state_reset(c, nf); if (st) return st;
+            st = rmsd_exact(p, c, sel, s0 + f0, nf, fit); if (st) return st;
+            st = fetch_states(c, nf); if (st) return st;
+            for (uint32_t f = f0; f < f1; ++f) res[f] = c->state_host[f - f0];
+            f0 = f1;
         }
         for (uint32_t f = 0; f < nb; ++f) {
             int s = res[f].status;

@@ -357,3 +357,38 @@ def test_aborted_launch_whose_redone_run_holds_a_proof_failing_frame(G, whole, n
         assert abs(float(r[f]) - want[f][0]) <= 1e-5, (f, float(r[f]), want[f][0])
         assert np.abs(cur.get_positions(f) - want[f][1]).max() <= 5e-5, f
     plan.close(); ref.close(); cur.close()
+
+
+@pytest.mark.parametrize("mode", [0, 2])
+def test_a_group_that_spans_the_cell_fails_the_proof_in_every_frame(G, mode):
+    """a membrane-like slab -- the whole cell in x and y -- is wider than half the box in EVERY frame: every frame of the call is handed to
+    the literal multi-pass path, which now takes them in runs (one set of launches per run of consecutive frames, not six launches
+    and a wait per frame: 89 -> 4.8 us per frame at 2e5 atoms, tools/wide_group_bench.py).  Two-pass path and forced resident launch;
+    RMSD, rotation-free parity of the fitted coordinates, statuses; a frame without a position in the middle of the run"""
+    n, nf = 30_000, 9
+    box = W.box_from_lengths_angles([8.0, 8.0, 6.0], [90.0, 90.0, 90.0])
+    rng = np.random.default_rng(12)
+    base = np.c_[rng.random(n) * 8.0, rng.random(n) * 8.0, 2.0 + rng.random(n) * 2.0]
+    masses = W.masses_cycle(n)
+    frames = [W.wrap_into_cell(base + rng.normal(0, 0.04, base.shape) + rng.uniform(0, 8, 3) * [1, 1, 0.2], box) for _ in range(nf)]
+    frames[4] = frames[4].copy(); frames[4][777] = np.nan
+    ref_pos = base.astype(np.float32)
+    ref = G.System(n, masses=masses, box=box, positions=ref_pos)
+    cur = G.System(n, masses=masses, n_slots=nf)
+    plan = G.RMSDPlan(ref, cur, "all")
+    cur.set_tuning(resident=mode)
+    idx = np.arange(n)
+    for fit in (False, True):
+        for f in range(nf):
+            cur.set_frame(frames[f], box, slot=f)
+        r, st = (plan.rmsd_fit if fit else plan.rmsd)(0, nf, raise_on_error=False)
+        assert [f for f in range(nf) if st[f] != 0] == [4], st
+        assert plan.last_fallbacks() == nf, plan.last_fallbacks()              # (the frame without a position poisons its sums: the literal path names the atom)
+        with O.acc64():
+            for f in (0, 3, 5, nf - 1):
+                ro, want = O.calc_rmsd_and_fit(ref_pos, masses, idx, box, frames[f], masses, idx, box)
+                assert abs(float(r[f]) - ro) <= 1e-5, (fit, f, float(r[f]), ro)
+                got = cur.get_positions(f)
+                assert np.abs(got - (want if fit else frames[f])).max() <= 5e-5, (fit, f)
+        assert np.array_equal(np.nan_to_num(cur.get_positions(4), nan=-1.0), np.nan_to_num(frames[4], nan=-1.0))
+    plan.close(); ref.close(); cur.close()
