@@ -48,6 +48,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--warmup-seconds", type=float, default=0.5, help="the warm-up lasts at least this long: after the --warmup steps "
                     "their slots are fitted again (results discarded) until the device has run this long")
+    ap.add_argument("--box-per-frame", action="store_true", help="a slightly different box in every frame (a constant-pressure trajectory): "
+                    "the kernels read the box per frame instead of once per launch; NOT the headline configuration")
     ap.add_argument("--atoms", type=int, default=1_000_000)
     ap.add_argument("--frames-per-step", type=int, default=0, help="0 = the largest multiple of 256 (<= 1024) for which every frame "
                     "of warmup + timed steps is a distinct buffer inside --max-pool-gb")
@@ -148,6 +150,9 @@ def main():
     t_gen = time.time()
     trace("synthesising %d frames" % pool)
     cur.synth_frames(pool, 0, pool, rank, 0.05, SEED, frame_index_stride=world)
+    if args.box_per_frame:
+        for f in range(pool):
+            cur.set_box(WL.c4_box(24.18 * (1.0 + 2.0e-4 * ((f * 7) % 11 - 5))), slot=f)
     cur.sync()
     trace("frames ready")
     t_gen = time.time() - t_gen
@@ -308,7 +313,7 @@ def main():
         "vs_baseline": None, "dtype": "f32 (fp64 accumulators)", "data": "synthetic",
         "config": {"workload": "synthetic %d-atom rhombic-dodecahedral (triclinic) frames resident in HBM, Kabsch RMSD-fit of all atoms "
                                "(BASELINE configs[3] shard per GPU)" % n,
-                   "n_atoms": n, "frames_per_step": B, "frames_per_gpu": K * B, "selection": "all atoms", "box9": [float(x) for x in box],
+                   "n_atoms": n, "box_per_frame": bool(args.box_per_frame), "frames_per_step": B, "frames_per_gpu": K * B, "selection": "all atoms", "box9": [float(x) for x in box],
                    "pool_frames": pool, "reused_frames": reused, "parallelism": "frames round-robin over %d GPU(s), final RCCL gather (%s)" % (world, "gr_comm_gather_per_frame" if abi_comm is not None else "torch.distributed all_gather"),
                    "fallback_frames": fallbacks, "synth_seconds": round(t_gen, 2), "warmup_seconds": round(t_warm, 3), "warmup_extra_steps_on_warmup_slots": warm_extra, "step_ms": step_ms,
                    "per_rank_frames_per_s": [round(v, 1) for v in per_rank_fps]},

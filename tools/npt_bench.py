@@ -27,6 +27,12 @@ for kind in ("same box", "box per frame", "same box", "box per frame"):
             s.set_box(boxes[f], slot=f)
         t_box = time.perf_counter() - t0
     s.sync()
+    # (setting 768 boxes keeps the host busy for 11 ms and the device idle: warm it up again on a scratch copy of the plan's work --
+    # the first version of this script timed a cold launch and read 4.7-4.9 us for a box per frame against 4.4; `bench.py
+    # --box-per-frame`, which warms up for 0.5 s, shows 4.358 against 4.357)
+    t_w = time.perf_counter()
+    while time.perf_counter() - t_w < 0.4:
+        s.group_center_batch("all", G._lib.CENTER_NAIVE, 1, 0, 256)
     s.profile_enable(True)
     t0 = time.perf_counter(); r, st = plan.rmsd_fit(0, NF); dt = time.perf_counter() - t0
     prof = s.profile_read()
