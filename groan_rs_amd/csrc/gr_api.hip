@@ -314,7 +314,11 @@ uint32_t resident_wgs(gr_ctx *c, bool lite, uint32_t nb, const GrSel &sel, uint3
     // (a frame's record needs all of them), and with a partial selection the workgroups that hold it run sums AND the literal fit
     // arithmetic while the others only fit: measured at 1e6 atoms with a tenth of them selected, 6.3 us per frame against 4.5 for
     // the two passes, whose sums pass shrinks with the selection (profiles/r03_secondary.json)
-    if (c->resident == 1 && (uint64_t)sel.n * 10 < c->n * 9) return 0;
+    // Round 4, with the pass's waits fixed (profiles/r04_selection.json, 1e6 atoms, us per frame, two passes / resident): 90 % of the atoms
+    // selected 6.53 / 5.10, 70 % 6.00 / 5.11, 50 % 5.50 / 5.16, 40 % 5.26 / 5.24, 30 % 5.05 / 5.27, 10 % 4.66 / 5.30 -- the pass is flat
+    // (every workgroup streams and fits whatever it holds of the selection), the two passes shrink with the selection: the
+    // cross-over lies at ~40 %, the default takes the pass from 45 % (round 3: from 90 %)
+    if (c->resident == 1 && (uint64_t)sel.n * 100 < c->n * 45) return 0;
     // a launch that missed its start handshake (the device was busy with somebody else's kernels) makes the context sit out a few
     // segments -- twice as many after every miss in a row -- instead of giving the pass up for good (gr_ctx_stat counts the misses)
     if (c->res_skip) { c->res_skip--; return 0; }

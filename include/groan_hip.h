@@ -259,7 +259,7 @@ int gr_rmsd_plan_force_exact(gr_rmsd_plan *plan, int on);
  *   GR_TUNE_TWO_PASS   1 (default): RMSD-fit = sums pass + fit pass that evaluates the rmsd; 0: closed-form single-pass rmsd
  *   GR_TUNE_RESIDENT   RMSD-fit as ONE pass over HBM, the frame waiting on chip for its rotation (gr_resident.h: one launch per
  *                      segment whose workgroups wait for one another; needs n_atoms <= ~1.04e6 on MI355X).  1 (default): when the
- *                      frames in flight (GR_TUNE_RESIDENT_STREAMS) fill at least 10/16 of the chip, the selection is at least 9/10
+ *                      frames in flight (GR_TUNE_RESIDENT_STREAMS) fill at least 10/16 of the chip, the selection is at least 45 %
  *                      of the system and every stream gets 16 frames of the call or more; 0: never; 2: whenever it
  *                      fits.  One such launch runs per device and process at a time (a context that finds the device taken uses
  *                      the two-pass path); a launch whose workgroups do not all get onto the chip (a device shared with another

@@ -77,7 +77,7 @@ def test_headline_shape_default_tuning_all_atoms(G):
 
 @pytest.mark.parametrize("forced", [False, True])
 def test_headline_shape_prefix_selection(G, forced):
-    """SURVEY 8(d)'s S = 1e5 prefix variant at full size.  By default a selection of less than 9/10 of the system takes the two
+    """SURVEY 8(d)'s S = 1e5 prefix variant at full size.  By default a selection of less than 45 % of the system takes the two
     passes (the resident pass advances at the pace of the workgroups that hold the selection: 6.3 us per frame against 4.5);
     forced (GR_TUNE_RESIDENT = 2) it runs the row-parking kernel variant: the first 25 workgroups carry the selection (the last
     of them a ragged end inside a lane's 4-atom group), the other 220 skip the sums arithmetic and only stream + fit"""
@@ -91,7 +91,7 @@ def test_headline_shape_prefix_selection(G, forced):
 
 
 def test_nearly_whole_selection_takes_the_row_parking_variant(G):
-    """a selection of more than 9/10 of the system that is not the whole system: resident by default, kernel variant V = false"""
+    """a selection of more than 45 % of the system that is not the whole system: resident by default, kernel variant V = false"""
     nf = 24
     box, masses, cur, ref, ref_pos, plan = _c4(G, N, nf, sel=(1_000, N - 3))
     prof, _ = _check(cur, plan, ref_pos, masses, np.arange(1_000, N - 2), box, [box] * nf, nf, [0, 7, nf - 1])
@@ -204,4 +204,17 @@ def test_headline_shape_with_frames_whose_image_proof_fails(G):
             assert abs(float(r[f]) - ro) <= 1e-5, (f, f in bad, float(r[f]), ro)
             got = cur.get_positions(f)
             assert np.abs(got - want).max() <= 5e-5, (f, f in bad, float(np.abs(got - want).max()))
+    plan.close(); ref.close(); cur.close()
+
+
+@pytest.mark.parametrize("frac,resident", [(0.60, True), (0.30, False)])
+def test_selection_fraction_decides_between_the_pass_and_the_two_passes(G, frac, resident):
+    """the resident pass costs the same whatever share of the atoms is selected, the two passes shrink with the selection; the
+    cross-over lies at ~40 % (profiles/r04_selection.json) and the default takes the pass from 45 %: a 60 % prefix runs
+    k_fit_resident<.., V = false>, a 30 % prefix the two passes; both against the oracle"""
+    nf = 24
+    s_last = int(frac * N) - 2
+    box, masses, cur, ref, ref_pos, plan = _c4(G, N, nf, sel=(0, s_last))
+    prof, _ = _check(cur, plan, ref_pos, masses, np.arange(s_last + 1), box, [box] * nf, nf, [0, 7, nf - 1])
+    assert (prof["k_fit_resident"][1] == 1) == resident and (prof["k_fit_pk"][1] > 0) == (not resident), prof
     plan.close(); ref.close(); cur.close()
