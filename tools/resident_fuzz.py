@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised soak of the resident RMSD-fit pass on the GPU box: system sizes from 3 000 to 1 000 000 atoms, 1-200 frames per call,
-forced and automatic numbers of frame streams, whole and nearly-whole selections, orthorhombic / triclinic / dodecahedral cells, a
+forced and automatic numbers of frame streams, whole, nearly-whole and 45-98 % selections, orthorhombic / triclinic / dodecahedral cells, a
 box per frame now and then, a frame without a position now and then -- every call compared with the two-pass path on the same
 frames (rmsd to 2e-6 nm, fitted coordinates to 2e-5 nm, statuses equal).  Prints one line per case; exit status 1 on a mismatch.
 
@@ -34,7 +34,14 @@ while time.time() < t_end:
     scale = (n / 20_000.0) ** (1.0 / 3.0)
     box = W.box_from_lengths_angles([x * scale for x in l], a)
     whole = bool(rng.integers(0, 2))
-    sel = (0, n - 1) if whole else (int(rng.integers(0, max(1, n // 30))), n - 1 - int(rng.integers(0, max(1, n // 30))))
+    if whole:
+        sel = (0, n - 1)
+    elif rng.integers(0, 2):
+        sel = (int(rng.integers(0, max(1, n // 30))), n - 1 - int(rng.integers(0, max(1, n // 30))))      # nearly the whole system
+    else:
+        m = int(n * rng.uniform(0.45, 0.98))                                                              # 45 .. 98 % of it, anywhere (the default takes the pass from 45 %)
+        a0 = int(rng.integers(0, n - m + 1))
+        sel = (a0, a0 + m - 1)
     masses = W.masses_cycle(n)
     cur = G.System(n, masses=masses, n_slots=nf + 1)
     cur.synth_reference(nf, box, 0.2 * float(min(box[:3])), 7 + case)
