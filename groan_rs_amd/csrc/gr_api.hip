@@ -83,6 +83,7 @@ struct gr_ctx {
     size_t fit_partials_cap = 0;
     int two_pass = 1;                 // GR_TUNE_TWO_PASS 0: RMSD-fit keeps the closed-form single-pass rmsd (k_rmsd_accum<0>)
     int rmsd_fast = 1;                // GR_TUNE_RMSD_FAST 0: the RMSD without fit always takes the exact-product pass (k_rmsd_accum<0>)
+    int rmsd_fast_sigmas = 6;         // GR_TUNE_RMSD_FAST_SIGMAS: multiples of the closing step's rounding estimate a frame's rmsd must stand clear of (0: no guard, calibration only)
     uint32_t rmsd_fast_min = 16384;   // GR_TUNE_RMSD_FAST_MIN: smallest contiguous mass-weighted selection that takes k_sums_pk<false, true>
     uint64_t rmsd_fast_frames = 0, rmsd_exact_redos = 0;   // frames closed by the f32-chain pass / handed back to the exact-product pass
     // resident RMSD fit (gr_resident.h): one launch per segment, the frame waits on chip for its rotation
@@ -1600,6 +1601,7 @@ int gr_ctx_set_tuning(gr_ctx *c, int key, int64_t value) try {
     case GR_TUNE_RESIDENT: if (value < 0 || value > 2) break; c->resident = value; return GR_OK;
     case GR_TUNE_RMSD_FAST: if (value != 0 && value != 1) break; c->rmsd_fast = (int)value; return GR_OK;
     case GR_TUNE_RMSD_FAST_MIN: if (value < 0 || value > 0x7fffffff) break; c->rmsd_fast_min = (uint32_t)value; return GR_OK;
+    case GR_TUNE_RMSD_FAST_SIGMAS: if (value < 0 || value > 1000) break; c->rmsd_fast_sigmas = (int)value; return GR_OK;
     case GR_TUNE_PAIRDIST_SYMMETRIC: if (value != 0 && value != 1) break; c->pd_sym = (int)value; return GR_OK;
     case GR_TUNE_RESIDENT_WG_GROUPS: if (value != 0 && (value < 64 || value > GR_RES_GROUPS || value % 64 != 0)) break; c->res_wg_groups = (int)value; return GR_OK;
     case GR_TUNE_RESIDENT_STREAMS: if (value < 0 || value > GR_RES_MAX_STREAMS) break; c->res_streams = (int)value; return GR_OK;
@@ -1680,6 +1682,7 @@ static int segment_begin(gr_rmsd_plan *p, uint32_t s0, uint32_t nb, int fit) {
         // are handed back (GR_ST_REDO_EXACT) and redone below by the exact-product pass that every other selection takes
         const bool fast = !fit && sel.contiguous && c->two_pass && c->rmsd_fast && p->dev.w_is_mass != 0 && g->n >= c->rmsd_fast_min;
         q.rmsd_fast = fast;
+        p->dev.fast_sigmas = (float)c->rmsd_fast_sigmas;
         const uint32_t n_groups = (nb + sb - 1) / sb;
         if (lite) {
             size_t need = 0;
