@@ -42,7 +42,9 @@ struct Group {
     bool contiguous = true;
     uint32_t start = 0;
     uint32_t *idx_dev = nullptr;
-    uint32_t *mask_dev = nullptr;     // one bit per atom of the system (group-limited trajectory reads), built on first use
+    uint32_t *mask_dev = nullptr;     // one bit per atom of the system (group-limited trajectory reads: built on first use; masked selections: built with the group)
+    bool masked = false;              // non-contiguous but DENSE (>= 1/8 of its span, >= 4096 atoms): the sums kernels walk the span with this mask
+    uint32_t span = 0;                // atoms from the first to the last selected one
 };
 
 }  // namespace
@@ -82,6 +84,7 @@ struct gr_ctx {
     double *fit_partials = nullptr;   // [frames of a segment][fit workgroups per frame]: sum w |R q - p|^2 of k_fit<true>
     size_t fit_partials_cap = 0;
     int two_pass = 1;                 // GR_TUNE_TWO_PASS 0: RMSD-fit keeps the closed-form single-pass rmsd (k_rmsd_accum<0>)
+    int masked_sel = 1;               // GR_TUNE_MASKED_SELECTIONS 0: dense scattered selections keep to their gather lists (groups built afterwards)
     int rmsd_fast = 1;                // GR_TUNE_RMSD_FAST 0: the RMSD without fit always takes the exact-product pass (k_rmsd_accum<0>)
     int rmsd_fast_sigmas = 6;         // GR_TUNE_RMSD_FAST_SIGMAS: multiples of the closing step's rounding estimate a frame's rmsd must stand clear of (0: no guard, calibration only)
     uint32_t rmsd_fast_min = 16384;   // GR_TUNE_RMSD_FAST_MIN: smallest contiguous mass-weighted selection that takes k_sums_pk<false, true>
@@ -162,6 +165,9 @@ struct gr_rmsd_plan {
     std::string group;
     uint64_t n_ref = 0;
     float *p_dev = nullptr, *w_dev = nullptr;
+    float *p_span_dev = nullptr;            // masked selections: the reference coordinates once more, laid out by atom over the group's span
+    std::vector<grc::Block> ref_blocks;     // ... valid for a target group with exactly these blocks
+    bool span_ok = false;                   // (decided with w_is_mass whenever the target's groups / masses change)
     std::vector<float> w_host;   // reference masses of the group, selection order
     GrPlanDev dev = {};
     int exact = 0;
@@ -190,6 +196,7 @@ int fail(gr_ctx *c, int status, const std::string &msg, uint64_t index = 0) {
 GrSel make_sel(const Group &g) {
     GrSel s;
     s.n = (uint32_t)g.n; s.contiguous = g.contiguous ? 1u : 0u; s.start = g.start; s.g0 = g.start >> 8; s.idx = g.idx_dev;
+    s.masked = (g.masked && g.mask_dev) ? 1u : 0u; s.span = g.contiguous ? (uint32_t)g.n : g.span; s.mask = g.mask_dev;
     return s;
 }
 
@@ -206,7 +213,7 @@ uint32_t chunks_for(const GrSel &s) {
 // allows, so each lane streams many atoms per 32-value fp64 wave reduction
 uint32_t batch_chunks(const gr_ctx *c, const GrSel &s, uint32_t nf) {
     if (c->chunks) return c->chunks;
-    const uint64_t units = s.contiguous ? ((uint64_t)s.n + 3) / 4 : ((uint64_t)s.n + 3) / 4;
+    const uint64_t units = ((uint64_t)(s.masked ? s.span : s.n) + 3) / 4;      // (a masked selection is walked over its whole span)
     uint64_t by_work = units / GR_WG;            // at least one trip per lane
     if (by_work < 1) by_work = 1;
     uint64_t want = (1536 + nf - 1) / nf;        // ~2 rounds of 768 resident workgroups
@@ -370,6 +377,19 @@ int group_build(gr_ctx *c, std::vector<grc::Block> blocks, Group *out) {
         if (hipMemcpy(g.idx_dev, e32.data(), e32.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) {
             (void)hipFree(g.idx_dev);
             return fail(c, GR_E_HIP, "copy of the selection's index list failed");
+        }
+        // a DENSE scattered selection also gets its bit mask: the streaming sums kernels then read its span coalesced instead of
+        // gathering it atom by atom (tools/gather_bench.py: two blocks of 166 667 atoms cost 3x one block of 333 334 on the gather list)
+        g.span = (uint32_t)(g.blocks.back().second - g.blocks.front().first + 1);
+        g.masked = c->masked_sel && g.n >= 4096 && g.n * 8 >= (uint64_t)g.span;
+        if (g.masked) {
+            std::vector<uint32_t> bits(((size_t)c->n_pad + 31) / 32, 0u);
+            for (const auto &b : g.blocks) for (uint64_t a = b.first; a <= b.second; ++a) bits[a >> 5] |= 1u << (a & 31u);
+            if (hipMalloc(&g.mask_dev, bits.size() * sizeof(uint32_t)) != hipSuccess ||
+                hipMemcpy(g.mask_dev, bits.data(), bits.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) {
+                if (g.mask_dev) (void)hipFree(g.mask_dev);
+                g.mask_dev = nullptr; g.masked = false;          // (the gather list serves every path)
+            }
         }
     }
     *out = g;
@@ -551,14 +571,18 @@ int pbc_center_stages(gr_ctx *c, uint32_t first_slot, uint32_t nf, const GrSel &
 // estimate + unwrapped mean.  Frames whose proof fails come back GR_ST_FALLBACK in state_dev; center_redo_fallbacks reruns
 // those on the two-pass path.  The states must have been initialised (status 0 or the frame's host-side error).
 static bool center_onepass_ok(const gr_ctx *c, const GrSel &sel) {
-    return c->com_onepass_min != 0 && sel.contiguous && sel.n >= c->com_onepass_min && c->two_pass;
+    return c->com_onepass_min != 0 && (sel.contiguous || sel.masked) && sel.n >= c->com_onepass_min && c->two_pass;
 }
 static int pbc_center_onepass(gr_ctx *c, uint32_t s0, uint32_t nb, const GrSel &sel, int weighted) {
     GrPlanDev plan; memset(&plan, 0, sizeof plan);
     plan.w_is_mass = weighted ? 1u : 0u;   // NOREF: "weighted"
     plan.n = sel.n; plan.sw = 1.0;
     const uint32_t nch = batch_chunks(c, sel, nb);
-    if (c->fuse) {
+    if (sel.masked) {   // a dense scattered group: its span, coalesced, with its bit mask
+        k_sums_pk<true, false, true><<<dim3(nch, nb), dim3(GR_WG), 0, c->stream>>>(c->frames, c->frame_stride, s0, c->masses, sel, c->boxes_dev, plan, c->acc_partials,
+                                                                                   c->fuse ? c->fuse_cnt : nullptr, c->fuse ? c->state_dev : nullptr);
+        if (!c->fuse) k_rmsd_finalize_lite<true><<<dim3(nb), dim3(64), 0, c->stream>>>(c->acc_partials, nch, c->frames, c->frame_stride, s0, sel, c->boxes_dev, plan, c->state_dev);
+    } else if (c->fuse) {
         k_sums_pk<true><<<dim3(nch, nb), dim3(GR_WG), 0, c->stream>>>(c->frames, c->frame_stride, s0, c->masses, sel, c->boxes_dev, plan, c->acc_partials, c->fuse_cnt, c->state_dev);
     } else {
         k_sums_pk<true><<<dim3(nch, nb), dim3(GR_WG), 0, c->stream>>>(c->frames, c->frame_stride, s0, c->masses, sel, c->boxes_dev, plan, c->acc_partials, nullptr, nullptr);
@@ -1259,7 +1283,7 @@ struct TempSel {
         *st = group_build(c, grc::make(s, e, n), &g);
         ok = *st == GR_OK;
     }
-    ~TempSel() { if (ok && g.idx_dev) { (void)hipStreamSynchronize(c->stream); (void)hipFree(g.idx_dev); } }
+    ~TempSel() { if (ok && (g.idx_dev || g.mask_dev)) { (void)hipStreamSynchronize(c->stream); if (g.idx_dev) (void)hipFree(g.idx_dev); if (g.mask_dev) (void)hipFree(g.mask_dev); } }
 };
 
 int gr_sel_center(gr_ctx *c, uint32_t slot, const uint64_t *start, const uint64_t *end, size_t n_blocks, int kind, int weighted, float out[3]) try {
@@ -1520,6 +1544,7 @@ void gr_rmsd_plan_destroy(gr_rmsd_plan *p) try {
     if (p->target && (p->target->in_flight == p || p->pend.active)) { (void)hipStreamSynchronize(p->target->stream); if (p->target->in_flight == p) p->target->in_flight = nullptr; if (p->pend.resident) resident_done(p->target); }
     if (p->p_dev) (void)hipFree(p->p_dev);
     if (p->w_dev) (void)hipFree(p->w_dev);
+    if (p->p_span_dev) (void)hipFree(p->p_span_dev);
     delete p;
 } catch (...) { }
 
@@ -1551,8 +1576,16 @@ gr_rmsd_plan *gr_rmsd_plan_create(gr_ctx *ref, uint32_t ref_slot, gr_ctx *target
     if (ok) ok = hipMemsetAsync(p->p_dev, 0, s_pad * 3 * sizeof(float), ref->stream) == hipSuccess &&
                  hipMemsetAsync(p->w_dev, 0, s_pad * sizeof(float), ref->stream) == hipSuccess;
     if (!ok) { *status = fail(ref, GR_E_HIP, "plan allocation failed"); gr_rmsd_plan_destroy(p); return nullptr; }
+    if (sel.masked) {   // the by-atom copy for k_sums_pk<.., MASK>: [tile of the first atom .. tile of the last], unselected atoms zero
+        const size_t span_pad = (((size_t)(sel.start & 255u) + sel.span + 255) & ~(size_t)255) + 256;
+        if (hipMalloc(&p->p_span_dev, span_pad * 3 * sizeof(float)) != hipSuccess || hipMemsetAsync(p->p_span_dev, 0, span_pad * 3 * sizeof(float), ref->stream) != hipSuccess) {
+            if (p->p_span_dev) (void)hipFree(p->p_span_dev);
+            p->p_span_dev = nullptr;                  // (the plan works without it: the gather paths)
+        }
+        p->ref_blocks = g->blocks;
+    }
     const uint32_t nch = chunks_for(sel);
-    k_plan_extract<<<dim3(nch), dim3(GR_WG), 0, ref->stream>>>(ref->frames + (size_t)ref_slot * ref->frame_stride, ref->masses, sel, ref->boxes_dev + ref_slot, ref->state_dev, pofs, p->p_dev, p->w_dev, ref->cen_partials);
+    k_plan_extract<<<dim3(nch), dim3(GR_WG), 0, ref->stream>>>(ref->frames + (size_t)ref_slot * ref->frame_stride, ref->masses, sel, ref->boxes_dev + ref_slot, ref->state_dev, pofs, p->p_dev, p->w_dev, ref->cen_partials, p->p_span_dev);
     std::vector<GrCenPartial> parts(nch);
     if (hipMemcpyAsync(parts.data(), ref->cen_partials, nch * sizeof(GrCenPartial), hipMemcpyDeviceToHost, ref->stream) != hipSuccess ||
         hipStreamSynchronize(ref->stream) != hipSuccess) {
@@ -1599,6 +1632,7 @@ int gr_ctx_set_tuning(gr_ctx *c, int key, int64_t value) try {
     case GR_TUNE_FUSE: c->fuse = value ? 1 : 0; return GR_OK;
     case GR_TUNE_TWO_PASS: c->two_pass = value ? 1 : 0; return GR_OK;
     case GR_TUNE_RESIDENT: if (value < 0 || value > 2) break; c->resident = value; return GR_OK;
+    case GR_TUNE_MASKED_SELECTIONS: if (value != 0 && value != 1) break; c->masked_sel = (int)value; return GR_OK;
     case GR_TUNE_RMSD_FAST: if (value != 0 && value != 1) break; c->rmsd_fast = (int)value; return GR_OK;
     case GR_TUNE_RMSD_FAST_MIN: if (value < 0 || value > 0x7fffffff) break; c->rmsd_fast_min = (uint32_t)value; return GR_OK;
     case GR_TUNE_RMSD_FAST_SIGMAS: if (value < 0 || value > 1000) break; c->rmsd_fast_sigmas = (int)value; return GR_OK;
@@ -1657,6 +1691,7 @@ static int segment_begin(gr_rmsd_plan *p, uint32_t s0, uint32_t nb, int fit) {
         bool same = (g->n == p->n_ref);
         if (same) { size_t k = 0; for (uint64_t i : grc::expand(g->blocks)) { const float a = c->masses_host[i], b = p->w_host[k++]; if (!(a == b)) { same = false; break; } } }
         p->dev.w_is_mass = same ? 1u : 0u; p->resolved = true;
+        p->span_ok = p->p_span_dev != nullptr && g->masked && g->mask_dev != nullptr && g->blocks == p->ref_blocks;   // the by-atom copy fits THIS group
     }
     for (uint32_t f = 0; f < nb; ++f) { GrFrameState z = {}; z.err_index = GR_NOIDX; z.status = q.pre[f]; c->state_host[f] = z; }
     HIPCHK(c, hipMemcpyAsync(c->state_dev, c->state_host, nb * sizeof(GrFrameState), hipMemcpyHostToDevice, c->stream));
@@ -1680,9 +1715,13 @@ static int segment_begin(gr_rmsd_plan *p, uint32_t s0, uint32_t nb, int fit) {
         // RMSD WITHOUT fit of a contiguous mass-weighted selection: the sums pass of the fit path + the closed-form RMSD's sums as f32
         // chains widened to fp64 (k_sums_pk<false, true>); frames whose rmsd comes out too close to the rounding of its own sums
         // are handed back (GR_ST_REDO_EXACT) and redone below by the exact-product pass that every other selection takes
-        const bool fast = !fit && sel.contiguous && c->two_pass && c->rmsd_fast && p->dev.w_is_mass != 0 && g->n >= c->rmsd_fast_min;
+        // ... and, with or without fit, of a DENSE scattered one (GrSel::masked, the plan's by-atom copy of the reference fitting this
+        // group): the same pass over the selection's span with its bit mask, then -- for a fit -- the plain transform of every atom
+        const bool msk = sel.masked && p->span_ok;
+        const bool fast = c->two_pass && c->rmsd_fast && p->dev.w_is_mass != 0 && g->n >= c->rmsd_fast_min && ((!fit && sel.contiguous) || msk);
         q.rmsd_fast = fast;
         p->dev.fast_sigmas = (float)c->rmsd_fast_sigmas;
+        GrPlanDev plan_span = p->dev; plan_span.p = p->p_span_dev;      // (after every field of p->dev this call sets)
         const uint32_t n_groups = (nb + sb - 1) / sb;
         if (lite) {
             size_t need = 0;
@@ -1766,6 +1805,8 @@ static int segment_begin(gr_rmsd_plan *p, uint32_t s0, uint32_t nb, int fit) {
             if (c->profile) EVREC(c, c->pev[6 * g], true, S);
             if (lite) k_sums_pk<false><<<dim3(nch, nf), dim3(GR_WG), 0, S>>>(c->frames, c->frame_stride, s0 + f0, c->masses, sel, c->boxes_dev, p->dev, parts,
                                                                              fused ? c->fuse_cnt + f0 : nullptr, c->state_dev + f0);
+            else if (fast && msk) k_sums_pk<false, true, true><<<dim3(nch, nf), dim3(GR_WG), 0, S>>>(c->frames, c->frame_stride, s0 + f0, c->masses, sel, c->boxes_dev, plan_span, parts,
+                                                                                                      fused ? c->fuse_cnt + f0 : nullptr, c->state_dev + f0);
             else if (fast) k_sums_pk<false, true><<<dim3(nch, nf), dim3(GR_WG), 0, S>>>(c->frames, c->frame_stride, s0 + f0, c->masses, sel, c->boxes_dev, p->dev, parts,
                                                                                         fused ? c->fuse_cnt + f0 : nullptr, c->state_dev + f0);
             else k_rmsd_accum<0><<<dim3(nch, nf), dim3(GR_WG), 0, S>>>(c->frames, c->frame_stride, s0 + f0, c->masses, sel, c->boxes_dev, p->dev, c->state_dev + f0, parts);
@@ -1773,7 +1814,7 @@ static int segment_begin(gr_rmsd_plan *p, uint32_t s0, uint32_t nb, int fit) {
             if (!fused) {
                 if (c->profile) EVREC(c, c->pev[6 * g + 2], true, S);
                 if (lite) k_rmsd_finalize_lite<false><<<dim3(nf), dim3(64), 0, S>>>(parts, nch, c->frames, c->frame_stride, s0 + f0, sel, c->boxes_dev, p->dev, c->state_dev + f0);
-                else if (fast) k_rmsd_finalize_lite<false, true><<<dim3(nf), dim3(64), 0, S>>>(parts, nch, c->frames, c->frame_stride, s0 + f0, sel, c->boxes_dev, p->dev, c->state_dev + f0);
+                else if (fast) k_rmsd_finalize_lite<false, true><<<dim3(nf), dim3(64), 0, S>>>(parts, nch, c->frames, c->frame_stride, s0 + f0, sel, c->boxes_dev, msk ? plan_span : p->dev, c->state_dev + f0);
                 else k_rmsd_finalize<0><<<dim3(nf), dim3(GR_WG), 0, S>>>(parts, nch, c->frames, c->frame_stride, s0 + f0, sel, c->boxes_dev, p->dev, c->state_dev + f0);
                 if (c->profile) EVREC(c, c->pev[6 * g + 3], true, S);
             }
@@ -1931,6 +1972,10 @@ static int segment_end(gr_rmsd_plan *p, float *rmsd_out, int *status_out, float 
                 GrAccPartial *parts = c->acc_partials;
                 k_rmsd_accum<0><<<dim3(nch, nf), dim3(GR_WG), 0, c->stream>>>(c->frames, c->frame_stride, s0 + f0, c->masses, sel, c->boxes_dev, p->dev, c->state_dev, parts);
                 k_rmsd_finalize<0><<<dim3(nf), dim3(GR_WG), 0, c->stream>>>(parts, nch, c->frames, c->frame_stride, s0 + f0, sel, c->boxes_dev, p->dev, c->state_dev);
+                if (fit) {   // (a masked selection's fit: the frames handed back have not been transformed)
+                    const uint32_t gx = fit_grid(c, nf);
+                    k_fit_pk<false><<<dim3(gx, nf), dim3(GR_WG), 0, c->stream>>>(c->frames, c->frame_stride, s0 + f0, (uint32_t)c->n, c->boxes_dev, p->dev, c->state_dev, c->masses, sel, nullptr);
+                }
                 HIPCHK(c, hipGetLastError());
                 st = fetch_states(c, nf); if (st) return st;
                 for (uint32_t f = f0; f < f1; ++f) res[f] = c->state_host[f - f0];

@@ -133,7 +133,10 @@ __device__ __forceinline__ void gr_sums_pair(GrSumsPk &S, gr_v2f x, gr_v2f y, gr
 // rounding is a random walk over ~n / 8 independent partials: the closing step ESTIMATES it from the magnitudes of the sums and
 // hands the frame back (GR_ST_REDO_EXACT -> the exact-product pass) when the estimate is not far below the 1e-5 nm bar --
 // rigid copies of the reference (rmsd ~ 0), tiny groups; see gr_finalize_math<.., FAST>.
-template <bool NOREF = false, bool RMSD = false>
+// MASK = true: a dense non-contiguous selection (GrSel::masked): the kernel walks the selection's whole span and takes every atom's
+// membership from one bit (a 4-bit nibble per lane and trip, prefetched with the rows); plan.p is then laid out by atom over the span.
+// Measured at 1e6 atoms (tools/gather_bench.py, us per frame, gather list -> masked span): every third atom 4.3 -> see DESIGN.
+template <bool NOREF = false, bool RMSD = false, bool MASK = false>
 __global__ __launch_bounds__(GR_WG) void k_sums_pk(
     const float *__restrict__ frames, size_t frame_stride, uint32_t first_slot,
     const float *__restrict__ masses, GrSel sel, const GrBox *__restrict__ boxes,
@@ -176,7 +179,7 @@ __global__ __launch_bounds__(GR_WG) void k_sums_pk(
         S.mx = S.my = S.mz = gr_v2(0.0f);
     };
 
-    const uint32_t first = sel.start, last = sel.start + sel.n;
+    const uint32_t first = sel.start, last = sel.start + (MASK ? sel.span : sel.n);
     const uint32_t g0 = sel.g0 << 6, g1 = (last + 3u) >> 2;      // float4 groups [g0, g1): g0 = first group of the first tile
     const float4 *f4 = reinterpret_cast<const float4 *>(xyz);
     const float4 *p4 = reinterpret_cast<const float4 *>(plan.p);
@@ -194,10 +197,11 @@ __global__ __launch_bounds__(GR_WG) void k_sums_pk(
 #ifndef GR_SUMS_PREFETCH_PM
 #define GR_SUMS_PREFETCH_PM 1
 #endif
-    struct Trip { float4 r0, r1, r2, q0, q1, q2, mm; };
+    struct Trip { float4 r0, r1, r2, q0, q1, q2, mm; uint32_t bits; };
     auto request = [&](uint32_t gg, Trip &t) {
         const uint32_t gc = gg < g1 ? gg : g0;
         gr_rows_load<true>(f4, gc, t.r0, t.r1, t.r2);
+        t.bits = MASK ? sel.mask[gc >> 3] : 0u;
         if (GR_SUMS_PREFETCH_PM) {
             if (!NOREF) gr_rows_load(p4, (size_t)(gc - g0), t.q0, t.q1, t.q2);
             if (!(NOREF && !wm)) t.mm = m4[gc]; else t.mm = one4;
@@ -213,14 +217,28 @@ __global__ __launch_bounds__(GR_WG) void k_sums_pk(
         GrP4 q = gr_pairs_rows(t.r0, t.r1, t.r2), p;
         if (!NOREF) p = gr_pairs_rows(q0, q1, q2); else p.x01 = p.y01 = p.z01 = p.x23 = p.y23 = p.z23 = gr_v2(0.0f);
         const uint32_t i = gg << 2;
-        if (!(gg < g1 && i >= first && i + 3 < last)) {
-            // a ragged end of the selection (or a trip behind it): atoms outside become copies of the first atom with zero mass and
-            // zero reference coordinates -- v = 0 adds nothing to any sum and lies inside every extent (the first atom's own v is 0)
-            const bool in = gg < g1;
-            if (!(in && i >= first && i < last)) { q.x01.x = gx; q.y01.x = gy; q.z01.x = gz; mm.x = 0.f; p.x01.x = p.y01.x = p.z01.x = 0.f; }
-            if (!(in && i + 1 >= first && i + 1 < last)) { q.x01.y = gx; q.y01.y = gy; q.z01.y = gz; mm.y = 0.f; p.x01.y = p.y01.y = p.z01.y = 0.f; }
-            if (!(in && i + 2 >= first && i + 2 < last)) { q.x23.x = gx; q.y23.x = gy; q.z23.x = gz; mm.z = 0.f; p.x23.x = p.y23.x = p.z23.x = 0.f; }
-            if (!(in && i + 3 >= first && i + 3 < last)) { q.x23.y = gx; q.y23.y = gy; q.z23.y = gz; mm.w = 0.f; p.x23.y = p.y23.y = p.z23.y = 0.f; }
+        const uint32_t nib = MASK ? (t.bits >> ((gg & 7u) * 4u)) & 15u : 15u;       // MASK: which of the lane's four atoms are selected
+        // which of the lane's four atoms count: inside [first, last), in a trip that exists, bit set (MASK).  The others -- a ragged end
+        // of the selection, a trip behind it, an atom whose bit is clear -- become copies of the first atom with zero mass and zero
+        // reference coordinates: v = 0 adds nothing to any sum and lies inside every extent (the first atom's own v is 0), and
+        // whatever such an atom holds, a NaN included, never reaches the arithmetic.  One wave-uniform branch around plain selects:
+        // written as per-atom `if`s under a divergent `if`, the masked kernel came out of the compiler with atom 0's coordinates
+        // NOT replaced in one of the two unrolled copies (its mass was) -- its fractional coordinates leaked into the image proof.
+        uint32_t keep = gg < g1 ? nib : 0u;
+        keep &= (i >= first ? 1u : 0u) | (i + 1 >= first ? 2u : 0u) | (i + 2 >= first ? 4u : 0u) | (i + 3 >= first ? 8u : 0u);
+        keep &= (i < last ? 1u : 0u) | (i + 1 < last ? 2u : 0u) | (i + 2 < last ? 4u : 0u) | (i + 3 < last ? 8u : 0u);
+        if (__builtin_amdgcn_ballot_w64(keep != 15u) != 0ull) {
+            const bool k0 = (keep & 1u) != 0, k1 = (keep & 2u) != 0, k2 = (keep & 4u) != 0, k3 = (keep & 8u) != 0;
+            q.x01.x = k0 ? q.x01.x : gx; q.y01.x = k0 ? q.y01.x : gy; q.z01.x = k0 ? q.z01.x : gz; mm.x = k0 ? mm.x : 0.f;
+            q.x01.y = k1 ? q.x01.y : gx; q.y01.y = k1 ? q.y01.y : gy; q.z01.y = k1 ? q.z01.y : gz; mm.y = k1 ? mm.y : 0.f;
+            q.x23.x = k2 ? q.x23.x : gx; q.y23.x = k2 ? q.y23.x : gy; q.z23.x = k2 ? q.z23.x : gz; mm.z = k2 ? mm.z : 0.f;
+            q.x23.y = k3 ? q.x23.y : gx; q.y23.y = k3 ? q.y23.y : gy; q.z23.y = k3 ? q.z23.y : gz; mm.w = k3 ? mm.w : 0.f;
+            if (!NOREF) {
+                p.x01.x = k0 ? p.x01.x : 0.f; p.y01.x = k0 ? p.y01.x : 0.f; p.z01.x = k0 ? p.z01.x : 0.f;
+                p.x01.y = k1 ? p.x01.y : 0.f; p.y01.y = k1 ? p.y01.y : 0.f; p.z01.y = k1 ? p.z01.y : 0.f;
+                p.x23.x = k2 ? p.x23.x : 0.f; p.y23.x = k2 ? p.y23.x : 0.f; p.z23.x = k2 ? p.z23.x : 0.f;
+                p.x23.y = k3 ? p.x23.y : 0.f; p.y23.y = k3 ? p.y23.y : 0.f; p.z23.y = k3 ? p.z23.y : 0.f;
+            }
         }
         gr_sums_pair<NOREF, RMSD>(S, q.x01, q.y01, q.z01, p.x01, p.y01, p.z01, gr_v2p(mm.x, mm.y), B, boxp, gx, gy, gz, &Rm);
         gr_sums_pair<NOREF, RMSD>(S, q.x23, q.y23, q.z23, p.x23, p.y23, p.z23, gr_v2p(mm.z, mm.w), B, boxp, gx, gy, gz, &Rm);

@@ -43,6 +43,13 @@ struct GrSel {
     uint32_t start;        // first atom (contiguous) / first atom of idx (gather)
     uint32_t g0;           // contiguous: first 256-atom tile (start / 256)
     const uint32_t *idx;   // gather list (device), NULL when contiguous
+    // a DENSE non-contiguous selection (every third atom, a few large blocks: at least an eighth of the atoms between its first and its
+    // last one): besides the gather list it carries one bit per atom of the system, and the streaming kernels that know about it
+    // (k_sums_pk<.., MASK>) walk the whole SPAN start .. start + span - 1 with coalesced row loads, turning the atoms whose bit is
+    // clear into what a ragged end's atoms become -- copies of the first atom with zero mass and zero reference
+    uint32_t masked;       // 1: `mask` is set (contiguous is 0: every other kernel takes the gather list)
+    uint32_t span;         // atoms from the first to the last selected one (contiguous: n)
+    const uint32_t *mask;  // bit (a & 31) of word a >> 5: atom a is selected
 };
 
 // per-frame state shared by the stages of one analysis (lives in HBM, one record per frame of a batch)
@@ -956,7 +963,7 @@ __global__ __launch_bounds__(64) void k_rmsd_close(const double *__restrict__ fi
 __global__ __launch_bounds__(GR_WG) void k_plan_extract(
     const float *__restrict__ xyz, const float *__restrict__ masses, GrSel sel, const GrBox *__restrict__ boxp,
     const GrFrameState *__restrict__ state, uint32_t pofs, float *__restrict__ p_out, float *__restrict__ w_out,
-    GrCenPartial *__restrict__ partials) {
+    GrCenPartial *__restrict__ partials, float *__restrict__ p_span = nullptr) {
     __shared__ GrBox box;
     __shared__ double lds[(GR_WG / 64) * GR_CEN_K];
     gr_stage_box(&box, boxp);
@@ -975,6 +982,7 @@ __global__ __launch_bounds__(GR_WG) void k_plan_extract(
         const float w = masses[i];
         const size_t jj = (size_t)j + pofs;
         gr_pos_store(p_out, jj, x, y, z); w_out[jj] = w;
+        if (p_span) gr_pos_store(p_span, (size_t)i - ((size_t)sel.g0 << 8), x, y, z);      // masked selections: a second copy laid out by ATOM (tiles line up with the frame's)
         const double dx = x, dy = y, dz = z, dw = w;
         acc[0] += dx; acc[1] += dy; acc[2] += dz;
         acc[3] += dw * dx; acc[4] += dw * dy; acc[5] += dw * dz;

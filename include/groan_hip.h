@@ -290,6 +290,9 @@ int gr_rmsd_plan_force_exact(gr_rmsd_plan *plan, int on);
 enum { GR_TUNE_SUB_BATCH = 1, GR_TUNE_CHUNKS = 2, GR_TUNE_FIT_WGS = 3, GR_TUNE_FUSE = 4, GR_TUNE_TWO_PASS = 5, GR_TUNE_RESIDENT = 6, GR_TUNE_RESIDENT_GROUPS = 7,
        GR_TUNE_RESIDENT_STREAMS = 8, GR_TUNE_RESIDENT_FILL = 9, GR_TUNE_PAIRDIST_SYMMETRIC = 10, GR_TUNE_RESIDENT_WG_GROUPS = 11,
        GR_TUNE_RMSD_FAST = 12, GR_TUNE_RMSD_FAST_MIN = 13,
+       GR_TUNE_MASKED_SELECTIONS = 15 /* 1 (default): a scattered selection that covers at least an eighth of the atoms between its first and its last one (>= 4096
+                                         atoms) also gets a bit mask, and RMSD / RMSD-fit / get_com read its span coalesced instead of gathering it atom by atom;
+                                         0: groups created afterwards keep to their index lists.  Same results to rounding. */,
        GR_TUNE_RMSD_FAST_SIGMAS = 14 /* multiples (default 6) of the pass's own rounding estimate a frame's rmsd must stand clear of to be kept; 0 keeps every frame: calibration runs only (tools/rmsd_calibrate.py) */,
        GR_TUNE_TEST_RESIDENT_NO_START = 100 /* tests: the next resident launch behaves as if its workgroups never got onto the chip */,
        GR_TUNE_TEST_RESIDENT_ABORT_AT = 101 /* tests: the next resident launch is aborted from inside when it reaches this frame of its segment (< 0: never) */ };
