@@ -326,7 +326,8 @@ uint32_t resident_wgs(gr_ctx *c, bool lite, uint32_t nb, const GrSel &sel, uint3
     // selected 6.53 / 5.10, 70 % 6.00 / 5.11, 50 % 5.50 / 5.16, 40 % 5.26 / 5.24, 30 % 5.05 / 5.27, 10 % 4.66 / 5.30 -- the pass is flat
     // (every workgroup streams and fits whatever it holds of the selection), the two passes shrink with the selection: the
     // cross-over lies at ~40 %, the default takes the pass from 45 % (round 3: from 90 %)
-    if (c->resident == 1 && (uint64_t)sel.n * 100 < c->n * 45) return 0;
+    // (a masked selection costs the two passes its SPAN, not its atoms: every third atom of the whole system 6.7 us against the pass's 5.2)
+    if (c->resident == 1 && (uint64_t)(sel.masked ? sel.span : sel.n) * 100 < c->n * 45) return 0;
     // a launch that missed its start handshake (the device was busy with somebody else's kernels) makes the context sit out a few
     // segments -- twice as many after every miss in a row -- instead of giving the pass up for good (gr_ctx_stat counts the misses)
     if (c->res_skip) { c->res_skip--; return 0; }
@@ -1737,7 +1738,9 @@ static int segment_begin(gr_rmsd_plan *p, uint32_t s0, uint32_t nb, int fit) {
         q.fused = fused;
         hipStream_t S = c->stream;
         uint32_t res_streams = 1, res_gwg = GR_RES_GROUPS;
-        uint32_t res_wgs = resident_wgs(c, lite, nb, sel, &res_streams, &res_gwg);   // workgroups per frame x frame streams
+        // (the pass also takes the RMSD-fit of a masked selection weighted by its masses: the lanes' membership flags carry the bits)
+        const bool res_msk = fit && msk && c->two_pass && p->dev.w_is_mass != 0;
+        uint32_t res_wgs = resident_wgs(c, lite || res_msk, nb, sel, &res_streams, &res_gwg);   // workgroups per frame x frame streams
         if (res_wgs && !resident_acquire(c->device)) res_wgs = 0;
         if (res_wgs) c->res_in_use = true;           // (released in segment_end, or by the caller when this function fails)
         if (res_wgs) {
@@ -1765,7 +1768,7 @@ static int segment_begin(gr_rmsd_plan *p, uint32_t s0, uint32_t nb, int fit) {
             ctl.patience_ticks = (unsigned long long)c->wall_khz * 3000ull; ctl.start_ticks = (unsigned long long)c->wall_khz * 200ull;   // 3 s, 0.2 s
             ctl.test_abort_frame = c->res_test_abort_at; c->res_test_abort_at = 0xFFFFFFFFu;
             float *frames = c->frames; size_t stride = c->frame_stride; uint32_t slot0 = s0, nfr = nb, natoms = (uint32_t)c->n;
-            const float *masses = c->masses; GrSel sel_arg = sel; const GrBox *boxes = c->boxes_dev; GrPlanDev plan = p->dev;
+            const float *masses = c->masses; GrSel sel_arg = sel; const GrBox *boxes = c->boxes_dev; GrPlanDev plan = res_msk ? plan_span : p->dev;
             GrFrameState *states = c->state_dev; double *fparts = c->fit_partials;
             void *args[] = { &frames, &stride, &slot0, &nfr, &natoms, &masses, &sel_arg, &boxes, &plan, &states, &fparts, &ctl };
             bool ubox = true;   // the same box in every frame of the segment (constant-volume runs): its constants are loaded once
@@ -1791,6 +1794,7 @@ static int segment_begin(gr_rmsd_plan *p, uint32_t s0, uint32_t nb, int fit) {
                 k_rmsd_close<<<dim3(nb), dim3(64), 0, S>>>(c->fit_partials, res_wgs, p->dev.sw, c->state_dev);
                 HIPCHK(c, hipGetLastError());
                 q.resident = true; q.res_stream = res_stream; q.res_streams = res_streams;
+                q.rmsd_fast = false;                    // (the pass closes its frames with the fit's own sum: nothing to hand back)
                 c->res_last_streams = res_streams;
             } else {
                 (void)hipGetLastError();          // nothing ran: the two-pass path takes the segment

@@ -409,17 +409,19 @@ __global__ __launch_bounds__(GR_WG) void k_fit_pk(
         if (RMSD && in_sel) {
             const uint32_t i = g << 2;
             const GrP4 p = gr_pairs_rows(pa, pb, pc);
-            if (!(i >= first && i + 3 < last)) {   // ragged end: atoms outside the selection weigh nothing
-                if (!(i >= first && i < last)) ww.x = 0.f;
-                if (!(i + 1 >= first && i + 1 < last)) ww.y = 0.f;
-                if (!(i + 2 >= first && i + 2 < last)) ww.z = 0.f;
-                if (!(i + 3 >= first && i + 3 < last)) ww.w = 0.f;
-            }
-            // sum w |R q - p|^2 (rmsd.rs:592-599): two atoms per packed operation, 4-atom f32 partial -> fp64 per lane
+            // sum w |R q - p|^2 (rmsd.rs:592-599): two atoms per packed operation, 4-atom f32 partial -> fp64 per lane.  At a ragged end
+            // of the selection the atoms outside it contribute an exact zero -- their TERM, not just their weight: an atom without a
+            // position next to the selection's edge would otherwise turn the sum into 0 * NaN
             gr_v2f dx = n.x01 - p.x01, dy = n.y01 - p.y01, dz = n.z01 - p.z01;
-            gr_v2f part = gr_v2p(ww.x, ww.y) * gr_v2_fma(dx, dx, gr_v2_fma(dy, dy, dz * dz));
+            gr_v2f s01 = gr_v2_fma(dx, dx, gr_v2_fma(dy, dy, dz * dz));
             dx = n.x23 - p.x23; dy = n.y23 - p.y23; dz = n.z23 - p.z23;
-            part = gr_v2_fma(gr_v2p(ww.z, ww.w), gr_v2_fma(dx, dx, gr_v2_fma(dy, dy, dz * dz)), part);
+            gr_v2f s23 = gr_v2_fma(dx, dx, gr_v2_fma(dy, dy, dz * dz));
+            const uint32_t keep = ((i >= first && i < last) ? 1u : 0u) | ((i + 1 >= first && i + 1 < last) ? 2u : 0u) | ((i + 2 >= first && i + 2 < last) ? 4u : 0u) | ((i + 3 >= first && i + 3 < last) ? 8u : 0u);
+            if (__builtin_amdgcn_ballot_w64(keep != 15u) != 0ull) {
+                s01.x = (keep & 1u) ? s01.x : 0.f; s01.y = (keep & 2u) ? s01.y : 0.f; s23.x = (keep & 4u) ? s23.x : 0.f; s23.y = (keep & 8u) ? s23.y : 0.f;
+                ww.x = (keep & 1u) ? ww.x : 0.f; ww.y = (keep & 2u) ? ww.y : 0.f; ww.z = (keep & 4u) ? ww.z : 0.f; ww.w = (keep & 8u) ? ww.w : 0.f;
+            }
+            const gr_v2f part = gr_v2_fma(gr_v2p(ww.z, ww.w), s23, gr_v2p(ww.x, ww.y) * s01);
             rs += (double)(part.x + part.y);
         }
         n.x01 += gr_v2(cx); n.y01 += gr_v2(cy); n.z01 += gr_v2(cz); n.x23 += gr_v2(cx); n.y23 += gr_v2(cy); n.z23 += gr_v2(cz);

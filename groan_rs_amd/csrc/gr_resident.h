@@ -254,9 +254,16 @@ __device__ __forceinline__ void gr_res_fit_group(const GrResGroup &Gr, const flo
     if (Gr.flags & GR_RG_ANY) {   // sum w |R q - p|^2 (rmsd.rs:592-599); the weights of atoms outside the selection are zero
         const gr_v2f w01 = WMASS ? gr_v2p(Gr.mm.x, Gr.mm.y) : gr_v2p(Gr.ww.x, Gr.ww.y), w23 = WMASS ? gr_v2p(Gr.mm.z, Gr.mm.w) : gr_v2p(Gr.ww.z, Gr.ww.w);
         gr_v2f dx = n.x01 - Gr.P.x01, dy = n.y01 - Gr.P.y01, dz = n.z01 - Gr.P.z01;
-        gr_v2f part = w01 * gr_v2_fma(dx, dx, gr_v2_fma(dy, dy, dz * dz));
+        gr_v2f s01 = gr_v2_fma(dx, dx, gr_v2_fma(dy, dy, dz * dz));
         dx = n.x23 - Gr.P.x23; dy = n.y23 - Gr.P.y23; dz = n.z23 - Gr.P.z23;
-        part = gr_v2_fma(w23, gr_v2_fma(dx, dx, gr_v2_fma(dy, dy, dz * dz)), part);
+        gr_v2f s23 = gr_v2_fma(dx, dx, gr_v2_fma(dy, dy, dz * dz));
+        // atoms of the group outside the selection (its ragged ends, clear bits of a masked one) contribute an exact zero -- the TERM,
+        // not just the weight: such an atom may have no position, and 0 * NaN would take the frame's rmsd with it
+        if (__builtin_amdgcn_ballot_w64((Gr.flags & GR_RG_FULL) == 0u) != 0ull) {
+            s01.x = (Gr.flags & GR_RG_IN0) ? s01.x : 0.f; s01.y = (Gr.flags & GR_RG_IN1) ? s01.y : 0.f;
+            s23.x = (Gr.flags & GR_RG_IN2) ? s23.x : 0.f; s23.y = (Gr.flags & GR_RG_IN3) ? s23.y : 0.f;
+        }
+        const gr_v2f part = gr_v2_fma(w23, s23, w01 * s01);
         rs += part.x + part.y;
     }
     n.x01 += gr_v2(cx); n.y01 += gr_v2(cy); n.z01 += gr_v2(cz); n.x23 += gr_v2(cx); n.y23 += gr_v2(cy); n.z23 += gr_v2(cz);
@@ -457,14 +464,20 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
         partner = (uint32_t)__builtin_amdgcn_readfirstlane((int)partner);
     }
 
-    const uint32_t first = sel.start, last = sel.start + sel.n, g0 = sel.g0 << 6;
+    // (a masked selection -- GrSel::masked, gr_hot.h -- is its span with a bit per atom: the lane's membership flags take the bits in,
+    //  once, and nothing else in the launch knows the difference; plan.p is then the plan's by-atom copy over the span)
+    const uint32_t first = sel.start, last = sel.start + (sel.masked ? sel.span : sel.n), g0 = sel.g0 << 6;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     // the lane's groups: A = chunk `wave` of the workgroup's first LANES groups, B = the same chunk of its second LANES
     auto setup = [&](uint32_t g, GrResGroup &Gr) {
         const uint32_t i0 = g << 2;
         Gr.valid = g < glimit;                                        // wave-uniform
-        const bool in0 = Gr.valid && (i0 >= first) && (i0 < last), in1 = Gr.valid && (i0 + 1u >= first) && (i0 + 1u < last);
-        const bool in2 = Gr.valid && (i0 + 2u >= first) && (i0 + 2u < last), in3 = Gr.valid && (i0 + 3u >= first) && (i0 + 3u < last);
+        bool in0 = Gr.valid && (i0 >= first) && (i0 < last), in1 = Gr.valid && (i0 + 1u >= first) && (i0 + 1u < last);
+        bool in2 = Gr.valid && (i0 + 2u >= first) && (i0 + 2u < last), in3 = Gr.valid && (i0 + 3u >= first) && (i0 + 3u < last);
+        if (!V && sel.masked && (in0 || in1 || in2 || in3)) {
+            const uint32_t nib = (sel.mask[g >> 3] >> ((g & 7u) * 4u)) & 15u;
+            in0 = in0 && (nib & 1u); in1 = in1 && (nib & 2u); in2 = in2 && (nib & 4u); in3 = in3 && (nib & 8u);
+        }
         const bool in_sel = in0 || in1 || in2 || in3, full = in0 && in1 && in2 && in3;
         Gr.flags = (in0 ? GR_RG_IN0 : 0u) | (in1 ? GR_RG_IN1 : 0u) | (in2 ? GR_RG_IN2 : 0u) | (in3 ? GR_RG_IN3 : 0u) | (in_sel ? GR_RG_ANY : 0u) | (full ? GR_RG_FULL : 0u);
         Gr.b = (uint32_t)gr_row_index(Gr.valid ? g : 0u, 0);

@@ -162,3 +162,63 @@ def test_unselected_atoms_of_the_span_never_reach_the_image_proof(G, start, stri
             assert np.abs(com[f] - O.get_center(frames[f], idx, box, mass=masses)).max() <= 1e-5, f
             assert np.abs(cen[f] - O.get_center(frames[f], idx, box)).max() <= 1e-5, f
     plan.close(); ref.close(); cur.close()
+
+
+@pytest.mark.parametrize("shape", ["every third atom", "two blocks"])
+@pytest.mark.parametrize("cell,streams", [("ortho", 1), ("dodeca", 3)])
+def test_rmsd_fit_of_a_masked_selection_through_the_resident_pass(G, shape, cell, streams):
+    """calc_rmsd_and_fit of a dense scattered selection in ONE pass (k_fit_resident, the lanes' membership flags carry the mask bits):
+    against the oracle and against the two passes on the same frames; unselected atoms all over the cell, a NaN in one of them, a NaN in a
+    selected atom, a frame whose image proof fails."""
+    n, nf = 70_001, 20
+    box = W.box_from_lengths_angles([9.0, 8.0, 7.0], [90.0] * 3) if cell == "ortho" else W.c4_box(9.0)
+    masses = W.masses_cycle(n)
+    blocks = SHAPES[shape](n)
+    idx = _idx(blocks)
+    unsel = np.setdiff1d(np.arange(n), idx)
+    rng = np.random.default_rng(5)
+    res = {}
+    for resident in (2, 0):
+        cur = G.System(n, masses=masses, n_slots=nf + 1)
+        cur.set_tuning(resident=resident, resident_streams=streams)
+        cur.synth_reference(nf, box, W.blob_radius(box), W.SEED)
+        cur.synth_frames(nf, 0, nf, 0, 0.05, W.SEED)
+        ref_pos = cur.get_positions(nf)
+        frames = [cur.get_positions(f) for f in range(nf)]
+        if resident == 2:
+            scatter = (rng.random((len(unsel), 3)) @ W.box_matrix(box)).astype(np.float32)
+        for f in (1, 8, 19):
+            frames[f] = frames[f].copy(); frames[f][unsel] = scatter                          # unselected atoms anywhere in the cell
+        frames[3] = W.proof_failing_frame(ref_pos, box, "two_lobes", 9)
+        frames[6] = frames[6].copy(); frames[6][unsel[len(unsel) // 2]] = np.nan
+        frames[11] = frames[11].copy(); frames[11][idx[len(idx) // 3]] = np.nan
+        ref = G.System(n, masses=masses, box=box, positions=ref_pos)
+        for s_ in (ref, cur):
+            s_.group_create_from_ranges("S", blocks)
+        for f in range(nf):
+            cur.set_frame(frames[f], box, slot=f)
+        plan = G.RMSDPlan(ref, cur, "S")
+        cur.profile_enable(True)
+        r, st = plan.rmsd_fit(0, nf, raise_on_error=False)
+        prof = cur.profile_read()
+        assert (prof["k_fit_resident"][1] > 0) == (resident == 2), prof
+        fitted = [cur.get_positions(f) for f in range(nf)]
+        res[resident] = (np.array(r), np.array(st), fitted)
+        if resident == 2:
+            assert [f for f in range(nf) if st[f] != 0] == [11], st
+            assert plan.last_fallbacks() >= 1                                                 # frame 3 went back to the exact path
+            with O.acc64():
+                for f in (0, 1, 3, 4, 8, 12, 19):
+                    ro, want = O.calc_rmsd_and_fit(ref_pos, masses, idx, box, frames[f], masses, idx, box)
+                    assert abs(float(r[f]) - ro) <= 1e-5, (f, float(r[f]), ro)
+                    assert np.abs(fitted[f] - want).max() <= 5e-5, f
+            assert np.array_equal(np.nan_to_num(fitted[11], nan=-1.0), np.nan_to_num(frames[11], nan=-1.0))     # a failed frame is left alone
+        plan.close(); ref.close(); cur.close()
+    a, b = res[2], res[0]
+    assert np.array_equal(a[1], b[1])
+    good = a[1] == 0
+    assert np.abs(a[0][good] - b[0][good]).max() <= 2e-6
+    for f in np.nonzero(good)[0]:
+        fin = np.isfinite(a[2][f][:, 0]) & np.isfinite(b[2][f][:, 0])
+        assert np.array_equal(np.isfinite(a[2][f][:, 0]), np.isfinite(b[2][f][:, 0]))
+        assert np.abs(a[2][f][fin] - b[2][f][fin]).max() <= 3e-5, f

@@ -392,3 +392,32 @@ def test_a_group_that_spans_the_cell_fails_the_proof_in_every_frame(G, mode):
                 assert np.abs(got - (want if fit else frames[f])).max() <= 5e-5, (fit, f)
         assert np.array_equal(np.nan_to_num(cur.get_positions(4), nan=-1.0), np.nan_to_num(frames[4], nan=-1.0))
     plan.close(); ref.close(); cur.close()
+
+
+@pytest.mark.parametrize("resident", [0, 2])
+def test_an_atom_without_position_next_to_the_selections_edge(G, resident):
+    """The selection starts and ends in the middle of a 4-atom group, and the atoms of those groups OUTSIDE it have no position:
+    they weigh nothing, and their term in sum w |R q - p|^2 must be an exact zero, not 0 * NaN (both passes multiplied by the
+    weight only until round 4).  The fit leaves such atoms as they are and moves everything else."""
+    n, nf, sel = 20_000, 9, (5, 19_993)
+    box = W.box_from_lengths_angles([7.0, 6.5, 6.0], [90.0, 90.0, 90.0])
+    masses, cur, ref, ref_pos, frames = _systems(G, n, nf, box, sel)
+    cur.set_tuning(resident=resident)
+    for f in (2, 7):
+        frames[f] = frames[f].copy(); frames[f][4] = np.nan; frames[f][19_994] = np.nan
+        cur.set_frame(frames[f], box, slot=f)
+    plan = G.RMSDPlan(ref, cur, "S")
+    cur.profile_enable(True)
+    r, st = plan.rmsd_fit(0, nf, raise_on_error=False)
+    assert (cur.profile_read()["k_fit_resident"][1] > 0) == (resident == 2)
+    assert (np.array(st) == 0).all(), st
+    idx = np.arange(sel[0], sel[1] + 1)
+    with O.acc64():
+        for f in (1, 2, 7):
+            clean = np.nan_to_num(frames[f], nan=1.0)
+            ro, want = O.calc_rmsd_and_fit(ref_pos, masses, idx, box, clean, masses, idx, box)
+            got = cur.get_positions(f)
+            assert abs(float(r[f]) - ro) <= 1e-5, (f, float(r[f]), ro)
+            fin = np.isfinite(frames[f][:, 0])
+            assert np.abs(got[fin] - want[fin]).max() <= 5e-5 and np.isnan(got[~fin]).all()
+    plan.close(); ref.close(); cur.close()

@@ -40,8 +40,12 @@ for name, blocks, masked in [(k, v, m) for k, v in sels.items() for m in (1, 0)]
         s.group_center_batch("all", G._lib.CENTER_NAIVE, 1, 0, 256)
     r = {"calc_rmsd": timed(lambda: plan.rmsd(0, NF)), "get_com": timed(lambda: s.group_get_com_batch("S", 0, NF)),
          "estimate_com": timed(lambda: s.group_estimate_com_batch("S", 0, NF))}
-    s.synth_frames(NF, 0, NF, 0, 0.05, 1)
-    t0 = time.perf_counter(); plan.rmsd_fit(0, NF); r["calc_rmsd_and_fit (one call, fresh frames)"] = round(1e6 * (time.perf_counter() - t0) / NF, 3)
+    fits = []
+    for _ in range(3):                                   # (the first call of a kind pays its buffers; every call gets fresh frames)
+        s.synth_frames(NF, 0, NF, 0, 0.05, 1); s.sync()
+        t0 = time.perf_counter(); plan.rmsd_fit(0, NF); fits.append(time.perf_counter() - t0)
+    r["calc_rmsd_and_fit (one call, fresh frames)"] = round(1e6 * min(fits[1:]) / NF, 3)
+    r["... resident launches"] = s.stat("res_launches")
     out["results"][name + ("" if masked or len(blocks) == 1 else " -- masked_selections=0: the index-list paths")] = r
     plan.close()
     for x in (ref, s):
