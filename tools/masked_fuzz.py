@@ -1,0 +1,138 @@
+#!/usr/bin/env python3
+"""Randomised soak of the masked-span passes (dense scattered selections: k_sums_pk<.., MASK>, the resident pass with mask bits) on the
+GPU box: system sizes 5 000 .. 400 000 atoms, selections drawn as strides, random blocks or random bits at 15 .. 95 % density of their
+span, three cells, unselected atoms left in the blob or thrown all over the cell, an atom without position inside or outside the
+selection now and then, a frame whose image proof fails now and then, the resident pass forced / default / off.  Every call --
+calc_rmsd, calc_rmsd_and_fit, get_com, get_center -- is compared with the index-list paths (GR_TUNE_MASKED_SELECTIONS = 0) on the same
+frames (statuses equal, rmsd to 2e-6 nm, centres to 5e-6, fitted coordinates to 3e-5), and one frame per case with the oracle when the
+system is small enough.  Prints one line per case; exit status 1 on a mismatch.
+
+    python tools/masked_fuzz.py [seconds] [seed]
+"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import groan_rs_amd as G
+import oracle_lib as O
+from groan_rs_amd import workload as W
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+CELLS = [([7.0, 6.5, 6.0], [90.0, 90.0, 90.0]), ([7.0, 6.5, 6.0], [75.0, 80.0, 70.0]), ([6.5, 6.5, 6.5], [60.0, 60.0, 90.0])]
+
+
+def runs_of(mask, offset):
+    """[(first, last)] of the set bits of `mask`, shifted by `offset`"""
+    d = np.diff(np.concatenate([[0], mask.astype(np.int8), [0]]))
+    a, b = np.nonzero(d == 1)[0], np.nonzero(d == -1)[0]
+    return [(int(x) + offset, int(y) - 1 + offset) for x, y in zip(a, b)]
+
+
+def draw_selection(n):
+    lo = int(rng.integers(0, max(1, n // 10)))
+    hi = n - 1 - int(rng.integers(0, max(1, n // 10)))
+    span = hi - lo + 1
+    kind = int(rng.integers(0, 4))
+    m = np.zeros(span, bool)
+    if kind == 0:                                           # stride
+        k = int(rng.integers(2, 7)); w = int(rng.integers(1, k))
+        for j in range(w):
+            m[j::k] = True
+    elif kind == 1:                                         # random blocks
+        nb = int(rng.integers(2, 40))
+        cuts = np.sort(rng.integers(0, span, 2 * nb))
+        for j in range(nb):
+            m[cuts[2 * j]:cuts[2 * j + 1] + 1] = True
+    elif kind == 2:                                         # random bits
+        m = rng.random(span) < rng.uniform(0.15, 0.95)
+    else:                                                   # residues: blocks of a few atoms every so many
+        step = int(rng.integers(8, 60)); w = int(rng.integers(2, step))
+        for j in range(w):
+            m[j::step] = True
+    m[0] = m[-1] = True
+    return runs_of(m, lo), np.nonzero(m)[0] + lo, ("stride", "blocks", "bits", "residues")[kind]
+
+
+t_end = time.time() + budget
+case = bad = 0
+took = {"masked": 0, "list": 0, "resident": 0}
+while time.time() < t_end:
+    case += 1
+    n = int(np.exp(rng.uniform(np.log(5_000), np.log(400_000))))
+    nf = int(rng.choice([1, 3, 8, 17, 33]))
+    l, a = CELLS[int(rng.integers(0, 3))]
+    scale = (n / 20_000.0) ** (1.0 / 3.0)
+    box = W.box_from_lengths_angles([x * scale for x in l], a)
+    blocks, idx, kind = draw_selection(n)
+    masses = W.masses_cycle(n)
+    resident = int(rng.choice([0, 1, 2]))
+    streams = int(rng.choice([0, 1, 2, 5]))
+    unsel = np.setdiff1d(np.arange(n), idx)
+    res = {}
+    frames = None
+    for masked in (1, 0):
+        cur = G.System(n, masses=masses, n_slots=nf + 1)
+        cur.set_tuning(masked_selections=masked, rmsd_fast_min=0, resident=resident, resident_streams=streams)
+        cur.synth_reference(nf, box, 0.2 * float(min(box[:3])), 7 + case)
+        cur.synth_frames(nf, 0, nf, 0, 0.04, 7 + case)
+        ref_pos = cur.get_positions(nf)
+        if frames is None:
+            frames = [cur.get_positions(f) for f in range(nf)]
+            notes = []
+            if len(unsel) and rng.integers(0, 2):           # unselected atoms anywhere in the cell
+                f = int(rng.integers(0, nf))
+                frames[f][unsel] = (rng.random((len(unsel), 3)) @ W.box_matrix(box)).astype(np.float32); notes.append("scatter@%d" % f)
+            if len(unsel) and rng.integers(0, 3) == 0:      # an unselected atom without position
+                f = int(rng.integers(0, nf)); frames[f][unsel[int(rng.integers(0, len(unsel)))]] = np.nan; notes.append("nan-out@%d" % f)
+            if rng.integers(0, 3) == 0:                     # a selected atom without position
+                f = int(rng.integers(0, nf)); frames[f][idx[int(rng.integers(0, len(idx)))]] = np.nan; notes.append("nan-in@%d" % f)
+            if nf > 2 and n <= 150_000 and rng.integers(0, 3) == 0:
+                f = int(rng.integers(0, nf)); frames[f] = W.proof_failing_frame(ref_pos, box, "two_lobes" if rng.integers(0, 2) else "stretched", 11 + case); notes.append("wide@%d" % f)
+        ref = G.System(n, masses=masses, box=box, positions=ref_pos)
+        ref.set_tuning(masked_selections=masked)
+        for s_ in (ref, cur):
+            s_.group_create_from_ranges("S", blocks)
+        for f in range(nf):
+            cur.set_frame(frames[f], box, slot=f)
+        plan = G.RMSDPlan(ref, cur, "S")
+        r, st = plan.rmsd(0, nf, raise_on_error=False)
+        fast = cur.stat("rmsd_fast_frames") + cur.stat("rmsd_exact_redos")
+        com, cst = cur.group_get_com_batch("S", 0, nf, raise_on_error=False)
+        cen, _ = cur.group_get_center_batch("S", 0, nf, raise_on_error=False)
+        rf, stf = plan.rmsd_fit(0, nf, raise_on_error=False)
+        fitted = [cur.get_positions(f) for f in range(nf)]
+        res[masked] = (np.array(r), np.array(st), np.array(com), np.array(cst), np.array(cen), np.array(rf), np.array(stf), fitted, fast, cur.stat("res_launches"))
+        plan.close(); ref.close(); cur.close()
+    a_, b_ = res[1], res[0]
+    ok, why = True, ""
+    if not (np.array_equal(a_[1], b_[1]) and np.array_equal(a_[3], b_[3]) and np.array_equal(a_[6], b_[6])):
+        ok, why = False, "statuses %s/%s %s/%s %s/%s" % (a_[1], b_[1], a_[3], b_[3], a_[6], b_[6])
+    good = (a_[1] == 0) & (a_[6] == 0)
+    if ok and good.any():
+        d = [np.abs(a_[0][good] - b_[0][good]).max(), np.abs(a_[5][good] - b_[5][good]).max(), np.abs(a_[2][good] - b_[2][good]).max(), np.abs(a_[4][good] - b_[4][good]).max()]
+        if d[0] > 2e-6 or d[1] > 2e-6 or d[2] > 5e-6 or d[3] > 5e-6:
+            ok, why = False, "rmsd %g rmsd_fit %g com %g centre %g" % tuple(d)
+        for f in np.nonzero(good)[0]:
+            fa, fb = np.isfinite(a_[7][f][:, 0]), np.isfinite(b_[7][f][:, 0])
+            if ok and not np.array_equal(fa, fb): ok, why = False, "positions without value differ in frame %d" % f
+            if ok and np.abs(a_[7][f][fa] - b_[7][f][fa]).max() > 3e-5: ok, why = False, "fitted coordinates of frame %d: %g" % (f, np.abs(a_[7][f][fa] - b_[7][f][fa]).max())
+    if ok and good.any() and n <= 60_000:
+        f = int(np.nonzero(good)[0][0])
+        with O.acc64():
+            clean = np.nan_to_num(frames[f], nan=1.0)
+            ro, want = O.calc_rmsd_and_fit(ref_pos, masses, idx, box, clean, masses, idx, box)
+            wc = O.get_center(clean, idx, box, mass=masses)
+        fin = np.isfinite(frames[f][:, 0])
+        if abs(float(a_[0][f]) - ro) > 1e-5 or abs(float(a_[5][f]) - ro) > 1e-5 or np.abs(a_[2][f] - wc).max() > 1e-5 or np.abs(a_[7][f][fin] - want[fin]).max() > 5e-5:
+            ok, why = False, "oracle, frame %d: rmsd %g / %g vs %g, com %g, coordinates %g" % (f, a_[0][f], a_[5][f], ro, np.abs(a_[2][f] - wc).max(), np.abs(a_[7][f][fin] - want[fin]).max())
+    took["masked" if a_[8] else "list"] += 1
+    took["resident"] += 1 if a_[9] else 0
+    print("case %3d n=%6d nf=%2d sel=%-8s n_sel=%6d blocks=%5d cell=%s resident=%d(%d launches) streams=%d %s masked=%d %s %s" % (
+        case, n, nf, kind, len(idx), len(blocks), a, resident, a_[9], streams, ",".join(notes) or "-", 1 if a_[8] else 0, "ok" if ok else "MISMATCH", why), flush=True)
+    bad += 0 if ok else 1
+print("cases %d, mismatches %d, %s" % (case, bad, took), flush=True)
+sys.exit(1 if bad else 0)
