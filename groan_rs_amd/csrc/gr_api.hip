@@ -43,6 +43,7 @@ struct Group {
     uint32_t start = 0;
     uint32_t *idx_dev = nullptr;
     uint32_t *mask_dev = nullptr;     // one bit per atom of the system (group-limited trajectory reads: built on first use; masked selections: built with the group)
+    bool walk_rw = false;             // ... and translate / wrap walk the span as well (k_translate_wrap)
     bool masked = false;              // non-contiguous but DENSE (>= 1/8 of its span, >= 4096 atoms): the sums kernels walk the span with this mask
     uint32_t span = 0;                // atoms from the first to the last selected one
 };
@@ -196,7 +197,7 @@ int fail(gr_ctx *c, int status, const std::string &msg, uint64_t index = 0) {
 GrSel make_sel(const Group &g) {
     GrSel s;
     s.n = (uint32_t)g.n; s.contiguous = g.contiguous ? 1u : 0u; s.start = g.start; s.g0 = g.start >> 8; s.idx = g.idx_dev;
-    s.masked = (g.masked && g.mask_dev) ? 1u : 0u; s.span = g.contiguous ? (uint32_t)g.n : g.span; s.mask = g.mask_dev;
+    s.masked = (g.masked && g.mask_dev) ? (g.walk_rw ? 3u : 1u) : 0u; s.span = g.contiguous ? (uint32_t)g.n : g.span; s.mask = g.mask_dev;
     return s;
 }
 
@@ -386,6 +387,12 @@ int group_build(gr_ctx *c, std::vector<grc::Block> blocks, Group *out) {
         if (g.masked) {
             std::vector<uint32_t> bits(((size_t)c->n_pad + 31) / 32, 0u);
             for (const auto &b : g.blocks) for (uint64_t a = b.first; a <= b.second; ++a) bits[a >> 5] |= 1u << (a & 31u);
+            // translate / wrap (read-modify-write of whole 4-atom groups) walk the span too when that moves fewer bytes than the list: a
+            // group without a selected atom is skipped unread, so what counts is the number of groups the selection TOUCHES -- ~17 ps
+            // per touched group against 8 (runs of neighbours) to 14 ps (lone atoms) per atom on the list (tools/wrap_bench.py)
+            uint64_t touched = 0;
+            for (uint32_t w : bits) for (int q = 0; q < 8; ++q) touched += ((w >> (4 * q)) & 15u) != 0u;
+            g.walk_rw = touched * 17 <= g.n * 14;
             if (hipMalloc(&g.mask_dev, bits.size() * sizeof(uint32_t)) != hipSuccess ||
                 hipMemcpy(g.mask_dev, bits.data(), bits.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) {
                 if (g.mask_dev) (void)hipFree(g.mask_dev);
@@ -1230,7 +1237,7 @@ static int translate_core(gr_ctx *c, uint32_t slot, const Group &g, const float 
     const GrSel sel = make_sel(g);
     SlotUse use(c, slot);
     HIPCHK(c, hipMemsetAsync(c->bad_dev, 0xFF, 4 * sizeof(uint32_t), c->stream));
-    const uint64_t units = sel.contiguous ? ((uint64_t)sel.n + 3) / 4 + 128 : sel.n;
+    const uint64_t units = sel.contiguous ? ((uint64_t)sel.n + 3) / 4 + 128 : (sel.masked & 2u) ? ((uint64_t)sel.span + 3) / 4 + 128 : sel.n;   // (4-atom groups of the block / of a masked selection's span; list entries)
     uint32_t nwg = (uint32_t)std::min<uint64_t>((units + GR_WG - 1) / GR_WG, 4096);
     k_translate_wrap<<<dim3(nwg), dim3(GR_WG), 0, c->stream>>>(c->frames + (size_t)slot * c->frame_stride, c->frame_stride, sel, c->boxes_dev + slot, c->state_dev, use_state, dim_mask, v ? v[0] : 0.f, v ? v[1] : 0.f, v ? v[2] : 0.f, c->bad_dev);
     HIPCHK(c, hipGetLastError());
@@ -1475,7 +1482,7 @@ static int translate_batch(gr_ctx *c, uint32_t s0, uint32_t nb, const Group *g, 
     const GrSel sel = make_sel(*g);
     HIPCHK(c, hipMemsetAsync(c->bad_dev, 0xFF, 4 * (size_t)nb * sizeof(uint32_t), c->stream));
     if (g->n) {
-        const uint64_t units = sel.contiguous ? ((uint64_t)sel.n + 3) / 4 + 128 : sel.n;
+        const uint64_t units = sel.contiguous ? ((uint64_t)sel.n + 3) / 4 + 128 : (sel.masked & 2u) ? ((uint64_t)sel.span + 3) / 4 + 128 : sel.n;   // (4-atom groups of the block / of a masked selection's span; list entries)
         const uint32_t nwg = (uint32_t)std::min<uint64_t>((units + GR_WG - 1) / GR_WG, 4096);
         k_translate_wrap<<<dim3(nwg, nb), dim3(GR_WG), 0, c->stream>>>(c->frames + (size_t)s0 * c->frame_stride, c->frame_stride, sel, c->boxes_dev + s0, c->state_dev, mode, dim_mask,
                                                                        v ? v[0] : 0.f, v ? v[1] : 0.f, v ? v[2] : 0.f, c->bad_dev);

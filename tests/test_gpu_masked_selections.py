@@ -222,3 +222,38 @@ def test_rmsd_fit_of_a_masked_selection_through_the_resident_pass(G, shape, cell
         fin = np.isfinite(a[2][f][:, 0]) & np.isfinite(b[2][f][:, 0])
         assert np.array_equal(np.isfinite(a[2][f][:, 0]), np.isfinite(b[2][f][:, 0]))
         assert np.abs(a[2][f][fin] - b[2][f][fin]).max() <= 3e-5, f
+
+
+@pytest.mark.parametrize("shape", ["nine in ten", "pairs", "two blocks"])
+def test_translate_and_wrap_of_a_masked_group_are_the_list_paths_bit_for_bit(G, shape):
+    """group translate / wrap of a scattered selection that covers at least half of its span walk the span with the mask
+    (k_translate_wrap); every atom goes through the same arithmetic as on the index-list path, so the frames must come out
+    identical bit for bit, atoms outside the selection untouched, an atom without position named the same way"""
+    n, nf = 50_001, 5
+    box = W.box_from_lengths_angles([7.0, 6.5, 6.0], [75.0, 80.0, 70.0])
+    blocks = {"nine in ten": [(i, i + 8) for i in range(3, n - 10, 10)], "pairs": [(i, i + 1) for i in range(1, n - 2, 4)], "two blocks": [(5, n // 3), (n // 2 + 3, n - 7)]}[shape]
+    idx = _idx(blocks)
+    out = {}
+    for masked in (1, 0):
+        cur = G.System(n, masses=W.masses_cycle(n), n_slots=nf + 1)
+        cur.set_tuning(masked_selections=masked)
+        cur.synth_reference(nf, box, 0.45 * min(box[:3]), W.SEED)
+        cur.synth_frames(nf, 0, nf, 0, 0.3, W.SEED)
+        before = [cur.get_positions(f) for f in range(nf)]
+        before[3] = before[3].copy(); before[3][idx[len(idx) // 2]] = np.nan
+        cur.set_frame(before[3], box, slot=3)
+        cur.group_create_from_ranges("S", blocks)
+        st1 = cur.group_translate_batch("S", [3.3, -7.1, 0.4], 0, nf, raise_on_error=False)
+        mid = [cur.get_positions(f) for f in range(nf)]
+        st2 = cur.group_wrap_batch("S", 0, nf, raise_on_error=False)
+        out[masked] = (np.array(st1), np.array(st2), mid, [cur.get_positions(f) for f in range(nf)])
+        if masked:
+            other = np.setdiff1d(np.arange(n), idx)
+            for f in range(nf):
+                assert np.array_equal(mid[f][other], before[f][other]) and np.array_equal(out[1][3][f][other], before[f][other])
+            assert st1[3] != 0 and all(st1[f] == 0 for f in (0, 1, 2, 4))
+        cur.close()
+    a, b = out[1], out[0]
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    for f in range(nf):
+        assert np.array_equal(a[2][f], b[2][f], equal_nan=True) and np.array_equal(a[3][f], b[3][f], equal_nan=True), f
