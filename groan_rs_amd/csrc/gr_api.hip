@@ -21,6 +21,7 @@
 #include "gr_xtc.h"
 #include "gr_shape.h"
 #include "gr_xtc_dev.h"
+#include "gr_xtc_enc_dev.h"
 #include "gr_trr.h"
 #include "gr_cellgrid.h"
 #include "gr_textio.h"
@@ -139,6 +140,11 @@ struct gr_ctx {
     hipStream_t unpack_stream = nullptr;
     uint32_t xtc_bank = 0;
     float *wr_host = nullptr; size_t wr_cap = 0;   // pinned landing buffer of gr_xtc_write_slots (grow-only)
+    // device xtc encoder (gr_xtc_enc_dev.h), grow-only: quantised atoms, run words, run descriptors, streams
+    void *xe_dev[6] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr }; size_t xe_cap[6] = { 0, 0, 0, 0, 0, 0 };   // ints, enc, runs, meta, hdr + offsets, out
+    unsigned char *xe_host = nullptr; size_t xe_host_cap = 0;     // pinned: headers + offsets + streams
+    int xtc_dev_encode = 0;           // GR_TUNE_XTC_DEVICE_ENCODE (off: at 256 frames per call 16 host encoders are faster -- a frame's sequential walk takes ~100 ms on one wave)
+    uint64_t xtc_dev_frames = 0;      // frames gr_xtc_write_slots compressed on the device (GR_STAT_XTC_DEVICE_FRAMES)
     int strict = 0;
     gr_rmsd_plan *in_flight = nullptr;   // the plan whose gr_rmsd_batch_begin has not been ended yet (shared workspace: one at a time)
     uint32_t in_flight_s0 = 0, in_flight_n = 0;   // its slots
@@ -751,6 +757,8 @@ void gr_ctx_destroy(gr_ctx *c) try {
     if (c->bad_dev) (void)hipFree(c->bad_dev);
     if (c->bad_host) (void)hipHostFree(c->bad_host);
     if (c->pd_out) (void)hipFree(c->pd_out);
+    for (int k = 0; k < 6; ++k) if (c->xe_dev[k]) (void)hipFree(c->xe_dev[k]);
+    if (c->xe_host) (void)hipHostFree(c->xe_host);
     if (c->unpack_stream) { (void)hipStreamSynchronize(c->unpack_stream); (void)hipStreamDestroy(c->unpack_stream); }
     for (int k = 0; k < 2; ++k) {
         if (c->xtc_host[k]) (void)hipHostFree(c->xtc_host[k]);
@@ -1627,6 +1635,7 @@ int gr_ctx_stat(const gr_ctx *c, int key, uint64_t *value) {
     case GR_STAT_RES_REDONE_FRAMES: *value = c->res_redone_frames; return GR_OK;
     case GR_STAT_RMSD_FAST_FRAMES: *value = c->rmsd_fast_frames; return GR_OK;
     case GR_STAT_RMSD_EXACT_REDOS: *value = c->rmsd_exact_redos; return GR_OK;
+    case GR_STAT_XTC_DEVICE_FRAMES: *value = c->xtc_dev_frames; return GR_OK;
     default: return GR_E_INVALID_ARG;
     }
 }
@@ -1641,6 +1650,7 @@ int gr_ctx_set_tuning(gr_ctx *c, int key, int64_t value) try {
     case GR_TUNE_TWO_PASS: c->two_pass = value ? 1 : 0; return GR_OK;
     case GR_TUNE_RESIDENT: if (value < 0 || value > 2) break; c->resident = value; return GR_OK;
     case GR_TUNE_MASKED_SELECTIONS: if (value != 0 && value != 1) break; c->masked_sel = (int)value; return GR_OK;
+    case GR_TUNE_XTC_DEVICE_ENCODE: if (value != 0 && value != 1) break; c->xtc_dev_encode = (int)value; return GR_OK;
     case GR_TUNE_RMSD_FAST: if (value != 0 && value != 1) break; c->rmsd_fast = (int)value; return GR_OK;
     case GR_TUNE_RMSD_FAST_MIN: if (value < 0 || value > 0x7fffffff) break; c->rmsd_fast_min = (uint32_t)value; return GR_OK;
     case GR_TUNE_RMSD_FAST_SIGMAS: if (value < 0 || value > 1000) break; c->rmsd_fast_sigmas = (int)value; return GR_OK;
@@ -2621,6 +2631,105 @@ int gr_xtc_write_frame(gr_xtc_writer *w, uint64_t n, const float *xyz, const flo
     if (!grx::serialise_frame(out, (uint32_t)n, (int32_t)step, time, m, xyz, precision, sc, ints)) return GR_E_OUT_OF_RANGE;
     return fwrite(out.data(), 1, out.size(), w->fp) == out.size() ? GR_OK : GR_E_IO;
 } catch (...) { return gr_abi_guard(); }
+// gr_xtc_write_slots on the device encoder: rounds of frames whose scratch (30 bytes per atom and frame) stays below ~4 GB
+static int xe_reserve(gr_ctx *c, int k, size_t bytes) {
+    if (bytes <= c->xe_cap[k]) return GR_OK;
+    if (c->xe_dev[k]) (void)hipFree(c->xe_dev[k]);
+    c->xe_dev[k] = nullptr; c->xe_cap[k] = 0;
+    HIPCHK(c, hipMalloc(&c->xe_dev[k], bytes));
+    c->xe_cap[k] = bytes;
+    return GR_OK;
+}
+static int xtc_write_slots_device(gr_xtc_writer *w, gr_ctx *c, uint32_t first_slot, uint32_t n_frames, const Group *g,
+                                  const int64_t *steps, const float *times, float precision) {
+    if (!(precision > 0.0f)) precision = 1000.0f;
+    const uint32_t n = (uint32_t)(g ? g->n : c->n);
+    GrSel sel;
+    if (g) sel = make_sel(*g);
+    else { Group all; all.n = c->n; all.contiguous = true; all.start = 0; sel = make_sel(all); }
+    const size_t per_frame = (size_t)n * 30u;
+    const uint32_t round = (uint32_t)std::max<size_t>(1, std::min<size_t>(n_frames, ((size_t)4 << 30) / per_frame));
+    int st;
+    if ((st = xe_reserve(c, 0, (size_t)round * n * 12u)) || (st = xe_reserve(c, 1, (size_t)round * n * 8u)) || (st = xe_reserve(c, 2, (size_t)round * n * 8u)) ||
+        (st = xe_reserve(c, 3, (size_t)round * n * 2u + 16u)) || (st = xe_reserve(c, 4, (size_t)round * (sizeof(GrXencHdr) + 8u)))) return st;
+    int *ints = (int *)c->xe_dev[0]; unsigned long long *enc = (unsigned long long *)c->xe_dev[1]; GrXencRun *runs = (GrXencRun *)c->xe_dev[2]; uint16_t *meta = (uint16_t *)c->xe_dev[3];
+    GrXencHdr *hdr_dev = (GrXencHdr *)c->xe_dev[4]; unsigned long long *off_dev = (unsigned long long *)((unsigned char *)c->xe_dev[4] + (size_t)round * sizeof(GrXencHdr));
+    const size_t head_bytes = (size_t)round * (sizeof(GrXencHdr) + 8u);
+    std::vector<unsigned char> frame_out;
+    for (uint32_t r0 = 0; r0 < n_frames; r0 += round) {
+        const uint32_t nf = std::min<uint32_t>(round, n_frames - r0), s0 = first_slot + r0;
+        SlotUse use(c, s0, nf);
+        // pinned: headers + offsets now, the streams behind them once their size is known
+        if (head_bytes > c->xe_host_cap) {
+            if (c->xe_host) (void)hipHostFree(c->xe_host);
+            c->xe_host = nullptr; c->xe_host_cap = 0;
+            HIPCHK(c, hipHostMalloc(&c->xe_host, head_bytes + ((size_t)nf * n * 4u), hipHostMallocDefault));   // (~4 B per atom: the usual stream; grown below when a batch needs more)
+            c->xe_host_cap = head_bytes + (size_t)nf * n * 4u;
+        }
+        GrXencHdr *hdr = (GrXencHdr *)c->xe_host; unsigned long long *off = (unsigned long long *)(c->xe_host + (size_t)round * sizeof(GrXencHdr));
+        for (uint32_t f = 0; f < nf; ++f) { GrXencHdr h = {}; for (int a = 0; a < 3; ++a) { h.mn[a] = INT_MAX; h.mx[a] = INT_MIN; } h.mindiff = (uint32_t)INT_MAX; hdr[f] = h; }
+        HIPCHK(c, hipMemcpyAsync(hdr_dev, hdr, (size_t)nf * sizeof(GrXencHdr), hipMemcpyHostToDevice, c->stream));
+        k_xenc_quant<<<dim3(std::min<uint32_t>((n + 255u) / 256u, 2048u), nf), dim3(256), 0, c->stream>>>(c->frames, c->frame_stride, s0, sel, n, precision, ints, hdr_dev);
+        k_xenc_enc<<<dim3(std::min<uint32_t>((n + 255u) / 256u, 2048u), nf), dim3(256), 0, c->stream>>>(ints, n, hdr_dev, enc);
+        k_xenc_plan<<<dim3(nf), dim3(64), 0, c->stream>>>(enc, n, hdr_dev, runs, meta);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync(hdr, hdr_dev, (size_t)nf * sizeof(GrXencHdr), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        // frames up to the first one the format cannot hold (exactly what a loop of write_frame calls would leave in the file)
+        uint32_t n_good = 0; uint32_t max_runs = 0; unsigned long long total = 0;
+        for (; n_good < nf; ++n_good) {
+            const GrXencHdr &h = hdr[n_good];
+            bool ok = (h.flags & 1u) == 0u;
+            for (int a = 0; a < 3; ++a) if ((float)h.mx[a] - (float)h.mn[a] >= (float)(INT_MAX - 2)) ok = false;
+            if (!ok) break;
+            off[n_good] = total;
+            total += (((unsigned long long)(h.n_bits + 7u) / 8u + 3ull) & ~3ull) + 8ull;
+            max_runs = std::max(max_runs, h.n_runs);
+        }
+        if (n_good) {
+            if ((st = xe_reserve(c, 5, (size_t)total))) return st;
+            unsigned char *out_dev = (unsigned char *)c->xe_dev[5];
+            if (head_bytes + total > c->xe_host_cap) {           // the streams do not fit behind the headers: a larger pinned buffer, headers kept
+                unsigned char *bigger = nullptr;
+                HIPCHK(c, hipHostMalloc(&bigger, head_bytes + (size_t)total, hipHostMallocDefault));
+                memcpy(bigger, c->xe_host, head_bytes);
+                (void)hipHostFree(c->xe_host);
+                c->xe_host = bigger; c->xe_host_cap = head_bytes + (size_t)total;
+                hdr = (GrXencHdr *)c->xe_host; off = (unsigned long long *)(c->xe_host + (size_t)round * sizeof(GrXencHdr));
+            }
+            HIPCHK(c, hipMemsetAsync(out_dev, 0, (size_t)total, c->stream));
+            HIPCHK(c, hipMemcpyAsync(off_dev, off, (size_t)n_good * 8u, hipMemcpyHostToDevice, c->stream));
+            k_xenc_emit<<<dim3(std::max<uint32_t>(1u, std::min<uint32_t>((max_runs + 255u) / 256u, 4096u)), n_good), dim3(256), 0, c->stream>>>(ints, n, hdr_dev, runs, meta, off_dev, out_dev);
+            HIPCHK(c, hipGetLastError());
+            unsigned char *streams = c->xe_host + head_bytes;
+            HIPCHK(c, hipMemcpyAsync(streams, out_dev, (size_t)total, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            for (uint32_t f = 0; f < n_good; ++f) {
+                const GrXencHdr &h = hdr[f];
+                const uint32_t nbytes = (h.n_bits + 7u) / 8u, k = r0 + f;
+                float m[9]; box9_rows(c->box9_set[s0 + f] ? &c->box9_host[9 * (size_t)(s0 + f)] : nullptr, m);
+                std::vector<unsigned char> &o = frame_out;
+                o.clear();
+                grx::put_be32(o, 1995u); grx::put_be32(o, n); grx::put_be32(o, (uint32_t)(int32_t)(steps ? steps[k] : 0)); grx::put_bef(o, times ? times[k] : 0.0f);
+                for (int q = 0; q < 9; ++q) grx::put_bef(o, m[q]);
+                grx::put_be32(o, n);
+                grx::put_bef(o, precision);
+                for (int a = 0; a < 3; ++a) grx::put_be32(o, (uint32_t)h.mn[a]);
+                for (int a = 0; a < 3; ++a) grx::put_be32(o, (uint32_t)h.mx[a]);
+                grx::put_be32(o, (uint32_t)h.smallidx0);
+                grx::put_be32(o, nbytes);
+                if (fwrite(o.data(), 1, o.size(), w->fp) != o.size()) return fail(c, GR_E_IO, "short write");
+                const size_t padded = ((size_t)nbytes + 3u) & ~(size_t)3u;          // (the stream's tail is zero: the pad bytes are already there)
+                if (fwrite(streams + off[f], 1, padded, w->fp) != padded) return fail(c, GR_E_IO, "short write");
+            }
+            c->xtc_dev_frames += n_good;
+        }
+        if (n_good < nf)
+            return fail(c, GR_E_OUT_OF_RANGE, "coordinates do not fit the xtc integers at this precision; the frames before this slot were written", s0 + n_good);
+    }
+    return GR_OK;
+}
+
 int gr_xtc_write_slots(gr_xtc_writer *w, gr_ctx *c, uint32_t first_slot, uint32_t n_frames, const char *group,
                        const int64_t *steps, const float *times, float precision, int host_threads) try {
     if (!w || !w->fp || !c) return GR_E_INVALID_ARG;
@@ -2634,6 +2743,9 @@ int gr_xtc_write_slots(gr_xtc_writer *w, gr_ctx *c, uint32_t first_slot, uint32_
         members = grc::expand(g->blocks);
     }
     const uint64_t n_out = g ? g->n : c->n;
+    // on request, large outputs are compressed on the device (gr_xtc_enc_dev.h): what crosses PCIe is the stream, and no host thread encodes
+    if (c->xtc_dev_encode && n_out > 9 && n_out <= (1ull << 24) && n_out * n_frames >= 200000ull)
+        return xtc_write_slots_device(w, c, first_slot, n_frames, g, steps, times, precision);
     const size_t fb = (size_t)c->n * 3 * sizeof(float);
     // D2H of the whole batch on the compute stream into one pinned buffer (frames are ordered behind the kernels that wrote them);
     // per-frame events let the encoders start as soon as their frame has landed

@@ -293,6 +293,10 @@ enum { GR_TUNE_SUB_BATCH = 1, GR_TUNE_CHUNKS = 2, GR_TUNE_FIT_WGS = 3, GR_TUNE_F
        GR_TUNE_MASKED_SELECTIONS = 15 /* 1 (default): a scattered selection that covers at least an eighth of the atoms between its first and its last one (>= 4096
                                          atoms) also gets a bit mask, and RMSD / RMSD-fit / get_com read its span coalesced instead of gathering it atom by atom;
                                          0: groups created afterwards keep to their index lists.  Same results to rounding. */,
+       GR_TUNE_XTC_DEVICE_ENCODE = 16 /* 1: gr_xtc_write_slots compresses outputs of >= 200 000 atoms (frames x atoms) on the device -- the same bytes as the host
+                                         encoder, only the compressed stream crosses PCIe and no host thread encodes; 0 (default): host threads encode.  The device path
+                                         is for hosts short of cores: a frame's run structure is walked by ONE wave (~100 ms per 5e5-atom frame whatever the batch), so
+                                         at 256 frames per call it writes 1.0-1.9 k frames/s where 16 host encoders write 1.6-2.8 k (tools/xtc_write_bench.py) */,
        GR_TUNE_RMSD_FAST_SIGMAS = 14 /* multiples (default 6) of the pass's own rounding estimate a frame's rmsd must stand clear of to be kept; 0 keeps every frame: calibration runs only (tools/rmsd_calibrate.py) */,
        GR_TUNE_TEST_RESIDENT_NO_START = 100 /* tests: the next resident launch behaves as if its workgroups never got onto the chip */,
        GR_TUNE_TEST_RESIDENT_ABORT_AT = 101 /* tests: the next resident launch is aborted from inside when it reaches this frame of its segment (< 0: never) */ };
@@ -308,7 +312,8 @@ int gr_ctx_set_tuning(gr_ctx *ctx, int key, int64_t value);
  *   GR_STAT_RES_LAST_STREAMS       frame streams of the context's last resident launch (GR_TUNE_RESIDENT_STREAMS) */
 enum { GR_STAT_N_CUS = 1, GR_STAT_RES_MAX_WGS = 2, GR_STAT_RES_LAUNCHES = 3, GR_STAT_RES_HANDSHAKE_MISSES = 4, GR_STAT_RES_ABORTS = 5, GR_STAT_RES_REDONE_FRAMES = 6, GR_STAT_RES_LAST_STREAMS = 7,
        GR_STAT_RMSD_FAST_FRAMES = 8 /* frames of RMSD-without-fit calls closed by the f32-chain pass (GR_TUNE_RMSD_FAST) */,
-       GR_STAT_RMSD_EXACT_REDOS = 9 /* ... and frames that pass handed back to the exact-product pass */ };
+       GR_STAT_RMSD_EXACT_REDOS = 9 /* ... and frames that pass handed back to the exact-product pass */,
+       GR_STAT_XTC_DEVICE_FRAMES = 10 /* frames gr_xtc_write_slots compressed on the device (GR_TUNE_XTC_DEVICE_ENCODE) */ };
 int gr_ctx_stat(const gr_ctx *ctx, int key, uint64_t *value);
 
 /* ---------------------------------------------------------------- text front end: gro structures, ndx index groups (host side)
