@@ -143,7 +143,7 @@ struct gr_ctx {
     // device xtc encoder (gr_xtc_enc_dev.h), grow-only: quantised atoms, run words, run descriptors, streams
     void *xe_dev[6] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr }; size_t xe_cap[6] = { 0, 0, 0, 0, 0, 0 };   // ints, enc, runs, meta, hdr + offsets, out
     unsigned char *xe_host = nullptr; size_t xe_host_cap = 0;     // pinned: headers + offsets + streams
-    int xtc_dev_encode = 0;           // GR_TUNE_XTC_DEVICE_ENCODE (off: at 256 frames per call 16 host encoders are faster -- a frame's sequential walk takes ~100 ms on one wave)
+    int xtc_dev_encode = 1;           // GR_TUNE_XTC_DEVICE_ENCODE
     uint64_t xtc_dev_frames = 0;      // frames gr_xtc_write_slots compressed on the device (GR_STAT_XTC_DEVICE_FRAMES)
     int strict = 0;
     gr_rmsd_plan *in_flight = nullptr;   // the plan whose gr_rmsd_batch_begin has not been ended yet (shared workspace: one at a time)
@@ -2671,7 +2671,7 @@ static int xtc_write_slots_device(gr_xtc_writer *w, gr_ctx *c, uint32_t first_sl
         HIPCHK(c, hipMemcpyAsync(hdr_dev, hdr, (size_t)nf * sizeof(GrXencHdr), hipMemcpyHostToDevice, c->stream));
         k_xenc_quant<<<dim3(std::min<uint32_t>((n + 255u) / 256u, 2048u), nf), dim3(256), 0, c->stream>>>(c->frames, c->frame_stride, s0, sel, n, precision, ints, hdr_dev);
         k_xenc_enc<<<dim3(std::min<uint32_t>((n + 255u) / 256u, 2048u), nf), dim3(256), 0, c->stream>>>(ints, n, hdr_dev, enc);
-        k_xenc_plan<<<dim3(nf), dim3(64), 0, c->stream>>>(enc, n, hdr_dev, runs, meta);
+        k_xenc_plan<<<dim3(nf), dim3(256), 0, c->stream>>>(enc, n, hdr_dev, runs, meta);
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipMemcpyAsync(hdr, hdr_dev, (size_t)nf * sizeof(GrXencHdr), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -2743,7 +2743,7 @@ int gr_xtc_write_slots(gr_xtc_writer *w, gr_ctx *c, uint32_t first_slot, uint32_
         members = grc::expand(g->blocks);
     }
     const uint64_t n_out = g ? g->n : c->n;
-    // on request, large outputs are compressed on the device (gr_xtc_enc_dev.h): what crosses PCIe is the stream, and no host thread encodes
+    // large outputs are compressed on the device (gr_xtc_enc_dev.h): what crosses PCIe is the stream, and no host thread encodes
     if (c->xtc_dev_encode && n_out > 9 && n_out <= (1ull << 24) && n_out * n_frames >= 200000ull)
         return xtc_write_slots_device(w, c, first_slot, n_frames, g, steps, times, precision);
     const size_t fb = (size_t)c->n * 3 * sizeof(float);

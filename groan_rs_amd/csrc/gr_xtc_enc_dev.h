@@ -11,9 +11,9 @@
 //                  smallest L1 step (atomics)
 //   k_xenc_enc     every atom j: what a run STARTING at j would be -- its length and whether it lets the small-range index move --
 //                  for each of the nine values that index can take in the frame: one 64-bit word per atom (see the kernel)
-//   k_xenc_plan    one wave per frame walks the frame's runs -- one word and a few bit operations per run (the first version
-//                  compared distances here: 104 ms per 5e5-atom frame, now see DESIGN.md) -- and writes one descriptor per run:
-//                  first atom, bit offset, run length, the +-1 step of the small-range index, whether the flag bits announce it
+//   k_xenc_plan    one workgroup per frame walks the frame's runs -- one word and a few bit operations per run, 256 segments side by
+//                  side between atoms where a run must start whatever came before (see the kernel) -- and writes one descriptor
+//                  per run: first atom, bit offset, run length, the +-1 step of the small-range index, whether the flag bits announce it
 //   k_xenc_emit    one lane per run: the run's big integer (mixed radix, up to 72 bits), flag bits and small triples, OR-ed into
 //                  the zeroed stream at the run's bit offset
 //
@@ -207,54 +207,100 @@ __global__ __launch_bounds__(256) void k_xenc_enc(const int *__restrict__ ints, 
     }
 }
 
-// One wave per frame walks the runs: xdrfile's decision procedure (gr_xtc.h::encode_coords) over the words of k_xenc_enc.  Everything
-// is wave-uniform; windows of the words are staged in LDS by the whole wave.
-__global__ __launch_bounds__(64) void k_xenc_plan(const unsigned long long *__restrict__ enc, uint32_t n, GrXencHdr *__restrict__ hdr,
-                                                  GrXencRun *__restrict__ runs, uint16_t *__restrict__ meta) {
-    const uint32_t frame = blockIdx.x, lane = threadIdx.x;
+// One workgroup per frame walks the runs: xdrfile's decision procedure (gr_xtc.h::encode_coords) over the words of k_xenc_enc.
+//
+// The walk is a pointer chase -- run r + 1 starts where run r ends, and the small-range index it uses is the one run r left -- and
+// as ONE chain it costs 0.6 us per run: 100 ms for a water-like frame of 5e5 atoms (the first version of this kernel).  But the chain
+// re-synchronises: an atom j whose word has bits 45 and 46 clear is farther than `larger` (>= every smallnum) from atom j - 1 and from
+// atom j - 2, so no run that starts before j can hold it -- not as a small atom (it would have to be near its predecessor in the chain,
+// j - 1 or, right after the swap, j - 2) and not as the swapped big atom of a run starting at j - 1 -- and a run STARTS at j whatever
+// happened before.  What is not known there is the index (nine values) and the length of the run before (for the flag bit:
+// flag_r = run_r != run_(r-1) || index moves -- the format's `prevrun` always equals the previous run's length).  So:
+//   1. thread t looks for the first such atom in its 1/256th of the frame (its anchor; thread 0: atom 0)
+//   2. it walks from its anchor to the next thread's anchor once for EACH of the nine possible entry indices, keeping per entry index:
+//      runs, bits (without the first run's flag field), the index at the exit, the first run's length and index step, the last run's length
+//   3. thread 0 threads the true entry states through the 256 x 9 table (a sequential scan of 256 look-ups)
+//   4. every thread walks its segment once more with its true entry state and writes the run descriptors
+// Ten walks of 1/256th of the frame each, side by side: measured see DESIGN.md.  A frame without such atoms (one dense chain) is walked
+// by thread 0 alone, as before.
+struct GrXencSeg { uint32_t runs, bits; uint16_t packed; };     // packed: exit index (4) | first k (4) << 4 | (first step + 1) << 8 | last k << 10
+__global__ __launch_bounds__(256) void k_xenc_plan(const unsigned long long *__restrict__ enc, uint32_t n, GrXencHdr *__restrict__ hdr,
+                                                   GrXencRun *__restrict__ runs, uint16_t *__restrict__ meta) {
+    const uint32_t frame = blockIdx.x, t = threadIdx.x;
     const unsigned long long *E = enc + (size_t)frame * n;
     GrXencRun *R = runs + (size_t)frame * n;
     uint16_t *M = meta + (size_t)frame * n;
     GrXencHdr &H = hdr[frame];
     const GrXencConst C = gr_xenc_const(H);
-    if (!C.ok) { if (lane == 0) { H.smallidx0 = C.smallidx0; H.n_runs = 0; H.n_bits = 0; } return; }
-    constexpr uint32_t W = 2048;
-    __shared__ unsigned long long win[W];
-    uint32_t w0 = 0;
-    auto fill = [&](uint32_t base) {
-        w0 = base;
-        for (uint32_t k = lane; k < W; k += 64u) { const uint32_t j = base + k; win[k] = j < n ? E[j] : 0ull; }
-        __syncthreads();
-    };
-    fill(0);
-    int smallidx = C.smallidx0;
-    int prevrun = -1;
-    uint32_t i = 0, r = 0, bitpos = 0;
-    bool last_k1 = false;
-    while (i < n) {
-        if (i >= w0 + W) { __syncthreads(); fill(i); }
-        const unsigned long long word = win[i - w0];
-        const uint32_t f = (uint32_t)(word >> (5 * (smallidx - C.minidx))) & 31u;
-        const uint32_t k = f & 15u;
-        const bool near = ((word >> (last_k1 ? 46 : 45)) & 1ull) != 0ull;
-        int is_smaller = 0;
-        if (smallidx < C.maxidx && near) is_smaller = 1;
-        else if (smallidx > C.minidx) is_smaller = -1;
-        if (is_smaller == -1 && (k == 0u || (f & 16u))) is_smaller = 0;
-        const int run = 3 * (int)k;
-        const bool flag = run != prevrun || is_smaller != 0;
-        if (flag) prevrun = run;
-        if (lane == 0) {
-            R[r].atom0 = i; R[r].bitpos = bitpos;
-            M[r] = (uint16_t)(k | ((uint32_t)(is_smaller + 1) << 4) | ((flag ? 1u : 0u) << 6) | ((uint32_t)smallidx << 8));
-        }
-        bitpos += (uint32_t)C.big_bits + (flag ? 6u : 1u) + k * (uint32_t)smallidx;
-        ++r;
-        i += 1u + k;
-        last_k1 = k == 1u;
-        smallidx += is_smaller;
+    if (!C.ok) { if (t == 0) { H.smallidx0 = C.smallidx0; H.n_runs = 0; H.n_bits = 0; } return; }
+    constexpr uint32_t NONE = 0xFFFFFFFFu, T = 256;
+    __shared__ uint32_t anchor[T];
+    __shared__ GrXencSeg tab[T][9];
+    __shared__ uint32_t ent_s[T], ent_k[T], ent_run[T], ent_bit[T];
+    // 1. anchors
+    const uint32_t S = (n + T - 1u) / T;
+    uint32_t a = NONE;
+    if (t == 0) a = 0u;
+    else {
+        const uint32_t j1 = min(n, (t + 1u) * S);
+        for (uint32_t j = t * S; j < j1; ++j) if (((E[j] >> 45) & 3ull) == 0ull) { a = j; break; }
     }
-    if (lane == 0) { H.smallidx0 = C.smallidx0; H.n_runs = r; H.n_bits = bitpos; }
+    anchor[t] = a;
+    __syncthreads();
+    uint32_t e = n;
+    if (a != NONE) for (uint32_t u = t + 1u; u < T; ++u) if (anchor[u] != NONE) { e = anchor[u]; break; }
+    // one walk of [a, e): `s` = entry index - minidx, `pk` = the previous run's length (255: none); EMIT: descriptors out
+    auto walk = [&](uint32_t s, uint32_t pk, bool emit, uint32_t run0, uint32_t bit0, GrXencSeg &out) {
+        int smallidx = C.minidx + (int)s;
+        uint32_t i = a, r = 0, bits = 0, first_k = 0, last_k = 0; int first_step = 0;
+        bool last_k1 = false;
+        while (i < e) {
+            const unsigned long long word = E[i];
+            const uint32_t f = (uint32_t)(word >> (5 * (smallidx - C.minidx))) & 31u, k = f & 15u;
+            const bool near = ((word >> (last_k1 ? 46 : 45)) & 1ull) != 0ull;
+            int step = 0;
+            if (smallidx < C.maxidx && near) step = 1;
+            else if (smallidx > C.minidx) step = -1;
+            if (step == -1 && (k == 0u || (f & 16u))) step = 0;
+            if (r == 0) { first_k = k; first_step = step; }
+            const bool flag = (r == 0 && !emit) ? false : (k != pk || step != 0);      // (the first run's flag of a summary walk is settled by the scan)
+            if (emit) {
+                R[run0 + r].atom0 = i; R[run0 + r].bitpos = bit0 + bits;
+                M[run0 + r] = (uint16_t)(k | ((uint32_t)(step + 1) << 4) | ((flag ? 1u : 0u) << 6) | ((uint32_t)smallidx << 8));
+            }
+            bits += (uint32_t)C.big_bits + k * (uint32_t)smallidx + ((r == 0 && !emit) ? 0u : (flag ? 6u : 1u));
+            ++r;
+            i += 1u + k;
+            last_k1 = k == 1u; last_k = k; pk = k;
+            smallidx += step;
+        }
+        out.runs = r; out.bits = bits;
+        out.packed = (uint16_t)((uint32_t)(smallidx - C.minidx) | (first_k << 4) | ((uint32_t)(first_step + 1) << 8) | (last_k << 10));
+    };
+    // 2. summaries for every entry index (thread 0 knows its own)
+    const uint32_t s0 = (uint32_t)(C.smallidx0 - C.minidx);
+    if (a != NONE) {
+        if (t == 0) walk(s0, 255u, false, 0u, 0u, tab[0][s0]);
+        else for (uint32_t s = 0; s < 9u; ++s) walk(s, 255u, false, 0u, 0u, tab[t][s]);
+    }
+    __syncthreads();
+    // 3. the true entry states
+    if (t == 0) {
+        uint32_t s = s0, pk = 255u, run_base = 0u, bit_base = 0u;
+        for (uint32_t u = 0; u < T; ++u) {
+            if (anchor[u] == NONE) continue;
+            ent_s[u] = s; ent_k[u] = pk; ent_run[u] = run_base; ent_bit[u] = bit_base;
+            const GrXencSeg sm = tab[u][s];
+            const uint32_t fk = (sm.packed >> 4) & 15u, lk = (sm.packed >> 10) & 15u; const int fs = (int)((sm.packed >> 8) & 3u) - 1;
+            bit_base += sm.bits + ((fk != pk || fs != 0) ? 6u : 1u);
+            run_base += sm.runs;
+            pk = lk; s = sm.packed & 15u;
+        }
+        H.smallidx0 = C.smallidx0; H.n_runs = run_base; H.n_bits = bit_base;
+    }
+    __syncthreads();
+    // 4. descriptors
+    if (a != NONE) { GrXencSeg unused; walk(ent_s[t], ent_k[t], true, ent_run[t], ent_bit[t], unused); }
 }
 
 // MSB-first bit stream as big-endian 32-bit words, OR-ed into zeroed memory

@@ -293,10 +293,10 @@ enum { GR_TUNE_SUB_BATCH = 1, GR_TUNE_CHUNKS = 2, GR_TUNE_FIT_WGS = 3, GR_TUNE_F
        GR_TUNE_MASKED_SELECTIONS = 15 /* 1 (default): a scattered selection that covers at least an eighth of the atoms between its first and its last one (>= 4096
                                          atoms) also gets a bit mask, and RMSD / RMSD-fit / get_com read its span coalesced instead of gathering it atom by atom;
                                          0: groups created afterwards keep to their index lists.  Same results to rounding. */,
-       GR_TUNE_XTC_DEVICE_ENCODE = 16 /* 1: gr_xtc_write_slots compresses outputs of >= 200 000 atoms (frames x atoms) on the device -- the same bytes as the host
-                                         encoder, only the compressed stream crosses PCIe and no host thread encodes; 0 (default): host threads encode.  The device path
-                                         is for hosts short of cores: a frame's run structure is walked by ONE wave (~100 ms per 5e5-atom frame whatever the batch), so
-                                         at 256 frames per call it writes 1.0-1.9 k frames/s where 16 host encoders write 1.6-2.8 k (tools/xtc_write_bench.py) */,
+       GR_TUNE_XTC_DEVICE_ENCODE = 16 /* 1 (default): gr_xtc_write_slots compresses outputs of >= 200 000 atoms (frames x atoms) on the device -- the same bytes as the
+                                         host encoder, only the compressed stream crosses PCIe and no host thread encodes (GR_STAT_XTC_DEVICE_FRAMES counts the
+                                         frames); 0: host threads encode (host_threads of the call).  Both sit at the rate the file takes on the test box:
+                                         1.6 / 2.0 k frames/s of 5e5 atoms against 1.4-1.6 / 2.1-2.8 k for 16 host encoders (tools/xtc_write_bench.py) */,
        GR_TUNE_RMSD_FAST_SIGMAS = 14 /* multiples (default 6) of the pass's own rounding estimate a frame's rmsd must stand clear of to be kept; 0 keeps every frame: calibration runs only (tools/rmsd_calibrate.py) */,
        GR_TUNE_TEST_RESIDENT_NO_START = 100 /* tests: the next resident launch behaves as if its workgroups never got onto the chip */,
        GR_TUNE_TEST_RESIDENT_ABORT_AT = 101 /* tests: the next resident launch is aborted from inside when it reaches this frame of its segment (< 0: never) */ };
