@@ -2640,8 +2640,10 @@ static int xe_reserve(gr_ctx *c, int k, size_t bytes) {
     c->xe_cap[k] = bytes;
     return GR_OK;
 }
+// *declined: the scratch buffers could not be had (nothing has been written): the caller takes the host encoders
 static int xtc_write_slots_device(gr_xtc_writer *w, gr_ctx *c, uint32_t first_slot, uint32_t n_frames, const Group *g,
-                                  const int64_t *steps, const float *times, float precision) {
+                                  const int64_t *steps, const float *times, float precision, bool *declined) {
+    *declined = false;
     if (!(precision > 0.0f)) precision = 1000.0f;
     const uint32_t n = (uint32_t)(g ? g->n : c->n);
     GrSel sel;
@@ -2651,7 +2653,9 @@ static int xtc_write_slots_device(gr_xtc_writer *w, gr_ctx *c, uint32_t first_sl
     const uint32_t round = (uint32_t)std::max<size_t>(1, std::min<size_t>(n_frames, ((size_t)4 << 30) / per_frame));
     int st;
     if ((st = xe_reserve(c, 0, (size_t)round * n * 12u)) || (st = xe_reserve(c, 1, (size_t)round * n * 8u)) || (st = xe_reserve(c, 2, (size_t)round * n * 8u)) ||
-        (st = xe_reserve(c, 3, (size_t)round * n * 2u + 16u)) || (st = xe_reserve(c, 4, (size_t)round * (sizeof(GrXencHdr) + 8u)))) return st;
+        (st = xe_reserve(c, 3, (size_t)round * n * 2u + 16u)) || (st = xe_reserve(c, 4, (size_t)round * (sizeof(GrXencHdr) + 8u)))) {
+        (void)hipGetLastError(); *declined = true; return GR_OK;
+    }
     int *ints = (int *)c->xe_dev[0]; unsigned long long *enc = (unsigned long long *)c->xe_dev[1]; GrXencRun *runs = (GrXencRun *)c->xe_dev[2]; uint16_t *meta = (uint16_t *)c->xe_dev[3];
     GrXencHdr *hdr_dev = (GrXencHdr *)c->xe_dev[4]; unsigned long long *off_dev = (unsigned long long *)((unsigned char *)c->xe_dev[4] + (size_t)round * sizeof(GrXencHdr));
     const size_t head_bytes = (size_t)round * (sizeof(GrXencHdr) + 8u);
@@ -2744,8 +2748,11 @@ int gr_xtc_write_slots(gr_xtc_writer *w, gr_ctx *c, uint32_t first_slot, uint32_
     }
     const uint64_t n_out = g ? g->n : c->n;
     // large outputs are compressed on the device (gr_xtc_enc_dev.h): what crosses PCIe is the stream, and no host thread encodes
-    if (c->xtc_dev_encode && n_out > 9 && n_out <= (1ull << 24) && n_out * n_frames >= 200000ull)
-        return xtc_write_slots_device(w, c, first_slot, n_frames, g, steps, times, precision);
+    if (c->xtc_dev_encode && n_out > 9 && n_out <= (1ull << 24) && n_out * n_frames >= 200000ull) {
+        bool declined = false;
+        st = xtc_write_slots_device(w, c, first_slot, n_frames, g, steps, times, precision, &declined);
+        if (!declined) return st;
+    }
     const size_t fb = (size_t)c->n * 3 * sizeof(float);
     // D2H of the whole batch on the compute stream into one pinned buffer (frames are ordered behind the kernels that wrote them);
     // per-frame events let the encoders start as soon as their frame has landed
