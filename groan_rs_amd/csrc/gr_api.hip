@@ -142,7 +142,7 @@ struct gr_ctx {
     float *wr_host = nullptr; size_t wr_cap = 0;   // pinned landing buffer of gr_xtc_write_slots (grow-only)
     // device xtc encoder (gr_xtc_enc_dev.h), grow-only: quantised atoms, run words, run descriptors, streams
     void *xe_dev[6] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr }; size_t xe_cap[6] = { 0, 0, 0, 0, 0, 0 };   // ints, enc, runs, meta, hdr + offsets, out
-    unsigned char *xe_host = nullptr; size_t xe_host_cap = 0;     // pinned: headers + offsets + streams
+    unsigned char *xe_host[2] = { nullptr, nullptr }; size_t xe_host_cap[2] = { 0, 0 };     // pinned, two banks (rounds in turn): headers + offsets + streams
     int xtc_dev_encode = 1;           // GR_TUNE_XTC_DEVICE_ENCODE
     uint64_t xtc_dev_frames = 0;      // frames gr_xtc_write_slots compressed on the device (GR_STAT_XTC_DEVICE_FRAMES)
     int strict = 0;
@@ -758,7 +758,7 @@ void gr_ctx_destroy(gr_ctx *c) try {
     if (c->bad_host) (void)hipHostFree(c->bad_host);
     if (c->pd_out) (void)hipFree(c->pd_out);
     for (int k = 0; k < 6; ++k) if (c->xe_dev[k]) (void)hipFree(c->xe_dev[k]);
-    if (c->xe_host) (void)hipHostFree(c->xe_host);
+    for (int k = 0; k < 2; ++k) if (c->xe_host[k]) (void)hipHostFree(c->xe_host[k]);
     if (c->unpack_stream) { (void)hipStreamSynchronize(c->unpack_stream); (void)hipStreamDestroy(c->unpack_stream); }
     for (int k = 0; k < 2; ++k) {
         if (c->xtc_host[k]) (void)hipHostFree(c->xtc_host[k]);
@@ -2649,8 +2649,12 @@ static int xtc_write_slots_device(gr_xtc_writer *w, gr_ctx *c, uint32_t first_sl
     GrSel sel;
     if (g) sel = make_sel(*g);
     else { Group all; all.n = c->n; all.contiguous = true; all.start = 0; sel = make_sel(all); }
+    // Rounds of frames: while the calling thread drives the kernels and copies of round r + 1, a writer thread puts round r into the
+    // file (the file write is the slowest stage: 4-5 GB/s from one thread).  A round is ~64 MB of output (so the overlap has something
+    // to overlap with) and at most ~2 GB of scratch (30 bytes per atom and frame); two pinned banks take the rounds in turn.
     const size_t per_frame = (size_t)n * 30u;
-    const uint32_t round = (uint32_t)std::max<size_t>(1, std::min<size_t>(n_frames, ((size_t)4 << 30) / per_frame));
+    uint32_t round = (uint32_t)std::max<size_t>(1, std::min<size_t>(n_frames, ((size_t)2 << 30) / per_frame));
+    round = std::min<uint32_t>(round, (uint32_t)std::max<size_t>(8, ((size_t)64 << 20) / ((size_t)n * 4u)));
     int st;
     if ((st = xe_reserve(c, 0, (size_t)round * n * 12u)) || (st = xe_reserve(c, 1, (size_t)round * n * 8u)) || (st = xe_reserve(c, 2, (size_t)round * n * 8u)) ||
         (st = xe_reserve(c, 3, (size_t)round * n * 2u + 16u)) || (st = xe_reserve(c, 4, (size_t)round * (sizeof(GrXencHdr) + 8u)))) {
@@ -2659,18 +2663,25 @@ static int xtc_write_slots_device(gr_xtc_writer *w, gr_ctx *c, uint32_t first_sl
     int *ints = (int *)c->xe_dev[0]; unsigned long long *enc = (unsigned long long *)c->xe_dev[1]; GrXencRun *runs = (GrXencRun *)c->xe_dev[2]; uint16_t *meta = (uint16_t *)c->xe_dev[3];
     GrXencHdr *hdr_dev = (GrXencHdr *)c->xe_dev[4]; unsigned long long *off_dev = (unsigned long long *)((unsigned char *)c->xe_dev[4] + (size_t)round * sizeof(GrXencHdr));
     const size_t head_bytes = (size_t)round * (sizeof(GrXencHdr) + 8u);
-    std::vector<unsigned char> frame_out;
-    for (uint32_t r0 = 0; r0 < n_frames; r0 += round) {
-        const uint32_t nf = std::min<uint32_t>(round, n_frames - r0), s0 = first_slot + r0;
+    std::thread writer;                 // the round before this one, on its way into the file
+    std::atomic<int> io_err(0);
+    struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{ writer };     // (every return path waits for it)
+    uint32_t ri = 0;
+    for (uint32_t r0 = 0; r0 < n_frames; r0 += round, ++ri) {
+        const uint32_t nf = std::min<uint32_t>(round, n_frames - r0), s0 = first_slot + r0, bank = ri & 1u;
         SlotUse use(c, s0, nf);
-        // pinned: headers + offsets now, the streams behind them once their size is known
-        if (head_bytes > c->xe_host_cap) {
-            if (c->xe_host) (void)hipHostFree(c->xe_host);
-            c->xe_host = nullptr; c->xe_host_cap = 0;
-            HIPCHK(c, hipHostMalloc(&c->xe_host, head_bytes + ((size_t)nf * n * 4u), hipHostMallocDefault));   // (~4 B per atom: the usual stream; grown below when a batch needs more)
-            c->xe_host_cap = head_bytes + (size_t)nf * n * 4u;
-        }
-        GrXencHdr *hdr = (GrXencHdr *)c->xe_host; unsigned long long *off = (unsigned long long *)(c->xe_host + (size_t)round * sizeof(GrXencHdr));
+        // (bank `bank` was last used by round ri - 2, whose writer was joined before round ri - 1's was started)
+        auto bank_reserve = [&](size_t bytes, bool keep_head) -> int {
+            if (bytes <= c->xe_host_cap[bank]) return GR_OK;
+            unsigned char *bigger = nullptr;
+            HIPCHK(c, hipHostMalloc(&bigger, bytes, hipHostMallocDefault));
+            if (keep_head && c->xe_host[bank]) memcpy(bigger, c->xe_host[bank], head_bytes);
+            if (c->xe_host[bank]) (void)hipHostFree(c->xe_host[bank]);
+            c->xe_host[bank] = bigger; c->xe_host_cap[bank] = bytes;
+            return GR_OK;
+        };
+        if ((st = bank_reserve(head_bytes + (size_t)nf * n * 4u, false))) return st;      // (~4 B per atom: the usual stream; grown below when a round needs more)
+        GrXencHdr *hdr = (GrXencHdr *)c->xe_host[bank]; unsigned long long *off = (unsigned long long *)(c->xe_host[bank] + (size_t)round * sizeof(GrXencHdr));
         for (uint32_t f = 0; f < nf; ++f) { GrXencHdr h = {}; for (int a = 0; a < 3; ++a) { h.mn[a] = INT_MAX; h.mx[a] = INT_MIN; } h.mindiff = (uint32_t)INT_MAX; hdr[f] = h; }
         HIPCHK(c, hipMemcpyAsync(hdr_dev, hdr, (size_t)nf * sizeof(GrXencHdr), hipMemcpyHostToDevice, c->stream));
         k_xenc_quant<<<dim3(std::min<uint32_t>((n + 255u) / 256u, 2048u), nf), dim3(256), 0, c->stream>>>(c->frames, c->frame_stride, s0, sel, n, precision, ints, hdr_dev);
@@ -2693,26 +2704,22 @@ static int xtc_write_slots_device(gr_xtc_writer *w, gr_ctx *c, uint32_t first_sl
         if (n_good) {
             if ((st = xe_reserve(c, 5, (size_t)total))) return st;
             unsigned char *out_dev = (unsigned char *)c->xe_dev[5];
-            if (head_bytes + total > c->xe_host_cap) {           // the streams do not fit behind the headers: a larger pinned buffer, headers kept
-                unsigned char *bigger = nullptr;
-                HIPCHK(c, hipHostMalloc(&bigger, head_bytes + (size_t)total, hipHostMallocDefault));
-                memcpy(bigger, c->xe_host, head_bytes);
-                (void)hipHostFree(c->xe_host);
-                c->xe_host = bigger; c->xe_host_cap = head_bytes + (size_t)total;
-                hdr = (GrXencHdr *)c->xe_host; off = (unsigned long long *)(c->xe_host + (size_t)round * sizeof(GrXencHdr));
-            }
+            if ((st = bank_reserve(head_bytes + (size_t)total, true))) return st;
+            hdr = (GrXencHdr *)c->xe_host[bank]; off = (unsigned long long *)(c->xe_host[bank] + (size_t)round * sizeof(GrXencHdr));
             HIPCHK(c, hipMemsetAsync(out_dev, 0, (size_t)total, c->stream));
             HIPCHK(c, hipMemcpyAsync(off_dev, off, (size_t)n_good * 8u, hipMemcpyHostToDevice, c->stream));
             k_xenc_emit<<<dim3(std::max<uint32_t>(1u, std::min<uint32_t>((max_runs + 255u) / 256u, 4096u)), n_good), dim3(256), 0, c->stream>>>(ints, n, hdr_dev, runs, meta, off_dev, out_dev);
             HIPCHK(c, hipGetLastError());
-            unsigned char *streams = c->xe_host + head_bytes;
+            unsigned char *streams = c->xe_host[bank] + head_bytes;
             HIPCHK(c, hipMemcpyAsync(streams, out_dev, (size_t)total, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));
+            // the frames' 92-byte headers, then the round goes to the writer (behind the round before it: the file is written in order)
+            std::vector<unsigned char> heads((size_t)n_good * 92u);
+            std::vector<unsigned char> o;
             for (uint32_t f = 0; f < n_good; ++f) {
                 const GrXencHdr &h = hdr[f];
                 const uint32_t nbytes = (h.n_bits + 7u) / 8u, k = r0 + f;
                 float m[9]; box9_rows(c->box9_set[s0 + f] ? &c->box9_host[9 * (size_t)(s0 + f)] : nullptr, m);
-                std::vector<unsigned char> &o = frame_out;
                 o.clear();
                 grx::put_be32(o, 1995u); grx::put_be32(o, n); grx::put_be32(o, (uint32_t)(int32_t)(steps ? steps[k] : 0)); grx::put_bef(o, times ? times[k] : 0.0f);
                 for (int q = 0; q < 9; ++q) grx::put_bef(o, m[q]);
@@ -2722,15 +2729,30 @@ static int xtc_write_slots_device(gr_xtc_writer *w, gr_ctx *c, uint32_t first_sl
                 for (int a = 0; a < 3; ++a) grx::put_be32(o, (uint32_t)h.mx[a]);
                 grx::put_be32(o, (uint32_t)h.smallidx0);
                 grx::put_be32(o, nbytes);
-                if (fwrite(o.data(), 1, o.size(), w->fp) != o.size()) return fail(c, GR_E_IO, "short write");
-                const size_t padded = ((size_t)nbytes + 3u) & ~(size_t)3u;          // (the stream's tail is zero: the pad bytes are already there)
-                if (fwrite(streams + off[f], 1, padded, w->fp) != padded) return fail(c, GR_E_IO, "short write");
+                memcpy(&heads[(size_t)f * 92u], o.data(), 92u);
             }
+            if (writer.joinable()) writer.join();
+            if (io_err.load()) return fail(c, GR_E_IO, "short write");
+            FILE *fp = w->fp;
+            auto put = [fp, streams, off, hdr, n_good, &io_err](std::vector<unsigned char> hd) {
+                for (uint32_t f = 0; f < n_good; ++f) {
+                    const size_t padded = (((size_t)hdr[f].n_bits + 7u) / 8u + 3u) & ~(size_t)3u;      // (the stream's tail is zero: the pad bytes are already there)
+                    if (fwrite(&hd[(size_t)f * 92u], 1, 92u, fp) != 92u || fwrite(streams + off[f], 1, padded, fp) != padded) { io_err.store(1); return; }
+                }
+            };
+            bool threaded = r0 + nf < n_frames && n_good == nf;       // (the last round -- or the one that ends the output -- is written here)
+            if (threaded) { try { writer = std::thread(put, std::move(heads)); } catch (const std::system_error &) { threaded = false; } }
+            if (!threaded) { put(std::move(heads)); if (io_err.load()) return fail(c, GR_E_IO, "short write"); }
             c->xtc_dev_frames += n_good;
         }
-        if (n_good < nf)
+        if (n_good < nf) {
+            if (writer.joinable()) writer.join();
+            if (io_err.load()) return fail(c, GR_E_IO, "short write");
             return fail(c, GR_E_OUT_OF_RANGE, "coordinates do not fit the xtc integers at this precision; the frames before this slot were written", s0 + n_good);
+        }
     }
+    if (writer.joinable()) writer.join();
+    if (io_err.load()) return fail(c, GR_E_IO, "short write");
     return GR_OK;
 }
 

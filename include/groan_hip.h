@@ -295,8 +295,8 @@ enum { GR_TUNE_SUB_BATCH = 1, GR_TUNE_CHUNKS = 2, GR_TUNE_FIT_WGS = 3, GR_TUNE_F
                                          0: groups created afterwards keep to their index lists.  Same results to rounding. */,
        GR_TUNE_XTC_DEVICE_ENCODE = 16 /* 1 (default): gr_xtc_write_slots compresses outputs of >= 200 000 atoms (frames x atoms) on the device -- the same bytes as the
                                          host encoder, only the compressed stream crosses PCIe and no host thread encodes (GR_STAT_XTC_DEVICE_FRAMES counts the
-                                         frames); 0: host threads encode (host_threads of the call).  Both sit at the rate the file takes on the test box:
-                                         1.6 / 2.0 k frames/s of 5e5 atoms against 1.4-1.6 / 2.1-2.8 k for 16 host encoders (tools/xtc_write_bench.py) */,
+                                         frames); 0: host threads encode (host_threads of the call).  2.0 / 2.5 k frames/s of 5e5 atoms (water-like / one dense chain)
+                                         against 1.4-1.6 / 2.1-2.8 k for 16 host encoders: the rate the file takes on the test box (tools/xtc_write_bench.py) */,
        GR_TUNE_RMSD_FAST_SIGMAS = 14 /* multiples (default 6) of the pass's own rounding estimate a frame's rmsd must stand clear of to be kept; 0 keeps every frame: calibration runs only (tools/rmsd_calibrate.py) */,
        GR_TUNE_TEST_RESIDENT_NO_START = 100 /* tests: the next resident launch behaves as if its workgroups never got onto the chip */,
        GR_TUNE_TEST_RESIDENT_ABORT_AT = 101 /* tests: the next resident launch is aborted from inside when it reaches this frame of its segment (< 0: never) */ };
