@@ -217,7 +217,8 @@ __global__ __launch_bounds__(256) void k_xenc_enc(const int *__restrict__ ints, 
 // happened before.  What is not known there is the index (nine values) and the length of the run before (for the flag bit:
 // flag_r = run_r != run_(r-1) || index moves -- the format's `prevrun` always equals the previous run's length).  So:
 //   1. thread t looks for the first such atom in its 1/256th of the frame (its anchor; thread 0: atom 0)
-//   2. it walks from its anchor to the next thread's anchor once for EACH of the nine possible entry indices, keeping per entry index:
+//   2. the segment from an anchor to the next one is walked once for EACH of the nine possible entry indices (by the anchor's thread
+//      and the anchorless threads behind it, sharing the nine out), keeping per entry index:
 //      runs, bits (without the first run's flag field), the index at the exit, the first run's length and index step, the last run's length
 //   3. thread 0 threads the true entry states through the 256 x 9 table (a sequential scan of 256 look-ups)
 //   4. every thread walks its segment once more with its true entry state and writes the run descriptors
@@ -247,12 +248,20 @@ __global__ __launch_bounds__(256) void k_xenc_plan(const unsigned long long *__r
     }
     anchor[t] = a;
     __syncthreads();
-    uint32_t e = n;
-    if (a != NONE) for (uint32_t u = t + 1u; u < T; ++u) if (anchor[u] != NONE) { e = anchor[u]; break; }
-    // one walk of [a, e): `s` = entry index - minidx, `pk` = the previous run's length (255: none); EMIT: descriptors out
+    // a thread without an anchor of its own helps the last thread before it that has one (its OWNER): the nine summary walks of a
+    // long segment -- a protein is one run after another with no place where a run must start -- are shared out over the owner and the
+    // threads behind it instead of all falling to one
+    uint32_t owner = t;
+    while (anchor[owner] == NONE) --owner;                            // (thread 0 always has one)
+    uint32_t nxt = owner + 1u;
+    while (nxt < T && anchor[nxt] == NONE) ++nxt;
+    const uint32_t group = nxt - owner, rank = t - owner;
+    const uint32_t seg_a = anchor[owner], seg_e = nxt < T ? anchor[nxt] : n;
+    // one walk of [seg_a, seg_e): `s` = entry index - minidx, `pk` = the previous run's length (255: none); EMIT: descriptors out
     auto walk = [&](uint32_t s, uint32_t pk, bool emit, uint32_t run0, uint32_t bit0, GrXencSeg &out) {
+        const uint32_t e = seg_e;
         int smallidx = C.minidx + (int)s;
-        uint32_t i = a, r = 0, bits = 0, first_k = 0, last_k = 0; int first_step = 0;
+        uint32_t i = seg_a, r = 0, bits = 0, first_k = 0, last_k = 0; int first_step = 0;
         bool last_k1 = false;
         while (i < e) {
             const unsigned long long word = E[i];
@@ -279,10 +288,8 @@ __global__ __launch_bounds__(256) void k_xenc_plan(const unsigned long long *__r
     };
     // 2. summaries for every entry index (thread 0 knows its own)
     const uint32_t s0 = (uint32_t)(C.smallidx0 - C.minidx);
-    if (a != NONE) {
-        if (t == 0) walk(s0, 255u, false, 0u, 0u, tab[0][s0]);
-        else for (uint32_t s = 0; s < 9u; ++s) walk(s, 255u, false, 0u, 0u, tab[t][s]);
-    }
+    if (owner == 0u) { if (t == 0u) walk(s0, 255u, false, 0u, 0u, tab[0][s0]); }
+    else for (uint32_t s = rank; s < 9u; s += group) walk(s, 255u, false, 0u, 0u, tab[owner][s]);
     __syncthreads();
     // 3. the true entry states
     if (t == 0) {
@@ -300,7 +307,7 @@ __global__ __launch_bounds__(256) void k_xenc_plan(const unsigned long long *__r
     }
     __syncthreads();
     // 4. descriptors
-    if (a != NONE) { GrXencSeg unused; walk(ent_s[t], ent_k[t], true, ent_run[t], ent_bit[t], unused); }
+    if (rank == 0u) { GrXencSeg unused; walk(ent_s[t], ent_k[t], true, ent_run[t], ent_bit[t], unused); }
 }
 
 // MSB-first bit stream as big-endian 32-bit words, OR-ed into zeroed memory

@@ -44,6 +44,8 @@ CASES = {
     "ten atoms": (10, 4, 1000.0, lambda r, n, f: _water(r, n, 3.0)),
     "257 atoms (one past a window)": (257, 3, 1000.0, lambda r, n, f: _water(r, n, 4.0)),
     "identical atoms": (1_000, 2, 1000.0, lambda r, n, f: np.full((n, 3), 1.234, np.float32)),
+    "a protein in water (one long chain of near atoms: no place where a run must start)": (60_000, 2, 1000.0, lambda r, n, f: np.concatenate(
+        [_water(r, 20_001, 8.0), (4.0 + np.cumsum(r.normal(0, 0.07, (19_998, 3)), axis=0)).astype(np.float32), _water(r, 20_001, 8.0)])),
     "mixed: water, gas, water": (40_000, 2, 500.0, lambda r, n, f: np.concatenate([_water(r, 15_000, 8.0), r.uniform(0, 8.0, (10_000, 3)).astype(np.float32), _water(r, 15_000, 8.0)])),
 }
 
