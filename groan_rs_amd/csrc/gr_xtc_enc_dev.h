@@ -288,11 +288,14 @@ __global__ __launch_bounds__(256) void k_xenc_plan(const unsigned long long *__r
     };
     // 2. summaries for every entry index (thread 0 knows its own)
     const uint32_t s0 = (uint32_t)(C.smallidx0 - C.minidx);
-    if (owner == 0u) { if (t == 0u) walk(s0, 255u, false, 0u, 0u, tab[0][s0]); }
+    // (a frame with no anchor but atom 0 -- one dense chain -- has nothing to summarise: thread 0 writes the descriptors in one walk)
+    const bool solo = owner == 0u && nxt == T;
+    if (owner == 0u) { if (t == 0u && !solo) walk(s0, 255u, false, 0u, 0u, tab[0][s0]); }
     else for (uint32_t s = rank; s < 9u; s += group) walk(s, 255u, false, 0u, 0u, tab[owner][s]);
     __syncthreads();
     // 3. the true entry states
-    if (t == 0) {
+    if (t == 0 && solo) { ent_s[0] = s0; ent_k[0] = 255u; ent_run[0] = 0u; ent_bit[0] = 0u; }
+    if (t == 0 && !solo) {
         uint32_t s = s0, pk = 255u, run_base = 0u, bit_base = 0u;
         for (uint32_t u = 0; u < T; ++u) {
             if (anchor[u] == NONE) continue;
@@ -307,7 +310,11 @@ __global__ __launch_bounds__(256) void k_xenc_plan(const unsigned long long *__r
     }
     __syncthreads();
     // 4. descriptors
-    if (rank == 0u) { GrXencSeg unused; walk(ent_s[t], ent_k[t], true, ent_run[t], ent_bit[t], unused); }
+    if (rank == 0u) {
+        GrXencSeg done;
+        walk(ent_s[t], ent_k[t], true, ent_run[t], ent_bit[t], done);
+        if (solo) { H.smallidx0 = C.smallidx0; H.n_runs = done.runs; H.n_bits = done.bits; }      // (t == 0: every other thread has owner 0 and a rank > 0)
+    }
 }
 
 // MSB-first bit stream as big-endian 32-bit words, OR-ed into zeroed memory
