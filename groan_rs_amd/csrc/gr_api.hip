@@ -164,6 +164,9 @@ struct Pending {   // a segment between gr_rmsd_batch_begin and gr_rmsd_batch_en
     GrSel sel = {};        // the group as it was at begin (the context refuses group / mass changes while a batch is in flight)
     uint64_t group_n = 0;
     bool has_group = false;
+#ifdef GR_EXP_TIMELINE
+    unsigned long long *tl_dev = nullptr;
+#endif
 };
 
 struct gr_rmsd_plan {
@@ -1784,6 +1787,16 @@ static int segment_begin(gr_rmsd_plan *p, uint32_t s0, uint32_t nb, int fit) {
             ctl.team_waves = resident_team_waves(res_wgs, res_streams);
             ctl.patience_ticks = (unsigned long long)c->wall_khz * 3000ull; ctl.start_ticks = (unsigned long long)c->wall_khz * 200ull;   // 3 s, 0.2 s
             ctl.test_abort_frame = c->res_test_abort_at; c->res_test_abort_at = 0xFFFFFFFFu;
+#ifdef GR_EXP_TIMELINE
+            // experiment (tools/timeline_bench.sh): device-clock stamps of every frame's way through the launch
+            {
+                static unsigned long long *tl_dev = nullptr; static size_t tl_cap = 0;
+                if (nb > tl_cap) { if (tl_dev) (void)hipFree(tl_dev); tl_dev = nullptr; tl_cap = 0; if (hipMalloc(&tl_dev, (size_t)nb * 8 * sizeof(unsigned long long)) == hipSuccess) tl_cap = nb; }
+                ctl.tl = getenv("GR_TIMELINE") ? tl_dev : nullptr;
+                if (ctl.tl) HIPCHK(c, hipMemsetAsync(ctl.tl, 0, (size_t)nb * 8 * sizeof(unsigned long long), S));
+                q.tl_dev = ctl.tl;
+            }
+#endif
             float *frames = c->frames; size_t stride = c->frame_stride; uint32_t slot0 = s0, nfr = nb, natoms = (uint32_t)c->n;
             const float *masses = c->masses; GrSel sel_arg = sel; const GrBox *boxes = c->boxes_dev; GrPlanDev plan = res_msk ? plan_span : p->dev;
             GrFrameState *states = c->state_dev; double *fparts = c->fit_partials;
@@ -1881,6 +1894,31 @@ static int segment_end(gr_rmsd_plan *p, float *rmsd_out, int *status_out, float 
         HIPCHK(c, hipStreamSynchronize(c->stream));
         std::vector<uint8_t> redo;      // frames of an aborted resident launch that nobody touched: redone on the two-pass path below
         std::vector<uint8_t> torn;      // ... and frames that SOME waves fitted and others did not
+#ifdef GR_EXP_TIMELINE
+        if (q.resident && q.tl_dev) {
+            // per frame (ticks of the 100 MHz device clock): 0 workgroup 0 published its record, 1 the finalizer had all records, 2 before /
+            // 3 after the load of the frame's state, 4 closing arithmetic done, 5 record published and state stored, 6 workgroup 0 wave 0
+            // looked at the record (| polls << 48), 7 the finalizer's polls
+            std::vector<unsigned long long> tl((size_t)nb * 8);
+            if (hipMemcpy(tl.data(), q.tl_dev, tl.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess) {
+                double sum[8] = { 0 }; double period = 0; uint64_t n = 0, polled = 0, fpolls = 0; unsigned long long prev = 0;
+                for (uint32_t f = 0; f < nb; ++f) {
+                    const unsigned long long *t = &tl[(size_t)f * 8];
+                    if (!t[0] || !t[1] || !t[5] || !(t[6] & 0xFFFFFFFFFFFFull)) continue;
+                    const unsigned long long look = t[6] & 0xFFFFFFFFFFFFull;
+                    sum[0] += (double)((long long)(t[1] - t[0])); sum[1] += (double)((long long)(t[2] - t[1])); sum[2] += (double)((long long)(t[3] - t[2]));
+                    sum[3] += (double)((long long)(t[4] - t[3])); sum[4] += (double)((long long)(t[5] - t[4])); sum[5] += (double)((long long)(look - t[5]));
+                    sum[6] += (double)((long long)(look - t[0]));
+                    if (prev) period += (double)((long long)(t[0] - prev));
+                    prev = t[0];
+                    polled += (t[6] >> 48) != 0; fpolls += t[7]; n++;
+                }
+                if (n > 1) fprintf(stderr, "timeline (%llu frames, us): pub->all records %.2f | ->team totals %.2f | state load %.2f | closing %.2f | publish+store %.2f | ->wg0 looks %.2f | pub->look %.2f | period %.3f | wg0 polled for %.0f %% of the frames | finalizer polls per frame %.1f\n",
+                                   (unsigned long long)n, sum[0] / n / 100.0, sum[1] / n / 100.0, sum[2] / n / 100.0, sum[3] / n / 100.0, sum[4] / n / 100.0, sum[5] / n / 100.0, sum[6] / n / 100.0,
+                                   period / (n - 1) / 100.0, 100.0 * polled / n, (double)fpolls / n);
+            }
+        }
+#endif
         if (q.resident) {
             resident_done(c);
             uint32_t words[3] = { 0, 0, 0 };

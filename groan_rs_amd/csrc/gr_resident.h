@@ -101,7 +101,12 @@ struct GrResShape {
     static constexpr int R = 8;                      // ring of wave-record slots ( > K: no wave is more than K frames ahead of another)
     static constexpr int PARK_F4 = K * 3 * LANES;    // float4: a slot = three rows of group A for every lane (24 KiB) x K = 144 KiB
     static constexpr int WSUM_F = R * WAVES * 32;    // float: a wave record = 19 sums + 12 extents
-    static constexpr int LDS_BYTES = PARK_F4 * 16 + WSUM_F * 4 + R * WAVES * 8 + 2 * R * 4 + 2 * WAVES * 4;   // ... + fit sums, counters, progress and SIMD of every wave
+#ifdef GR_EXP_TIMELINE
+    static constexpr int TL_BYTES = 128 * 4 * 8;     // experiment: stamps of workgroup 0's last 128 turns (published / first look / polls / fit done)
+#else
+    static constexpr int TL_BYTES = 0;
+#endif
+    static constexpr int LDS_BYTES = PARK_F4 * 16 + WSUM_F * 4 + R * WAVES * 8 + 2 * R * 4 + 2 * WAVES * 4 + TL_BYTES;   // ... + fit sums, counters, progress and SIMD of every wave
     static constexpr int REC_PER_WAVE = 256 / WAVES, LANES_PER_REC = 64 / REC_PER_WAVE, WORDS_PER_LANE = 32 / LANES_PER_REC;   // finalizer
 };
 #ifndef GR_RES_SLEEP
@@ -140,6 +145,9 @@ struct GrResCtl {
     uint32_t team_waves;           // waves of a finalizer workgroup that close one frame together: 1, 2, 4 or 8 with 32 x that >= wgs_frame
     unsigned long long patience_ticks, start_ticks;   // bounds of the waits in ticks of wall_clock64() (the host knows the rate)
     uint32_t test_abort_frame;     // tests: the finalizer of this frame raises `abort` instead of closing it (0xFFFFFFFF: never)
+#ifdef GR_EXP_TIMELINE
+    unsigned long long *tl;        // [frames][8] device-clock stamps of a frame's way through the launch (tools/timeline_bench.sh)
+#endif
 };
 
 template <typename T> __device__ __forceinline__ T gr_ld_agent(const T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -353,6 +361,9 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
                 }
                 __builtin_amdgcn_s_sleep(1);
             }
+#ifdef GR_EXP_TIMELINE
+            if (ctl.tl && wt == 0 && lane == 0 && live) { ctl.tl[(size_t)f * 8 + 1] = wall_clock64(); ctl.tl[(size_t)f * 8 + 7] = polls; }
+#endif
             // (a wave that gave up still meets the others at the barriers; the frame is then published as ABORTED, never as closed)
             // sums in fp64, extents as maxima: word index = part * W + k; 0..18 sums, 19..30 maxima
             double v[W];
@@ -384,7 +395,13 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
             }
             gr_wave_sync();
             if (wt == 0 && lane == 0 && live) {
+#ifdef GR_EXP_TIMELINE
+                if (ctl.tl) ctl.tl[(size_t)f * 8 + 2] = wall_clock64();
+#endif
                 GrFrameState st = state[f];                            // (closed in registers, stored once: results are read back below)
+#ifdef GR_EXP_TIMELINE
+                if (ctl.tl) { if (st.status > 1000000) ctl.tl[0] = 0; ctl.tl[(size_t)f * 8 + 3] = wall_clock64(); }
+#endif
                 const bool lost = *gave_up != 0u;                      // ANY wave of the workgroup gave up on a record of this round or an earlier one
                 const double *t = wtot + (WAVES + team) * 32u;
                 if (lost) {
@@ -406,6 +423,9 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
                     gr_finalize_math<0, true, false>(acc, mn, mx3, fmn, fmx, GR_NOIDX, GR_NOIDX, lb, plan, g, sel.n, st);
 #endif
                 }
+#ifdef GR_EXP_TIMELINE
+                if (ctl.tl) { if (st.R[0] > 1.0e30f) ctl.tl[0] = 0; ctl.tl[(size_t)f * 8 + 4] = wall_clock64(); }
+#endif
                 unsigned long long *o = ctl.rec + (size_t)f * 16;
                 // (a frame that was not closed is published as failed: the streaming waves leave it unmodified and move on)
                 gr_st_agent(o + 0, tagv | (uint32_t)st.status);
@@ -422,6 +442,9 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
                     gr_st_agent(o + 13 + a, tagv | __float_as_uint(t0));
                 }
                 state[f] = st;
+#ifdef GR_EXP_TIMELINE
+                if (ctl.tl) ctl.tl[(size_t)f * 8 + 5] = wall_clock64();
+#endif
             }
             __syncthreads();                                          // wtot is free again
         }
@@ -450,6 +473,10 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
     double *fsum = reinterpret_cast<double *>(wsum + S::WSUM_F);
     uint32_t *cnt_s = reinterpret_cast<uint32_t *>(fsum + R * WAVES), *cnt_f = cnt_s + R;
     uint32_t *prog = cnt_f + R, *simd_of = prog + WAVES;             // iterations each wave has begun; the SIMD each wave runs on
+#ifdef GR_EXP_TIMELINE
+    unsigned long long *tls = reinterpret_cast<unsigned long long *>(simd_of + WAVES);   // [256][4]
+    const bool tl_wg = ctl.tl != nullptr && wg_all == 0u;
+#endif
     if (tid < 2 * R) cnt_s[tid] = 0u;
     if (lane == 0) { prog[wave] = 0u; simd_of[wave] = (uint32_t)__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4) /* HW_ID.SIMD_ID */; }
     __syncthreads();                                                  // the only barrier: before the first frame
@@ -657,6 +684,9 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
             }
             gr_st_agent(ctl.wgrec + ((size_t)kf(i) * n_pad + wg) * GR_RES_REC_WORDS + lane, ((unsigned long long)ctl.epoch << 32) | __float_as_uint(v));
         }
+#ifdef GR_EXP_TIMELINE
+        if (tl_wg && lane == 0) tls[(i & 127u) * 4u + 0u] = wall_clock64();
+#endif
         // the slot's counter starts the next use (frame i + R) at zero.  No wave can reach frame i + R before this wave -- the slowest
         // of the workgroup at this point -- has published frame i, the finalizer has closed it and the fit stage of frame i has been
         // passed by everybody (R > K), so the reset cannot meet an arrival
@@ -702,6 +732,10 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
     };
     auto fit = [&](uint32_t j, unsigned long long rv, const Rows &ra, const Rows &rb, const GrBoxU &B) {
         Rec rec;
+#ifdef GR_EXP_TIMELINE
+        uint32_t tl_polls = 0;
+        if (tl_wg && wave == 0 && lane == 0) tls[(j & 127u) * 4u + 1u] = wall_clock64();
+#endif
         if (__builtin_amdgcn_ballot_w64(lane < 16u && (uint32_t)(rv >> 32) != ctl.epoch) == 0ull) {
             rec = take(rv);
             asm volatile("; record had arrived");
@@ -716,7 +750,13 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
             } while (__builtin_amdgcn_ballot_w64(lane < 16u && (uint32_t)(rv >> 32) != ctl.epoch) != 0ull);
             rec = take(rv);
             asm volatile("; record polled for");
+#ifdef GR_EXP_TIMELINE
+            tl_polls = polls;
+#endif
         }
+#ifdef GR_EXP_TIMELINE
+        if (tl_wg && wave == 0 && lane == 0) { tls[(j & 127u) * 4u + 2u] = tl_polls; tls[(j & 127u) * 4u + 3u] = wall_clock64(); }
+#endif
         set_prio();
         const int status = rec.status;
         float rs = 0.0f;
@@ -833,4 +873,15 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
         if (!bail && i + 1 < n_iter) step(i + 1, L1, L0);
     }
     if (lane == 0) ctl.progress[wg_all * WAVES + wave] = n_fitted;
+#ifdef GR_EXP_TIMELINE
+    // workgroup 0's stamps of its last 256 turns: frame f's publication of the workgroup record -> slot 0, first look at the frame's
+    // record -> slot 6 (slot 5 is the finalizer's), polls -> word 0 of the frame's row is left alone (slot 0 = publication)
+    if (tl_wg && wave == 0 && !bail) {
+        for (uint32_t t = (n_turns > 128u ? n_turns - 128u : 0u) + lane; t < n_turns; t += 64u) {
+            const size_t f = kf(t);
+            ctl.tl[f * 8 + 0] = tls[(t & 127u) * 4u + 0u];
+            ctl.tl[f * 8 + 6] = tls[(t & 127u) * 4u + 1u] | (tls[(t & 127u) * 4u + 2u] << 48);
+        }
+    }
+#endif
 }
