@@ -609,6 +609,7 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
             auto max8 = [](gr_v2f p0, gr_v2f p1, gr_v2f p2, gr_v2f p3) { return gr_fmaxf(gr_max3f(gr_max3f(gr_max3f(p0.x, p0.y, p1.x), p1.y, p2.x), p2.y, p3.x), p3.y); };
             // fractional coordinates of v, axis by axis (c, then b, then a: each axis' values are dead once its four results are
             // formed -- the lane is close to its register budget here): moments + extents feed the image proof (gr_finalize_math)
+#ifndef GR_EXP_NOPROOF   /* experiment: what the image proof's share of the instruction stream costs (results are then wrong) */
             {
                 const gr_v2f icz = gr_v2(B.icz), ncy = gr_v2(-B.cy), ncx = gr_v2(-B.cx);
                 const gr_v2f fc0 = a.z01 * icz, fc1 = a.z23 * icz, fc2 = b.z01 * icz, fc3 = b.z23 * icz;
@@ -628,6 +629,7 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
             }
             e32[0] = -min8(a.x01, a.x23, b.x01, b.x23); e32[1] = -min8(a.y01, a.y23, b.y01, b.y23); e32[2] = -min8(a.z01, a.z23, b.z01, b.z23);
             e32[3] = max8(a.x01, a.x23, b.x01, b.x23); e32[4] = max8(a.y01, a.y23, b.y01, b.y23); e32[5] = max8(a.z01, a.z23, b.z01, b.z23);
+#endif
             const gr_v2f m0 = gr_v2p(GA.mm.x, GA.mm.y), m1 = gr_v2p(GA.mm.z, GA.mm.w), m2 = gr_v2p(GB.mm.x, GB.mm.y), m3 = gr_v2p(GB.mm.z, GB.mm.w);
             // value k (1..18) lives at s32[k - 1]; value 0 = sum m does not depend on the frame (m_wave)
             s32[0] = dot8(m0, m1, m2, m3, a.x01, a.x23, b.x01, b.x23); s32[1] = dot8(m0, m1, m2, m3, a.y01, a.y23, b.y01, b.y23); s32[2] = dot8(m0, m1, m2, m3, a.z01, a.z23, b.z01, b.z23);
@@ -645,7 +647,11 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
             // sums (a 32-wide scatter would push 14 zeros through its two widest steps); 12 extents = a 16-wide scatter with max
             const float tot = gr_wave_sum_scatter16(s32, lane);                       // values 1..16
             const float t17 = gr_wave_allsum_f32(s32[16]), t18 = gr_wave_allsum_f32(s32[17]);
+#ifndef GR_EXP_NOPROOF
             const float emax = gr_wave_max_scatter16(e32, lane);
+#else
+            const float emax = e32[0];
+#endif
             if ((lane & 3u) == 0) mine[1 + (lane >> 2)] = tot;                         // sums 1..16
             if (lane == 1u) { mine[0] = m_wave; mine[17] = t17; mine[18] = t18; }      // sum m (the same every frame), sums 17, 18
             if ((lane & 3u) == 0 && lane < 48u) mine[19 + (lane >> 2)] = emax;         // extents 0..11
