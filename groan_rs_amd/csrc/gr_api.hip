@@ -18,6 +18,7 @@
 #include "gr_kernels.h"
 #include "gr_hot.h"
 #include "gr_resident.h"
+#include "gr_small.h"
 #include "gr_xtc.h"
 #include "gr_shape.h"
 #include "gr_xtc_dev.h"
@@ -112,6 +113,13 @@ struct gr_ctx {
     uint64_t res_launches = 0, res_handshake_misses = 0, res_aborts = 0, res_redone_frames = 0;   // gr_ctx_stat
     GrFrameState *state_dev = nullptr;
     GrFrameState *state_host = nullptr;   // pinned
+    // single-wave kernels of per-frame calls on small selections (gr_small.h): the kernel leaves the frame's state and the call's
+    // sequence number in coherent host memory, the host polls the word instead of synchronising the stream
+    GrFrameState *small_state = nullptr, *small_state_dev = nullptr;   // host-mapped record and its device address
+    uint32_t *small_flag = nullptr, *small_flag_dev = nullptr;         // ... and the sequence word
+    uint32_t small_seq = 0;
+    uint32_t small_max = GR_SMALL_MAX_DEFAULT;                         // GR_TUNE_SMALL_CALLS: largest selection (atoms) that takes them, 0 = never
+    uint64_t small_calls = 0, small_sync_fallbacks = 0;                // gr_ctx_stat
     uint32_t *bad_dev = nullptr;          // [4 * GR_MAX_BATCH]: per frame, first atom without position (rows / columns)
     uint32_t *bad_host = nullptr;         // pinned, same size
     float *pd_out = nullptr; size_t pd_cap = 0;
@@ -164,6 +172,7 @@ struct Pending {   // a segment between gr_rmsd_batch_begin and gr_rmsd_batch_en
     GrSel sel = {};        // the group as it was at begin (the context refuses group / mass changes while a batch is in flight)
     uint64_t group_n = 0;
     bool has_group = false;
+    bool small = false; uint32_t small_seq = 0;   // the segment is one single-wave dispatch (gr_small.h): segment_end polls the mapped word
 #ifdef GR_EXP_TIMELINE
     unsigned long long *tl_dev = nullptr;
 #endif
@@ -458,11 +467,13 @@ int slot_check(gr_ctx *c, uint32_t slot, uint32_t n = 1, bool ingest = false) {
 //           (the other half of a double buffer) starts only after the kernels that read it have finished.
 struct SlotUse {
     gr_ctx *c; uint32_t first, n;
+    bool quiet = false;   // the caller has already WAITED for the kernels that read the slots (gr_small.h: the result came back): no event needed
     SlotUse(gr_ctx *ctx, uint32_t first_slot, uint32_t count = 1) : c(ctx), first(first_slot), n(count) {
         for (uint32_t s = first; s < first + n && s < c->n_slots; ++s)
             if (c->upload_pending[s]) { (void)hipStreamWaitEvent(c->stream, c->ev_ready[s], 0); c->upload_pending[s] = 0; }
     }
     ~SlotUse() {
+        if (quiet) return;
         const uint64_t gen = ++c->done_gen;
         (void)hipEventRecord(c->ev_done_ring[gen % 64], c->stream);
         for (uint32_t s = first; s < first + n && s < c->n_slots; ++s) c->slot_gen[s] = gen;
@@ -559,12 +570,36 @@ int frame_status(gr_ctx *c, const GrFrameState &st) {
     return fail(c, st.status, "frame analysis failed");
 }
 
+// Per-frame calls on small selections (gr_small.h).  small_wait: the kernel's last act is the store of `seq` into the mapped word; spin
+// on it for up to ~20 ms of wall clock (a healthy call answers in microseconds), then let the stream synchronisation decide.
+static bool small_ok(const gr_ctx *c, const GrSel &sel) { return c->small_max != 0 && c->small_state != nullptr && sel.n <= c->small_max && !c->profile; }
+static int small_wait(gr_ctx *c, uint32_t seq) {
+    volatile uint32_t *w = c->small_flag;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t spins = 0; *w != seq; ++spins) {
+        if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) {
+            c->small_sync_fallbacks++;
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            if (*w != seq) return fail(c, GR_E_HIP, "a single-wave kernel ended without publishing its result");
+            break;
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    c->small_calls++;
+    return GR_OK;
+}
+
 // launch one centre stage (sums + finalize) for `nf` frames starting at first_slot
 int center_stage(gr_ctx *c, uint32_t first_slot, uint32_t nf, const GrSel &sel, int kind, int weighted,
                  int mass_first, int target, int only_status = 0) {
     // batches: a multiple of 8 chunks per frame, so that chunk c of every frame runs on XCD c % 8 and that XCD's L2 keeps its
     // eighth of the masses.  (The RMSD kernels' few, long chunks -- batch_chunks -- are slower here: 3.9 vs 3.1 us per 1e6-atom
     // frame for the naive centre; this kernel's per-atom fp64 chains want many workgroups.)
+    if (small_ok(c, sel)) {   // a small selection: one wave per frame, sums and closing step in one launch (gr_small.h)
+        k_center_small_stage<<<dim3(nf), dim3(64), 0, c->stream>>>(c->frames, c->frame_stride, first_slot, c->masses, sel, c->boxes_dev, kind, weighted, mass_first, target, c->state_dev, only_status);
+        HIPCHK(c, hipGetLastError());
+        return GR_OK;
+    }
     uint32_t nch = chunks_for(sel);
     if (nf > 1 && nch >= 8) nch &= ~7u;
     const dim3 grid(nch, nf), wg(GR_WG);
@@ -692,6 +727,17 @@ gr_ctx *gr_ctx_create(int device, uint64_t n_atoms, uint32_t n_slots, int *statu
     ok = ok && hipMalloc(&c->acc_partials, (size_t)GR_MAX_BATCH * GR_MAX_CHUNKS * sizeof(GrAccPartial)) == hipSuccess;
     ok = ok && hipMalloc(&c->state_dev, GR_MAX_BATCH * sizeof(GrFrameState)) == hipSuccess;
     ok = ok && hipHostMalloc(&c->state_host, GR_MAX_BATCH * sizeof(GrFrameState), hipHostMallocDefault) == hipSuccess;
+    {   // (when the mapped record cannot be had the single-wave kernels are simply not used)
+        void *hp = nullptr, *dp = nullptr;
+        if (ok && hipHostMalloc(&hp, 256, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
+            if (hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess && dp) {
+                memset(hp, 0, 256);
+                c->small_state = reinterpret_cast<GrFrameState *>(hp); c->small_state_dev = reinterpret_cast<GrFrameState *>(dp);
+                c->small_flag = reinterpret_cast<uint32_t *>(static_cast<char *>(hp) + 192); c->small_flag_dev = reinterpret_cast<uint32_t *>(static_cast<char *>(dp) + 192);
+            } else { (void)hipHostFree(hp); (void)hipGetLastError(); }
+        } else if (ok) (void)hipGetLastError();
+        static_assert(sizeof(GrFrameState) <= 192, "the mapped record holds one frame state + the sequence word");
+    }
     ok = ok && hipMalloc(&c->bad_dev, 4 * GR_MAX_BATCH * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipHostMalloc(&c->bad_host, 4 * GR_MAX_BATCH * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess;
     ok = ok && hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess;
@@ -757,6 +803,7 @@ void gr_ctx_destroy(gr_ctx *c) try {
     if (c->res_progress) (void)hipFree(c->res_progress);
     if (c->state_dev) (void)hipFree(c->state_dev);
     if (c->state_host) (void)hipHostFree(c->state_host);
+    if (c->small_state) (void)hipHostFree(c->small_state);
     if (c->bad_dev) (void)hipFree(c->bad_dev);
     if (c->bad_host) (void)hipHostFree(c->bad_host);
     if (c->pd_out) (void)hipFree(c->pd_out);
@@ -957,6 +1004,20 @@ static int center_core(gr_ctx *c, uint32_t slot, const Group &g, int kind, int w
     int st;
     SlotUse use(c, slot);
     const GrSel sel = make_sel(g);
+    if (small_ok(c, sel) && !(kind == GR_CENTER_PBC && center_onepass_ok(c, sel))) {
+        // a small selection: one single-wave dispatch, the result read out of host-mapped memory (gr_small.h)
+        const uint32_t seq = ++c->small_seq;
+        k_center_small<<<dim3(1), dim3(64), 0, c->stream>>>(c->frames, c->frame_stride, slot, c->masses, sel, c->boxes_dev,
+                                                           kind == GR_CENTER_NAIVE ? 0 : (kind == GR_CENTER_ESTIMATE ? 1 : 2), weighted,
+                                                           c->state_dev, c->small_state_dev, c->small_flag_dev, seq);
+        HIPCHK(c, hipGetLastError());
+        st = small_wait(c, seq); if (st) return st;
+        use.quiet = true;                 // (the kernel has read everything it reads: nothing for a later upload into the slot to wait for)
+        c->state_host[0] = *c->small_state;
+        st = frame_status(c, c->state_host[0]); if (st) return st;
+        if (out) { out[0] = c->state_host[0].com[0]; out[1] = c->state_host[0].com[1]; out[2] = c->state_host[0].com[2]; }
+        return GR_OK;
+    }
     st = state_reset(c, 1); if (st) return st;
     if (kind == GR_CENTER_NAIVE) st = center_stage(c, slot, 1, sel, 0, weighted, 0, 1);          // position first (:946-958)
     else if (kind == GR_CENTER_ESTIMATE) st = center_stage(c, slot, 1, sel, 1, weighted, 1, 1);  // mass first (:1324-1339)
@@ -1639,6 +1700,8 @@ int gr_ctx_stat(const gr_ctx *c, int key, uint64_t *value) {
     case GR_STAT_RMSD_FAST_FRAMES: *value = c->rmsd_fast_frames; return GR_OK;
     case GR_STAT_RMSD_EXACT_REDOS: *value = c->rmsd_exact_redos; return GR_OK;
     case GR_STAT_XTC_DEVICE_FRAMES: *value = c->xtc_dev_frames; return GR_OK;
+    case GR_STAT_SMALL_CALLS: *value = c->small_calls; return GR_OK;
+    case GR_STAT_SMALL_SYNC_FALLBACKS: *value = c->small_sync_fallbacks; return GR_OK;
     default: return GR_E_INVALID_ARG;
     }
 }
@@ -1650,6 +1713,7 @@ int gr_ctx_set_tuning(gr_ctx *c, int key, int64_t value) try {
     case GR_TUNE_CHUNKS: if (value < 0 || value > GR_MAX_CHUNKS) break; c->chunks = (uint32_t)value; return GR_OK;
     case GR_TUNE_FIT_WGS: if (value < 0 || value > 65535) break; c->fit_wgs = (uint32_t)value; return GR_OK;
     case GR_TUNE_FUSE: c->fuse = value ? 1 : 0; return GR_OK;
+    case GR_TUNE_SMALL_CALLS: if (value < 0 || value > 65536) break; c->small_max = (uint32_t)value; return GR_OK;
     case GR_TUNE_TWO_PASS: c->two_pass = value ? 1 : 0; return GR_OK;
     case GR_TUNE_RESIDENT: if (value < 0 || value > 2) break; c->resident = value; return GR_OK;
     case GR_TUNE_MASKED_SELECTIONS: if (value != 0 && value != 1) break; c->masked_sel = (int)value; return GR_OK;
@@ -1714,11 +1778,28 @@ static int segment_begin(gr_rmsd_plan *p, uint32_t s0, uint32_t nb, int fit) {
         p->dev.w_is_mass = same ? 1u : 0u; p->resolved = true;
         p->span_ok = p->p_span_dev != nullptr && g->masked && g->mask_dev != nullptr && g->blocks == p->ref_blocks;   // the by-atom copy fits THIS group
     }
+    q.consistent = (g->n == p->n_ref);
+    // (a selection the caller has sent to the f32-chain RMSD pass -- GR_TUNE_RMSD_FAST_MIN lowered below GR_TUNE_SMALL_CALLS -- takes that pass)
+    const bool fast_asked = c->two_pass && c->rmsd_fast && p->dev.w_is_mass != 0 && g->n >= c->rmsd_fast_min && ((!fit && sel.contiguous) || (sel.masked && p->span_ok));
+    const bool small = !fit && q.consistent && !p->exact && small_ok(c, sel) && !fast_asked;
+    if (small && nb == 1) {
+        // ONE frame, RMSD without fit of a small selection (the reference's per-frame calc_rmsd on a protein): one single-wave dispatch
+        // that accumulates, closes the frame and leaves its state in host-mapped memory (gr_small.h); everything after the wait --
+        // the redo of a frame whose image proof failed included -- is segment_end's usual way
+        q.small = true; q.small_seq = ++c->small_seq;
+        k_rmsd_small<<<dim3(1), dim3(64), 0, c->stream>>>(c->frames, c->frame_stride, s0, c->masses, sel, c->boxes_dev, p->dev,
+                                                         c->state_dev, 0, c->small_state_dev, c->small_flag_dev, q.small_seq);
+        HIPCHK(c, hipGetLastError());
+        return GR_OK;
+    }
     for (uint32_t f = 0; f < nb; ++f) { GrFrameState z = {}; z.err_index = GR_NOIDX; z.status = q.pre[f]; c->state_host[f] = z; }
     HIPCHK(c, hipMemcpyAsync(c->state_dev, c->state_host, nb * sizeof(GrFrameState), hipMemcpyHostToDevice, c->stream));
-    q.consistent = (g->n == p->n_ref);
     int st;
-    if (!q.consistent) {
+    if (small) {
+        // ... and a batch of frames of such a selection: the same kernel, one wave per frame (a batch equals its per-frame calls bit for bit)
+        k_rmsd_small<<<dim3(nb), dim3(64), 0, c->stream>>>(c->frames, c->frame_stride, s0, c->masses, sel, c->boxes_dev, p->dev, c->state_dev, 1, nullptr, nullptr, 0u);
+        HIPCHK(c, hipGetLastError());
+    } else if (!q.consistent) {
         // positions and masses of the target are still checked first (extract_data_from_system runs to
         // completion before number_of_positions_consistent, rmsd.rs:206-214)
         st = pbc_center_stages(c, s0, nb, sel, 1); if (st) return st;
@@ -1891,7 +1972,8 @@ static int segment_end(gr_rmsd_plan *p, float *rmsd_out, int *status_out, float 
     } else {
         if (!q.has_group) return fail(c, GR_E_INVALID_ARG, "batch state lost");
         const GrSel sel = q.sel;
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (q.small) { const int sw = small_wait(c, q.small_seq); if (sw) return sw; c->state_host[0] = *c->small_state; }
+        else HIPCHK(c, hipStreamSynchronize(c->stream));
         std::vector<uint8_t> redo;      // frames of an aborted resident launch that nobody touched: redone on the two-pass path below
         std::vector<uint8_t> torn;      // ... and frames that SOME waves fitted and others did not
 #ifdef GR_EXP_TIMELINE

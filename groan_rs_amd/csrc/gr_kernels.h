@@ -250,6 +250,63 @@ __device__ __forceinline__ float gr_wave_max_scatter16(float (&a)[32], const uin
 #define GR_CEN_K 8
 struct GrCenPartial { double s[GR_CEN_K]; uint32_t bad_pos, bad_mass; };
 
+// one atom's terms of a centre, added to the f32 partials p[0..6] (4 atoms per partial on k_center_sums' contiguous path); shared by
+// k_center_sums and the single-wave kernel of gr_small.h (sc* = 2 pi / box length for the Bai-Breen angles, c* = the centre to unwrap about)
+template <int KIND>
+__device__ __forceinline__ void gr_center_atom(uint32_t i, float x, float y, float z, float m, const int weighted, const GrBox &box,
+                                               const float scx, const float scy, const float scz, const float cx, const float cy, const float cz,
+                                               uint32_t &bad_pos, uint32_t &bad_mass, float (&p)[7]) {
+    if (weighted) { if (m != m) { bad_mass = min(bad_mass, i); m = 0.0f; } } else m = 1.0f;
+    if (x != x) { bad_pos = min(bad_pos, i); return; }
+    if (KIND == 0) {
+        p[0] = fmaf(x, m, p[0]); p[1] = fmaf(y, m, p[1]); p[2] = fmaf(z, m, p[2]); p[3] += m;
+    } else if (KIND == 1) {
+        // position.wrap(simbox): an atom inside the cell is left as it is (every stage's k is 0: the reference's loops do
+        // not turn), so the closed form (~25 VALU slots per axis) only runs for the lanes that need it
+        if (!(x >= 0.0f && x <= box.ax && y >= 0.0f && y <= box.by && z >= 0.0f && z <= box.cz)) gr_wrap(x, y, z, box);
+        if (!box.ortho) {   // fractional ("u") coordinates, scaled by the box diagonal
+            // (z / cz and uy / by as reciprocal x one Newton correction: the quotient to within an ulp -- nearly always the
+            // correctly rounded one -- in 3 instructions instead of the ~12 of an IEEE division; this branch has no reference
+            // arithmetic to match, and the pass was VALU-bound on non-orthogonal cells: 3.5 us against 3.0)
+            float sc = z * box.icz;
+            sc = fmaf(fmaf(-sc, box.cz, z), box.icz, sc);
+            const float uy = y - sc * box.cy;
+            float sb = uy * box.iby;
+            sb = fmaf(fmaf(-sb, box.by, uy), box.iby, sb);
+            const float ux = x - sb * box.bx - sc * box.cx;
+            x = ux; y = uy;
+        }
+        // the reference's own f32 angle theta = wrap(x) * (2 pi / L) (auxiliary.rs:59-84), bit for bit -- for a group spread
+        // over the whole box the resultant is short and the estimate amplifies every 1e-7 in theta
+        // and its sine and cosine from the hardware: v_sin_f32 / v_cos_f32 take their argument in REVOLUTIONS, so theta / 2 pi --
+        // a number in [0, 1] -- needs no range reduction at all.  Measured on gfx950 over 4.2 M arguments in [0, 1)
+        // (tools/microbench/vsin_accuracy.hip): max |error| 1.25e-7, rms 3.5e-8, mean 1e-13 -- libm's sinf quality, at 2
+        // quarter-rate instructions per pair instead of the ~25 of a Cody-Waite reduction + two polynomials (round 2; the pass
+        // was VALU-bound: 3.9 -> 2.x us per 1e6-atom frame).  u = theta / 2 pi is formed with its rounding error e (the exact
+        // residual of the product + the low part of 1 / 2 pi) and the two results are corrected to first order, sin(2 pi (u + e))
+        // = s + 2 pi e c: without that the rounding of u (up to 3.7e-7 rad near a full turn) is the largest error in the sum, and
+        // a group spread evenly over the whole box -- the water of example.gro: a resultant of ~1 from 10 399 unit vectors --
+        // turns every 1e-7 per atom into 1e-5 nm of the estimate
+        float s0, c0, s1, c1, s2, c2;
+        auto sincos_rev = [](float theta, float &sn, float &cs) {
+            const float IH = 0.15915493667125702f, IL = 6.4206382432985265e-09f, TWO_PI = 6.283185307179586f;
+            const float u = theta * IH;
+            const float e = fmaf(theta, IL, fmaf(theta, IH, -u));
+            const float s = __builtin_amdgcn_sinf(u), c = __builtin_amdgcn_cosf(u), k = TWO_PI * e;
+            sn = fmaf(k, c, s); cs = fmaf(-k, s, c);
+        };
+        sincos_rev(x * scx, s0, c0); sincos_rev(y * scy, s1, c1); sincos_rev(z * scz, s2, c2);
+        p[0] = fmaf(m, c0, p[0]); p[1] = fmaf(m, c1, p[1]); p[2] = fmaf(m, c2, p[2]);
+        p[3] = fmaf(m, s0, p[3]); p[4] = fmaf(m, s1, p[4]); p[5] = fmaf(m, s2, p[5]);
+        p[6] += 1.0f;
+    } else {
+        float vx, vy, vz;
+        gr_vector_to(cx, cy, cz, x, y, z, box, vx, vy, vz);
+        p[0] = fmaf(cx + vx, m, p[0]); p[1] = fmaf(cy + vy, m, p[1]); p[2] = fmaf(cz + vz, m, p[2]);
+        p[3] += m;
+    }
+}
+
 template <int KIND>   // 0 naive, 1 Bai-Breen, 2 unwrapped about state.center (compile-time: the naive sums need neither box nor branches)
 __global__ __launch_bounds__(GR_WG) void k_center_sums(
     const float *__restrict__ frames, size_t frame_stride, uint32_t first_slot,
@@ -272,57 +329,8 @@ __global__ __launch_bounds__(GR_WG) void k_center_sums(
     const float scx = KIND == 1 ? PI_X2 / box.ax : 0.f, scy = KIND == 1 ? PI_X2 / box.by : 0.f, scz = KIND == 1 ? PI_X2 / box.cz : 0.f;
     float cx = 0.f, cy = 0.f, cz = 0.f;
     if (KIND == 2) { cx = state[frame].center[0]; cy = state[frame].center[1]; cz = state[frame].center[2]; }
-    // one atom's terms, added to the f32 partials p[0..6] (4 atoms per partial on the contiguous path)
     auto atom = [&](uint32_t i, float x, float y, float z, float m, float (&p)[7]) {
-        if (weighted) { if (m != m) { bad_mass = min(bad_mass, i); m = 0.0f; } } else m = 1.0f;
-        if (x != x) { bad_pos = min(bad_pos, i); return; }
-        if (KIND == 0) {
-            p[0] = fmaf(x, m, p[0]); p[1] = fmaf(y, m, p[1]); p[2] = fmaf(z, m, p[2]); p[3] += m;
-        } else if (KIND == 1) {
-            // position.wrap(simbox): an atom inside the cell is left as it is (every stage's k is 0: the reference's loops do
-            // not turn), so the closed form (~25 VALU slots per axis) only runs for the lanes that need it
-            if (!(x >= 0.0f && x <= box.ax && y >= 0.0f && y <= box.by && z >= 0.0f && z <= box.cz)) gr_wrap(x, y, z, box);
-            if (!box.ortho) {   // fractional ("u") coordinates, scaled by the box diagonal
-                // (z / cz and uy / by as reciprocal x one Newton correction: the quotient to within an ulp -- nearly always the
-                // correctly rounded one -- in 3 instructions instead of the ~12 of an IEEE division; this branch has no reference
-                // arithmetic to match, and the pass was VALU-bound on non-orthogonal cells: 3.5 us against 3.0)
-                float sc = z * box.icz;
-                sc = fmaf(fmaf(-sc, box.cz, z), box.icz, sc);
-                const float uy = y - sc * box.cy;
-                float sb = uy * box.iby;
-                sb = fmaf(fmaf(-sb, box.by, uy), box.iby, sb);
-                const float ux = x - sb * box.bx - sc * box.cx;
-                x = ux; y = uy;
-            }
-            // the reference's own f32 angle theta = wrap(x) * (2 pi / L) (auxiliary.rs:59-84), bit for bit -- for a group spread
-            // over the whole box the resultant is short and the estimate amplifies every 1e-7 in theta
-            // and its sine and cosine from the hardware: v_sin_f32 / v_cos_f32 take their argument in REVOLUTIONS, so theta / 2 pi --
-            // a number in [0, 1] -- needs no range reduction at all.  Measured on gfx950 over 4.2 M arguments in [0, 1)
-            // (tools/microbench/vsin_accuracy.hip): max |error| 1.25e-7, rms 3.5e-8, mean 1e-13 -- libm's sinf quality, at 2
-            // quarter-rate instructions per pair instead of the ~25 of a Cody-Waite reduction + two polynomials (round 2; the pass
-            // was VALU-bound: 3.9 -> 2.x us per 1e6-atom frame).  u = theta / 2 pi is formed with its rounding error e (the exact
-            // residual of the product + the low part of 1 / 2 pi) and the two results are corrected to first order, sin(2 pi (u + e))
-            // = s + 2 pi e c: without that the rounding of u (up to 3.7e-7 rad near a full turn) is the largest error in the sum, and
-            // a group spread evenly over the whole box -- the water of example.gro: a resultant of ~1 from 10 399 unit vectors --
-            // turns every 1e-7 per atom into 1e-5 nm of the estimate
-            float s0, c0, s1, c1, s2, c2;
-            auto sincos_rev = [](float theta, float &sn, float &cs) {
-                const float IH = 0.15915493667125702f, IL = 6.4206382432985265e-09f, TWO_PI = 6.283185307179586f;
-                const float u = theta * IH;
-                const float e = fmaf(theta, IL, fmaf(theta, IH, -u));
-                const float s = __builtin_amdgcn_sinf(u), c = __builtin_amdgcn_cosf(u), k = TWO_PI * e;
-                sn = fmaf(k, c, s); cs = fmaf(-k, s, c);
-            };
-            sincos_rev(x * scx, s0, c0); sincos_rev(y * scy, s1, c1); sincos_rev(z * scz, s2, c2);
-            p[0] = fmaf(m, c0, p[0]); p[1] = fmaf(m, c1, p[1]); p[2] = fmaf(m, c2, p[2]);
-            p[3] = fmaf(m, s0, p[3]); p[4] = fmaf(m, s1, p[4]); p[5] = fmaf(m, s2, p[5]);
-            p[6] += 1.0f;
-        } else {
-            float vx, vy, vz;
-            gr_vector_to(cx, cy, cz, x, y, z, box, vx, vy, vz);
-            p[0] = fmaf(cx + vx, m, p[0]); p[1] = fmaf(cy + vy, m, p[1]); p[2] = fmaf(cz + vz, m, p[2]);
-            p[3] += m;
-        }
+        gr_center_atom<KIND>(i, x, y, z, m, weighted, box, scx, scy, scz, cx, cy, cz, bad_pos, bad_mass, p);
     };
     if (sel.contiguous) {
         // read-only stream: a lane's 4 atoms are its three row loads (coalesced: consecutive lanes, consecutive 16 bytes) + one of
@@ -373,32 +381,10 @@ __global__ __launch_bounds__(GR_WG) void k_center_sums(
     }
 }
 
-// one workgroup per frame; target: 0 -> state.center, 1 -> state.com (+ shift = box centre - com)
-__global__ __launch_bounds__(GR_WG) void k_center_finalize(
-    const GrCenPartial *__restrict__ partials, uint32_t nchunks, const GrBox *__restrict__ boxes,
-    uint32_t first_slot, int kind, int weighted, int mass_first, int target, uint32_t n_sel,
-    GrFrameState *__restrict__ state, int only_status = 0) {
-    __shared__ double lds[(GR_WG / 64) * GR_CEN_K];
-    __shared__ uint32_t ldsu[GR_WG / 64];
-    const uint32_t frame = blockIdx.x;
-    if (only_status && state[frame].status != only_status) return;
-    double acc[GR_CEN_K];
-#pragma unroll
-    for (int k = 0; k < GR_CEN_K; ++k) acc[k] = 0.0;
-    uint32_t bad_pos = GR_NOIDX, bad_mass = GR_NOIDX;
-    for (uint32_t c = threadIdx.x; c < nchunks; c += GR_WG) {
-        const GrCenPartial &p = partials[(size_t)frame * nchunks + c];
-#pragma unroll
-        for (int k = 0; k < GR_CEN_K; ++k) acc[k] += p.s[k];
-        bad_pos = min(bad_pos, p.bad_pos); bad_mass = min(bad_mass, p.bad_mass);
-    }
-    gr_block_sum<GR_CEN_K>(acc, lds);
-    bad_pos = gr_block_min_u32(bad_pos, ldsu);
-    bad_mass = gr_block_min_u32(bad_mass, ldsu);
-    if (threadIdx.x != 0) return;
-    GrFrameState &st = state[frame];
-    if (st.status != only_status) return;   // an earlier stage of this frame already failed
-    const GrBox &b = boxes[first_slot + frame];
+// closing step of one centre stage for one frame (one lane): error precedence, the Bai-Breen angles back to a position, targets;
+// shared by k_center_finalize and the single-wave kernel of gr_small.h
+__device__ __forceinline__ void gr_center_close(const double *acc, const uint32_t bad_pos, const uint32_t bad_mass, const GrBox &b, const int kind, const int weighted,
+                                                const int mass_first, const int target, const uint32_t n_sel, GrFrameState &st, const int only_status) {
     // error precedence of the reference loops: estimate_com / get_com_naive test per atom
     // (mass first: iterators.rs:1324-1339; position first: :946-958); get_com runs the unweighted
     // estimate over all atoms before any mass is read (:1405-1422)
@@ -442,6 +428,34 @@ __global__ __launch_bounds__(GR_WG) void k_center_finalize(
         st.shift[0] = b.bcx - r[0]; st.shift[1] = b.bcy - r[1]; st.shift[2] = b.bcz - r[2];
         if (only_status) st.status = 0;   // the frame's last stage: done
     }
+}
+
+// one workgroup per frame; target: 0 -> state.center, 1 -> state.com (+ shift = box centre - com)
+__global__ __launch_bounds__(GR_WG) void k_center_finalize(
+    const GrCenPartial *__restrict__ partials, uint32_t nchunks, const GrBox *__restrict__ boxes,
+    uint32_t first_slot, int kind, int weighted, int mass_first, int target, uint32_t n_sel,
+    GrFrameState *__restrict__ state, int only_status = 0) {
+    __shared__ double lds[(GR_WG / 64) * GR_CEN_K];
+    __shared__ uint32_t ldsu[GR_WG / 64];
+    const uint32_t frame = blockIdx.x;
+    if (only_status && state[frame].status != only_status) return;
+    double acc[GR_CEN_K];
+#pragma unroll
+    for (int k = 0; k < GR_CEN_K; ++k) acc[k] = 0.0;
+    uint32_t bad_pos = GR_NOIDX, bad_mass = GR_NOIDX;
+    for (uint32_t c = threadIdx.x; c < nchunks; c += GR_WG) {
+        const GrCenPartial &p = partials[(size_t)frame * nchunks + c];
+#pragma unroll
+        for (int k = 0; k < GR_CEN_K; ++k) acc[k] += p.s[k];
+        bad_pos = min(bad_pos, p.bad_pos); bad_mass = min(bad_mass, p.bad_mass);
+    }
+    gr_block_sum<GR_CEN_K>(acc, lds);
+    bad_pos = gr_block_min_u32(bad_pos, ldsu);
+    bad_mass = gr_block_min_u32(bad_mass, ldsu);
+    if (threadIdx.x != 0) return;
+    GrFrameState &st = state[frame];
+    if (st.status != only_status) return;   // an earlier stage of this frame already failed
+    gr_center_close(acc, bad_pos, bad_mass, boxes[first_slot + frame], kind, weighted, mass_first, target, n_sel, st, only_status);
 }
 
 __global__ void k_state_reset(GrFrameState *state, uint32_t n) {

@@ -298,6 +298,10 @@ enum { GR_TUNE_SUB_BATCH = 1, GR_TUNE_CHUNKS = 2, GR_TUNE_FIT_WGS = 3, GR_TUNE_F
                                          frames); 0: host threads encode (host_threads of the call).  2.0 / 2.5 k frames/s of 5e5 atoms (water-like / one dense chain)
                                          against 1.4-1.6 / 2.1-2.8 k for 16 host encoders: the rate the file takes on the test box (tools/xtc_write_bench.py) */,
        GR_TUNE_RMSD_FAST_SIGMAS = 14 /* multiples (default 6) of the pass's own rounding estimate a frame's rmsd must stand clear of to be kept; 0 keeps every frame: calibration runs only (tools/rmsd_calibrate.py) */,
+       GR_TUNE_SMALL_CALLS = 17 /* largest selection (atoms; default 4096, 0 = never) for which ONE-frame calls -- gr_group_center, gr_sel_center, gr_rmsd /
+                                    gr_rmsd_batch of one frame -- run as one single-wave dispatch whose result the host reads out of coherent host
+                                    memory instead of a chain of launches, two small copies and a stream synchronisation (gr_small.h: 36 -> ~10 us for the
+                                    centre of mass, 55 -> ~14 us for the RMSD of a 363-atom selection); same closing arithmetic, sums in another order */,
        GR_TUNE_TEST_RESIDENT_NO_START = 100 /* tests: the next resident launch behaves as if its workgroups never got onto the chip */,
        GR_TUNE_TEST_RESIDENT_ABORT_AT = 101 /* tests: the next resident launch is aborted from inside when it reaches this frame of its segment (< 0: never) */ };
 int gr_ctx_set_tuning(gr_ctx *ctx, int key, int64_t value);
@@ -313,7 +317,9 @@ int gr_ctx_set_tuning(gr_ctx *ctx, int key, int64_t value);
 enum { GR_STAT_N_CUS = 1, GR_STAT_RES_MAX_WGS = 2, GR_STAT_RES_LAUNCHES = 3, GR_STAT_RES_HANDSHAKE_MISSES = 4, GR_STAT_RES_ABORTS = 5, GR_STAT_RES_REDONE_FRAMES = 6, GR_STAT_RES_LAST_STREAMS = 7,
        GR_STAT_RMSD_FAST_FRAMES = 8 /* frames of RMSD-without-fit calls closed by the f32-chain pass (GR_TUNE_RMSD_FAST) */,
        GR_STAT_RMSD_EXACT_REDOS = 9 /* ... and frames that pass handed back to the exact-product pass */,
-       GR_STAT_XTC_DEVICE_FRAMES = 10 /* frames gr_xtc_write_slots compressed on the device (GR_TUNE_XTC_DEVICE_ENCODE) */ };
+       GR_STAT_XTC_DEVICE_FRAMES = 10 /* frames gr_xtc_write_slots compressed on the device (GR_TUNE_XTC_DEVICE_ENCODE) */,
+       GR_STAT_SMALL_CALLS = 11 /* one-frame calls answered by a single-wave dispatch (GR_TUNE_SMALL_CALLS) */,
+       GR_STAT_SMALL_SYNC_FALLBACKS = 12 /* ... of which the host gave up polling for the result (20 ms) and synchronised the stream instead */ };
 int gr_ctx_stat(const gr_ctx *ctx, int key, uint64_t *value);
 
 /* ---------------------------------------------------------------- text front end: gro structures, ndx index groups (host side)
