@@ -1781,14 +1781,17 @@ static int segment_begin(gr_rmsd_plan *p, uint32_t s0, uint32_t nb, int fit) {
     q.consistent = (g->n == p->n_ref);
     // (a selection the caller has sent to the f32-chain RMSD pass -- GR_TUNE_RMSD_FAST_MIN lowered below GR_TUNE_SMALL_CALLS -- takes that pass)
     const bool fast_asked = c->two_pass && c->rmsd_fast && p->dev.w_is_mass != 0 && g->n >= c->rmsd_fast_min && ((!fit && sel.contiguous) || (sel.masked && p->span_ok));
-    const bool small = !fit && q.consistent && !p->exact && small_ok(c, sel) && !fast_asked;
+    const bool small = q.consistent && !p->exact && small_ok(c, sel) && !fast_asked;
     if (small && nb == 1) {
-        // ONE frame, RMSD without fit of a small selection (the reference's per-frame calc_rmsd on a protein): one single-wave dispatch
-        // that accumulates, closes the frame and leaves its state in host-mapped memory (gr_small.h); everything after the wait --
-        // the redo of a frame whose image proof failed included -- is segment_end's usual way
+        // ONE frame, RMSD (with or without fit) of a small selection -- the reference's per-frame calc_rmsd / calc_rmsd_and_fit on a
+        // protein: one single-wave dispatch that accumulates, closes the frame (closed-form rmsd from exact products, rotation, shift) and
+        // leaves its state in host-mapped memory (gr_small.h); a fit follows it on the stream as the plain transform of all atoms, and the
+        // host does not wait for that one (the rmsd is known; whatever touches the slot next is ordered behind it).  Everything after
+        // the wait -- the redo of a frame whose image proof failed included -- is segment_end's usual way.
         q.small = true; q.small_seq = ++c->small_seq;
         k_rmsd_small<<<dim3(1), dim3(64), 0, c->stream>>>(c->frames, c->frame_stride, s0, c->masses, sel, c->boxes_dev, p->dev,
                                                          c->state_dev, 0, c->small_state_dev, c->small_flag_dev, q.small_seq);
+        if (fit) k_fit_pk<false><<<dim3(fit_grid(c, 1), 1), dim3(GR_WG), 0, c->stream>>>(c->frames, c->frame_stride, s0, (uint32_t)c->n, c->boxes_dev, p->dev, c->state_dev, c->masses, sel, nullptr);
         HIPCHK(c, hipGetLastError());
         return GR_OK;
     }
@@ -1798,6 +1801,7 @@ static int segment_begin(gr_rmsd_plan *p, uint32_t s0, uint32_t nb, int fit) {
     if (small) {
         // ... and a batch of frames of such a selection: the same kernel, one wave per frame (a batch equals its per-frame calls bit for bit)
         k_rmsd_small<<<dim3(nb), dim3(64), 0, c->stream>>>(c->frames, c->frame_stride, s0, c->masses, sel, c->boxes_dev, p->dev, c->state_dev, 1, nullptr, nullptr, 0u);
+        if (fit) k_fit_pk<false><<<dim3(fit_grid(c, nb), nb), dim3(GR_WG), 0, c->stream>>>(c->frames, c->frame_stride, s0, (uint32_t)c->n, c->boxes_dev, p->dev, c->state_dev, c->masses, sel, nullptr);
         HIPCHK(c, hipGetLastError());
     } else if (!q.consistent) {
         // positions and masses of the target are still checked first (extract_data_from_system runs to

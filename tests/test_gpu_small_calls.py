@@ -106,6 +106,29 @@ def test_rmsd_of_small_selections(G, cell):
             singles.append(r[0])
         rb, st = plan.rmsd(0, nf)
         assert (st == 0).all() and np.array_equal(rb, np.array(singles, np.float32))
+        # ... and with the fit (calc_rmsd_and_fit, rmsd.rs:141-166, 508-528): the same rmsd, every atom of the frame transformed; one
+        # frame per call on a twin system == the batch, bit for bit
+        twin = G.System(n, masses=m, n_slots=nf + 1)
+        for f in range(nf):
+            twin.set_frame(frames[f], box, slot=f)
+        if name == "block": twin.group_create_from_ranges(name, [(100, 462)])
+        else: twin.group_create_from_indices(name, scattered)
+        plan2 = G.RMSDPlan(ref, twin, name)
+        before = twin.stat("small_calls")
+        for f in range(nf):
+            r1, st1 = plan2.rmsd_fit(f, 1)
+            assert st1[0] == 0 and r1[0] == singles[f]
+        assert twin.stat("small_calls") == before + nf
+        rb2, st2 = plan.rmsd_fit(0, nf)
+        assert (st2 == 0).all() and np.array_equal(rb2, rb)
+        for f in range(nf):
+            assert np.array_equal(twin.get_positions(f), s.get_positions(f))
+        with O.acc64():
+            ro, want = O.calc_rmsd_and_fit(frames[nf], m, idx, box, frames[0], m, idx, box)
+        assert abs(float(rb2[0]) - ro) <= 1e-5 and np.abs(s.get_positions(0) - want).max() <= 5e-5
+        for f in range(nf):
+            s.set_frame(frames[f], box, slot=f)          # (the next selection starts from the unfitted frames again)
+        plan2.close(); twin.close()
         plan.close()
     assert s.stat("small_sync_fallbacks") == 0
     ref.close(); s.close()
