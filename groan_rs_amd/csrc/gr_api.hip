@@ -573,14 +573,14 @@ int frame_status(gr_ctx *c, const GrFrameState &st) {
 // Per-frame calls on small selections (gr_small.h).  small_wait: the kernel's last act is the store of `seq` into the mapped word; spin
 // on it for up to ~20 ms of wall clock (a healthy call answers in microseconds), then let the stream synchronisation decide.
 static bool small_ok(const gr_ctx *c, const GrSel &sel) { return c->small_max != 0 && c->small_state != nullptr && sel.n <= c->small_max && !c->profile; }
-static int small_wait(gr_ctx *c, uint32_t seq) {
+static int small_wait(gr_ctx *c, uint32_t seq, uint32_t words = 1) {
     volatile uint32_t *w = c->small_flag;
     const auto t0 = std::chrono::steady_clock::now();
-    for (uint32_t spins = 0; *w != seq; ++spins) {
+    for (uint32_t spins = 0; w[0] != seq || w[words - 1] != seq; ++spins) {
         if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) {
             c->small_sync_fallbacks++;
             HIPCHK(c, hipStreamSynchronize(c->stream));
-            if (*w != seq) return fail(c, GR_E_HIP, "a single-wave kernel ended without publishing its result");
+            if (w[0] != seq || w[words - 1] != seq) return fail(c, GR_E_HIP, "a single-wave kernel ended without publishing its result");
             break;
         }
     }
@@ -736,7 +736,7 @@ gr_ctx *gr_ctx_create(int device, uint64_t n_atoms, uint32_t n_slots, int *statu
                 c->small_flag = reinterpret_cast<uint32_t *>(static_cast<char *>(hp) + 192); c->small_flag_dev = reinterpret_cast<uint32_t *>(static_cast<char *>(dp) + 192);
             } else { (void)hipHostFree(hp); (void)hipGetLastError(); }
         } else if (ok) (void)hipGetLastError();
-        static_assert(sizeof(GrFrameState) <= 192, "the mapped record holds one frame state + the sequence word");
+        static_assert(2 * sizeof(GrFrameState) <= 192, "the mapped block holds two frame states + their sequence words");
     }
     ok = ok && hipMalloc(&c->bad_dev, 4 * GR_MAX_BATCH * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipHostMalloc(&c->bad_host, 4 * GR_MAX_BATCH * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess;
@@ -1007,7 +1007,7 @@ static int center_core(gr_ctx *c, uint32_t slot, const Group &g, int kind, int w
     if (small_ok(c, sel) && !(kind == GR_CENTER_PBC && center_onepass_ok(c, sel))) {
         // a small selection: one single-wave dispatch, the result read out of host-mapped memory (gr_small.h)
         const uint32_t seq = ++c->small_seq;
-        k_center_small<<<dim3(1), dim3(64), 0, c->stream>>>(c->frames, c->frame_stride, slot, c->masses, sel, c->boxes_dev,
+        k_center_small<<<dim3(1), dim3(64), 0, c->stream>>>(c->frames, c->frame_stride, slot, c->masses, sel, sel, c->boxes_dev,
                                                            kind == GR_CENTER_NAIVE ? 0 : (kind == GR_CENTER_ESTIMATE ? 1 : 2), weighted,
                                                            c->state_dev, c->small_state_dev, c->small_flag_dev, seq);
         HIPCHK(c, hipGetLastError());
@@ -1047,6 +1047,28 @@ int gr_group_center(gr_ctx *c, uint32_t slot, const char *group, int kind, int w
 /* ------------------------------------------------------------ distances */
 int gr_group_distance(gr_ctx *c, uint32_t slot, const char *g1, const char *g2, int dim, float *out) try {
     float c1[3], c2[3];
+    {   // both groups small (a protein and a ligand, two domains): their centres in ONE dispatch of two waves (gr_small.h); errors in the
+        // reference's order -- everything about the first group before anything about the second -- whichever way the call goes
+        const Group *a = (c && slot < c->n_slots) ? find_group(c, g1) : nullptr, *b = a ? find_group(c, g2) : nullptr;
+        if (a && b && a->n && b->n && dim >= 0 && dim <= 7 && box_check(c, slot) == GR_OK && !c->in_flight) {
+            const GrSel sa = make_sel(*a), sb = make_sel(*b);
+            if (small_ok(c, sa) && small_ok(c, sb) && !center_onepass_ok(c, sa) && !center_onepass_ok(c, sb)) {
+                (void)hipSetDevice(c->device);
+                SlotUse use(c, slot);
+                const uint32_t seq = ++c->small_seq;
+                k_center_small<<<dim3(2), dim3(64), 0, c->stream>>>(c->frames, c->frame_stride, slot, c->masses, sa, sb, c->boxes_dev, 2, 0,
+                                                                   c->state_dev, c->small_state_dev, c->small_flag_dev, seq);
+                HIPCHK(c, hipGetLastError());
+                int st = small_wait(c, seq, 2); if (st) return st;
+                use.quiet = true;
+                const GrFrameState r1 = c->small_state[0], r2 = c->small_state[1];
+                st = frame_status(c, r1); if (st) return st;
+                st = frame_status(c, r2); if (st) return st;
+                if (out) *out = gr_distance(r1.com[0], r1.com[1], r1.com[2], r2.com[0], r2.com[1], r2.com[2], dim, c->boxes_host[slot]);
+                return GR_OK;
+            }
+        }
+    }
     int st = gr_group_center(c, slot, g1, GR_CENTER_PBC, 0, c1); if (st) return st;   // analysis.rs:354-355
     st = gr_group_center(c, slot, g2, GR_CENTER_PBC, 0, c2); if (st) return st;
     st = box_check(c, slot); if (st) return st;

@@ -103,11 +103,15 @@ __global__ __launch_bounds__(64) void k_center_small_stage(
 
 // ONE frame, the whole centre in one dispatch, the result left in host-mapped memory (center_core, gr_api.hip):
 // kind 0 naive, 1 Bai-Breen estimate, 2 estimate + unwrapped mean (get_center / get_com) -- the same stages in the same order
+// (blockIdx.x = 1: the SECOND selection of a call that wants the centres of two groups of one frame -- group_distance, analysis.rs:348-360 --
+//  with its own record and sequence word behind the first)
 __global__ __launch_bounds__(64) void k_center_small(
-    const float *__restrict__ frames, size_t frame_stride, uint32_t slot, const float *__restrict__ masses, GrSel sel,
+    const float *__restrict__ frames, size_t frame_stride, uint32_t slot, const float *__restrict__ masses, GrSel sel_a, GrSel sel_b,
     const GrBox *__restrict__ boxes, int kind, int weighted, GrFrameState *state_dev, GrFrameState *state_host, uint32_t *flag_host, uint32_t seq) {
     __shared__ double lds_tot[GR_CEN_K];
     const uint32_t lane = threadIdx.x;
+    const GrSel &sel = blockIdx.x ? sel_b : sel_a;
+    state_dev += blockIdx.x; state_host += blockIdx.x; flag_host += blockIdx.x;
     const GrBox &box = boxes[slot];
     const float *xyz = frames + (size_t)slot * frame_stride;
     GrFrameState st = {};

@@ -169,3 +169,38 @@ def test_errors_in_the_reference_order_and_a_frame_whose_proof_fails(G):
     assert st[0] == 0 and abs(float(r[0]) - want) <= 1e-5
     assert plan.last_fallbacks() == 1
     plan.close(); ref.close(); s.close()
+
+
+@pytest.mark.parametrize("cell", list(BOXES))
+def test_group_distance_of_two_small_groups_is_one_dispatch(G, cell):
+    """group_distance (analysis.rs:348-360): the centres of both groups in one launch of two waves; the same numbers as the two centre calls,
+    the oracle's distance, errors of the first group before the second's"""
+    box = O.box_from_lengths_angles(*BOXES[cell])
+    n = 6000
+    s, frames, m, rng = make(G, n, 2, box, 31, spread=0.4)
+    ia, ib = np.arange(50, 413), np.unique(rng.integers(2000, 5000, 200))
+    s.group_create_from_ranges("a", [(50, 412)])
+    s.group_create_from_indices("b", ib)
+    for f in range(2):
+        ca, cb = s.group_get_center("a", slot=f), s.group_get_center("b", slot=f)
+        for dim in (G.Dimension.XYZ, G.Dimension.X, G.Dimension.YZ):
+            before = s.stat("small_calls")
+            d = s.group_distance("a", "b", dim, slot=f)
+            assert s.stat("small_calls") == before + 1
+            s.set_tuning(small_calls=0)
+            d0 = s.group_distance("a", "b", dim, slot=f)
+            s.set_tuning(small_calls=4096)
+            assert abs(d - d0) <= 2e-6
+            with O.acc64():
+                want = O.distance(O.get_center(frames[f], ia, box), O.get_center(frames[f], ib, box), dim.name.lower(), box)
+            assert abs(d - want) <= 2e-5, (cell, f, dim, d, want)
+            assert abs(d - O.distance(ca, cb, dim.name.lower(), box)) <= 2e-6
+    pos = frames[0].copy(); pos[60] = np.nan; pos[int(ib[3])] = np.nan
+    s.set_frame(pos, box, slot=0)
+    with pytest.raises(G.GroupError) as e:
+        s.group_distance("a", "b", G.Dimension.XYZ, slot=0)
+    assert e.value.variant == "InvalidPosition" and e.value.detail == 60
+    with pytest.raises(G.GroupError) as e:
+        s.group_distance("b", "a", G.Dimension.XYZ, slot=0)
+    assert e.value.variant == "InvalidPosition" and e.value.detail == int(ib[3])
+    s.close()
