@@ -1,0 +1,131 @@
+#!/usr/bin/env python3
+"""Randomised soak of the single-wave kernels of one-frame calls (gr_small.h, GR_TUNE_SMALL_CALLS) on the GPU box: systems of 300 .. 20 000
+atoms, selections of 1 .. 4 096 atoms drawn as one block or as scattered indices, three cells, blobs narrow enough for the image proof
+or wide enough to fail it, an atom without position or without mass inside the selection now and then.  Every call -- naive COM, Bai-Breen
+estimate (centre and COM), get_center / get_com, group_distance of two groups, calc_rmsd, calc_rmsd_and_fit (one frame per call and as a
+batch) -- is compared with the batched kernels (GR_TUNE_SMALL_CALLS = 0) on the same frames: the same error (variant and atom index) or
+centres to 5e-6 nm, rmsd to 2e-6, fitted coordinates to 3e-5; one frame per case against the oracle.  Prints one line per case; exit
+status 1 on a mismatch.
+
+    python tools/small_fuzz.py [seconds] [seed]
+"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import groan_rs_amd as G
+import oracle_lib as O
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+CELLS = [([7.0, 6.5, 6.0], [90.0, 90.0, 90.0]), ([7.0, 6.5, 6.0], [75.0, 80.0, 70.0]), ([6.5, 6.5, 6.5], [60.0, 60.0, 90.0])]
+CENTRES = ("group_get_com_naive", "group_estimate_com", "group_estimate_center", "group_get_com", "group_get_center")
+
+
+def draw_group(n, lo_n=1):
+    size = int(min(n, 4096, max(lo_n, rng.integers(1, 4097) if rng.random() < 0.3 else rng.integers(1, 600))))
+    if rng.random() < 0.5:
+        a = int(rng.integers(0, n - size + 1))
+        return ("block", np.arange(a, a + size))
+    return ("scattered", np.sort(rng.choice(n, size, replace=False)))
+
+
+def call(fn):
+    try:
+        return ("ok", fn())
+    except G.GroanError as e:
+        return ("err", (type(e).__name__, e.variant, e.detail))
+
+
+def same(a, b, tol):
+    if a[0] != b[0]:
+        return False
+    if a[0] == "err":
+        return a[1] == b[1]
+    return np.abs(np.asarray(a[1], np.float64) - np.asarray(b[1], np.float64)).max() <= tol
+
+
+t_end = time.time() + budget
+cases = bad = small_total = 0
+while time.time() < t_end:
+    n = int(rng.integers(300, 20001))
+    lengths, angles = CELLS[int(rng.integers(0, 3))]
+    box = O.box_from_lengths_angles(lengths, angles)
+    nf = int(rng.integers(1, 5))
+    wide = rng.random() < 0.2                               # a blob wider than half the cell: the image proof fails, the frame is redone
+    spread = 1.6 if wide else float(rng.uniform(0.15, 0.55))
+    masses = rng.uniform(1.0, 16.0, n).astype(np.float32)
+    kind_a, ia = draw_group(n)
+    kind_b, ib = draw_group(n)
+    frames = []
+    for f in range(nf + 1):
+        blob = rng.normal(0, spread, (n, 3)) + rng.uniform(0.1, 0.9, 3) * np.array(lengths)
+        frames.append(O.wrap_atoms(blob.astype(np.float32), np.arange(n), box))
+    poison = rng.random() < 0.25
+    if poison:                                              # an atom of group a without position (frame 0) / without mass
+        if rng.random() < 0.5: frames[0][int(rng.choice(ia))] = np.nan
+        else: masses[int(rng.choice(ia))] = np.nan
+    systems = []
+    for small in (4096, 0):
+        s = G.System(n, masses=masses, n_slots=nf + 1)
+        for f in range(nf + 1):
+            s.set_frame(frames[f], box, slot=f)
+        s.group_create_from_indices("a", ia) if kind_a == "scattered" else s.group_create_from_ranges("a", [(int(ia[0]), int(ia[-1]))])
+        s.group_create_from_indices("b", ib) if kind_b == "scattered" else s.group_create_from_ranges("b", [(int(ib[0]), int(ib[-1]))])
+        s.set_tuning(small_calls=small)
+        systems.append(s)
+    S, B = systems
+    ref = G.System(n, masses=np.nan_to_num(masses, nan=1.0), box=box, positions=np.nan_to_num(frames[nf], nan=1.0))
+    ref.group_create_from_indices("a", ia) if kind_a == "scattered" else ref.group_create_from_ranges("a", [(int(ia[0]), int(ia[-1]))])
+    ok = True
+    why = ""
+    for f in range(nf):
+        for fn in CENTRES:
+            ra, rb = call(lambda: getattr(S, fn)("a", slot=f)), call(lambda: getattr(B, fn)("a", slot=f))
+            if not same(ra, rb, 5e-6): ok = False; why += " %s[%d] %r != %r" % (fn, f, ra, rb)
+        ra, rb = call(lambda: S.group_distance("a", "b", G.Dimension.XYZ, slot=f)), call(lambda: B.group_distance("a", "b", G.Dimension.XYZ, slot=f))
+        if not same(ra, rb, 5e-6): ok = False; why += " distance[%d] %r != %r" % (f, ra, rb)
+    plans = []
+    try:
+        plans = [G.RMSDPlan(ref, x, "a") for x in (S, B)]
+    except G.GroanError:
+        plans = []                                          # (the reference group has no mass-weighted centre: nothing to compare)
+    if plans:
+        for f in range(nf):
+            ra, rb = call(lambda: plans[0].rmsd(f, 1)[0][0]), call(lambda: plans[1].rmsd(f, 1)[0][0])
+            if not same(ra, rb, 2e-6): ok = False; why += " rmsd[%d] %r != %r" % (f, ra, rb)
+        ra, rb = call(lambda: plans[0].rmsd(0, nf, raise_on_error=False)), call(lambda: plans[1].rmsd(0, nf, raise_on_error=False))
+        if ra[0] != rb[0] or (ra[0] == "ok" and (not np.array_equal(ra[1][1], rb[1][1]) or np.nanmax(np.abs(np.where(ra[1][1] == 0, ra[1][0] - rb[1][0], 0.0)), initial=0.0) > 2e-6)):
+            ok = False; why += " rmsd batch %r != %r" % (ra, rb)
+        # the fit: one frame per call on S, the batch on B; the same statuses, rmsd and coordinates
+        fa = [call(lambda: plans[0].rmsd_fit(f, 1)[0][0]) for f in range(nf)]
+        fb = call(lambda: plans[1].rmsd_fit(0, nf, raise_on_error=False))
+        for f in range(nf):
+            if fb[0] != "ok": ok = False; why += " fit batch %r" % (fb,); break
+            st_b = int(fb[1][1][f])
+            if (fa[f][0] == "ok") != (st_b == 0): ok = False; why += " fit status[%d] %r / %d" % (f, fa[f], st_b)
+            elif st_b == 0 and abs(float(fa[f][1]) - float(fb[1][0][f])) > 2e-6: ok = False; why += " fit rmsd[%d] %r / %r" % (f, fa[f][1], fb[1][0][f])
+            pa, pb = S.get_positions(f), B.get_positions(f)
+            if not np.array_equal(np.isnan(pa), np.isnan(pb)) or np.nanmax(np.abs(pa - pb), initial=0.0) > 3e-5:
+                ok = False; why += " fitted coordinates[%d] differ by %g" % (f, np.nanmax(np.abs(pa - pb), initial=0.0))
+        for p in plans: p.close()
+    # the oracle on frame nf (never poisoned, never fitted): COM of group b
+    if not np.isnan(masses[ib]).any():
+        with O.acc64():
+            want = O.get_center(frames[nf], ib, box, mass=masses)
+        got = call(lambda: S.group_get_com("b", slot=nf))
+        if got[0] != "ok" or np.abs(got[1] - want).max() > 1e-5: ok = False; why += " oracle COM %r != %r" % (got, want)
+    small_total += S.stat("small_calls")
+    if S.stat("small_sync_fallbacks"): ok = False; why += " sync fallbacks"
+    if B.stat("small_calls"): ok = False; why += " the batched twin took the single-wave path"
+    cases += 1
+    bad += 0 if ok else 1
+    if cases <= 30 or not ok:
+        print("%s n=%d a=%s(%d) b=%s(%d) cell=%s frames=%d %s%s%s" % ("ok " if ok else "BAD", n, kind_a, ia.size, kind_b, ib.size, "/".join("%g" % x for x in angles), nf,
+                                                                    "wide " if wide else "", "poisoned " if poison else "", why), flush=True)
+    for x in (S, B, ref): x.close()
+print("%d cases, %d mismatches, %d calls answered by the single-wave kernels" % (cases, bad, small_total))
+sys.exit(1 if bad else 0)
