@@ -25,6 +25,9 @@ def main():
     src, dst = sys.argv[1], sys.argv[2]
     stats = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)
     if stats:
+        # (bench.py runs the persistent-copy probe as a child process, which gets a stats file of its own: the bench process is the one
+        #  with the most kernels)
+        stats.sort(key=lambda f: -sum(1 for _ in open(f)))
         shutil.copyfile(stats[0], dst + "_kernel_stats.csv")
     agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, set()]))
     for f in glob.glob(os.path.join(src, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
