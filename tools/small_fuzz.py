@@ -109,6 +109,9 @@ while time.time() < t_end:
             if (fa[f][0] == "ok") != (st_b == 0): ok = False; why += " fit status[%d] %r / %d" % (f, fa[f], st_b)
             elif st_b == 0 and abs(float(fa[f][1]) - float(fb[1][0][f])) > 2e-6: ok = False; why += " fit rmsd[%d] %r / %r" % (f, fa[f][1], fb[1][0][f])
             pa, pb = S.get_positions(f), B.get_positions(f)
+            # (one or two atoms -- or three in a line -- do not determine a rotation: H is rank-deficient and every path is free to turn the
+            #  rest of the system about the group's axis; only the rmsd and the group's own atoms are comparable then)
+            if ia.size < 4: pa, pb = pa[ia], pb[ia]
             if not np.array_equal(np.isnan(pa), np.isnan(pb)) or np.nanmax(np.abs(pa - pb), initial=0.0) > 3e-5:
                 ok = False; why += " fitted coordinates[%d] differ by %g" % (f, np.nanmax(np.abs(pa - pb), initial=0.0))
         for p in plans: p.close()
