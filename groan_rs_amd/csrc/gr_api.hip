@@ -108,6 +108,7 @@ struct gr_ctx {
     unsigned long long *res_wgrec = nullptr; size_t res_wgrec_cap = 0;   // [frames][streaming workgroups, padded to 16][32] tagged words
     unsigned long long *res_rec = nullptr;   // [GR_MAX_BATCH][16]
     uint32_t *res_abort = nullptr;    // device word
+    uint32_t *res_words_host = nullptr;   // pinned: the three control words of the last resident launch, copied behind it on the stream
     uint32_t res_epoch = 0;
     bool res_in_use = false;          // the pending segment took the resident pass (segment_end checks the abort word)
     uint64_t res_launches = 0, res_handshake_misses = 0, res_aborts = 0, res_redone_frames = 0;   // gr_ctx_stat
@@ -742,6 +743,7 @@ gr_ctx *gr_ctx_create(int device, uint64_t n_atoms, uint32_t n_slots, int *statu
     ok = ok && hipHostMalloc(&c->bad_host, 4 * GR_MAX_BATCH * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess;
     ok = ok && hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess;
     ok = ok && hipMalloc(&c->res_abort, 4 * sizeof(uint32_t)) == hipSuccess;
+    ok = ok && hipHostMalloc(&c->res_words_host, 4 * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess;
     ok = ok && hipMemset(c->res_abort, 0, 4 * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipMalloc(&c->res_rec, (size_t)GR_MAX_BATCH * 16 * sizeof(unsigned long long)) == hipSuccess;
     ok = ok && hipMemset(c->res_rec, 0, (size_t)GR_MAX_BATCH * 16 * sizeof(unsigned long long)) == hipSuccess;
@@ -798,6 +800,7 @@ void gr_ctx_destroy(gr_ctx *c) try {
     if (c->fit_partials) (void)hipFree(c->fit_partials);
     if (c->fuse_cnt) (void)hipFree(c->fuse_cnt);
     if (c->res_abort) (void)hipFree(c->res_abort);
+    if (c->res_words_host) (void)hipHostFree(c->res_words_host);
     if (c->res_wgrec) (void)hipFree(c->res_wgrec);
     if (c->res_rec) (void)hipFree(c->res_rec);
     if (c->res_progress) (void)hipFree(c->res_progress);
@@ -1930,6 +1933,9 @@ static int segment_begin(gr_rmsd_plan *p, uint32_t s0, uint32_t nb, int fit) {
                 if (c->profile) EVREC(c, c->pev[1], true, S);
                 k_rmsd_close<<<dim3(nb), dim3(64), 0, S>>>(c->fit_partials, res_wgs, p->dev.sw, c->state_dev);
                 HIPCHK(c, hipGetLastError());
+                // (the launch's control words follow it on the stream into pinned memory: segment_end reads them after its one synchronisation
+                //  instead of fetching them with a blocking copy of their own -- 15-25 us per call)
+                HIPCHK(c, hipMemcpyAsync(c->res_words_host, c->res_abort, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, S));
                 q.resident = true; q.res_stream = res_stream; q.res_streams = res_streams;
                 q.rmsd_fast = false;                    // (the pass closes its frames with the fit's own sum: nothing to hand back)
                 c->res_last_streams = res_streams;
@@ -2030,7 +2036,7 @@ static int segment_end(gr_rmsd_plan *p, float *rmsd_out, int *status_out, float 
         if (q.resident) {
             resident_done(c);
             uint32_t words[3] = { 0, 0, 0 };
-            HIPCHK(c, hipMemcpy(words, c->res_abort, sizeof words, hipMemcpyDeviceToHost));
+            words[0] = c->res_words_host[0]; words[1] = c->res_words_host[1]; words[2] = c->res_words_host[2];   // (copied behind the launch: segment_begin)
             if (words[2] != 1u) {
                 // the launch never started (its workgroups did not all get onto the chip: the device is shared): no frame was
                 // touched -- the segment runs on the two-pass path, and this context sits out the next segments (twice as many after
