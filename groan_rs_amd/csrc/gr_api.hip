@@ -109,6 +109,7 @@ struct gr_ctx {
     unsigned long long *res_rec = nullptr;   // [GR_MAX_BATCH][16]
     uint32_t *res_abort = nullptr;    // device word
     uint32_t *res_words_host = nullptr;   // pinned: the three control words of the last resident launch, copied behind it on the stream
+    unsigned long long *shape_mask_dev = nullptr, *shape_mask_host = nullptr; size_t shape_mask_cap = 0;   // geometry selection: one bit per atom of the source group (device, pinned host), grown on demand
     uint32_t res_epoch = 0;
     bool res_in_use = false;          // the pending segment took the resident pass (segment_end checks the abort word)
     uint64_t res_launches = 0, res_handshake_misses = 0, res_aborts = 0, res_redone_frames = 0;   // gr_ctx_stat
@@ -801,6 +802,8 @@ void gr_ctx_destroy(gr_ctx *c) try {
     if (c->fuse_cnt) (void)hipFree(c->fuse_cnt);
     if (c->res_abort) (void)hipFree(c->res_abort);
     if (c->res_words_host) (void)hipHostFree(c->res_words_host);
+    if (c->shape_mask_dev) (void)hipFree(c->shape_mask_dev);
+    if (c->shape_mask_host) (void)hipHostFree(c->shape_mask_host);
     if (c->res_wgrec) (void)hipFree(c->res_wgrec);
     if (c->res_rec) (void)hipFree(c->res_rec);
     if (c->res_progress) (void)hipFree(c->res_progress);
@@ -1289,23 +1292,49 @@ static int geometry_filter(gr_ctx *c, uint32_t slot, const Group &g, const gr_sh
     if (!g.n) return GR_OK;
     const GrSel sel = make_sel(g);
     const size_t words = ((size_t)g.n + 63) / 64;
-    unsigned long long *mask_dev = nullptr;
-    HIPCHK(c, hipMalloc(&mask_dev, words * sizeof(unsigned long long)));
+    // (the mask buffers live with the context: a hipMalloc / hipFree pair per call cost more than the kernel and the copy together, and the
+    //  copy lands in pinned memory)
+    if (words > c->shape_mask_cap) {
+        if (c->shape_mask_dev) (void)hipFree(c->shape_mask_dev);
+        if (c->shape_mask_host) (void)hipHostFree(c->shape_mask_host);
+        c->shape_mask_dev = nullptr; c->shape_mask_host = nullptr; c->shape_mask_cap = 0;
+        const size_t cap = words + words / 8 + 64;
+        HIPCHK(c, hipMalloc(&c->shape_mask_dev, cap * sizeof(unsigned long long)));
+        HIPCHK(c, hipHostMalloc(&c->shape_mask_host, cap * sizeof(unsigned long long), hipHostMallocDefault));
+        c->shape_mask_cap = cap;
+    }
+    unsigned long long *mask_dev = c->shape_mask_dev;
     {
         SlotUse use(c, slot);
         k_shape_mask<<<dim3((unsigned)((g.n + 255) / 256)), dim3(256), 0, c->stream>>>(c->frames + (size_t)slot * c->frame_stride, sel, c->boxes_host[slot], set, mask_dev);
     }
-    std::vector<unsigned long long> mask(words);
+    const unsigned long long *mask = c->shape_mask_host;
     hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipMemcpyAsync(mask.data(), mask_dev, words * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(c->shape_mask_host, mask_dev, words * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    (void)hipFree(mask_dev);
     if (e != hipSuccess) { c->err = std::string("geometry selection: ") + hipGetErrorString(e); return GR_E_HIP; }
-    // ordinal -> atom index in the source group's iteration order (AtomContainer::iter, container.rs:381-411)
-    size_t j = 0;
-    for (const auto &blk : g.blocks)
-        for (uint64_t a = blk.first; a <= blk.second; ++a, ++j)
-            if ((mask[j >> 6] >> (j & 63)) & 1ull) picked.push_back(a);
+    // ordinal -> atom index in the source group's iteration order (AtomContainer::iter, container.rs:381-411): the set bits of each word
+    // (count-trailing-zeros walk: the cost follows the atoms picked, not the atoms tested), block by block
+    size_t picked_n = 0;
+    for (size_t w = 0; w < words; ++w) picked_n += (size_t)__builtin_popcountll(mask[w]);
+    picked.reserve(picked_n);
+    size_t j0 = 0;                                            // ordinal of the block's first atom
+    for (const auto &blk : g.blocks) {
+        const size_t len = (size_t)(blk.second - blk.first + 1), j1 = j0 + len;
+        for (size_t w = j0 >> 6; w <= ((j1 - 1) >> 6); ++w) {
+            unsigned long long bits = mask[w];
+            if (!bits) continue;
+            const size_t base = w << 6;
+            if (base < j0) bits &= ~0ull << (j0 - base);                       // ordinals before the block
+            if (base + 64 > j1) bits &= ~0ull >> (base + 64 - j1);             // ... and behind it
+            while (bits) {
+                const size_t j = base + (size_t)__builtin_ctzll(bits);
+                bits &= bits - 1;
+                picked.push_back(blk.first + (uint64_t)(j - j0));
+            }
+        }
+        j0 = j1;
+    }
     return GR_OK;
 }
 // the box gate of Shape::inside with PBC (groups.rs:104-110 / the iterator's get_simbox_unwrap): a usable box; in strict mode orthogonal

@@ -17,7 +17,7 @@ typedef std::pair<uint64_t, uint64_t> Block;   // inclusive [start, end]; ordere
 inline std::vector<Block> from_indices(std::vector<uint64_t> idx, uint64_t n_atoms) {
     std::vector<Block> blocks;
     if (idx.empty()) return blocks;
-    std::sort(idx.begin(), idx.end());
+    if (!std::is_sorted(idx.begin(), idx.end())) std::sort(idx.begin(), idx.end());   // (the geometry selection hands in a million sorted indices)
     uint64_t start = idx[0], end = idx[0];
     for (size_t k = 1; k < idx.size(); ++k) {
         const uint64_t index = idx[k];
