@@ -1849,8 +1849,18 @@ static int segment_begin(gr_rmsd_plan *p, uint32_t s0, uint32_t nb, int fit) {
         HIPCHK(c, hipGetLastError());
         return GR_OK;
     }
-    for (uint32_t f = 0; f < nb; ++f) { GrFrameState z = {}; z.err_index = GR_NOIDX; z.status = q.pre[f]; c->state_host[f] = z; }
-    HIPCHK(c, hipMemcpyAsync(c->state_dev, c->state_host, nb * sizeof(GrFrameState), hipMemcpyHostToDevice, c->stream));
+    {
+        // the frames' states start from the host-side checks.  When every frame passed them -- the usual case -- the states are zeroed by a
+        // kernel: the copy of nb records out of pinned memory costs ~30 us of host time BEFORE the first kernel of the segment can be
+        // queued (rocprofv3 --hip-trace of bench.py: hipMemcpyAsync 29 us per call), i.e. with the device idle
+        bool all_ok = true;
+        for (uint32_t f = 0; f < nb; ++f) all_ok = all_ok && q.pre[f] == GR_OK;
+        if (all_ok) { const int sr = state_reset(c, nb); if (sr) return sr; }
+        else {
+            for (uint32_t f = 0; f < nb; ++f) { GrFrameState z = {}; z.err_index = GR_NOIDX; z.status = q.pre[f]; c->state_host[f] = z; }
+            HIPCHK(c, hipMemcpyAsync(c->state_dev, c->state_host, nb * sizeof(GrFrameState), hipMemcpyHostToDevice, c->stream));
+        }
+    }
     int st;
     if (small) {
         // ... and a batch of frames of such a selection: the same kernel, one wave per frame (a batch equals its per-frame calls bit for bit)
@@ -1949,8 +1959,9 @@ static int segment_begin(gr_rmsd_plan *p, uint32_t s0, uint32_t nb, int fit) {
             const bool whole = sel.start == 0 && sel.n == c->n;
             const void *fn = resident_fn(p->dev.w_is_mass != 0, ubox, whole);
             const uint32_t lanes = GrResShape::LANES, lds = GrResShape::LDS_BYTES;
-            HIPCHK(c, hipMemsetAsync(c->res_abort + 1, 0, 2 * sizeof(uint32_t), S));   // start handshake: count, verdict
-            HIPCHK(c, hipMemsetAsync(c->res_progress, 0, (size_t)res_stream * 8 * sizeof(uint32_t), S));
+            // start handshake (count, verdict) and the waves' progress words back to zero: one small kernel instead of two memsets
+            k_res_prepare<<<dim3((res_stream * 8 + 255) / 256), dim3(256), 0, S>>>(c->res_abort + 1, c->res_progress, res_stream * 8);
+            HIPCHK(c, hipGetLastError());
             if (c->res_test_no_start) { const uint32_t two = 2u; c->res_test_no_start = 0; HIPCHK(c, hipMemcpyAsync(c->res_abort + 2, &two, sizeof two, hipMemcpyHostToDevice, S)); HIPCHK(c, hipStreamSynchronize(S)); }
             if (c->profile) EVREC(c, c->pev[0], true, S);
             // An ORDINARY launch: the grid fits the device with one workgroup per CU (resident_wgs checked), other kernels that hold

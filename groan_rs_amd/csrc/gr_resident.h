@@ -150,6 +150,13 @@ struct GrResCtl {
 #endif
 };
 
+// before a launch: the start handshake's two words (count, verdict) and every streaming wave's progress word are zeroed
+__global__ void k_res_prepare(uint32_t *handshake, uint32_t *progress, uint32_t n_progress) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 2u) handshake[i] = 0u;
+    if (i < n_progress) progress[i] = 0u;
+}
+
 template <typename T> __device__ __forceinline__ T gr_ld_agent(const T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ float gr_first_f(float v) { return __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(v))); }
 __device__ __forceinline__ float gr_lane_f(unsigned long long v, int l) { return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l)); }
