@@ -1357,9 +1357,11 @@ int gr_group_create_from_geometries(gr_ctx *c, uint32_t slot, const char *name, 
 } catch (...) { return gr_abi_guard(); }
 
 /* ------------------------------------------------------------ translate / wrap / centre */
-static int translate_core(gr_ctx *c, uint32_t slot, const Group &g, const float *v, int use_state, int dim_mask) {
+// (check_state: the frame's state -- the centre estimate that precedes the translation on the stream -- is fetched with the same
+//  synchronisation, and its error, if any, comes first: the kernel has left such a frame alone)
+static int translate_core(gr_ctx *c, uint32_t slot, const Group &g, const float *v, int use_state, int dim_mask, bool check_state = false) {
     int st = box_check(c, slot); if (st) return st;
-    if (g.n == 0) return GR_OK;
+    if (g.n == 0 && !check_state) return GR_OK;
     const GrSel sel = make_sel(g);
     SlotUse use(c, slot);
     HIPCHK(c, hipMemsetAsync(c->bad_dev, 0xFF, 4 * sizeof(uint32_t), c->stream));
@@ -1368,14 +1370,16 @@ static int translate_core(gr_ctx *c, uint32_t slot, const Group &g, const float 
     k_translate_wrap<<<dim3(nwg), dim3(GR_WG), 0, c->stream>>>(c->frames + (size_t)slot * c->frame_stride, c->frame_stride, sel, c->boxes_dev + slot, c->state_dev, use_state, dim_mask, v ? v[0] : 0.f, v ? v[1] : 0.f, v ? v[2] : 0.f, c->bad_dev);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(c->bad_host, c->bad_dev, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    if (check_state) HIPCHK(c, hipMemcpyAsync(c->state_host, c->state_dev, sizeof(GrFrameState), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (check_state) { st = frame_status(c, c->state_host[0]); if (st) return st; }
     if (c->bad_host[0] != GR_NOIDX) return fail(c, GR_E_NO_POSITION, "atom has no position", c->bad_host[0]);
     return GR_OK;
 }
-static int translate_impl(gr_ctx *c, uint32_t slot, const char *group, const float *v, int use_state, int dim_mask) {
+static int translate_impl(gr_ctx *c, uint32_t slot, const char *group, const float *v, int use_state, int dim_mask, bool check_state = false) {
     const Group *g = find_group(c, group ? group : "all");
     if (!g) return fail(c, GR_E_GROUP_NOT_FOUND, group);
-    return translate_core(c, slot, *g, v, use_state, dim_mask);
+    return translate_core(c, slot, *g, v, use_state, dim_mask, check_state);
 }
 
 int gr_group_translate(gr_ctx *c, uint32_t slot, const char *group, const float v[3]) try {
@@ -1402,9 +1406,9 @@ int gr_atoms_center(gr_ctx *c, uint32_t slot, const char *ref_group, int dim, in
     { SlotUse use(c, slot); }   // the estimate below and translate_impl each bracket themselves; this orders a pending upload first
     st = state_reset(c, 1); if (st) return st;
     st = center_stage(c, slot, 1, make_sel(*g), 1, weighted, 1, 0); if (st) return st;   // group_estimate_center / _com
-    st = fetch_states(c, 1); if (st) return st;
-    st = frame_status(c, c->state_host[0]); if (st) return st;
-    return translate_impl(c, slot, "all", nullptr, 1, mask[dim]);
+    // (the translation follows the estimate on the stream and leaves the frame alone when the estimate failed: ONE synchronisation for
+    //  both, the estimate's error reported first)
+    return translate_impl(c, slot, "all", nullptr, 1, mask[dim], true);
 } catch (...) { return gr_abi_guard(); }
 
 /* ------------------------------------------------------------ anonymous selections (the iterator-level surface) */

@@ -11,6 +11,7 @@ s = G.System(n, masses=masses, n_slots=65)
 s.synth_reference(64, box, 1.2, 3); s.synth_frames(64, 0, 64, 0, 0.04, 3)
 ref = G.System(n, masses=masses, box=box, positions=s.get_positions(64))
 for x in (ref, s): x.group_create_from_ranges("Peptide", [(0, 362)])
+s.group_create_from_ranges("Tail", [(400, 600)])
 plan = G.RMSDPlan(ref, s, "Peptide")
 out = {}
 def t(fn, reps=300):
@@ -30,5 +31,7 @@ for label, small in (("single-wave kernels (default)", 4096), ("batched kernels 
     o["group_estimate_com 1 frame us"] = t(lambda: s.group_estimate_com("Peptide", slot=0))
     o["group_get_com_naive 1 frame us"] = t(lambda: s.group_get_com_naive("Peptide", slot=0))
     o["group_get_com_batch 64 us per frame"] = round(t(lambda: s.group_get_com_batch("Peptide", 0, 64)) / 64, 3)
+    o["atoms_center_mass(Peptide) 1 frame us"] = t(lambda: s.atoms_center_mass("Peptide", G.Dimension.XYZ, slot=0))
+    o["group_distance 1 frame us"] = t(lambda: s.group_distance("Peptide", "Tail", G.Dimension.XYZ, slot=0))
 out["small_calls"] = s.stat("small_calls"); out["small_sync_fallbacks"] = s.stat("small_sync_fallbacks")
 print(json.dumps(out, indent=1))
