@@ -615,6 +615,11 @@ int center_stage(gr_ctx *c, uint32_t first_slot, uint32_t nf, const GrSel &sel, 
 
 // get_center / get_com: unweighted Bai-Breen estimate, then the (weighted) unwrapped mean
 int pbc_center_stages(gr_ctx *c, uint32_t first_slot, uint32_t nf, const GrSel &sel, int weighted, int only_status = 0) {
+    if (small_ok(c, sel) && only_status == 0) {   // a small selection: both stages of every frame in one launch, one wave per frame (gr_small.h)
+        k_center_small_pbc<<<dim3(nf), dim3(64), 0, c->stream>>>(c->frames, c->frame_stride, first_slot, c->masses, sel, c->boxes_dev, weighted, c->state_dev);
+        HIPCHK(c, hipGetLastError());
+        return GR_OK;
+    }
     int st = center_stage(c, first_slot, nf, sel, 1, 0, 0, 0, only_status);
     if (st != GR_OK) return st;
     return center_stage(c, first_slot, nf, sel, 2, weighted, 0, 1, only_status);

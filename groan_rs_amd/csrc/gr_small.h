@@ -101,6 +101,22 @@ __global__ __launch_bounds__(64) void k_center_small_stage(
     if (lane == 0) state[frame] = st;
 }
 
+// get_center / get_com of a batch of frames (pbc_center_stages, gr_api.hip): both stages of every frame in one launch, one wave per frame --
+// the same two stage functions in the same order as k_center_small below and as two k_center_small_stage launches
+__global__ __launch_bounds__(64) void k_center_small_pbc(
+    const float *__restrict__ frames, size_t frame_stride, uint32_t first_slot, const float *__restrict__ masses, GrSel sel,
+    const GrBox *__restrict__ boxes, int weighted, GrFrameState *state) {
+    __shared__ double lds_tot[GR_CEN_K];
+    const uint32_t lane = threadIdx.x, frame = blockIdx.x;
+    GrFrameState st = state[frame];
+    if (st.status != 0) return;
+    const GrBox &box = boxes[first_slot + frame];
+    const float *xyz = frames + (size_t)(first_slot + frame) * frame_stride;
+    gr_small_center_stage<1>(xyz, masses, sel, box, 0, 0, 0, st, lds_tot, lane, 0);                               // the unweighted estimate (iterators.rs:1405-1407)
+    if (__shfl(st.status, 0, 64) == 0) gr_small_center_stage<2>(xyz, masses, sel, box, weighted, 0, 1, st, lds_tot, lane, 0);
+    if (lane == 0) state[frame] = st;
+}
+
 // ONE frame, the whole centre in one dispatch, the result left in host-mapped memory (center_core, gr_api.hip):
 // kind 0 naive, 1 Bai-Breen estimate, 2 estimate + unwrapped mean (get_center / get_com) -- the same stages in the same order
 // (blockIdx.x = 1: the SECOND selection of a call that wants the centres of two groups of one frame -- group_distance, analysis.rs:348-360 --

@@ -48,15 +48,26 @@ def same(a, b, tol):
     return np.abs(np.asarray(a[1], np.float64) - np.asarray(b[1], np.float64)).max() <= tol
 
 
+def resultant(pos, idx, box, mass=None):
+    """shortest mean resultant of the Bai-Breen angles over the three axes (1 = a point, ~1 / sqrt(n) = spread over the whole cell): the
+    condition number of the centre estimate -- and of everything that unwraps about it -- is its inverse"""
+    b = np.asarray(box, np.float64)
+    H = np.array([[b[0], b[5], b[7]], [0.0, b[1], b[8]], [0.0, 0.0, b[2]]])          # columns a, b, c (gro order: xx yy zz xy xz yx yz zx zy)
+    f = np.linalg.solve(H, np.nan_to_num(pos[idx].astype(np.float64)).T).T
+    w = np.ones(len(idx)) if mass is None else np.nan_to_num(mass[idx].astype(np.float64), nan=1.0)
+    z = (w[:, None] * np.exp(2j * np.pi * f)).sum(0) / w.sum()
+    return float(np.abs(z).min())
+
+
 t_end = time.time() + budget
-cases = bad = small_total = 0
+cases = bad = small_total = ill = 0
 while time.time() < t_end:
     n = int(rng.integers(300, 20001))
     lengths, angles = CELLS[int(rng.integers(0, 3))]
     box = O.box_from_lengths_angles(lengths, angles)
     nf = int(rng.integers(1, 5))
     wide = rng.random() < 0.2                               # a blob wider than half the cell: the image proof fails, the frame is redone
-    spread = 1.6 if wide else float(rng.uniform(0.15, 0.55))
+    spread = float(rng.uniform(0.8, 1.6)) if wide else float(rng.uniform(0.15, 0.55))
     masses = rng.uniform(1.0, 16.0, n).astype(np.float32)
     kind_a, ia = draw_group(n)
     kind_b, ib = draw_group(n)
@@ -82,6 +93,13 @@ while time.time() < t_end:
     ref.group_create_from_indices("a", ia) if kind_a == "scattered" else ref.group_create_from_ranges("a", [(int(ia[0]), int(ia[-1]))])
     ok = True
     why = ""
+    # A group spread over the whole cell has a short resultant: its centre estimate -- and the images every later step chooses about it --
+    # turn on the last bits of the sums, in the reference's f32 loop as much as here.  Such a case (resultant < 0.05 on some axis in some
+    # frame) proves nothing about either path and is counted, not compared.
+    if min(min(resultant(frames[f], ia, box), resultant(frames[f], ia, box, masses), resultant(frames[f], ib, box)) for f in range(nf + 1)) < 0.05:
+        ill += 1
+        for x in (S, B, ref): x.close()
+        continue
     for f in range(nf):
         for fn in CENTRES:
             ra, rb = call(lambda: getattr(S, fn)("a", slot=f)), call(lambda: getattr(B, fn)("a", slot=f))
@@ -130,5 +148,5 @@ while time.time() < t_end:
         print("%s n=%d a=%s(%d) b=%s(%d) cell=%s frames=%d %s%s%s" % ("ok " if ok else "BAD", n, kind_a, ia.size, kind_b, ib.size, "/".join("%g" % x for x in angles), nf,
                                                                     "wide " if wide else "", "poisoned " if poison else "", why), flush=True)
     for x in (S, B, ref): x.close()
-print("%d cases, %d mismatches, %d calls answered by the single-wave kernels" % (cases, bad, small_total))
+print("%d cases, %d mismatches, %d calls answered by the single-wave kernels; %d ill-conditioned cases (a group spread over the whole cell) not compared" % (cases, bad, small_total, ill))
 sys.exit(1 if bad else 0)
