@@ -264,11 +264,7 @@ __device__ __forceinline__ void gr_center_atom(uint32_t i, float x, float y, flo
         // position.wrap(simbox): an atom inside the cell is left as it is (every stage's k is 0: the reference's loops do
         // not turn), so the closed form (~25 VALU slots per axis) only runs for the lanes that need it
         if (!(x >= 0.0f && x <= box.ax && y >= 0.0f && y <= box.by && z >= 0.0f && z <= box.cz)) gr_wrap(x, y, z, box);
-#ifdef GR_EXP_EST_ALWAYS_FRAC
-        {
-#else
         if (!box.ortho) {   // fractional ("u") coordinates, scaled by the box diagonal
-#endif
             // (z / cz and uy / by as reciprocal x one Newton correction: the quotient to within an ulp -- nearly always the
             // correctly rounded one -- in 3 instructions instead of the ~12 of an IEEE division; this branch has no reference
             // arithmetic to match, and the pass was VALU-bound on non-orthogonal cells: 3.5 us against 3.0)
