@@ -153,3 +153,15 @@ def test_comm_without_rccl_reports_no_device_instead_of_crashing(tmp_path):
         "print('ok')\n") % (ROOT, str(tmp_path / "no_such_rccl.so"))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.returncode, r.stdout[-300:], r.stderr[-600:])
+
+
+def test_tuning_and_stat_keys_of_the_python_mirror_are_the_header_s(G):
+    """gr_ctx_set_tuning / gr_ctx_stat take integer keys: the mirror's name -> key tables must be the header's enumerations, key by key
+    (a key added to one and not the other would silently tune something else)"""
+    txt = open(os.path.join(ROOT, "include", "groan_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    tune = {m.group(1).lower(): int(m.group(2)) for m in re.finditer(r"\bGR_TUNE_([A-Z0-9_]+)\s*=\s*(\d+)", txt)}
+    stat = {m.group(1).lower(): int(m.group(2)) for m in re.finditer(r"\bGR_STAT_([A-Z0-9_]+)\s*=\s*(\d+)", txt)}
+    assert len(tune) >= 18 and len(stat) >= 12
+    assert G.System.TUNE == tune, (sorted(set(G.System.TUNE.items()) ^ set(tune.items())))
+    assert G.System.STAT == stat, (sorted(set(G.System.STAT.items()) ^ set(stat.items())))
