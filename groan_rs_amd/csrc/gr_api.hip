@@ -1576,6 +1576,16 @@ static void batch_prechecks(gr_ctx *c, uint32_t s0, uint32_t nb, bool need_box, 
         if (s != GR_OK) msg[f] = c->err;
     }
 }
+// the frames' states of a batched call start from the host-side checks: zeroed by a kernel when every frame passed them (the usual
+// case), copied out of pinned memory otherwise -- that copy costs ~30 us of host time before the call's first kernel can be queued
+static int states_from_prechecks(gr_ctx *c, uint32_t nb, const std::vector<int> &pre) {
+    bool all_ok = true;
+    for (uint32_t f = 0; f < nb; ++f) all_ok = all_ok && pre[f] == GR_OK;
+    if (all_ok) return state_reset(c, nb);
+    for (uint32_t f = 0; f < nb; ++f) { GrFrameState z = {}; z.err_index = GR_NOIDX; z.status = pre[f]; c->state_host[f] = z; }
+    HIPCHK(c, hipMemcpyAsync(c->state_dev, c->state_host, nb * sizeof(GrFrameState), hipMemcpyHostToDevice, c->stream));
+    return GR_OK;
+}
 int gr_group_center_batch(gr_ctx *c, uint32_t first_slot, uint32_t n_frames, const char *group, int kind, int weighted, float *out, int *status_out) try {
     int st = slot_check(c, first_slot, n_frames); if (st) return st;
     (void)hipSetDevice(c->device);
@@ -1590,8 +1600,7 @@ int gr_group_center_batch(gr_ctx *c, uint32_t first_slot, uint32_t n_frames, con
         std::vector<int> pre; std::vector<std::string> msg;
         batch_prechecks(c, s0, nb, kind != GR_CENTER_NAIVE, pre, msg);
         SlotUse use(c, s0, nb);
-        for (uint32_t f = 0; f < nb; ++f) { GrFrameState z = {}; z.err_index = GR_NOIDX; z.status = pre[f]; c->state_host[f] = z; }
-        HIPCHK(c, hipMemcpyAsync(c->state_dev, c->state_host, nb * sizeof(GrFrameState), hipMemcpyHostToDevice, c->stream));
+        st = states_from_prechecks(c, nb, pre); if (st) return st;
         if (kind == GR_CENTER_NAIVE) st = center_stage(c, s0, nb, sel, 0, weighted, 0, 1);
         else if (kind == GR_CENTER_ESTIMATE) st = center_stage(c, s0, nb, sel, 1, weighted, 1, 1);
         else st = center_onepass_ok(c, sel) ? pbc_center_onepass(c, s0, nb, sel, weighted) : pbc_center_stages(c, s0, nb, sel, weighted);
@@ -1655,8 +1664,7 @@ static int translate_batch_api(gr_ctx *c, uint32_t first_slot, uint32_t n_frames
         std::vector<int> pre; std::vector<std::string> msg;
         batch_prechecks(c, s0, nb, true, pre, msg);
         SlotUse use(c, s0, nb);
-        for (uint32_t f = 0; f < nb; ++f) { GrFrameState z = {}; z.err_index = GR_NOIDX; z.status = pre[f]; c->state_host[f] = z; }
-        HIPCHK(c, hipMemcpyAsync(c->state_dev, c->state_host, nb * sizeof(GrFrameState), hipMemcpyHostToDevice, c->stream));
+        st = states_from_prechecks(c, nb, pre); if (st) return st;
         if (cg) { st = center_stage(c, s0, nb, make_sel(*cg), 1, weighted, 1, 0); if (st) return st; }   // group_estimate_center / _com per frame
         st = translate_batch(c, s0, nb, g, v, cg ? 1 : 2, cg ? mask[dim] : 7, pre, msg, status_out ? status_out + b0 : nullptr, first_err, first_msg, first_idx);
         if (st) return st;
