@@ -1364,12 +1364,12 @@ int gr_group_create_from_geometries(gr_ctx *c, uint32_t slot, const char *name, 
 /* ------------------------------------------------------------ translate / wrap / centre */
 // (check_state: the frame's state -- the centre estimate that precedes the translation on the stream -- is fetched with the same
 //  synchronisation, and its error, if any, comes first: the kernel has left such a frame alone)
-static int translate_core(gr_ctx *c, uint32_t slot, const Group &g, const float *v, int use_state, int dim_mask, bool check_state = false) {
+static int translate_core(gr_ctx *c, uint32_t slot, const Group &g, const float *v, int use_state, int dim_mask, bool check_state = false, bool bad_is_set = false) {
     int st = box_check(c, slot); if (st) return st;
     if (g.n == 0 && !check_state) return GR_OK;
     const GrSel sel = make_sel(g);
     SlotUse use(c, slot);
-    HIPCHK(c, hipMemsetAsync(c->bad_dev, 0xFF, 4 * sizeof(uint32_t), c->stream));
+    if (!bad_is_set) HIPCHK(c, hipMemsetAsync(c->bad_dev, 0xFF, 4 * sizeof(uint32_t), c->stream));
     const uint64_t units = sel.contiguous ? ((uint64_t)sel.n + 3) / 4 + 128 : (sel.masked & 2u) ? ((uint64_t)sel.span + 3) / 4 + 128 : sel.n;   // (4-atom groups of the block / of a masked selection's span; list entries)
     uint32_t nwg = (uint32_t)std::min<uint64_t>((units + GR_WG - 1) / GR_WG, 4096);
     k_translate_wrap<<<dim3(nwg), dim3(GR_WG), 0, c->stream>>>(c->frames + (size_t)slot * c->frame_stride, c->frame_stride, sel, c->boxes_dev + slot, c->state_dev, use_state, dim_mask, v ? v[0] : 0.f, v ? v[1] : 0.f, v ? v[2] : 0.f, c->bad_dev);
@@ -1381,10 +1381,10 @@ static int translate_core(gr_ctx *c, uint32_t slot, const Group &g, const float 
     if (c->bad_host[0] != GR_NOIDX) return fail(c, GR_E_NO_POSITION, "atom has no position", c->bad_host[0]);
     return GR_OK;
 }
-static int translate_impl(gr_ctx *c, uint32_t slot, const char *group, const float *v, int use_state, int dim_mask, bool check_state = false) {
+static int translate_impl(gr_ctx *c, uint32_t slot, const char *group, const float *v, int use_state, int dim_mask, bool check_state = false, bool bad_is_set = false) {
     const Group *g = find_group(c, group ? group : "all");
     if (!g) return fail(c, GR_E_GROUP_NOT_FOUND, group);
-    return translate_core(c, slot, *g, v, use_state, dim_mask, check_state);
+    return translate_core(c, slot, *g, v, use_state, dim_mask, check_state, bad_is_set);
 }
 
 int gr_group_translate(gr_ctx *c, uint32_t slot, const char *group, const float v[3]) try {
@@ -1409,8 +1409,16 @@ int gr_atoms_center(gr_ctx *c, uint32_t slot, const char *ref_group, int dim, in
     if (dim < 0 || dim > 7) return fail(c, GR_E_INVALID_ARG, "bad dimension");
     static const int mask[8] = { 0, 1, 2, 4, 3, 5, 6, 7 };
     { SlotUse use(c, slot); }   // the estimate below and translate_impl each bracket themselves; this orders a pending upload first
+    const GrSel csel = make_sel(*g);
+    if (small_ok(c, csel)) {
+        // a small reference group: its single-wave estimate starts the frame's state itself and sets the translate kernel's words -- two
+        // dispatches (estimate, translation) instead of four
+        k_center_small_stage<<<dim3(1), dim3(64), 0, c->stream>>>(c->frames, c->frame_stride, slot, c->masses, csel, c->boxes_dev, 1, weighted, 1, 0, c->state_dev, 0, c->bad_dev);
+        HIPCHK(c, hipGetLastError());
+        return translate_impl(c, slot, "all", nullptr, 1, mask[dim], true, true);
+    }
     st = state_reset(c, 1); if (st) return st;
-    st = center_stage(c, slot, 1, make_sel(*g), 1, weighted, 1, 0); if (st) return st;   // group_estimate_center / _com
+    st = center_stage(c, slot, 1, csel, 1, weighted, 1, 0); if (st) return st;   // group_estimate_center / _com
     // (the translation follows the estimate on the stream and leaves the frame alone when the estimate failed: ONE synchronisation for
     //  both, the estimate's error reported first)
     return translate_impl(c, slot, "all", nullptr, 1, mask[dim], true);

@@ -87,10 +87,14 @@ __device__ __forceinline__ void gr_small_center_stage(const float *__restrict__ 
 // calls bit for bit" (tests/test_gpu_batch_calls.py) keeps holding
 __global__ __launch_bounds__(64) void k_center_small_stage(
     const float *__restrict__ frames, size_t frame_stride, uint32_t first_slot, const float *__restrict__ masses, GrSel sel,
-    const GrBox *__restrict__ boxes, int kind, int weighted, int mass_first, int target, GrFrameState *state, int only_status) {
+    const GrBox *__restrict__ boxes, int kind, int weighted, int mass_first, int target, GrFrameState *state, int only_status,
+    uint32_t *__restrict__ fresh_bad = nullptr /* one-frame gr_atoms_center: the state starts fresh HERE (no reset launch before this one) and the
+                                                  translate kernel's "first atom without position" words are set for it (no memset launch) */) {
     __shared__ double lds_tot[GR_CEN_K];
     const uint32_t lane = threadIdx.x, frame = blockIdx.x;
-    GrFrameState st = state[frame];
+    GrFrameState st = {};
+    if (fresh_bad) { st.err_index = GR_NOIDX; if (lane < 4u) fresh_bad[4 * frame + lane] = GR_NOIDX; }
+    else st = state[frame];
     if (st.status != only_status) return;             // an earlier stage of this frame already failed / not one of the frames asked for
     const GrBox &box = boxes[first_slot + frame];
     const float *xyz = frames + (size_t)(first_slot + frame) * frame_stride;
