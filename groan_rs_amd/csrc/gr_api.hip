@@ -1815,9 +1815,13 @@ int gr_ctx_set_tuning(gr_ctx *c, int key, int64_t value) try {
 // multi-pass exact path for `nf` frames starting at first_slot; states [0, nf) must be reset by the caller
 static int rmsd_exact(gr_rmsd_plan *p, gr_ctx *c, const GrSel &sel, uint32_t first_slot, uint32_t nf, int fit) {
     int st = pbc_center_stages(c, first_slot, nf, sel, 1); if (st) return st;
-    const uint32_t nch = chunks_for(sel);
-    k_rmsd_accum<1><<<dim3(nch, nf), dim3(GR_WG), 0, c->stream>>>(c->frames, c->frame_stride, first_slot, c->masses, sel, c->boxes_dev, p->dev, c->state_dev, c->acc_partials);
-    k_rmsd_finalize<1><<<dim3(nf), dim3(GR_WG), 0, c->stream>>>(c->acc_partials, nch, c->frames, c->frame_stride, first_slot, sel, c->boxes_dev, p->dev, c->state_dev);
+    if (small_ok(c, sel)) {   // a small selection: sums and closing step of every frame by one wave (gr_small.h), as its centre stages above
+        k_rmsd_small<1><<<dim3(nf), dim3(64), 0, c->stream>>>(c->frames, c->frame_stride, first_slot, c->masses, sel, c->boxes_dev, p->dev, c->state_dev, 1, nullptr, nullptr, 0u);
+    } else {
+        const uint32_t nch = chunks_for(sel);
+        k_rmsd_accum<1><<<dim3(nch, nf), dim3(GR_WG), 0, c->stream>>>(c->frames, c->frame_stride, first_slot, c->masses, sel, c->boxes_dev, p->dev, c->state_dev, c->acc_partials);
+        k_rmsd_finalize<1><<<dim3(nf), dim3(GR_WG), 0, c->stream>>>(c->acc_partials, nch, c->frames, c->frame_stride, first_slot, sel, c->boxes_dev, p->dev, c->state_dev);
+    }
     if (fit) {
         const uint32_t gx = (uint32_t)std::min<uint64_t>(((c->n >> 2) + GR_WG * 4 - 1) / (GR_WG * 4) + 1, 1024);
         k_fit_pk<false><<<dim3(gx, nf), dim3(GR_WG), 0, c->stream>>>(c->frames, c->frame_stride, first_slot, (uint32_t)c->n, c->boxes_dev, p->dev, c->state_dev, c->masses, sel, nullptr);
@@ -1868,7 +1872,7 @@ static int segment_begin(gr_rmsd_plan *p, uint32_t s0, uint32_t nb, int fit) {
         // host does not wait for that one (the rmsd is known; whatever touches the slot next is ordered behind it).  Everything after
         // the wait -- the redo of a frame whose image proof failed included -- is segment_end's usual way.
         q.small = true; q.small_seq = ++c->small_seq;
-        k_rmsd_small<<<dim3(1), dim3(64), 0, c->stream>>>(c->frames, c->frame_stride, s0, c->masses, sel, c->boxes_dev, p->dev,
+        k_rmsd_small<0><<<dim3(1), dim3(64), 0, c->stream>>>(c->frames, c->frame_stride, s0, c->masses, sel, c->boxes_dev, p->dev,
                                                          c->state_dev, 0, c->small_state_dev, c->small_flag_dev, q.small_seq);
         if (fit) k_fit_pk<false><<<dim3(fit_grid(c, 1), 1), dim3(GR_WG), 0, c->stream>>>(c->frames, c->frame_stride, s0, (uint32_t)c->n, c->boxes_dev, p->dev, c->state_dev, c->masses, sel, nullptr);
         HIPCHK(c, hipGetLastError());
@@ -1889,7 +1893,7 @@ static int segment_begin(gr_rmsd_plan *p, uint32_t s0, uint32_t nb, int fit) {
     int st;
     if (small) {
         // ... and a batch of frames of such a selection: the same kernel, one wave per frame (a batch equals its per-frame calls bit for bit)
-        k_rmsd_small<<<dim3(nb), dim3(64), 0, c->stream>>>(c->frames, c->frame_stride, s0, c->masses, sel, c->boxes_dev, p->dev, c->state_dev, 1, nullptr, nullptr, 0u);
+        k_rmsd_small<0><<<dim3(nb), dim3(64), 0, c->stream>>>(c->frames, c->frame_stride, s0, c->masses, sel, c->boxes_dev, p->dev, c->state_dev, 1, nullptr, nullptr, 0u);
         if (fit) k_fit_pk<false><<<dim3(fit_grid(c, nb), nb), dim3(GR_WG), 0, c->stream>>>(c->frames, c->frame_stride, s0, (uint32_t)c->n, c->boxes_dev, p->dev, c->state_dev, c->masses, sel, nullptr);
         HIPCHK(c, hipGetLastError());
     } else if (!q.consistent) {

@@ -148,6 +148,10 @@ __global__ __launch_bounds__(64) void k_center_small(
 // RMSD without fit of a small selection (calc_rmsd, rmsd.rs:75-129,141-166): k_rmsd_accum<0> + k_rmsd_finalize<0> by one wave
 // (one wave per frame of the segment; have_state: the frames' states were initialised with the host-side checks -- a frame that failed
 //  them is left alone; state_host / flag_host: the one-frame call's mapped record, NULL for a batch, whose states are fetched as usual)
+// MODE 0: the closed-form single pass (k_rmsd_accum<0> + k_rmsd_finalize<0>); MODE 1: the literal sums about the frame's own COM, whose
+// shift the centre stages have left in the state (k_rmsd_accum<1> + k_rmsd_finalize<1>: the redo of a frame whose image proof failed,
+// rmsd_exact in gr_api.hip) -- have_state is then always set
+template <int MODE>
 __global__ __launch_bounds__(64) void k_rmsd_small(
     const float *__restrict__ frames, size_t frame_stride, uint32_t first_slot, const float *__restrict__ masses, GrSel sel,
     const GrBox *__restrict__ boxes, GrPlanDev plan, GrFrameState *state_dev, int have_state, GrFrameState *state_host, uint32_t *flag_host, uint32_t seq) {
@@ -155,7 +159,9 @@ __global__ __launch_bounds__(64) void k_rmsd_small(
     __shared__ float lds_ext[16];
     const uint32_t lane = threadIdx.x, frame = blockIdx.x, slot = first_slot + frame;
     state_dev += frame;
-    if (have_state && state_dev->status != 0) return;
+    GrFrameState st0 = {};
+    st0.err_index = GR_NOIDX;
+    if (have_state) { st0 = *state_dev; if (st0.status != 0) return; }
     const GrBox &box = boxes[slot];
     const float *xyz = frames + (size_t)slot * frame_stride;
     GrLaneAcc L;
@@ -163,6 +169,7 @@ __global__ __launch_bounds__(64) void k_rmsd_small(
     GrFrameConst fc;
     gr_pos_load(xyz, sel.contiguous ? sel.start : sel.idx[0], fc.gx, fc.gy, fc.gz);
     fc.sx = fc.sy = fc.sz = 0.f;
+    if (MODE == 1) { fc.sx = st0.shift[0]; fc.sy = st0.shift[1]; fc.sz = st0.shift[2]; }
     fc.iax = box.iax; fc.iby = box.iby; fc.icz = box.icz;
     fc.rws2 = box.r_ws * box.r_ws;
     fc.tric = !box.ortho;
@@ -200,7 +207,7 @@ __global__ __launch_bounds__(64) void k_rmsd_small(
                 q.w[0] = ww[t].x; q.w[1] = ww[t].y; q.w[2] = ww[t].z; q.w[3] = ww[t].w;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) { q.i[k] = i + k; q.ok[k] = (i + k >= first) && (i + k < last); }
-                if (i >= first && i + 3 < last) gr_flush4<0>(L, q, false, box, fc); else gr_flush4<0>(L, q, true, box, fc);
+                if (MODE == 0 && i >= first && i + 3 < last) gr_flush4<MODE>(L, q, false, box, fc); else gr_flush4<MODE>(L, q, true, box, fc);
             }
         }
     } else {
@@ -217,7 +224,7 @@ __global__ __launch_bounds__(64) void k_rmsd_small(
                 gr_pos_load(plan.p, jj, t.px[q], t.py[q], t.pz[q]);
                 t.w[q] = wm ? t.m[q] : plan.w[jj];
             }
-            if (j4 * 4 + 3 < sel.n) gr_flush4<0>(L, t, false, box, fc); else gr_flush4<0>(L, t, true, box, fc);
+            if (MODE == 0 && j4 * 4 + 3 < sel.n) gr_flush4<MODE>(L, t, false, box, fc); else gr_flush4<MODE>(L, t, true, box, fc);
         }
     }
     L.close(wm);
@@ -233,15 +240,14 @@ __global__ __launch_bounds__(64) void k_rmsd_small(
     if ((lane & 3u) == 0u) lds_ext[lane >> 2] = em;
     gr_wave_sync();
     if (lane == 0) {
-        GrFrameState st = {};
-        st.err_index = GR_NOIDX;
+        GrFrameState st = st0;
         double acc[GR_ACC_K];
 #pragma unroll
         for (int k = 0; k < GR_ACC_K; ++k) acc[k] = lds_tot[k];
         const float mn[3] = { -lds_ext[0], -lds_ext[1], -lds_ext[2] }, mx[3] = { lds_ext[3], lds_ext[4], lds_ext[5] };
         const float fmn[3] = { -lds_ext[6], -lds_ext[7], -lds_ext[8] }, fmx[3] = { lds_ext[9], lds_ext[10], lds_ext[11] };
         const double g[3] = { fc.gx, fc.gy, fc.gz };
-        gr_finalize_math<0>(acc, mn, mx, fmn, fmx, bad_pos, bad_mass, box, plan, g, sel.n, st);
+        gr_finalize_math<MODE>(acc, mn, mx, fmn, fmx, bad_pos, bad_mass, box, plan, g, sel.n, st);
         if (state_host) gr_small_publish(st, state_dev, state_host, flag_host, seq); else *state_dev = st;
     }
 }
