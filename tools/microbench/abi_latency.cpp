@@ -5,15 +5,17 @@
 #include "groan_hip.h"
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <random>
 #include <vector>
 static double now() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
-int main() {
+int main(int argc, char **argv) {
+    const float sigma = argc > 1 ? (float)atof(argv[1]) : 0.3f;   // spread of the group (nm): 0.6 makes it wider than half the cell -- the image proof fails, every RMSD call takes the literal redo
     const uint64_t n = 32817;
     int st = 0;
     gr_ctx *cur = gr_ctx_create(0, n, 2, &st), *ref = gr_ctx_create(0, n, 1, &st);
     if (!cur || !ref) { printf("no context: %d\n", st); return 1; }
-    std::mt19937 rng(7); std::normal_distribution<float> g(0.f, 0.3f); std::uniform_real_distribution<float> u(1.f, 16.f);
+    std::mt19937 rng(7); std::normal_distribution<float> g(0.f, sigma); std::uniform_real_distribution<float> u(1.f, 16.f);
     std::vector<float> m(n), x0(3 * n), x1(3 * n);
     const float box9[9] = { 6.44f, 6.76f, 7.26f, 0, 0, 0, 0, 0, 0 };
     for (uint64_t i = 0; i < n; ++i) { m[i] = u(rng); for (int a = 0; a < 3; ++a) { x0[3 * i + a] = 3.2f + g(rng); x1[3 * i + a] = x0[3 * i + a] + 0.05f * g(rng); } }
