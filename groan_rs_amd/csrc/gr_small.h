@@ -13,7 +13,10 @@
 // device copy and to the host-mapped copy, fences at system scope and publishes the call's sequence number; the host spins on that
 // word (and falls back to hipStreamSynchronize when it does not come).  By then the kernel has nothing left to do: everything it
 // read it has read, everything it writes it has written.
-// Per-atom arithmetic is the batched kernels' own (gr_center_atom, gr_flush4<0>); only the order of the fp64 additions differs.
+// Per-atom arithmetic is the batched kernels' own (gr_center_atom, gr_flush4); only the order of the fp64 additions differs -- so
+// EVERY path of a small selection goes through these waves (centre stages of batches and of atoms_center, RMSD batches, the literal redo of
+// a frame whose image proof failed: k_center_small_stage / _pbc, k_rmsd_small<0 / 1> with one wave per frame), and a batch keeps
+// equalling its per-frame calls bit for bit.
 #pragma once
 #include "gr_kernels.h"
 
