@@ -59,6 +59,8 @@ def main():
                     "to this process); a second figure at 16 threads (one GPU's share of the node) is always reported")
     ap.add_argument("--cpu-max-frames", type=int, default=256, help="upper bound on the CPU sample (frames)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-live-floor", action="store_true", help="do not run the arithmetic-free copy probe (tools/bin/ceiling_resident) beside the "
+                    "result; implied under a profiler (ROCPROF* / ROCP_* variables or an LD_PRELOAD are inherited by the child)")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE", help="gr_ctx_set_tuning (sub_batch, chunks, fit_wgs, fuse, "
                     "two_pass): launch-geometry sweeps; the defaults are the measured optimum")
     ap.add_argument("--gather", choices=["torch", "abi"], default="torch", help="final gather of the per-frame RMSDs at N > 1: torch.distributed "
@@ -71,6 +73,17 @@ def main():
     args = ap.parse_args()
     if args.cpu_baseline_child:
         return cpu_baseline_child(args.cpu_baseline_child)
+
+    # --gpus N means N ranks.  Under a launcher (WORLD_SIZE set) the two must agree; without one, `python bench.py --gpus N` starts the
+    # N ranks itself -- fresh child processes of python -m torch.distributed.run, started BEFORE this process makes any GPU call -- and
+    # only relays rank 0's line and the launcher's return code.
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return launch_ranks(args.gpus)
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        print("bench.py: --gpus %d but WORLD_SIZE=%s: the rank count is the launcher's; run\n  python -m torch.distributed.run --nnodes=1 "
+              "--nproc-per-node %d --master-addr 127.0.0.1 --master-port P bench.py --gpus %d ...\nor plain `python bench.py --gpus %d` "
+              "(which starts the ranks itself)" % (args.gpus, os.environ.get("WORLD_SIZE"), args.gpus, args.gpus, args.gpus), file=sys.stderr)
+        return 2
 
     # stdout carries exactly ONE JSON line: everything else any library prints there (RCCL prints a version banner on
     # init) is sent to stderr by pointing fd 1 at fd 2 until the result is written to the saved descriptor
@@ -273,12 +286,16 @@ def main():
     # It is a probe, not a bound: from box to box it reads 4.3-4.65 us per 1e6-atom frame while the pass itself stays at 4.32-4.35,
     # so the ratio may exceed 1 (a copy issues its loads and stores in bursts; the pass spreads them over its arithmetic).  Never fatal.
     copy_floor_live = None
-    if rank == 0 and dom == "k_fit_resident":
+    profiled = bool(os.environ.get("LD_PRELOAD")) or any(k.startswith(("ROCP_", "ROCPROF", "ROCPROFILER_")) for k in os.environ)
+    if rank == 0 and dom == "k_fit_resident" and not args.no_live_floor and not profiled:
         try:
             exe = os.path.join(ROOT, "tools", "bin", "ceiling_resident")
             if os.path.isfile(exe):
+                # the child sees exactly this rank's device: index `dev` of the list this process was given (itself possibly a restriction)
+                vis = [v for v in os.environ.get("HIP_VISIBLE_DEVICES", "").split(",") if v != ""]
+                child_dev = vis[dev] if dev < len(vis) else str(dev)
                 cp = subprocess.run([exe, "--quick", str(n), str(int(frames / max(launches, 1)))], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=120,
-                                    env=dict(os.environ, HIP_VISIBLE_DEVICES=os.environ.get("HIP_VISIBLE_DEVICES", str(dev)) if world == 1 else str(dev)))
+                                    env=dict(os.environ, HIP_VISIBLE_DEVICES=child_dev))
                 line = [ln for ln in cp.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]
                 if cp.returncode == 0 and line:
                     copy_floor_live = json.loads(line[-1])
@@ -364,7 +381,7 @@ def main():
                 shutil.rmtree(tmpdir, ignore_errors=True)
     # what the resident pass did on every rank (ranks that share a device take turns on it or fall back to the two passes: gr_resident.h)
     res_stats = {}
-    for k in ("res_launches", "res_handshake_misses", "res_aborts", "res_redone_frames", "res_last_streams"):
+    for k in ("res_launches", "res_handshake_misses", "res_aborts", "res_redone_frames", "res_last_streams", "res_metro_period_ns", "res_last_turn_ns", "res_late_permille", "res_sclk_mhz"):
         try:
             res_stats[k] = cur.stat(k)
         except Exception:                         # (an older build of the library under GR_LIB_PATH: A/B runs)
@@ -388,6 +405,27 @@ def main():
     plan.close(); ref.close(); cur.close()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def launch_ranks(n_ranks):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as the driver would (one process per GPU, rendezvous on
+    127.0.0.1) and relay rank 0's JSON line.  This process has made no GPU call and makes none: the ranks are children, not an exec."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    child = subprocess.run(cmd, stdout=subprocess.PIPE, env=env)
+    lines = [ln for ln in child.stdout.decode(errors="replace").splitlines() if ln.startswith("{") and '"metric"' in ln]
+    for ln in lines[-1:]:
+        sys.stdout.write(ln + "\n")
+    sys.stdout.flush()
+    if child.returncode != 0:
+        return child.returncode
+    return 0 if len(lines) == 1 else 3
 
 
 def usable_cores():

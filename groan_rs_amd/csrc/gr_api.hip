@@ -99,6 +99,13 @@ struct gr_ctx {
     int res_streams = 0;              // GR_TUNE_RESIDENT_STREAMS 0 automatic, 1..GR_RES_MAX_STREAMS: at most so many frame streams per resident launch
     int res_fill16 = 10;              // GR_TUNE_RESIDENT_FILL: sixteenths of the chip the streaming workgroups must fill for the pass to be chosen (resident = 1)
     uint32_t res_last_streams = 0;    // frame streams of the last resident launch (gr_ctx_stat)
+    // the resident pass's metronome (gr_resident.h): GR_TUNE_RESIDENT_METRO_NS 0 = the controller below, 1 = off, else a fixed period.
+    // The controller keeps, per launch shape, the shortest period the launches have KEPT (a turn took no longer than the period and
+    // next to no slot was reached late); it starts from a free-running launch, probes downwards 1.5 % at a time, steps back to the
+    // best kept period when a probe fails, and switches the clock off for a shape whose free-running turn it cannot beat.
+    int res_metro_ns = 0;
+    struct Metro { uint64_t shape = 0; double free_ns = 0, T_ns = 0, best_ns = 0, fail_ns = 0; uint32_t off_for = 0, held = 0; } metro;
+    uint64_t res_metro_period_ns = 0, res_last_turn_ns = 0, res_late_permille = 0, res_sclk_mhz = 0;   // gr_ctx_stat: the last resident launch
     int wall_khz = 100000;            // rate of the device's wall_clock64() (hipDeviceAttributeWallClockRate)
     uint32_t res_max_wgs = 0;         // workgroups of k_fit_resident the device holds at once (0: the pass cannot run here)
     int res_test_no_start = 0;        // GR_TUNE_TEST_RESIDENT_NO_START (tests): the next resident launch finds its start verdict already "never started"
@@ -166,6 +173,7 @@ struct gr_ctx {
 
 struct Pending {   // a segment between gr_rmsd_batch_begin and gr_rmsd_batch_end
     bool active = false, any_ok = false, consistent = true, fused = false, resident = false, rmsd_fast = false;
+    uint32_t res_metro_ns = 0; bool res_metro_auto = false;   // (resident launch: the metronome period it ran with; chosen by the controller?)
     uint32_t s0 = 0, nb = 0, n_prof_groups = 0, res_stream = 0, res_streams = 1;   // (resident launch: streaming workgroups, frame streams)
     int fit = 0;
     std::vector<int> pre;
@@ -748,9 +756,9 @@ gr_ctx *gr_ctx_create(int device, uint64_t n_atoms, uint32_t n_slots, int *statu
     ok = ok && hipMalloc(&c->bad_dev, 4 * GR_MAX_BATCH * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipHostMalloc(&c->bad_host, 4 * GR_MAX_BATCH * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess;
     ok = ok && hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess;
-    ok = ok && hipMalloc(&c->res_abort, 4 * sizeof(uint32_t)) == hipSuccess;
-    ok = ok && hipHostMalloc(&c->res_words_host, 4 * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess;
-    ok = ok && hipMemset(c->res_abort, 0, 4 * sizeof(uint32_t)) == hipSuccess;
+    ok = ok && hipMalloc(&c->res_abort, 96 * sizeof(uint32_t)) == hipSuccess;
+    ok = ok && hipHostMalloc(&c->res_words_host, 16 * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipMemset(c->res_abort, 0, 96 * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipMalloc(&c->res_rec, (size_t)GR_MAX_BATCH * 16 * sizeof(unsigned long long)) == hipSuccess;
     ok = ok && hipMemset(c->res_rec, 0, (size_t)GR_MAX_BATCH * 16 * sizeof(unsigned long long)) == hipSuccess;
     ok = ok && hipMalloc(&c->res_progress, (size_t)GR_MAX_CHUNKS * 8 * sizeof(uint32_t)) == hipSuccess;
@@ -1781,6 +1789,10 @@ int gr_ctx_stat(const gr_ctx *c, int key, uint64_t *value) {
     case GR_STAT_XTC_DEVICE_FRAMES: *value = c->xtc_dev_frames; return GR_OK;
     case GR_STAT_SMALL_CALLS: *value = c->small_calls; return GR_OK;
     case GR_STAT_SMALL_SYNC_FALLBACKS: *value = c->small_sync_fallbacks; return GR_OK;
+    case GR_STAT_RES_METRO_PERIOD_NS: *value = c->res_metro_period_ns; return GR_OK;
+    case GR_STAT_RES_LAST_TURN_NS: *value = c->res_last_turn_ns; return GR_OK;
+    case GR_STAT_RES_LATE_PERMILLE: *value = c->res_late_permille; return GR_OK;
+    case GR_STAT_RES_SCLK_MHZ: *value = c->res_sclk_mhz; return GR_OK;
     default: return GR_E_INVALID_ARG;
     }
 }
@@ -1803,6 +1815,7 @@ int gr_ctx_set_tuning(gr_ctx *c, int key, int64_t value) try {
     case GR_TUNE_PAIRDIST_SYMMETRIC: if (value != 0 && value != 1) break; c->pd_sym = (int)value; return GR_OK;
     case GR_TUNE_RESIDENT_WG_GROUPS: if (value != 0 && (value < 64 || value > GR_RES_GROUPS || value % 64 != 0)) break; c->res_wg_groups = (int)value; return GR_OK;
     case GR_TUNE_RESIDENT_STREAMS: if (value < 0 || value > GR_RES_MAX_STREAMS) break; c->res_streams = (int)value; return GR_OK;
+    case GR_TUNE_RESIDENT_METRO_NS: if (value < 0 || value > 1000000 || (value > 1 && value < 100)) break; c->res_metro_ns = (int)value; c->metro = gr_ctx::Metro(); return GR_OK;
     case GR_TUNE_RESIDENT_FILL: if (value < 1 || value > 16) break; c->res_fill16 = (int)value; return GR_OK;
     case GR_TUNE_RESIDENT_GROUPS: if (value != 2) break; return GR_OK;   // (the one-group shape was removed: gr_resident.h)
     case GR_TUNE_TEST_RESIDENT_NO_START: c->res_test_no_start = value ? 1 : 0; return GR_OK;
@@ -1965,6 +1978,22 @@ static int segment_begin(gr_rmsd_plan *p, uint32_t s0, uint32_t nb, int fit) {
             ctl.team_waves = resident_team_waves(res_wgs, res_streams);
             ctl.patience_ticks = (unsigned long long)c->wall_khz * 3000ull; ctl.start_ticks = (unsigned long long)c->wall_khz * 200ull;   // 3 s, 0.2 s
             ctl.test_abort_frame = c->res_test_abort_at; c->res_test_abort_at = 0xFFFFFFFFu;
+            {   // the metronome's period for this launch
+                const uint64_t shape = ((uint64_t)res_wgs << 40) ^ ((uint64_t)res_streams << 32) ^ ((uint64_t)res_gwg << 16) ^ (uint64_t)(c->n & 0xFFFF) ^ ((uint64_t)(sel.start == 0 && sel.n == c->n) << 63);
+                uint32_t period_ns = 0;
+                q.res_metro_auto = false;
+                if (c->res_metro_ns >= 100) period_ns = (uint32_t)c->res_metro_ns;
+                else if (c->res_metro_ns == 0) {
+                    gr_ctx::Metro &m = c->metro;
+                    if (m.shape != shape) { m = gr_ctx::Metro(); m.shape = shape; }
+                    if (m.off_for) m.off_for--;
+                    else if (m.free_ns > 0) period_ns = (uint32_t)(m.T_ns + 0.5);
+                    q.res_metro_auto = true;
+                }
+                q.res_metro_ns = period_ns;
+                ctl.metro_t16 = (uint32_t)std::min<uint64_t>(0xFFFFFFFFull, (uint64_t)period_ns * (uint64_t)c->wall_khz * 16ull / 1000000ull);
+                ctl.metro_lead = (uint32_t)((uint64_t)c->wall_khz * 2000ull / 1000000ull);   // 2 us
+            }
 #ifdef GR_EXP_TIMELINE
             // experiment (tools/timeline_bench.sh): device-clock stamps of every frame's way through the launch
             {
@@ -2004,7 +2033,7 @@ static int segment_begin(gr_rmsd_plan *p, uint32_t s0, uint32_t nb, int fit) {
                 HIPCHK(c, hipGetLastError());
                 // (the launch's control words follow it on the stream into pinned memory: segment_end reads them after its one synchronisation
                 //  instead of fetching them with a blocking copy of their own -- 15-25 us per call)
-                HIPCHK(c, hipMemcpyAsync(c->res_words_host, c->res_abort, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, S));
+                HIPCHK(c, hipMemcpyAsync(c->res_words_host, c->res_abort, 12 * sizeof(uint32_t), hipMemcpyDeviceToHost, S));
                 q.resident = true; q.res_stream = res_stream; q.res_streams = res_streams;
                 q.rmsd_fast = false;                    // (the pass closes its frames with the fit's own sum: nothing to hand back)
                 c->res_last_streams = res_streams;
@@ -2155,6 +2184,54 @@ static int segment_end(gr_rmsd_plan *p, float *rmsd_out, int *status_out, float 
                 }
             } else {
                 c->res_launches++;
+#ifdef GR_EXP_STEPTIME
+                if (getenv("GR_STEPTIME")) {
+                    unsigned long long st[32];
+                    if (hipMemcpy(st, c->res_abort + 16, sizeof st, hipMemcpyDeviceToHost) == hipSuccess) {
+                        const double turns_ = (double)((nb + q.res_streams - 1) / q.res_streams + GrResShape::K);
+                        const char *who[4] = { "wg 0 wave 0", "wg 0 wave 5", "wg mid wave 0", "wg mid wave 5" };
+                        for (int w = 0; w < 4; ++w) {
+                            fprintf(stderr, "steptime %-14s ticks/turn:", who[w]);
+                            double tot = 0; for (int k = 0; k < 7; ++k) tot += (double)st[w * 8 + k];
+                            const char *nm[7] = { "gate", "request", "rows+sums", "reduce+handover", "record wait", "fit+stores", "park" };
+                            for (int k = 0; k < 7; ++k) fprintf(stderr, " %s %.0f", nm[k], (double)st[w * 8 + k] / turns_);
+                            fprintf(stderr, " | total %.0f | polled %.0f %% of fits\n", tot / turns_, 100.0 * (double)st[w * 8 + 7] / turns_);
+                        }
+                    }
+                }
+#endif
+                // what the launch says about its own pace (device clock): first slot -> the last streaming wave's exit, over its turns
+                // (+ the six turns a frame waits on chip), and how many of its metronome slots were reached late
+                unsigned long long t0 = 0, t1 = 0;
+                memcpy(&t0, c->res_words_host + 4, 8); memcpy(&t1, c->res_words_host + 6, 8);
+                const uint32_t turns = (nb + q.res_streams - 1) / q.res_streams;
+                const double turn_ns = (t1 > t0 && turns) ? (double)(t1 - t0) * 1.0e6 / (double)c->wall_khz / (double)(turns + GrResShape::K) : 0.0;
+                const uint64_t slots = (uint64_t)q.res_stream * GrResShape::WAVES * turns;
+                const uint64_t late_pm = slots ? (uint64_t)c->res_words_host[8] * 1000ull / slots : 0;
+                c->res_metro_period_ns = q.res_metro_ns; c->res_last_turn_ns = (uint64_t)(turn_ns + 0.5); c->res_late_permille = late_pm;
+                c->res_sclk_mhz = c->res_words_host[11] ? (uint64_t)((double)c->res_words_host[10] / (double)c->res_words_host[11] * (double)c->wall_khz / 1000.0 + 0.5) : 0;
+                if (q.res_metro_auto && turns >= 64 && turn_ns > 0.0) {
+                    gr_ctx::Metro &m = c->metro;
+                    const double T = (double)q.res_metro_ns;
+                    if (q.res_metro_ns == 0) {
+                        if (!m.off_for) {                            // a free-running launch: the figure to beat (the first probe asks for 3 % less)
+                            m.free_ns = m.free_ns > 0 ? std::min(m.free_ns, turn_ns) : turn_ns;
+                            if (m.T_ns == 0) m.T_ns = m.free_ns * 0.97;
+                        }
+                    } else if (turn_ns <= T * 1.012 && late_pm < 50) {   // kept: remember it, probe on unless a period this short has failed
+                        m.best_ns = m.best_ns > 0 ? std::min(m.best_ns, T) : T;
+                        const double next = T * 0.985;
+                        if (m.fail_ns == 0 || next > m.fail_ns * 1.004) m.T_ns = next;
+                        else if (++m.held >= 64) { m.held = 0; m.fail_ns *= 0.995; }   // (conditions drift: let an old failure fade)
+                    } else {                                          // not kept: back to the best kept period, or up
+                        m.fail_ns = std::max(m.fail_ns, T);
+                        m.T_ns = m.best_ns > T ? m.best_ns : T * 1.02;
+                        if (m.best_ns > 0 && m.best_ns <= T) m.best_ns = 0;      // (what was kept once is not kept any more)
+                        if (m.T_ns >= m.free_ns * 0.995) {           // the clock buys nothing for this shape (it is not bound by memory): off for a while
+                            m.off_for = 512; m.free_ns = 0; m.T_ns = 0; m.best_ns = 0; m.fail_ns = 0;
+                        }
+                    }
+                }
             }
             if (c->profile) {
                 float ms = 0.f;

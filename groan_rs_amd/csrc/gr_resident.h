@@ -136,8 +136,11 @@ struct GrResShape {
 struct GrResCtl {
     unsigned long long *wgrec;     // [frames][n_stream padded][32] value | epoch << 32
     unsigned long long *rec;       // [frames][16] value | epoch << 32: 0 status, 1..3 shift, 4..12 R (column-major), 13..15 t0 = -R (COM - first atom)
-    uint32_t *abort;               // [3]: 0 abort (0 = fine), 1 workgroups that have started, 2 start verdict (0 open, 1 go, 2 never started);
-                                   // words 1 and 2 are zeroed by the host before every launch
+    uint32_t *abort;               // [12]: 0 abort (0 = fine), 1 workgroups that have started, 2 start verdict (0 open, 1 go, 2 never started);
+                                   // 4-5 the metronome's origin t0 (device clock, written by the workgroup that opens the launch), 6-7 the clock
+                                   // when the last streaming wave left, 8 slots that waves reached late, 9 slots they waited for;
+                                   // 10, 11 shader-clock and device-clock ticks (/ 256) of workgroup 0's walk;
+                                   // words 1 .. 9 are zeroed by the host before every launch
     uint32_t *progress;            // [n_stream][8]: turns (frames of its stream) each streaming wave had been through when it left
     uint32_t epoch, n_stream, n_fin;   // n_stream = streams x wgs_frame streaming workgroups, then n_fin finalizers
     uint32_t wgs_frame, streams;   // workgroups one frame needs; frame streams the launch runs side by side (stream s: frames s, s + streams, ...)
@@ -145,6 +148,8 @@ struct GrResCtl {
     uint32_t team_waves;           // waves of a finalizer workgroup that close one frame together: 1, 2, 4 or 8 with 32 x that >= wgs_frame
     unsigned long long patience_ticks, start_ticks;   // bounds of the waits in ticks of wall_clock64() (the host knows the rate)
     uint32_t test_abort_frame;     // tests: the finalizer of this frame raises `abort` instead of closing it (0xFFFFFFFF: never)
+    uint32_t metro_t16;            // METRONOME (see the walk): the turn period in ticks of wall_clock64() x 16; 0 = the waves run free
+    uint32_t metro_lead;           // ticks between the opening of the launch and turn 0's first slot
 #ifdef GR_EXP_TIMELINE
     unsigned long long *tl;        // [frames][8] device-clock stamps of a frame's way through the launch (tools/timeline_bench.sh)
 #endif
@@ -153,7 +158,7 @@ struct GrResCtl {
 // before a launch: the start handshake's two words (count, verdict) and every streaming wave's progress word are zeroed
 __global__ void k_res_prepare(uint32_t *handshake, uint32_t *progress, uint32_t n_progress) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < 2u) handshake[i] = 0u;
+    if (i < 11u) handshake[i] = 0u;                                  // (ctl.abort + 1 .. + 11)
     if (i < n_progress) progress[i] = 0u;
 }
 
@@ -303,12 +308,19 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
     // checks in, the one that completes the count opens the launch (verdict 1).  A workgroup that waits too long -- the device is
     // shared with another process's kernels that will not leave, or two of these launches hold half the chip each -- closes it
     // (verdict 2) and everybody leaves WITHOUT having touched a frame: the host then runs the segment on the two-pass path.
+    __shared__ unsigned long long metro_t0;
     {
         __shared__ uint32_t verdict;
         if (tid == 0) {
             const uint32_t n = __hip_atomic_fetch_add(ctl.abort + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
             uint32_t zero = 0u;
-            if (n == gridDim.x) (void)__hip_atomic_compare_exchange_strong(ctl.abort + 2, &zero, 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (n == gridDim.x) {
+                // the workgroup that opens the launch also sets the metronome's origin: visible (release) before the verdict is
+                __hip_atomic_store(reinterpret_cast<unsigned long long *>(ctl.abort + 4), wall_clock64() + ctl.metro_lead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                (void)__hip_atomic_compare_exchange_strong(ctl.abort + 2, &zero, 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             uint32_t v, polls = 0;
             const unsigned long long t0 = wall_clock64();
             while ((v = gr_ld_agent(ctl.abort + 2)) == 0u) {
@@ -316,6 +328,7 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
                 __builtin_amdgcn_s_sleep(16);
             }
             verdict = v;
+            if (v == 1u) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); metro_t0 = gr_ld_agent(reinterpret_cast<const unsigned long long *>(ctl.abort + 4)); }
         }
         __syncthreads();
         if (verdict != 1u) return;
@@ -323,7 +336,7 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
 
     // ------------------------------------------------------------------------------------------ finalizers
     if (blockIdx.x >= ctl.n_stream) {
-        constexpr uint32_t RPW = S::REC_PER_WAVE, LPR = S::LANES_PER_REC, W = S::WORDS_PER_LANE;
+        constexpr uint32_t RPW = S::REC_PER_WAVE;
         // A frame of up to 32 / 64 / 128 / 256 workgroups is closed by a TEAM of 1 / 2 / 4 / 8 waves (a wave collects 32 records),
         // and a finalizer workgroup closes 8 / 4 / 2 / 1 consecutive frames at a time, one per team: the closing arithmetic is one
         // lane's chain of fp64 operations (~10 us), so with several frame streams the frames per second the finalizers can close
@@ -333,7 +346,6 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
         uint32_t *gave_up = reinterpret_cast<uint32_t *>(wtot + 2u * WAVES * 32u);   // some wave of this workgroup ran out of patience
         if (tid == 0) *gave_up = 0u;
         __syncthreads();
-        const uint32_t r = wt * RPW + lane / LPR, part = lane % LPR;   // this lane's record (of its team's frame) and its W words
         const unsigned long long tagv = (unsigned long long)ctl.epoch << 32;
         for (uint32_t f0 = (blockIdx.x - ctl.n_stream) * NT; f0 < nframes; f0 += ctl.n_fin * NT) {
             const uint32_t f = f0 + team < nframes ? f0 + team : nframes - 1u;
@@ -346,19 +358,27 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
             float g0x, g0y, g0z;
             gr_pos_load(frames + (size_t)(first_slot + f) * frame_stride, sel.start, g0x, g0y, g0z);
             const int pre_status = state[f].status;
-            const bool mine = live && r < ctl.wgs_frame;
-            const unsigned long long *src = ctl.wgrec + ((size_t)f * n_pad + r) * GR_RES_REC_WORDS + part * W;
-            unsigned long long w[W];
+            // The wave's 32 records are 8 KiB in a row, and the wave reads them AS 8 KiB: eight 16-byte loads per lane, each instruction one
+            // contiguous KiB (round 5; until then a lane read its own record's words 8 bytes at a time -- 1024 cache lines touched per wave
+            // and look, 16 instructions of 64 scattered 8-byte accesses: a look took microseconds and the looks of all finalizers were a
+            // sixth of the launch's memory requests).  Load k hands lane l the words 2 (l % 16) and 2 (l % 16) + 1 of record 4 k + l / 16.
+            // (a team may have more waves than the frame has blocks of 32 records: such a wave reads a resource of zero bytes)
+            const uint32_t rec0 = wt * RPW < n_pad ? wt * RPW : 0u, nrec = wt * RPW < n_pad ? min(RPW, n_pad - wt * RPW) : 0u;
+            const unsigned long long *src = ctl.wgrec + ((size_t)f * n_pad + rec0) * GR_RES_REC_WORDS;
+            const __amdgpu_buffer_rsrc_t rr = gr_buf_rsrc(src, nrec * GR_RES_REC_WORDS * 8u);
+            const uint32_t w0 = (lane & 15u) * 2u, rbase = wt * RPW + (lane >> 4);
+            gr_i4 q[8];
             uint32_t polls = 0;
             const unsigned long long t0 = wall_clock64();
             if (live && f == ctl.test_abort_frame) { if (lane == 0) { gr_st_agent(ctl.abort, 1u); __hip_atomic_store(gave_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } polls = 0xFFFFFFFFu; }
             while (polls != 0xFFFFFFFFu) {
                 bool ok = true;
-                if (mine) {
 #pragma unroll
-                    for (uint32_t k = 0; k < W; ++k) w[k] = gr_ld_agent(src + k);
+                for (uint32_t k = 0; k < 8u; ++k) q[k] = __builtin_amdgcn_raw_buffer_load_b128(rr, (int)((k * 64u + lane) * 16u), 0, 16 /* sc1: agent scope */);
 #pragma unroll
-                    for (uint32_t k = 0; k < W; ++k) ok = ok && ((uint32_t)(w[k] >> 32) == ctl.epoch || part * W + k == 31u);
+                for (uint32_t k = 0; k < 8u; ++k) {
+                    const bool mine = live && rbase + 4u * k < ctl.wgs_frame;
+                    ok = ok && (!mine || ((uint32_t)q[k].y == ctl.epoch && ((uint32_t)q[k].w == ctl.epoch || w0 == 30u)));   // (word 31 is never written)
                 }
                 if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
                 if (++polls > GR_RES_PATIENCE || ((polls & 255u) == 0 && (gr_ld_agent(ctl.abort) != 0u || wall_clock64() - t0 > ctl.patience_ticks))) {
@@ -372,27 +392,25 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
             if (ctl.tl && wt == 0 && lane == 0 && live) { ctl.tl[(size_t)f * 8 + 1] = wall_clock64(); ctl.tl[(size_t)f * 8 + 7] = polls; }
 #endif
             // (a wave that gave up still meets the others at the barriers; the frame is then published as ABORTED, never as closed)
-            // sums in fp64, extents as maxima: word index = part * W + k; 0..18 sums, 19..30 maxima
-            double v[W];
+            // sums in fp64, extents as maxima (words 0..18 sums, 19..30 maxima): the lane's eight records in order, then the four lanes
+            // that hold the same words (l, l ^ 16, l ^ 32, l ^ 48) -- a fixed order: results do not depend on the order of arrival
+            const bool mx0 = w0 >= 19u, mx1 = w0 + 1u >= 19u;
+            double a0 = mx0 ? (double)-3.0e38f : 0.0, a1 = mx1 ? (double)-3.0e38f : 0.0;
 #pragma unroll
-            for (uint32_t k = 0; k < W; ++k) {
-                const bool mxw = part * W + k >= 19u;
-                const float x = (mine && polls != 0xFFFFFFFFu) ? __uint_as_float((uint32_t)w[k]) : (mxw ? -3.0e38f : 0.0f);
-                v[k] = (double)x;
+            for (uint32_t k = 0; k < 8u; ++k) {
+                const bool have = live && rbase + 4u * k < ctl.wgs_frame && polls != 0xFFFFFFFFu;
+                const double x0 = have ? (double)__int_as_float(q[k].x) : (mx0 ? (double)-3.0e38f : 0.0);
+                const double x1 = (have && w0 != 30u) ? (double)__int_as_float(q[k].z) : (mx1 ? (double)-3.0e38f : 0.0);
+                a0 = mx0 ? fmax(a0, x0) : a0 + x0;
+                a1 = mx1 ? fmax(a1, x1) : a1 + x1;
             }
 #pragma unroll
-            for (uint32_t off = LPR; off < 64u; off <<= 1) {
-#pragma unroll
-                for (uint32_t k = 0; k < W; ++k) {
-                    const double o = __shfl_xor(v[k], (int)off, 64);
-                    const bool mxw = part * W + k >= 19u;
-                    v[k] = mxw ? fmax(v[k], o) : v[k] + o;
-                }
+            for (uint32_t off = 16u; off < 64u; off <<= 1) {
+                const double o0 = __shfl_xor(a0, (int)off, 64), o1 = __shfl_xor(a1, (int)off, 64);
+                a0 = mx0 ? fmax(a0, o0) : a0 + o0;
+                a1 = mx1 ? fmax(a1, o1) : a1 + o1;
             }
-            if (lane < LPR) {
-#pragma unroll
-                for (uint32_t k = 0; k < W; ++k) wtot[wave * 32u + lane * W + k] = v[k];
-            }
+            if (lane < 16u) { wtot[wave * 32u + w0] = a0; wtot[wave * 32u + w0 + 1u] = a1; }
             __syncthreads();                                          // (also publishes gave_up)
             if (wt == 0 && lane < 31u) {     // totals over the team's waves, in wave order: lane k owns word k
                 double a = wtot[wave * 32u + lane];
@@ -573,6 +591,48 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
         set_prio();
     };
 
+    // THE METRONOME.  Left alone, the waves issue their row requests whenever their own turn comes round: at any moment the chip asks for
+    // 1 KiB pieces from all over the frame in no order, and HBM delivers a copy at 5.2-5.5 TB/s.  A copy whose requests sweep memory
+    // in ADDRESS ORDER -- fresh single-load waves handed out by the dispatcher -- runs at 6.5 (tools/copy_matrix*.hip, profiles/
+    // r05_copy_matrix.md).  So the walk is given a clock: wave w of streaming workgroup b may request the rows of turn k no earlier than
+    //      t0 + (k + (8 b + w) / (8 n_stream)) T        (device clock; t0 set by the workgroup that opens the launch, T = ctl.metro_t16 / 16)
+    // -- the chip's requests, and six turns later its stores, then sweep every frame from its first byte to its last once per period.
+    // The same walk without arithmetic: 4.61 us per 1e6-atom frame free-running, 3.70 with the clock at T = 3.7 us (6.4 TB/s), 4.04 with
+    // a T it cannot keep (3.6).  A wave that reaches its slot late does not wait (it is counted); T is the host's to choose (gr_api.hip).
+    const unsigned long long metro_base = metro_t0;
+#ifndef GR_RES_METRO_ANTI
+#define GR_RES_METRO_ANTI 0        /* experiment: waves 4-7 (the second wave of every SIMD) half a period behind waves 0-3 */
+#endif
+    const unsigned long long metro_phase16 = ((unsigned long long)(wg_all * WAVES + wave) * ctl.metro_t16) / ((unsigned long long)ctl.n_stream * WAVES)
+                                           + (GR_RES_METRO_ANTI ? (unsigned long long)(wave >> 2) * (ctl.metro_t16 >> 1) : 0ull);
+    uint32_t n_late = 0, n_waited = 0;
+    // (workgroup 0's first wave also reads the SHADER clock at both ends of its walk: with the device clock beside it the host knows the
+    //  frequency the launch ran at -- under the power cap the pass, streaming and computing at once, does not run at the nominal 2.4 GHz)
+#ifdef GR_EXP_STEPTIME
+    // experiment: where a wave's turn goes (shader-clock ticks summed over the walk, per segment): 0 the metronome's wait, 1 request + balance,
+    // 2 the wait for the rows + images + sums arithmetic, 3 reductions + hand-over (+ the combine of the wave that arrives last), 4 the wait
+    // for the record (first look / polls), 5 fit arithmetic + stores + hand-over of the fit sum, 6 parking; 7 = fit stages that had to poll
+    unsigned long long st_acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, st_last = (unsigned long long)clock64();
+#define GR_STEP_STAMP(k) do { const unsigned long long now_ = (unsigned long long)clock64(); st_acc[k] += now_ - st_last; st_last = now_; } while (0)
+#else
+#define GR_STEP_STAMP(k) do { } while (0)
+#endif
+    const bool clk_wave = wg_all == 0u && wave == 0u;
+    unsigned long long clk_c0 = 0ull, clk_w0 = 0ull;
+    if (clk_wave) { clk_c0 = (unsigned long long)clock64(); clk_w0 = (unsigned long long)wall_clock64(); }
+    auto gate = [&](uint32_t turn) {
+        if (ctl.metro_t16 == 0u || turn >= n_turns) return;
+        const unsigned long long target = metro_base + (((unsigned long long)turn * ctl.metro_t16 + metro_phase16) >> 4);
+        long long early = (long long)(target - wall_clock64());
+        if (early <= 0) { n_late += early < -(long long)(ctl.metro_t16 >> 6) ? 1u : 0u; return; }   // (late by more than a quarter of a period)
+        if (early > (long long)ctl.metro_t16 * 4) return;             // (farther ahead than any wave can be, 64 periods: the origin is not this launch's; run free)
+        n_waited++;
+        __builtin_amdgcn_s_setprio(0);
+        uint32_t polls = 0;
+        do { __builtin_amdgcn_s_sleep(1); early = (long long)(target - wall_clock64()); } while (early > 0 && ++polls < 100000u);
+        set_prio();
+    };
+
     // the image vectors of one group: v = image of (x - first atom) nearest to the first atom
     auto images = [&](const GrResGroup &Gr, const Rows &rw, const GrBoxU &B, const GrBox *boxp, float gx, float gy, float gz) -> GrP4 {
         GrP4 q = gr_pairs_rows(rw.r0, rw.r1, rw.r2);
@@ -647,6 +707,7 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
             s32[9] = dot8(GA.P.z01, GA.P.z23, GB.P.z01, GB.P.z23, a.x01, a.x23, b.x01, b.x23); s32[10] = dot8(GA.P.z01, GA.P.z23, GB.P.z01, GB.P.z23, a.y01, a.y23, b.y01, b.y23);
             s32[11] = dot8(GA.P.z01, GA.P.z23, GB.P.z01, GB.P.z23, a.z01, a.z23, b.z01, b.z23);
         }
+        GR_STEP_STAMP(2);
         const uint32_t rs = i % R;
         float *mine = wsum + (rs * WAVES + wave) * 32;
         if (wave_sel) {
@@ -763,6 +824,9 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
             } while (__builtin_amdgcn_ballot_w64(lane < 16u && (uint32_t)(rv >> 32) != ctl.epoch) != 0ull);
             rec = take(rv);
             asm volatile("; record polled for");
+#ifdef GR_EXP_STEPTIME
+            st_acc[7] += 1ull;
+#endif
 #ifdef GR_EXP_TIMELINE
             tl_polls = polls;
 #endif
@@ -771,6 +835,7 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
         if (tl_wg && wave == 0 && lane == 0) { tls[(j & 127u) * 4u + 2u] = tl_polls; tls[(j & 127u) * 4u + 3u] = wall_clock64(); }
 #endif
         set_prio();
+        GR_STEP_STAMP(4);
         const int status = rec.status;
         float rs = 0.0f;
         Rows oa, ob;
@@ -843,15 +908,62 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
     Rows Q0, Q1, Q2, Q3, Q4, Q5;
     Q0.r0 = Q0.r1 = Q0.r2 = zero4; Q1 = Q0; Q2 = Q0; Q3 = Q0; Q4 = Q0; Q5 = Q0;
     unsigned long long rv = 0ull;
+    gate(0);
     if (n_turns) request(0, L0);
     const uint32_t n_iter = n_turns + K;
     const GrBoxU B0 = gr_box_uniform(boxes + first_slot);
     auto lds_put = [&](uint32_t slot, const Rows &rw) { park[(slot * 3 + 0) * LANES + tid] = rw.r0; park[(slot * 3 + 1) * LANES + tid] = rw.r1; park[(slot * 3 + 2) * LANES + tid] = rw.r2; };
     auto lds_get = [&](uint32_t slot) { Rows rw; rw.r0 = park[(slot * 3 + 0) * LANES + tid]; rw.r1 = park[(slot * 3 + 1) * LANES + tid]; rw.r2 = park[(slot * 3 + 2) * LANES + tid]; return rw; };
+#ifndef GR_RES_FIT_LAST
+#define GR_RES_FIT_LAST 1          /* a step = sums of frame i, THEN the fit of frame i - K (round 5); 0: the fit first (rounds 2-4) */
+#endif
+#if GR_RES_FIT_LAST
+    // Order of a step (round 5): the sums of frame i FIRST, then the fit of frame i - K.  A frame's record is the end of a chain --
+    // every workgroup's sums -> their records visible to a finalizer -> its tree -> the closing arithmetic -> the record visible here:
+    // 17-20 us (tools/timeline_bench.sh) -- and with the fit at the head of the step the chain had (K - 1) turns: workgroup 0 found
+    // the record missing in 30-50 % of its turns and polled, a memory round trip per look.  Sums first publishes a turn's record ~0.35
+    // turns earlier and needs the old one ~0.65 turns later: the chain has K turns.  Registers: the image vectors of frame i wait in the
+    // landing registers the sums have just emptied while frame i - K is fitted, and are parked behind it (the slot is free then).
+    auto step = [&](uint32_t i, Landing &cur, Landing &nxt) {
+        // the record this step's fit needs: requested before everything else of the step (the wait for it then leaves the rows
+        // requested below out); unconditional -- the record of the stream's first frame when there is nothing to fit -- see below
+        rv = request_rec(i >= K && i < n_iter ? i - K : 0u);
+#ifdef GR_EXP_NOLOAD
+        if (i < 2) request(i + 1, nxt);
+#else
+        GR_STEP_STAMP(6);
+        gate(i + 1);
+        GR_STEP_STAMP(0);
+        request(i + 1, nxt);
+#endif
+        balance(i);
+        const GrBoxU Bf = UBOX ? B0 : gr_box_uniform(boxes + first_slot + kf(i >= K ? i - K : 0u));
+        const GrBoxU Bs = UBOX ? B0 : gr_box_uniform(boxes + first_slot + kf(i < n_turns ? i : 0u));
+        Rows va = cur.a, vb = cur.b;                            // what gets parked: the rows, or (V: set by sums) the image vectors
+        const uint32_t ps = i % K;
+        GR_STEP_STAMP(1);
+        if (i < n_turns) sums(i, cur, Bs, va, vb);
+        GR_STEP_STAMP(3);
+        if (i >= K) {
+            Rows qb;
+            if (ps == 0u) { qb = Q0; asm volatile("; set 0 out"); } else if (ps == 1u) { qb = Q1; asm volatile("; set 1 out"); } else if (ps == 2u) { qb = Q2; asm volatile("; set 2 out"); }
+            else if (ps == 3u) { qb = Q3; asm volatile("; set 3 out"); } else if (ps == 4u) { qb = Q4; asm volatile("; set 4 out"); } else { qb = Q5; asm volatile("; set 5 out"); }
+            fit(i - K, rv, lds_get(ps), qb, Bf);
+            if (bail) return;
+        }
+        GR_STEP_STAMP(5);
+        if (i < n_turns) {                                      // (the slot's old content has been read by the fit above)
+            lds_put(ps, va);
+            if (ps == 0u) { Q0 = vb; asm volatile("; set 0 in"); } else if (ps == 1u) { Q1 = vb; asm volatile("; set 1 in"); } else if (ps == 2u) { Q2 = vb; asm volatile("; set 2 in"); }
+            else if (ps == 3u) { Q3 = vb; asm volatile("; set 3 in"); } else if (ps == 4u) { Q4 = vb; asm volatile("; set 4 in"); } else { Q5 = vb; asm volatile("; set 5 in"); }
+        }
+    };
+#else
     auto step = [&](uint32_t i, Landing &cur, Landing &nxt) {
 #ifdef GR_EXP_NOLOAD
         if (i < 2) request(i + 1, nxt);
 #elif !defined(GR_EXP_LATE_REQUEST)
+        gate(i + 1);
         request(i + 1, nxt);
 #endif
         balance(i);
@@ -881,11 +993,28 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
             if (!V) sums(i, cur, Bs, va, vb);
         }
     };
+#endif
     for (uint32_t i = 0; i < n_iter && !bail; i += 2) {
         step(i, L0, L1);
         if (!bail && i + 1 < n_iter) step(i + 1, L1, L0);
     }
-    if (lane == 0) ctl.progress[wg_all * WAVES + wave] = n_fitted;
+    if (lane == 0) {
+        ctl.progress[wg_all * WAVES + wave] = n_fitted;
+        // what the host sets the metronome by: when the last wave left, how many slots were reached late / waited for
+        (void)__hip_atomic_fetch_max(reinterpret_cast<unsigned long long *>(ctl.abort + 6), (unsigned long long)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (n_late) (void)__hip_atomic_fetch_add(ctl.abort + 8, n_late, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (n_waited) (void)__hip_atomic_fetch_add(ctl.abort + 9, n_waited, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef GR_EXP_STEPTIME
+        if ((wg_all == 0u || wg_all == ctl.n_stream / 2u) && (wave == 0u || wave == 5u)) {
+            unsigned long long *o = reinterpret_cast<unsigned long long *>(ctl.abort + 16) + ((wg_all ? 2u : 0u) + (wave ? 1u : 0u)) * 8u;
+            for (int k = 0; k < 8; ++k) o[k] = st_acc[k];
+        }
+#endif
+        if (clk_wave) {
+            const unsigned long long dc = (unsigned long long)clock64() - clk_c0, dw = (unsigned long long)wall_clock64() - clk_w0;
+            gr_st_agent(ctl.abort + 10, (uint32_t)(dc >> 8)); gr_st_agent(ctl.abort + 11, (uint32_t)(dw >> 8));   // shader / device clock ticks of the walk, / 256
+        }
+    }
 #ifdef GR_EXP_TIMELINE
     // workgroup 0's stamps of its last 256 turns: frame f's publication of the workgroup record -> slot 0, first look at the frame's
     // record -> slot 6 (slot 5 is the finalizer's), polls -> word 0 of the frame's row is left alone (slot 0 = publication)

@@ -286,10 +286,14 @@ int gr_rmsd_plan_force_exact(gr_rmsd_plan *plan, int on);
  *                      least GR_TUNE_RMSD_FAST_MIN atoms runs as the fit path's sums pass with the closed-form RMSD's sums kept as short
  *                      f32 chains widened to fp64; a frame whose rmsd is too close to the rounding of those sums (a rigid copy of the
  *                      reference) is redone by the exact-product pass, counted in GR_STAT_RMSD_EXACT_REDOS.  0: always the exact pass
- *   GR_TUNE_RMSD_FAST_MIN  smallest selection (atoms, default 16384) that takes it */
+ *   GR_TUNE_RMSD_FAST_MIN  smallest selection (atoms, default 16384) that takes it
+ *   GR_TUNE_RESIDENT_METRO_NS  the resident pass's METRONOME (gr_resident.h): the period, in nanoseconds per turn, at which the launch's
+ *                      row requests sweep each frame in address order.  0 (default) = chosen and kept up to date by the library from what
+ *                      its own launches report (GR_STAT_RES_METRO_PERIOD_NS / _LAST_TURN_NS / _LATE_PERMILLE); 1 = off (the waves run
+ *                      free, as before round 5); 100 .. 1 000 000 = this period.  Results do not depend on it. */
 enum { GR_TUNE_SUB_BATCH = 1, GR_TUNE_CHUNKS = 2, GR_TUNE_FIT_WGS = 3, GR_TUNE_FUSE = 4, GR_TUNE_TWO_PASS = 5, GR_TUNE_RESIDENT = 6, GR_TUNE_RESIDENT_GROUPS = 7,
        GR_TUNE_RESIDENT_STREAMS = 8, GR_TUNE_RESIDENT_FILL = 9, GR_TUNE_PAIRDIST_SYMMETRIC = 10, GR_TUNE_RESIDENT_WG_GROUPS = 11,
-       GR_TUNE_RMSD_FAST = 12, GR_TUNE_RMSD_FAST_MIN = 13,
+       GR_TUNE_RMSD_FAST = 12, GR_TUNE_RMSD_FAST_MIN = 13, GR_TUNE_RESIDENT_METRO_NS = 18,
        GR_TUNE_MASKED_SELECTIONS = 15 /* 1 (default): a scattered selection that covers at least an eighth of the atoms between its first and its last one (>= 4096
                                          atoms) also gets a bit mask, and RMSD / RMSD-fit / get_com read its span coalesced instead of gathering it atom by atom;
                                          0: groups created afterwards keep to their index lists.  Same results to rounding. */,
@@ -313,13 +317,18 @@ int gr_ctx_set_tuning(gr_ctx *ctx, int key, int64_t value);
  *   GR_STAT_RES_HANDSHAKE_MISSES   resident launches that closed themselves at the start handshake (the segment then took the two-pass path)
  *   GR_STAT_RES_ABORTS             resident launches in which a wait ran out of patience (see gr_rmsd_fit_batch)
  *   GR_STAT_RES_REDONE_FRAMES      frames of such launches that were still untouched and were redone on the two-pass path
- *   GR_STAT_RES_LAST_STREAMS       frame streams of the context's last resident launch (GR_TUNE_RESIDENT_STREAMS) */
+ *   GR_STAT_RES_LAST_STREAMS       frame streams of the context's last resident launch (GR_TUNE_RESIDENT_STREAMS)
+ *   GR_STAT_RES_METRO_PERIOD_NS    the metronome period the last resident launch ran with (0: it ran free)
+ *   GR_STAT_RES_LAST_TURN_NS       what a turn of that launch took on the device clock (first slot to the last wave's exit, per turn)
+ *   GR_STAT_RES_LATE_PERMILLE      thousandths of its metronome slots that waves reached more than a quarter period late
+ *   GR_STAT_RES_SCLK_MHZ           shader clock that launch ran at (shader-clock ticks over device-clock ticks of its first workgroup's walk) */
 enum { GR_STAT_N_CUS = 1, GR_STAT_RES_MAX_WGS = 2, GR_STAT_RES_LAUNCHES = 3, GR_STAT_RES_HANDSHAKE_MISSES = 4, GR_STAT_RES_ABORTS = 5, GR_STAT_RES_REDONE_FRAMES = 6, GR_STAT_RES_LAST_STREAMS = 7,
        GR_STAT_RMSD_FAST_FRAMES = 8 /* frames of RMSD-without-fit calls closed by the f32-chain pass (GR_TUNE_RMSD_FAST) */,
        GR_STAT_RMSD_EXACT_REDOS = 9 /* ... and frames that pass handed back to the exact-product pass */,
        GR_STAT_XTC_DEVICE_FRAMES = 10 /* frames gr_xtc_write_slots compressed on the device (GR_TUNE_XTC_DEVICE_ENCODE) */,
        GR_STAT_SMALL_CALLS = 11 /* one-frame calls answered by a single-wave dispatch (GR_TUNE_SMALL_CALLS) */,
-       GR_STAT_SMALL_SYNC_FALLBACKS = 12 /* ... of which the host gave up polling for the result (20 ms) and synchronised the stream instead */ };
+       GR_STAT_SMALL_SYNC_FALLBACKS = 12 /* ... of which the host gave up polling for the result (20 ms) and synchronised the stream instead */,
+       GR_STAT_RES_METRO_PERIOD_NS = 13, GR_STAT_RES_LAST_TURN_NS = 14, GR_STAT_RES_LATE_PERMILLE = 15, GR_STAT_RES_SCLK_MHZ = 16 };
 int gr_ctx_stat(const gr_ctx *ctx, int key, uint64_t *value);
 
 /* ---------------------------------------------------------------- text front end: gro structures, ndx index groups (host side)

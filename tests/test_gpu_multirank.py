@@ -63,3 +63,16 @@ def test_two_ranks_on_one_gpu_equal_one_rank_bit_for_bit(tmp_path, tag, extra):
         assert all(st["res_launches"] + st["res_handshake_misses"] >= 0 for st in two["config"]["per_rank_resident"])
         assert one["config"]["per_rank_resident"][0]["res_launches"] >= 3
         assert sum(st["res_launches"] for st in two["config"]["per_rank_resident"]) >= 1, two["config"]["per_rank_resident"]
+
+
+def test_bench_gpus_2_without_a_launcher_starts_two_ranks(tmp_path):
+    """`python bench.py --gpus 2` (no torch.distributed.run in front, WORLD_SIZE unset) must MEAN two ranks: the parent starts them as
+    fresh child processes before it touches the GPU and relays rank 0's line (--gpus used to be parsed and ignored)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(GROAN_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "bench.py", "--gpus", "2", "--atoms", "200000", "--steps", "2", "--warmup", "1", "--frames-per-step", "64", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-500:], r.stderr[-1500:])
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["gathered_frames"] == 2 * 2 * 64 and len(out["config"]["per_rank_frames_per_s"]) == 2

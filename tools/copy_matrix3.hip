@@ -1,0 +1,218 @@
+// copy_matrix3.hip -- third sheet of the copy matrix.
+//  (A) Why does a loop lose against fresh single-load waves (sheet 1: 6.5 vs 5.2-5.5 TB/s)?
+//        "one+wait"   one float4 per lane, no loop, but the wave WAITS for its store (s_waitcnt vmcnt(0)) before it ends
+//        "seqN"       no loop over the grid, but every wave does N dependent rounds of load -> store (N = 2, 3, 8): a loop of N turns
+//  (B) Sheet 2 found the XCCs unequal: the workgroups of the odd XCCs end 4-6 % after those of the even ones in every persistent walk.
+//      In the resident pass every frame needs EVERY workgroup's sums, so the slowest XCC paces the launch.  Does it pay to give the slow
+//      XCCs less to do?  The pass has workgroups that stream nothing (8 finalizers + 3 CUs left over): the probe is the pass's memory
+//      walk (245 streaming workgroups x 512 lanes x 2 groups, one frame of prefetch, stores `lag` frames behind, COUPLED: the store of
+//      frame i - lag waits until all workgroups have loaded frame i - lag, as the fit stage waits for the frame's record) on a grid of
+//      256 workgroups, one per CU, whose ROLES are dealt at run time from the XCC each one finds itself on:
+//        policy 0   idle workgroups = the last 11 by blockIdx (the pass today: spread over all XCCs)
+//        policy 1   idle workgroups on the ODD XCCs (3, 3, 3, 2)
+//        policy 2   idle workgroups on the EVEN XCCs (control)
+//        policy 3   idle on odd XCCs, and the ragged last streaming workgroup too
+//      Output per row: us per frame + mean end stamp of the streaming workgroups by XCC.
+// Build: hipcc --offload-arch=gfx950 -O3 -o tools/bin/copy_matrix3 tools/copy_matrix3.hip
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef int i4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ v4f ldnt(const v4f *p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ void stnt(v4f *p, v4f v) { __builtin_nontemporal_store(v, p); }
+__device__ __forceinline__ v4f touch(v4f v) { return v * 1.0000001f + 1e-9f; }
+
+template <bool WAIT>
+__global__ __launch_bounds__(256) void k_one(const v4f *__restrict__ src, v4f *__restrict__ dst) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    stnt(dst + i, touch(ldnt(src + i)));
+    if (WAIT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+// N dependent rounds per wave, the rounds of a workgroup N x 4 KiB apart (consecutive workgroups stay adjacent within a round)
+template <int N>
+__global__ __launch_bounds__(256) void k_seq(const v4f *__restrict__ src, v4f *__restrict__ dst, size_t round_pitch4) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+#pragma unroll 1
+    for (int r = 0; r < N; ++r, i += round_pitch4) {
+        const v4f v = ldnt(src + i);
+        stnt(dst + i, touch(v));
+    }
+}
+
+#define RSRC(ptr, bytes) __builtin_amdgcn_make_buffer_rsrc((void *)(ptr), 0, (int)(bytes), 0x00020000)
+__device__ __forceinline__ i4v touch_i(i4v v) { v.x += 1; v.y ^= 3; v.z += 5; v.w ^= 7; return v; }
+struct Ctl {
+    uint32_t *tickets;          // [8] per-XCC check-in tickets, [8] checked-in total, [9] spare          (zeroed before every launch)
+    uint32_t *frame_cnt;        // [nframes] workgroups that have loaded frame f                          (zeroed before every launch)
+    unsigned long long *stamps; // [grid][4]: start, end, xcc, virtual id (0xFFFFFFFF idle)
+    uint32_t n_stream, policy, coupled;
+    uint32_t metro_ticks;       // 0: free-running; else the turn period of the metronome in ticks of wall_clock64 x 16 (fixed point: 100 MHz clock)
+    uint32_t metro_mode;        // 1: phases set once at the start; 2: every turn's loads wait for their slot
+};
+__global__ __launch_bounds__(512) void k_walk(const float *frames, float *dst_frames, size_t stride, uint32_t nframes, uint32_t ngroups, int lag, Ctl c) {
+    extern __shared__ char ballast[];
+    __shared__ uint32_t s_vid;
+    __shared__ unsigned long long s_t0;
+    if (threadIdx.x == 0) {
+        const uint32_t xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 7u;
+        const uint32_t k = __hip_atomic_fetch_add(c.tickets + xcc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__hip_atomic_fetch_add(c.tickets + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == gridDim.x) {
+            __hip_atomic_store(reinterpret_cast<unsigned long long *>(c.tickets + 10), wall_clock64() + 300ull /* 3 us from now */, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(c.tickets + 9, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        uint32_t spins = 0;
+        while (__hip_atomic_load(c.tickets + 9, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0u && ++spins < 20000000u) __builtin_amdgcn_s_sleep(8);
+        s_t0 = __hip_atomic_load(reinterpret_cast<unsigned long long *>(c.tickets + 10), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t cnt[8], idle[8], s[8];
+        for (int x = 0; x < 8; ++x) { cnt[x] = __hip_atomic_load(c.tickets + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); idle[x] = 0; }
+        uint32_t I = gridDim.x - c.n_stream;
+        uint32_t vid = 0xFFFFFFFFu;
+        if (spins >= 20000000u) vid = 0xFFFFFFFEu;                      // (never all resident: everybody leaves)
+        else if (c.policy == 0) vid = blockIdx.x < c.n_stream ? blockIdx.x : 0xFFFFFFFFu;
+        else {
+            const uint32_t par = (c.policy == 2) ? 0u : 1u;             // the XCC parity that gets the idle workgroups
+            for (uint32_t t = 0; I > 0 && t < 64; ++t) { const uint32_t x = ((t & 3u) << 1) | par; if (idle[x] < cnt[x]) { ++idle[x]; --I; } }
+            for (int x = 0; x < 8; ++x) s[x] = cnt[x] - idle[x];
+            if (k < s[xcc]) {
+                vid = 0;
+                for (uint32_t x = 0; x < 8; ++x) vid += min(k, s[x]) + ((x < xcc && k < s[x]) ? 1u : 0u);
+                if (c.policy == 3) {   // the ragged last workgroup (least work) to an odd XCC: swap the last id with the last id held by an odd XCC
+                    uint32_t last_odd = 0;   // id of the highest-ticket streaming workgroup of XCC 1
+                    const uint32_t kk = s[1] - 1u;
+                    for (uint32_t x = 0; x < 8; ++x) last_odd += min(kk, s[x]) + ((x < 1u && kk < s[x]) ? 1u : 0u);
+                    if (vid == c.n_stream - 1u) vid = last_odd; else if (vid == last_odd) vid = c.n_stream - 1u;
+                }
+            }
+        }
+        s_vid = vid;
+        c.stamps[4 * blockIdx.x + 0] = wall_clock64(); c.stamps[4 * blockIdx.x + 2] = xcc; c.stamps[4 * blockIdx.x + 3] = vid;
+    }
+    __syncthreads();
+    const uint32_t vid = s_vid;
+    if (vid >= 0xFFFFFFFEu) return;
+    const uint32_t base = vid * 1024u;
+    uint32_t off[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) { const uint32_t g = base + q * 512 + threadIdx.x; off[q] = g < ngroups ? ((g >> 6) * 192 + (g & 63)) * 16u : 0xFFFFF000u; }
+    const uint32_t fbytes = (uint32_t)(stride * 4);
+    i4v A[2][3], B[2][3];
+    // metronome: wave (vid, w) may issue the loads of frame f at t0 + (f + (8 vid + w) / (8 n_stream)) T -- the chip's requests then sweep
+    // every frame in address order, as the dispatcher's fresh waves do in the "one" kernel
+    const unsigned long long t0 = s_t0;
+    const unsigned long long phase16 = c.metro_ticks ? ((unsigned long long)(vid * 8u + (threadIdx.x >> 6)) * c.metro_ticks) / (c.n_stream * 8u) : 0ull;
+    auto load = [&](uint32_t f, i4v (&R)[2][3]) {
+        const bool live = f < nframes;
+        if (c.metro_ticks && (c.metro_mode == 2u || f == 0u)) {
+            const unsigned long long target = t0 + (((unsigned long long)f * c.metro_ticks + phase16) >> 4);
+            uint32_t spins = 0;
+            while ((long long)(wall_clock64() - target) < 0 && ++spins < 1000000u) __builtin_amdgcn_s_sleep(1);
+        }
+        __amdgpu_buffer_rsrc_t s = RSRC(frames + (size_t)(live ? f : 0u) * stride, live ? fbytes : 0u);
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int r = 0; r < 3; ++r) R[q][r] = __builtin_amdgcn_raw_buffer_load_b128(s, off[q] + 1024 * r, 0, 2);
+    };
+    // frame i has landed in this wave's registers: count it (one add per wave), then -- coupled -- wait until every streaming wave has
+    // counted frame i - lag before that frame's slot is written
+    const uint32_t n_waves_all = c.n_stream * 8u;
+    bool gave_up = false;                                               // a wait that ran out once is never repeated (the launch must end)
+    auto store = [&](uint32_t i, i4v (&R)[2][3]) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int r = 0; r < 3; ++r) R[q][r] = touch_i(R[q][r]);      // (uses the rows: the wait for them sits here)
+        if (c.coupled) {
+            if ((threadIdx.x & 63u) == 0) __hip_atomic_fetch_add(c.frame_cnt + i, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (i >= (uint32_t)lag && !gave_up) {
+                uint32_t spins = 0;
+                while ((uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(c.frame_cnt + (i - lag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < n_waves_all && ++spins < 4000000u) __builtin_amdgcn_s_sleep(2);
+                if (spins >= 4000000u) gave_up = true;
+            }
+        }
+        if (i < (uint32_t)lag) return;
+        __amdgpu_buffer_rsrc_t d = RSRC(dst_frames + (size_t)(i - lag) * stride, fbytes);
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int r = 0; r < 3; ++r) __builtin_amdgcn_raw_buffer_store_b128(R[q][r], d, off[q] + 1024 * r, 0, 18);
+    };
+    load(0, A);
+    for (uint32_t i = 0; i < nframes; i += 2) {       // nframes even; the last `lag` frames are loaded and never stored (bytes counted accordingly)
+        load(i + 1, B);
+        store(i, A);
+        load(i + 2, A);
+        store(i + 1, B);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) c.stamps[4 * blockIdx.x + 1] = wall_clock64();
+}
+
+static hipEvent_t e0, e1;
+int main(int argc, char **argv) {
+    const double gib = argc > 1 ? atof(argv[1]) : 16.0;
+    const size_t bytes = (size_t)(gib * 1024.0) << 20, n4 = bytes / 16;
+    v4f *A, *B;
+    CHECK(hipMalloc(&A, bytes)); CHECK(hipMalloc(&B, bytes));
+    CHECK(hipMemset(A, 0, bytes)); CHECK(hipMemset(B, 0, bytes));
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    auto timed = [&](auto f, int reps, std::vector<float> &t) {
+        t.clear();
+        for (int rep = 0; rep < reps + 1; ++rep) {
+            f(0);
+            CHECK(hipEventRecord(e0)); f(1); CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+            float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+            if (rep) t.push_back(ms);
+        }
+        CHECK(hipGetLastError());
+        std::sort(t.begin(), t.end());
+    };
+    std::vector<float> t;
+    auto row = [&](const char *family, const char *desc, double by, const std::string &tail) {
+        printf("{\"family\": \"%s\", %s, \"GB\": %.3f, \"best_ms\": %.4f, \"median_ms\": %.4f, \"best_TBs\": %.3f, \"median_TBs\": %.3f%s}\n", family, desc, by / 1e9, t[0], t[t.size() / 2],
+               by / (t[0] * 1e-3) / 1e12, by / (t[t.size() / 2] * 1e-3) / 1e12, tail.c_str());
+        fflush(stdout);
+    };
+    // ---- (A)
+    timed([&](int go) { if (go) k_one<false><<<dim3((unsigned)(n4 / 256)), dim3(256)>>>(A, B); }, 5, t); row("one", "\"wait_for_store\": 0", 2.0 * n4 * 16, "");
+    timed([&](int go) { if (go) k_one<true><<<dim3((unsigned)(n4 / 256)), dim3(256)>>>(A, B); }, 5, t); row("one", "\"wait_for_store\": 1", 2.0 * n4 * 16, "");
+#define SEQ(N) do { const size_t nwg = n4 / 256 / N; char d[128]; snprintf(d, sizeof d, "\"rounds\": %d", N); \
+        timed([&](int go) { if (go) k_seq<N><<<dim3((unsigned)nwg), dim3(256)>>>(A, B, nwg * 256); }, 5, t); row("seq", d, 2.0 * nwg * 256 * N * 16, ""); } while (0)
+    SEQ(1); SEQ(2); SEQ(3); SEQ(8); SEQ(32);
+    // ---- (B)
+    const uint32_t n_atoms = 1000000u, ntiles = (n_atoms + 255) / 256, ngroups = ntiles * 64;
+    const size_t stride = (size_t)ntiles * 768;
+    const uint32_t F = std::min<uint32_t>(768u, (uint32_t)(n4 * 4 / stride)) & ~1u;
+    const uint32_t n_stream = (ngroups + 1023) / 1024, grid = 256;
+    Ctl c;
+    CHECK(hipMalloc(&c.tickets, 64)); CHECK(hipMalloc(&c.frame_cnt, 4 * (F + 8))); CHECK(hipMalloc(&c.stamps, 8 * 4 * grid));
+    c.n_stream = n_stream;
+    const int lds = 100 * 1024;
+    CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_walk), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    struct M { int mode; double T_us; };
+    const M ms[] = { { 0, 0 }, { 1, 4.4 }, { 2, 4.6 }, { 2, 4.4 }, { 2, 4.2 }, { 2, 4.0 }, { 2, 3.9 }, { 2, 3.8 }, { 2, 3.7 }, { 2, 3.6 }, { 0, 0 } };
+    for (uint32_t Fr : { 64u, 256u, F })
+        for (const M &m : ms) {
+            const int lag = 6, policy = 0;
+            c.policy = policy; c.coupled = 0; c.metro_mode = m.mode; c.metro_ticks = (uint32_t)(m.T_us * 100.0 * 16.0);
+            timed([&](int go) {
+                if (!go) { CHECK(hipMemsetAsync(c.tickets, 0, 64, 0)); CHECK(hipStreamSynchronize(0)); }
+                else k_walk<<<dim3(grid), dim3(512), lds>>>((const float *)A, (float *)B, stride, Fr, ngroups, lag, c);
+            }, 6, t);
+            std::vector<unsigned long long> h(4 * grid);
+            CHECK(hipMemcpy(h.data(), c.stamps, h.size() * 8, hipMemcpyDeviceToHost));
+            unsigned long long t0 = ~0ull, t1 = 0;
+            for (uint32_t b = 0; b < grid; ++b) { if ((uint32_t)h[4 * b + 3] >= 0xFFFFFFFEu) continue; t0 = std::min(t0, h[4 * b]); t1 = std::max(t1, h[4 * b + 1]); }
+            char tail[256]; snprintf(tail, sizeof tail, ", \"us_per_frame_events\": %.4f, \"us_per_frame_device_clock\": %.4f", 1e3 * t[0] / Fr, (t1 - t0) * 0.01 / Fr);
+            char d[256];
+            snprintf(d, sizeof d, "\"metronome\": \"%s\", \"T_us\": %.2f, \"lag\": %d, \"frames\": %u, \"streaming_wgs\": %u, \"grid\": %u", m.mode == 0 ? "off" : m.mode == 1 ? "start only" : "every turn", m.T_us, lag, Fr, n_stream, grid);
+            row("walk", d, (double)(2 * Fr - lag) * stride * 4, tail);
+        }
+    return 0;
+}

@@ -4,7 +4,9 @@
 # Summaries land in gpurun_out/prof_<tag>/; copy the ones to be judged into profiles/.
 set -o pipefail
 TAG=${1:-r01}
-ARGS=${2:-"--steps 3 --warmup 1 --warmup-seconds 0 --no-cpu-baseline"}
+# the bench with its OWN warm-up (0.5 s of launches on the warm-up slots): the averages of the trace are then steady-state figures
+# (r04 profiled --warmup-seconds 0, i.e. the launches the bench itself discards, and read 5.7 % slow)
+ARGS=${2:-"--steps 20 --warmup 3 --warmup-seconds 0.5 --no-cpu-baseline --no-live-floor"}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
