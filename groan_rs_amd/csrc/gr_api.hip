@@ -104,6 +104,7 @@ struct gr_ctx {
     // next to no slot was reached late); it starts from a free-running launch, probes downwards 1.5 % at a time, steps back to the
     // best kept period when a probe fails, and switches the clock off for a shape whose free-running turn it cannot beat.
     int res_metro_ns = 0;
+    int res_fit_last = 0;             // GR_TUNE_RESIDENT_FIT_LAST 0: chosen by the launch's fill, 1: the fit first, 2: the sums first
     struct Metro { uint64_t shape = 0; double free_ns = 0, T_ns = 0, best_ns = 0, fail_ns = 0; uint32_t off_for = 0, held = 0; } metro;
     uint64_t res_metro_period_ns = 0, res_last_turn_ns = 0, res_late_permille = 0, res_sclk_mhz = 0;   // gr_ctx_stat: the last resident launch
     int wall_khz = 100000;            // rate of the device's wall_clock64() (hipDeviceAttributeWallClockRate)
@@ -273,20 +274,22 @@ uint32_t fit_grid(const gr_ctx *c, uint32_t nf) {
     return (uint32_t)(gx < 1 ? 1 : gx);
 }
 
-// the eight variants of the resident kernel (weights are the masses / every frame has the same box / the selection is the whole
-// system): allow their LDS size, hand out the one a launch needs
-static const void *resident_fn(bool wmass, bool ubox, bool v) {
-    static const void *const fn[8] = {
-        reinterpret_cast<const void *>(&k_fit_resident<false, false, false>), reinterpret_cast<const void *>(&k_fit_resident<true, false, false>),
-        reinterpret_cast<const void *>(&k_fit_resident<false, true, false>), reinterpret_cast<const void *>(&k_fit_resident<true, true, false>),
-        reinterpret_cast<const void *>(&k_fit_resident<false, false, true>), reinterpret_cast<const void *>(&k_fit_resident<true, false, true>),
-        reinterpret_cast<const void *>(&k_fit_resident<false, true, true>), reinterpret_cast<const void *>(&k_fit_resident<true, true, true>) };
-    return fn[(wmass ? 1 : 0) | (ubox ? 2 : 0) | (v ? 4 : 0)];
+// the sixteen variants of the resident kernel (weights are the masses / every frame has the same box / the selection is the whole
+// system / sums before fit): allow their LDS size, hand out the one a launch needs
+static const void *resident_fn(bool wmass, bool ubox, bool v, bool fl) {
+#define GR_RES_FN(W, U, V, F) reinterpret_cast<const void *>(&k_fit_resident<W, U, V, F>)
+    static const void *const fn[16] = {
+        GR_RES_FN(false, false, false, false), GR_RES_FN(true, false, false, false), GR_RES_FN(false, true, false, false), GR_RES_FN(true, true, false, false),
+        GR_RES_FN(false, false, true, false), GR_RES_FN(true, false, true, false), GR_RES_FN(false, true, true, false), GR_RES_FN(true, true, true, false),
+        GR_RES_FN(false, false, false, true), GR_RES_FN(true, false, false, true), GR_RES_FN(false, true, false, true), GR_RES_FN(true, true, false, true),
+        GR_RES_FN(false, false, true, true), GR_RES_FN(true, false, true, true), GR_RES_FN(false, true, true, true), GR_RES_FN(true, true, true, true) };
+#undef GR_RES_FN
+    return fn[(wmass ? 1 : 0) | (ubox ? 2 : 0) | (v ? 4 : 0) | (fl ? 8 : 0)];
 }
 static bool resident_prepare() {
     bool ok = true;
-    for (int v = 0; v < 8; ++v)
-        ok = ok && hipFuncSetAttribute(resident_fn((v & 1) != 0, (v & 2) != 0, (v & 4) != 0), hipFuncAttributeMaxDynamicSharedMemorySize, GrResShape::LDS_BYTES) == hipSuccess;
+    for (int v = 0; v < 16; ++v)
+        ok = ok && hipFuncSetAttribute(resident_fn((v & 1) != 0, (v & 2) != 0, (v & 4) != 0, (v & 8) != 0), hipFuncAttributeMaxDynamicSharedMemorySize, GrResShape::LDS_BYTES) == hipSuccess;
     return ok;
 }
 
@@ -364,6 +367,9 @@ uint32_t resident_wgs(gr_ctx *c, bool lite, uint32_t nb, const GrSel &sel, uint3
     return (uint32_t)wgs_used;
 }
 
+#ifdef GR_EXP_STEPTIME
+static unsigned long long *g_steptime_dbg = nullptr;
+#endif
 // One resident launch at a time per device and process: its workgroups wait for one another, so two of them sharing the CUs could
 // each hold half the chip and starve.  A context that finds the device taken lets the two-pass path handle its segment.
 static std::atomic<int> g_resident_in_flight[64];
@@ -771,8 +777,8 @@ gr_ctx *gr_ctx_create(int device, uint64_t n_atoms, uint32_t n_slots, int *statu
         int per_cu = 0;
         int per_cu_x = 0;
         if (resident_prepare() &&
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_fit_resident<false, false, true>, GrResShape::LANES, GrResShape::LDS_BYTES) == hipSuccess && per_cu >= 1 &&
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_x, k_fit_resident<false, false, false>, GrResShape::LANES, GrResShape::LDS_BYTES) == hipSuccess && per_cu_x >= 1)
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_fit_resident<false, false, true, true>, GrResShape::LANES, GrResShape::LDS_BYTES) == hipSuccess && per_cu >= 1 &&
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_x, k_fit_resident<false, false, false, true>, GrResShape::LANES, GrResShape::LDS_BYTES) == hipSuccess && per_cu_x >= 1)
             c->res_max_wgs = c->n_cus * (uint32_t)std::min(per_cu, per_cu_x);
         (void)hipGetLastError();
     }
@@ -1816,6 +1822,7 @@ int gr_ctx_set_tuning(gr_ctx *c, int key, int64_t value) try {
     case GR_TUNE_RESIDENT_WG_GROUPS: if (value != 0 && (value < 64 || value > GR_RES_GROUPS || value % 64 != 0)) break; c->res_wg_groups = (int)value; return GR_OK;
     case GR_TUNE_RESIDENT_STREAMS: if (value < 0 || value > GR_RES_MAX_STREAMS) break; c->res_streams = (int)value; return GR_OK;
     case GR_TUNE_RESIDENT_METRO_NS: if (value < 0 || value > 1000000 || (value > 1 && value < 100)) break; c->res_metro_ns = (int)value; c->metro = gr_ctx::Metro(); return GR_OK;
+    case GR_TUNE_RESIDENT_FIT_LAST: if (value < 0 || value > 2) break; c->res_fit_last = (int)value; return GR_OK;
     case GR_TUNE_RESIDENT_FILL: if (value < 1 || value > 16) break; c->res_fill16 = (int)value; return GR_OK;
     case GR_TUNE_RESIDENT_GROUPS: if (value != 2) break; return GR_OK;   // (the one-group shape was removed: gr_resident.h)
     case GR_TUNE_TEST_RESIDENT_NO_START: c->res_test_no_start = value ? 1 : 0; return GR_OK;
@@ -1994,6 +2001,14 @@ static int segment_begin(gr_rmsd_plan *p, uint32_t s0, uint32_t nb, int fit) {
                 ctl.metro_t16 = (uint32_t)std::min<uint64_t>(0xFFFFFFFFull, (uint64_t)period_ns * (uint64_t)c->wall_khz * 16ull / 1000000ull);
                 ctl.metro_lead = (uint32_t)((uint64_t)c->wall_khz * 2000ull / 1000000ull);   // 2 us
             }
+#ifdef GR_EXP_STEPTIME
+            {
+                static unsigned long long *dbg_dev = nullptr;
+                if (!dbg_dev) (void)hipMalloc(&dbg_dev, (size_t)GR_MAX_CHUNKS * 8 * 4 * sizeof(unsigned long long));
+                ctl.dbg = getenv("GR_STEPTIME") ? dbg_dev : nullptr;
+                g_steptime_dbg = ctl.dbg;
+            }
+#endif
 #ifdef GR_EXP_TIMELINE
             // experiment (tools/timeline_bench.sh): device-clock stamps of every frame's way through the launch
             {
@@ -2015,7 +2030,11 @@ static int segment_begin(gr_rmsd_plan *p, uint32_t s0, uint32_t nb, int fit) {
 #endif
             // the selection is the whole system: the kernel that parks image vectors (gr_resident.h, V)
             const bool whole = sel.start == 0 && sel.n == c->n;
-            const void *fn = resident_fn(p->dev.w_is_mass != 0, ubox, whole);
+            // sums before fit (gr_resident.h, FL) where the streaming workgroups fill the chip and memory paces the walk: measured (profiles/
+            // r05_ab_sizes.txt, frames/s, fit first -> sums first) 1e6 atoms 230 -> 235 k, 3 x 330 k 656 -> 679 k, level at 4 x 250 k and below;
+            // one stream of 520-800 k atoms (170-196 of 256 CUs) 261 -> 252 k, 251 -> 247 k, 237 -> 235 k: those keep the fit first
+            const bool fit_last = c->res_fit_last ? c->res_fit_last == 2 : (uint64_t)res_stream * 10u >= (uint64_t)c->res_max_wgs * 9u;
+            const void *fn = resident_fn(p->dev.w_is_mass != 0, ubox, whole, fit_last);
             const uint32_t lanes = GrResShape::LANES, lds = GrResShape::LDS_BYTES;
             // start handshake (count, verdict) and the waves' progress words back to zero: one small kernel instead of two memsets
             k_res_prepare<<<dim3((res_stream * 8 + 255) / 256), dim3(256), 0, S>>>(c->res_abort + 1, c->res_progress, res_stream * 8);
@@ -2185,6 +2204,29 @@ static int segment_end(gr_rmsd_plan *p, float *rmsd_out, int *status_out, float 
             } else {
                 c->res_launches++;
 #ifdef GR_EXP_STEPTIME
+                if (getenv("GR_STEPTIME") && g_steptime_dbg) {
+                    // every streaming wave: share of its walk spent waiting for records, by XCC / by wave number / the 12 waves that waited least
+                    std::vector<unsigned long long> d((size_t)q.res_stream * 8 * 4);
+                    if (hipMemcpy(d.data(), g_steptime_dbg, d.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+                        double by_xcc[8] = { 0 }, by_wave[8] = { 0 }; int n_xcc[8] = { 0 }, n_wave[8] = { 0 };
+                        std::vector<std::pair<double, uint32_t>> share;
+                        for (uint32_t w = 0; w < q.res_stream * 8; ++w) {
+                            if (!d[(size_t)w * 4 + 3]) continue;
+                            const double sh = (double)d[(size_t)w * 4] / (double)d[(size_t)w * 4 + 3];
+                            const uint32_t x = (uint32_t)(d[(size_t)w * 4 + 2] & 7);
+                            by_xcc[x] += sh; n_xcc[x]++; by_wave[w & 7] += sh; n_wave[w & 7]++;
+                            share.push_back({ sh, w });
+                        }
+                        std::sort(share.begin(), share.end());
+                        fprintf(stderr, "steptime record-wait share by XCC:");
+                        for (int x = 0; x < 8; ++x) fprintf(stderr, " %.3f", n_xcc[x] ? by_xcc[x] / n_xcc[x] : 0.0);
+                        fprintf(stderr, " | by wave:");
+                        for (int x = 0; x < 8; ++x) fprintf(stderr, " %.3f", n_wave[x] ? by_wave[x] / n_wave[x] : 0.0);
+                        fprintf(stderr, " | least:");
+                        for (size_t k = 0; k < 12 && k < share.size(); ++k) fprintf(stderr, " wg%u.w%u(x%u)=%.3f", share[k].second >> 3, share[k].second & 7, (uint32_t)(d[(size_t)share[k].second * 4 + 2] & 7), share[k].first);
+                        fprintf(stderr, " | median %.3f max %.3f\n", share[share.size() / 2].first, share.back().first);
+                    }
+                }
                 if (getenv("GR_STEPTIME")) {
                     unsigned long long st[32];
                     if (hipMemcpy(st, c->res_abort + 16, sizeof st, hipMemcpyDeviceToHost) == hipSuccess) {

@@ -153,6 +153,9 @@ struct GrResCtl {
 #ifdef GR_EXP_TIMELINE
     unsigned long long *tl;        // [frames][8] device-clock stamps of a frame's way through the launch (tools/timeline_bench.sh)
 #endif
+#ifdef GR_EXP_STEPTIME
+    unsigned long long *dbg;       // [streaming waves][4]: shader-clock ticks spent waiting for records, fits that polled, XCC | SIMD << 8, total ticks
+#endif
 };
 
 // before a launch: the start handshake's two words (count, verdict) and every streaming wave's progress word are zeroed
@@ -292,7 +295,8 @@ __device__ __forceinline__ void gr_res_fit_group(const GrResGroup &Gr, const flo
 
 // UBOX: every frame of the launch has the same box (the host compared them): its constants are loaded once, not per frame.
 // V: the selection is the whole system -> image vectors are parked (see the header of this file).
-template <bool WMASS, bool UBOX, bool V>
+// FL: a step runs the sums of frame i before the fit of frame i - K (see `step`)
+template <bool WMASS, bool UBOX, bool V, bool FL>
 __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
     float *__restrict__ frames, size_t frame_stride, uint32_t first_slot, uint32_t nframes, uint32_t n_atoms,
     const float *__restrict__ masses, GrSel sel, const GrBox *__restrict__ boxes, GrPlanDev plan,
@@ -914,17 +918,13 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
     const GrBoxU B0 = gr_box_uniform(boxes + first_slot);
     auto lds_put = [&](uint32_t slot, const Rows &rw) { park[(slot * 3 + 0) * LANES + tid] = rw.r0; park[(slot * 3 + 1) * LANES + tid] = rw.r1; park[(slot * 3 + 2) * LANES + tid] = rw.r2; };
     auto lds_get = [&](uint32_t slot) { Rows rw; rw.r0 = park[(slot * 3 + 0) * LANES + tid]; rw.r1 = park[(slot * 3 + 1) * LANES + tid]; rw.r2 = park[(slot * 3 + 2) * LANES + tid]; return rw; };
-#ifndef GR_RES_FIT_LAST
-#define GR_RES_FIT_LAST 1          /* a step = sums of frame i, THEN the fit of frame i - K (round 5); 0: the fit first (rounds 2-4) */
-#endif
-#if GR_RES_FIT_LAST
-    // Order of a step (round 5): the sums of frame i FIRST, then the fit of frame i - K.  A frame's record is the end of a chain --
+    // Order of a step, FL (round 5; the host takes it where the streaming workgroups fill the chip): the sums of frame i FIRST, then the fit of frame i - K.  A frame's record is the end of a chain --
     // every workgroup's sums -> their records visible to a finalizer -> its tree -> the closing arithmetic -> the record visible here:
     // 17-20 us (tools/timeline_bench.sh) -- and with the fit at the head of the step the chain had (K - 1) turns: workgroup 0 found
     // the record missing in 30-50 % of its turns and polled, a memory round trip per look.  Sums first publishes a turn's record ~0.35
     // turns earlier and needs the old one ~0.65 turns later: the chain has K turns.  Registers: the image vectors of frame i wait in the
     // landing registers the sums have just emptied while frame i - K is fitted, and are parked behind it (the slot is free then).
-    auto step = [&](uint32_t i, Landing &cur, Landing &nxt) {
+    auto step_sums_first = [&](uint32_t i, Landing &cur, Landing &nxt) {
         // the record this step's fit needs: requested before everything else of the step (the wait for it then leaves the rows
         // requested below out); unconditional -- the record of the stream's first frame when there is nothing to fit -- see below
         rv = request_rec(i >= K && i < n_iter ? i - K : 0u);
@@ -958,8 +958,8 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
             else if (ps == 3u) { Q3 = vb; asm volatile("; set 3 in"); } else if (ps == 4u) { Q4 = vb; asm volatile("; set 4 in"); } else { Q5 = vb; asm volatile("; set 5 in"); }
         }
     };
-#else
-    auto step = [&](uint32_t i, Landing &cur, Landing &nxt) {
+    // ... and the order of rounds 2-4, the fit first: still the faster one for a single stream that leaves a quarter of the chip idle
+    auto step_fit_first = [&](uint32_t i, Landing &cur, Landing &nxt) {
 #ifdef GR_EXP_NOLOAD
         if (i < 2) request(i + 1, nxt);
 #elif !defined(GR_EXP_LATE_REQUEST)
@@ -993,7 +993,7 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
             if (!V) sums(i, cur, Bs, va, vb);
         }
     };
-#endif
+    auto step = [&](uint32_t i, Landing &cur, Landing &nxt) { if constexpr (FL) step_sums_first(i, cur, nxt); else step_fit_first(i, cur, nxt); };
     for (uint32_t i = 0; i < n_iter && !bail; i += 2) {
         step(i, L0, L1);
         if (!bail && i + 1 < n_iter) step(i + 1, L1, L0);
@@ -1005,6 +1005,13 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
         if (n_late) (void)__hip_atomic_fetch_add(ctl.abort + 8, n_late, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (n_waited) (void)__hip_atomic_fetch_add(ctl.abort + 9, n_waited, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #ifdef GR_EXP_STEPTIME
+        if (ctl.dbg) {
+            unsigned long long *o = ctl.dbg + (size_t)(wg_all * WAVES + wave) * 4u;
+            unsigned long long tot = 0; for (int k = 0; k < 7; ++k) tot += st_acc[k];
+            o[0] = st_acc[4]; o[1] = st_acc[7];
+            o[2] = (__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 7u) | (simd_of[wave] << 8);
+            o[3] = tot;
+        }
         if ((wg_all == 0u || wg_all == ctl.n_stream / 2u) && (wave == 0u || wave == 5u)) {
             unsigned long long *o = reinterpret_cast<unsigned long long *>(ctl.abort + 16) + ((wg_all ? 2u : 0u) + (wave ? 1u : 0u)) * 8u;
             for (int k = 0; k < 8; ++k) o[k] = st_acc[k];

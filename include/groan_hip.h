@@ -290,10 +290,13 @@ int gr_rmsd_plan_force_exact(gr_rmsd_plan *plan, int on);
  *   GR_TUNE_RESIDENT_METRO_NS  the resident pass's METRONOME (gr_resident.h): the period, in nanoseconds per turn, at which the launch's
  *                      row requests sweep each frame in address order.  0 (default) = chosen and kept up to date by the library from what
  *                      its own launches report (GR_STAT_RES_METRO_PERIOD_NS / _LAST_TURN_NS / _LATE_PERMILLE); 1 = off (the waves run
- *                      free, as before round 5); 100 .. 1 000 000 = this period.  Results do not depend on it. */
+ *                      free, as before round 5); 100 .. 1 000 000 = this period.  Results do not depend on it.
+ *   GR_TUNE_RESIDENT_FIT_LAST  order of a turn of the resident pass: 1 = the fit of frame i - 6, then the sums of frame i (rounds 2-4);
+ *                      2 = the sums first (the frame's record is needed later and published earlier: one more turn for the finalizers);
+ *                      0 (default) = sums first when the streaming workgroups fill 9/10 of the chip.  Same results either way. */
 enum { GR_TUNE_SUB_BATCH = 1, GR_TUNE_CHUNKS = 2, GR_TUNE_FIT_WGS = 3, GR_TUNE_FUSE = 4, GR_TUNE_TWO_PASS = 5, GR_TUNE_RESIDENT = 6, GR_TUNE_RESIDENT_GROUPS = 7,
        GR_TUNE_RESIDENT_STREAMS = 8, GR_TUNE_RESIDENT_FILL = 9, GR_TUNE_PAIRDIST_SYMMETRIC = 10, GR_TUNE_RESIDENT_WG_GROUPS = 11,
-       GR_TUNE_RMSD_FAST = 12, GR_TUNE_RMSD_FAST_MIN = 13, GR_TUNE_RESIDENT_METRO_NS = 18,
+       GR_TUNE_RMSD_FAST = 12, GR_TUNE_RMSD_FAST_MIN = 13, GR_TUNE_RESIDENT_METRO_NS = 18, GR_TUNE_RESIDENT_FIT_LAST = 19,
        GR_TUNE_MASKED_SELECTIONS = 15 /* 1 (default): a scattered selection that covers at least an eighth of the atoms between its first and its last one (>= 4096
                                          atoms) also gets a bit mask, and RMSD / RMSD-fit / get_com read its span coalesced instead of gathering it atom by atom;
                                          0: groups created afterwards keep to their index lists.  Same results to rounding. */,

@@ -421,3 +421,34 @@ def test_an_atom_without_position_next_to_the_selections_edge(G, resident):
             fin = np.isfinite(frames[f][:, 0])
             assert np.abs(got[fin] - want[fin]).max() <= 5e-5 and np.isnan(got[~fin]).all()
     plan.close(); ref.close(); cur.close()
+
+
+def test_step_order_and_metronome_change_nothing_but_the_pace(G):
+    """Round 5's two knobs of the resident pass -- the order of a turn (GR_TUNE_RESIDENT_FIT_LAST: fit first / sums first) and the
+    metronome of the row requests (GR_TUNE_RESIDENT_METRO_NS: off / a period the launch keeps easily / one it cannot keep) -- move work
+    in time, never in value: RMSDs and fitted coordinates of every combination are bit-identical, and the launch reports its pace."""
+    n, nf = 70_001, 23
+    box = W.box_from_lengths_angles([7.0, 6.5, 6.0], [75.0, 80.0, 70.0])
+    masses, cur, ref, ref_pos, frames = _systems(G, n, nf, box, (0, n - 1))
+    plan = G.RMSDPlan(ref, cur, "S")
+    base = None
+    for order in (1, 2):
+        for metro in (1, 30_000, 200, 0):
+            cur.set_tuning(resident=2, resident_fit_last=order, resident_metro_ns=metro)
+            for f in range(nf):
+                cur.set_frame(frames[f], box, slot=f)
+            r, st = plan.rmsd_fit(0, nf)
+            assert (st == 0).all() and cur.stat("res_aborts") == 0
+            got = (np.array(r).view(np.uint32), np.stack([cur.get_positions(f) for f in range(nf)]).view(np.uint32))
+            assert cur.stat("res_metro_period_ns") == (metro if metro >= 100 else 0) and cur.stat("res_last_turn_ns") > 0 and 500 < cur.stat("res_sclk_mhz") < 3000
+            if metro == 30_000:      # a period far above what a turn takes: every slot is waited for, the launch takes as long as the clock says
+                assert cur.stat("res_last_turn_ns") >= 24_000 and cur.stat("res_late_permille") < 100
+            if metro == 200:         # a period no launch can keep: (nearly) every slot is reached late, nothing waits
+                assert cur.stat("res_late_permille") > 500
+            if base is None:
+                base = got
+            assert np.array_equal(got[0], base[0]) and np.array_equal(got[1], base[1]), (order, metro)
+    with pytest.raises(Exception):
+        cur.set_tuning(resident_metro_ns=50)            # neither a switch (0, 1) nor a period
+    with pytest.raises(Exception):
+        cur.set_tuning(resident_fit_last=3)
