@@ -201,6 +201,7 @@ struct gr_rmsd_plan {
     std::vector<float> w_host;   // reference masses of the group, selection order
     GrPlanDev dev = {};
     int exact = 0;
+    bool fit_behind_small = false;          // the last segment queued a fit kernel behind a single-wave kernel and returned on that kernel's flag (gr_rmsd_plan_destroy)
     uint32_t last_fallbacks = 0;
     bool resolved = false;
     uint64_t resolved_epoch = 0;   // context epoch at which w_is_mass was decided
@@ -338,7 +339,8 @@ uint32_t resident_wgs(gr_ctx *c, bool lite, uint32_t nb, const GrSel &sel, uint3
     // and a turn gets shorter with it.  Measured (profiles/r04_hole_sweep.txt, frames/s, two passes / 1024 / 768): 520 k atoms
     // 274 k / 281 k / 291 k, 600 k 242 k / 271 k / 278 k, 650 k 229 k / 268 k / 273 k, 690 k 212 k / 265 k / 267 k.
     uint64_t wgs_used = wgs;
-    if (c->resident == 1 && !c->res_wg_groups && s_max <= 1 && wgs <= 170) {
+    // (the window is a share of the device's workgroups -- two thirds: 170 of MI355X's 256 -- not a constant of one part)
+    if (c->resident == 1 && !c->res_wg_groups && s_max <= 1 && wgs * 3u <= (uint64_t)c->res_max_wgs * 2u) {
         const uint64_t w768 = (groups + 767) / 768;
         if (w768 + 2 <= c->res_max_wgs && w768 <= GR_MAX_CHUNKS) { wgs_used = w768; *groups_wg = 768; }
     }
@@ -1715,6 +1717,10 @@ void gr_rmsd_plan_destroy(gr_rmsd_plan *p) try {
     if (!p) return;
     if (p->target) (void)hipSetDevice(p->target->device);
     if (p->target && (p->target->in_flight == p || p->pend.active)) { (void)hipStreamSynchronize(p->target->stream); if (p->target->in_flight == p) p->target->in_flight = nullptr; if (p->pend.resident) resident_done(p->target); }
+    // a one-frame fit of a small selection returns as soon as its single-wave kernel has flagged the result; the fit kernel queued behind it reads
+    // the plan's reference rows and weights: they are freed only when the stream has run dry (hipFree happens to synchronise the device
+    // today; a pooled or asynchronous free would not)
+    if (p->target && p->fit_behind_small) (void)hipStreamSynchronize(p->target->stream);
     if (p->p_dev) (void)hipFree(p->p_dev);
     if (p->w_dev) (void)hipFree(p->w_dev);
     if (p->p_span_dev) (void)hipFree(p->p_span_dev);
@@ -1895,6 +1901,7 @@ static int segment_begin(gr_rmsd_plan *p, uint32_t s0, uint32_t nb, int fit) {
         k_rmsd_small<0><<<dim3(1), dim3(64), 0, c->stream>>>(c->frames, c->frame_stride, s0, c->masses, sel, c->boxes_dev, p->dev,
                                                          c->state_dev, 0, c->small_state_dev, c->small_flag_dev, q.small_seq);
         if (fit) k_fit_pk<false><<<dim3(fit_grid(c, 1), 1), dim3(GR_WG), 0, c->stream>>>(c->frames, c->frame_stride, s0, (uint32_t)c->n, c->boxes_dev, p->dev, c->state_dev, c->masses, sel, nullptr);
+        p->fit_behind_small = fit != 0;       // (the host returns when the small kernel's flag is seen: this fit may still be reading plan->p_dev / w_dev -- see gr_rmsd_plan_destroy)
         HIPCHK(c, hipGetLastError());
         return GR_OK;
     }
@@ -2995,6 +3002,7 @@ static int xtc_write_slots_device(gr_xtc_writer *w, gr_ctx *c, uint32_t first_sl
     const size_t per_frame = (size_t)n * 30u;
     uint32_t round = (uint32_t)std::max<size_t>(1, std::min<size_t>(n_frames, ((size_t)2 << 30) / per_frame));
     round = std::min<uint32_t>(round, (uint32_t)std::max<size_t>(8, ((size_t)64 << 20) / ((size_t)n * 4u)));
+    round = std::min<uint32_t>(round, 65535u);      // (a round's frames are the y dimension of the kernels' grids: a small group written from very many slots)
     int st;
     if ((st = xe_reserve(c, 0, (size_t)round * n * 12u)) || (st = xe_reserve(c, 1, (size_t)round * n * 8u)) || (st = xe_reserve(c, 2, (size_t)round * n * 8u)) ||
         (st = xe_reserve(c, 3, (size_t)round * n * 2u + 16u)) || (st = xe_reserve(c, 4, (size_t)round * (sizeof(GrXencHdr) + 8u)))) {
@@ -3026,10 +3034,12 @@ static int xtc_write_slots_device(gr_xtc_writer *w, gr_ctx *c, uint32_t first_sl
         HIPCHK(c, hipMemcpyAsync(hdr_dev, hdr, (size_t)nf * sizeof(GrXencHdr), hipMemcpyHostToDevice, c->stream));
         k_xenc_quant<<<dim3(std::min<uint32_t>((n + 255u) / 256u, 2048u), nf), dim3(256), 0, c->stream>>>(c->frames, c->frame_stride, s0, sel, n, precision, ints, hdr_dev);
         k_xenc_enc<<<dim3(std::min<uint32_t>((n + 255u) / 256u, 2048u), nf), dim3(256), 0, c->stream>>>(ints, n, hdr_dev, enc);
-        k_xenc_plan<<<dim3(nf), dim3(256), 0, c->stream>>>(enc, n, hdr_dev, runs, meta);
+        k_xenc_plan<<<dim3(nf), dim3(256), 0, c->stream>>>(enc, n, hdr_dev, runs, meta, ri == 0 ? 1 : 0);
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipMemcpyAsync(hdr, hdr_dev, (size_t)nf * sizeof(GrXencHdr), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
+        // a first round of dense chains (k_xenc_plan declined them): nothing is in the file yet, the host encoders take the whole call
+        if (ri == 0) { bool dense = false; for (uint32_t f = 0; f < nf; ++f) dense = dense || (hdr[f].flags & 2u) != 0u; if (dense) { *declined = true; return GR_OK; } }
         // frames up to the first one the format cannot hold (exactly what a loop of write_frame calls would leave in the file)
         uint32_t n_good = 0; uint32_t max_runs = 0; unsigned long long total = 0;
         for (; n_good < nf; ++n_good) {

@@ -34,7 +34,7 @@
 struct GrXencHdr {
     int mn[3], mx[3];
     uint32_t mindiff;          // smallest L1 step between consecutive atoms, clamped to INT_MAX
-    uint32_t flags;            // bit 0: some coordinate does not fit the format's integers (the frame is refused)
+    uint32_t flags;            // bit 0: some coordinate does not fit the format's integers (the frame is refused); bit 1: k_xenc_plan declined the frame (one dense chain)
     int smallidx0;             // the small-range index the frame starts with (header field)
     uint32_t n_runs;
     uint32_t n_bits;           // length of the bit stream
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256) void k_xenc_enc(const int *__restrict__ ints, 
 // by thread 0 alone, as before.
 struct GrXencSeg { uint32_t runs, bits; uint16_t packed; };     // packed: exit index (4) | first k (4) << 4 | (first step + 1) << 8 | last k << 10
 __global__ __launch_bounds__(256) void k_xenc_plan(const unsigned long long *__restrict__ enc, uint32_t n, GrXencHdr *__restrict__ hdr,
-                                                   GrXencRun *__restrict__ runs, uint16_t *__restrict__ meta) {
+                                                   GrXencRun *__restrict__ runs, uint16_t *__restrict__ meta, int decline_dense) {
     const uint32_t frame = blockIdx.x, t = threadIdx.x;
     const unsigned long long *E = enc + (size_t)frame * n;
     GrXencRun *R = runs + (size_t)frame * n;
@@ -257,6 +257,19 @@ __global__ __launch_bounds__(256) void k_xenc_plan(const unsigned long long *__r
     while (nxt < T && anchor[nxt] == NONE) ++nxt;
     const uint32_t group = nxt - owner, rank = t - owner;
     const uint32_t seg_a = anchor[owner], seg_e = nxt < T ? anchor[nxt] : n;
+    // A segment is walked by ONE thread (nine times over for the summaries, shared out over nine threads at most): a frame whose atoms
+    // are one dense chain -- a protein-only output: no atom farther than `larger` from its predecessor, so no place where a run must
+    // start -- is a single walk of ~0.6 us per run, several ms per 1e5 atoms, where 16 host encoder threads need ~1.  With `decline_dense`
+    // (the host sets it for a call's first round, before anything is in the file) such a frame is flagged (bit 1) instead of walked,
+    // and the host encoders take the call.
+    if (decline_dense && n >= 32768u) {
+        __shared__ uint32_t longest;
+        if (t == 0) longest = 0u;
+        __syncthreads();
+        if (t == owner) atomicMax(&longest, seg_e - seg_a);
+        __syncthreads();
+        if (longest > n / 2u) { if (t == 0) { H.flags |= 2u; H.smallidx0 = C.smallidx0; H.n_runs = 0; H.n_bits = 0; } return; }
+    }
     // one walk of [seg_a, seg_e): `s` = entry index - minidx, `pk` = the previous run's length (255: none); EMIT: descriptors out
     auto walk = [&](uint32_t s, uint32_t pk, bool emit, uint32_t run0, uint32_t bit0, GrXencSeg &out) {
         const uint32_t e = seg_e;

@@ -102,3 +102,52 @@ def test_config2_peptide_rmsd_to_first_frame(G, aa):
     for f in (0, 7, 20):
         assert abs(cur.calc_rmsd(ref, "all", slot=f) - e["c2_peptide_rmsd_to_first_frame"][f]) <= TOL
     plan.close(); ref.close(); cur.close()
+
+
+@pytest.mark.gpu
+def test_config2_as_a_selection_inside_the_full_system(G, aa):
+    """configs[1] at its real shape: the 32 817-atom membrane system, `@protein` chosen by the selection language
+    (groups.rs:36-92, select/mod.rs) out of the structure's residue names, frames 0 and 20 of aa_membrane_peptide.xtc (fixture
+    aa_full.npz, decoded with the reference's vendored xdrfile: tests/golden/make_c2_full_fixture.py).  System::calc_rmsd and
+    calc_rmsd_and_fit (rmsd.rs:75-166; the iterator form :1202-1226) against the committed golden RMSD of frame 20, the oracle on the
+    full system, and -- for the fit -- every one of the 32 817 atoms (rmsd.rs:508-528 moves the whole system, not the selection)."""
+    import types
+    from groan_rs_amd.select import group_create
+    e = expected()
+    d = np.load(os.path.join(GOLD, "aa_full.npz"))
+    frames, boxes = d["frames"], d["boxes9"]
+    n = frames.shape[1]
+    assert n == 32817 and list(d["frame_index"]) == [0, 20]
+    structure = types.SimpleNamespace(n_atoms=n, resid=d["resid"], atomid=d["atomid"], resname=[x.decode() for x in d["resname"]], atomname=[x.decode() for x in d["atomname"]])
+    masses = aa["masses"]
+    ref = G.System(n, masses=masses, box=boxes[0], positions=frames[0])
+    cur = G.System(n, masses=masses, n_slots=2)
+    for f in range(2):
+        cur.set_frame(frames[f], boxes[f], slot=f)
+    for s in (ref, cur):
+        group_create(s, "Protein", "@protein", structure)
+    idx = np.array(list(cur.group_container("Protein")), np.int64)
+    assert idx.size == 363 and np.array_equal(idx, np.arange(363))                      # bit-exact selection (SURVEY 8c: indices 0-362)
+    # the same coordinates as the peptide-only fixture the golden values were computed from
+    assert np.array_equal(frames[0][:363], aa["traj_peptide"][0]) and np.array_equal(frames[1][:363], aa["traj_peptide"][20])
+    want = [e["c2_peptide_rmsd_to_first_frame"][0], e["c2_peptide_rmsd_to_first_frame"][20]]
+    for small in (4096, 0):                                                            # the single-wave call and the batched kernels
+        cur.set_tuning(small_calls=small)
+        for f in range(2):
+            assert abs(cur.calc_rmsd(ref, "Protein", slot=f) - want[f]) <= TOL, (small, f)
+        plan = G.RMSDPlan(ref, cur, "Protein")
+        r, st = plan.rmsd(0, 2)
+        assert (st == 0).all() and np.abs(r - np.array(want, np.float32)).max() <= TOL
+        plan.close()
+    # the oracle inside the full system, and the fit of ALL atoms
+    for small in (4096, 0):
+        cur.set_tuning(small_calls=small)
+        cur.set_frame(frames[1], boxes[1], slot=1)
+        ro, fitted = O.calc_rmsd_and_fit(frames[0], masses, idx, boxes[0], frames[1], masses, idx, boxes[1])
+        assert abs(ro - want[1]) <= 2e-6
+        got = cur.calc_rmsd_and_fit(ref, "Protein", slot=1)
+        assert abs(got - want[1]) <= TOL
+        out = cur.get_positions(1)
+        assert out.shape == (n, 3) and np.abs(out - fitted).max() <= 5e-5, (small, float(np.abs(out - fitted).max()))
+        assert np.abs(out[363:] - frames[1][363:]).max() > 1e-3                          # (the membrane and the water moved with the peptide)
+    ref.close(); cur.close()

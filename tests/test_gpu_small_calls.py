@@ -19,6 +19,29 @@ def G():
     return g
 
 
+@pytest.fixture(scope="module", autouse=True)
+def warm_single_wave_kernels(G):
+    """Every single-wave kernel variant once, untimed, on a throwaway context: the FIRST launch of a kernel in a process (code-object load
+    on a cold box) can outlast the 20 ms the host polls for a small call's result -- the call then synchronises the stream instead and
+    counts it (GR_STAT_SMALL_SYNC_FALLBACKS).  With the kernels loaded, the tests below assert that counter stays 0 on their own
+    contexts: the polling path must be the one the tests exercise (round 4 had dropped the assertion instead)."""
+    box = O.box_from_lengths_angles([6.0, 6.0, 6.0], [60.0, 60.0, 90.0])
+    s, frames, m, rng = make(G, 2000, 2, box, 1)
+    s.group_create_from_ranges("a", [(10, 300)]); s.group_create_from_indices("b", np.unique(rng.integers(0, 2000, 200)))
+    ref = G.System(2000, masses=m, box=box, positions=frames[2])
+    ref.group_create_from_ranges("a", [(10, 300)]); ref.group_create_from_indices("b", np.unique(rng.integers(0, 2000, 200)))
+    for name in ("a", "b"):
+        for fn in ("group_get_com", "group_get_center", "group_estimate_com", "group_estimate_center", "group_get_com_naive", "group_get_center_naive"):
+            if hasattr(s, fn):
+                getattr(s, fn)(name, slot=0)
+        s.group_get_com_batch(name, 0, 2)
+    s.group_distance("a", "b", G.Dimension.XYZ, slot=0)
+    plan = G.RMSDPlan(ref, s, "a")
+    plan.rmsd(0, 1); plan.rmsd(0, 2); plan.rmsd_fit(0, 1); plan.rmsd_fit(0, 2)
+    plan.close(); ref.close(); s.close()
+    yield
+
+
 BOXES = {
     "orthorhombic": ([6.44, 6.76, 7.26], [90.0, 90.0, 90.0]),
     "dodecahedron": ([7.0, 7.0, 7.0], [60.0, 60.0, 90.0]),
@@ -65,8 +88,7 @@ def test_centres_of_small_selections(G, cell):
                 ref = getattr(s, fn)(name, slot=f)
                 s.set_tuning(small_calls=4096)
                 assert np.abs(got - ref).max() <= 2e-6, (name, fn, f, got, ref)
-    # (GR_STAT_SMALL_SYNC_FALLBACKS is not asserted: a cold box may take more than the 20 ms of polling for a kernel's first launch --
-    #  the call then synchronises the stream and is as right as any other)
+    assert s.stat("small_sync_fallbacks") == 0          # (the kernels were loaded by warm_single_wave_kernels: every call above was polled out)
     # a batch of such frames equals its per-frame calls bit for bit (one wave per frame, the same kernel stages)
     for name in ("block", "scattered"):
         got, st = s.group_get_com_batch(name, 0, nf)
@@ -131,6 +153,7 @@ def test_rmsd_of_small_selections(G, cell):
             s.set_frame(frames[f], box, slot=f)          # (the next selection starts from the unfitted frames again)
         plan2.close(); twin.close()
         plan.close()
+    assert s.stat("small_sync_fallbacks") == 0
     ref.close(); s.close()
 
 

@@ -143,3 +143,38 @@ def test_randomised_systems(G, tmp_path):
         dev, e1, took = _write(G, tmp_path, "r%d" % k, frames, box, 1, precision)
         host, e0, _ = _write(G, tmp_path, "r%d" % k, frames, box, 0, precision)
         assert e1 == e0 and dev == host, (k, n, nf, scale, precision, e1, e0)
+
+
+def test_a_small_group_written_from_more_slots_than_a_grid_has_rows(G, tmp_path):
+    """12 atoms of a ligand out of 66 000 resident frames: the device encoder takes its frames as the y dimension of its grids, which
+    ends at 65 535 -- the rounds must be cut there (the launch failed with hipErrorInvalidConfiguration, the call returned
+    GR_E_HIP and the host encoders were never tried).  Same bytes as the host encoders."""
+    n, nf = 300, 66_000
+    box = np.array([6, 6, 6, 0, 0, 0, 0, 0, 0], np.float32)
+    out = {}
+    for device in (1, 0):
+        s = G.System(n, n_slots=nf + 1)
+        s.set_tuning(xtc_device_encode=device)
+        s.synth_reference(nf, box, 1.0, 11)
+        s.synth_frames(nf, 0, nf, 0, 0.05, 11)
+        s.group_create_from_ranges("L", [(10, 21)])
+        path = tmp_path / ("many_%d.xtc" % device)
+        with G.XtcWriter(path) as w:
+            w.write_slots(s, 0, nf, group="L", steps=np.arange(nf, dtype=np.int64), times=np.arange(nf, dtype=np.float32), precision=1000.0, host_threads=4)
+        out[device] = (open(path, "rb").read(), s.stat("xtc_device_frames"))
+        s.close()
+    assert out[1][1] == nf and out[0][1] == 0
+    assert out[1][0] == out[0][0] and len(out[0][0]) > nf * 60
+
+
+def test_a_frame_that_is_one_dense_chain_goes_to_the_host_encoders(G, tmp_path):
+    """a protein-only output has no atom far from its predecessor: no place where a run MUST start, so the device planner would walk the
+    whole frame with one thread.  The first round declines such frames and the host encoders write the call: same bytes,
+    `xtc_device_frames` stays 0; a chain that is a third of the frame (the case above) still runs on the device."""
+    rng = np.random.default_rng(21)
+    n, nf = 40_000, 6
+    frames = [(5.0 + np.cumsum(rng.normal(0, 0.06, (n, 3)), axis=0)).astype(np.float32) for _ in range(nf)]
+    box = np.array([50, 50, 50, 0, 0, 0, 0, 0, 0], np.float32)
+    dev, e1, took = _write(G, tmp_path, "chain", frames, box, 1, 1000.0)
+    host, e0, _ = _write(G, tmp_path, "chain", frames, box, 0, 1000.0)
+    assert e1 is None and e0 is None and took == 0 and dev == host and len(dev) > 0
