@@ -173,7 +173,10 @@ def test_a_frame_that_is_one_dense_chain_goes_to_the_host_encoders(G, tmp_path):
     `xtc_device_frames` stays 0; a chain that is a third of the frame (the case above) still runs on the device."""
     rng = np.random.default_rng(21)
     n, nf = 40_000, 6
-    frames = [(5.0 + np.cumsum(rng.normal(0, 0.06, (n, 3)), axis=0)).astype(np.float32) for _ in range(nf)]
+    def chain():    # bonded neighbours: every step ~0.1 nm long (so the frame's smallest step, which sets the range of the small-atom index, is large and
+        u = rng.normal(0, 1, (n, 3)); u /= np.linalg.norm(u, axis=1)[:, None]      # `larger` -- the reach of a run -- covers every step)
+        return (25.0 + np.cumsum(u * rng.uniform(0.09, 0.11, (n, 1)), axis=0)).astype(np.float32)
+    frames = [chain() for _ in range(nf)]
     box = np.array([50, 50, 50, 0, 0, 0, 0, 0, 0], np.float32)
     dev, e1, took = _write(G, tmp_path, "chain", frames, box, 1, 1000.0)
     host, e0, _ = _write(G, tmp_path, "chain", frames, box, 0, 1000.0)
