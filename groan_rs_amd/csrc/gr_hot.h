@@ -65,7 +65,7 @@ struct GrSumsPk {
 
 // the sums the closed-form RMSD needs on top of the rotation's (k_sums_pk<false, true>): B = sum (w p) v^T, sum w |v|^2 -- f32 products
 // in SHORT chains (GR_RMSD_FLUSH trips = 8 atoms per half) that are widened to fp64 per lane before they grow: see k_sums_pk
-struct GrRmsdPk { gr_v2f b[9]; gr_v2f wvv; };
+struct GrRmsdPk { gr_v2f b[9]; gr_v2f wvv; gr_v2f wvb[2]; gr_v2f trb; };     // wvb: sum m |v|^2 once more, as two chains (atoms 01 / atoms 23 of every trip); trb: tr B = sum m (p . v) with the products associated the other way: the rounding probes
 #ifndef GR_RMSD_FLUSH
 #define GR_RMSD_FLUSH 4            // trips (4 atoms per lane each) between two flushes of the f32 chains into the lane's fp64 sums
 #endif
@@ -91,7 +91,7 @@ __device__ __forceinline__ void gr_image_pair(gr_v2f &vx, gr_v2f &vy, gr_v2f &vz
 // two atoms: v = image of (x - g) nearest to g, then every sum.  `p*` = reference coordinates (NOREF: unused), m = masses.
 template <bool NOREF, bool RMSD = false>
 __device__ __forceinline__ void gr_sums_pair(GrSumsPk &S, gr_v2f x, gr_v2f y, gr_v2f z, gr_v2f px, gr_v2f py, gr_v2f pz, gr_v2f m,
-                                             const GrBoxU &B, const GrBox *__restrict__ boxp, float gx, float gy, float gz, GrRmsdPk *Rm = nullptr) {
+                                             const GrBoxU &B, const GrBox *__restrict__ boxp, float gx, float gy, float gz, GrRmsdPk *Rm = nullptr, int half = 0) {
     gr_v2f vx = x - gr_v2(gx), vy = y - gr_v2(gy), vz = z - gr_v2(gz);
     gr_image_pair(vx, vy, vz, B, boxp);
     // fractional coordinates of v: moments + extents feed the image proof (gr_finalize_math)
@@ -117,7 +117,10 @@ __device__ __forceinline__ void gr_sums_pair(GrSumsPk &S, gr_v2f x, gr_v2f y, gr
         Rm->b[0] = gr_v2_fma(wx, vx, Rm->b[0]); Rm->b[1] = gr_v2_fma(wx, vy, Rm->b[1]); Rm->b[2] = gr_v2_fma(wx, vz, Rm->b[2]);
         Rm->b[3] = gr_v2_fma(wy, vx, Rm->b[3]); Rm->b[4] = gr_v2_fma(wy, vy, Rm->b[4]); Rm->b[5] = gr_v2_fma(wy, vz, Rm->b[5]);
         Rm->b[6] = gr_v2_fma(wz, vx, Rm->b[6]); Rm->b[7] = gr_v2_fma(wz, vy, Rm->b[7]); Rm->b[8] = gr_v2_fma(wz, vz, Rm->b[8]);
-        Rm->wvv = gr_v2_fma(m, gr_v2_fma(vx, vx, gr_v2_fma(vy, vy, vz * vz)), Rm->wvv);
+        const gr_v2f vv = gr_v2_fma(vx, vx, gr_v2_fma(vy, vy, vz * vz));
+        Rm->wvv = gr_v2_fma(m, vv, Rm->wvv);
+        Rm->wvb[half] = gr_v2_fma(m, vv, Rm->wvb[half]);
+        Rm->trb = gr_v2_fma(m, gr_v2_fma(px, vx, gr_v2_fma(py, vy, pz * vz)), Rm->trb);      // = b[0] + b[4] + b[8], whose terms are (m p) v: other roundings of the same numbers
     }
 }
 
@@ -144,7 +147,7 @@ __global__ __launch_bounds__(GR_WG) void k_sums_pk(
     static_assert(!(NOREF && RMSD), "the RMSD needs the reference");
     __shared__ double lds[(GR_WG / 64) * GR_ACC_K];
     __shared__ double lds_pd[RMSD ? (GR_WG / 64) * 16 : 1];
-    __shared__ double lds_acc[RMSD ? 13 * GR_WG : 1];        // RMSD: the lanes' fp64 sums [13][GR_WG] (26 KiB: no registers, one ds_add_f64 per value and flush)
+    __shared__ double lds_acc[RMSD ? 15 * GR_WG : 1];        // RMSD: the lanes' fp64 sums [13][GR_WG] + the two rounding probes (30 KiB: no registers, one ds_add_f64 per value and flush)
     const uint32_t frame = blockIdx.y, chunk = blockIdx.x, nchunks = gridDim.x;
     const float *xyz = frames + (size_t)(first_slot + frame) * frame_stride;
     const GrBox *boxp = boxes + first_slot + frame;
@@ -166,12 +169,21 @@ __global__ __launch_bounds__(GR_WG) void k_sums_pk(
     if (RMSD) {
 #pragma unroll
         for (int k = 0; k < 9; ++k) Rm.b[k] = gr_v2(0.0f);
-        Rm.wvv = gr_v2(0.0f);
+        Rm.wvv = Rm.wvb[0] = Rm.wvb[1] = Rm.trb = gr_v2(0.0f);
 #pragma unroll
-        for (int k = 0; k < 13; ++k) lds_acc[k * GR_WG + threadIdx.x] = 0.0;
+        for (int k = 0; k < 15; ++k) lds_acc[k * GR_WG + threadIdx.x] = 0.0;
     }
     auto widen = [&](int k, gr_v2f v) { (void)__hip_atomic_fetch_add(&lds_acc[k * GR_WG + threadIdx.x], (double)(v.x + v.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); };
     auto flush = [&]() {
+        // the probe: the same eight terms summed as two chains of four -- what the two associations differ by is a sample of the chains' rounding
+        (void)__hip_atomic_fetch_add(&lds_acc[13 * GR_WG + threadIdx.x], (double)(Rm.wvv.x + Rm.wvv.y) - ((double)(Rm.wvb[0].x + Rm.wvb[0].y) + (double)(Rm.wvb[1].x + Rm.wvb[1].y)),
+                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        Rm.wvb[0] = Rm.wvb[1] = gr_v2(0.0f);
+        // ... and the trace of B against sum m (p . v): the same numbers with the products taken in the other order -- a sample of what forming
+        // the TERMS in f32 costs (m p is rounded before it meets v), which repeats from atom to atom when the coordinates do
+        (void)__hip_atomic_fetch_add(&lds_acc[14 * GR_WG + threadIdx.x], ((double)(Rm.b[0].x + Rm.b[0].y) + (double)(Rm.b[4].x + Rm.b[4].y) + (double)(Rm.b[8].x + Rm.b[8].y)) - (double)(Rm.trb.x + Rm.trb.y),
+                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        Rm.trb = gr_v2(0.0f);
 #pragma unroll
         for (int k = 0; k < 9; ++k) { widen(k, Rm.b[k]); Rm.b[k] = gr_v2(0.0f); }
         widen(9, Rm.wvv); Rm.wvv = gr_v2(0.0f);
@@ -240,8 +252,8 @@ __global__ __launch_bounds__(GR_WG) void k_sums_pk(
                 p.x23.y = k3 ? p.x23.y : 0.f; p.y23.y = k3 ? p.y23.y : 0.f; p.z23.y = k3 ? p.z23.y : 0.f;
             }
         }
-        gr_sums_pair<NOREF, RMSD>(S, q.x01, q.y01, q.z01, p.x01, p.y01, p.z01, gr_v2p(mm.x, mm.y), B, boxp, gx, gy, gz, &Rm);
-        gr_sums_pair<NOREF, RMSD>(S, q.x23, q.y23, q.z23, p.x23, p.y23, p.z23, gr_v2p(mm.z, mm.w), B, boxp, gx, gy, gz, &Rm);
+        gr_sums_pair<NOREF, RMSD>(S, q.x01, q.y01, q.z01, p.x01, p.y01, p.z01, gr_v2p(mm.x, mm.y), B, boxp, gx, gy, gz, &Rm, 0);
+        gr_sums_pair<NOREF, RMSD>(S, q.x23, q.y23, q.z23, p.x23, p.y23, p.z23, gr_v2p(mm.z, mm.w), B, boxp, gx, gy, gz, &Rm, 1);
         if (RMSD && (++trips % GR_RMSD_FLUSH) == 0) flush();
     };
     const uint32_t gstep = nchunks * GR_WG;
@@ -270,7 +282,7 @@ __global__ __launch_bounds__(GR_WG) void k_sums_pk(
         flush();
         double d32[32];
 #pragma unroll
-        for (int k = 0; k < 32; ++k) d32[k] = k < 13 ? lds_acc[k * GR_WG + threadIdx.x] : 0.0;
+        for (int k = 0; k < 32; ++k) d32[k] = k < 15 ? lds_acc[k * GR_WG + threadIdx.x] : 0.0;
         S.mx = gr_v2p((float)d32[10], 0.0f); S.my = gr_v2p((float)d32[11], 0.0f); S.mz = gr_v2p((float)d32[12], 0.0f);
         const double dt = gr_wave_sum_scatter16_f64(d32, lane);           // lane l: the wave total of value l >> 2
         if ((lane & 3u) == 0) lds_pd[wave * 16 + (lane >> 2)] = dt;
@@ -307,6 +319,16 @@ __global__ __launch_bounds__(GR_WG) void k_sums_pk(
     } else if (lane == 44) {
         gr_st_agent(&o.bad_pos, GR_NOIDX);      // no per-atom tests here: a missing position / mass shows up as a NaN sum
         gr_st_agent(&o.bad_mass, GR_NOIDX);
+        if (RMSD) {
+            // the chunk's measured roundings -- sum m |v|^2 as one chain of 8 against two of 4; tr B with the products taken in the other order --
+            // against the model's figure for a chunk of this many atoms, 6e-8 (magnitude of the terms) sqrt(20 / n): see gr_finalize_math<.., FAST>
+            const double d1 = ((lds_pd[13] + lds_pd[16 + 13]) + lds_pd[32 + 13]) + lds_pd[48 + 13], d2 = ((lds_pd[14] + lds_pd[16 + 14]) + lds_pd[32 + 14]) + lds_pd[48 + 14];
+            const double ssum = ((lds_pd[9] + lds_pd[16 + 9]) + lds_pd[32 + 9]) + lds_pd[48 + 9];
+            const double n_chunk = fmax(8.0, (double)(MASK ? sel.span : sel.n) / (double)nchunks);
+            const double expect = 6.0e-8 * 0.5 * (ssum + plan.swpp / (double)nchunks) * sqrt(20.0 / n_chunk);
+            const double dsum = fmax(fabs(d1), fabs(d2));
+            gr_st_agent(&o.rd, expect > 0.0 ? (float)fmin(fabs(dsum) / expect, 1.0e30) : 0.0f);
+        }
     }
     if (fuse) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // every lane's record stores have left

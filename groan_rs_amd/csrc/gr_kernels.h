@@ -475,7 +475,8 @@ __global__ void k_state_reset(GrFrameState *state, uint32_t n) {
 //            that the images chosen about g are the images the reference chooses about its own centre
 //   min/max of v per axis (Cartesian and fractional), first atom without position / mass.
 #define GR_ACC_K 32
-struct GrAccPartial { double s[GR_ACC_K]; float vmin[3], vmax[3], fmin[3], fmax[3]; uint32_t bad_pos, bad_mass; };
+struct GrAccPartial { double s[GR_ACC_K]; float vmin[3], vmax[3], fmin[3], fmax[3]; uint32_t bad_pos, bad_mass;
+                      float rd; uint32_t pad; };   // rd (k_sums_pk<.., RMSD> only): this chunk's MEASURED rounding of its f32 chains, in units of what the random-walk model expects
 
 // ---- per-lane state and per-atom arithmetic of the closed-form single pass
 struct GrA4 { float x[4], y[4], z[4], m[4], px[4], py[4], pz[4], w[4]; uint32_t i[4]; bool ok[4]; };   // four atoms of one lane
@@ -702,7 +703,7 @@ __global__ __launch_bounds__(GR_WG) void k_rmsd_accum(
 template <int MODE, bool LITE = false, bool NOREF = false, bool FAST = false>
 __device__ inline void gr_finalize_math(const double *acc, const float mn[3], const float mx[3], const float fmn[3], const float fmx[3],
                                         uint32_t bad_pos, uint32_t bad_mass, const GrBox &b, const GrPlanDev &plan,
-                                        const double g[3], uint32_t n_sel, GrFrameState &st) {
+                                        const double g[3], uint32_t n_sel, GrFrameState &st, float rd = 0.0f) {
     if (MODE == 0) {
         // get_com: positions of the whole group are checked before any mass (iterators.rs:1405-1422)
         if (bad_pos != GR_NOIDX) { st.status = 6; st.err_index = bad_pos; return; }
@@ -838,7 +839,14 @@ __device__ inline void gr_finalize_math(const double *acc, const float mn[3], co
             // larger than either).  A frame is kept when plan.fast_sigmas (default 6) sigma move its rmsd by less than 2.5e-6 nm:
             // d(rmsd) = d(r2) / (2 rmsd); at that limit the largest deviation seen so far would be 9e-7 nm.
             const double S = (plan.swpp + acc[22]) / plan.sw;
-            const double sigma = 6.0e-8 * S * sqrt(20.0 / (double)n_sel);
+            // THE MODEL IS ONLY A MODEL (round 5): coordinates on a lattice -- a crystal, or simply every xtc frame's multiples of 0.001 nm
+            // against a regular reference -- repeat the same values, and with them the same roundings, thousands of times: the chains' errors
+            // then add up instead of walking (measured, tests/test_gpu_rmsd_fast.py: a simple-cubic lattice of 1e6 atoms against its displaced,
+            // quantised copy: |fast - exact| = 4.7e-6 nm where the model said 1.3e-7).  So the pass MEASURES its own rounding: every lane sums
+            // sum m |v|^2 twice, as one f32 chain of 8 terms and as two chains of 4 (a different association of the same terms), and each
+            // chunk reports the difference of its two totals in units of what the model expects of it (`rd`, the largest chunk's).  Random
+            // roundings give rd ~ 1 (at most ~3 over a frame's chunks); coherent ones gave 30-100: sigma is scaled by rd / 3 beyond that.
+            const double sigma = 6.0e-8 * S * sqrt(20.0 / (double)n_sel) * ((double)rd > 3.0 ? (double)rd / 3.0 : 1.0);
             if (plan.fast_sigmas > 0.0f && (!(r2 > 0.0) || !((double)plan.fast_sigmas * sigma < 5.0e-6 * sqrt(r2)))) { st.status = GR_ST_REDO_EXACT; return; }
         }
         if (r2 < 0.0) r2 = 0.0;
@@ -920,6 +928,7 @@ __device__ __forceinline__ void gr_finalize_frame_lite(const GrAccPartial *parti
             e[a] = gr_fmaxf(e[a], -p.vmin[a]); e[3 + a] = gr_fmaxf(e[3 + a], p.vmax[a]);
             e[6 + a] = gr_fmaxf(e[6 + a], -p.fmin[a]); e[9 + a] = gr_fmaxf(e[9 + a], p.fmax[a]);
         }
+        if (RMSD) e[12] = gr_fmaxf(e[12], p.rd);
         bad_pos = min(bad_pos, p.bad_pos); bad_mass = min(bad_mass, p.bad_mass);
     }
     const double t = gr_wave_sum_scatter32_f64(s, lane);
@@ -944,7 +953,7 @@ __device__ __forceinline__ void gr_finalize_frame_lite(const GrAccPartial *parti
     float g0x, g0y, g0z;
     gr_pos_load(xyz, sel.contiguous ? sel.start : sel.idx[0], g0x, g0y, g0z);
     const double g[3] = { g0x, g0y, g0z };
-    gr_finalize_math<0, !RMSD, NOREF, RMSD>(acc, mn, mx, fmn, fmx, bad_pos, bad_mass, boxes[first_slot + frame], plan, g, sel.n, st);
+    gr_finalize_math<0, !RMSD, NOREF, RMSD>(acc, mn, mx, fmn, fmx, bad_pos, bad_mass, boxes[first_slot + frame], plan, g, sel.n, st, RMSD ? ext[12] : 0.0f);
 }
 
 template <bool NOREF = false, bool RMSD = false>

@@ -186,3 +186,71 @@ def test_what_the_pass_must_refuse(G):
         assert abs(float(r[1]) - ro) <= 1e-5, (name, float(r[1]), ro)
         plan.close()
     ref.close(); cur.close()
+
+
+def _lattice(n, spacing, centre):
+    """n points of a simple-cubic lattice (spacing nm) filling a cube about `centre`: identical fractional parts along every row -- the
+    opposite of the Gaussian blobs the pass's error estimate was calibrated on"""
+    k = int(np.ceil(n ** (1.0 / 3.0)))
+    g = np.stack(np.meshgrid(np.arange(k), np.arange(k), np.arange(k), indexing="ij"), -1).reshape(-1, 3)[:n].astype(np.float64)
+    return ((g - (k - 1) / 2.0) * spacing + np.asarray(centre, np.float64))
+
+
+def _rot(rng):
+    q = rng.normal(size=4); q /= np.linalg.norm(q)
+    a, b, c, d = q
+    return np.array([[a * a + b * b - c * c - d * d, 2 * (b * c - a * d), 2 * (b * d + a * c)], [2 * (b * c + a * d), a * a - b * b + c * c - d * d, 2 * (c * d - a * b)],
+                     [2 * (b * d - a * c), 2 * (c * d + a * b), a * a - b * b - c * c + d * d]])
+
+
+@pytest.mark.parametrize("n", [20_000, 1_000_000])
+def test_hostile_inputs_lattices_and_quantised_coordinates(G, n):
+    """The pass keeps a frame on a STATISTICAL model of what its f32 chains lose (independent roundings, a random walk: gr_kernels.h,
+    gr_finalize_math<.., FAST>), calibrated on Gaussian-noise blobs.  Inputs whose roundings are NOT independent:
+      * every coordinate a multiple of 0.001 nm -- what every xtc file delivers (precision 1000);
+      * a crystalline reference: a simple-cubic lattice, thousands of atoms sharing each coordinate value;
+      * frames that are that lattice rotated and displaced (large products, structured), the lattice plus 1e-4 nm of noise (rmsd ~ 1e-4:
+        the guard must hand it to the exact pass or be right), and the lattice itself (rmsd 0).
+    For every frame: |fast - exact| <= 2.5e-6 nm -- the guard a kept frame was kept under -- and <= 1e-5 nm against the oracle (fp64 sums)."""
+    rng = np.random.default_rng(n)
+    spacing = 0.300 if n <= 20_000 else 0.100
+    L = 40.0
+    box = W.box_from_lengths_angles([L, L, L], [90.0, 90.0, 90.0])
+    centre = np.array([L / 2, L / 2, L / 2])
+    refx = np.round(_lattice(n, spacing, centre) * 1000.0) / 1000.0
+    masses = W.masses_cycle(n)
+    frames = []
+    # 0: the lattice itself; 1: + 1e-4 nm noise; 2: + 0.02 nm noise, quantised; 3-4: rotated about its centre and displaced, quantised; 5: a
+    # PBC-broken copy (displaced across the cell faces and wrapped), quantised
+    frames.append(refx.copy())
+    frames.append(refx + rng.normal(0, 1e-4, refx.shape))
+    frames.append(np.round((refx + rng.normal(0, 0.02, refx.shape)) * 1000.0) / 1000.0)
+    for _ in range(2):
+        R = _rot(rng)
+        frames.append(np.round((((refx - centre) @ R.T) + centre + rng.uniform(-3, 3, 3) + rng.normal(0, 0.01, refx.shape)) * 1000.0) / 1000.0)
+    moved = np.round((refx + np.array([L / 2 - 1.0, 3.0, -L / 2 + 2.0]) + rng.normal(0, 0.03, refx.shape)) * 1000.0) / 1000.0
+    frames.append(np.mod(moved, L))
+    nf = len(frames)
+    frames = [f.astype(np.float32) for f in frames]
+    cur = G.System(n, masses=masses, n_slots=nf)
+    for f in range(nf):
+        cur.set_frame(frames[f], box, slot=f)
+    ref = G.System(n, masses=masses, box=box, positions=refx.astype(np.float32))
+    plan = G.RMSDPlan(ref, cur, "all")
+    r, st = plan.rmsd(0, nf)
+    kept, redone = cur.stat("rmsd_fast_frames"), cur.stat("rmsd_exact_redos")
+    assert (st == 0).all() and kept + redone + plan.last_fallbacks() >= nf, (st, kept, redone)
+    cur.set_tuning(rmsd_fast=0)
+    r0, st0 = plan.rmsd(0, nf)
+    assert (st0 == 0).all()
+    d = np.abs(np.asarray(r, np.float64) - np.asarray(r0, np.float64))
+    assert d.max() <= 2.5e-6, (d, r, r0, kept, redone)
+    idx = np.arange(n)
+    refpos32 = refx.astype(np.float32)
+    with O.acc64():
+        for f in range(nf):
+            ro = O.calc_rmsd(refpos32, masses, idx, box, frames[f], masses, idx, box)[0]
+            assert abs(float(r[f]) - ro) <= 1e-5 and abs(float(r0[f]) - ro) <= 1e-5, (f, float(r[f]), float(r0[f]), ro)
+    # the tiny-rmsd frames are where the estimate matters: they were handed to the exact pass, or kept and right (asserted above)
+    assert redone >= 1 or kept == nf
+    plan.close(); ref.close(); cur.close()
