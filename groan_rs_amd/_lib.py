@@ -73,6 +73,8 @@ SIGNATURES = {
     "gr_group_all_distances": (C.c_int, [C.c_void_p, C.c_uint32, C.c_char_p, C.c_char_p, C.c_int, C.c_void_p, C.c_size_t]),
     "gr_group_all_distances_device": (C.c_int, [C.c_void_p, C.c_uint32, C.c_char_p, C.c_char_p, C.c_int, C.POINTER(C.c_void_p), c_u64p, c_u64p]),
     "gr_group_all_distances_batch_device": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_char_p, C.c_char_p, C.c_int, C.POINTER(C.c_void_p), c_u64p, c_u64p, C.c_void_p]),
+    "gr_group_all_distances_reduce": (C.c_int, [C.c_void_p, C.c_uint32, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_uint32, C.c_void_p, C.c_size_t]),
+    "gr_group_all_distances_reduce_batch": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p]),
     "gr_device_read": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "gr_trr_open": (C.c_void_p, [C.c_char_p, C.POINTER(C.c_int)]),
     "gr_trr_close": (None, [C.c_void_p]),

@@ -1106,7 +1106,7 @@ int gr_group_distance(gr_ctx *c, uint32_t slot, const char *g1, const char *g2, 
 
 static void batch_prechecks(gr_ctx *c, uint32_t s0, uint32_t nb, bool need_box, std::vector<int> &pre, std::vector<std::string> &msg);
 // pair distances of `nb` consecutive slots in one launch; matrices `out_stride` floats apart; -> bad_host[4 f + 0 / 1]
-static int pairdist_launch(gr_ctx *c, uint32_t s0, uint32_t nb, const GrSel &s1, const GrSel &s2, int dim, float *out_dev, size_t out_stride) {
+static int pairdist_launch(gr_ctx *c, uint32_t s0, uint32_t nb, const GrSel &s1, const GrSel &s2, int dim, float *out_dev, size_t out_stride, const GrPdRed *red = nullptr) {
     SlotUse use(c, s0, nb);
     HIPCHK(c, hipMemsetAsync(c->bad_dev, 0xFF, 4 * (size_t)nb * sizeof(uint32_t), c->stream));
     if (s1.n && s2.n) {
@@ -1120,7 +1120,8 @@ static int pairdist_launch(gr_ctx *c, uint32_t s0, uint32_t nb, const GrSel &s1,
         // orthorhombic loops are bound by the stores, and the mirror image's 256-byte runs cost more than half the arithmetic saves
         bool skewed = true;
         for (uint32_t f = 0; f < nb; ++f) skewed = skewed && !c->boxes_host[s0 + f].ortho;
-        const bool self = c->pd_sym && skewed && s1.n == s2.n && s1.contiguous == s2.contiguous && s1.start == s2.start && s1.idx == s2.idx && s1.n >= 4 * GR_PDS_T;
+        const GrPdRed none = { 0, 0, 0.0f, 0u, nullptr, 0 };
+        const bool self = !red && c->pd_sym && skewed && s1.n == s2.n && s1.contiguous == s2.contiguous && s1.start == s2.start && s1.idx == s2.idx && s1.n >= 4 * GR_PDS_T;
         if (self) {
             const uint32_t nbk = (s1.n + GR_PDS_T - 1) / GR_PDS_T;
             dim3 tiles(nbk, nbk, nb);
@@ -1128,9 +1129,14 @@ static int pairdist_launch(gr_ctx *c, uint32_t s0, uint32_t nb, const GrSel &s1,
             else if (ncand <= 8) k_pairdist_sym<8><<<tiles, dim3(GR_WG), 0, c->stream>>>(fr, c->frame_stride, s1, c->boxes_dev + s0, dim, out_dev, out_stride, c->bad_dev);
             else k_pairdist_sym<16><<<tiles, dim3(GR_WG), 0, c->stream>>>(fr, c->frame_stride, s1, c->boxes_dev + s0, dim, out_dev, out_stride, c->bad_dev);
         }
-        else if (ncand <= 4) k_pairdist<4><<<grid, dim3(GR_WG), 0, c->stream>>>(fr, c->frame_stride, s1, s2, c->boxes_dev + s0, dim, out_dev, out_stride, c->bad_dev);
-        else if (ncand <= 8) k_pairdist<8><<<grid, dim3(GR_WG), 0, c->stream>>>(fr, c->frame_stride, s1, s2, c->boxes_dev + s0, dim, out_dev, out_stride, c->bad_dev);
-        else k_pairdist<16><<<grid, dim3(GR_WG), 0, c->stream>>>(fr, c->frame_stride, s1, s2, c->boxes_dev + s0, dim, out_dev, out_stride, c->bad_dev);
+        else if (red) {     // the fused reducers: the same tiles, nothing of the matrix stored
+            if (ncand <= 4) k_pairdist<4, true><<<grid, dim3(GR_WG), 0, c->stream>>>(fr, c->frame_stride, s1, s2, c->boxes_dev + s0, dim, nullptr, 0, c->bad_dev, *red);
+            else if (ncand <= 8) k_pairdist<8, true><<<grid, dim3(GR_WG), 0, c->stream>>>(fr, c->frame_stride, s1, s2, c->boxes_dev + s0, dim, nullptr, 0, c->bad_dev, *red);
+            else k_pairdist<16, true><<<grid, dim3(GR_WG), 0, c->stream>>>(fr, c->frame_stride, s1, s2, c->boxes_dev + s0, dim, nullptr, 0, c->bad_dev, *red);
+        }
+        else if (ncand <= 4) k_pairdist<4><<<grid, dim3(GR_WG), 0, c->stream>>>(fr, c->frame_stride, s1, s2, c->boxes_dev + s0, dim, out_dev, out_stride, c->bad_dev, none);
+        else if (ncand <= 8) k_pairdist<8><<<grid, dim3(GR_WG), 0, c->stream>>>(fr, c->frame_stride, s1, s2, c->boxes_dev + s0, dim, out_dev, out_stride, c->bad_dev, none);
+        else k_pairdist<16><<<grid, dim3(GR_WG), 0, c->stream>>>(fr, c->frame_stride, s1, s2, c->boxes_dev + s0, dim, out_dev, out_stride, c->bad_dev, none);
         HIPCHK(c, hipGetLastError());
     }
     HIPCHK(c, hipMemcpyAsync(c->bad_host, c->bad_dev, 4 * (size_t)nb * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
@@ -1225,6 +1231,66 @@ int gr_group_all_distances(gr_ctx *c, uint32_t slot, const char *g1, const char 
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
     return GR_OK;
+} catch (...) { return gr_abi_guard(); }
+
+// group_all_distances followed by a reduction (analysis.rs:401-427 and what its callers do with the matrix, :1420-1451) WITHOUT the matrix:
+// see k_pairdist<NC, true>.  `out`: GR_PD_MIN / GR_PD_MAX float[n_frames][per_row ? n1 : 1]; GR_PD_COUNT_BELOW uint64_t[n_frames][per_row ? n1 : 1];
+// GR_PD_HIST uint64_t[n_frames][nbins].
+int gr_group_all_distances_reduce_batch(gr_ctx *c, uint32_t first_slot, uint32_t n_frames, const char *g1, const char *g2, int dim, int op, int per_row,
+                                        float param, uint32_t nbins, void *out, size_t out_capacity_bytes, int *status_out) try {
+    int st = slot_check(c, first_slot, n_frames); if (st) return st;
+    (void)hipSetDevice(c->device);
+    const Group *a = find_group(c, g1); if (!a) return fail(c, GR_E_GROUP_NOT_FOUND, g1 ? g1 : "(null)");
+    const Group *b = find_group(c, g2); if (!b) return fail(c, GR_E_GROUP_NOT_FOUND, g2 ? g2 : "(null)");
+    if (dim < 0 || dim > 7) return fail(c, GR_E_INVALID_ARG, "bad dimension");
+    if (op < GR_PD_MIN || op > GR_PD_HIST) return fail(c, GR_E_INVALID_ARG, "unknown reduction");
+    if (op == GR_PD_HIST && (per_row || nbins == 0 || nbins > GR_PDR_MAX_BINS || !(param > 0.0f))) return fail(c, GR_E_INVALID_ARG, "histogram: 1 .. 4096 bins over (0, rmax), never per row");
+    if (a->n == 0) return fail(c, GR_E_EMPTY_GROUP, g1);
+    if (b->n == 0) return fail(c, GR_E_EMPTY_GROUP, g2);
+    const bool wide = op == GR_PD_COUNT_BELOW || op == GR_PD_HIST;          // results the caller receives as 64-bit counts
+    const size_t len = op == GR_PD_HIST ? nbins : (per_row ? a->n : 1);
+    if (!out || out_capacity_bytes < (size_t)n_frames * len * (wide ? 8 : 4)) return fail(c, GR_E_INVALID_ARG, "output buffer too small");
+    const size_t words = len + 1;                                              // (+ 1: the whole-matrix count is one 64-bit word)
+    const GrSel s1 = make_sel(*a), s2 = make_sel(*b);
+    int first_err = GR_OK; std::string first_msg; uint64_t first_idx = 0;
+    std::vector<uint32_t> host;
+    for (uint32_t b0 = 0; b0 < n_frames; b0 += GR_MAX_BATCH) {
+        const uint32_t nb = std::min<uint32_t>(GR_MAX_BATCH, n_frames - b0), s0 = first_slot + b0;
+        st = pairdist_reserve(c, ((size_t)nb * words + 1) & ~(size_t)1); if (st) return st;
+        uint32_t *acc = reinterpret_cast<uint32_t *>(c->pd_out);
+        HIPCHK(c, hipMemsetAsync(acc, op == GR_PD_MIN ? 0xFF : 0x00, (size_t)nb * words * sizeof(uint32_t), c->stream));
+        std::vector<int> pre; std::vector<std::string> msg;
+        batch_prechecks(c, s0, nb, true, pre, msg);
+        const GrPdRed red = { op, per_row ? 1 : 0, op == GR_PD_HIST ? (float)nbins / param : param, nbins, acc, words };
+        st = pairdist_launch(c, s0, nb, s1, s2, dim, nullptr, 0, &red); if (st) return st;
+        host.resize((size_t)nb * words);
+        HIPCHK(c, hipMemcpyAsync(host.data(), acc, host.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        for (uint32_t f = 0; f < nb; ++f) {
+            int s = pre[f];
+            if (s != GR_OK) c->err = msg[f];
+            else s = pairdist_status(c, f, s1);
+            if (s != GR_OK && first_err == GR_OK) { first_err = s; first_msg = c->err; first_idx = c->err_index; }
+            if (status_out) status_out[b0 + f] = s;
+            const uint32_t *h = host.data() + (size_t)f * words;
+            if (wide) {
+                uint64_t *o = static_cast<uint64_t *>(out) + (size_t)(b0 + f) * len;
+                if (op == GR_PD_COUNT_BELOW && !per_row) { uint64_t v; memcpy(&v, h, 8); o[0] = v; }
+                else for (size_t k = 0; k < len; ++k) o[k] = h[k];
+            } else {
+                float *o = static_cast<float *>(out) + (size_t)(b0 + f) * len;
+                for (size_t k = 0; k < len; ++k) o[k] = gr_key_f32(h[k]);
+            }
+        }
+    }
+    if (first_err != GR_OK) { c->err = first_msg; c->err_index = first_idx; }
+    return first_err;
+} catch (...) { return gr_abi_guard(); }
+int gr_group_all_distances_reduce(gr_ctx *c, uint32_t slot, const char *g1, const char *g2, int dim, int op, int per_row, float param, uint32_t nbins,
+                                  void *out, size_t out_capacity_bytes) try {
+    int st = slot_check(c, slot); if (st) return st;
+    st = box_check(c, slot); if (st) return st;
+    return gr_group_all_distances_reduce_batch(c, slot, 1, g1, g2, dim, op, per_row, param, nbins, out, out_capacity_bytes, nullptr);
 } catch (...) { return gr_abi_guard(); }
 
 int gr_atoms_distance(gr_ctx *c, uint32_t slot, uint64_t i1, uint64_t i2, int dim, float *out) try {

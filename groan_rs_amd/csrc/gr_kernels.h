@@ -1239,12 +1239,29 @@ __device__ __forceinline__ gr_v2f gr_pd_tric_vec2(const float4 t, gr_v2f jx, gr_
     return r;
 }
 
-template <int NC>
+// FUSED REDUCERS (round 5; SURVEY 8 A8's extension, analysis.rs:401-427 with its consumers :1420-1451): the same tiles, the same distances, bit
+// for bit -- but instead of 4 n1 n2 bytes of matrix only what the caller wants of it reaches memory: the smallest / largest distance, the number
+// of pairs closer than a cut-off (each per row of the matrix or over all of it), or a histogram.  min / max / counts do not depend on the order
+// of the pairs, so the results EQUAL the same reduction of the full matrix.  Floats travel as order-preserving unsigned keys (atomicMin / Max).
+enum { GR_PDR_MIN = 1, GR_PDR_MAX = 2, GR_PDR_COUNT_BELOW = 3, GR_PDR_HIST = 4 };
+#define GR_PDR_MAX_BINS 4096
+struct GrPdRed { int op, per_row; float param /* cut-off | bins per nm */; uint32_t nbins; uint32_t *out; size_t out_stride; };
+__host__ __device__ __forceinline__ uint32_t gr_f32_key(float f) { uint32_t b; memcpy(&b, &f, 4); return b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u); }
+__host__ __device__ __forceinline__ float gr_key_f32(uint32_t k) { const uint32_t b = k ^ ((k >> 31) ? 0x80000000u : 0xFFFFFFFFu); float f; memcpy(&f, &b, 4); return f; }
+
+template <int NC, bool RED = false>
 __global__ __launch_bounds__(GR_WG) void k_pairdist(
     const float *__restrict__ xyz, size_t frame_stride, GrSel s1, GrSel s2, const GrBox *__restrict__ boxes, int dim,
-    float *__restrict__ out, size_t out_stride, uint32_t *__restrict__ bad_out) {
+    float *__restrict__ out, size_t out_stride, uint32_t *__restrict__ bad_out, GrPdRed red) {
     const GrBox &box = boxes[blockIdx.z];
     xyz += (size_t)blockIdx.z * frame_stride; out += (size_t)blockIdx.z * out_stride; bad_out += 4 * blockIdx.z;
+    __shared__ uint32_t red_row[RED ? GR_PD_TI : 1], red_hist[RED ? GR_PDR_MAX_BINS : 1], red_blk[RED ? GR_WG / 64 : 1];
+    uint32_t red_key = RED && red.op == GR_PDR_MIN ? 0xFFFFFFFFu : 0u, red_cnt = 0u;     // this lane's share of a whole-matrix reduction
+    if (RED) {
+        red.out += (size_t)blockIdx.z * red.out_stride;
+        if (threadIdx.x < GR_PD_TI) red_row[threadIdx.x] = red.op == GR_PDR_MIN ? 0xFFFFFFFFu : 0u;
+        if (red.op == GR_PDR_HIST) for (uint32_t b = threadIdx.x; b < red.nbins; b += GR_WG) red_hist[b] = 0u;
+    }
     __shared__ float ti[GR_PD_TI][4];
     __shared__ uint32_t ldsu[GR_WG / 64];
     __shared__ float4 ttab[NC + 1];            // the image table for per-lane look-ups (1-D / 2-D dimensions of a triclinic cell)
@@ -1293,6 +1310,29 @@ __global__ __launch_bounds__(GR_WG) void k_pairdist(
     const uint32_t ni = min((uint32_t)GR_PD_TI, s1.n > i0 ? s1.n - i0 : 0u);
     const bool vec_ok = ((s2.n & 3u) == 0u);   // rows stay 16-byte aligned
     auto put = [&](uint32_t r, const float (&d)[4]) {
+        if (RED) {
+            // the lane's four distances of row r -> the reduction (columns behind the group's end do not exist)
+            uint32_t key = red.op == GR_PDR_MIN ? 0xFFFFFFFFu : 0u, cnt = 0u;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (j0 + k >= s2.n) continue;
+                if (red.op == GR_PDR_MIN) key = min(key, gr_f32_key(d[k]));
+                else if (red.op == GR_PDR_MAX) key = max(key, gr_f32_key(d[k]));
+                else if (red.op == GR_PDR_COUNT_BELOW) cnt += d[k] < red.param ? 1u : 0u;
+                else if (d[k] >= 0.0f) { const float fb = d[k] * red.param; if (fb < (float)red.nbins) atomicAdd(&red_hist[(uint32_t)fb], 1u); }
+            }
+            if (red.op == GR_PDR_HIST) return;
+            if (!red.per_row) { red_key = red.op == GR_PDR_MIN ? min(red_key, key) : max(red_key, key); red_cnt += cnt; return; }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const uint32_t ok = (uint32_t)__shfl_xor((int)key, off, 64), oc = (uint32_t)__shfl_xor((int)cnt, off, 64);
+                key = red.op == GR_PDR_MIN ? min(key, ok) : max(key, ok); cnt += oc;
+            }
+            if ((threadIdx.x & 63u) == 0u) {
+                if (red.op == GR_PDR_MIN) atomicMin(&red_row[r], key); else if (red.op == GR_PDR_MAX) atomicMax(&red_row[r], key); else atomicAdd(&red_row[r], cnt);
+            }
+            return;
+        }
         float *row = out + (size_t)(i0 + r) * s2.n;
         if (vec_ok && j0 + 3 < s2.n) {
 #if GR_PD_NT
@@ -1358,6 +1398,32 @@ __global__ __launch_bounds__(GR_WG) void k_pairdist(
 #pragma unroll
             for (int k = 0; k < 4; ++k) d[k] = gr_distance<NC>(t.x, t.y, t.z, jx[k], jy[k], jz[k], dim, box);
             put(r, d);
+        }
+    }
+    if (RED) {
+        // the tile's results -> the frame's: one atomic per row / per bin that holds anything / per workgroup
+        __syncthreads();
+        if (red.op == GR_PDR_HIST) {
+            for (uint32_t b = threadIdx.x; b < red.nbins; b += GR_WG) if (red_hist[b]) atomicAdd(red.out + b, red_hist[b]);
+        } else if (red.per_row) {
+            if (threadIdx.x < ni) {
+                uint32_t *o = red.out + i0 + threadIdx.x;
+                if (red.op == GR_PDR_MIN) atomicMin(o, red_row[threadIdx.x]); else if (red.op == GR_PDR_MAX) atomicMax(o, red_row[threadIdx.x]); else atomicAdd(o, red_row[threadIdx.x]);
+            }
+        } else if (ni) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const uint32_t ok = (uint32_t)__shfl_xor((int)red_key, off, 64), oc = (uint32_t)__shfl_xor((int)red_cnt, off, 64);
+                red_key = red.op == GR_PDR_MIN ? min(red_key, ok) : max(red_key, ok); red_cnt += oc;
+            }
+            if ((threadIdx.x & 63u) == 0u) red_blk[threadIdx.x >> 6] = red.op == GR_PDR_COUNT_BELOW ? red_cnt : red_key;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                uint32_t v = red_blk[0];
+                for (int w = 1; w < GR_WG / 64; ++w) v = red.op == GR_PDR_MIN ? min(v, red_blk[w]) : red.op == GR_PDR_MAX ? max(v, red_blk[w]) : v + red_blk[w];
+                if (red.op == GR_PDR_MIN) atomicMin(red.out, v); else if (red.op == GR_PDR_MAX) atomicMax(red.out, v);
+                else atomicAdd(reinterpret_cast<unsigned long long *>(red.out), (unsigned long long)v);     // (a whole matrix may hold more than 2^32 pairs)
+            }
         }
     }
     bad = gr_block_min_u32(bad, ldsu);

@@ -641,6 +641,22 @@ class System:
             self._raise_group(st)
         return dev, int(n1.value), int(n2.value), status
 
+    PD_MIN, PD_MAX, PD_COUNT_BELOW, PD_HIST = 1, 2, 3, 4
+
+    def group_all_distances_reduce(self, group1, group2, op, dim=Dimension.XYZ, per_row=False, param=0.0, nbins=0, first_slot=0, n_frames=1, raise_on_error=True):
+        """what the callers of group_all_distances do with its matrix (analysis.rs:401-427; :1420-1451), without the matrix: `op` = "min" | "max"
+        (float32), "count_below" (entries < param, uint64), "hist" (nbins bins over [0, param), uint64); per_row: one value per atom of
+        group1 instead of one per frame.  -> (array [n_frames, len], status[n_frames]); equal to the reduction of the full matrices"""
+        opc = {"min": self.PD_MIN, "max": self.PD_MAX, "count_below": self.PD_COUNT_BELOW, "hist": self.PD_HIST}[op]
+        length = nbins if opc == self.PD_HIST else (self.group_get_n_atoms(group1) if per_row else 1)
+        out = np.zeros((n_frames, max(length, 1)), np.float32 if opc in (self.PD_MIN, self.PD_MAX) else np.uint64)
+        status = np.zeros(n_frames, np.int32)
+        st = self._lib.gr_group_all_distances_reduce_batch(self._ctx, first_slot, n_frames, group1.encode(), group2.encode(), int(dim), opc, int(bool(per_row)),
+                                                           C.c_float(param), int(nbins), _ptr(out), out.nbytes, _ptr(status))
+        if st != OK and raise_on_error:
+            self._raise_group(st)
+        return out, status
+
     def device_read(self, dev, offset_floats, shape):
         """host copy of `shape` float32 values starting `offset_floats` into a device buffer handed out by the library"""
         out = np.zeros(shape, np.float32)

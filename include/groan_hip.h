@@ -179,6 +179,19 @@ int gr_group_all_distances_device(gr_ctx *ctx, uint32_t slot, const char *group1
  * matrix is undefined -- and the return value is the first frame's error, as for the other batch calls. */
 int gr_group_all_distances_batch_device(gr_ctx *ctx, uint32_t first_slot, uint32_t n_frames, const char *group1, const char *group2, int dim,
                                         float **out_dev, uint64_t *n1, uint64_t *n2, int *status_out);
+/* group_all_distances + what its callers do with the matrix (analysis.rs:401-427; :1420-1451 take its maximum and minimum), WITHOUT the
+ * matrix: the kernels compute the same tiles, bit for bit, and only the reduction reaches memory (a 1e4 x 1e4 matrix is 400 MB per frame).
+ *   GR_PD_MIN / GR_PD_MAX     out = float[n_frames][per_row ? n1 : 1]: the smallest / largest entry of every row, or of the matrix
+ *                             (1-D dimensions are signed, as in the matrix)
+ *   GR_PD_COUNT_BELOW         out = uint64_t[n_frames][per_row ? n1 : 1]: entries < param
+ *   GR_PD_HIST                out = uint64_t[n_frames][nbins]: entries d with 0 <= d, bin (uint32_t)(d * (float)nbins / param) < nbins, i.e.
+ *                             nbins (<= 4096) bins over [0, param); per_row must be 0
+ * Errors and statuses as gr_group_all_distances_batch_device; the results equal the same reduction of that call's matrix exactly. */
+enum { GR_PD_MIN = 1, GR_PD_MAX = 2, GR_PD_COUNT_BELOW = 3, GR_PD_HIST = 4 };
+int gr_group_all_distances_reduce(gr_ctx *ctx, uint32_t slot, const char *group1, const char *group2, int dim, int op, int per_row, float param,
+                                  uint32_t nbins, void *out, size_t out_capacity_bytes);
+int gr_group_all_distances_reduce_batch(gr_ctx *ctx, uint32_t first_slot, uint32_t n_frames, const char *group1, const char *group2, int dim, int op,
+                                        int per_row, float param, uint32_t nbins, void *out, size_t out_capacity_bytes, int *status_out);
 /* copy `bytes` from a device pointer this library handed out (e.g. *out_dev above) into host memory, after the
  * context's stream has drained */
 int gr_device_read(gr_ctx *ctx, const void *dev, void *host, size_t bytes);

@@ -49,6 +49,11 @@ extern "C" {
     pub fn gr_group_all_distances(ctx: *mut gr_ctx, slot: u32, g1: *const c_char, g2: *const c_char, dim: c_int, out: *mut c_float, cap: usize) -> c_int;
     pub fn gr_group_all_distances_batch_device(ctx: *mut gr_ctx, first_slot: u32, n_frames: u32, g1: *const c_char, g2: *const c_char, dim: c_int,
                                                out_dev: *mut *mut c_float, n1: *mut u64, n2: *mut u64, status_out: *mut c_int) -> c_int;
+    // group_all_distances + the reduction its callers apply (analysis.rs:1420-1451), without the matrix: GR_PD_MIN = 1, _MAX = 2, _COUNT_BELOW = 3, _HIST = 4
+    pub fn gr_group_all_distances_reduce(ctx: *mut gr_ctx, slot: u32, g1: *const c_char, g2: *const c_char, dim: c_int, op: c_int, per_row: c_int, param: c_float,
+                                         nbins: u32, out: *mut c_void, out_capacity_bytes: usize) -> c_int;
+    pub fn gr_group_all_distances_reduce_batch(ctx: *mut gr_ctx, first_slot: u32, n_frames: u32, g1: *const c_char, g2: *const c_char, dim: c_int, op: c_int,
+                                               per_row: c_int, param: c_float, nbins: u32, out: *mut c_void, out_capacity_bytes: usize, status_out: *mut c_int) -> c_int;
     pub fn gr_trr_open(path: *const c_char, status: *mut c_int) -> *mut gr_trr;
     pub fn gr_trr_close(trr: *mut gr_trr);
     pub fn gr_trr_n_atoms(trr: *const gr_trr) -> u64;
