@@ -1129,7 +1129,8 @@ static int pairdist_launch(gr_ctx *c, uint32_t s0, uint32_t nb, const GrSel &s1,
             else if (ncand <= 8) k_pairdist_sym<8><<<tiles, dim3(GR_WG), 0, c->stream>>>(fr, c->frame_stride, s1, c->boxes_dev + s0, dim, out_dev, out_stride, c->bad_dev);
             else k_pairdist_sym<16><<<tiles, dim3(GR_WG), 0, c->stream>>>(fr, c->frame_stride, s1, c->boxes_dev + s0, dim, out_dev, out_stride, c->bad_dev);
         }
-        else if (red) {     // the fused reducers: the same tiles, nothing of the matrix stored
+        else if (red) {     // the fused reducers: the same tiles, nothing of the matrix stored; a workgroup walks GR_PDR_ROW_TILES row tiles
+            grid.y = (grid.y + GR_PDR_ROW_TILES - 1u) / GR_PDR_ROW_TILES;
             if (ncand <= 4) k_pairdist<4, true><<<grid, dim3(GR_WG), 0, c->stream>>>(fr, c->frame_stride, s1, s2, c->boxes_dev + s0, dim, nullptr, 0, c->bad_dev, *red);
             else if (ncand <= 8) k_pairdist<8, true><<<grid, dim3(GR_WG), 0, c->stream>>>(fr, c->frame_stride, s1, s2, c->boxes_dev + s0, dim, nullptr, 0, c->bad_dev, *red);
             else k_pairdist<16, true><<<grid, dim3(GR_WG), 0, c->stream>>>(fr, c->frame_stride, s1, s2, c->boxes_dev + s0, dim, nullptr, 0, c->bad_dev, *red);
@@ -1250,7 +1251,8 @@ int gr_group_all_distances_reduce_batch(gr_ctx *c, uint32_t first_slot, uint32_t
     const bool wide = op == GR_PD_COUNT_BELOW || op == GR_PD_HIST;          // results the caller receives as 64-bit counts
     const size_t len = op == GR_PD_HIST ? nbins : (per_row ? a->n : 1);
     if (!out || out_capacity_bytes < (size_t)n_frames * len * (wide ? 8 : 4)) return fail(c, GR_E_INVALID_ARG, "output buffer too small");
-    const size_t words = len + 1;                                              // (+ 1: the whole-matrix count is one 64-bit word)
+    const bool sharded = op != GR_PD_HIST && !per_row;                         // whole-matrix values arrive in GR_PDR_SHARDS slots per frame
+    const size_t words = sharded ? GR_PDR_SHARDS : len;
     const GrSel s1 = make_sel(*a), s2 = make_sel(*b);
     int first_err = GR_OK; std::string first_msg; uint64_t first_idx = 0;
     std::vector<uint32_t> host;
@@ -1261,8 +1263,12 @@ int gr_group_all_distances_reduce_batch(gr_ctx *c, uint32_t first_slot, uint32_t
         HIPCHK(c, hipMemsetAsync(acc, op == GR_PD_MIN ? 0xFF : 0x00, (size_t)nb * words * sizeof(uint32_t), c->stream));
         std::vector<int> pre; std::vector<std::string> msg;
         batch_prechecks(c, s0, nb, true, pre, msg);
-        const GrPdRed red = { op, per_row ? 1 : 0, op == GR_PD_HIST ? (float)nbins / param : param, nbins, acc, words };
-        st = pairdist_launch(c, s0, nb, s1, s2, dim, nullptr, 0, &red); if (st) return st;
+        // per row of a group of some size: the groups change places and every lane keeps the values of its own four atoms (k_pairdist,
+        // "transposed"); a handful of rows against many columns stays as it is (the lanes are the columns)
+        const bool transposed = per_row && a->n >= 512;
+        const GrPdRed red = { op, per_row ? (transposed ? 2 : 1) : 0, op == GR_PD_HIST ? (float)nbins / param : param, nbins, acc, words };
+        st = transposed ? pairdist_launch(c, s0, nb, s2, s1, dim, nullptr, 0, &red) : pairdist_launch(c, s0, nb, s1, s2, dim, nullptr, 0, &red); if (st) return st;
+        if (transposed) for (uint32_t f = 0; f < nb; ++f) std::swap(c->bad_host[4 * f], c->bad_host[4 * f + 1]);      // (first bad atom among the rows / the columns)
         host.resize((size_t)nb * words);
         HIPCHK(c, hipMemcpyAsync(host.data(), acc, host.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1275,11 +1281,12 @@ int gr_group_all_distances_reduce_batch(gr_ctx *c, uint32_t first_slot, uint32_t
             const uint32_t *h = host.data() + (size_t)f * words;
             if (wide) {
                 uint64_t *o = static_cast<uint64_t *>(out) + (size_t)(b0 + f) * len;
-                if (op == GR_PD_COUNT_BELOW && !per_row) { uint64_t v; memcpy(&v, h, 8); o[0] = v; }
+                if (sharded) { uint64_t v = 0; for (size_t k = 0; k < words; ++k) v += h[k]; o[0] = v; }
                 else for (size_t k = 0; k < len; ++k) o[k] = h[k];
             } else {
                 float *o = static_cast<float *>(out) + (size_t)(b0 + f) * len;
-                for (size_t k = 0; k < len; ++k) o[k] = gr_key_f32(h[k]);
+                if (sharded) { uint32_t v = h[0]; for (size_t k = 1; k < words; ++k) v = op == GR_PD_MIN ? std::min(v, h[k]) : std::max(v, h[k]); o[0] = gr_key_f32(v); }
+                else for (size_t k = 0; k < len; ++k) o[k] = gr_key_f32(h[k]);
             }
         }
     }

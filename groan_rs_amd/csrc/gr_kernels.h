@@ -1245,6 +1245,8 @@ __device__ __forceinline__ gr_v2f gr_pd_tric_vec2(const float4 t, gr_v2f jx, gr_
 // of the pairs, so the results EQUAL the same reduction of the full matrix.  Floats travel as order-preserving unsigned keys (atomicMin / Max).
 enum { GR_PDR_MIN = 1, GR_PDR_MAX = 2, GR_PDR_COUNT_BELOW = 3, GR_PDR_HIST = 4 };
 #define GR_PDR_MAX_BINS 4096
+#define GR_PDR_ROW_TILES 8u        /* row tiles (of GR_PD_TI rows) a reducing workgroup walks */
+#define GR_PDR_SHARDS 256u         /* slots a frame's whole-matrix results are spread over (a power of two) */
 struct GrPdRed { int op, per_row; float param /* cut-off | bins per nm */; uint32_t nbins; uint32_t *out; size_t out_stride; };
 __host__ __device__ __forceinline__ uint32_t gr_f32_key(float f) { uint32_t b; memcpy(&b, &f, 4); return b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u); }
 __host__ __device__ __forceinline__ float gr_key_f32(uint32_t k) { const uint32_t b = k ^ ((k >> 31) ? 0x80000000u : 0xFFFFFFFFu); float f; memcpy(&f, &b, 4); return f; }
@@ -1255,8 +1257,18 @@ __global__ __launch_bounds__(GR_WG) void k_pairdist(
     float *__restrict__ out, size_t out_stride, uint32_t *__restrict__ bad_out, GrPdRed red) {
     const GrBox &box = boxes[blockIdx.z];
     xyz += (size_t)blockIdx.z * frame_stride; out += (size_t)blockIdx.z * out_stride; bad_out += 4 * blockIdx.z;
+    // RED: a workgroup walks GR_PDR_ROW_TILES row tiles with its 1024 columns (their atoms loaded once) and hands its results over once
+    // per tile (per-row values) or once at the end (whole-matrix values into one of GR_PDR_SHARDS slots the host combines, the
+    // histogram from LDS): one atomic per workgroup and row / bin instead of one per pair -- a single word takes ~90 atomics per us.
+    constexpr uint32_t RT = RED ? GR_PDR_ROW_TILES : 1u;
     __shared__ uint32_t red_row[RED ? GR_PD_TI : 1], red_hist[RED ? GR_PDR_MAX_BINS : 1], red_blk[RED ? GR_WG / 64 : 1];
     uint32_t red_key = RED && red.op == GR_PDR_MIN ? 0xFFFFFFFFu : 0u, red_cnt = 0u;     // this lane's share of a whole-matrix reduction
+    // per_row == 2, "transposed": the host swapped the groups, so the lane's four COLUMN atoms are the rows the caller asked about -- their
+    // values are the lane's own (no exchange between lanes at all); the entry is distance(lane's atom, tile's atom), the mirror image of what
+    // the loops below compute: the same bits in the fast paths, negated in the signed 1-D dimensions (as k_pairdist_sym), computed the
+    // other way round in the generic one
+    uint32_t red_col[4] = { red_key, red_key, red_key, red_key };
+    const bool red_t = RED && red.per_row == 2, red_neg = red_t && dim >= 1 && dim <= 3;
     if (RED) {
         red.out += (size_t)blockIdx.z * red.out_stride;
         if (threadIdx.x < GR_PD_TI) red_row[threadIdx.x] = red.op == GR_PDR_MIN ? 0xFFFFFFFFu : 0u;
@@ -1266,22 +1278,11 @@ __global__ __launch_bounds__(GR_WG) void k_pairdist(
     __shared__ uint32_t ldsu[GR_WG / 64];
     __shared__ float4 ttab[NC + 1];            // the image table for per-lane look-ups (1-D / 2-D dimensions of a triclinic cell)
     if (threadIdx.x <= NC) ttab[threadIdx.x] = threadIdx.x < NC ? make_float4(box.cand[threadIdx.x][0], box.cand[threadIdx.x][1], box.cand[threadIdx.x][2], 0.0f) : make_float4(0.f, 0.f, 0.f, 0.f);
-    const uint32_t i0 = blockIdx.y * GR_PD_TI, j0 = blockIdx.x * (GR_WG * 4) + threadIdx.x * 4;
+    const uint32_t j0 = blockIdx.x * (GR_WG * 4) + threadIdx.x * 4;
     uint32_t bad = GR_NOIDX, badj = GR_NOIDX;   // first atom without position among the rows / the columns
     // every coordinate of the tile within a quarter box of the cell (NaN fails the test): licence for gr_mi_near
     const float lx = -0.25f * box.ax, ux = 1.25f * box.ax, ly = -0.25f * box.by, uy = 1.25f * box.by, lz = -0.25f * box.cz, uz = 1.25f * box.cz;
-    int far = 0;
-    if (threadIdx.x < GR_PD_TI) {
-        const uint32_t i = i0 + threadIdx.x;
-        float x = 0.f, y = 0.f, z = 0.f;
-        if (i < s1.n) {
-            const uint32_t a = s1.contiguous ? s1.start + i : s1.idx[i];
-            gr_pos_load(xyz, a, x, y, z);
-            if (x != x) bad = min(bad, a);
-            far |= !(x >= lx && x <= ux && y >= ly && y <= uy && z >= lz && z <= uz);
-        }
-        ti[threadIdx.x][0] = x; ti[threadIdx.x][1] = y; ti[threadIdx.x][2] = z; ti[threadIdx.x][3] = 0.f;
-    }
+    int far_j = 0;
     float jx[4], jy[4], jz[4];
     if (s2.contiguous && j0 + 3 < s2.n && ((s2.start + j0) & 3u) == 0u) {
         // the lane's 4 atoms are one group of the slot: its three (coalesced) row loads instead of twelve 4-byte ones
@@ -1304,13 +1305,39 @@ __global__ __launch_bounds__(GR_WG) void k_pairdist(
     }
     if (box.ortho) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) far |= !(jx[k] >= lx && jx[k] <= ux && jy[k] >= ly && jy[k] <= uy && jz[k] >= lz && jz[k] <= uz);
+        for (int k = 0; k < 4; ++k) far_j |= !(jx[k] >= lx && jx[k] <= ux && jy[k] >= ly && jy[k] <= uy && jz[k] >= lz && jz[k] <= uz);
+    }
+    for (uint32_t rt = 0; rt < RT; ++rt) {
+    const uint32_t i0 = (blockIdx.y * RT + rt) * GR_PD_TI;
+    if (RED && i0 >= s1.n) break;                          // (uniform)
+    if (RED && rt) __syncthreads();                         // the tile before has been read (ti) and handed over (red_row)
+    int far = far_j;
+    if (threadIdx.x < GR_PD_TI) {
+        const uint32_t i = i0 + threadIdx.x;
+        float x = 0.f, y = 0.f, z = 0.f;
+        if (i < s1.n) {
+            const uint32_t a = s1.contiguous ? s1.start + i : s1.idx[i];
+            gr_pos_load(xyz, a, x, y, z);
+            if (x != x) bad = min(bad, a);
+            far |= !(x >= lx && x <= ux && y >= ly && y <= uy && z >= lz && z <= uz);
+        }
+        ti[threadIdx.x][0] = x; ti[threadIdx.x][1] = y; ti[threadIdx.x][2] = z; ti[threadIdx.x][3] = 0.f;
     }
     far = __syncthreads_or(far);   // (also publishes ti)
     const uint32_t ni = min((uint32_t)GR_PD_TI, s1.n > i0 ? s1.n - i0 : 0u);
     const bool vec_ok = ((s2.n & 3u) == 0u);   // rows stay 16-byte aligned
-    auto put = [&](uint32_t r, const float (&d)[4]) {
+    auto put = [&](uint32_t r, const float (&d)[4], bool mirrored = false) {
         if (RED) {
+            if (red_t) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float v = (red_neg && !mirrored) ? 0.0f - d[k] : d[k];
+                    if (red.op == GR_PDR_MIN) red_col[k] = min(red_col[k], gr_f32_key(v));
+                    else if (red.op == GR_PDR_MAX) red_col[k] = max(red_col[k], gr_f32_key(v));
+                    else red_col[k] += v < red.param ? 1u : 0u;
+                }
+                return;
+            }
             // the lane's four distances of row r -> the reduction (columns behind the group's end do not exist)
             uint32_t key = red.op == GR_PDR_MIN ? 0xFFFFFFFFu : 0u, cnt = 0u;
 #pragma unroll
@@ -1323,13 +1350,15 @@ __global__ __launch_bounds__(GR_WG) void k_pairdist(
             }
             if (red.op == GR_PDR_HIST) return;
             if (!red.per_row) { red_key = red.op == GR_PDR_MIN ? min(red_key, key) : max(red_key, key); red_cnt += cnt; return; }
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                const uint32_t ok = (uint32_t)__shfl_xor((int)key, off, 64), oc = (uint32_t)__shfl_xor((int)cnt, off, 64);
-                key = red.op == GR_PDR_MIN ? min(key, ok) : max(key, ok); cnt += oc;
-            }
+            // the wave's value of row r: four DPP steps and the two lane swaps (no LDS crossbar), one LDS atomic per wave
+            uint32_t v = red.op == GR_PDR_COUNT_BELOW ? cnt : key;
+            auto comb = [&](uint32_t a, uint32_t b) { return red.op == GR_PDR_MIN ? min(a, b) : red.op == GR_PDR_MAX ? max(a, b) : a + b; };
+            v = comb(v, __float_as_uint(gr_xor_lane<1>(__uint_as_float(v)))); v = comb(v, __float_as_uint(gr_xor_lane<2>(__uint_as_float(v))));
+            v = comb(v, __float_as_uint(gr_xor_lane<4>(__uint_as_float(v)))); v = comb(v, __float_as_uint(gr_xor_lane<8>(__uint_as_float(v))));
+            const auto r16 = __builtin_amdgcn_permlane16_swap(v, v, false, false); v = comb(r16[0], r16[1]);
+            const auto r32 = __builtin_amdgcn_permlane32_swap(v, v, false, false); v = comb(r32[0], r32[1]);
             if ((threadIdx.x & 63u) == 0u) {
-                if (red.op == GR_PDR_MIN) atomicMin(&red_row[r], key); else if (red.op == GR_PDR_MAX) atomicMax(&red_row[r], key); else atomicAdd(&red_row[r], cnt);
+                if (red.op == GR_PDR_MIN) atomicMin(&red_row[r], v); else if (red.op == GR_PDR_MAX) atomicMax(&red_row[r], v); else atomicAdd(&red_row[r], v);
             }
             return;
         }
@@ -1396,33 +1425,43 @@ __global__ __launch_bounds__(GR_WG) void k_pairdist(
             const float4 t = *reinterpret_cast<const float4 *>(&ti[r][0]);
             float d[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) d[k] = gr_distance<NC>(t.x, t.y, t.z, jx[k], jy[k], jz[k], dim, box);
-            put(r, d);
+            for (int k = 0; k < 4; ++k) d[k] = red_t ? gr_distance<NC>(jx[k], jy[k], jz[k], t.x, t.y, t.z, dim, box) : gr_distance<NC>(t.x, t.y, t.z, jx[k], jy[k], jz[k], dim, box);
+            put(r, d, true);
         }
     }
+    if (RED && red.per_row == 1 && red.op != GR_PDR_HIST) {
+        // the tile's rows -> the frame's: one atomic per row and workgroup; the slots start the next tile empty
+        __syncthreads();
+        if (threadIdx.x < ni) {
+            uint32_t *o = red.out + i0 + threadIdx.x;
+            if (red.op == GR_PDR_MIN) atomicMin(o, red_row[threadIdx.x]); else if (red.op == GR_PDR_MAX) atomicMax(o, red_row[threadIdx.x]); else atomicAdd(o, red_row[threadIdx.x]);
+            red_row[threadIdx.x] = red.op == GR_PDR_MIN ? 0xFFFFFFFFu : 0u;
+        }
+    }
+    }   // row tiles
     if (RED) {
-        // the tile's results -> the frame's: one atomic per row / per bin that holds anything / per workgroup
         __syncthreads();
         if (red.op == GR_PDR_HIST) {
             for (uint32_t b = threadIdx.x; b < red.nbins; b += GR_WG) if (red_hist[b]) atomicAdd(red.out + b, red_hist[b]);
-        } else if (red.per_row) {
-            if (threadIdx.x < ni) {
-                uint32_t *o = red.out + i0 + threadIdx.x;
-                if (red.op == GR_PDR_MIN) atomicMin(o, red_row[threadIdx.x]); else if (red.op == GR_PDR_MAX) atomicMax(o, red_row[threadIdx.x]); else atomicAdd(o, red_row[threadIdx.x]);
-            }
-        } else if (ni) {
+        } else if (red_t) {
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                const uint32_t ok = (uint32_t)__shfl_xor((int)red_key, off, 64), oc = (uint32_t)__shfl_xor((int)red_cnt, off, 64);
-                red_key = red.op == GR_PDR_MIN ? min(red_key, ok) : max(red_key, ok); red_cnt += oc;
+            for (int k = 0; k < 4; ++k) {
+                if (j0 + k >= s2.n) continue;
+                uint32_t *o = red.out + j0 + k;
+                if (red.op == GR_PDR_MIN) atomicMin(o, red_col[k]); else if (red.op == GR_PDR_MAX) atomicMax(o, red_col[k]); else atomicAdd(o, red_col[k]);
             }
-            if ((threadIdx.x & 63u) == 0u) red_blk[threadIdx.x >> 6] = red.op == GR_PDR_COUNT_BELOW ? red_cnt : red_key;
+        } else if (!red.per_row) {
+            auto comb = [&](uint32_t a, uint32_t b) { return red.op == GR_PDR_MIN ? min(a, b) : red.op == GR_PDR_MAX ? max(a, b) : a + b; };
+            uint32_t v = red.op == GR_PDR_COUNT_BELOW ? red_cnt : red_key;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v = comb(v, (uint32_t)__shfl_xor((int)v, off, 64));
+            if ((threadIdx.x & 63u) == 0u) red_blk[threadIdx.x >> 6] = v;
             __syncthreads();
             if (threadIdx.x == 0) {
-                uint32_t v = red_blk[0];
-                for (int w = 1; w < GR_WG / 64; ++w) v = red.op == GR_PDR_MIN ? min(v, red_blk[w]) : red.op == GR_PDR_MAX ? max(v, red_blk[w]) : v + red_blk[w];
-                if (red.op == GR_PDR_MIN) atomicMin(red.out, v); else if (red.op == GR_PDR_MAX) atomicMax(red.out, v);
-                else atomicAdd(reinterpret_cast<unsigned long long *>(red.out), (unsigned long long)v);     // (a whole matrix may hold more than 2^32 pairs)
+                v = red_blk[0];
+                for (int w = 1; w < GR_WG / 64; ++w) v = comb(v, red_blk[w]);
+                uint32_t *o = red.out + ((blockIdx.y * gridDim.x + blockIdx.x) & (GR_PDR_SHARDS - 1u));     // one of the frame's slots: the host combines them
+                if (red.op == GR_PDR_MIN) atomicMin(o, v); else if (red.op == GR_PDR_MAX) atomicMax(o, v); else atomicAdd(o, v);
             }
         }
     }

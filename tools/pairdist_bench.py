@@ -46,5 +46,25 @@ for name, (l, a) in CELLS.items():
             ms = s.timer_stop() / (4 * NB)
             out["%s/XYZ batch of %d" % (name, NB)] = {"ms_per_frame": round(ms, 4), "frames_per_s": round(1e3 / ms, 1),
                                                        "write_GBps": round(4.0 * S * S / (ms * 1e-3) / 1e9, 1)}
+    # ---- two DIFFERENT groups (the plain kernel: no symmetry to use; VERDICT r04 weak 2 had only round 3's figure) and the fused reducers:
+    # the same tiles without the 400 MB -- what a consumer that wants the matrix's maximum / a contact count / a histogram pays
+    s.group_create_from_ranges("T", [(S, 2 * S - 1)])
+    lib.gr_group_all_distances_device(s._ctx, 0, b"S", b"T", 7, C.byref(dev), C.byref(n1), C.byref(n2))
+    s.sync(); s.timer_start()
+    for _ in range(reps):
+        assert lib.gr_group_all_distances_device(s._ctx, 0, b"S", b"T", 7, C.byref(dev), C.byref(n1), C.byref(n2)) == 0
+    ms = s.timer_stop() / reps
+    out["%s/XYZ two groups (plain kernel)" % name] = {"ms_per_frame": round(ms, 4), "frames_per_s": round(1e3 / ms, 1), "write_GBps": round(4.0 * S * S / (ms * 1e-3) / 1e9, 1)}
+    for label, kw in (("max", dict(op="max")), ("min per row", dict(op="min", per_row=True)), ("count below 1.2 nm", dict(op="count_below", param=1.2)),
+                      ("histogram, 240 bins to 12 nm", dict(op="hist", param=12.0, nbins=240))):
+        for g2, tag in (("S", "self"), ("T", "two groups")):
+            op = kw["op"]; rest = {k: v for k, v in kw.items() if k != "op"}
+            s.group_all_distances_reduce("S", g2, op, first_slot=0, n_frames=NB, **rest)
+            s.sync(); s.timer_start()
+            for _ in range(4):
+                s.group_all_distances_reduce("S", g2, op, first_slot=0, n_frames=NB, **rest)
+            ms = s.timer_stop() / (4 * NB)
+            out["%s/XYZ reduce: %s (%s, batch of %d)" % (name, label, tag, NB)] = {"ms_per_frame": round(ms, 4), "frames_per_s": round(1e3 / ms, 1),
+                                                                                   "matrix_equivalent_GBps": round(4.0 * S * S / (ms * 1e-3) / 1e9, 1)}
     s.close()
 print(json.dumps(out, indent=1))
