@@ -27,11 +27,14 @@ for bname, (l, a) in {"orthorhombic": ([24.0, 23.0, 22.0], [90.0, 90.0, 90.0]), 
     s.synth_frames(NF, 0, NF, 0, 0.05, 1)
     s.group_create_from_ranges("tenth", [(0, n // 10 - 1)])
 
+    calls = []
+
     def timed(fn):
         fn(); fn(); s.sync()
         ts = []                     # wall clock around whole calls (each ends with its own read-back + synchronisation)
         for _ in range(REPS):
             t = time.perf_counter(); fn(); ts.append(time.perf_counter() - t)
+        calls.append([round(t / NF * 1e6, 3) for t in ts])          # every call of the op, in order (where does a slow one sit?)
         return float(np.median(ts)) / NF * 1e6, float(np.max(ts)) / NF * 1e6     # us per frame: median, worst call
 
     # (callable, algorithmic bytes per frame [SURVEY 8d: every array once PER FRAME], HBM-compulsory bytes per frame [the frame's own
@@ -68,7 +71,8 @@ for bname, (l, a) in {"orthorhombic": ([24.0, 23.0, 22.0], [90.0, 90.0, 90.0]), 
         gbs = nbytes / (us * 1e-6) / 1e9
         hbm = (hbm_frame + hbm_call / NF) / (us * 1e-6) / 1e9
         res[name] = {"us_per_frame": round(us, 3), "frames_per_s": round(1e6 / us, 1), "hbm_compulsory_GBps": round(hbm, 1), "frac_of_hbm_peak": round(hbm / PEAK, 3),
-                     "algorithmic_GBps": round(gbs, 1), "worst_call_us_per_frame": round(worst, 3), "extra_pass_frames_per_call": round(extra, 1)}
+                     "algorithmic_GBps": round(gbs, 1), "worst_call_us_per_frame": round(worst, 3), "extra_pass_frames_per_call": round(extra, 1),
+                     "calls_us_per_frame": calls[-1]}
     out[bname] = res
     plan_all.close(); plan_tenth.close(); ref.close()
     s.close()
