@@ -47,7 +47,7 @@ def main():
             if line.startswith("{") and '"metric"' in line:
                 bench = json.loads(line)
     out = {
-        "command": "rocprofv3 --pmc <counter set> -- python3 bench.py %s  (one pass per counter set; tools/profile.sh)" % os.environ.get("PROFILE_ARGS", "--steps 5 --warmup 2 --no-cpu-baseline"),
+        "command": "rocprofv3 --pmc <counter set> -- python3 bench.py %s  (one pass per counter set; tools/profile.sh)" % os.environ.get("PROFILE_ARGS", "(arguments not recorded)"),
         "n_atoms": bench.get("config", {}).get("n_atoms"),
         "frames_per_launch": bench.get("roofline", {}).get("frames_per_launch"),
         "counters": counters, "traffic": traffic,

@@ -20,5 +20,5 @@ for C in FETCH_SIZE WRITE_SIZE "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_
   timeout -k 10 ${PASS_TIMEOUT:-240} rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_$N -- python3 $REPO/bench.py $ARGS > $OUT/pmc_$N.log 2>&1
   echo "pmc $N rc=$?"
 done
-python3 $REPO/tools/pmc_summary.py $OUT $OUT/$TAG
+PROFILE_ARGS="$ARGS" python3 $REPO/tools/pmc_summary.py $OUT $OUT/$TAG
 ls $OUT
