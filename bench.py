@@ -281,15 +281,15 @@ def main():
     except Exception:
         pass
     # ... and the arithmetic-free PROBE of the same shape measured NOW, on this box, by a child process beside the (idle) frame pool:
-    # the persistent copy of the resident pass's address stream (tools/ceiling_resident.hip --quick, warmed up, as many frames per
-    # launch as this run's launches; built by __graft_entry__.build()).  Round 3's ratio used a committed figure from another box.
-    # It is a probe, not a bound: from box to box it reads 4.3-4.65 us per 1e6-atom frame while the pass itself stays at 4.32-4.35,
-    # so the ratio may exceed 1 (a copy issues its loads and stores in bursts; the pass spreads them over its arithmetic).  Never fatal.
+    # the walk of the resident pass's address stream (tools/copy_matrix3.hip --quick, warmed up, as many frames per launch as this
+    # run's launches; built by __graft_entry__.build()): free-running (4.3-4.65 us per 1e6-atom frame from box to box) and with its row
+    # requests swept in address order by the metronome (3.7: round 5's finding, profiles/r05_copy_matrix.md).  Never fatal.
     copy_floor_live = None
-    profiled = bool(os.environ.get("LD_PRELOAD")) or any(k.startswith(("ROCP_", "ROCPROF", "ROCPROFILER_")) for k in os.environ)
+    # only a profiler that is actually wrapped round this process (rocprofv3 preloads its tool library and names it in these variables)
+    profiled = "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k in os.environ for k in ("ROCP_TOOL_LIBRARIES", "ROCPROF_OUTPUT_PATH", "ROCPROFILER_LIBRARY_CTOR"))
     if rank == 0 and dom == "k_fit_resident" and not args.no_live_floor and not profiled:
         try:
-            exe = os.path.join(ROOT, "tools", "bin", "ceiling_resident")
+            exe = os.path.join(ROOT, "tools", "bin", "copy_matrix3")
             if os.path.isfile(exe):
                 # the child sees exactly this rank's device: index `dev` of the list this process was given (itself possibly a restriction)
                 vis = [v for v in os.environ.get("HIP_VISIBLE_DEVICES", "").split(",") if v != ""]
@@ -311,8 +311,10 @@ def main():
                 "copy_floor_us_per_frame": copy_floor_us, "copy_floor_source": copy_floor_src,
                 "frac_of_copy_floor": round(copy_floor_us / us_per_frame_dom, 4) if copy_floor_us and us_per_frame_dom > 0 else None,
                 "copy_floor_live": copy_floor_live,
-                "frac_of_copy_floor_live": (round(copy_floor_live["persistent_copy_us_per_frame_stores_sc1_nt"] / us_per_frame_dom, 4)
+                "frac_of_copy_floor_live": (round(copy_floor_live["persistent_copy_us_per_frame_metronome"] / us_per_frame_dom, 4)
                                             if copy_floor_live and us_per_frame_dom > 0 else None),
+                "copy_floor_live_note": "the walk of the pass's address stream without arithmetic, measured now on this box (tools/copy_matrix3.hip --quick): free-running, "
+                                        "and with its requests in address order at the shortest metronome period it keeps; the fraction is the latter over the kernel's time",
                 "us_per_frame": round(us_per_frame_dom, 4),
                 "avg_launch_ms": round(avg_ms, 4), "launches": launches, "frames_per_launch": frames / max(launches, 1),
                 "algorithmic_bytes_per_launch": bytes_per_launch,

@@ -155,7 +155,62 @@ __global__ __launch_bounds__(512) void k_walk(const float *frames, float *dst_fr
 }
 
 static hipEvent_t e0, e1;
+// --quick [atoms] [frames]: what bench.py prints beside its own line, from the same box and process tree: the walk of the resident pass's
+// address stream (arithmetic-free) free-running, and paced by the metronome at the shortest period it keeps (3.5 .. 4.3 us, 0.1 apart;
+// "kept": the launch took no longer than 1.01 x frames x period on the device clock).  One JSON line.
+static int quick(uint32_t n_atoms, uint32_t F) {
+    const uint32_t ntiles = (n_atoms + 255) / 256, ngroups = ntiles * 64;
+    const size_t stride = (size_t)ntiles * 768;
+    F &= ~1u;
+    float *A;
+    CHECK(hipMalloc(&A, stride * F * sizeof(float)));
+    CHECK(hipMemset(A, 0, stride * F * sizeof(float)));
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    const uint32_t n_stream = (ngroups + 1023) / 1024, grid = n_stream + 8;      // + 8 idle workgroups, as the pass's finalizers
+    Ctl c;
+    CHECK(hipMalloc(&c.tickets, 64)); CHECK(hipMalloc(&c.frame_cnt, 64)); CHECK(hipMalloc(&c.stamps, 8 * 4 * grid));
+    c.n_stream = n_stream; c.policy = 0; c.coupled = 0;
+    const int lds = 100 * 1024;
+    CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_walk), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    auto once = [&](double T_us, double &us_events, double &us_clock) {
+        c.metro_mode = T_us > 0 ? 2u : 0u; c.metro_ticks = (uint32_t)(T_us * 100.0 * 16.0);
+        float best = 1e30f; double clk = 0;
+        for (int rep = 0; rep < 5; ++rep) {
+            CHECK(hipMemsetAsync(c.tickets, 0, 64, 0)); CHECK(hipStreamSynchronize(0));
+            CHECK(hipEventRecord(e0));
+            k_walk<<<dim3(grid), dim3(512), lds>>>(A, A, stride, F, ngroups, 6, c);
+            CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+            float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+            if (rep && ms < best) {
+                best = ms;
+                std::vector<unsigned long long> h(4 * grid);
+                CHECK(hipMemcpy(h.data(), c.stamps, h.size() * 8, hipMemcpyDeviceToHost));
+                unsigned long long t0 = ~0ull, t1 = 0;
+                for (uint32_t b = 0; b < grid; ++b) { if ((uint32_t)h[4 * b + 3] >= 0xFFFFFFFEu) continue; t0 = std::min(t0, h[4 * b]); t1 = std::max(t1, h[4 * b + 1]); }
+                clk = (t1 - t0) * 0.01 / F;
+            }
+        }
+        us_events = 1e3 * best / F; us_clock = clk;
+    };
+    {   // warm the device up (~0.5 s)
+        double a, b; float total = 0.f;
+        while (total < 500.f) { once(0.0, a, b); total += (float)(a * F * 5e-3); }
+    }
+    double free_ev, free_clk; once(0.0, free_ev, free_clk);
+    double best_T = 0, best_ev = 0, best_clk = 0;
+    for (double T = 4.3; T > 3.45; T -= 0.1) {
+        double ev, clk; once(T, ev, clk);
+        if (clk <= T * 1.01) { best_T = T; best_ev = ev; best_clk = clk; } else break;
+    }
+    printf("{\"n_atoms\": %u, \"frames_per_launch\": %u, \"workgroups\": %u, \"persistent_copy_us_per_frame_free_running\": %.4f, \"persistent_copy_us_per_frame_stores_sc1_nt\": %.4f, "
+           "\"persistent_copy_us_per_frame_metronome\": %.4f, \"metronome_period_us\": %.2f, \"metronome_device_clock_us_per_frame\": %.4f, "
+           "\"free_running_TBs\": %.3f, \"metronome_TBs\": %.3f}\n", n_atoms, F, n_stream, free_ev, free_ev, best_T > 0 ? best_ev : free_ev, best_T, best_clk,
+           24.0 * n_atoms / (free_ev * 1e-6) / 1e12, 24.0 * n_atoms / ((best_T > 0 ? best_ev : free_ev) * 1e-6) / 1e12);
+    return 0;
+}
+
 int main(int argc, char **argv) {
+    if (argc > 1 && !strcmp(argv[1], "--quick")) return quick(argc > 2 ? (uint32_t)atoi(argv[2]) : 1000000u, argc > 3 ? (uint32_t)atoi(argv[3]) : 768u);
     const double gib = argc > 1 ? atof(argv[1]) : 16.0;
     const size_t bytes = (size_t)(gib * 1024.0) << 20, n4 = bytes / 16;
     v4f *A, *B;
