@@ -54,10 +54,10 @@ def main():
     ap.add_argument("--frames-per-step", type=int, default=0, help="0 = the largest multiple of 256 (<= 1024) for which every frame "
                     "of warmup + timed steps is a distinct buffer inside --max-pool-gb")
     ap.add_argument("--max-pool-gb", type=float, default=240.0, help="HBM for the frame pool (288 GB per MI355X)")
-    ap.add_argument("--cpu-frames-per-thread", type=int, default=4)
+    ap.add_argument("--cpu-frames-per-thread", type=int, default=32, help="frames of the CPU sample per thread (32 x 16 threads = 512 frames: ~6 s of CPU work per figure)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline's main figure (0 = all host cores visible "
                     "to this process); a second figure at 16 threads (one GPU's share of the node) is always reported")
-    ap.add_argument("--cpu-max-frames", type=int, default=256, help="upper bound on the CPU sample (frames)")
+    ap.add_argument("--cpu-max-frames", type=int, default=512, help="upper bound on the CPU sample (frames; 12 MB each in /dev/shm)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-live-floor", action="store_true", help="do not run the arithmetic-free copy probe (tools/bin/ceiling_resident) beside the "
                     "result; implied under a profiler (ROCPROF* / ROCP_* variables or an LD_PRELOAD are inherited by the child)")
@@ -477,8 +477,8 @@ def cpu_baseline_child(tmpdir):
         pass
     cargo = subprocess.run("cargo --version", shell=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout.decode().strip()
 
-    def run(threads, layout):
-        nf = min(nf_all, max(threads * fpt, 1))
+    def run(threads, layout, cap=None):
+        nf = min(nf_all, max(threads * fpt, 1), cap or nf_all)
         buf = np.array(frames[:nf])                     # private copy: fitted in place
         sec, r = O.baseline_rmsd_fit(buf, ref_pos, masses, box, threads, layout)
         return nf / sec, nf, r, buf
@@ -487,7 +487,7 @@ def cpu_baseline_child(tmpdir):
     fps_main, nf_main, r_f, _ = run(t_main, 0)          # reference-faithful 232-byte AoS records, frames round-robin over threads
     fps_soa, _, _, _ = run(t_main, 1)
     fps_16, nf_16, _, _ = run(16, 0) if t_main != 16 else (fps_main, nf_main, None, None)
-    fps_1, _, _, _ = run(1, 0) if fpt <= 4 else (None, 0, None, None)
+    fps_1, _, _, _ = run(1, 0, cap=8)                   # (one thread: 8 frames, ~1.3 s)
     # parity at full size: the reference's sequential f32 sums lose ~1e-2 nm over 1e6 terms, so the GPU (fp64 sums) is compared
     # with the same CPU restatement summing in double; the literal f32 figure is reported beside it
     O.set_accumulate_f64(True)
