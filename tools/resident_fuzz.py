@@ -82,7 +82,10 @@ while time.time() < t_end:
                         cur.set_box(boxes_f[f], slot=f)
             cur.set_tuning(resident=0)
         else:
-            cur.set_tuning(resident=2 if forced else 1, resident_streams=streams)
+            # round 5's knobs, drawn per case: the order of a turn (by fill / fit first / sums first) and the metronome (controller / off / a
+            # period the launch keeps easily / one it cannot keep): they move work in time, never in value
+            order, metro = int(rng.integers(0, 3)), int(rng.choice([0, 1, 20_000, 300]))
+            cur.set_tuning(resident=2 if forced else 1, resident_streams=streams, resident_fit_last=order, resident_metro_ns=metro)
         cur.profile_enable(True)
         r, st = plan.rmsd_fit(0, nf, raise_on_error=False)
         prof = cur.profile_read()
