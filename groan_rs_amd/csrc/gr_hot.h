@@ -140,6 +140,7 @@ __device__ __forceinline__ void gr_sums_pair(GrSumsPk &S, gr_v2f x, gr_v2f y, gr
 // membership from one bit (a 4-bit nibble per lane and trip, prefetched with the rows); plan.p is then laid out by atom over the span.
 // Measured at 1e6 atoms (tools/gather_bench.py, us per frame, gather list -> masked span): every third atom 4.3 -> see DESIGN.
 template <bool NOREF = false, bool RMSD = false, bool MASK = false>
+// (three waves per SIMD forced through __launch_bounds__(GR_WG, 3): 168 VGPRs + 74 spilled, 9.0-9.6 us per 1e6-atom frame instead of 2.35 -- round 5)
 __global__ __launch_bounds__(GR_WG) void k_sums_pk(
     const float *__restrict__ frames, size_t frame_stride, uint32_t first_slot,
     const float *__restrict__ masses, GrSel sel, const GrBox *__restrict__ boxes,
