@@ -104,6 +104,10 @@ struct gr_ctx {
     // next to no slot was reached late); it starts from a free-running launch, probes downwards 1.5 % at a time, steps back to the
     // best kept period when a probe fails, and switches the clock off for a shape whose free-running turn it cannot beat.
     int res_metro_ns = 0;
+    // workgroups per CU of the grid-launched read-modify-write streams (k_translate_wrap, k_fit_pk): GR_TUNE_STREAM_WGS_PER_CU.  A copy runs
+    // fastest with 20-32 KiB of loads in flight per CU (tools/copy_matrix3 --occ: 3 KiB per wave at 2 workgroups per CU 6.2 TB/s, at 8 -- what the
+    // registers allow -- 5.77); the surplus workgroups are kept off the CU by LDS they do not use
+    int stream_wgs_cu = 0;            // 0: chosen by the library (see stream_lds), 1..8
     int res_fit_last = 0;             // GR_TUNE_RESIDENT_FIT_LAST 0: chosen by the launch's fill, 1: the fit first, 2: the sums first
     struct Metro { uint64_t shape = 0; double free_ns = 0, T_ns = 0, best_ns = 0, fail_ns = 0; uint32_t off_for = 0, held = 0; } metro;
     uint64_t res_metro_period_ns = 0, res_last_turn_ns = 0, res_late_permille = 0, res_sclk_mhz = 0;   // gr_ctx_stat: the last resident launch
@@ -287,8 +291,13 @@ static const void *resident_fn(bool wmass, bool ubox, bool v, bool fl) {
 #undef GR_RES_FN
     return fn[(wmass ? 1 : 0) | (ubox ? 2 : 0) | (v ? 4 : 0) | (fl ? 8 : 0)];
 }
+#ifndef GR_STREAM_WGS_CU_DEFAULT
+#define GR_STREAM_WGS_CU_DEFAULT 8
+#endif
 static bool resident_prepare() {
     bool ok = true;
+    ok = ok && hipFuncSetAttribute(reinterpret_cast<const void *>(&k_translate_wrap), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 5120) == hipSuccess;
+    ok = ok && hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fit_pk<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 5120) == hipSuccess;
     for (int v = 0; v < 16; ++v)
         ok = ok && hipFuncSetAttribute(resident_fn((v & 1) != 0, (v & 2) != 0, (v & 4) != 0, (v & 8) != 0), hipFuncAttributeMaxDynamicSharedMemorySize, GrResShape::LDS_BYTES) == hipSuccess;
     return ok;
@@ -372,6 +381,11 @@ uint32_t resident_wgs(gr_ctx *c, bool lite, uint32_t nb, const GrSel &sel, uint3
 #ifdef GR_EXP_STEPTIME
 static unsigned long long *g_steptime_dbg = nullptr;
 #endif
+// dynamic LDS that keeps a streaming kernel at `per_cu` workgroups per CU (160 KiB per CU; the kernels' own static LDS is < 5 KiB)
+static uint32_t stream_lds(const gr_ctx *c, int fallback_per_cu) {
+    const int per_cu = c->stream_wgs_cu ? c->stream_wgs_cu : fallback_per_cu;
+    return per_cu >= 8 ? 0u : (uint32_t)(160 * 1024 / per_cu - 5120);
+}
 // One resident launch at a time per device and process: its workgroups wait for one another, so two of them sharing the CUs could
 // each hold half the chip and starve.  A context that finds the device taken lets the two-pass path handle its segment.
 static std::atomic<int> g_resident_in_flight[64];
@@ -1725,7 +1739,7 @@ static int translate_batch(gr_ctx *c, uint32_t s0, uint32_t nb, const Group *g, 
     if (g->n) {
         const uint64_t units = sel.contiguous ? ((uint64_t)sel.n + 3) / 4 + 128 : (sel.masked & 2u) ? ((uint64_t)sel.span + 3) / 4 + 128 : sel.n;   // (4-atom groups of the block / of a masked selection's span; list entries)
         const uint32_t nwg = (uint32_t)std::min<uint64_t>((units + GR_WG - 1) / GR_WG, 4096);
-        k_translate_wrap<<<dim3(nwg, nb), dim3(GR_WG), 0, c->stream>>>(c->frames + (size_t)s0 * c->frame_stride, c->frame_stride, sel, c->boxes_dev + s0, c->state_dev, mode, dim_mask,
+        k_translate_wrap<<<dim3(nwg, nb), dim3(GR_WG), stream_lds(c, GR_STREAM_WGS_CU_DEFAULT), c->stream>>>(c->frames + (size_t)s0 * c->frame_stride, c->frame_stride, sel, c->boxes_dev + s0, c->state_dev, mode, dim_mask,
                                                                        v ? v[0] : 0.f, v ? v[1] : 0.f, v ? v[2] : 0.f, c->bad_dev);
         HIPCHK(c, hipGetLastError());
     }
@@ -1902,6 +1916,7 @@ int gr_ctx_set_tuning(gr_ctx *c, int key, int64_t value) try {
     case GR_TUNE_RESIDENT_STREAMS: if (value < 0 || value > GR_RES_MAX_STREAMS) break; c->res_streams = (int)value; return GR_OK;
     case GR_TUNE_RESIDENT_METRO_NS: if (value < 0 || value > 1000000 || (value > 1 && value < 100)) break; c->res_metro_ns = (int)value; c->metro = gr_ctx::Metro(); return GR_OK;
     case GR_TUNE_RESIDENT_FIT_LAST: if (value < 0 || value > 2) break; c->res_fit_last = (int)value; return GR_OK;
+    case GR_TUNE_STREAM_WGS_PER_CU: if (value < 0 || value > 8) break; c->stream_wgs_cu = (int)value; return GR_OK;
     case GR_TUNE_RESIDENT_FILL: if (value < 1 || value > 16) break; c->res_fill16 = (int)value; return GR_OK;
     case GR_TUNE_RESIDENT_GROUPS: if (value != 2) break; return GR_OK;   // (the one-group shape was removed: gr_resident.h)
     case GR_TUNE_TEST_RESIDENT_NO_START: c->res_test_no_start = value ? 1 : 0; return GR_OK;
@@ -2165,7 +2180,7 @@ static int segment_begin(gr_rmsd_plan *p, uint32_t s0, uint32_t nb, int fit) {
             if (fit) {
                 if (c->profile) EVREC(c, c->pev[6 * g + 4], true, S);
                 // (closing the rmsd on the tail of this kernel makes every one of its 62 k workgroups drain its stores: 3x slower)
-                if (lite) k_fit_pk<true><<<dim3(gx, nf), dim3(GR_WG), 0, S>>>(c->frames, c->frame_stride, s0 + f0, (uint32_t)c->n, c->boxes_dev, p->dev, c->state_dev + f0, c->masses, sel, c->fit_partials + (size_t)f0 * gx);
+                if (lite) k_fit_pk<true><<<dim3(gx, nf), dim3(GR_WG), stream_lds(c, GR_STREAM_WGS_CU_DEFAULT), S>>>(c->frames, c->frame_stride, s0 + f0, (uint32_t)c->n, c->boxes_dev, p->dev, c->state_dev + f0, c->masses, sel, c->fit_partials + (size_t)f0 * gx);
                 else k_fit_pk<false><<<dim3(gx, nf), dim3(GR_WG), 0, S>>>(c->frames, c->frame_stride, s0 + f0, (uint32_t)c->n, c->boxes_dev, p->dev, c->state_dev + f0, c->masses, sel, nullptr);
                 if (c->profile) EVREC(c, c->pev[6 * g + 5], true, S);
                 if (lite) k_rmsd_close<<<dim3(nf), dim3(64), 0, S>>>(c->fit_partials + (size_t)f0 * gx, gx, p->dev.sw, c->state_dev + f0);
@@ -2344,6 +2359,9 @@ static int segment_end(gr_rmsd_plan *p, float *rmsd_out, int *status_out, float 
                         m.best_ns = m.best_ns > 0 ? std::min(m.best_ns, T) : T;
                         const double next = T * 0.985;
                         if (m.fail_ns == 0 || next > m.fail_ns * 1.004) m.T_ns = next;
+                        else if (m.best_ns > m.free_ns * 0.98) {      // settled, and less than 2 % under the free-running turn: the waits cost what the order buys
+                            m.off_for = 512; m.free_ns = 0; m.T_ns = 0; m.best_ns = 0; m.fail_ns = 0;
+                        }
                         else if (++m.held >= 64) { m.held = 0; m.fail_ns *= 0.995; }   // (conditions drift: let an old failure fade)
                     } else {                                          // not kept: back to the best kept period, or up
                         m.fail_ns = std::max(m.fail_ns, T);

@@ -306,10 +306,12 @@ int gr_rmsd_plan_force_exact(gr_rmsd_plan *plan, int on);
  *                      free, as before round 5); 100 .. 1 000 000 = this period.  Results do not depend on it.
  *   GR_TUNE_RESIDENT_FIT_LAST  order of a turn of the resident pass: 1 = the fit of frame i - 6, then the sums of frame i (rounds 2-4);
  *                      2 = the sums first (the frame's record is needed later and published earlier: one more turn for the finalizers);
- *                      0 (default) = sums first when the streaming workgroups fill 9/10 of the chip.  Same results either way. */
+ *                      0 (default) = sums first when the streaming workgroups fill 9/10 of the chip.  Same results either way.
+ *   GR_TUNE_STREAM_WGS_PER_CU  workgroups per CU of the grid-launched read-modify-write streams (translate / wrap / centre, the two-pass fit):
+ *                      1 .. 8, 0 (default) = the library's choice.  A copy is fastest with 20-32 KiB of loads in flight per CU. */
 enum { GR_TUNE_SUB_BATCH = 1, GR_TUNE_CHUNKS = 2, GR_TUNE_FIT_WGS = 3, GR_TUNE_FUSE = 4, GR_TUNE_TWO_PASS = 5, GR_TUNE_RESIDENT = 6, GR_TUNE_RESIDENT_GROUPS = 7,
        GR_TUNE_RESIDENT_STREAMS = 8, GR_TUNE_RESIDENT_FILL = 9, GR_TUNE_PAIRDIST_SYMMETRIC = 10, GR_TUNE_RESIDENT_WG_GROUPS = 11,
-       GR_TUNE_RMSD_FAST = 12, GR_TUNE_RMSD_FAST_MIN = 13, GR_TUNE_RESIDENT_METRO_NS = 18, GR_TUNE_RESIDENT_FIT_LAST = 19,
+       GR_TUNE_RMSD_FAST = 12, GR_TUNE_RMSD_FAST_MIN = 13, GR_TUNE_RESIDENT_METRO_NS = 18, GR_TUNE_RESIDENT_FIT_LAST = 19, GR_TUNE_STREAM_WGS_PER_CU = 20,
        GR_TUNE_MASKED_SELECTIONS = 15 /* 1 (default): a scattered selection that covers at least an eighth of the atoms between its first and its last one (>= 4096
                                          atoms) also gets a bit mask, and RMSD / RMSD-fit / get_com read its span coalesced instead of gathering it atom by atom;
                                          0: groups created afterwards keep to their index lists.  Same results to rounding. */,

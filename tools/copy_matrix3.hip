@@ -209,7 +209,46 @@ static int quick(uint32_t n_atoms, uint32_t F) {
     return 0;
 }
 
+// --occ: the no-loop copy with the pass's 3 KiB tile per wave (sheet 2: 5.8 TB/s against 6.5 for one float4 per lane) at 1 .. 8 workgroups per
+// CU (LDS ballast): is it the bytes in flight per CU that cost the 11 %?  (k_tile3: a wave moves rows b, b + 64, b + 128 of its 192-float4 tile)
+template <int U>
+__global__ __launch_bounds__(256) void k_tileU(const v4f *__restrict__ src, v4f *__restrict__ dst) {
+    extern __shared__ char ballast[];
+    const size_t base = ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * (64 * U) + (threadIdx.x & 63);
+    v4f r[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) r[u] = ldnt(src + base + (size_t)u * 64);
+#pragma unroll
+    for (int u = 0; u < U; ++u) stnt(dst + base + (size_t)u * 64, touch(r[u]));
+}
+static int occ_sweep(double gib) {
+    const size_t bytes = (size_t)(gib * 1024.0) << 20, n4 = bytes / 16;
+    v4f *A, *B;
+    CHECK(hipMalloc(&A, bytes)); CHECK(hipMalloc(&B, bytes));
+    CHECK(hipMemset(A, 0, bytes)); CHECK(hipMemset(B, 0, bytes));
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    auto go = [&](auto kern, int U, int per_cu) {
+        const int lds = per_cu >= 8 ? 0 : (160 * 1024 / per_cu - 2048);
+        CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
+        const size_t nwg = n4 / (256 * (size_t)U);
+        float best = 1e30f;
+        for (int rep = 0; rep < 6; ++rep) {
+            CHECK(hipEventRecord(e0));
+            kern<<<dim3((unsigned)nwg), dim3(256), lds>>>(A, B);
+            CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+            float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+            if (rep && ms < best) best = ms;
+        }
+        CHECK(hipGetLastError());
+        printf("{\"family\": \"tile no loop\", \"U\": %d, \"wgs_per_cu\": %d, \"KiB_in_flight_per_cu\": %d, \"best_TBs\": %.3f}\n", U, per_cu, per_cu * 4 * U, 2.0 * nwg * 256 * U * 16 / (best * 1e-3) / 1e12);
+        fflush(stdout);
+    };
+    for (int per_cu : { 1, 2, 3, 4, 5, 6, 8 }) { go(k_tileU<1>, 1, per_cu); go(k_tileU<2>, 2, per_cu); go(k_tileU<3>, 3, per_cu); go(k_tileU<6>, 6, per_cu); }
+    return 0;
+}
+
 int main(int argc, char **argv) {
+    if (argc > 1 && !strcmp(argv[1], "--occ")) return occ_sweep(argc > 2 ? atof(argv[2]) : 16.0);
     if (argc > 1 && !strcmp(argv[1], "--quick")) return quick(argc > 2 ? (uint32_t)atoi(argv[2]) : 1000000u, argc > 3 ? (uint32_t)atoi(argv[3]) : 768u);
     const double gib = argc > 1 ? atof(argv[1]) : 16.0;
     const size_t bytes = (size_t)(gib * 1024.0) << 20, n4 = bytes / 16;
