@@ -53,3 +53,31 @@ def test_every_tuning_gives_the_same_answers(G, start):
     with pytest.raises(G.DeviceError):
         cur.set_tuning(sub_batch=0)
     plan.close(); ref.close(); cur.close()
+
+
+def test_workgroups_per_cu_of_the_streams_change_nothing(G):
+    """GR_TUNE_STREAM_WGS_PER_CU keeps surplus workgroups of the grid-launched read-modify-write streams off a CU with LDS they do not use:
+    translate / wrap / centring and the two-pass fit give the same bits at 8 (uncapped), 3 and 1 workgroups per CU"""
+    n, nf = 50_003, 4
+    box = W.box_from_lengths_angles([7.0, 6.5, 6.0], [60.0, 60.0, 90.0])
+    masses = W.masses_cycle(n)
+    out = {}
+    for per_cu in (0, 8, 3, 1):
+        cur = G.System(n, masses=masses, n_slots=nf + 1)
+        cur.synth_reference(nf, box, 1.0, W.SEED)
+        cur.synth_frames(nf, 0, nf, 0, 0.04, W.SEED)
+        ref = G.System(n, masses=masses, box=box, positions=cur.get_positions(nf))
+        for s in (ref, cur):
+            s.group_create_from_ranges("S", [(5, n - 9)])
+        cur.set_tuning(stream_wgs_per_cu=per_cu, resident=0)
+        plan = G.RMSDPlan(ref, cur, "S")
+        r, st = plan.rmsd_fit(0, nf)
+        assert (st == 0).all()
+        cur.group_translate_batch(None, [0.31, -0.2, 0.15], 0, nf)
+        cur.atoms_center_batch("S", 0, nf, weighted=True)
+        out[per_cu] = (np.array(r).view(np.uint32), np.stack([cur.get_positions(f) for f in range(nf)]).view(np.uint32))
+        plan.close(); ref.close(); cur.close()
+    for per_cu in (8, 3, 1):
+        assert np.array_equal(out[per_cu][0], out[0][0]) and np.array_equal(out[per_cu][1], out[0][1]), per_cu
+    with pytest.raises(Exception):
+        G.System(100).set_tuning(stream_wgs_per_cu=9)
