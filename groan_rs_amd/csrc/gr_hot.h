@@ -89,10 +89,11 @@ __device__ __forceinline__ void gr_image_pair(gr_v2f &vx, gr_v2f &vy, gr_v2f &vz
 }
 
 // two atoms: v = image of (x - g) nearest to g, then every sum.  `p*` = reference coordinates (NOREF: unused), m = masses.
-template <bool NOREF, bool RMSD = false>
+template <bool NOREF, bool RMSD = false, bool PRESUB = false>
 __device__ __forceinline__ void gr_sums_pair(GrSumsPk &S, gr_v2f x, gr_v2f y, gr_v2f z, gr_v2f px, gr_v2f py, gr_v2f pz, gr_v2f m,
                                              const GrBoxU &B, const GrBox *__restrict__ boxp, float gx, float gy, float gz, GrRmsdPk *Rm = nullptr, int half = 0) {
-    gr_v2f vx = x - gr_v2(gx), vy = y - gr_v2(gy), vz = z - gr_v2(gz);
+    // (PRESUB: x, y, z are x - g already: the caller took the difference to free the row registers for the next request)
+    gr_v2f vx = PRESUB ? x : x - gr_v2(gx), vy = PRESUB ? y : y - gr_v2(gy), vz = PRESUB ? z : z - gr_v2(gz);
     gr_image_pair(vx, vy, vz, B, boxp);
     // fractional coordinates of v: moments + extents feed the image proof (gr_finalize_math)
     const gr_v2f fc = vz * gr_v2(B.icz);
@@ -207,20 +208,28 @@ __global__ __launch_bounds__(GR_WG) void k_sums_pk(
     // selection's first group, and a trip that lies behind the selection is turned into copies of the first atom with zero mass
     // by the same masking that handles the selection's ragged ends -- so the trip count is wave-uniform and nothing diverges.
     const float4 one4 = make_float4(1.f, 1.f, 1.f, 1.f);
+    const uint32_t gstep_ = nchunks * GR_WG;
 #ifndef GR_SUMS_PREFETCH_PM
 #define GR_SUMS_PREFETCH_PM 1
 #endif
+#ifndef GR_SUMS_DEEP
+#define GR_SUMS_DEEP 0             /* 1: the frame's rows are requested TWO trips ahead (into the registers the current trip has just emptied), reference + masses one */
+#endif
     struct Trip { float4 r0, r1, r2, q0, q1, q2, mm; uint32_t bits; };
-    auto request = [&](uint32_t gg, Trip &t) {
+    auto request_rows = [&](uint32_t gg, Trip &t) {
         const uint32_t gc = gg < g1 ? gg : g0;
         gr_rows_load<true>(f4, gc, t.r0, t.r1, t.r2);
+    };
+    auto request_pm = [&](uint32_t gg, Trip &t) {
+        const uint32_t gc = gg < g1 ? gg : g0;
         t.bits = MASK ? sel.mask[gc >> 3] : 0u;
         if (GR_SUMS_PREFETCH_PM) {
             if (!NOREF) gr_rows_load(p4, (size_t)(gc - g0), t.q0, t.q1, t.q2);
             if (!(NOREF && !wm)) t.mm = m4[gc]; else t.mm = one4;
         }
     };
-    auto process = [&](const Trip &t, uint32_t gg) {
+    auto request = [&](uint32_t gg, Trip &t) { request_rows(gg, t); request_pm(gg, t); };
+    auto process = [&](Trip &t, uint32_t gg) {
         float4 q0 = t.q0, q1 = t.q1, q2 = t.q2, mm = t.mm;
         if (!GR_SUMS_PREFETCH_PM) {
             const uint32_t gc = gg < g1 ? gg : g0;
@@ -253,8 +262,17 @@ __global__ __launch_bounds__(GR_WG) void k_sums_pk(
                 p.x23.y = k3 ? p.x23.y : 0.f; p.y23.y = k3 ? p.y23.y : 0.f; p.z23.y = k3 ? p.z23.y : 0.f;
             }
         }
-        gr_sums_pair<NOREF, RMSD>(S, q.x01, q.y01, q.z01, p.x01, p.y01, p.z01, gr_v2p(mm.x, mm.y), B, boxp, gx, gy, gz, &Rm, 0);
-        gr_sums_pair<NOREF, RMSD>(S, q.x23, q.y23, q.z23, p.x23, p.y23, p.z23, gr_v2p(mm.z, mm.w), B, boxp, gx, gy, gz, &Rm, 1);
+        if (GR_SUMS_DEEP) {
+            // the differences first: the row registers are then free, and the rows of the trip after next are requested into them now
+            q.x01 -= gr_v2(gx); q.y01 -= gr_v2(gy); q.z01 -= gr_v2(gz); q.x23 -= gr_v2(gx); q.y23 -= gr_v2(gy); q.z23 -= gr_v2(gz);
+            asm volatile("" :: "v"(q.x01), "v"(q.y01), "v"(q.z01), "v"(q.x23), "v"(q.y23), "v"(q.z23));
+            request_rows(gg + 2u * gstep_, t);
+            gr_sums_pair<NOREF, RMSD, true>(S, q.x01, q.y01, q.z01, p.x01, p.y01, p.z01, gr_v2p(mm.x, mm.y), B, boxp, gx, gy, gz, &Rm, 0);
+            gr_sums_pair<NOREF, RMSD, true>(S, q.x23, q.y23, q.z23, p.x23, p.y23, p.z23, gr_v2p(mm.z, mm.w), B, boxp, gx, gy, gz, &Rm, 1);
+        } else {
+            gr_sums_pair<NOREF, RMSD>(S, q.x01, q.y01, q.z01, p.x01, p.y01, p.z01, gr_v2p(mm.x, mm.y), B, boxp, gx, gy, gz, &Rm, 0);
+            gr_sums_pair<NOREF, RMSD>(S, q.x23, q.y23, q.z23, p.x23, p.y23, p.z23, gr_v2p(mm.z, mm.w), B, boxp, gx, gy, gz, &Rm, 1);
+        }
         if (RMSD && (++trips % GR_RMSD_FLUSH) == 0) flush();
     };
     const uint32_t gstep = nchunks * GR_WG;
@@ -262,12 +280,13 @@ __global__ __launch_bounds__(GR_WG) void k_sums_pk(
     if (__builtin_amdgcn_ballot_w64(g < g1) != 0ull) {
         Trip TA, TB;
         request(g, TA);
+        if (GR_SUMS_DEEP) request_rows(g + gstep, TB);
         for (;;) {
-            request(g + gstep, TB);
+            if (GR_SUMS_DEEP) request_pm(g + gstep, TB); else request(g + gstep, TB);
             process(TA, g);
             g += gstep;
             if (__builtin_amdgcn_ballot_w64(g < g1) == 0ull) break;
-            request(g + gstep, TA);
+            if (GR_SUMS_DEEP) request_pm(g + gstep, TA); else request(g + gstep, TA);
             process(TB, g);
             g += gstep;
             if (__builtin_amdgcn_ballot_w64(g < g1) == 0ull) break;
