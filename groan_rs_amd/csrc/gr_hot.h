@@ -194,79 +194,94 @@ __global__ __launch_bounds__(GR_WG) void k_sums_pk(
     };
 
     const uint32_t first = sel.start, last = sel.start + (MASK ? sel.span : sel.n);
-    const uint32_t g0 = sel.g0 << 6, g1 = (last + 3u) >> 2;      // float4 groups [g0, g1): g0 = first group of the first tile
-    const float4 *f4 = reinterpret_cast<const float4 *>(xyz);
-    const float4 *p4 = reinterpret_cast<const float4 *>(plan.p);
-    const float4 *m4 = reinterpret_cast<const float4 *>(masses);
+    const uint32_t g1 = (last + 3u) >> 2;                        // float4 groups [sel.g0 << 6, g1)
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // Software pipeline of depth one with TWO NAMED register sets and the loop unrolled by two: the rows of trip k + 1 are requested
-    // before the arithmetic of trip k, and the only wait before that arithmetic is "all but the seven loads just issued".  (Rounds
-    // 2-3 wrote this as `if (next < end) request(next, n..); ...; r = n` -- and the compiler, which has to merge the loaded and the
-    // not-loaded value at the join and to copy the landing registers at the end of the body, waited for the new loads right after
-    // issuing them (s_waitcnt vmcnt(5) of 7) and drained the queue at the end of every trip: nothing was prefetched, only the
-    // other waves of the SIMD hid the latency.)  Every request is unconditional: a lane that has no further trip re-reads the
-    // selection's first group, and a trip that lies behind the selection is turned into copies of the first atom with zero mass
-    // by the same masking that handles the selection's ragged ends -- so the trip count is wave-uniform and nothing diverges.
     const float4 one4 = make_float4(1.f, 1.f, 1.f, 1.f);
-    const uint32_t gstep_ = nchunks * GR_WG;
-#ifndef GR_SUMS_PREFETCH_PM
-#define GR_SUMS_PREFETCH_PM 1
-#endif
+    // ADDRESSES AND MASKS ARE THE WAVE'S, NOT THE LANE'S (round 5).  A wave walks whole 256-atom tiles -- tile T0 + k TS, both wave-uniform --
+    // and a lane keeps its place inside the tile, so the frame, the reference, the masses and the mask bits are buffer resources read at
+    // (lane's constant offset) + (an SGPR that a scalar add moves on), and "does this trip exist / is every atom of it inside the selection"
+    // is a scalar comparison.  Until then a trip spent ~30 of its ~220 vector instructions on 64-bit address arithmetic, index clamps and the
+    // per-atom bounds of a selection's ragged ends that 99.9 % of all trips do not touch.
+    const uint32_t wave_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave);
+    const uint32_t tile_first = sel.g0, tile_end = (g1 + 63u) >> 6;                            // tiles [tile_first, tile_end)
+    const uint32_t tstep = nchunks * (GR_WG / 64u);
+    const __amdgpu_buffer_rsrc_t rs_f = gr_buf_rsrc(xyz, tile_end * 3072u);
+    const __amdgpu_buffer_rsrc_t rs_p = gr_buf_rsrc(NOREF ? (const void *)xyz : (const void *)plan.p, NOREF ? 0u : (tile_end - tile_first) * 3072u);
+    const __amdgpu_buffer_rsrc_t rs_m = gr_buf_rsrc(masses, tile_end * 1024u);
+    const __amdgpu_buffer_rsrc_t rs_b = gr_buf_rsrc(MASK ? (const void *)sel.mask : (const void *)xyz, MASK ? tile_end * 32u : 0u);
+    const uint32_t lane16 = lane * 16u, lane_bits = (lane >> 3) * 4u;
+    // interior tiles: every atom inside [first, last) -- no lane of such a trip needs a mask (MASK: the bits decide, always)
+    const uint32_t int_lo = (first + 255u) >> 8, int_hi = last >> 8;                          // tiles [int_lo, int_hi) are interior
 #ifndef GR_SUMS_DEEP
-#define GR_SUMS_DEEP 0             /* 1: the frame's rows are requested TWO trips ahead (into the registers the current trip has just emptied), reference + masses one */
+#define GR_SUMS_DEEP 1             /* the frame's rows are requested TWO trips ahead (into the registers the current trip has just emptied), reference + masses one */
 #endif
     struct Trip { float4 r0, r1, r2, q0, q1, q2, mm; uint32_t bits; };
-    auto request_rows = [&](uint32_t gg, Trip &t) {
-        const uint32_t gc = gg < g1 ? gg : g0;
-        gr_rows_load<true>(f4, gc, t.r0, t.r1, t.r2);
+    // (a trip behind the selection reads the selection's first tile: every request is unconditional, the trip count wave-uniform)
+    auto request_rows = [&](uint32_t tile, Trip &t) {
+#ifdef GR_EXP_SUMS_NOLOAD     /* experiment: the arithmetic alone (every trip works on the first trip's rows) */
+        if (tile >= tile_first + (chunk + 2u * nchunks) * (GR_WG / 64u)) { asm volatile("" : "+v"(t.r0.x), "+v"(t.r0.y), "+v"(t.r0.z), "+v"(t.r0.w), "+v"(t.r1.x), "+v"(t.r1.y), "+v"(t.r1.z), "+v"(t.r1.w), "+v"(t.r2.x), "+v"(t.r2.y), "+v"(t.r2.z), "+v"(t.r2.w)); return; }
+#endif
+        const uint32_t tc = tile < tile_end ? tile : tile_first, so = tc * 3072u;
+        t.r0 = gr_buf_load_f4<2>(rs_f, lane16, so); t.r1 = gr_buf_load_f4<2>(rs_f, lane16 + 1024u, so); t.r2 = gr_buf_load_f4<2>(rs_f, lane16 + 2048u, so);
     };
-    auto request_pm = [&](uint32_t gg, Trip &t) {
-        const uint32_t gc = gg < g1 ? gg : g0;
-        t.bits = MASK ? sel.mask[gc >> 3] : 0u;
-        if (GR_SUMS_PREFETCH_PM) {
-            if (!NOREF) gr_rows_load(p4, (size_t)(gc - g0), t.q0, t.q1, t.q2);
-            if (!(NOREF && !wm)) t.mm = m4[gc]; else t.mm = one4;
+    auto request_pm = [&](uint32_t tile, Trip &t) {
+#if defined(GR_EXP_SUMS_NOLOAD) || defined(GR_EXP_SUMS_NOPM)     /* NOPM: reference + masses loaded for the first two trips only */
+        if (tile >= tile_first + (chunk + 2u * nchunks) * (GR_WG / 64u)) return;
+#endif
+        const uint32_t tc = tile < tile_end ? tile : tile_first;
+        t.bits = MASK ? (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs_b, (int)lane_bits, (int)(tc * 32u), 0) : 0u;
+        if (!NOREF) {
+            const uint32_t so = (tc - tile_first) * 3072u;
+            t.q0 = gr_buf_load_f4<0>(rs_p, lane16, so); t.q1 = gr_buf_load_f4<0>(rs_p, lane16 + 1024u, so); t.q2 = gr_buf_load_f4<0>(rs_p, lane16 + 2048u, so);
         }
+        if (!(NOREF && !wm)) t.mm = gr_buf_load_f4<0>(rs_m, lane16, tc * 1024u); else t.mm = one4;
     };
-    auto request = [&](uint32_t gg, Trip &t) { request_rows(gg, t); request_pm(gg, t); };
-    auto process = [&](Trip &t, uint32_t gg) {
-        float4 q0 = t.q0, q1 = t.q1, q2 = t.q2, mm = t.mm;
-        if (!GR_SUMS_PREFETCH_PM) {
-            const uint32_t gc = gg < g1 ? gg : g0;
-            if (!NOREF) gr_rows_load(p4, (size_t)(gc - g0), q0, q1, q2);
-            if (!(NOREF && !wm)) mm = m4[gc]; else mm = one4;
-        }
+    auto process = [&](Trip &t, uint32_t tile) {
+        const float4 q0 = t.q0, q1 = t.q1, q2 = t.q2;
+        float4 mm = t.mm;
         GrP4 q = gr_pairs_rows(t.r0, t.r1, t.r2), p;
         if (!NOREF) p = gr_pairs_rows(q0, q1, q2); else p.x01 = p.y01 = p.z01 = p.x23 = p.y23 = p.z23 = gr_v2(0.0f);
-        const uint32_t i = gg << 2;
-        const uint32_t nib = MASK ? (t.bits >> ((gg & 7u) * 4u)) & 15u : 15u;       // MASK: which of the lane's four atoms are selected
         // which of the lane's four atoms count: inside [first, last), in a trip that exists, bit set (MASK).  The others -- a ragged end
         // of the selection, a trip behind it, an atom whose bit is clear -- become copies of the first atom with zero mass and zero
         // reference coordinates: v = 0 adds nothing to any sum and lies inside every extent (the first atom's own v is 0), and
         // whatever such an atom holds, a NaN included, never reaches the arithmetic.  One wave-uniform branch around plain selects:
         // written as per-atom `if`s under a divergent `if`, the masked kernel came out of the compiler with atom 0's coordinates
         // NOT replaced in one of the two unrolled copies (its mass was) -- its fractional coordinates leaked into the image proof.
-        uint32_t keep = gg < g1 ? nib : 0u;
-        keep &= (i >= first ? 1u : 0u) | (i + 1 >= first ? 2u : 0u) | (i + 2 >= first ? 4u : 0u) | (i + 3 >= first ? 8u : 0u);
-        keep &= (i < last ? 1u : 0u) | (i + 1 < last ? 2u : 0u) | (i + 2 < last ? 4u : 0u) | (i + 3 < last ? 8u : 0u);
-        if (__builtin_amdgcn_ballot_w64(keep != 15u) != 0ull) {
-            const bool k0 = (keep & 1u) != 0, k1 = (keep & 2u) != 0, k2 = (keep & 4u) != 0, k3 = (keep & 8u) != 0;
-            q.x01.x = k0 ? q.x01.x : gx; q.y01.x = k0 ? q.y01.x : gy; q.z01.x = k0 ? q.z01.x : gz; mm.x = k0 ? mm.x : 0.f;
-            q.x01.y = k1 ? q.x01.y : gx; q.y01.y = k1 ? q.y01.y : gy; q.z01.y = k1 ? q.z01.y : gz; mm.y = k1 ? mm.y : 0.f;
-            q.x23.x = k2 ? q.x23.x : gx; q.y23.x = k2 ? q.y23.x : gy; q.z23.x = k2 ? q.z23.x : gz; mm.z = k2 ? mm.z : 0.f;
-            q.x23.y = k3 ? q.x23.y : gx; q.y23.y = k3 ? q.y23.y : gy; q.z23.y = k3 ? q.z23.y : gz; mm.w = k3 ? mm.w : 0.f;
-            if (!NOREF) {
-                p.x01.x = k0 ? p.x01.x : 0.f; p.y01.x = k0 ? p.y01.x : 0.f; p.z01.x = k0 ? p.z01.x : 0.f;
-                p.x01.y = k1 ? p.x01.y : 0.f; p.y01.y = k1 ? p.y01.y : 0.f; p.z01.y = k1 ? p.z01.y : 0.f;
-                p.x23.x = k2 ? p.x23.x : 0.f; p.y23.x = k2 ? p.y23.x : 0.f; p.z23.x = k2 ? p.z23.x : 0.f;
-                p.x23.y = k3 ? p.x23.y : 0.f; p.y23.y = k3 ? p.y23.y : 0.f; p.z23.y = k3 ? p.z23.y : 0.f;
+        const bool interior = tile >= int_lo && tile < int_hi;                                 // (scalar)
+        if (MASK || !interior) {
+            const uint32_t gg = (tile << 6) + lane, i = gg << 2;
+            const uint32_t nib = MASK ? (t.bits >> ((gg & 7u) * 4u)) & 15u : 15u;             // MASK: which of the lane's four atoms are selected
+            uint32_t keep = tile < tile_end ? nib : 0u;
+            if (!interior) {
+                keep &= (i >= first ? 1u : 0u) | (i + 1 >= first ? 2u : 0u) | (i + 2 >= first ? 4u : 0u) | (i + 3 >= first ? 8u : 0u);
+                keep &= (i < last ? 1u : 0u) | (i + 1 < last ? 2u : 0u) | (i + 2 < last ? 4u : 0u) | (i + 3 < last ? 8u : 0u);
+            }
+            if (__builtin_amdgcn_ballot_w64(keep != 15u) != 0ull) {
+                const bool k0 = (keep & 1u) != 0, k1 = (keep & 2u) != 0, k2 = (keep & 4u) != 0, k3 = (keep & 8u) != 0;
+                q.x01.x = k0 ? q.x01.x : gx; q.y01.x = k0 ? q.y01.x : gy; q.z01.x = k0 ? q.z01.x : gz; mm.x = k0 ? mm.x : 0.f;
+                q.x01.y = k1 ? q.x01.y : gx; q.y01.y = k1 ? q.y01.y : gy; q.z01.y = k1 ? q.z01.y : gz; mm.y = k1 ? mm.y : 0.f;
+                q.x23.x = k2 ? q.x23.x : gx; q.y23.x = k2 ? q.y23.x : gy; q.z23.x = k2 ? q.z23.x : gz; mm.z = k2 ? mm.z : 0.f;
+                q.x23.y = k3 ? q.x23.y : gx; q.y23.y = k3 ? q.y23.y : gy; q.z23.y = k3 ? q.z23.y : gz; mm.w = k3 ? mm.w : 0.f;
+                if (!NOREF) {
+                    p.x01.x = k0 ? p.x01.x : 0.f; p.y01.x = k0 ? p.y01.x : 0.f; p.z01.x = k0 ? p.z01.x : 0.f;
+                    p.x01.y = k1 ? p.x01.y : 0.f; p.y01.y = k1 ? p.y01.y : 0.f; p.z01.y = k1 ? p.z01.y : 0.f;
+                    p.x23.x = k2 ? p.x23.x : 0.f; p.y23.x = k2 ? p.y23.x : 0.f; p.z23.x = k2 ? p.z23.x : 0.f;
+                    p.x23.y = k3 ? p.x23.y : 0.f; p.y23.y = k3 ? p.y23.y : 0.f; p.z23.y = k3 ? p.z23.y : 0.f;
+                }
             }
         }
+#ifdef GR_EXP_SUMS_NOMATH      /* experiment: the loads alone (every loaded value is consumed by one add) */
+        {
+            S.m += (q.x01 + q.y01) + (q.z01 + q.x23) + (q.y23 + q.z23) + (p.x01 + p.y01) + (p.z01 + p.x23) + (p.y23 + p.z23) + gr_v2p(mm.x + mm.z, mm.y + mm.w);
+            if (GR_SUMS_DEEP) request_rows(tile + 2u * tstep, t);
+            return;
+        }
+#endif
         if (GR_SUMS_DEEP) {
             // the differences first: the row registers are then free, and the rows of the trip after next are requested into them now
             q.x01 -= gr_v2(gx); q.y01 -= gr_v2(gy); q.z01 -= gr_v2(gz); q.x23 -= gr_v2(gx); q.y23 -= gr_v2(gy); q.z23 -= gr_v2(gz);
             asm volatile("" :: "v"(q.x01), "v"(q.y01), "v"(q.z01), "v"(q.x23), "v"(q.y23), "v"(q.z23));
-            request_rows(gg + 2u * gstep_, t);
+            request_rows(tile + 2u * tstep, t);
             gr_sums_pair<NOREF, RMSD, true>(S, q.x01, q.y01, q.z01, p.x01, p.y01, p.z01, gr_v2p(mm.x, mm.y), B, boxp, gx, gy, gz, &Rm, 0);
             gr_sums_pair<NOREF, RMSD, true>(S, q.x23, q.y23, q.z23, p.x23, p.y23, p.z23, gr_v2p(mm.z, mm.w), B, boxp, gx, gy, gz, &Rm, 1);
         } else {
@@ -275,21 +290,27 @@ __global__ __launch_bounds__(GR_WG) void k_sums_pk(
         }
         if (RMSD && (++trips % GR_RMSD_FLUSH) == 0) flush();
     };
-    const uint32_t gstep = nchunks * GR_WG;
-    uint32_t g = g0 + chunk * GR_WG + threadIdx.x;
-    if (__builtin_amdgcn_ballot_w64(g < g1) != 0ull) {
+    // Software pipeline with TWO NAMED register sets and the loop unrolled by two: reference + masses of trip k + 1 are requested before
+    // the arithmetic of trip k, the frame's rows of trip k + 2 inside it (GR_SUMS_DEEP), and the only wait before the arithmetic is "all but
+    // the loads issued since".  (Rounds 2-3 wrote this as `if (next < end) request(next, n..); ...; r = n` -- and the compiler, which has
+    // to merge the loaded and the not-loaded value at the join and to copy the landing registers at the end of the body, waited for the
+    // new loads right after issuing them and drained the queue at the end of every trip: nothing was prefetched.)
+    uint32_t tile = tile_first + chunk * (GR_WG / 64u) + wave_u;
+    if (tile < tile_end) {
         Trip TA, TB;
-        request(g, TA);
-        if (GR_SUMS_DEEP) request_rows(g + gstep, TB);
+        request_rows(tile, TA); request_pm(tile, TA);
+        if (GR_SUMS_DEEP) request_rows(tile + tstep, TB);
         for (;;) {
-            if (GR_SUMS_DEEP) request_pm(g + gstep, TB); else request(g + gstep, TB);
-            process(TA, g);
-            g += gstep;
-            if (__builtin_amdgcn_ballot_w64(g < g1) == 0ull) break;
-            if (GR_SUMS_DEEP) request_pm(g + gstep, TA); else request(g + gstep, TA);
-            process(TB, g);
-            g += gstep;
-            if (__builtin_amdgcn_ballot_w64(g < g1) == 0ull) break;
+            if (!GR_SUMS_DEEP) request_rows(tile + tstep, TB);
+            request_pm(tile + tstep, TB);
+            process(TA, tile);
+            tile += tstep;
+            if (tile >= tile_end) break;
+            if (!GR_SUMS_DEEP) request_rows(tile + tstep, TA);
+            request_pm(tile + tstep, TA);
+            process(TB, tile);
+            tile += tstep;
+            if (tile >= tile_end) break;
         }
     }
     // epilogue (as k_rmsd_accum's LITE epilogue): every wave reduce-scatters its 19 sums and 12 extents, the four waves

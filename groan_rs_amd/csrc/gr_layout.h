@@ -48,6 +48,31 @@ __device__ __forceinline__ void gr_rows_store(float4 *__restrict__ f4, size_t g,
     if (NT) { gr_stream_store(f4 + b, r0); gr_stream_store(f4 + b + 64, r1); gr_stream_store(f4 + b + 128, r2); }
     else { f4[b] = r0; f4[b + 64] = r1; f4[b + 128] = r2; }
 }
+// Frame rows through BUFFER loads: the frame's slot is a buffer resource (its base a wave-uniform pointer, its size the slot's),
+// the lane's rows 32-bit byte offsets into it.  What that buys the streaming loop is loads WITHOUT CONDITIONS: a turn that does not
+// exist gets a resource of zero records, a group that does not exist an offset beyond every slot -- the hardware's bounds check
+// returns zeros and touches no memory.  With `if (turn exists) load` / `if (group B exists) load` the compiler has to merge loaded
+// and not-loaded values where the branches join, does it with register copies, and waits for the loads it has just issued in
+// order to copy them (round 4 found `s_waitcnt vmcnt(3)` + six moves right behind the row request of every other turn).
+typedef int gr_i4 __attribute__((ext_vector_type(4)));
+#define GR_BUF_NOWHERE 0xFFFFF000u      /* byte offset of a group that does not exist: out of range of every slot (+ 2 KiB of row offsets) */
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t gr_buf_rsrc(const void *base, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float4 gr_buf_load_stream(__amdgpu_buffer_rsrc_t r, uint32_t byte_off) {
+    const gr_i4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 2 /* nt */);
+    return make_float4(__int_as_float(v.x), __int_as_float(v.y), __int_as_float(v.z), __int_as_float(v.w));
+}
+__device__ __forceinline__ float gr_buf_load_f32(__amdgpu_buffer_rsrc_t r, uint32_t byte_off) {
+    return __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, 0));
+}
+// ... with a wave-uniform part of the address in an SGPR (`soff`, bytes): a walk whose lanes keep their place inside a tile and move from
+// tile to tile spends no vector instruction on addresses (k_sums_pk)
+template <int AUX /* 0 plain, 2 nt */>
+__device__ __forceinline__ float4 gr_buf_load_f4(__amdgpu_buffer_rsrc_t r, uint32_t lane_off, uint32_t soff) {
+    const gr_i4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)lane_off, (int)soff, AUX);
+    return make_float4(__int_as_float(v.x), __int_as_float(v.y), __int_as_float(v.z), __int_as_float(v.w));
+}
 // rows <-> the four atoms of the group
 __device__ __forceinline__ void gr_rows_unpack(const float4 &r0, const float4 &r1, const float4 &r2, float (&x)[4], float (&y)[4], float (&z)[4]) {
     x[0] = r0.x; x[1] = r0.y; y[0] = r0.z; y[1] = r0.w; z[0] = r1.x; z[1] = r1.y; x[2] = r1.z; x[3] = r1.w; y[2] = r2.x; y[3] = r2.y; z[2] = r2.z; z[3] = r2.w;

@@ -173,21 +173,7 @@ __device__ __forceinline__ float gr_lane_f(unsigned long long v, int l) { return
 __device__ __forceinline__ void gr_lds_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); }
 __device__ __forceinline__ void gr_lds_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local"); }
 
-// Frame rows through BUFFER loads: the frame's slot is a buffer resource (its base a wave-uniform pointer, its size the slot's),
-// the lane's rows 32-bit byte offsets into it.  What that buys the streaming loop is loads WITHOUT CONDITIONS: a turn that does not
-// exist gets a resource of zero records, a group that does not exist an offset beyond every slot -- the hardware's bounds check
-// returns zeros and touches no memory.  With `if (turn exists) load` / `if (group B exists) load` the compiler has to merge loaded
-// and not-loaded values where the branches join, does it with register copies, and waits for the loads it has just issued in
-// order to copy them (round 4 found `s_waitcnt vmcnt(3)` + six moves right behind the row request of every other turn).
-typedef int gr_i4 __attribute__((ext_vector_type(4)));
-#define GR_BUF_NOWHERE 0xFFFFF000u      /* byte offset of a group that does not exist: out of range of every slot (+ 2 KiB of row offsets) */
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t gr_buf_rsrc(const void *base, uint32_t bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, 0x00020000);
-}
-__device__ __forceinline__ float4 gr_buf_load_stream(__amdgpu_buffer_rsrc_t r, uint32_t byte_off) {
-    const gr_i4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 2 /* nt */);
-    return make_float4(__int_as_float(v.x), __int_as_float(v.y), __int_as_float(v.z), __int_as_float(v.w));
-}
+// (buffer resources and loads: gr_layout.h)
 // the fitted rows leave as agent-scope non-temporal stores (sc1 nt): measured on a persistent copy of this launch shape
 // (tools/store_variants.hip, three runs): 4.31-4.35 us per 1e6-atom frame against 4.45-4.49 with plain non-temporal stores
 #ifndef GR_RES_STORE_AUX
@@ -196,9 +182,6 @@ __device__ __forceinline__ float4 gr_buf_load_stream(__amdgpu_buffer_rsrc_t r, u
 __device__ __forceinline__ void gr_buf_store_stream(__amdgpu_buffer_rsrc_t r, uint32_t byte_off, const float4 &v) {
     gr_i4 t; t.x = __float_as_int(v.x); t.y = __float_as_int(v.y); t.z = __float_as_int(v.z); t.w = __float_as_int(v.w);
     __builtin_amdgcn_raw_buffer_store_b128(t, r, (int)byte_off, 0, GR_RES_STORE_AUX);
-}
-__device__ __forceinline__ float gr_buf_load_f32(__amdgpu_buffer_rsrc_t r, uint32_t byte_off) {
-    return __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, 0));
 }
 
 // one 4-atom group of a lane: which of its atoms belong to the selection, its reference rows, masses and weights (registers)
