@@ -108,6 +108,8 @@ struct gr_ctx {
     // fastest with 20-32 KiB of loads in flight per CU (tools/copy_matrix3 --occ: 3 KiB per wave at 2 workgroups per CU 6.2 TB/s, at 8 -- what the
     // registers allow -- 5.77); the surplus workgroups are kept off the CU by LDS they do not use
     int stream_wgs_cu = 0;            // 0: chosen by the library (see stream_lds), 1..8
+    int center_resident = 1;          // GR_TUNE_CENTER_RESIDENT 0: atoms_center is always two passes; 1: the resident pass's atoms_center form where it pays (see center_resident)
+    uint64_t cen_res_launches = 0, cen_res_redone = 0;   // gr_ctx_stat: resident atoms_center launches; frames they handed back to the two passes
     int res_fit_last = 0;             // GR_TUNE_RESIDENT_FIT_LAST 0: chosen by the launch's fill, 1: the fit first, 2: the sums first
     struct Metro { uint64_t shape = 0; double free_ns = 0, T_ns = 0, best_ns = 0, fail_ns = 0; uint32_t off_for = 0, held = 0; } metro;
     uint64_t res_metro_period_ns = 0, res_last_turn_ns = 0, res_late_permille = 0, res_sclk_mhz = 0;   // gr_ctx_stat: the last resident launch
@@ -291,6 +293,12 @@ static const void *resident_fn(bool wmass, bool ubox, bool v, bool fl) {
 #undef GR_RES_FN
     return fn[(wmass ? 1 : 0) | (ubox ? 2 : 0) | (v ? 4 : 0) | (fl ? 8 : 0)];
 }
+// ... and the four of its atoms_center form (MODE 1: rows parked, sums first; the centre mass-weighted or not is a launch parameter)
+static const void *resident_center_fn(bool ubox, bool fl) {
+    static const void *const fn[4] = { reinterpret_cast<const void *>(&k_fit_resident<false, false, false, false, 1>), reinterpret_cast<const void *>(&k_fit_resident<false, true, false, false, 1>),
+                                       reinterpret_cast<const void *>(&k_fit_resident<false, false, false, true, 1>), reinterpret_cast<const void *>(&k_fit_resident<false, true, false, true, 1>) };
+    return fn[(ubox ? 1 : 0) | (fl ? 2 : 0)];
+}
 #ifndef GR_STREAM_WGS_CU_DEFAULT
 #define GR_STREAM_WGS_CU_DEFAULT 8
 #endif
@@ -300,6 +308,8 @@ static bool resident_prepare() {
     ok = ok && hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fit_pk<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 5120) == hipSuccess;
     for (int v = 0; v < 16; ++v)
         ok = ok && hipFuncSetAttribute(resident_fn((v & 1) != 0, (v & 2) != 0, (v & 4) != 0, (v & 8) != 0), hipFuncAttributeMaxDynamicSharedMemorySize, GrResShape::LDS_BYTES) == hipSuccess;
+    for (int v = 0; v < 4; ++v)
+        ok = ok && hipFuncSetAttribute(resident_center_fn((v & 1) != 0, (v & 2) != 0), hipFuncAttributeMaxDynamicSharedMemorySize, GrResShape::LDS_BYTES) == hipSuccess;
     return ok;
 }
 
@@ -1731,6 +1741,113 @@ int gr_group_center_batch(gr_ctx *c, uint32_t first_slot, uint32_t n_frames, con
     if (first_err != GR_OK) { c->err = first_msg; c->err_index = first_idx; }
     return first_err;
 } catch (...) { return gr_abi_guard(); }
+// atoms_center of the WHOLE system about a large contiguous reference group as ONE pass over HBM: the resident pass in its MODE 1 (gr_resident.h).
+// `done[f]` = 1: frame f is finished (its state is in c->state_host[f]); 0: the caller runs the two passes on it (the launch was not taken, never
+// started, was aborted before the frame, or handed the frame back -- an atom without position or mass, sums that are not finite);
+// `torn[f]` = 1: an aborted launch left the frame half-moved (reported as GR_E_HIP, as the RMSD-fit form does).
+static int center_resident(gr_ctx *c, uint32_t s0, uint32_t nb, const GrSel &all, const GrSel &csel, int dim_mask, int weighted,
+                           const std::vector<int> &pre, std::vector<uint8_t> &done, std::vector<uint8_t> &torn) {
+    done.assign(nb, 0); torn.assign(nb, 0);
+    if (!c->center_resident || !csel.contiguous || csel.masked || !all.contiguous || all.start != 0 || all.n != c->n) return GR_OK;
+    // which groups: the launch costs the same whatever the group (measured at 1e6 atoms, us per frame, two passes -> one: the whole system
+    // 6.1-6.3 -> 4.4-4.6, half of it 5.2 -> 4.7, a tenth 4.4 -> not taken: the estimate pass shrinks with the group, this one does not;
+    // profiles/r05_center_bench.json); from 30 % of the system
+    if (c->resident == 1 && (uint64_t)csel.n * 100 < c->n * 30) return GR_OK;
+    uint32_t streams = 1, gwg = GR_RES_GROUPS;
+    const uint32_t wgs = resident_wgs(c, true, nb, all, &streams, &gwg);
+    if (!wgs) return GR_OK;
+    if (!resident_acquire(c->device)) return GR_OK;
+    struct Release { gr_ctx *c; ~Release() { resident_release(c->device); } } release{ c };
+    hipStream_t S = c->stream;
+    const uint32_t res_stream = wgs * streams;
+    const uint32_t n_fin = std::min<uint32_t>(streams > 8 ? GR_RES_MAX_FIN : 8, c->res_max_wgs - res_stream);
+    const size_t rec_words = (size_t)nb * ((wgs + GR_RES_REC_PAD - 1u) & ~(uint32_t)(GR_RES_REC_PAD - 1u)) * GR_RES_REC_WORDS;
+    if (rec_words > c->res_wgrec_cap) {
+        if (c->res_wgrec) (void)hipFree(c->res_wgrec);
+        c->res_wgrec = nullptr; c->res_wgrec_cap = 0;
+        HIPCHK(c, hipMalloc(&c->res_wgrec, rec_words * sizeof(unsigned long long)));
+        HIPCHK(c, hipMemsetAsync(c->res_wgrec, 0, rec_words * sizeof(unsigned long long), S));   // tag 0 = no launch
+        c->res_wgrec_cap = rec_words;
+    }
+    GrResCtl ctl;
+    memset(&ctl, 0, sizeof ctl);
+    ctl.wgrec = c->res_wgrec; ctl.rec = c->res_rec; ctl.abort = c->res_abort; ctl.progress = c->res_progress; ctl.epoch = ++c->res_epoch; ctl.n_stream = res_stream; ctl.n_fin = n_fin;
+    ctl.wgs_frame = wgs; ctl.streams = streams; ctl.groups_wg = gwg;
+    ctl.team_waves = resident_team_waves(wgs, streams);
+    ctl.patience_ticks = (unsigned long long)c->wall_khz * 3000ull; ctl.start_ticks = (unsigned long long)c->wall_khz * 200ull;   // 3 s, 0.2 s
+    ctl.test_abort_frame = c->res_test_abort_at; c->res_test_abort_at = 0xFFFFFFFFu;
+    ctl.metro_t16 = 0; ctl.metro_lead = 0;                // (the waves run free)
+    ctl.cen_weighted = weighted ? 1u : 0u; ctl.cen_dim_mask = (uint32_t)dim_mask;
+    float *frames = c->frames; size_t stride = c->frame_stride; uint32_t slot0 = s0, nfr = nb, natoms = (uint32_t)c->n;
+    const float *masses = c->masses; GrSel sel_arg = csel; const GrBox *boxes = c->boxes_dev; GrPlanDev plan; memset(&plan, 0, sizeof plan);
+    GrFrameState *states = c->state_dev; double *fparts = nullptr;
+    void *args[] = { &frames, &stride, &slot0, &nfr, &natoms, &masses, &sel_arg, &boxes, &plan, &states, &fparts, &ctl };
+    bool ubox = true;
+    for (uint32_t f = 1; f < nb && ubox; ++f) ubox = memcmp(&c->boxes_host[s0 + f], &c->boxes_host[s0], sizeof(GrBox)) == 0;
+    const bool fit_last = c->res_fit_last ? c->res_fit_last == 2 : (uint64_t)res_stream * 10u >= (uint64_t)c->res_max_wgs * 9u;
+    k_res_prepare<<<dim3((res_stream * 8 + 255) / 256), dim3(256), 0, S>>>(c->res_abort + 1, c->res_progress, res_stream * 8);
+    HIPCHK(c, hipGetLastError());
+    if (c->res_test_no_start) { const uint32_t two = 2u; c->res_test_no_start = 0; HIPCHK(c, hipMemcpyAsync(c->res_abort + 2, &two, sizeof two, hipMemcpyHostToDevice, S)); HIPCHK(c, hipStreamSynchronize(S)); }
+    if (hipLaunchKernel(resident_center_fn(ubox, fit_last), dim3(res_stream + n_fin), dim3(GrResShape::LANES), args, GrResShape::LDS_BYTES, S) != hipSuccess) {
+        (void)hipGetLastError();          // nothing ran: the two passes take the batch
+        c->res_max_wgs = 0;
+        return GR_OK;
+    }
+    HIPCHK(c, hipMemcpyAsync(c->res_words_host, c->res_abort, 12 * sizeof(uint32_t), hipMemcpyDeviceToHost, S));
+    HIPCHK(c, hipMemcpyAsync(c->state_host, c->state_dev, nb * sizeof(GrFrameState), hipMemcpyDeviceToHost, S));
+    HIPCHK(c, hipStreamSynchronize(S));
+    c->res_last_streams = streams;
+    if (c->res_words_host[2] != 1u) {      // the launch never started (the device is shared): nothing was touched; sit out the next batches
+        c->res_handshake_misses++;
+        c->res_backoff = c->res_backoff ? std::min<uint32_t>(c->res_backoff * 2u, 1024u) : 4u;
+        c->res_skip = c->res_backoff;
+        return GR_OK;
+    }
+    c->res_backoff = 0;
+    c->cen_res_launches++;
+#ifdef GR_EXP_STEPTIME
+    if (getenv("GR_STEPTIME")) {
+        unsigned long long st[32];
+        if (hipMemcpy(st, c->res_abort + 16, sizeof st, hipMemcpyDeviceToHost) == hipSuccess) {
+            const double turns_ = (double)((nb + streams - 1) / streams + GrResShape::K);
+            const char *who[4] = { "wg 0 wave 0", "wg 0 wave 5", "wg mid wave 0", "wg mid wave 5" };
+            for (int w = 0; w < 4; ++w) {
+                fprintf(stderr, "center steptime %-14s ticks/turn:", who[w]);
+                double tot = 0; for (int k = 0; k < 7; ++k) tot += (double)st[w * 8 + k];
+                const char *nm[7] = { "gate", "request", "rows+sums", "reduce+handover", "record wait", "fit+stores", "park" };
+                for (int k = 0; k < 7; ++k) fprintf(stderr, " %s %.0f", nm[k], (double)st[w * 8 + k] / turns_);
+                fprintf(stderr, " | total %.0f | polled %.0f %% of fits\n", tot / turns_, 100.0 * (double)st[w * 8 + 7] / turns_);
+            }
+        }
+    }
+#endif
+    std::vector<uint32_t> lo(streams, nb), hi(streams, nb);   // per stream: turns every wave has been through / some wave has
+    if (c->res_words_host[0]) {
+        // aborted (see segment_end): frames below the smallest count of their stream are complete, frames at or above the largest are untouched
+        (void)hipMemset(c->res_abort, 0, sizeof(uint32_t));
+        c->res_aborts++;
+        std::vector<uint32_t> prog((size_t)res_stream * 8);
+        HIPCHK(c, hipMemcpy(prog.data(), c->res_progress, prog.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        const uint32_t per = wgs * 8u;
+        for (uint32_t s = 0; s < streams; ++s) {
+            lo[s] = nb; hi[s] = 0u;
+            for (uint32_t k = 0; k < per; ++k) {
+                const uint32_t v = prog[(size_t)s * per + k];
+                if (v == GR_RES_IDLE_WAVE) continue;
+                lo[s] = std::min(lo[s], v); hi[s] = std::max(hi[s], v);
+            }
+        }
+    }
+    for (uint32_t f = 0; f < nb; ++f) {
+        const int st = c->state_host[f].status;
+        const uint32_t s = f % streams, turn = f / streams;
+        if (pre[f] != GR_OK) { done[f] = 1; continue; }                       // (failed before the launch: nobody touched it)
+        if (st == GR_ST_FALLBACK || st == GR_ST_ABORTED || turn >= hi[s]) { c->cen_res_redone++; continue; }
+        if (turn >= lo[s]) { torn[f] = 1; done[f] = 1; continue; }
+        done[f] = 1;
+    }
+    return GR_OK;
+}
 // translate / wrap / centre a batch of frames: pre[] carries the host checks, frames that failed are left untouched
 static int translate_batch(gr_ctx *c, uint32_t s0, uint32_t nb, const Group *g, const float *v, int mode, int dim_mask,
                            const std::vector<int> &pre, const std::vector<std::string> &msg, int *status_out, int &first_err, std::string &first_msg, uint64_t &first_idx) {
@@ -1776,6 +1893,36 @@ static int translate_batch_api(gr_ctx *c, uint32_t first_slot, uint32_t n_frames
         batch_prechecks(c, s0, nb, true, pre, msg);
         SlotUse use(c, s0, nb);
         st = states_from_prechecks(c, nb, pre); if (st) return st;
+        // atoms_center of the whole system about a large group: one pass over HBM where the resident pass takes it (center_resident); the frames
+        // it did not finish -- all of them when it was not taken -- go through the two passes below, one run of consecutive frames at a time
+        std::vector<uint8_t> done(nb, 0), torn(nb, 0);
+        if (cg) { st = center_resident(c, s0, nb, make_sel(*g), make_sel(*cg), mask[dim], weighted, pre, done, torn); if (st) return st; }
+        bool any_done = false;
+        for (uint32_t f = 0; f < nb; ++f) any_done = any_done || done[f];
+        if (any_done) {
+            for (uint32_t f = 0; f < nb; ++f) {
+                if (!done[f]) continue;
+                int sf = pre[f];
+                if (sf != GR_OK) c->err = msg[f];
+                else if (torn[f]) sf = fail(c, GR_E_HIP, "the resident atoms_center pass stalled while this frame was being moved: some of its atoms carry the new coordinates, others the original ones (frame index in gr_last_error_index)", b0 + f);
+                else if (c->state_host[f].status != GR_OK) sf = frame_status(c, c->state_host[f]);
+                if (sf != GR_OK && first_err == GR_OK) { first_err = sf; first_msg = c->err; first_idx = c->err_index; }
+                if (status_out) status_out[b0 + f] = sf;
+            }
+            for (uint32_t a = 0; a < nb; ) {
+                if (done[a]) { ++a; continue; }
+                uint32_t b = a;
+                while (b < nb && !done[b]) ++b;
+                const std::vector<int> pre_run(pre.begin() + a, pre.begin() + b);
+                const std::vector<std::string> msg_run(msg.begin() + a, msg.begin() + b);
+                st = states_from_prechecks(c, b - a, pre_run); if (st) return st;
+                st = center_stage(c, s0 + a, b - a, make_sel(*cg), 1, weighted, 1, 0); if (st) return st;
+                st = translate_batch(c, s0 + a, b - a, g, v, 1, mask[dim], pre_run, msg_run, status_out ? status_out + b0 + a : nullptr, first_err, first_msg, first_idx);
+                if (st) return st;
+                a = b;
+            }
+            continue;
+        }
         if (cg) { st = center_stage(c, s0, nb, make_sel(*cg), 1, weighted, 1, 0); if (st) return st; }   // group_estimate_center / _com per frame
         st = translate_batch(c, s0, nb, g, v, cg ? 1 : 2, cg ? mask[dim] : 7, pre, msg, status_out ? status_out + b0 : nullptr, first_err, first_msg, first_idx);
         if (st) return st;
@@ -1892,6 +2039,8 @@ int gr_ctx_stat(const gr_ctx *c, int key, uint64_t *value) {
     case GR_STAT_RES_LAST_TURN_NS: *value = c->res_last_turn_ns; return GR_OK;
     case GR_STAT_RES_LATE_PERMILLE: *value = c->res_late_permille; return GR_OK;
     case GR_STAT_RES_SCLK_MHZ: *value = c->res_sclk_mhz; return GR_OK;
+    case GR_STAT_CENTER_RES_LAUNCHES: *value = c->cen_res_launches; return GR_OK;
+    case GR_STAT_CENTER_RES_REDONE: *value = c->cen_res_redone; return GR_OK;
     default: return GR_E_INVALID_ARG;
     }
 }
@@ -1917,6 +2066,7 @@ int gr_ctx_set_tuning(gr_ctx *c, int key, int64_t value) try {
     case GR_TUNE_RESIDENT_METRO_NS: if (value < 0 || value > 1000000 || (value > 1 && value < 100)) break; c->res_metro_ns = (int)value; c->metro = gr_ctx::Metro(); return GR_OK;
     case GR_TUNE_RESIDENT_FIT_LAST: if (value < 0 || value > 2) break; c->res_fit_last = (int)value; return GR_OK;
     case GR_TUNE_STREAM_WGS_PER_CU: if (value < 0 || value > 8) break; c->stream_wgs_cu = (int)value; return GR_OK;
+    case GR_TUNE_CENTER_RESIDENT: if (value < 0 || value > 1) break; c->center_resident = (int)value; return GR_OK;
     case GR_TUNE_RESIDENT_FILL: if (value < 1 || value > 16) break; c->res_fill16 = (int)value; return GR_OK;
     case GR_TUNE_RESIDENT_GROUPS: if (value != 2) break; return GR_OK;   // (the one-group shape was removed: gr_resident.h)
     case GR_TUNE_TEST_RESIDENT_NO_START: c->res_test_no_start = value ? 1 : 0; return GR_OK;

@@ -150,6 +150,7 @@ struct GrResCtl {
     uint32_t test_abort_frame;     // tests: the finalizer of this frame raises `abort` instead of closing it (0xFFFFFFFF: never)
     uint32_t metro_t16;            // METRONOME (see the walk): the turn period in ticks of wall_clock64() x 16; 0 = the waves run free
     uint32_t metro_lead;           // ticks between the opening of the launch and turn 0's first slot
+    uint32_t cen_weighted, cen_dim_mask;   // MODE 1 (atoms_center): the reference group's centre is mass-weighted; the Dimension's axes (bit 0 x, 1 y, 2 z)
 #ifdef GR_EXP_TIMELINE
     unsigned long long *tl;        // [frames][8] device-clock stamps of a frame's way through the launch (tools/timeline_bench.sh)
 #endif
@@ -187,7 +188,8 @@ __device__ __forceinline__ void gr_buf_store_stream(__amdgpu_buffer_rsrc_t r, ui
 // one 4-atom group of a lane: which of its atoms belong to the selection, its reference rows, masses and weights (registers)
 // (the per-lane facts are bits of ONE register: seven `bool`s would be seven 64-bit lane masks -- 14 SGPRs per group held
 // across the whole loop, and the kernel was spilling SGPRs into vector lanes)
-enum { GR_RG_IN0 = 1u, GR_RG_IN1 = 2u, GR_RG_IN2 = 4u, GR_RG_IN3 = 8u, GR_RG_ANY = 16u /* some atom in the selection */, GR_RG_FULL = 32u /* all four */ };
+enum { GR_RG_IN0 = 1u, GR_RG_IN1 = 2u, GR_RG_IN2 = 4u, GR_RG_IN3 = 8u, GR_RG_ANY = 16u /* some atom in the selection */, GR_RG_FULL = 32u /* all four */,
+       GR_RG_EX0 = 64u, GR_RG_EX1 = 128u, GR_RG_EX2 = 256u, GR_RG_EX3 = 512u /* the atom exists (index < n_atoms): MODE 1 moves every atom of the system, not only the group's */, GR_RG_EXALL = 1024u };
 struct GrResGroup {
     bool valid;        // wave-uniform: the group lies inside the slot
     uint32_t flags;
@@ -279,7 +281,13 @@ __device__ __forceinline__ void gr_res_fit_group(const GrResGroup &Gr, const flo
 // UBOX: every frame of the launch has the same box (the host compared them): its constants are loaded once, not per frame.
 // V: the selection is the whole system -> image vectors are parked (see the header of this file).
 // FL: a step runs the sums of frame i before the fit of frame i - K (see `step`)
-template <bool WMASS, bool UBOX, bool V, bool FL>
+// MODE 1: ATOMS_CENTER (utility.rs:109-185) instead of the RMSD fit -- the same walk with other arithmetic: the sums stage forms the Bai-Breen
+//         sums of the reference group (`sel`; gr_center_atom<1>'s terms, 4-atom f32 partials widened to fp64 as k_center_sums does), a finalizer
+//         turns them into the group's centre (gr_center_close) and publishes shift = filter(box centre - centre, Dimension), the fit stage is
+//         x <- wrap(x + shift) for EVERY atom of the system (k_translate_wrap's arithmetic).  24 B per atom and frame instead of 36.  V is false
+//         (rows are parked), WMASS unused (ctl.cen_weighted), `plan` unused.  A frame with an atom without position, or whose sums are not
+//         finite, is published as GR_ST_FALLBACK: nobody touches it and the host runs the two passes on it, which name the atom.
+template <bool WMASS, bool UBOX, bool V, bool FL, int MODE = 0>
 __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
     float *__restrict__ frames, size_t frame_stride, uint32_t first_slot, uint32_t nframes, uint32_t n_atoms,
     const float *__restrict__ masses, GrSel sel, const GrBox *__restrict__ boxes, GrPlanDev plan,
@@ -418,6 +426,25 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
                 const double *t = wtot + (WAVES + team) * 32u;
                 if (lost) {
                     if (pre_status == 0) st.status = GR_ST_ABORTED;
+                } else if (MODE == 1) {
+                    if (pre_status == 0) {
+                        // the group's Bai-Breen sums (hi + lo words), closed as k_center_finalize closes them; a frame with an atom without
+                        // position / mass, or with sums that are not finite, goes back to the host untouched (the two passes name the atom)
+                        double acc[GR_CEN_K];
+                        bool fine = !(t[7] + t[15] > 0.0);
+#pragma unroll
+                        for (int k = 0; k < GR_CEN_K; ++k) acc[k] = k < 6 ? t[k] + t[8 + k] : 0.0;
+#pragma unroll
+                        for (int k = 0; k < 6; ++k) fine = fine && (fabs(acc[k]) <= 1.0e300);
+                        if (!fine) st.status = GR_ST_FALLBACK;
+                        else gr_center_close(acc, GR_NOIDX, GR_NOIDX, lb, 1, (int)ctl.cen_weighted, 1, 0, sel.n, st, 0);
+                        // shift = filter(box centre - centre, Dimension) (utility.rs:116-119; k_translate_wrap's own subtraction)
+                        st.shift[0] = (ctl.cen_dim_mask & 1u) ? lb.bcx - st.center[0] : 0.0f;
+                        st.shift[1] = (ctl.cen_dim_mask & 2u) ? lb.bcy - st.center[1] : 0.0f;
+                        st.shift[2] = (ctl.cen_dim_mask & 4u) ? lb.bcz - st.center[2] : 0.0f;
+#pragma unroll
+                        for (int k = 0; k < 9; ++k) st.R[k] = 0.0f;
+                    }
                 } else if (pre_status == 0) {
                     double acc[GR_ACC_K];
 #pragma unroll
@@ -519,10 +546,22 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
         }
         const bool in_sel = in0 || in1 || in2 || in3, full = in0 && in1 && in2 && in3;
         Gr.flags = (in0 ? GR_RG_IN0 : 0u) | (in1 ? GR_RG_IN1 : 0u) | (in2 ? GR_RG_IN2 : 0u) | (in3 ? GR_RG_IN3 : 0u) | (in_sel ? GR_RG_ANY : 0u) | (full ? GR_RG_FULL : 0u);
+        if (MODE == 1) {
+            const bool e0 = Gr.valid && i0 < n_atoms, e1 = Gr.valid && i0 + 1u < n_atoms, e2 = Gr.valid && i0 + 2u < n_atoms, e3 = Gr.valid && i0 + 3u < n_atoms;
+            Gr.flags |= (e0 ? GR_RG_EX0 : 0u) | (e1 ? GR_RG_EX1 : 0u) | (e2 ? GR_RG_EX2 : 0u) | (e3 ? GR_RG_EX3 : 0u) | ((e0 && e1 && e2 && e3) ? GR_RG_EXALL : 0u);
+        }
         Gr.b = (uint32_t)gr_row_index(Gr.valid ? g : 0u, 0);
         float4 pa = zero4, pb = zero4, pc = zero4;
         Gr.mm = zero4; Gr.ww = zero4;
-        if (in_sel) {
+        if (MODE == 1) {   // the group's weights: its masses, or one per atom (gr_center_atom: `weighted`)
+            if (in_sel) {
+                Gr.mm = ctl.cen_weighted ? reinterpret_cast<const float4 *>(masses)[g] : make_float4(1.f, 1.f, 1.f, 1.f);
+                if (!in0) Gr.mm.x = 0.f;
+                if (!in1) Gr.mm.y = 0.f;
+                if (!in2) Gr.mm.z = 0.f;
+                if (!in3) Gr.mm.w = 0.f;
+            }
+        } else if (in_sel) {
             gr_rows_load(reinterpret_cast<const float4 *>(plan.p), (size_t)(g - g0), pa, pb, pc);
             Gr.mm = reinterpret_cast<const float4 *>(masses)[g];
             if (!WMASS) Gr.ww = reinterpret_cast<const float4 *>(plan.w)[g - g0];
@@ -541,6 +580,9 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
     const float cx = plan.ref_com[0], cy = plan.ref_com[1], cz = plan.ref_com[2];
     // sum of the masses of the wave's atoms inside the selection: the same for every frame of the launch (an SGPR)
     const float m_wave = gr_first_f(gr_wave_allsum_f32(((GA.mm.x + GA.mm.y) + (GA.mm.z + GA.mm.w)) + ((GB.mm.x + GB.mm.y) + (GB.mm.z + GB.mm.w))));
+    // MODE 1: an atom of the group without mass (NaN; only a weighted centre looks at masses): every frame of the launch goes back to the host
+    const bool cen_mass_bad = MODE == 1 && ((GA.mm.x != GA.mm.x) || (GA.mm.y != GA.mm.y) || (GA.mm.z != GA.mm.z) || (GA.mm.w != GA.mm.w) ||
+                                            (GB.mm.x != GB.mm.x) || (GB.mm.y != GB.mm.y) || (GB.mm.z != GB.mm.z) || (GB.mm.w != GB.mm.w));
     // does the wave hold any atom of the selection?  (V: always; otherwise most waves of a small selection do not, and skip the sums arithmetic)
     const bool wave_sel = V || __builtin_amdgcn_ballot_w64(((GA.flags | GB.flags) & GR_RG_ANY) != 0u) != 0ull;
 
@@ -754,6 +796,106 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
         if (lane == 0) __hip_atomic_store(cnt_s + rs, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
 
+    // ---- MODE 1, the sums stage of frame i: the Bai-Breen sums of the reference group (iterators.rs:1152-1191,1314-1357).  Every atom's terms are
+    // gr_center_atom<1>'s -- the arithmetic of the two-pass path's k_center_sums<1>, bit for bit -- gathered per 4-atom group in f32 and widened
+    // to fp64 there, as that kernel does per trip; lanes -> wave (fp64 reduce-scatter) -> LDS (fp64) -> the workgroup's record: every sum as
+    // TWO tagged words, v = hi + lo (f32 each: 48 bits of the fp64 value), so that the finalizer's fp64 total differs from the two-pass path's
+    // only by the order of fp64 additions.  Word 7 / 15: atoms without position (x is NaN) among ALL the workgroup's atoms -- the frame is
+    // then left alone (see the finalizer).
+    auto sums_cen = [&](uint32_t i, const Landing &L, const GrBoxU &B) {
+        double d32[32];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) d32[k] = 0.0;
+        const GrBox *boxp = boxes + first_slot + kf(i);
+        bool bad = cen_mass_bad;
+        const float PI_X2 = 3.14159265358979323846f * 2.0f;       // auxiliary.rs:15 (as k_center_sums)
+        const float scx = PI_X2 / B.ax, scy = PI_X2 / B.by, scz = PI_X2 / B.cz;
+        // gr_center_atom<1>'s arithmetic for two atoms at a time -- the same IEEE operations in the same order, so the same bits: the position
+        // into the cell where it is not (one wave-wide test; gr_wrap is the identity inside), fractional coordinates in a non-orthogonal cell
+        // (reciprocal + one Newton step), theta = x (2 pi / L), its sine and cosine from the hardware in revolutions with the first-order
+        // correction for the rounding of theta / 2 pi
+        auto angles = [&](gr_v2f x, gr_v2f y, gr_v2f z, gr_v2f (&sn)[3], gr_v2f (&cs)[3]) {
+            if (B.tric) {
+                gr_v2f sc = z * gr_v2(B.icz);
+                sc = gr_v2_fma(gr_v2_fma(-sc, gr_v2(B.cz), z), gr_v2(B.icz), sc);
+                const gr_v2f uy = gr_v2_fma(-sc, gr_v2(B.cy), y);
+                gr_v2f sb = uy * gr_v2(B.iby);
+                sb = gr_v2_fma(gr_v2_fma(-sb, gr_v2(B.by), uy), gr_v2(B.iby), sb);
+                x = gr_v2_fma(-sc, gr_v2(B.cx), gr_v2_fma(-sb, gr_v2(B.bx), x));
+                y = uy;
+            }
+            const float IH = 0.15915493667125702f, IL = 6.4206382432985265e-09f, TWO_PI = 6.283185307179586f;
+            const gr_v2f th[3] = { x * gr_v2(scx), y * gr_v2(scy), z * gr_v2(scz) };
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const gr_v2f u = th[a] * gr_v2(IH);
+                const gr_v2f e = gr_v2_fma(th[a], gr_v2(IL), gr_v2_fma(th[a], gr_v2(IH), -u));
+                const gr_v2f s = gr_v2p(__builtin_amdgcn_sinf(u.x), __builtin_amdgcn_sinf(u.y)), c = gr_v2p(__builtin_amdgcn_cosf(u.x), __builtin_amdgcn_cosf(u.y));
+                const gr_v2f k = gr_v2(TWO_PI) * e;
+                sn[a] = gr_v2_fma(k, c, s); cs[a] = gr_v2_fma(-k, s, c);
+            }
+        };
+        auto group = [&](const GrResGroup &Gr, const Rows &rw) {
+            GrP4 q = gr_pairs_rows(rw.r0, rw.r1, rw.r2);
+            // atoms behind the system's last one hold anything: they become the origin (their weight is zero)
+            if (__builtin_amdgcn_ballot_w64((Gr.flags & GR_RG_EXALL) == 0u) != 0ull) {
+                if (!(Gr.flags & GR_RG_EX0)) { q.x01.x = 0.f; q.y01.x = 0.f; q.z01.x = 0.f; }
+                if (!(Gr.flags & GR_RG_EX1)) { q.x01.y = 0.f; q.y01.y = 0.f; q.z01.y = 0.f; }
+                if (!(Gr.flags & GR_RG_EX2)) { q.x23.x = 0.f; q.y23.x = 0.f; q.z23.x = 0.f; }
+                if (!(Gr.flags & GR_RG_EX3)) { q.x23.y = 0.f; q.y23.y = 0.f; q.z23.y = 0.f; }
+            }
+            // an atom without position (x is NaN: atom.rs) anywhere in the system: the frame goes back to the host
+            bad = bad || (q.x01.x != q.x01.x) || (q.x01.y != q.x01.y) || (q.x23.x != q.x23.x) || (q.x23.y != q.x23.y);
+            if (!wave_sel) return;    // no atom of the group in this wave
+            const float xl = gr_fminf(gr_min3f(q.x01.x, q.x01.y, q.x23.x), q.x23.y), xh = gr_fmaxf(gr_max3f(q.x01.x, q.x01.y, q.x23.x), q.x23.y);
+            const float yl = gr_fminf(gr_min3f(q.y01.x, q.y01.y, q.y23.x), q.y23.y), yh = gr_fmaxf(gr_max3f(q.y01.x, q.y01.y, q.y23.x), q.y23.y);
+            const float zl = gr_fminf(gr_min3f(q.z01.x, q.z01.y, q.z23.x), q.z23.y), zh = gr_fmaxf(gr_max3f(q.z01.x, q.z01.y, q.z23.x), q.z23.y);
+            const bool inside = (xl >= 0.0f) & (xh <= B.ax) & (yl >= 0.0f) & (yh <= B.by) & (zl >= 0.0f) & (zh <= B.cz);
+            if (__builtin_amdgcn_ballot_w64(!inside) != 0ull) {
+                float4 r0, r1, r2;
+                gr_rows_pairs(q, r0, r1, r2);
+                q = gr_res_wrap_slow(r0, r1, r2, 0.0f, 0.0f, 0.0f, boxp);
+            }
+            gr_v2f s01[3], c01[3], s23[3], c23[3];
+            angles(q.x01, q.y01, q.z01, s01, c01);
+            angles(q.x23, q.y23, q.z23, s23, c23);
+            // the group's 4-atom partials, atom by atom as k_center_sums adds them (p = fma(m, c, p)), widened once
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const float pc = fmaf(Gr.mm.w, c23[a].y, fmaf(Gr.mm.z, c23[a].x, fmaf(Gr.mm.y, c01[a].y, fmaf(Gr.mm.x, c01[a].x, 0.0f))));
+                const float ps = fmaf(Gr.mm.w, s23[a].y, fmaf(Gr.mm.z, s23[a].x, fmaf(Gr.mm.y, s01[a].y, fmaf(Gr.mm.x, s01[a].x, 0.0f))));
+                d32[a] += (double)pc; d32[3 + a] += (double)ps;
+            }
+        };
+        if (i < n_turns) {
+            group(GA, L.a);
+            if (GB.valid) group(GB, L.b);
+        }
+        d32[7] = bad ? 1.0 : 0.0;
+        GR_STEP_STAMP(2);
+        const uint32_t rs = i % R;
+        double *mine = reinterpret_cast<double *>(wsum + (rs * WAVES + wave) * 32);     // 16 doubles per wave record
+        const double dt = gr_wave_sum_scatter16_f64(d32, lane);                          // lane l: the wave total of value l >> 2
+        if ((lane & 3u) == 0 && lane < 32u) mine[lane >> 2] = dt;
+        gr_lds_release();
+        uint32_t old = 0;
+        if (lane == 0) old = __hip_atomic_fetch_add(cnt_s + rs, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if ((uint32_t)__builtin_amdgcn_readfirstlane((int)old) != n_waves - 1u) return;
+        gr_lds_acquire();
+        const double *all = reinterpret_cast<const double *>(wsum + rs * WAVES * 32);
+        if (lane < 31u) {
+            float word = 0.0f;
+            if (lane < 16u) {
+                double v = all[lane & 7u];
+                for (uint32_t w = 1; w < n_waves; ++w) v += all[w * 16u + (lane & 7u)];      // wave order
+                const float hi = (float)v;
+                word = lane < 8u ? hi : (float)(v - (double)hi);
+            }
+            gr_st_agent(ctl.wgrec + ((size_t)kf(i) * n_pad + wg) * GR_RES_REC_WORDS + lane, ((unsigned long long)ctl.epoch << 32) | __float_as_uint(word));
+        }
+        if (lane == 0) __hip_atomic_store(cnt_s + rs, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+
     // V fit of one group: R v + t0, sum w |R q - p|^2 (rmsd.rs:592-599; pad atoms weigh nothing), + reference COM
     auto fit_group_v = [&](const GrResGroup &Gr, const Rows &rw, const GrResRot &T, float t0x, float t0y, float t0z, Rows &o, float &rs) {
         const GrP4 v = gr_pairs_rows(rw.r0, rw.r1, rw.r2);
@@ -827,7 +969,56 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
         float rs = 0.0f;
         Rows oa, ob;
         oa.r0 = oa.r1 = oa.r2 = ob.r0 = ob.r1 = ob.r2 = zero4;
-        if (status == 0) {
+        if (MODE == 1) {
+            // x <- wrap(x + shift) for every atom of the system (k_translate_wrap: iterators.rs:1520-1553): the one-turn closed form per axis
+            // (c, then b, then a) is the general wrap's own arithmetic whenever no stage turns more than once and every result lies inside
+            // (0, L] -- one wave-wide test; otherwise the wave redoes its atoms with gr_wrap itself
+            if (status == 0) {
+                const GrBox *boxp = boxes + first_slot + kf(j);
+                auto center_group = [&](const GrResGroup &Gr, const Rows &rw, Rows &o) {
+                    GrP4 q = gr_pairs_rows(rw.r0, rw.r1, rw.r2);
+                    q.x01 += gr_v2(rec.sx); q.y01 += gr_v2(rec.sy); q.z01 += gr_v2(rec.sz); q.x23 += gr_v2(rec.sx); q.y23 += gr_v2(rec.sy); q.z23 += gr_v2(rec.sz);
+                    // (the pad atoms behind the system's last one keep what they hold, see below: here they sit at the box centre, so that whatever
+                    //  they hold -- zeros, as a rule: a point on a face -- never sends their wave through the general wrap, turn after turn,
+                    //  with every other workgroup of the launch waiting for that wave's next record)
+                    if (__builtin_amdgcn_ballot_w64((Gr.flags & GR_RG_EXALL) == 0u) != 0ull) {
+                        if (!(Gr.flags & GR_RG_EX0)) { q.x01.x = B.bcx; q.y01.x = B.bcy; q.z01.x = B.bcz; }
+                        if (!(Gr.flags & GR_RG_EX1)) { q.x01.y = B.bcx; q.y01.y = B.bcy; q.z01.y = B.bcz; }
+                        if (!(Gr.flags & GR_RG_EX2)) { q.x23.x = B.bcx; q.y23.x = B.bcy; q.z23.x = B.bcz; }
+                        if (!(Gr.flags & GR_RG_EX3)) { q.x23.y = B.bcx; q.y23.y = B.bcy; q.z23.y = B.bcz; }
+                    }
+                    float kmax = 0.0f;
+                    auto wrap1 = [&](gr_v2f &x, gr_v2f &y, gr_v2f &z) {
+                        gr_v2f k = gr_v2_floor(z * gr_v2(B.icz));
+                        kmax = gr_max3f(kmax, __builtin_fabsf(k.x), __builtin_fabsf(k.y));
+                        x = gr_v2_fma(-k, gr_v2(B.cx), x); y = gr_v2_fma(-k, gr_v2(B.cy), y); z = gr_v2_fma(-k, gr_v2(B.cz), z);
+                        k = gr_v2_floor(y * gr_v2(B.iby));
+                        kmax = gr_max3f(kmax, __builtin_fabsf(k.x), __builtin_fabsf(k.y));
+                        x = gr_v2_fma(-k, gr_v2(B.bx), x); y = gr_v2_fma(-k, gr_v2(B.by), y);
+                        k = gr_v2_floor(x * gr_v2(B.iax));
+                        kmax = gr_max3f(kmax, __builtin_fabsf(k.x), __builtin_fabsf(k.y));
+                        x = gr_v2_fma(-k, gr_v2(B.ax), x);
+                    };
+                    wrap1(q.x01, q.y01, q.z01);
+                    wrap1(q.x23, q.y23, q.z23);
+                    const float xl = gr_fminf(gr_min3f(q.x01.x, q.x01.y, q.x23.x), q.x23.y), xh = gr_fmaxf(gr_max3f(q.x01.x, q.x01.y, q.x23.x), q.x23.y);
+                    const float yl = gr_fminf(gr_min3f(q.y01.x, q.y01.y, q.y23.x), q.y23.y), yh = gr_fmaxf(gr_max3f(q.y01.x, q.y01.y, q.y23.x), q.y23.y);
+                    const float zl = gr_fminf(gr_min3f(q.z01.x, q.z01.y, q.z23.x), q.z23.y), zh = gr_fmaxf(gr_max3f(q.z01.x, q.z01.y, q.z23.x), q.z23.y);
+                    const bool ok = (xl > 0.0f) & (xh <= B.ax) & (yl > 0.0f) & (yh <= B.by) & (zl > 0.0f) & (zh <= B.cz) & (kmax <= 1.0f);
+                    if (__builtin_amdgcn_ballot_w64(!ok) != 0ull) q = gr_res_wrap_slow(rw.r0, rw.r1, rw.r2, rec.sx, rec.sy, rec.sz, boxp);
+                    gr_rows_pairs(q, o.r0, o.r1, o.r2);
+                    // the pad atoms behind the system's last one keep what they hold (k_translate_wrap does not touch them)
+                    if (__builtin_amdgcn_ballot_w64((Gr.flags & GR_RG_EXALL) == 0u) != 0ull) {
+                        if (!(Gr.flags & GR_RG_EX0)) { o.r0.x = rw.r0.x; o.r0.z = rw.r0.z; o.r1.x = rw.r1.x; }
+                        if (!(Gr.flags & GR_RG_EX1)) { o.r0.y = rw.r0.y; o.r0.w = rw.r0.w; o.r1.y = rw.r1.y; }
+                        if (!(Gr.flags & GR_RG_EX2)) { o.r1.z = rw.r1.z; o.r2.x = rw.r2.x; o.r2.z = rw.r2.z; }
+                        if (!(Gr.flags & GR_RG_EX3)) { o.r1.w = rw.r1.w; o.r2.y = rw.r2.y; o.r2.w = rw.r2.w; }
+                    }
+                };
+                center_group(GA, ra, oa);
+                if (GB.valid) center_group(GB, rb, ob);
+            }
+        } else if (status == 0) {
             GrResRot T;
             T.r00 = rec.r00; T.r10 = rec.r10; T.r20 = rec.r20; T.r01 = rec.r01; T.r11 = rec.r11; T.r21 = rec.r21;
             T.r02 = rec.r02; T.r12 = rec.r12; T.r22 = rec.r22;
@@ -857,6 +1048,7 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
             gr_buf_store_stream(out, offB, ob.r0); gr_buf_store_stream(out, offB + 1024u, ob.r1); gr_buf_store_stream(out, offB + 2048u, ob.r2);
         }
         n_fitted = j + 1u;
+        if (MODE == 1) return;                                    // (no sum to hand over)
         // the workgroup's share of sum w |R q - p|^2: the lane's eight atoms in f32, the wave in f32 (no LDS crossbar), waves in fp64
         // in wave order by the last wave to arrive (release / acquire as in the sums stage)
         const float wtot = gr_wave_allsum_f32(rs);
@@ -925,7 +1117,7 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
         Rows va = cur.a, vb = cur.b;                            // what gets parked: the rows, or (V: set by sums) the image vectors
         const uint32_t ps = i % K;
         GR_STEP_STAMP(1);
-        if (i < n_turns) sums(i, cur, Bs, va, vb);
+        if (i < n_turns) { if constexpr (MODE == 1) sums_cen(i, cur, Bs); else sums(i, cur, Bs, va, vb); }
         GR_STEP_STAMP(3);
         if (i >= K) {
             Rows qb;
@@ -969,11 +1161,12 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
         request(i + 1, nxt);                                    // (experiment: the next frame's rows requested after this step's stores)
 #endif
         if (i < n_turns) {
-            if (V) sums(i, cur, Bs, va, vb);                    // (the slot's old content has been read by the fit above)
+            if (MODE == 1) sums_cen(i, cur, Bs);
+            else if (V) sums(i, cur, Bs, va, vb);               // (the slot's old content has been read by the fit above)
             lds_put(ps, va);
             if (ps == 0u) { Q0 = vb; asm volatile("; set 0 in"); } else if (ps == 1u) { Q1 = vb; asm volatile("; set 1 in"); } else if (ps == 2u) { Q2 = vb; asm volatile("; set 2 in"); }
             else if (ps == 3u) { Q3 = vb; asm volatile("; set 3 in"); } else if (ps == 4u) { Q4 = vb; asm volatile("; set 4 in"); } else { Q5 = vb; asm volatile("; set 5 in"); }
-            if (!V) sums(i, cur, Bs, va, vb);
+            if (!V && MODE != 1) sums(i, cur, Bs, va, vb);
         }
     };
     auto step = [&](uint32_t i, Landing &cur, Landing &nxt) { if constexpr (FL) step_sums_first(i, cur, nxt); else step_fit_first(i, cur, nxt); };

@@ -355,7 +355,7 @@ class System:
         if st != OK:
             raise DeviceError("set_masses", self._err(st)[1], st)
 
-    TUNE = {"sub_batch": 1, "chunks": 2, "fit_wgs": 3, "fuse": 4, "two_pass": 5, "resident": 6, "resident_groups": 7, "resident_streams": 8, "resident_fill": 9, "pairdist_symmetric": 10, "resident_wg_groups": 11, "rmsd_fast": 12, "rmsd_fast_min": 13, "rmsd_fast_sigmas": 14, "masked_selections": 15, "xtc_device_encode": 16, "small_calls": 17, "resident_metro_ns": 18, "resident_fit_last": 19, "stream_wgs_per_cu": 20, "test_resident_no_start": 100, "test_resident_abort_at": 101}
+    TUNE = {"sub_batch": 1, "chunks": 2, "fit_wgs": 3, "fuse": 4, "two_pass": 5, "resident": 6, "resident_groups": 7, "resident_streams": 8, "resident_fill": 9, "pairdist_symmetric": 10, "resident_wg_groups": 11, "rmsd_fast": 12, "rmsd_fast_min": 13, "rmsd_fast_sigmas": 14, "masked_selections": 15, "xtc_device_encode": 16, "small_calls": 17, "resident_metro_ns": 18, "resident_fit_last": 19, "stream_wgs_per_cu": 20, "center_resident": 21, "test_resident_no_start": 100, "test_resident_abort_at": 101}
 
     def set_tuning(self, **kw):
         """gr_ctx_set_tuning: launch geometry / path selection of the batched RMSD calls (measurement only; same results)"""
@@ -364,7 +364,7 @@ class System:
             if st != OK:
                 raise DeviceError("set_tuning", self._err(st)[1], st)
 
-    STAT = {"n_cus": 1, "res_max_wgs": 2, "res_launches": 3, "res_handshake_misses": 4, "res_aborts": 5, "res_redone_frames": 6, "res_last_streams": 7, "rmsd_fast_frames": 8, "rmsd_exact_redos": 9, "xtc_device_frames": 10, "small_calls": 11, "small_sync_fallbacks": 12, "res_metro_period_ns": 13, "res_last_turn_ns": 14, "res_late_permille": 15, "res_sclk_mhz": 16}
+    STAT = {"n_cus": 1, "res_max_wgs": 2, "res_launches": 3, "res_handshake_misses": 4, "res_aborts": 5, "res_redone_frames": 6, "res_last_streams": 7, "rmsd_fast_frames": 8, "rmsd_exact_redos": 9, "xtc_device_frames": 10, "small_calls": 11, "small_sync_fallbacks": 12, "res_metro_period_ns": 13, "res_last_turn_ns": 14, "res_late_permille": 15, "res_sclk_mhz": 16, "center_res_launches": 17, "center_res_redone": 18}
 
     def stat(self, key):
         """gr_ctx_stat: device facts and counters of the batched RMSD path"""

@@ -308,10 +308,13 @@ int gr_rmsd_plan_force_exact(gr_rmsd_plan *plan, int on);
  *                      2 = the sums first (the frame's record is needed later and published earlier: one more turn for the finalizers);
  *                      0 (default) = sums first when the streaming workgroups fill 9/10 of the chip.  Same results either way.
  *   GR_TUNE_STREAM_WGS_PER_CU  workgroups per CU of the grid-launched read-modify-write streams (translate / wrap / centre, the two-pass fit):
- *                      1 .. 8, 0 (default) = the library's choice.  A copy is fastest with 20-32 KiB of loads in flight per CU. */
+ *                      1 .. 8, 0 (default) = the library's choice.  A copy is fastest with 20-32 KiB of loads in flight per CU.
+ *   GR_TUNE_CENTER_RESIDENT  1 (default): gr_atoms_center_batch about a contiguous reference group of at least 30 % of the system runs as ONE pass
+ *                      over HBM where the resident pass can take it (gr_resident.h MODE 1: every frame read once, written once -- 24 instead of
+ *                      36 bytes per atom); 0: always the two passes (centre estimate, then translate + wrap).  Same bits either way. */
 enum { GR_TUNE_SUB_BATCH = 1, GR_TUNE_CHUNKS = 2, GR_TUNE_FIT_WGS = 3, GR_TUNE_FUSE = 4, GR_TUNE_TWO_PASS = 5, GR_TUNE_RESIDENT = 6, GR_TUNE_RESIDENT_GROUPS = 7,
        GR_TUNE_RESIDENT_STREAMS = 8, GR_TUNE_RESIDENT_FILL = 9, GR_TUNE_PAIRDIST_SYMMETRIC = 10, GR_TUNE_RESIDENT_WG_GROUPS = 11,
-       GR_TUNE_RMSD_FAST = 12, GR_TUNE_RMSD_FAST_MIN = 13, GR_TUNE_RESIDENT_METRO_NS = 18, GR_TUNE_RESIDENT_FIT_LAST = 19, GR_TUNE_STREAM_WGS_PER_CU = 20,
+       GR_TUNE_RMSD_FAST = 12, GR_TUNE_RMSD_FAST_MIN = 13, GR_TUNE_RESIDENT_METRO_NS = 18, GR_TUNE_RESIDENT_FIT_LAST = 19, GR_TUNE_STREAM_WGS_PER_CU = 20, GR_TUNE_CENTER_RESIDENT = 21,
        GR_TUNE_MASKED_SELECTIONS = 15 /* 1 (default): a scattered selection that covers at least an eighth of the atoms between its first and its last one (>= 4096
                                          atoms) also gets a bit mask, and RMSD / RMSD-fit / get_com read its span coalesced instead of gathering it atom by atom;
                                          0: groups created afterwards keep to their index lists.  Same results to rounding. */,
@@ -339,14 +342,17 @@ int gr_ctx_set_tuning(gr_ctx *ctx, int key, int64_t value);
  *   GR_STAT_RES_METRO_PERIOD_NS    the metronome period the last resident launch ran with (0: it ran free)
  *   GR_STAT_RES_LAST_TURN_NS       what a turn of that launch took on the device clock (first slot to the last wave's exit, per turn)
  *   GR_STAT_RES_LATE_PERMILLE      thousandths of its metronome slots that waves reached more than a quarter period late
- *   GR_STAT_RES_SCLK_MHZ           shader clock that launch ran at (shader-clock ticks over device-clock ticks of its first workgroup's walk) */
+ *   GR_STAT_RES_SCLK_MHZ           shader clock that launch ran at (shader-clock ticks over device-clock ticks of its first workgroup's walk)
+ *   GR_STAT_CENTER_RES_LAUNCHES    resident atoms_center launches that started (GR_TUNE_CENTER_RESIDENT)
+ *   GR_STAT_CENTER_RES_REDONE      frames those launches handed back to the two passes (an atom without position or mass, sums that are not finite, an abort) */
 enum { GR_STAT_N_CUS = 1, GR_STAT_RES_MAX_WGS = 2, GR_STAT_RES_LAUNCHES = 3, GR_STAT_RES_HANDSHAKE_MISSES = 4, GR_STAT_RES_ABORTS = 5, GR_STAT_RES_REDONE_FRAMES = 6, GR_STAT_RES_LAST_STREAMS = 7,
        GR_STAT_RMSD_FAST_FRAMES = 8 /* frames of RMSD-without-fit calls closed by the f32-chain pass (GR_TUNE_RMSD_FAST) */,
        GR_STAT_RMSD_EXACT_REDOS = 9 /* ... and frames that pass handed back to the exact-product pass */,
        GR_STAT_XTC_DEVICE_FRAMES = 10 /* frames gr_xtc_write_slots compressed on the device (GR_TUNE_XTC_DEVICE_ENCODE) */,
        GR_STAT_SMALL_CALLS = 11 /* one-frame calls answered by a single-wave dispatch (GR_TUNE_SMALL_CALLS) */,
        GR_STAT_SMALL_SYNC_FALLBACKS = 12 /* ... of which the host gave up polling for the result (20 ms) and synchronised the stream instead */,
-       GR_STAT_RES_METRO_PERIOD_NS = 13, GR_STAT_RES_LAST_TURN_NS = 14, GR_STAT_RES_LATE_PERMILLE = 15, GR_STAT_RES_SCLK_MHZ = 16 };
+       GR_STAT_RES_METRO_PERIOD_NS = 13, GR_STAT_RES_LAST_TURN_NS = 14, GR_STAT_RES_LATE_PERMILLE = 15, GR_STAT_RES_SCLK_MHZ = 16,
+       GR_STAT_CENTER_RES_LAUNCHES = 17, GR_STAT_CENTER_RES_REDONE = 18 };
 int gr_ctx_stat(const gr_ctx *ctx, int key, uint64_t *value);
 
 /* ---------------------------------------------------------------- text front end: gro structures, ndx index groups (host side)
