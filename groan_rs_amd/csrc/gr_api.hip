@@ -1753,6 +1753,7 @@ static int center_resident(gr_ctx *c, uint32_t s0, uint32_t nb, const GrSel &all
     // 6.1-6.3 -> 4.4-4.6, half of it 5.2 -> 4.7, a tenth 4.4 -> not taken: the estimate pass shrinks with the group, this one does not;
     // profiles/r05_center_bench.json); from 30 % of the system
     if (c->resident == 1 && (uint64_t)csel.n * 100 < c->n * 30) return GR_OK;
+    if (small_ok(c, csel)) return GR_OK;      // (a group the single-wave estimate takes: that kernel adds in another order -- the same bits only against k_center_sums)
     uint32_t streams = 1, gwg = GR_RES_GROUPS;
     const uint32_t wgs = resident_wgs(c, true, nb, all, &streams, &gwg);
     if (!wgs) return GR_OK;
