@@ -123,6 +123,7 @@ struct gr_ctx {
     unsigned long long *res_rec = nullptr;   // [GR_MAX_BATCH][16]
     uint32_t *res_abort = nullptr;    // device word
     uint32_t *res_words_host = nullptr;   // pinned: the three control words of the last resident launch, copied behind it on the stream
+    GrShapeSet *shape_set_dev = nullptr;      // the shapes of the geometry selection in flight (k_shape_mask reads them through a uniform pointer)
     unsigned long long *shape_mask_dev = nullptr, *shape_mask_host = nullptr; size_t shape_mask_cap = 0;   // geometry selection: one bit per atom of the source group (device, pinned host), grown on demand
     uint32_t res_epoch = 0;
     bool res_in_use = false;          // the pending segment took the resident pass (segment_end checks the abort word)
@@ -847,6 +848,7 @@ void gr_ctx_destroy(gr_ctx *c) try {
     if (c->fuse_cnt) (void)hipFree(c->fuse_cnt);
     if (c->res_abort) (void)hipFree(c->res_abort);
     if (c->res_words_host) (void)hipHostFree(c->res_words_host);
+    if (c->shape_set_dev) (void)hipFree(c->shape_set_dev);
     if (c->shape_mask_dev) (void)hipFree(c->shape_mask_dev);
     if (c->shape_mask_host) (void)hipHostFree(c->shape_mask_host);
     if (c->res_wgrec) (void)hipFree(c->res_wgrec);
@@ -1422,9 +1424,11 @@ static int geometry_filter(gr_ctx *c, uint32_t slot, const Group &g, const gr_sh
         c->shape_mask_cap = cap;
     }
     unsigned long long *mask_dev = c->shape_mask_dev;
+    if (!c->shape_set_dev) HIPCHK(c, hipMalloc(&c->shape_set_dev, sizeof(GrShapeSet)));
+    HIPCHK(c, hipMemcpyAsync(c->shape_set_dev, &set, sizeof set, hipMemcpyHostToDevice, c->stream));     // (pageable source: staged by the runtime before the call returns)
     {
         SlotUse use(c, slot);
-        k_shape_mask<<<dim3((unsigned)((g.n + 255) / 256)), dim3(256), 0, c->stream>>>(c->frames + (size_t)slot * c->frame_stride, sel, c->boxes_host[slot], set, mask_dev);
+        k_shape_mask<<<dim3((unsigned)((g.n + 255) / 256)), dim3(256), 0, c->stream>>>(c->frames + (size_t)slot * c->frame_stride, sel, c->boxes_dev + slot, c->shape_set_dev, mask_dev);
     }
     const unsigned long long *mask = c->shape_mask_host;
     hipError_t e = hipGetLastError();

@@ -196,8 +196,12 @@ GR_HD bool gr_shape_inside_naive(const GrShapeDev &s, float x, float y, float z)
 // One bit per atom of the selection (ordinal order): has a position and lies inside every shape.  The host turns the
 // mask into AtomContainer blocks -- groups are host objects; the mask is n/8 bytes (125 KB per 1e6 atoms).
 // The box and the shapes come in by value: scalar loads, SGPR operands.
-__global__ __launch_bounds__(256) void k_shape_mask(const float *__restrict__ xyz, GrSel sel, const GrBox box, const GrShapeSet shapes,
+// (round 5: the box and the shapes through uniform pointers -- by value and indexed at run time, they were copied into
+//  816 bytes of scratch memory per lane)
+__global__ __launch_bounds__(256) void k_shape_mask(const float *__restrict__ xyz, GrSel sel, const GrBox *__restrict__ boxp, const GrShapeSet *__restrict__ shapesp,
                                                      unsigned long long *__restrict__ mask) {
+    const GrBox &box = *boxp;
+    const GrShapeSet &shapes = *shapesp;
     const uint32_t j = blockIdx.x * 256u + threadIdx.x;
     bool in = false;
     if (j < sel.n) {
