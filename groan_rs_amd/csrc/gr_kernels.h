@@ -243,6 +243,39 @@ __device__ __forceinline__ float gr_wave_max_scatter16(float (&a)[32], const uin
 }
 
 // ------------------------------------------------------------------------------------------ centres
+// two f32 values in one register pair: gfx950 issues v_pk_add / mul / fma_f32 at full rate, i.e. two atoms per instruction
+typedef float gr_v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ gr_v2f gr_v2(float a) { gr_v2f r = { a, a }; return r; }
+__device__ __forceinline__ gr_v2f gr_v2_fma(gr_v2f a, gr_v2f b, gr_v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ float gr_min3f(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+
+// The Bai-Breen terms of TWO atoms at a time (gr_center_atom<1> below, operation for operation -- the same IEEE operations in the same
+// order, hence the same bits): fractional ("u") coordinates in a non-orthogonal cell (reciprocal + one Newton step), theta = x (2 pi / L),
+// sine and cosine from the hardware in revolutions with the first-order correction for the rounding of theta / 2 pi.  The positions must
+// lie inside the cell already (the caller wraps those that do not).  Box constants are wave-uniform (SGPR operands).
+struct GrBbBox { float by, cz, bx, cx, cy, iby, icz, scx, scy, scz; bool tric; };
+__device__ __forceinline__ void gr_bb_angles_pair(gr_v2f x, gr_v2f y, gr_v2f z, const GrBbBox &b, gr_v2f (&sn)[3], gr_v2f (&cs)[3]) {
+    if (b.tric) {
+        gr_v2f sc = z * gr_v2(b.icz);
+        sc = gr_v2_fma(gr_v2_fma(-sc, gr_v2(b.cz), z), gr_v2(b.icz), sc);
+        const gr_v2f uy = gr_v2_fma(-sc, gr_v2(b.cy), y);
+        gr_v2f sb = uy * gr_v2(b.iby);
+        sb = gr_v2_fma(gr_v2_fma(-sb, gr_v2(b.by), uy), gr_v2(b.iby), sb);
+        x = gr_v2_fma(-sc, gr_v2(b.cx), gr_v2_fma(-sb, gr_v2(b.bx), x));
+        y = uy;
+    }
+    const float IH = 0.15915493667125702f, IL = 6.4206382432985265e-09f, TWO_PI = 6.283185307179586f;
+    const gr_v2f th[3] = { x * gr_v2(b.scx), y * gr_v2(b.scy), z * gr_v2(b.scz) };
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const gr_v2f u = th[a] * gr_v2(IH);
+        const gr_v2f e = gr_v2_fma(th[a], gr_v2(IL), gr_v2_fma(th[a], gr_v2(IH), -u));
+        gr_v2f s, c;
+        s.x = __builtin_amdgcn_sinf(u.x); s.y = __builtin_amdgcn_sinf(u.y); c.x = __builtin_amdgcn_cosf(u.x); c.y = __builtin_amdgcn_cosf(u.y);
+        const gr_v2f k = gr_v2(TWO_PI) * e;
+        sn[a] = gr_v2_fma(k, c, s); cs[a] = gr_v2_fma(-k, s, c);
+    }
+}
 // kind 0: naive sums  sum(m x), sum(m) [or count]            iterators.rs:886-903,946-967
 // kind 1: Bai-Breen   sum(m cos th), sum(m sin th) per axis  iterators.rs:1152-1191,1314-1357
 // kind 2: unwrapped about state.center: sum(m (c + vector_to(c, x))), sum(m)   :1237-1266,1404-1438
@@ -332,6 +365,14 @@ __global__ __launch_bounds__(GR_WG) void k_center_sums(
     auto atom = [&](uint32_t i, float x, float y, float z, float m, float (&p)[7]) {
         gr_center_atom<KIND>(i, x, y, z, m, weighted, box, scx, scy, scz, cx, cy, cz, bad_pos, bad_mass, p);
     };
+    // the frame's box once more as wave-uniform values (scalar loads through the kernel argument: SGPR operands of the packed arithmetic)
+    GrBbBox bb;
+    float bb_ax = 0.f;
+    if (KIND == 1) {
+        const GrBox *bp = boxes + first_slot + frame;
+        bb_ax = bp->ax; bb.by = bp->by; bb.cz = bp->cz; bb.bx = bp->bx; bb.cx = bp->cx; bb.cy = bp->cy; bb.iby = bp->iby; bb.icz = bp->icz;
+        bb.scx = PI_X2 / bp->ax; bb.scy = PI_X2 / bp->by; bb.scz = PI_X2 / bp->cz; bb.tric = !bp->ortho;
+    }
     if (sel.contiguous) {
         // read-only stream: a lane's 4 atoms are its three row loads (coalesced: consecutive lanes, consecutive 16 bytes) + one of
         // masses; their terms form 4-atom f32 partials that go into the lane's fp64 accumulators
@@ -354,6 +395,38 @@ __global__ __launch_bounds__(GR_WG) void k_center_sums(
             const float m[4] = { mm.x, mm.y, mm.z, mm.w };
             const uint32_t i = g << 2;
             float p[7] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
+            if (KIND == 1) {
+                // the whole wave's trip at once when nothing special happens in it (round 5): every lane's four atoms in the selection, with
+                // position and mass, inside the cell -- then the terms are formed two atoms per instruction, without a branch, and added in
+                // the order of the loop below (the same bits); any other trip takes that loop as before
+                bool plain = i >= first && i + 3u < last && x[0] == x[0] && x[1] == x[1] && x[2] == x[2] && x[3] == x[3];
+                if (weighted) plain = plain && m[0] == m[0] && m[1] == m[1] && m[2] == m[2] && m[3] == m[3];
+                {
+                    const float xl = fminf(fminf(x[0], x[1]), fminf(x[2], x[3])), xh = fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3]));
+                    const float yl = fminf(fminf(y[0], y[1]), fminf(y[2], y[3])), yh = fmaxf(fmaxf(y[0], y[1]), fmaxf(y[2], y[3]));
+                    const float zl = fminf(fminf(z[0], z[1]), fminf(z[2], z[3])), zh = fmaxf(fmaxf(z[0], z[1]), fmaxf(z[2], z[3]));
+                    plain = plain && xl >= 0.0f && xh <= bb_ax && yl >= 0.0f && yh <= bb.by && zl >= 0.0f && zh <= bb.cz;
+                }
+#ifdef GR_EXP_NO_BBFAST
+                plain = false;
+#endif
+                if (__builtin_amdgcn_ballot_w64(!plain) == 0ull) {
+                    gr_v2f s01[3], c01[3], s23[3], c23[3];
+                    const gr_v2f x01 = { x[0], x[1] }, y01 = { y[0], y[1] }, z01 = { z[0], z[1] }, x23 = { x[2], x[3] }, y23 = { y[2], y[3] }, z23 = { z[2], z[3] };
+                    gr_bb_angles_pair(x01, y01, z01, bb, s01, c01);
+                    gr_bb_angles_pair(x23, y23, z23, bb, s23, c23);
+                    const float w0 = weighted ? m[0] : 1.0f, w1 = weighted ? m[1] : 1.0f, w2 = weighted ? m[2] : 1.0f, w3 = weighted ? m[3] : 1.0f;
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) {
+                        p[a] = fmaf(w3, c23[a].y, fmaf(w2, c23[a].x, fmaf(w1, c01[a].y, fmaf(w0, c01[a].x, 0.0f))));
+                        p[3 + a] = fmaf(w3, s23[a].y, fmaf(w2, s23[a].x, fmaf(w1, s01[a].y, fmaf(w0, s01[a].x, 0.0f))));
+                    }
+                    p[6] = 4.0f;
+#pragma unroll
+                    for (int k = 0; k < 7; ++k) acc[k] += (double)p[k];
+                    continue;
+                }
+            }
 #pragma unroll
             for (int k = 0; k < 4; ++k) if (i + k >= first && i + k < last) atom(i + k, x[k], y[k], z[k], m[k], p);
 #pragma unroll
@@ -1121,10 +1194,7 @@ __global__ __launch_bounds__(GR_WG) void k_translate_wrap(
 //     f32 rounding -- bit-identical, 5 slots per axis instead of 11; anything else takes the generic closed form;
 //   triclinic (our extension): brick reduction with k = rint(d/L) per axis (an ulp outside the brick is harmless, the
 //     image table covers it), then gain = |t|^2 - 2|d.t| per table entry with two entries per v_min3.
-typedef float gr_v2f __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ gr_v2f gr_v2(float a) { gr_v2f r = { a, a }; return r; }
-__device__ __forceinline__ gr_v2f gr_v2_fma(gr_v2f a, gr_v2f b, gr_v2f c) { return __builtin_elementwise_fma(a, b, c); }
-__device__ __forceinline__ float gr_min3f(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+// (gr_v2f and its helpers: defined with the centres, above)
 __device__ __forceinline__ float gr_mi_near(float d, float L, float h) {
     const float s = d - __builtin_copysignf(L, d);
     return __builtin_fabsf(d) > h ? s : d;

@@ -810,31 +810,11 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
         bool bad = cen_mass_bad;
         const float PI_X2 = 3.14159265358979323846f * 2.0f;       // auxiliary.rs:15 (as k_center_sums)
         const float scx = PI_X2 / B.ax, scy = PI_X2 / B.by, scz = PI_X2 / B.cz;
-        // gr_center_atom<1>'s arithmetic for two atoms at a time -- the same IEEE operations in the same order, so the same bits: the position
-        // into the cell where it is not (one wave-wide test; gr_wrap is the identity inside), fractional coordinates in a non-orthogonal cell
-        // (reciprocal + one Newton step), theta = x (2 pi / L), its sine and cosine from the hardware in revolutions with the first-order
-        // correction for the rounding of theta / 2 pi
-        auto angles = [&](gr_v2f x, gr_v2f y, gr_v2f z, gr_v2f (&sn)[3], gr_v2f (&cs)[3]) {
-            if (B.tric) {
-                gr_v2f sc = z * gr_v2(B.icz);
-                sc = gr_v2_fma(gr_v2_fma(-sc, gr_v2(B.cz), z), gr_v2(B.icz), sc);
-                const gr_v2f uy = gr_v2_fma(-sc, gr_v2(B.cy), y);
-                gr_v2f sb = uy * gr_v2(B.iby);
-                sb = gr_v2_fma(gr_v2_fma(-sb, gr_v2(B.by), uy), gr_v2(B.iby), sb);
-                x = gr_v2_fma(-sc, gr_v2(B.cx), gr_v2_fma(-sb, gr_v2(B.bx), x));
-                y = uy;
-            }
-            const float IH = 0.15915493667125702f, IL = 6.4206382432985265e-09f, TWO_PI = 6.283185307179586f;
-            const gr_v2f th[3] = { x * gr_v2(scx), y * gr_v2(scy), z * gr_v2(scz) };
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                const gr_v2f u = th[a] * gr_v2(IH);
-                const gr_v2f e = gr_v2_fma(th[a], gr_v2(IL), gr_v2_fma(th[a], gr_v2(IH), -u));
-                const gr_v2f s = gr_v2p(__builtin_amdgcn_sinf(u.x), __builtin_amdgcn_sinf(u.y)), c = gr_v2p(__builtin_amdgcn_cosf(u.x), __builtin_amdgcn_cosf(u.y));
-                const gr_v2f k = gr_v2(TWO_PI) * e;
-                sn[a] = gr_v2_fma(k, c, s); cs[a] = gr_v2_fma(-k, s, c);
-            }
-        };
+        // gr_center_atom<1>'s arithmetic for two atoms at a time (gr_bb_angles_pair: the same IEEE operations in the same order, so the same
+        // bits), after the positions that lie outside the cell have been wrapped into it (one wave-wide test; gr_wrap is the identity inside)
+        GrBbBox bb;
+        bb.by = B.by; bb.cz = B.cz; bb.bx = B.bx; bb.cx = B.cx; bb.cy = B.cy; bb.iby = B.iby; bb.icz = B.icz; bb.scx = scx; bb.scy = scy; bb.scz = scz; bb.tric = B.tric;
+        auto angles = [&](gr_v2f x, gr_v2f y, gr_v2f z, gr_v2f (&sn)[3], gr_v2f (&cs)[3]) { gr_bb_angles_pair(x, y, z, bb, sn, cs); };
         auto group = [&](const GrResGroup &Gr, const Rows &rw) {
             GrP4 q = gr_pairs_rows(rw.r0, rw.r1, rw.r2);
             // atoms behind the system's last one hold anything: they become the origin (their weight is zero)
