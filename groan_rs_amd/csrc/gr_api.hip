@@ -1781,7 +1781,9 @@ static int center_resident(gr_ctx *c, uint32_t s0, uint32_t nb, const GrSel &all
     ctl.team_waves = resident_team_waves(wgs, streams);
     ctl.patience_ticks = (unsigned long long)c->wall_khz * 3000ull; ctl.start_ticks = (unsigned long long)c->wall_khz * 200ull;   // 3 s, 0.2 s
     ctl.test_abort_frame = c->res_test_abort_at; c->res_test_abort_at = 0xFFFFFFFFu;
-    ctl.metro_t16 = 0; ctl.metro_lead = 0;                // (the waves run free)
+    // (the waves run free unless GR_TUNE_RESIDENT_METRO_NS names a period: the controller of the RMSD-fit form is not applied here)
+    ctl.metro_t16 = c->res_metro_ns >= 100 ? (uint32_t)std::min<uint64_t>(0xFFFFFFFFull, (uint64_t)c->res_metro_ns * (uint64_t)c->wall_khz * 16ull / 1000000ull) : 0u;
+    ctl.metro_lead = (uint32_t)((uint64_t)c->wall_khz * 2000ull / 1000000ull);   // 2 us
     ctl.cen_weighted = weighted ? 1u : 0u; ctl.cen_dim_mask = (uint32_t)dim_mask;
     float *frames = c->frames; size_t stride = c->frame_stride; uint32_t slot0 = s0, nfr = nb, natoms = (uint32_t)c->n;
     const float *masses = c->masses; GrSel sel_arg = csel; const GrBox *boxes = c->boxes_dev; GrPlanDev plan; memset(&plan, 0, sizeof plan);
