@@ -223,6 +223,38 @@ __device__ __forceinline__ float gr_wave_sum_scatter32(float (&a)[32], const uin
     gr_rs_step<2, 4, false>(a, lane); gr_rs_step<1, 2, false>(a, lane);
     return a[0] + gr_xor_lane<1>(a[0]);
 }
+// 8 doubles, without the LDS crossbar (the steps above move a double as two ds_bpermute: ~34 of them per 16 values, and eight waves of a
+// workgroup queue for the one crossbar): lane swaps for the partners 32 and 16 lanes away and DPP moves for 8, 4, 2, 1, a double as its two
+// 32-bit halves.  Afterwards lane l holds the wave total of value (l >> 3) (the lanes of a group of 8 all hold it).
+__device__ __forceinline__ double gr_f64_from_halves(uint32_t lo, uint32_t hi) { return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo)); }
+template <int M> __device__ __forceinline__ double gr_xor_lane_f64(double v) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const float lo = gr_xor_lane<M>(__uint_as_float((uint32_t)b)), hi = gr_xor_lane<M>(__uint_as_float((uint32_t)(b >> 32)));
+    return gr_f64_from_halves(__float_as_uint(lo), __float_as_uint(hi));
+}
+template <int HALF, int MASK>
+__device__ __forceinline__ void gr_rs_step_swap_f64(double (&a)[8]) {
+    static_assert(MASK == 32 || MASK == 16, "lane swaps exist for 32 and 16");
+#pragma unroll
+    for (int k = 0; k < HALF; ++k) {
+        const unsigned long long p = (unsigned long long)__double_as_longlong(a[k]), q = (unsigned long long)__double_as_longlong(a[k + HALF]);
+        const auto rl = MASK == 32 ? __builtin_amdgcn_permlane32_swap((uint32_t)p, (uint32_t)q, false, false) : __builtin_amdgcn_permlane16_swap((uint32_t)p, (uint32_t)q, false, false);
+        const auto rh = MASK == 32 ? __builtin_amdgcn_permlane32_swap((uint32_t)(p >> 32), (uint32_t)(q >> 32), false, false) : __builtin_amdgcn_permlane16_swap((uint32_t)(p >> 32), (uint32_t)(q >> 32), false, false);
+        a[k] = gr_f64_from_halves(rl[0], rh[0]) + gr_f64_from_halves(rl[1], rh[1]);
+    }
+}
+__device__ __forceinline__ double gr_wave_sum_scatter8_f64(double (&a)[8], const uint32_t lane) {
+    gr_rs_step_swap_f64<4, 32>(a);                 // lanes 0-31: values 0..3, lanes 32-63: values 4..7
+    gr_rs_step_swap_f64<2, 16>(a);                 // ... of which the even 16-lane rows keep the first two, the odd rows the other two
+    {                                              // partner 8 lanes away: the lower half of a row keeps a[0], the upper half a[1]
+        const bool hi = (lane & 8u) != 0;
+        const double send = hi ? a[0] : a[1], keep = hi ? a[1] : a[0];
+        a[0] = keep + gr_xor_lane_f64<8>(send);
+    }
+    double v = a[0];
+    v += gr_xor_lane_f64<4>(v); v += gr_xor_lane_f64<2>(v); v += gr_xor_lane_f64<1>(v);
+    return v;
+}
 // 16 doubles (a[0..15]): afterwards lane l holds the wave total of value (l >> 2)
 __device__ __forceinline__ double gr_wave_sum_scatter16_f64(double (&a)[32], const uint32_t lane) {
     gr_rs_step_f64<8, 32>(a, lane); gr_rs_step_f64<4, 16>(a, lane); gr_rs_step_f64<2, 8>(a, lane); gr_rs_step_f64<1, 4>(a, lane);

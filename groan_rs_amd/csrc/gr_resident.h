@@ -803,9 +803,9 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
     // only by the order of fp64 additions.  Word 7 / 15: atoms without position (x is NaN) among ALL the workgroup's atoms -- the frame is
     // then left alone (see the finalizer).
     auto sums_cen = [&](uint32_t i, const Landing &L, const GrBoxU &B) {
-        double d32[32];
+        double d32[8];
 #pragma unroll
-        for (int k = 0; k < 32; ++k) d32[k] = 0.0;
+        for (int k = 0; k < 8; ++k) d32[k] = 0.0;
         const GrBox *boxp = boxes + first_slot + kf(i);
         bool bad = cen_mass_bad;
         const float PI_X2 = 3.14159265358979323846f * 2.0f;       // auxiliary.rs:15 (as k_center_sums)
@@ -855,8 +855,8 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
         GR_STEP_STAMP(2);
         const uint32_t rs = i % R;
         double *mine = reinterpret_cast<double *>(wsum + (rs * WAVES + wave) * 32);     // 16 doubles per wave record
-        const double dt = gr_wave_sum_scatter16_f64(d32, lane);                          // lane l: the wave total of value l >> 2
-        if ((lane & 3u) == 0 && lane < 32u) mine[lane >> 2] = dt;
+        const double dt = gr_wave_sum_scatter8_f64(d32, lane);                           // lane l: the wave total of value l >> 3 (no LDS crossbar)
+        if ((lane & 7u) == 0) mine[lane >> 3] = dt;
         gr_lds_release();
         uint32_t old = 0;
         if (lane == 0) old = __hip_atomic_fetch_add(cnt_s + rs, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
