@@ -108,6 +108,7 @@ struct gr_ctx {
     // fastest with 20-32 KiB of loads in flight per CU (tools/copy_matrix3 --occ: 3 KiB per wave at 2 workgroups per CU 6.2 TB/s, at 8 -- what the
     // registers allow -- 5.77); the surplus workgroups are kept off the CU by LDS they do not use
     int stream_wgs_cu = 0;            // 0: chosen by the library (see stream_lds), 1..8
+    int translate_rows = 1;           // GR_TUNE_TRANSLATE_ROWS 1: translate / wrap / centre of a contiguous selection in an orthorhombic cell as one float4 per lane (k_translate_wrap_rows), 0: the three-rows walk
     int center_resident = 1;          // GR_TUNE_CENTER_RESIDENT 0: atoms_center is always two passes; 1: the resident pass's atoms_center form where it pays (see center_resident)
     uint64_t cen_res_launches = 0, cen_res_redone = 0;   // gr_ctx_stat: resident atoms_center launches; frames they handed back to the two passes
     int res_fit_last = 0;             // GR_TUNE_RESIDENT_FIT_LAST 0: chosen by the launch's fill, 1: the fit first, 2: the sums first
@@ -1489,6 +1490,10 @@ static int translate_core(gr_ctx *c, uint32_t slot, const Group &g, const float 
     if (!bad_is_set) HIPCHK(c, hipMemsetAsync(c->bad_dev, 0xFF, 4 * sizeof(uint32_t), c->stream));
     const uint64_t units = sel.contiguous ? ((uint64_t)sel.n + 3) / 4 + 128 : (sel.masked & 2u) ? ((uint64_t)sel.span + 3) / 4 + 128 : sel.n;   // (4-atom groups of the block / of a masked selection's span; list entries)
     uint32_t nwg = (uint32_t)std::min<uint64_t>((units + GR_WG - 1) / GR_WG, 4096);
+    if (g.n != 0 && sel.contiguous && c->translate_rows && c->boxes_host[slot].ortho)
+        k_translate_wrap_rows<<<dim3((((sel.start + sel.n - 1u) >> 8) - (sel.start >> 8) + 1u) * 3u), dim3(64), 0, c->stream>>>(c->frames + (size_t)slot * c->frame_stride, c->frame_stride, sel, c->boxes_dev + slot, c->state_dev, use_state, dim_mask,
+                                                                                                                       v ? v[0] : 0.f, v ? v[1] : 0.f, v ? v[2] : 0.f, c->bad_dev);
+    else
     k_translate_wrap<<<dim3(nwg), dim3(GR_WG), 0, c->stream>>>(c->frames + (size_t)slot * c->frame_stride, c->frame_stride, sel, c->boxes_dev + slot, c->state_dev, use_state, dim_mask, v ? v[0] : 0.f, v ? v[1] : 0.f, v ? v[2] : 0.f, c->bad_dev);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(c->bad_host, c->bad_dev, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
@@ -1860,7 +1865,15 @@ static int translate_batch(gr_ctx *c, uint32_t s0, uint32_t nb, const Group *g, 
                            const std::vector<int> &pre, const std::vector<std::string> &msg, int *status_out, int &first_err, std::string &first_msg, uint64_t &first_idx) {
     const GrSel sel = make_sel(*g);
     HIPCHK(c, hipMemsetAsync(c->bad_dev, 0xFF, 4 * (size_t)nb * sizeof(uint32_t), c->stream));
-    if (g->n) {
+    // orthorhombic cells (every frame of the batch that will be touched): one float4 per lane, a 256-atom tile per workgroup (k_translate_wrap_rows)
+    bool rows = g->n != 0 && sel.contiguous && c->translate_rows;
+    for (uint32_t f = 0; f < nb && rows; ++f) rows = pre[f] != GR_OK || c->boxes_host[s0 + f].ortho != 0;
+    if (rows) {
+        const uint32_t tiles = ((sel.start + sel.n - 1u) >> 8) - (sel.start >> 8) + 1u;
+        k_translate_wrap_rows<<<dim3(tiles * 3u, nb), dim3(64), 0, c->stream>>>(c->frames + (size_t)s0 * c->frame_stride, c->frame_stride, sel, c->boxes_dev + s0, c->state_dev, mode, dim_mask,
+                                                                            v ? v[0] : 0.f, v ? v[1] : 0.f, v ? v[2] : 0.f, c->bad_dev);
+        HIPCHK(c, hipGetLastError());
+    } else if (g->n) {
         const uint64_t units = sel.contiguous ? ((uint64_t)sel.n + 3) / 4 + 128 : (sel.masked & 2u) ? ((uint64_t)sel.span + 3) / 4 + 128 : sel.n;   // (4-atom groups of the block / of a masked selection's span; list entries)
         const uint32_t nwg = (uint32_t)std::min<uint64_t>((units + GR_WG - 1) / GR_WG, 4096);
         k_translate_wrap<<<dim3(nwg, nb), dim3(GR_WG), stream_lds(c, GR_STREAM_WGS_CU_DEFAULT), c->stream>>>(c->frames + (size_t)s0 * c->frame_stride, c->frame_stride, sel, c->boxes_dev + s0, c->state_dev, mode, dim_mask,
@@ -2074,6 +2087,7 @@ int gr_ctx_set_tuning(gr_ctx *c, int key, int64_t value) try {
     case GR_TUNE_RESIDENT_FIT_LAST: if (value < 0 || value > 2) break; c->res_fit_last = (int)value; return GR_OK;
     case GR_TUNE_STREAM_WGS_PER_CU: if (value < 0 || value > 8) break; c->stream_wgs_cu = (int)value; return GR_OK;
     case GR_TUNE_CENTER_RESIDENT: if (value < 0 || value > 1) break; c->center_resident = (int)value; return GR_OK;
+    case GR_TUNE_TRANSLATE_ROWS: if (value < 0 || value > 1) break; c->translate_rows = (int)value; return GR_OK;
     case GR_TUNE_RESIDENT_FILL: if (value < 1 || value > 16) break; c->res_fill16 = (int)value; return GR_OK;
     case GR_TUNE_RESIDENT_GROUPS: if (value != 2) break; return GR_OK;   // (the one-group shape was removed: gr_resident.h)
     case GR_TUNE_TEST_RESIDENT_NO_START: c->res_test_no_start = value ? 1 : 0; return GR_OK;
@@ -3032,7 +3046,7 @@ __global__ __launch_bounds__(256) void k_trr_unpack(const unsigned char *__restr
             for (int a = 0; a < 3; ++a) { const uint64_t u = __builtin_bswap64(reinterpret_cast<const uint64_t *>(src)[3 * (size_t)i + a]); v[a] = (float)__longlong_as_double((long long)u); }
         }
     }
-    if (v[0] == 0.0f && v[1] == 0.0f && v[2] == 0.0f) v[0] = __uint_as_float(0x7fc00000u);
+    if (v[0] == 0.0f && v[1] == 0.0f && v[2] == 0.0f) v[0] = v[1] = v[2] = __uint_as_float(0x7fc00000u);      // (no position: NaN in x -- and, inside the library, in y and z: gr_layout.h::k_tile)
     gr_pos_store(frames + (size_t)slots[k] * frame_stride, i, v[0], v[1], v[2]);
 }
 

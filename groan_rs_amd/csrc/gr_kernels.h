@@ -1201,6 +1201,55 @@ __global__ __launch_bounds__(GR_WG) void k_translate_wrap(
     if (threadIdx.x == 0 && bad != GR_NOIDX) atomicMin(bad_out, bad);
 }
 
+// The same operation on an ORTHORHOMBIC cell as one 16-byte load and one 16-byte store per lane (round 5).  There every coordinate wraps on
+// its own (x <- wrap(x + tx) along a, y along b, z along c: gr_wrap's three independent gr_wrap_value), so a lane needs no whole atom --
+// and a copy whose waves are fresh, hold one float4 per lane and are handed out by the dispatcher in address order streams at 6.3-6.5 TB/s
+// where the three-rows-per-lane walk above reaches 5.8 (profiles/r05_copy_matrix.md, "U = 3").  A workgroup is ONE WAVE and one row of
+// a 256-atom tile (gr_layout.h: row 0 = x0 x1 y0 y1, row 1 = z0 z1 x2 x3, row 2 = y2 y3 z2 z3 of the lane's four atoms): three waves of
+// one workgroup with a barrier between them -- tried first -- ran at the walk's speed.  An atom without position is NaN in x AND in y and z
+// inside the library (k_tile), so every coordinate knows by itself that it must stay as it is.  Contiguous selections only.
+__global__ __launch_bounds__(64) void k_translate_wrap_rows(
+    float *__restrict__ xyz, size_t frame_stride, GrSel sel, const GrBox *__restrict__ boxp, const GrFrameState *__restrict__ state,
+    int use_state_shift, int dim_mask, float tx, float ty, float tz, uint32_t *__restrict__ bad_out) {
+    xyz += (size_t)blockIdx.y * frame_stride; boxp += blockIdx.y; state += blockIdx.y; bad_out += 4 * blockIdx.y;
+    if (use_state_shift == 2 && state->status != 0) return;
+    if (use_state_shift == 1) {   // atoms_center: shift = filter(box centre - estimated centre, dim) (utility.rs:116-119)
+        if (state->status != 0) return;
+        tx = (dim_mask & 1) ? boxp->bcx - state->center[0] : 0.0f;
+        ty = (dim_mask & 2) ? boxp->bcy - state->center[1] : 0.0f;
+        tz = (dim_mask & 4) ? boxp->bcz - state->center[2] : 0.0f;
+    }
+    const uint32_t row = blockIdx.x % 3u, lane = threadIdx.x;
+    const uint32_t tile = (sel.start >> 8) + blockIdx.x / 3u, i0 = (tile * 64u + lane) << 2;
+    const uint32_t first = sel.start, last = sel.start + sel.n;
+    float4 *p = reinterpret_cast<float4 *>(xyz) + (size_t)tile * 192u + row * 64u + lane;
+    const float4 v = gr_stream_load(p);
+    // element e of the float4: which atom of the lane's four, which axis (wave-uniform per row)
+    //   row 0: atoms 0 1 0 1, axes x x y y     row 1: atoms 0 1 2 3, axes z z x x     row 2: atoms 2 3 2 3, axes y y z z
+    const uint32_t a0 = row == 2u ? 2u : 0u, a1 = row == 2u ? 3u : 1u, a2 = row == 0u ? 0u : 2u, a3 = row == 0u ? 1u : 3u;
+    const float L01 = row == 0u ? boxp->ax : row == 1u ? boxp->cz : boxp->by, L23 = row == 0u ? boxp->by : row == 1u ? boxp->ax : boxp->cz;
+    const float iL01 = row == 0u ? boxp->iax : row == 1u ? boxp->icz : boxp->iby, iL23 = row == 0u ? boxp->iby : row == 1u ? boxp->iax : boxp->icz;
+    const float t01 = row == 0u ? tx : row == 1u ? tz : ty, t23 = row == 0u ? ty : row == 1u ? tx : tz;
+    const bool in0 = i0 + a0 >= first && i0 + a0 < last, in1 = i0 + a1 >= first && i0 + a1 < last;
+    const bool in2 = i0 + a2 >= first && i0 + a2 < last, in3 = i0 + a3 >= first && i0 + a3 < last;
+    float4 o = v;
+    if (in0 && v.x == v.x) o.x = gr_wrap_value(v.x + t01, L01, iL01);
+    if (in1 && v.y == v.y) o.y = gr_wrap_value(v.y + t01, L01, iL01);
+    if (in2 && v.z == v.z) o.z = gr_wrap_value(v.z + t23, L23, iL23);
+    if (in3 && v.w == v.w) o.w = gr_wrap_value(v.w + t23, L23, iL23);
+    gr_stream_store(p, o);
+    // first atom without position of the frame: the x coordinates are the first two elements of row 0 and the last two of row 1
+    // (rare: the reduction is behind a wave-wide test)
+    uint32_t bad = GR_NOIDX;
+    if (row == 0u) { if (in0 && v.x != v.x) bad = i0; if (in1 && v.y != v.y) bad = min(bad, i0 + 1u); }
+    else if (row == 1u) { if (in2 && v.z != v.z) bad = i0 + 2u; if (in3 && v.w != v.w) bad = min(bad, i0 + 3u); }
+    if (__builtin_amdgcn_ballot_w64(bad != GR_NOIDX) != 0ull) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) bad = min(bad, (uint32_t)__shfl_xor((int)bad, off, 64));
+        if (lane == 0) atomicMin(bad_out, bad);
+    }
+}
+
 // ------------------------------------------------------------------------------------------ pair distances
 // group_all_distances (analysis.rs:401-427): D[i][j] = distance(x_i, x_j, dim), row-major n1 x n2.
 // Workgroup tile: GR_PD_TI rows x 1024 columns.  Each lane keeps 4 consecutive j atoms in registers,

@@ -86,7 +86,14 @@ __global__ __launch_bounds__(256) void k_tile(const float *__restrict__ aos, flo
     const uint32_t g = blockIdx.x * 256u + threadIdx.x;
     if (g >= n_groups) return;
     const float4 *q = reinterpret_cast<const float4 *>(aos) + 3 * (size_t)g;
-    const float4 a = q[0], b = q[1], c = q[2];
+    float4 a = q[0], b = q[1], c = q[2];
+    // an atom WITHOUT POSITION is NaN in x (groan_hip.h); inside the library its y and z are NaN as well, whatever the caller sent: kernels that
+    // treat the three coordinates of an atom in different lanes (k_translate_wrap_rows) then leave such an atom alone without asking for its x
+    const float qn = __uint_as_float(0x7fc00000u);
+    if (a.x != a.x) { a.y = qn; a.z = qn; }     // atom 0: a.x a.y a.z
+    if (a.w != a.w) { b.x = qn; b.y = qn; }     // atom 1: a.w b.x b.y
+    if (b.z != b.z) { b.w = qn; c.x = qn; }     // atom 2: b.z b.w c.x
+    if (c.y != c.y) { c.z = qn; c.w = qn; }     // atom 3: c.y c.z c.w
     gr_rows_store<true>(reinterpret_cast<float4 *>(slot), g, make_float4(a.x, a.w, a.y, b.x), make_float4(a.z, b.y, b.z, c.y), make_float4(b.w, c.z, c.x, c.w));
 }
 __global__ __launch_bounds__(256) void k_untile(const float *__restrict__ slot, float *__restrict__ aos, uint32_t n_groups) {

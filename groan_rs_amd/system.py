@@ -355,7 +355,7 @@ class System:
         if st != OK:
             raise DeviceError("set_masses", self._err(st)[1], st)
 
-    TUNE = {"sub_batch": 1, "chunks": 2, "fit_wgs": 3, "fuse": 4, "two_pass": 5, "resident": 6, "resident_groups": 7, "resident_streams": 8, "resident_fill": 9, "pairdist_symmetric": 10, "resident_wg_groups": 11, "rmsd_fast": 12, "rmsd_fast_min": 13, "rmsd_fast_sigmas": 14, "masked_selections": 15, "xtc_device_encode": 16, "small_calls": 17, "resident_metro_ns": 18, "resident_fit_last": 19, "stream_wgs_per_cu": 20, "center_resident": 21, "test_resident_no_start": 100, "test_resident_abort_at": 101}
+    TUNE = {"sub_batch": 1, "chunks": 2, "fit_wgs": 3, "fuse": 4, "two_pass": 5, "resident": 6, "resident_groups": 7, "resident_streams": 8, "resident_fill": 9, "pairdist_symmetric": 10, "resident_wg_groups": 11, "rmsd_fast": 12, "rmsd_fast_min": 13, "rmsd_fast_sigmas": 14, "masked_selections": 15, "xtc_device_encode": 16, "small_calls": 17, "resident_metro_ns": 18, "resident_fit_last": 19, "stream_wgs_per_cu": 20, "center_resident": 21, "translate_rows": 22, "test_resident_no_start": 100, "test_resident_abort_at": 101}
 
     def set_tuning(self, **kw):
         """gr_ctx_set_tuning: launch geometry / path selection of the batched RMSD calls (measurement only; same results)"""

@@ -19,7 +19,8 @@
  *
  * Conventions
  *   box9     gro order v1x v2y v3z v1y v1z v2x v2z v3x v3y (src/structures/simbox.rs:13-26); NULL = no box
- *   Option   a missing position / mass (Rust None) is NaN in x / in the mass
+ *   Option   a missing position / mass (Rust None) is NaN in x / in the mass (the library stores such an atom with NaN in y and z as well:
+ *            gr_frame_download returns NaN, NaN, NaN for it whatever y and z the caller had sent)
  *   matrices rotation matrices are column-major (nalgebra storage)
  *   status   every call returns an int: 0 = OK (xdrfile convention, src/io/xtc_io/xdrfile_xtc.rs:63-83)
  *   Non-orthogonal boxes: the reference rejects them (SimBoxError::NotOrthogonal,
@@ -311,10 +312,13 @@ int gr_rmsd_plan_force_exact(gr_rmsd_plan *plan, int on);
  *                      1 .. 8, 0 (default) = the library's choice.  A copy is fastest with 20-32 KiB of loads in flight per CU.
  *   GR_TUNE_CENTER_RESIDENT  1 (default): gr_atoms_center_batch about a contiguous reference group of at least 30 % of the system runs as ONE pass
  *                      over HBM where the resident pass can take it (gr_resident.h MODE 1: every frame read once, written once -- 24 instead of
- *                      36 bytes per atom); 0: always the two passes (centre estimate, then translate + wrap).  Same bits either way. */
+ *                      36 bytes per atom); 0: always the two passes (centre estimate, then translate + wrap).  Same bits either way.
+ *   GR_TUNE_TRANSLATE_ROWS  1 (default): translate / wrap / centring of a contiguous selection in an ORTHORHOMBIC cell runs one 16-byte load and
+ *                      store per lane, a 256-atom tile per workgroup (every coordinate wraps on its own there); 0: the three-rows-per-lane walk
+ *                      that non-orthogonal cells and scattered selections take.  Same bits either way. */
 enum { GR_TUNE_SUB_BATCH = 1, GR_TUNE_CHUNKS = 2, GR_TUNE_FIT_WGS = 3, GR_TUNE_FUSE = 4, GR_TUNE_TWO_PASS = 5, GR_TUNE_RESIDENT = 6, GR_TUNE_RESIDENT_GROUPS = 7,
        GR_TUNE_RESIDENT_STREAMS = 8, GR_TUNE_RESIDENT_FILL = 9, GR_TUNE_PAIRDIST_SYMMETRIC = 10, GR_TUNE_RESIDENT_WG_GROUPS = 11,
-       GR_TUNE_RMSD_FAST = 12, GR_TUNE_RMSD_FAST_MIN = 13, GR_TUNE_RESIDENT_METRO_NS = 18, GR_TUNE_RESIDENT_FIT_LAST = 19, GR_TUNE_STREAM_WGS_PER_CU = 20, GR_TUNE_CENTER_RESIDENT = 21,
+       GR_TUNE_RMSD_FAST = 12, GR_TUNE_RMSD_FAST_MIN = 13, GR_TUNE_RESIDENT_METRO_NS = 18, GR_TUNE_RESIDENT_FIT_LAST = 19, GR_TUNE_STREAM_WGS_PER_CU = 20, GR_TUNE_CENTER_RESIDENT = 21, GR_TUNE_TRANSLATE_ROWS = 22,
        GR_TUNE_MASKED_SELECTIONS = 15 /* 1 (default): a scattered selection that covers at least an eighth of the atoms between its first and its last one (>= 4096
                                          atoms) also gets a bit mask, and RMSD / RMSD-fit / get_com read its span coalesced instead of gathering it atom by atom;
                                          0: groups created afterwards keep to their index lists.  Same results to rounding. */,

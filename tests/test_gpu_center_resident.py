@@ -127,3 +127,11 @@ def test_a_launch_that_never_starts_and_one_that_is_aborted(G):
             assert np.array_equal(s.get_positions(f), want[0][f]), f
     assert (st == 0).sum() >= nf - 8
     s.close()
+
+
+def test_the_switch_takes_zero_or_one(G):
+    s = G.System(100)
+    s.set_tuning(center_resident=0); s.set_tuning(center_resident=1)
+    with pytest.raises(G.DeviceError):
+        s.set_tuning(center_resident=2)
+    s.close()

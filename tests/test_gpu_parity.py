@@ -342,7 +342,9 @@ def test_rmsd_errors(G, example, short_traj):
     with pytest.raises(G.RMSDError) as e:
         cur.calc_rmsd_and_fit(ref, "Protein")
     assert e.value.variant == "InvalidPosition" and e.value.detail == 7
-    assert np.array_equal(np.isnan(cur.get_positions()), np.isnan(bad))      # not modified on failure (rmsd.rs:91)
+    got = cur.get_positions()                                                 # not modified on failure (rmsd.rs:91)
+    assert np.array_equal(np.isnan(got[:, 0]), np.isnan(bad[:, 0])) and np.array_equal(got[~np.isnan(bad[:, 0])], bad[~np.isnan(bad[:, 0])])
+    assert np.isnan(got[7]).all()          # (an atom without position -- NaN in x -- is stored with NaN in y and z as well: groan_hip.h, "Option")
     cur.set_frame(short_traj["frames"][0], None)
     with pytest.raises(G.RMSDError) as e:
         cur.calc_rmsd(ref, "Protein")
