@@ -8,7 +8,7 @@ import numpy as np
 import groan_rs_amd as G
 from groan_rs_amd import workload as W
 n, NF = 1_000_000, 256
-box = W.box_from_lengths_angles([24.0, 23.0, 22.0], [90.0, 90.0, 90.0])
+box = W.c4_box() if os.environ.get("TRIC") else W.box_from_lengths_angles([24.0, 23.0, 22.0], [90.0, 90.0, 90.0])
 s = G.System(n, masses=W.masses_cycle(n), n_slots=NF + 1)
 s.synth_reference(NF, box, 0.2 * float(min(box[:3])), 1)
 s.synth_frames(NF, 0, NF, 0, 0.05, 1)
