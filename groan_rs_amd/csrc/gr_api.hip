@@ -2483,6 +2483,18 @@ static int segment_end(gr_rmsd_plan *p, float *rmsd_out, int *status_out, float 
                             by_xcc[x] += sh; n_xcc[x]++; by_wave[w & 7] += sh; n_wave[w & 7]++;
                             share.push_back({ sh, w });
                         }
+                        {   // which wave of a workgroup completes the workgroup's record (and so runs the combine): the share of the wave that does it most often
+                            double top = 0, top2 = 0; uint32_t nwg = 0; double by_w[8] = { 0 };
+                            for (uint32_t g = 0; g < q.res_stream; ++g) {
+                                double tot = 0, mx = 0, mx2 = 0;
+                                for (uint32_t w = 0; w < 8; ++w) { const double cnt = (double)(d[(size_t)(g * 8 + w) * 4 + 1] >> 32); tot += cnt; by_w[w] += cnt; if (cnt > mx) { mx2 = mx; mx = cnt; } else if (cnt > mx2) mx2 = cnt; }
+                                if (tot > 0) { top += mx / tot; top2 += mx2 / tot; nwg++; }
+                            }
+                            double all = 0; for (int w = 0; w < 8; ++w) all += by_w[w];
+                            fprintf(stderr, "steptime combines: the busiest wave of a workgroup does %.1f %% of its combines, the second %.1f %% (even: 12.5); by wave number:", nwg ? 100.0 * top / nwg : 0.0, nwg ? 100.0 * top2 / nwg : 0.0);
+                            for (int w = 0; w < 8; ++w) fprintf(stderr, " %.1f", all > 0 ? 100.0 * by_w[w] / all : 0.0);
+                            fprintf(stderr, "\n");
+                        }
                         std::sort(share.begin(), share.end());
                         fprintf(stderr, "steptime record-wait share by XCC:");
                         for (int x = 0; x < 8; ++x) fprintf(stderr, " %.3f", n_xcc[x] ? by_xcc[x] / n_xcc[x] : 0.0);

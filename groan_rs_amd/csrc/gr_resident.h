@@ -106,7 +106,7 @@ struct GrResShape {
 #else
     static constexpr int TL_BYTES = 0;
 #endif
-    static constexpr int LDS_BYTES = PARK_F4 * 16 + WSUM_F * 4 + R * WAVES * 8 + 2 * R * 4 + 2 * WAVES * 4 + TL_BYTES;   // ... + fit sums, counters, progress and SIMD of every wave
+    static constexpr int LDS_BYTES = PARK_F4 * 16 + WSUM_F * 4 + R * WAVES * 8 + 3 * R * 4 + 2 * WAVES * 4 + TL_BYTES;   // ... + fit sums, counters (arrivals at the sums / the fit hand-over, combines done), progress and SIMD of every wave
     static constexpr int REC_PER_WAVE = 256 / WAVES, LANES_PER_REC = 64 / REC_PER_WAVE, WORDS_PER_LANE = 32 / LANES_PER_REC;   // finalizer
 };
 #ifndef GR_RES_SLEEP
@@ -510,13 +510,13 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
     float4 *park = smem;
     float *wsum = reinterpret_cast<float *>(smem + S::PARK_F4);
     double *fsum = reinterpret_cast<double *>(wsum + S::WSUM_F);
-    uint32_t *cnt_s = reinterpret_cast<uint32_t *>(fsum + R * WAVES), *cnt_f = cnt_s + R;
-    uint32_t *prog = cnt_f + R, *simd_of = prog + WAVES;             // iterations each wave has begun; the SIMD each wave runs on
+    uint32_t *cnt_s = reinterpret_cast<uint32_t *>(fsum + R * WAVES), *cnt_f = cnt_s + R, *done_s = cnt_f + R;
+    uint32_t *prog = done_s + R, *simd_of = prog + WAVES;             // iterations each wave has begun; the SIMD each wave runs on
 #ifdef GR_EXP_TIMELINE
     unsigned long long *tls = reinterpret_cast<unsigned long long *>(simd_of + WAVES);   // [256][4]
     const bool tl_wg = ctl.tl != nullptr && wg_all == 0u;
 #endif
-    if (tid < 2 * R) cnt_s[tid] = 0u;
+    if (tid < 3 * R) cnt_s[tid] = 0u;
     if (lane == 0) { prog[wave] = 0u; simd_of[wave] = (uint32_t)__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4) /* HW_ID.SIMD_ID */; }
     __syncthreads();                                                  // the only barrier: before the first frame
     // the other wave of this workgroup on the same SIMD: the two share the SIMD's issue slots, and whichever of them is BEHIND gets
@@ -641,7 +641,7 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
     // experiment: where a wave's turn goes (shader-clock ticks summed over the walk, per segment): 0 the metronome's wait, 1 request + balance,
     // 2 the wait for the rows + images + sums arithmetic, 3 reductions + hand-over (+ the combine of the wave that arrives last), 4 the wait
     // for the record (first look / polls), 5 fit arithmetic + stores + hand-over of the fit sum, 6 parking; 7 = fit stages that had to poll
-    unsigned long long st_acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, st_last = (unsigned long long)clock64();
+    unsigned long long st_acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, st_last = (unsigned long long)clock64(), st_combines = 0ull;
 #define GR_STEP_STAMP(k) do { const unsigned long long now_ = (unsigned long long)clock64(); st_acc[k] += now_ - st_last; st_last = now_; } while (0)
 #else
 #define GR_STEP_STAMP(k) do { } while (0)
@@ -681,8 +681,65 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
         return v;
     };
 
+    // WHO ADDS THE WAVE RECORDS UP.  Until round 5 the wave whose arrival completed the count did -- by construction the slowest wave of its
+    // workgroup at that moment, and the extra work kept it the slowest: measured (-DGR_EXP_STEPTIME), one wave of a workgroup ran half of its
+    // combines (an even share is an eighth; the younger wave of every SIMD pair twice as often as the older), every other wave polled for
+    // records in 45-50 % of its fits, and the pace of the launch is the pace of its slowest wave.  Now (GR_RES_LATE_COMBINE) arrivals are only
+    // counted -- cumulatively: slot s is complete for its use u when cnt_s[s] = n_waves (u + 1), nothing is ever reset -- and the record of
+    // frame f is put together by the FIRST wave that passes its own hand-over of frame f + 1 and finds frame f complete and unclaimed
+    // (done_s[s]: u -> u + 1 by compare-and-swap): a wave that is ahead does the chore.  The last wave to pass finds every earlier arrival
+    // in, so somebody always does; the stream's last frame is claimed in the first turn after it.  (A slot is reused 8 frames later: a wave
+    // that writes it then has fitted frame f, so frame f's record -- and with it this combine -- was complete long before.)  Measured:
+    // combines spread evenly (the busiest wave 21 %), fits that poll 45 % -> 2 %, RMSD-fit 4.12 -> 4.04 us per frame, atoms_center 4.31 -> 4.21.
+#ifndef GR_RES_LATE_COMBINE
+#define GR_RES_LATE_COMBINE 1
+#endif
+    auto claim = [&](uint32_t f) -> bool {        // wave-uniform: may this wave put the workgroup's record of frame f together?
+        const uint32_t rs = f % R, u = f / R;
+        if (__hip_atomic_load(cnt_s + rs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != n_waves * (u + 1u)) return false;
+        if (__hip_atomic_load(done_s + rs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != u) return false;
+        uint32_t won = 0u;
+        if (lane == 0) { uint32_t expect = u; won = __hip_atomic_compare_exchange_strong(done_s + rs, &expect, u + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) ? 1u : 0u; }
+        if (__builtin_amdgcn_readfirstlane((int)won) == 0) return false;
+        gr_lds_acquire();
+        return true;
+    };
     // ---- the sums stage of frame i (rows in L): the lane's 18 + 12 values -> wave (reduce-scatter) -> workgroup (LDS, the last
     // wave to arrive adds the wave records in wave order) -> the frame's tagged record.  V: `va`, `vb` receive the image vectors.
+    // the workgroup's record of frame f: the wave records in wave order, 31 tagged words
+    auto combine_rmsd = [&](uint32_t f) {
+        const uint32_t rs = f % R;
+#ifdef GR_EXP_STEPTIME
+        st_combines += 1ull;
+#endif
+        const float *all = wsum + rs * WAVES * 32;
+        if (lane < 31u) {
+            float v;
+            if (n_waves == WAVES) {
+                // a full workgroup (all but the last one of a frame): the wave records are requested together -- one LDS round trip
+                // instead of a chain of dependent ones (5.44 -> 5.30 us)
+                float t[WAVES];
+#pragma unroll
+                for (uint32_t w = 0; w < WAVES; ++w) t[w] = all[w * 32 + lane];
+                v = t[0];
+                if (lane < 19u) {
+#pragma unroll
+                    for (uint32_t w = 1; w < WAVES; ++w) v += t[w];
+                } else {
+#pragma unroll
+                    for (uint32_t w = 1; w < WAVES; ++w) v = gr_fmaxf(v, t[w]);
+                }
+            } else {
+                v = all[lane];
+                if (lane < 19u) { for (uint32_t w = 1; w < n_waves; ++w) v += all[w * 32 + lane]; }
+                else { for (uint32_t w = 1; w < n_waves; ++w) v = gr_fmaxf(v, all[w * 32 + lane]); }
+            }
+            gr_st_agent(ctl.wgrec + ((size_t)kf(f) * n_pad + wg) * GR_RES_REC_WORDS + lane, ((unsigned long long)ctl.epoch << 32) | __float_as_uint(v));
+        }
+#ifdef GR_EXP_TIMELINE
+        if (tl_wg && lane == 0) tls[(f & 127u) * 4u + 0u] = wall_clock64();
+#endif
+    };
     auto sums = [&](uint32_t i, const Landing &L, const GrBoxU &B, Rows &va, Rows &vb) {
         float s32[32], e32[32];
 #pragma unroll
@@ -758,42 +815,16 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
         // hand-off to the wave that completes the count: the record is RELEASED before the arrival is counted (LDS-only fence: one
         // s_waitcnt lgkmcnt(0)); the completing wave ACQUIRES before it reads the other waves' records
         gr_lds_release();
+#if GR_RES_LATE_COMBINE
+        if (lane == 0) (void)__hip_atomic_fetch_add(cnt_s + rs, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (i > 0u && claim(i - 1u)) combine_rmsd(i - 1u);
+#else
         uint32_t old = 0;
         if (lane == 0) old = __hip_atomic_fetch_add(cnt_s + rs, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if ((uint32_t)__builtin_amdgcn_readfirstlane((int)old) != n_waves - 1u) return;
-        // this wave completed the workgroup's record of frame i: add the wave records in wave order, publish 31 tagged words
+        if ((uint32_t)__builtin_amdgcn_readfirstlane((int)old) != n_waves * (i / R + 1u) - 1u) return;
         gr_lds_acquire();
-        const float *all = wsum + rs * WAVES * 32;
-        if (lane < 31u) {
-            float v;
-            if (n_waves == WAVES) {
-                // a full workgroup (all but the last one of a frame): the wave records are requested together -- one LDS round trip
-                // instead of a chain of dependent ones on the wave that is, by construction, the last of its workgroup (5.44 -> 5.30 us)
-                float t[WAVES];
-#pragma unroll
-                for (uint32_t w = 0; w < WAVES; ++w) t[w] = all[w * 32 + lane];
-                v = t[0];
-                if (lane < 19u) {
-#pragma unroll
-                    for (uint32_t w = 1; w < WAVES; ++w) v += t[w];
-                } else {
-#pragma unroll
-                    for (uint32_t w = 1; w < WAVES; ++w) v = gr_fmaxf(v, t[w]);
-                }
-            } else {
-                v = all[lane];
-                if (lane < 19u) { for (uint32_t w = 1; w < n_waves; ++w) v += all[w * 32 + lane]; }
-                else { for (uint32_t w = 1; w < n_waves; ++w) v = gr_fmaxf(v, all[w * 32 + lane]); }
-            }
-            gr_st_agent(ctl.wgrec + ((size_t)kf(i) * n_pad + wg) * GR_RES_REC_WORDS + lane, ((unsigned long long)ctl.epoch << 32) | __float_as_uint(v));
-        }
-#ifdef GR_EXP_TIMELINE
-        if (tl_wg && lane == 0) tls[(i & 127u) * 4u + 0u] = wall_clock64();
+        combine_rmsd(i);
 #endif
-        // the slot's counter starts the next use (frame i + R) at zero.  No wave can reach frame i + R before this wave -- the slowest
-        // of the workgroup at this point -- has published frame i, the finalizer has closed it and the fit stage of frame i has been
-        // passed by everybody (R > K), so the reset cannot meet an arrival
-        if (lane == 0) __hip_atomic_store(cnt_s + rs, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
 
     // ---- MODE 1, the sums stage of frame i: the Bai-Breen sums of the reference group (iterators.rs:1152-1191,1314-1357).  Every atom's terms are
@@ -802,6 +833,20 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
     // TWO tagged words, v = hi + lo (f32 each: 48 bits of the fp64 value), so that the finalizer's fp64 total differs from the two-pass path's
     // only by the order of fp64 additions.  Word 7 / 15: atoms without position (x is NaN) among ALL the workgroup's atoms -- the frame is
     // then left alone (see the finalizer).
+    auto combine_cen = [&](uint32_t f) {          // MODE 1: the workgroup's record of frame f, every fp64 sum as hi + lo words
+        const uint32_t rs = f % R;
+        const double *all = reinterpret_cast<const double *>(wsum + rs * WAVES * 32);
+        if (lane < 31u) {
+            float word = 0.0f;
+            if (lane < 16u) {
+                double v = all[lane & 7u];
+                for (uint32_t w = 1; w < n_waves; ++w) v += all[w * 16u + (lane & 7u)];      // wave order
+                const float hi = (float)v;
+                word = lane < 8u ? hi : (float)(v - (double)hi);
+            }
+            gr_st_agent(ctl.wgrec + ((size_t)kf(f) * n_pad + wg) * GR_RES_REC_WORDS + lane, ((unsigned long long)ctl.epoch << 32) | __float_as_uint(word));
+        }
+    };
     auto sums_cen = [&](uint32_t i, const Landing &L, const GrBoxU &B) {
         double d32[8];
 #pragma unroll
@@ -858,22 +903,16 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
         const double dt = gr_wave_sum_scatter8_f64(d32, lane);                           // lane l: the wave total of value l >> 3 (no LDS crossbar)
         if ((lane & 7u) == 0) mine[lane >> 3] = dt;
         gr_lds_release();
+#if GR_RES_LATE_COMBINE
+        if (lane == 0) (void)__hip_atomic_fetch_add(cnt_s + rs, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (i > 0u && claim(i - 1u)) combine_cen(i - 1u);
+#else
         uint32_t old = 0;
         if (lane == 0) old = __hip_atomic_fetch_add(cnt_s + rs, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if ((uint32_t)__builtin_amdgcn_readfirstlane((int)old) != n_waves - 1u) return;
+        if ((uint32_t)__builtin_amdgcn_readfirstlane((int)old) != n_waves * (i / R + 1u) - 1u) return;
         gr_lds_acquire();
-        const double *all = reinterpret_cast<const double *>(wsum + rs * WAVES * 32);
-        if (lane < 31u) {
-            float word = 0.0f;
-            if (lane < 16u) {
-                double v = all[lane & 7u];
-                for (uint32_t w = 1; w < n_waves; ++w) v += all[w * 16u + (lane & 7u)];      // wave order
-                const float hi = (float)v;
-                word = lane < 8u ? hi : (float)(v - (double)hi);
-            }
-            gr_st_agent(ctl.wgrec + ((size_t)kf(i) * n_pad + wg) * GR_RES_REC_WORDS + lane, ((unsigned long long)ctl.epoch << 32) | __float_as_uint(word));
-        }
-        if (lane == 0) __hip_atomic_store(cnt_s + rs, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        combine_cen(i);
+#endif
     };
 
     // V fit of one group: R v + t0, sum w |R q - p|^2 (rmsd.rs:592-599; pad atoms weigh nothing), + reference COM
@@ -1098,6 +1137,10 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
         const uint32_t ps = i % K;
         GR_STEP_STAMP(1);
         if (i < n_turns) { if constexpr (MODE == 1) sums_cen(i, cur, Bs); else sums(i, cur, Bs, va, vb); }
+#if GR_RES_LATE_COMBINE
+        // (the stream's last frame has no hand-over after it: its record is put together in the first turn behind it)
+        if (i == n_turns && n_turns > 0u && claim(n_turns - 1u)) { if constexpr (MODE == 1) combine_cen(n_turns - 1u); else combine_rmsd(n_turns - 1u); }
+#endif
         GR_STEP_STAMP(3);
         if (i >= K) {
             Rows qb;
@@ -1148,6 +1191,10 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
             else if (ps == 3u) { Q3 = vb; asm volatile("; set 3 in"); } else if (ps == 4u) { Q4 = vb; asm volatile("; set 4 in"); } else { Q5 = vb; asm volatile("; set 5 in"); }
             if (!V && MODE != 1) sums(i, cur, Bs, va, vb);
         }
+#if GR_RES_LATE_COMBINE
+        // (the stream's last frame has no hand-over after it: its record is put together in the first turn behind it)
+        if (i == n_turns && n_turns > 0u && claim(n_turns - 1u)) { if constexpr (MODE == 1) combine_cen(n_turns - 1u); else combine_rmsd(n_turns - 1u); }
+#endif
     };
     auto step = [&](uint32_t i, Landing &cur, Landing &nxt) { if constexpr (FL) step_sums_first(i, cur, nxt); else step_fit_first(i, cur, nxt); };
     for (uint32_t i = 0; i < n_iter && !bail; i += 2) {
@@ -1164,7 +1211,7 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
         if (ctl.dbg) {
             unsigned long long *o = ctl.dbg + (size_t)(wg_all * WAVES + wave) * 4u;
             unsigned long long tot = 0; for (int k = 0; k < 7; ++k) tot += st_acc[k];
-            o[0] = st_acc[4]; o[1] = st_acc[7];
+            o[0] = st_acc[4]; o[1] = st_acc[7] | (st_combines << 32);
             o[2] = (__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 7u) | (simd_of[wave] << 8);
             o[3] = tot;
         }
