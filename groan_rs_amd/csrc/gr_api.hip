@@ -2231,11 +2231,11 @@ static int segment_begin(gr_rmsd_plan *p, uint32_t s0, uint32_t nb, int fit) {
             // ONE launch for the segment: every frame is read once and written once (gr_resident.h)
             const uint32_t res_stream = res_wgs * res_streams;
             const uint32_t n_fin = std::min<uint32_t>(res_streams > 8 ? GR_RES_MAX_FIN : 8, c->res_max_wgs - res_stream);
-            if ((size_t)nb * res_wgs > c->fit_partials_cap) {
+            if ((size_t)nb * res_wgs * GrResShape::WAVES > c->fit_partials_cap) {      // (one word per streaming WAVE and frame)
                 if (c->fit_partials) (void)hipFree(c->fit_partials);
                 c->fit_partials = nullptr; c->fit_partials_cap = 0;
-                HIPCHK(c, hipMalloc(&c->fit_partials, (size_t)nb * res_wgs * sizeof(double)));
-                c->fit_partials_cap = (size_t)nb * res_wgs;
+                HIPCHK(c, hipMalloc(&c->fit_partials, (size_t)nb * res_wgs * GrResShape::WAVES * sizeof(double)));
+                c->fit_partials_cap = (size_t)nb * res_wgs * GrResShape::WAVES;
             }
             const size_t rec_words = (size_t)nb * ((res_wgs + GR_RES_REC_PAD - 1u) & ~(uint32_t)(GR_RES_REC_PAD - 1u)) * GR_RES_REC_WORDS;
             if (rec_words > c->res_wgrec_cap) {
@@ -2314,7 +2314,7 @@ static int segment_begin(gr_rmsd_plan *p, uint32_t s0, uint32_t nb, int fit) {
             const hipError_t le = hipLaunchKernel(fn, dim3(res_stream + n_fin), dim3(lanes), args, lds, S);
             if (le == hipSuccess) {
                 if (c->profile) EVREC(c, c->pev[1], true, S);
-                k_rmsd_close<<<dim3(nb), dim3(64), 0, S>>>(c->fit_partials, res_wgs, p->dev.sw, c->state_dev);
+                k_rmsd_close<<<dim3(nb), dim3(64), 0, S>>>(c->fit_partials, res_wgs * GrResShape::WAVES, p->dev.sw, c->state_dev);
                 HIPCHK(c, hipGetLastError());
                 // (the launch's control words follow it on the stream into pinned memory: segment_end reads them after its one synchronisation
                 //  instead of fetching them with a blocking copy of their own -- 15-25 us per call)

@@ -504,6 +504,7 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
     auto kf = [&](uint32_t k) { return stream + k * ctl.streams; };
     if (base + wave * 64u >= glimit) {                                // every chunk of this wave lies behind the workgroup's last group: nothing to fit
         if (lane == 0) ctl.progress[wg_all * WAVES + wave] = GR_RES_IDLE_WAVE;   // (not "all turns done": the host skips this word)
+        if (MODE == 0 && fit_partials) for (uint32_t k = lane; k < n_turns; k += 64u) fit_partials[((size_t)kf(k) * ctl.wgs_frame + wg) * WAVES + wave] = 0.0;   // (its words of the frames' fit sums)
         return;
     }
     const uint32_t n_waves = min(WAVES, (glimit - base) >> 6);
@@ -1068,30 +1069,12 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
         }
         n_fitted = j + 1u;
         if (MODE == 1) return;                                    // (no sum to hand over)
-        // the workgroup's share of sum w |R q - p|^2: the lane's eight atoms in f32, the wave in f32 (no LDS crossbar), waves in fp64
-        // in wave order by the last wave to arrive (release / acquire as in the sums stage)
+        // the wave's share of sum w |R q - p|^2: the lane's eight atoms in f32, the wave in f32 (no LDS crossbar) -- and straight to memory,
+        // one fp64 word per wave and frame: k_rmsd_close adds the waves' words of a frame in a fixed order.  (Until round 5 the waves met in
+        // LDS and the last one to arrive added the eight up: a fence, an atomic and a chain of LDS reads on the workgroup's slowest wave,
+        // every turn.)
         const float wtot = gr_wave_allsum_f32(rs);
-        const uint32_t fs = j % R;
-        if (lane == 0) fsum[fs * WAVES + wave] = (double)wtot;
-        gr_lds_release();
-        uint32_t old = 0;
-        if (lane == 0) old = __hip_atomic_fetch_add(cnt_f + fs, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if ((uint32_t)__builtin_amdgcn_readfirstlane((int)old) != n_waves - 1u) return;
-        gr_lds_acquire();
-        if (lane == 0) {
-            double t = 0.0;
-            if (n_waves == WAVES) {
-                double x[WAVES];
-#pragma unroll
-                for (uint32_t w = 0; w < WAVES; ++w) x[w] = fsum[fs * WAVES + w];
-#pragma unroll
-                for (uint32_t w = 0; w < WAVES; ++w) t += x[w];
-            } else {
-                for (uint32_t w = 0; w < n_waves; ++w) t += fsum[fs * WAVES + w];
-            }
-            fit_partials[(size_t)kf(j) * ctl.wgs_frame + wg] = t;
-            __hip_atomic_store(cnt_f + fs, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // (as cnt_s: the next use is R frames away)
-        }
+        if (lane == 0) fit_partials[((size_t)kf(j) * ctl.wgs_frame + wg) * WAVES + wave] = (double)wtot;
     };
 
     // ---- the walk: iteration i = fit of frame i - K, then sums of frame i.  A frame (its rows; V: its image vectors) waits for its
