@@ -511,8 +511,8 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
     float4 *park = smem;
     float *wsum = reinterpret_cast<float *>(smem + S::PARK_F4);
     double *fsum = reinterpret_cast<double *>(wsum + S::WSUM_F);
-    uint32_t *cnt_s = reinterpret_cast<uint32_t *>(fsum + R * WAVES), *cnt_f = cnt_s + R, *done_s = cnt_f + R;
-    uint32_t *prog = done_s + R, *simd_of = prog + WAVES;             // iterations each wave has begun; the SIMD each wave runs on
+    uint32_t *cnt_s = reinterpret_cast<uint32_t *>(fsum + R * WAVES);   // [R][2]: arrivals at the sums hand-over of a slot (cumulative), combines done for it
+    uint32_t *prog = cnt_s + 3 * R, *simd_of = prog + WAVES;             // iterations each wave has begun; the SIMD each wave runs on
 #ifdef GR_EXP_TIMELINE
     unsigned long long *tls = reinterpret_cast<unsigned long long *>(simd_of + WAVES);   // [256][4]
     const bool tl_wg = ctl.tl != nullptr && wg_all == 0u;
@@ -697,10 +697,11 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
 #endif
     auto claim = [&](uint32_t f) -> bool {        // wave-uniform: may this wave put the workgroup's record of frame f together?
         const uint32_t rs = f % R, u = f / R;
-        if (__hip_atomic_load(cnt_s + rs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != n_waves * (u + 1u)) return false;
-        if (__hip_atomic_load(done_s + rs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != u) return false;
+        // (arrivals and combines of a slot sit side by side: one 64-bit LDS read answers both questions)
+        const unsigned long long both = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(cnt_s + 2u * rs), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if ((uint32_t)both != n_waves * (u + 1u) || (uint32_t)(both >> 32) != u) return false;
         uint32_t won = 0u;
-        if (lane == 0) { uint32_t expect = u; won = __hip_atomic_compare_exchange_strong(done_s + rs, &expect, u + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) ? 1u : 0u; }
+        if (lane == 0) { uint32_t expect = u; won = __hip_atomic_compare_exchange_strong(cnt_s + 2u * rs + 1u, &expect, u + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) ? 1u : 0u; }
         if (__builtin_amdgcn_readfirstlane((int)won) == 0) return false;
         gr_lds_acquire();
         return true;
@@ -817,11 +818,11 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
         // s_waitcnt lgkmcnt(0)); the completing wave ACQUIRES before it reads the other waves' records
         gr_lds_release();
 #if GR_RES_LATE_COMBINE
-        if (lane == 0) (void)__hip_atomic_fetch_add(cnt_s + rs, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (lane == 0) (void)__hip_atomic_fetch_add(cnt_s + 2u * rs, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (i > 0u && claim(i - 1u)) combine_rmsd(i - 1u);
 #else
         uint32_t old = 0;
-        if (lane == 0) old = __hip_atomic_fetch_add(cnt_s + rs, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (lane == 0) old = __hip_atomic_fetch_add(cnt_s + 2u * rs, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if ((uint32_t)__builtin_amdgcn_readfirstlane((int)old) != n_waves * (i / R + 1u) - 1u) return;
         gr_lds_acquire();
         combine_rmsd(i);
@@ -905,11 +906,11 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
         if ((lane & 7u) == 0) mine[lane >> 3] = dt;
         gr_lds_release();
 #if GR_RES_LATE_COMBINE
-        if (lane == 0) (void)__hip_atomic_fetch_add(cnt_s + rs, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (lane == 0) (void)__hip_atomic_fetch_add(cnt_s + 2u * rs, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (i > 0u && claim(i - 1u)) combine_cen(i - 1u);
 #else
         uint32_t old = 0;
-        if (lane == 0) old = __hip_atomic_fetch_add(cnt_s + rs, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (lane == 0) old = __hip_atomic_fetch_add(cnt_s + 2u * rs, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if ((uint32_t)__builtin_amdgcn_readfirstlane((int)old) != n_waves * (i / R + 1u) - 1u) return;
         gr_lds_acquire();
         combine_cen(i);
