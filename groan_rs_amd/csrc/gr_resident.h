@@ -11,13 +11,15 @@
 //                    registers); a lane walks the frames of the batch with its own groups:
 //                       sums stage, frame i      rows arrive (requested one frame earlier), image v of every atom about the first
 //                                                atom of the selection, the 18 sums + 12 extents of the lane's 8 atoms -> wave
-//                                                reduce-scatter -> LDS; the last wave of the workgroup to arrive adds the 8 wave
-//                                                records in wave order and writes the workgroup's record: 31 tagged words
-//                                                (value | epoch << 32), no flag, no fence; the frame is parked: group A in LDS
+//                                                reduce-scatter -> LDS; a wave that is AHEAD (the first to pass its next hand-over
+//                                                and find the count complete: see `claim`) adds the 8 wave records in wave order and
+//                                                writes the workgroup's record: 31 tagged words (value | epoch << 32), no flag, no
+//                                                fence between workgroups; the frame is parked: group A in LDS
 //                                                (24 KiB per frame and CU), group B in one of six register sets (12 registers)
 //                       fit stage, frame i - 6   the frame's record (status, shift, R, t0) has come back from a finalizer ->
 //                                                the parked data out of LDS / the register set, rotate + translate,
-//                                                sum w |R q - p|^2, one non-temporal store per row
+//                                                sum w |R q - p|^2 (one fp64 word per wave and frame, added up by k_rmsd_close),
+//                                                one non-temporal store per row
 //                    + `n_fin` workgroups that stream nothing: finalizer j owns the frames j, j + n_fin, ...; its 8 waves
 //                    read 32 workgroup records each (one load round trip for the whole frame), re-reading until every
 //                    word carries the launch's tag; a fixed tree adds them in fp64, one lane closes the frame exactly as
@@ -82,9 +84,9 @@
 // of the wave's prefetched rows) out of the streaming loop.
 // Inside a workgroup (no barrier in the loop): a wave writes its record to LDS, RELEASES it with a workgroup-scope fence
 // restricted to the LDS address space (one s_waitcnt lgkmcnt(0); the unrestricted fence would drain the prefetched rows too)
-// and bumps the frame's LDS counter; the wave whose bump completes the count ACQUIRES with the same kind of fence before it
-// reads the other waves' records.  Results do not depend on the order of arrival: the wave records are added in wave order by
-// whichever wave arrives last, the workgroup records by a fixed tree in the finalizer.
+// and bumps the slot's LDS counter; the wave that later claims the complete frame ACQUIRES with the same kind of fence before it
+// reads the waves' records.  Results do not depend on the order of arrival or on who claims: the wave records are added in wave
+// order, the workgroup records by a fixed tree in the finalizer.
 // Precision: a workgroup record is the f32 sum of 16 f32 wave sums (4096 atoms; the two-pass path sums ~7800 atoms in f32
 // before it widens), the finalizer adds the workgroup records in fp64.
 #pragma once
@@ -640,7 +642,7 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
     //  frequency the launch ran at -- under the power cap the pass, streaming and computing at once, does not run at the nominal 2.4 GHz)
 #ifdef GR_EXP_STEPTIME
     // experiment: where a wave's turn goes (shader-clock ticks summed over the walk, per segment): 0 the metronome's wait, 1 request + balance,
-    // 2 the wait for the rows + images + sums arithmetic, 3 reductions + hand-over (+ the combine of the wave that arrives last), 4 the wait
+    // 2 the wait for the rows + images + sums arithmetic, 3 reductions + hand-over (+ the combine, when this wave claims one), 4 the wait
     // for the record (first look / polls), 5 fit arithmetic + stores + hand-over of the fit sum, 6 parking; 7 = fit stages that had to poll
     unsigned long long st_acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, st_last = (unsigned long long)clock64(), st_combines = 0ull;
 #define GR_STEP_STAMP(k) do { const unsigned long long now_ = (unsigned long long)clock64(); st_acc[k] += now_ - st_last; st_last = now_; } while (0)
