@@ -97,7 +97,7 @@ struct gr_ctx {
     int pd_sym = 1;                   // GR_TUNE_PAIRDIST_SYMMETRIC: the pair matrix of a selection with itself computes one triangle and mirrors it
     int res_wg_groups = 0;            // GR_TUNE_RESIDENT_WG_GROUPS 0: automatic, 64 .. 1024 (multiple of 64): 4-atom groups per streaming workgroup
     int res_streams = 0;              // GR_TUNE_RESIDENT_STREAMS 0 automatic, 1..GR_RES_MAX_STREAMS: at most so many frame streams per resident launch
-    int res_fill16 = 10;              // GR_TUNE_RESIDENT_FILL: sixteenths of the chip the streaming workgroups must fill for the pass to be chosen (resident = 1)
+    int res_fill16 = 1;               // GR_TUNE_RESIDENT_FILL: sixteenths of the chip the streaming workgroups must fill for the pass to be chosen (resident = 1); 10 until the late combine of round 5
     uint32_t res_last_streams = 0;    // frame streams of the last resident launch (gr_ctx_stat)
     // the resident pass's metronome (gr_resident.h): GR_TUNE_RESIDENT_METRO_NS 0 = the controller below, 1 = off, else a fixed period.
     // The controller keeps, per launch shape, the shortest period the launches have KEPT (a turn took no longer than the period and
@@ -367,7 +367,9 @@ uint32_t resident_wgs(gr_ctx *c, bool lite, uint32_t nb, const GrSel &sel, uint3
     }
     // the pass costs the same per turn whatever the frame's size (every CU runs its 4096 atoms' worth or idles): it only beats
     // the two passes, whose time shrinks with the frame, when the streams together fill enough of the chip (measured,
-    // profiles/r03_size_sweep.txt: + 3 % at 0.67 of the chip, - 8 % at 0.57; the default asks for 10/16)
+    // profiles/r03_size_sweep.txt: + 3 % at 0.67 of the chip, - 8 % at 0.57; the default asked for 10/16).  Round 5: with the workgroup's
+    // chores on a wave that is ahead the pass wins at ANY fill -- 500 .. 16 000 atoms per frame, 32 streams on 32-128 CUs: 4.9-6.2 M frames/s
+    // against 2.8-4.3 M for the two passes (profiles/r05_small_frames.txt); the default asks for 1/16
     if (c->resident == 1 && (s_max == 0 || s_max * wgs_used * 16 < (uint64_t)c->res_max_wgs * (uint64_t)c->res_fill16)) return 0;
     // ... and when the segment is long enough to pay for filling and draining the six-frame pipeline (measured at 16 frames per
     // call: 9.8 us per frame against 10.6 for the two passes; single frames are a chain of waits)

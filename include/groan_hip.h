@@ -286,8 +286,8 @@ int gr_rmsd_plan_force_exact(gr_rmsd_plan *plan, int on);
  *                      launch (stream s of S owns frames s, s + S, ... of the segment and its own share of the CUs).  0 (default):
  *                      as many as fit, up to 32, when GR_TUNE_RESIDENT is 1 (each stream needs 16 frames of the segment), one when
  *                      it is 2; 1 .. 32: at most so many.  Results do not depend on the number of streams.
- *   GR_TUNE_RESIDENT_FILL    sixteenths of the chip (1 .. 16, default 10) the streams of a launch must fill together for
- *                      GR_TUNE_RESIDENT = 1 to choose the pass
+ *   GR_TUNE_RESIDENT_FILL    sixteenths of the chip (1 .. 16, default 1; 10 until round 5) the streams of a launch must fill together
+ *                      for GR_TUNE_RESIDENT = 1 to choose the pass
  *   GR_TUNE_RESIDENT_WG_GROUPS  4-atom groups per streaming workgroup of the resident pass: 0 (default) = 1024, two per lane; 64 ..
  *                      1024 in steps of 64 cuts a frame into more, smaller workgroups.  An experiment's knob: a turn of the pass is
  *                      bound by instruction issue and latency, not by the work per CU -- 768 groups instead of 1024 gave 5 % at
