@@ -103,7 +103,9 @@ struct gr_ctx {
     // The controller keeps, per launch shape, the shortest period the launches have KEPT (a turn took no longer than the period and
     // next to no slot was reached late); it starts from a free-running launch, probes downwards 1.5 % at a time, steps back to the
     // best kept period when a probe fails, and switches the clock off for a shape whose free-running turn it cannot beat.
-    int res_metro_ns = 0;
+    int res_metro_ns = 1;             // (1 = off, the default since the end of round 5: with the workgroups' chores on waves that are ahead the pass is no longer paced by memory,
+                                      //  no period beats the free-running turn -- and the controller (0) could settle on a SLOW period when a process's first, cold launch
+                                      //  read long: 4.52 us kept as "3 % under the free-running 4.66" while the pass free-runs at 3.95: a 12 % loss, seen once in bench.py)
     // workgroups per CU of the grid-launched read-modify-write streams (k_translate_wrap, k_fit_pk): GR_TUNE_STREAM_WGS_PER_CU.  A copy runs
     // fastest with 20-32 KiB of loads in flight per CU (tools/copy_matrix3 --occ: 3 KiB per wave at 2 workgroups per CU 6.2 TB/s, at 8 -- what the
     // registers allow -- 5.77); the surplus workgroups are kept off the CU by LDS they do not use

@@ -302,9 +302,10 @@ int gr_rmsd_plan_force_exact(gr_rmsd_plan *plan, int on);
  *                      reference) is redone by the exact-product pass, counted in GR_STAT_RMSD_EXACT_REDOS.  0: always the exact pass
  *   GR_TUNE_RMSD_FAST_MIN  smallest selection (atoms, default 16384) that takes it
  *   GR_TUNE_RESIDENT_METRO_NS  the resident pass's METRONOME (gr_resident.h): the period, in nanoseconds per turn, at which the launch's
- *                      row requests sweep each frame in address order.  0 (default) = chosen and kept up to date by the library from what
- *                      its own launches report (GR_STAT_RES_METRO_PERIOD_NS / _LAST_TURN_NS / _LATE_PERMILLE); 1 = off (the waves run
- *                      free, as before round 5); 100 .. 1 000 000 = this period.  Results do not depend on it.
+ *                      row requests sweep each frame in address order.  1 (default) = off, the waves run free; 0 = chosen and kept up to date
+ *                      by the library from what its own launches report (GR_STAT_RES_METRO_PERIOD_NS / _LAST_TURN_NS / _LATE_PERMILLE: the
+ *                      default for most of round 5 -- it bought 3 % while the pass was paced by memory, nothing since, and could settle on a
+ *                      slow period after a cold first launch); 100 .. 1 000 000 = this period.  Results do not depend on it.
  *   GR_TUNE_RESIDENT_FIT_LAST  order of a turn of the resident pass: 1 = the fit of frame i - 6, then the sums of frame i (rounds 2-4);
  *                      2 = the sums first (the frame's record is needed later and published earlier: one more turn for the finalizers);
  *                      0 (default) = sums first when the streaming workgroups fill 9/10 of the chip.  Same results either way.
