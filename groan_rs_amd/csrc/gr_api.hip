@@ -2214,7 +2214,7 @@ static int segment_begin(gr_rmsd_plan *p, uint32_t s0, uint32_t nb, int fit) {
         const uint32_t n_groups = (nb + sb - 1) / sb;
         if (lite) {
             size_t need = 0;
-            for (uint32_t f0 = 0; f0 < nb; f0 += sb) need = std::max(need, (size_t)nb * fit_grid(c, std::min<uint32_t>(sb, nb - f0)));
+            for (uint32_t f0 = 0; f0 < nb; f0 += sb) need = std::max(need, (size_t)nb * fit_grid(c, std::min<uint32_t>(sb, nb - f0)) * (GR_WG / 64));   // (one word per wave)
             if (need > c->fit_partials_cap) {
                 if (c->fit_partials) (void)hipFree(c->fit_partials);
                 c->fit_partials = nullptr; c->fit_partials_cap = 0;
@@ -2355,10 +2355,10 @@ static int segment_begin(gr_rmsd_plan *p, uint32_t s0, uint32_t nb, int fit) {
             if (fit) {
                 if (c->profile) EVREC(c, c->pev[6 * g + 4], true, S);
                 // (closing the rmsd on the tail of this kernel makes every one of its 62 k workgroups drain its stores: 3x slower)
-                if (lite) k_fit_pk<true><<<dim3(gx, nf), dim3(GR_WG), stream_lds(c, GR_STREAM_WGS_CU_DEFAULT), S>>>(c->frames, c->frame_stride, s0 + f0, (uint32_t)c->n, c->boxes_dev, p->dev, c->state_dev + f0, c->masses, sel, c->fit_partials + (size_t)f0 * gx);
+                if (lite) k_fit_pk<true><<<dim3(gx, nf), dim3(GR_WG), stream_lds(c, GR_STREAM_WGS_CU_DEFAULT), S>>>(c->frames, c->frame_stride, s0 + f0, (uint32_t)c->n, c->boxes_dev, p->dev, c->state_dev + f0, c->masses, sel, c->fit_partials + (size_t)f0 * gx * (GR_WG / 64));
                 else k_fit_pk<false><<<dim3(gx, nf), dim3(GR_WG), 0, S>>>(c->frames, c->frame_stride, s0 + f0, (uint32_t)c->n, c->boxes_dev, p->dev, c->state_dev + f0, c->masses, sel, nullptr);
                 if (c->profile) EVREC(c, c->pev[6 * g + 5], true, S);
-                if (lite) k_rmsd_close<<<dim3(nf), dim3(64), 0, S>>>(c->fit_partials + (size_t)f0 * gx, gx, p->dev.sw, c->state_dev + f0);
+                if (lite) k_rmsd_close<<<dim3(nf), dim3(64), 0, S>>>(c->fit_partials + (size_t)f0 * gx * (GR_WG / 64), gx * (GR_WG / 64), p->dev.sw, c->state_dev + f0);
             }
         }
         HIPCHK(c, hipGetLastError());

@@ -405,7 +405,6 @@ __global__ __launch_bounds__(GR_WG) void k_fit_pk(
     float *__restrict__ frames, size_t frame_stride, uint32_t first_slot, uint32_t n_atoms,
     const GrBox *__restrict__ boxes, GrPlanDev plan, const GrFrameState *__restrict__ state,
     const float *__restrict__ masses, GrSel sel, double *fit_partials) {
-    __shared__ double lds[GR_WG / 64];
     const uint32_t frame = blockIdx.y;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float *xyz = frames + (size_t)(first_slot + frame) * frame_stride;
@@ -495,15 +494,20 @@ __global__ __launch_bounds__(GR_WG) void k_fit_pk(
         if (g < ngroups) request(g);
     }
     if (RMSD) {
-        rs = gr_wave_sum(rs);
-        if (lane == 0) lds[wave] = rs;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            double tot = 0.0;
-#pragma unroll
-            for (int k = 0; k < GR_WG / 64; ++k) tot += lds[k];
-            fit_partials[(size_t)frame * gridDim.x + blockIdx.x] = tot;
-        }
+        // the wave's share goes straight to memory, one fp64 word per wave (k_rmsd_close adds a frame's words in a fixed order): no LDS
+        // crossbar, no barrier, no second hop -- at the default grid a workgroup is ONE trip, and this epilogue used to cost it twelve
+        // ds_bpermute and a barrier (round 5)
+        const double v = gr_xor_lane_f64<1>(rs) + rs;
+        const double w = gr_xor_lane_f64<2>(v) + v;
+        const double x = gr_xor_lane_f64<4>(w) + w;
+        const double y = gr_xor_lane_f64<8>(x) + x;
+        const unsigned long long yb = (unsigned long long)__double_as_longlong(y);
+        const auto l16 = __builtin_amdgcn_permlane16_swap((uint32_t)yb, (uint32_t)yb, false, false), h16 = __builtin_amdgcn_permlane16_swap((uint32_t)(yb >> 32), (uint32_t)(yb >> 32), false, false);
+        const double z = gr_f64_from_halves(l16[0], h16[0]) + gr_f64_from_halves(l16[1], h16[1]);
+        const unsigned long long zb = (unsigned long long)__double_as_longlong(z);
+        const auto l32 = __builtin_amdgcn_permlane32_swap((uint32_t)zb, (uint32_t)zb, false, false), h32 = __builtin_amdgcn_permlane32_swap((uint32_t)(zb >> 32), (uint32_t)(zb >> 32), false, false);
+        const double tot = gr_f64_from_halves(l32[0], h32[0]) + gr_f64_from_halves(l32[1], h32[1]);
+        if (lane == 0) fit_partials[((size_t)frame * gridDim.x + blockIdx.x) * (GR_WG / 64) + wave] = tot;
     }
 }
 
