@@ -1134,7 +1134,6 @@ __global__ __launch_bounds__(GR_WG) void k_translate_wrap(
     float *__restrict__ xyz, size_t frame_stride, GrSel sel, const GrBox *__restrict__ boxp, const GrFrameState *__restrict__ state,
     int use_state_shift, int dim_mask, float tx, float ty, float tz, uint32_t *__restrict__ bad_out) {
     __shared__ GrBox box;
-    __shared__ uint32_t ldsu[GR_WG / 64];
     xyz += (size_t)blockIdx.y * frame_stride; boxp += blockIdx.y; state += blockIdx.y; bad_out += 4 * blockIdx.y;
     gr_stage_box(&box, boxp);
     if (use_state_shift == 2 && state->status != 0) return;
@@ -1197,8 +1196,13 @@ __global__ __launch_bounds__(GR_WG) void k_translate_wrap(
             gr_pos_store(xyz, i, x, y, z);
         }
     }
-    bad = gr_block_min_u32(bad, ldsu);
-    if (threadIdx.x == 0 && bad != GR_NOIDX) atomicMin(bad_out, bad);
+    // first atom without position: rare -- a wave that has one reduces and reports it, the others do nothing (at the default grid a workgroup
+    // is ONE trip: a block-wide minimum through LDS and a barrier per trip cost more than the test they serve; round 5)
+    if (__builtin_amdgcn_ballot_w64(bad != GR_NOIDX) != 0ull) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) bad = min(bad, (uint32_t)__shfl_xor((int)bad, off, 64));
+        if ((threadIdx.x & 63u) == 0u) atomicMin(bad_out, bad);
+    }
 }
 
 // The same operation on an ORTHORHOMBIC cell as one 16-byte load and one 16-byte store per lane (round 5).  There every coordinate wraps on
