@@ -1762,10 +1762,15 @@ static int center_resident(gr_ctx *c, uint32_t s0, uint32_t nb, const GrSel &all
                            const std::vector<int> &pre, std::vector<uint8_t> &done, std::vector<uint8_t> &torn) {
     done.assign(nb, 0); torn.assign(nb, 0);
     if (!c->center_resident || !csel.contiguous || csel.masked || !all.contiguous || all.start != 0 || all.n != c->n) return GR_OK;
-    // which groups: the launch costs the same whatever the group (measured at 1e6 atoms, us per frame, two passes -> one: the whole system
-    // 6.1-6.3 -> 4.4-4.6, half of it 5.2 -> 4.7, a tenth 4.4 -> not taken: the estimate pass shrinks with the group, this one does not;
-    // profiles/r05_center_bench.json); from 30 % of the system
-    if (c->resident == 1 && (uint64_t)csel.n * 100 < c->n * 30) return GR_OK;
+    // which groups: the launch costs the same whatever the group -- 4.25 us per 1e6-atom frame in an orthorhombic cell, 4.35-4.4 in others -- while
+    // the two passes shrink with it: orthorhombic (the one-float4-per-lane translate) 4.0 / 4.18 / 4.37 for a hundredth / a tenth / a fifth of the
+    // system, other cells 4.33 / 4.53 / 4.71 (tools/center_small_groups.py, profiles/r05_center_bench.json): taken from 15 % of the system in
+    // orthorhombic cells, from 3 % in others
+    {
+        bool ortho = true;
+        for (uint32_t f = 0; f < nb; ++f) if (pre[f] == GR_OK) { ortho = c->boxes_host[s0 + f].ortho != 0; break; }
+        if (c->resident == 1 && (uint64_t)csel.n * 100 < c->n * (ortho ? 15u : 3u)) return GR_OK;
+    }
     if (small_ok(c, csel)) return GR_OK;      // (a group the single-wave estimate takes: that kernel adds in another order -- the same bits only against k_center_sums)
     uint32_t streams = 1, gwg = GR_RES_GROUPS;
     const uint32_t wgs = resident_wgs(c, true, nb, all, &streams, &gwg);

@@ -311,7 +311,7 @@ int gr_rmsd_plan_force_exact(gr_rmsd_plan *plan, int on);
  *                      0 (default) = sums first when the streaming workgroups fill 9/10 of the chip.  Same results either way.
  *   GR_TUNE_STREAM_WGS_PER_CU  workgroups per CU of the grid-launched read-modify-write streams (translate / wrap / centre, the two-pass fit):
  *                      1 .. 8, 0 (default) = the library's choice.  A copy is fastest with 20-32 KiB of loads in flight per CU.
- *   GR_TUNE_CENTER_RESIDENT  1 (default): gr_atoms_center_batch about a contiguous reference group of at least 30 % of the system runs as ONE pass
+ *   GR_TUNE_CENTER_RESIDENT  1 (default): gr_atoms_center_batch about a contiguous reference group of at least 15 % of the system (3 % in non-orthogonal cells) runs as ONE pass
  *                      over HBM where the resident pass can take it (gr_resident.h MODE 1: every frame read once, written once -- 24 instead of
  *                      36 bytes per atom); 0: always the two passes (centre estimate, then translate + wrap).  Same bits either way.
  *   GR_TUNE_TRANSLATE_ROWS  1 (default): translate / wrap / centring of a contiguous selection in an ORTHORHOMBIC cell runs one 16-byte load and
