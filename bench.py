@@ -46,7 +46,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--warmup-seconds", type=float, default=0.5, help="the warm-up lasts at least this long: after the --warmup steps "
+    ap.add_argument("--warmup-seconds", type=float, default=1.5, help="the warm-up lasts at least this long: after the --warmup steps "
                     "their slots are fitted again (results discarded) until the device has run this long")
     ap.add_argument("--box-per-frame", action="store_true", help="a slightly different box in every frame (a constant-pressure trajectory): "
                     "the kernels read the box per frame instead of once per launch; NOT the headline configuration")
