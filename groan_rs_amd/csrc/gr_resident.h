@@ -711,12 +711,23 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
     // ---- the sums stage of frame i (rows in L): the lane's 18 + 12 values -> wave (reduce-scatter) -> workgroup (LDS, the last
     // wave to arrive adds the wave records in wave order) -> the frame's tagged record.  V: `va`, `vb` receive the image vectors.
     // the workgroup's record of frame f: the wave records in wave order, 31 tagged words
+    // (the lane's number is taken afresh inside the combines, and the record leaves through a buffer store off a wave-uniform base: with the
+    //  lane's LDS offsets and 64-bit record address as loop invariants the compiler, out of registers, kept them in scratch memory, and their
+    //  reload -- a vector memory load -- made the combining wave wait for ALL its outstanding loads, the next turn's rows included)
+    auto fresh_lane = []() { uint32_t l; asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l)); return l; };
+    auto publish_word = [&](uint32_t f, uint32_t l, float v) {
+        const __amdgpu_buffer_rsrc_t rr = gr_buf_rsrc(ctl.wgrec + ((size_t)kf(f) * n_pad + wg) * GR_RES_REC_WORDS, 31u * 8u);
+        typedef int gr_i2 __attribute__((ext_vector_type(2)));
+        gr_i2 w; w.x = __float_as_int(v); w.y = (int)ctl.epoch;
+        __builtin_amdgcn_raw_buffer_store_b64(w, rr, (int)(l * 8u), 0, 16 /* sc1: agent scope */);
+    };
     auto combine_rmsd = [&](uint32_t f) {
         const uint32_t rs = f % R;
 #ifdef GR_EXP_STEPTIME
         st_combines += 1ull;
 #endif
         const float *all = wsum + rs * WAVES * 32;
+        const uint32_t lane = fresh_lane();
         if (lane < 31u) {
             float v;
             if (n_waves == WAVES) {
@@ -738,7 +749,7 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
                 if (lane < 19u) { for (uint32_t w = 1; w < n_waves; ++w) v += all[w * 32 + lane]; }
                 else { for (uint32_t w = 1; w < n_waves; ++w) v = gr_fmaxf(v, all[w * 32 + lane]); }
             }
-            gr_st_agent(ctl.wgrec + ((size_t)kf(f) * n_pad + wg) * GR_RES_REC_WORDS + lane, ((unsigned long long)ctl.epoch << 32) | __float_as_uint(v));
+            publish_word(f, lane, v);
         }
 #ifdef GR_EXP_TIMELINE
         if (tl_wg && lane == 0) tls[(f & 127u) * 4u + 0u] = wall_clock64();
@@ -840,6 +851,7 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
     auto combine_cen = [&](uint32_t f) {          // MODE 1: the workgroup's record of frame f, every fp64 sum as hi + lo words
         const uint32_t rs = f % R;
         const double *all = reinterpret_cast<const double *>(wsum + rs * WAVES * 32);
+        const uint32_t lane = fresh_lane();
         if (lane < 31u) {
             float word = 0.0f;
             if (lane < 16u) {
@@ -848,7 +860,7 @@ __global__ __launch_bounds__(GrResShape::LANES) void k_fit_resident(
                 const float hi = (float)v;
                 word = lane < 8u ? hi : (float)(v - (double)hi);
             }
-            gr_st_agent(ctl.wgrec + ((size_t)kf(f) * n_pad + wg) * GR_RES_REC_WORDS + lane, ((unsigned long long)ctl.epoch << 32) | __float_as_uint(word));
+            publish_word(f, lane, word);
         }
     };
     auto sums_cen = [&](uint32_t i, const Landing &L, const GrBoxU &B) {
